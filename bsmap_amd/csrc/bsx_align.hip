@@ -1,0 +1,826 @@
+// bsx_align.hip — the alignment hot path as ONE persistent gfx950 kernel.
+//
+// Reference call tree replaced (BSMAP v2.6 file:line):
+//   SingleAlign::Do_Batch align.cpp:591 / PairAlign::Do_Batch pairs.cpp:192
+//     FilterReads align.cpp:579  (TrimAdapter :371, TrimLowQual :59, CountNs :48)
+//     RunAlign align.cpp:435 / PairAlign::RunAlign pairs.cpp:137
+//       ConvertBinaySeq align.cpp:90, ReorderSeed align.cpp:454 (+ AdjustSeedStartArray :506, CountSeeds :549)
+//       SnpAlign align.cpp:168 (+ CountMismatch align.h:167, RefSeq::int2hit dbseq.cpp:585)
+//       SortHits4PE align.cpp:363, GetPairs pairs.cpp:34
+//     StringAlign align.cpp:610 / StringAlignPair pairs.cpp:222 / StringAlignUnpair pairs.cpp:244 (selection only)
+//
+// Mapping onto CDNA4: one 64-lane wavefront owns one read (or read pair) at a time and pulls the next unit from a
+// global queue (persistent grid: the reference's "thread grabs the next batch" loop, main.cpp:49-73, at wave
+// granularity).  Inside a unit every data-parallel step is spread over the 64 lanes:
+//   * seed hashes + bucket-header gathers: lane = read offset (one dependent HBM round trip for all ~130 offsets)
+//   * candidate scan: the (phase x strand) bucket ranges of a round are concatenated into one virtual list that the
+//     wave walks 64 candidates at a time; each lane loads its index entry (coalesced), the first 16 bytes of
+//     reference at entry+h (random), funnel-shifts them to the read's frame and counts mismatches with
+//     xor/and/popcount; only lanes that survive the first 48 nt load the rest
+//   * the reference's order-dependent tail (duplicate suppression, -w cap, -r 0 early return) is replayed over the
+//     surviving lanes in lane order (= list order) with wave-uniform state, so results are bit-identical
+//   * PE: class lists are rank-sorted across lanes; the window join runs lane-parallel over the b-list
+// Read words and masks live in SGPRs during the scan; planner tables live in LDS; hit lists live in a per-wave HBM
+// slab (they are usually 1-2 entries but may legally reach 1000 per class).
+#include "bsx_internal.h"
+#include "bsx_dev.h"
+#include "bsx_kernel_args.h"
+
+namespace {
+
+typedef unsigned long long u64;
+
+struct __attribute__((packed, aligned(4))) U4 { uint32_t a, b, c, d; };
+struct __attribute__((packed, aligned(4))) U2 { uint32_t a, b; };
+
+__device__ __forceinline__ uint32_t rfl(uint32_t x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ uint32_t rl(uint32_t x, int l) { return __builtin_amdgcn_readlane(x, l); }
+__device__ __forceinline__ u64 rl64(u64 x, int l) { return ((u64)rl((uint32_t)(x >> 32), l) << 32) | rl((uint32_t)x, l); }
+__device__ __forceinline__ u64 lanemask_lt(int lane) { return lane ? (~0ull >> (64 - lane)) : 0ull; }
+__device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
+
+// wave-wide minimum of a 64-bit key (all lanes get the result)
+__device__ __forceinline__ u64 wave_min64(u64 v)
+{
+#pragma unroll
+    for (int o = 32; o; o >>= 1) {
+        u64 t = ((u64)__shfl_xor((uint32_t)(v >> 32), o) << 32) | __shfl_xor((uint32_t)v, o);
+        v = t < v ? t : v;
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+struct MateLds {
+    uint8_t seq[160];
+    uint8_t qual[160];
+    uint32_t w[2][10], m[2][10];  // packed read words / N-masks per orientation (align.h:74-77, copy 0 only)
+    uint32_t cnt[2][144];         // index2[seed][0] for every read offset (CountSeeds' operand)
+    uint8_t start[2][16];         // seed_start_array / cseed_start_array
+    uint8_t order[2][16];         // seedindex[].second / cseedindex[].second
+};
+
+template <bool PE> struct WaveLds { MateLds mate[PE ? 2 : 1]; };
+
+struct BlockLds {
+    uint8_t prof[16][16];
+    uint32_t anchor[BSX_LDS_CHR + 1], chr_size[BSX_LDS_CHR], rc_offset[BSX_LDS_CHR];
+};
+
+// wave-uniform per-mate state; cnt_reg / key_reg are lane-distributed tables
+struct Mate {
+    int len, raw_len, max_snp, seedseg, filtered;
+    uint32_t flags;      // bit0 flag_chain, bit1 cflag_chain
+    uint32_t snp_thres;
+    uint32_t nkeys;
+    uint32_t cnt_reg;    // lane (orient*16+w) holds _cur_n_hit / _cur_n_chit
+    uint32_t key_reg;    // lane i holds the i-th accepted forward coordinate (hitset, first 64)
+    uint32_t index;      // ReadInf.index
+};
+
+struct Slab {
+    // Rows are laid out exactly like the reference's `new HitArray[MAXSNPS+1]` (align.cpp:21-22): row w starts at
+    // w*(MAXHITS+1).  A class may legally exceed -w by one entry per extra SnpAlign call (PE levels, RRBS rounds); with
+    // the default -w 1000 those entries land in the first slots of row w+1 — in the reference and, by construction, here.
+    u64 *hits;        // [2][nclass+1][rowcap]
+    uint32_t *keys;   // [(nclass+1)*rowcap] overflow of key_reg
+    u64 *tmp;         // [BSX_SORT_TMP] sort scratch
+    uint32_t rowcap, nclass;
+    __device__ __forceinline__ u64 *list(int orient, int w) const { return hits + ((size_t)(orient * (nclass + 1) + w)) * rowcap; }
+};
+
+struct Counters { u64 n_lookup, n_cand, sum_w, n_orient; };
+
+__device__ __forceinline__ int nt_idx(uint32_t c)
+{
+    c |= 0x20;
+    return c == 'a' ? 0 : c == 'c' ? 1 : c == 'g' ? 2 : c == 't' ? 3 : -1;
+}
+
+__device__ __forceinline__ uint32_t n_of(const Mate &M, int orient, int w) { return rl(M.cnt_reg, orient * 16 + w); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// FilterReads (align.cpp:579-589)
+// ---------------------------------------------------------------------------------------------------------------
+__device__ void load_and_filter(const AlignArgs &A, MateLds &L, Mate &M, int mate, uint32_t unit, int lane)
+{
+    const DevParams &P = A.P;
+    const uint64_t b = A.off[mate][unit], e = A.off[mate][unit + 1];
+    int len = (int)min((uint64_t)P.max_readlen, e - b);  // reads.cpp:115-117
+    const uint8_t *s = A.seq[mate] + b, *q = A.qual[mate] ? A.qual[mate] + b : nullptr;
+    for (int i = lane; i < 160; i += 64) {
+        L.seq[i] = i < len ? s[i] : 0;
+        L.qual[i] = (q && i < len) ? q[i] : 0;
+    }
+    wave_fence();
+    M.raw_len = len;
+    M.filtered = 0;
+    // TrimAdapter, WGBS branch (align.cpp:410-423): first adapter, then first position, whose <=15-nt prefix matches
+    // the read tail with k >= 5*mismatches and k > 3
+    if (P.n_adapter > 0 && len >= 5) {
+        bool done = false;
+        for (int a = 0; a < P.n_adapter && !done; a++) {
+            const int al = P.adapter_len[a];
+            for (int base = P.seed_size; base < len - (P.rrbs ? 5 : 4) && !done; base += 64) {
+                const int pos = base + lane;
+                bool hit = false;
+                if (pos < len - (P.rrbs ? 5 : 4)) {
+                    int k = 0, m0 = 0;
+                    for (; k < al && k < 15 && pos + k < len; k++)
+                        if ((m0 += (P.adapter[a][k] != (char)L.seq[pos + k])) > 4) break;
+                    if (!P.rrbs) hit = (k >= m0 * 5 && k > 3);
+                    else if (k >= m0 * 5) {
+                        // RRBS branch (align.cpp:375-408): the digestion-site remainder must precede the adapter
+                        const int dl = P.digest_len;
+                        int m = m0;
+                        for (int t = 0; t < dl - P.digest_pos; t++) {
+                            char an = P.digest_site[t], rn = (char)L.seq[pos - dl + P.digest_pos + t];
+                            m += (an != rn) && (an != 'C' || rn != 'T');
+                        }
+                        hit = (k >= m * 5);
+                        if (!hit && P.pairend) {
+                            m = m0;
+                            for (int t = 0; t < dl - P.digest_pos; t++) {
+                                char an = P.digest_site[t], rn = (char)L.seq[pos - dl + P.digest_pos + t];
+                                m += (an != rn) && (an != 'G' || rn != 'A');
+                            }
+                            hit = (k >= m * 5);
+                        }
+                    }
+                }
+                const u64 mask = __ballot(hit);
+                if (mask) { len = base + (int)__builtin_ctzll(mask); done = true; }
+            }
+        }
+    }
+    // TrimLowQual (align.cpp:59-79): cut after the last base whose quality exceeds zero_qual+threshold, if that keeps
+    // >= seed_size bases; otherwise the read is rejected.  (The SAM rebasing at :64-67 shifts both sides equally.)
+    const int qlen = q ? len : 0;
+    if (P.qual_threshold != 0 && q && qlen != 1) {
+        int best = 0;
+        for (int base = 0; base < qlen; base += 64) {
+            const int i = base + lane;
+            const bool good = i < qlen && (int)(int8_t)L.qual[i] > P.zero_qual + P.qual_threshold;
+            const u64 mask = __ballot(good);
+            if (mask) best = base + 64 - (int)__builtin_clzll(mask);
+        }
+        if (best >= P.seed_size) len = min(len, best);
+        else M.filtered = 1;
+    }
+    if (len < P.seed_size) M.filtered = 1;  // min_read_size
+    {
+        uint32_t ns = 0;  // CountNs (align.cpp:48-55)
+        for (int base = 0; base < len; base += 64) {
+            const int i = base + lane;
+            ns += (uint32_t)__builtin_popcountll(__ballot(i < len && nt_idx(L.seq[i]) < 0));
+        }
+        if ((int)ns > P.max_ns) M.filtered = 1;
+    }
+    M.len = len;
+    M.max_snp = M.filtered ? 0 : (int)(((uint64_t)(P.max_snp_num + 1) * (uint64_t)(len - 1)) / (uint64_t)M.raw_len);
+    const int x = (len - P.index_interval + 1) / P.seed_size, y = M.max_snp + 1;  // align.cpp:440
+    M.seedseg = M.filtered ? 0 : min(x, y);
+    M.snp_thres = (uint32_t)M.max_snp;
+    M.nkeys = 0;
+    M.cnt_reg = 0;
+    M.key_reg = 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// ConvertBinaySeq (align.cpp:90-162): 2-bit words + N masks for the enabled orientations (no shifted copies:
+// the scan shifts the reference instead)
+// ---------------------------------------------------------------------------------------------------------------
+__device__ void pack_read(const DevParams &P, MateLds &L, Mate &M, int readset, int lane, Counters &C)
+{
+    M.flags = ((P.chains || readset < 2) ? 1u : 0u) | ((P.chains || readset == 2) ? 2u : 0u);  // align.cpp:93-94
+    const int orient = lane >> 4, t = lane & 15;
+    if (orient < 2 && t < 10) {
+        uint32_t w = 0, m = 0;
+        for (int j = 0; j < 16; j++) {
+            const int pos = t * 16 + j;
+            uint32_t code = 0, reg = 0;
+            if (pos < M.len) {
+                const int k = nt_idx(L.seq[orient ? M.len - 1 - pos : pos]);
+                const int sel = orient ? (k < 0 ? 3 : 3 - k) : (k < 0 ? 0 : k);  // rev_alphabet / alphabet
+                code = (P.bit_nt_packed >> (8 * sel)) & 3u;
+                reg = k < 0 ? 0u : 3u;                                              // reg_alphabet
+            }
+            w = (w << 2) | code;
+            m = (m << 2) | reg;
+        }
+        L.w[orient][t] = w;
+        L.m[orient][t] = m;
+    }
+    wave_fence();
+    C.n_orient += (M.flags & 1) + ((M.flags >> 1) & 1);
+}
+
+__device__ __forceinline__ uint32_t seed_key_at(const DevParams &P, const uint32_t *w, int o)
+{
+    const int q = o >> 4, r = o & 15;
+    const u64 v = ((u64)w[q] << 32) | w[q + 1 < 10 ? q + 1 : 9];
+    return bsx_seed_hash((uint32_t)(v >> (64 - 2 * P.seed_size - 2 * r)) & P.seed_bits);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// ReorderSeed (align.cpp:454-504) for one orientation
+// ---------------------------------------------------------------------------------------------------------------
+__device__ void plan_orient(const DevParams &P, const BlockLds &BL, MateLds &L, const Mate &M, int orient, int lane, Counters &C)
+{
+    const int I = P.index_interval, S = P.seed_size, nseg = M.seedseg;
+    const int noff = M.len - S + 1;
+    // index2[s][0] (= 2 + bucket size, 0 for an empty bucket) for every offset of this orientation
+    for (int base = 0; base < noff; base += 64) {
+        const int o = base + lane;
+        if (o < noff) {
+            const uint32_t key = seed_key_at(P, L.w[orient], o);
+            const U2 b = *reinterpret_cast<const U2 *>(P.bucket_off + key);
+            const uint32_t n = b.b - b.a;
+            L.cnt[orient][o] = P.rrbs ? n : (n ? n + 2 : 0);
+        }
+    }
+    wave_fence();
+    const uint32_t *cnt = L.cnt[orient];
+    int offset = 0;
+    const int nstart = P.rrbs ? 0 : (M.len - I + 1) % S;
+    u64 lookups = 0;
+    if (nstart > 0) {  // GetTotalSeedLoc for every start, first minimum wins (align.cpp:458-468)
+        u64 key = ~0ull;
+        if (lane < nstart) {
+            int tot = 0;
+            for (int seg = 0; seg < nseg; seg++)
+                for (int ph = 0; ph < I; ph++) tot += (int)cnt[BL.prof[seg][ph] + lane - ph];
+            if ((uint32_t)tot != 0xffffffffu) key = ((u64)(uint32_t)tot << 8) | (uint32_t)lane;
+        }
+        key = wave_min64(key);
+        if (key != ~0ull) offset = (int)(key & 0xff);
+        lookups += (u64)nstart * nseg * I;
+    }
+    // AdjustSeedStartArray (align.cpp:506-528)
+    if (lane < 16) L.start[orient][lane] = (uint8_t)offset;
+    wave_fence();
+    if (!P.rrbs) {
+        for (int i = 0; i < nseg; i++) {
+            const int ptr = (i % 2 == 0) ? i / 2 : nseg - 1 - i / 2;
+            const int start = ptr == 0 ? 0 : L.start[orient][ptr - 1];
+            const int end = ptr == nseg - 1 ? nstart : L.start[orient][ptr + 1];
+            u64 key = ~0ull;
+            const int ii = start + lane;
+            if (ii <= end) {
+                int tt = 0;
+                for (int ph = 0; ph < I; ph++) tt += (int)cnt[BL.prof[ptr][ph] + ii - ph];
+                if ((uint32_t)tt != 0xffffffffu) key = ((u64)(uint32_t)tt << 8) | (uint32_t)lane;
+            }
+            key = wave_min64(key);
+            const int pick = key != ~0ull ? start + (int)(key & 0xff) : start;
+            if (lane == 0) L.start[orient][ptr] = (uint8_t)pick;
+            wave_fence();
+            if (end >= start) lookups += (u64)(end - start + 1) * I;
+        }
+    }
+    // seedindex: segments ordered by (sum of bucket headers, segment)  (align.cpp:476-485)
+    {
+        int s = 0;
+        if (lane < nseg) {
+            if (P.rrbs) s = (int)cnt[BL.prof[lane][0] + (orient ? (M.len % S) : 0) + L.start[orient][lane]];  // GenerateCSeeds adds cseed_offset
+            else
+                for (int ph = 0; ph < I; ph++) s += (int)cnt[BL.prof[lane][ph] + L.start[orient][lane] - ph];
+        }
+        int rank = 0;
+        for (int j = 0; j < nseg; j++) {
+            const int sj = (int)rl((uint32_t)s, j);
+            rank += (sj < s) || (sj == s && j < lane);
+        }
+        if (lane < nseg) L.order[orient][rank] = (uint8_t)lane;
+        wave_fence();
+        lookups += P.rrbs ? (u64)nseg : (u64)nseg * I;
+    }
+    C.n_lookup += lookups;
+}
+
+// RefSeq::int2hit (dbseq.cpp:585-595) on the LDS copy of the anchors (global memory when there are too many)
+__device__ __forceinline__ uint32_t chr_of(const DevParams &P, const BlockLds &BL, uint32_t p)
+{
+    int left = 0, right = (int)P.n_chr;
+    const bool lds = P.n_chr <= BSX_LDS_CHR;
+    while (left < right - 1) {
+        const int mid = (left + right) >> 1;
+        const uint32_t a = lds ? BL.anchor[mid] : P.anchor[mid];
+        if (p >= a) left = mid; else right = mid;
+    }
+    return (uint32_t)left;
+}
+
+// duplicate test against every hit accepted so far for this read (hitset, align.cpp:274)
+__device__ __forceinline__ bool seen_before(const Mate &M, const Slab &SL, uint32_t key, int lane)
+{
+    u64 dup = __ballot((uint32_t)lane < M.nkeys && M.key_reg == key);
+    if (M.nkeys > 64) {
+        for (uint32_t base = 64; base < M.nkeys && !dup; base += 64) {
+            const uint32_t i = base + lane;
+            dup = __ballot(i < M.nkeys && SL.keys[i] == key);
+        }
+    }
+    return dup != 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// SnpAlign (align.cpp:168-347) — returns when the reference's SnpAlign would return
+// ---------------------------------------------------------------------------------------------------------------
+// RefSeq::CCGG_seglen (dbseq.cpp:541-567), fragment length only
+__device__ int ccgg_seglen(const DevParams &P, uint32_t chr, uint32_t pos, int readlen)
+{
+    const uint32_t c = chr >> 1;
+    const uint32_t *sites = P.sites + P.site_off[c];
+    const int size = (int)(P.site_off[c + 1] - P.site_off[c]);
+    int left = 0, right = size - 1;
+    while (left < right - 1) {
+        const int mid = (left + right) / 2;
+        const uint32_t mv = sites[mid];
+        if (mv == pos) { left = mid; right = mid + 1; break; }
+        else if (mv < pos) left = mid;
+        else right = mid;
+    }
+    const uint32_t seg_start = size > 0 ? sites[left] : 0;
+    uint32_t seg_end;
+    for (;;) {
+        // the reference reads sites[right] before testing right < size; the one-past-the-end value is defined as 0 here
+        const uint32_t sv = (right >= 0 && right < size) ? sites[right] : 0;
+        seg_end = sv + (uint32_t)P.digest_len - (uint32_t)(P.digest_pos * 2);
+        if (seg_end < pos + (uint32_t)readlen && right < size) right++;
+        else break;
+    }
+    return (int)(seg_end - seg_start);
+}
+
+struct CandEval { uint32_t w, w0ref, p48, w01ref; };
+
+// CountMismatch (align.h:167-200) for the candidate starting at global nt p of one strand copy.  The reference
+// compares a pre-shifted copy of the read with aligned reference words; here the reference words are funnel-shifted
+// into the read's frame instead.  w0ref / w01ref are the partial sums the reference's two early-outs look at.
+__device__ __forceinline__ CandEval eval_candidate(const DevParams &P, const uint32_t (&rw)[9], const uint32_t (&rm)[9], int nwords,
+                                                   uint32_t p, uint32_t strand, uint32_t thres0)
+{
+    CandEval r;
+    const uint32_t *rp = (strand ? P.crefcat : P.refcat) + (p >> 4);
+    const uint32_t k = p & 15, sh = 32 - 2 * k;
+    const U4 r0 = *reinterpret_cast<const U4 *>(rp);
+    const uint32_t f0 = (uint32_t)((((u64)r0.a << 32) | r0.b) >> sh), f1 = (uint32_t)((((u64)r0.b << 32) | r0.c) >> sh),
+                   f2 = (uint32_t)((((u64)r0.c << 32) | r0.d) >> sh);
+    const uint32_t m0 = bsx_mismatch_bits(rw[0], rm[0], f0), m1 = bsx_mismatch_bits(rw[1], rm[1], f1), m2 = bsx_mismatch_bits(rw[2], rm[2], f2);
+    const uint32_t him = k ? ~(0xFFFFFFFFu >> (2 * (16 - k))) : 0xFFFFFFFFu;  // first 16-k nt of a word
+    r.w0ref = __popc(m0) + __popc(m1 & him);  // the reference's 1st 64-bit word holds read nt [0, 32-k)
+    r.p48 = __popc(m0) + __popc(m1) + __popc(m2);
+    r.w = r.p48;
+    r.w01ref = 0;
+    if (r.p48 <= thres0) {
+        uint32_t wd[7];
+        wd[0] = r0.d;
+        if (nwords > 3) { const U4 r1 = *reinterpret_cast<const U4 *>(rp + 4); wd[1] = r1.a; wd[2] = r1.b; wd[3] = r1.c; wd[4] = r1.d; }
+        else { wd[1] = wd[2] = wd[3] = wd[4] = 0; }
+        if (nwords > 7) { const U2 r2 = *reinterpret_cast<const U2 *>(rp + 8); wd[5] = r2.a; wd[6] = r2.b; }
+        else { wd[5] = wd[6] = 0; }
+        uint32_t tot = r.p48;
+        r.w01ref = r.p48;
+#pragma unroll
+        for (int t = 3; t < 9; t++) {
+            const uint32_t f = (uint32_t)((((u64)wd[t - 3] << 32) | wd[t - 2]) >> sh);
+            const uint32_t mm = bsx_mismatch_bits(rw[t], rm[t], f);
+            tot += __popc(mm);
+            if (t == 3) r.w01ref += __popc(mm & him);
+        }
+        r.w = tot;
+    }
+    return r;
+}
+
+__device__ void snp_align(const DevParams &P, const BlockLds &BL, const MateLds &L, Mate &M, const Slab &SL, int mode, int lane,
+                          Counters &C)
+{
+    const int I = P.index_interval;
+    const int nwords = (M.len + 15) >> 4;
+    const bool lds_chr = P.n_chr <= BSX_LDS_CHR;
+    for (int orient = 0; orient < 2; orient++) {
+        if (!((M.flags >> orient) & 1)) continue;
+        const int seg = L.order[orient][mode];  // modeindex
+        // read words + masks into scalar registers
+        uint32_t rw[9], rm[9];
+#pragma unroll
+        for (int t = 0; t < 9; t++) { rw[t] = rfl(L.w[orient][t]); rm[t] = rfl(L.m[orient][t]); }
+        // The candidate list of this call: WGBS = (phase x strand) sub-ranges of the index, sub-range s = 2*phase+strand
+        // described by lane s; RRBS = one bucket of {tag,loc} pairs (align.cpp:175-252).
+        uint32_t sub_base = 0, sub_n = 0, sub_h = 0;
+        const int nsub = P.rrbs ? 1 : 2 * I;
+        if (lane < nsub) {
+            if (P.rrbs) {
+                const int a = BL.prof[seg][0];
+                const int coff = orient ? (M.len % P.seed_size) : 0;  // cseed_offset (align.cpp:443)
+                const uint32_t key = seed_key_at(P, L.w[orient], a + coff + L.start[orient][seg]);
+                const U2 b = *reinterpret_cast<const U2 *>(P.bucket_off + key);
+                sub_base = b.a; sub_n = b.b - b.a; sub_h = (uint32_t)(a + coff);
+            } else {
+                const int ph = lane >> 1;
+                const int a = BL.prof[seg][ph], st = L.start[orient][seg];
+                const uint32_t key = seed_key_at(P, L.w[orient], a + st - ph);
+                const U2 b = *reinterpret_cast<const U2 *>(P.bucket_off + key);
+                const uint32_t nf = P.bucket_nfwd[key];
+                sub_base = (lane & 1) ? b.a + nf : b.a;
+                sub_n = (lane & 1) ? (b.b - b.a - nf) : nf;
+                sub_h = (uint32_t)(-a + ph - st);  // h (align.cpp:263)
+            }
+        }
+        uint32_t sub_pre = sub_n;  // inclusive prefix over lanes
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) { uint32_t t = __shfl_up(sub_pre, o); if (lane >= o) sub_pre += t; }
+        const uint32_t total = rl(sub_pre, nsub - 1);
+        sub_pre -= sub_n;
+        const int cmode = M.len / P.seed_size - 1 - seg;  // cmodeindex (align.cpp:221)
+        for (uint32_t c0 = 0; c0 < total; c0 += 64) {
+            const uint32_t idx = c0 + lane;
+            bool valid = idx < total;
+            uint32_t p = 0, strand = 0, rchr = 0;
+            if (P.rrbs) {
+                if (valid) {
+                    const U2 e = *reinterpret_cast<const U2 *>(P.entries + 2 * (size_t)(rl(sub_base, 0) + idx));
+                    const uint32_t h = rl(sub_h, 0);
+                    const bool tag_ok = orient ? (((e.a ^ 0x1000000u) >> 16) == (uint32_t)cmode) : ((e.a >> 16) == (uint32_t)seg);
+                    rchr = e.a & 0xffff;
+                    valid = tag_ok && e.b >= h;  // mode or strand not match / underflow the start of refseq
+                    strand = rchr & 1;
+                    p = (lds_chr ? BL.anchor[rchr >> 1] : P.anchor[rchr >> 1]) + (e.b - h);
+                }
+            } else {
+                uint32_t e_idx = 0, h = 0;
+                for (int s = 0; s < 2 * I; s++) {
+                    const uint32_t ps = rl(sub_pre, s), ns = rl(sub_n, s);
+                    if (idx >= ps && idx < ps + ns) { e_idx = rl(sub_base, s) + (idx - ps); h = rl(sub_h, s); strand = s & 1; }
+                }
+                if (valid) p = P.entries[e_idx] + h;
+            }
+            CandEval ev = {0xffff, 0, 0, 0};
+            const uint32_t thres0 = M.snp_thres;
+            if (valid) ev = eval_candidate(P, rw, rm, nwords, p, strand, thres0);
+            const uint32_t w = ev.w;
+            // per-lane hit coordinates for lanes that pass the current threshold
+            bool pass = valid && w <= thres0;
+            uint32_t hchr = 0, hloc = 0, hkey = 0;
+            if (pass) {
+                const uint32_t c = P.rrbs ? (rchr >> 1) : chr_of(P, BL, p);
+                const uint32_t an = lds_chr ? BL.anchor[c] : P.anchor[c], sz = lds_chr ? BL.chr_size[c] : P.chr_size[c];
+                uint32_t loc = p - an;
+                if (strand) loc = (lds_chr ? BL.rc_offset[c] : P.rc_offset[c]) - (uint32_t)M.len - loc;  // align.cpp:289
+                hchr = 2 * c + strand; hloc = loc; hkey = an + loc;
+                if ((u64)loc + (u64)M.len > (u64)sz) pass = false;  // overflow the end of refseq (align.cpp:273)
+            }
+            // ordered replay of the survivors (align.cpp:274-278)
+            uint32_t thr_eff = thres0;
+            bool alive = valid, stop = false;
+            u64 surv = __ballot(pass);
+            while (surv) {
+                const int ls = (int)__builtin_ctzll(surv);
+                surv &= surv - 1;
+                const uint32_t ws = rl(w, ls);
+                if (ws > M.snp_thres) continue;
+                const uint32_t ks = rl(hkey, ls);
+                if (seen_before(M, SL, ks, lane)) continue;
+                // hitset.insert
+                if (M.nkeys < 64) { if ((uint32_t)lane == M.nkeys) M.key_reg = ks; }
+                else if (lane == 0) SL.keys[M.nkeys] = ks;
+                M.nkeys++;
+                if (P.rrbs && !P.pairend && orient == 0) {  // fragment size filter, forward chain only (align.cpp:202-207)
+                    const int sl = ccgg_seglen(P, rl(hchr, ls), rl(hloc, ls), M.len);
+                    if (sl > P.max_insert || sl < P.min_insert) continue;
+                }
+                // hits[w][n++] = hit
+                const uint32_t n = n_of(M, orient, (int)ws);
+                if (lane == ls) SL.list(orient, (int)ws)[n] = ((u64)hchr << 32) | hloc;
+                if (lane == orient * 16 + (int)ws) M.cnt_reg++;
+                const uint32_t both = n_of(M, 0, (int)ws) + n_of(M, 1, (int)ws);
+                bool ret = false;
+                if ((int)ws == mode && !P.pairend && P.report_repeat_hits == 0 && both > 1) ret = true;
+                else if (both >= (uint32_t)P.max_num_hits) {
+                    if (ws == 0) ret = true;
+                    else { M.snp_thres = ws - 1; if (lane > ls) thr_eff = M.snp_thres; }
+                }
+                if (ret) { if (lane > ls) alive = false; stop = true; break; }
+            }
+            // work accounting exactly as the reference's CountMismatch early-outs (align.h:189-197)
+            {
+                const bool one = alive && ev.w0ref > thr_eff;
+                const bool two = alive && !one && (ev.p48 > thr_eff || ev.w01ref > thr_eff);
+                const bool five = alive && !one && !two;
+                C.n_cand += (u64)__builtin_popcountll(__ballot(alive));
+                C.sum_w += (u64)__builtin_popcountll(__ballot(one)) + 2ull * __builtin_popcountll(__ballot(two)) + 5ull * __builtin_popcountll(__ballot(five));
+            }
+            if (stop) { wave_fence(); return; }
+        }
+    }
+    wave_fence();
+}
+
+// SingleAlign::RunAlign (align.cpp:435-452) after packing/planning
+__device__ void run_align_single(const DevParams &P, const BlockLds &BL, const MateLds &L, Mate &M, const Slab &SL, int lane, Counters &C)
+{
+    for (int i = 0; i < M.seedseg; i++) {
+        snp_align(P, BL, L, M, SL, i, lane, C);
+        if (!P.rrbs) {
+            const u64 nz = __ballot(M.cnt_reg != 0 && (lane & 15) <= i && lane < 32);
+            if (nz) return;
+        }
+    }
+}
+
+// SingleAlign::Fix_Unpaired_Short_Fragment (align.cpp:768-791): RRBS mates shorter than -m that ended up unpaired lose
+// the hits whose restriction fragment is out of range; stops at the first class that still has a hit
+__device__ void fix_unpaired_short_fragment(const DevParams &P, Mate &M, const Slab &SL, int lane)
+{
+    if (M.filtered || M.len >= P.min_insert) return;
+    for (int ii = 0; ii <= M.max_snp; ii++) {
+        for (int orient = 0; orient < 2; orient++) {
+            const uint32_t n = n_of(M, orient, ii);
+            u64 *lst = SL.list(orient, ii);
+            uint32_t kept = 0;
+            for (uint32_t base = 0; base < n; base += 64) {
+                const uint32_t i = base + lane;
+                const u64 h = i < n ? lst[i] : 0;
+                bool keep = false;
+                if (i < n) { const int sl = ccgg_seglen(P, (uint32_t)(h >> 32), (uint32_t)h, M.len); keep = !(sl < P.min_insert || sl > P.max_insert); }
+                const u64 m = __ballot(keep);
+                if (keep) lst[kept + (uint32_t)__builtin_popcountll(m & lanemask_lt(lane))] = h;
+                kept += (uint32_t)__builtin_popcountll(m);
+            }
+            if (lane == orient * 16 + ii) M.cnt_reg = kept;
+            wave_fence();
+        }
+        if (n_of(M, 0, ii) + n_of(M, 1, ii) > 0) break;
+    }
+}
+
+// first non-empty class and a deterministic pick inside it (StringAlign align.cpp:610-627 / StringAlignUnpair pairs.cpp:255-275)
+__device__ void select_hit(const DevParams &P, const Mate &M, const Slab &SL, bsx_hit &out, bool unpair_semantics)
+{
+    out.chr = 0; out.loc = 0; out.n_best = 0; out.best_class = -1;
+    out.flags = M.filtered ? BSX_F_FILTERED : 0;
+    out.len = (uint8_t)M.len; out.raw_len = (uint8_t)M.raw_len; out.max_snp = (uint8_t)M.max_snp; out.seedseg = (uint8_t)M.seedseg;
+    if (M.filtered) return;
+    int ii; uint32_t sum = 0, nf = 0;
+    for (ii = 0; ii <= M.max_snp; ii++) {
+        nf = n_of(M, 0, ii);
+        if ((sum = nf + n_of(M, 1, ii)) > 0) break;
+    }
+    if (sum == 0) return;
+    out.n_best = (uint16_t)sum; out.best_class = (int8_t)ii;
+    uint32_t j = 0;
+    if (!unpair_semantics || sum > 1) j = bsx_myrand(M.index, P.randseed) % sum;
+    u64 h;
+    if (j < nf) h = SL.list(0, ii)[j];
+    else { h = SL.list(1, ii)[j - nf]; out.flags |= BSX_F_CHAIN; }
+    out.chr = (uint32_t)(h >> 32); out.loc = (uint32_t)h;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// paired-end pieces
+// ---------------------------------------------------------------------------------------------------------------
+// sort(hits, hits+n, HitComp) (align.cpp:363-368): keys (chr<<32|loc) are unique inside a list, so ranks are positions
+__device__ void sort_list(u64 *list, uint32_t n, u64 *tmp, int lane)
+{
+    if (n <= 1) return;
+    if (n <= 64) {
+        const u64 v = (uint32_t)lane < n ? list[lane] : ~0ull;
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < n; j++) rank += rl64(v, (int)j) < v;
+        if ((uint32_t)lane < n) list[rank] = v;
+    } else {
+        for (uint32_t base = 0; base < n; base += 64) {
+            const uint32_t i = base + lane;
+            const u64 v = i < n ? list[i] : ~0ull;
+            uint32_t rank = 0;
+            for (uint32_t cb = 0; cb < n; cb += 64) {
+                const u64 u = cb + lane < n ? list[cb + lane] : ~0ull;
+                const uint32_t lim = min(64u, n - cb);
+                for (uint32_t j = 0; j < lim; j++) rank += rl64(u, (int)j) < v;
+            }
+            if (i < n) tmp[rank] = v;
+        }
+        wave_fence();
+        for (uint32_t i = lane; i < n; i += 64) list[i] = tmp[i];
+    }
+    wave_fence();
+}
+
+struct PairSlab { uint32_t *rows; uint32_t rowcap; __device__ __forceinline__ uint32_t *row(int cls) const { return rows + (size_t)cls * rowcap * 6; } };
+
+__device__ __forceinline__ uint32_t first_chr_ge(const u64 *lst, uint32_t from, uint32_t n, uint32_t chr, bool strict, int lane)
+{
+    for (uint32_t base = from; base < n; base += 64) {
+        const uint32_t i = base + lane;
+        const uint32_t c = i < n ? (uint32_t)(lst[i] >> 32) : 0xffffffffu;
+        const u64 m = __ballot(i < n && (strict ? c > chr : c >= chr));
+        if (m) return base + (uint32_t)__builtin_ctzll(m);
+    }
+    return n;
+}
+
+// PairAlign::GetPairs (pairs.cpp:34-135)
+__device__ int get_pairs(const DevParams &P, const Mate &MA, const Mate &MB, const Slab &SA, const Slab &SB, const PairSlab &PS,
+                         uint32_t &pcnt_reg, int na, int nb, int lane)
+{
+    if (na > MA.max_snp || nb > MB.max_snp) return 0;
+    const int cls = na + nb;
+    uint32_t cnt = rl(pcnt_reg, cls);
+    uint32_t *row = PS.row(cls);
+    int result = -1;
+    for (int pass = 0; pass < 2 && result < 0; pass++) {
+        const u64 *al = SA.list(pass, na), *bl = SB.list(1 - pass, nb);
+        const uint32_t n_a = n_of(MA, pass, na), n_b = n_of(MB, 1 - pass, nb);
+        uint32_t chra = 0xffffffffu, bstart = 0, bend = 0;
+        for (uint32_t i = 0; i < n_a && result < 0; i++) {
+            const u64 ha = al[i];
+            const uint32_t achr = (uint32_t)(ha >> 32), aloc = (uint32_t)ha;
+            if (chra != achr) {
+                chra = achr;
+                bstart = first_chr_ge(bl, bend, n_b, chra, false, lane);
+                bend = first_chr_ge(bl, bstart, n_b, chra, true, lane);
+            }
+            for (uint32_t jb = bstart; jb < bend && result < 0; jb += 64) {
+                const uint32_t j = jb + lane;
+                const bool valid = j < bend;
+                const u64 hb = valid ? bl[j] : 0;
+                const uint32_t bloc = (uint32_t)hb;
+                uint32_t seg_start, seg_end;
+                const bool odd = (chra & 1) != 0;
+                if (pass == 0 ? odd : !odd) { seg_start = bloc; seg_end = aloc + (uint32_t)MA.len; }   // pairs.cpp:72,99
+                else { seg_start = aloc; seg_end = bloc + (uint32_t)MB.len; }                          // pairs.cpp:73,100
+                const int insert = (int)(seg_end - seg_start);
+                const bool ok = valid && insert >= P.min_insert && insert <= P.max_insert;
+                u64 m = __ballot(ok);
+                while (m) {  // appends happen one at a time in the reference, each followed by the cap test
+                    const int ls = (int)__builtin_ctzll(m);
+                    m &= m - 1;
+                    if (lane == ls) {
+                        uint32_t *o = row + (size_t)cnt * 6;
+                        o[0] = (uint32_t)pass | ((uint32_t)na << 16) | ((uint32_t)nb << 24);
+                        o[1] = (uint32_t)insert; o[2] = achr; o[3] = aloc; o[4] = (uint32_t)(hb >> 32); o[5] = bloc;
+                    }
+                    cnt++;
+                    if (cnt >= (uint32_t)P.max_num_hits) { result = 1; break; }
+                }
+            }
+        }
+    }
+    if (lane == cls) pcnt_reg = cnt;
+    wave_fence();
+    if (result < 0) result = cnt > 0 ? 1 : 0;
+    return result;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// the kernel
+// ---------------------------------------------------------------------------------------------------------------
+template <bool PE>
+__global__ __launch_bounds__(256) void k_align(AlignArgs A)
+{
+    __shared__ BlockLds BL;
+    __shared__ WaveLds<PE> WL[4];
+    const DevParams &P = A.P;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 256; i += 256) ((uint8_t *)BL.prof)[i] = ((const uint8_t *)P.profile_a)[i];
+    if (P.n_chr <= BSX_LDS_CHR) {
+        for (uint32_t i = threadIdx.x; i <= P.n_chr; i += 256) BL.anchor[i] = P.anchor[i];
+        for (uint32_t i = threadIdx.x; i < P.n_chr; i += 256) { BL.chr_size[i] = P.chr_size[i]; BL.rc_offset[i] = P.rc_offset[i]; }
+    }
+    __syncthreads();
+    const uint32_t slot = blockIdx.x * 4 + wv;
+    MateLds &LA = WL[wv].mate[0];
+    MateLds &LB = WL[wv].mate[PE ? 1 : 0];
+    Counters C = {0, 0, 0, 0};
+    u64 n_units_done = 0, n_aligned = 0, n_aligned_pairs = 0;
+    const uint32_t nclass = (uint32_t)P.max_snp_num + 1, rowcap = A.rowcap;
+    for (;;) {
+        uint32_t unit = 0;
+        if (lane == 0) unit = atomicAdd(A.queue, 1u);
+        unit = rfl(unit);
+        if (unit >= A.n_units) break;
+        n_units_done++;
+        uint8_t *slab = A.scratch + (size_t)(A.debug ? unit : slot) * A.slab_bytes;
+        Slab SA, SB;
+        SA.rowcap = SB.rowcap = rowcap; SA.nclass = SB.nclass = nclass;
+        SA.hits = (u64 *)slab;
+        SA.keys = (uint32_t *)(SA.hits + (size_t)2 * (nclass + 1) * rowcap);
+        SA.tmp = (u64 *)(SA.keys + (size_t)(nclass + 1) * rowcap);
+        uint8_t *after_a = (uint8_t *)(SA.tmp + BSX_SORT_TMP);
+        SB = SA;
+        PairSlab PS{nullptr, rowcap};
+        if (PE) {
+            SB.hits = (u64 *)after_a;
+            SB.keys = (uint32_t *)(SB.hits + (size_t)2 * (nclass + 1) * rowcap);
+            SB.tmp = (u64 *)(SB.keys + (size_t)(nclass + 1) * rowcap);
+            PS.rows = (uint32_t *)(SB.tmp + BSX_SORT_TMP);
+        }
+        Mate MA, MB;
+        MA.index = MB.index = A.first_index + unit;
+        load_and_filter(A, LA, MA, 0, unit, lane);
+        if (PE) load_and_filter(A, LB, MB, 1, unit, lane);
+        if (!PE) {
+            if (!MA.filtered) {
+                pack_read(P, LA, MA, 0, lane, C);
+                for (int o = 0; o < 2; o++) if ((MA.flags >> o) & 1) plan_orient(P, BL, LA, MA, o, lane, C);
+                run_align_single(P, BL, LA, MA, SA, lane, C);
+            }
+            bsx_hit out;
+            select_hit(P, MA, SA, out, false);
+            if (lane == 0) A.hits_out[unit] = out;
+            if (A.cc[0] && lane < 32) { uint16_t *cc = (uint16_t *)&A.cc[0][unit]; cc[lane] = (uint16_t)MA.cnt_reg; }
+            if (A.debug && lane < 32) { A.dbg_plan[(size_t)unit * 128 + lane] = LA.start[lane >> 4][lane & 15]; A.dbg_plan[(size_t)unit * 128 + 32 + lane] = LA.order[lane >> 4][lane & 15]; }
+            if (out.n_best == 1 || (out.n_best > 1 && P.report_repeat_hits == 1)) n_aligned++;
+        } else {
+            uint32_t pcnt_reg = 0;  // lane c holds _cur_n_hits[c]
+            int paired = 0;
+            if (!MA.filtered) { pack_read(P, LA, MA, 1, lane, C); }
+            if (!MB.filtered) { pack_read(P, LB, MB, 2, lane, C); }
+            // ReorderSeed for both mates (pairs.cpp:160) — also when only one mate survives (SingleAlign::RunAlign)
+            if (!MA.filtered) for (int o = 0; o < 2; o++) if ((MA.flags >> o) & 1) plan_orient(P, BL, LA, MA, o, lane, C);
+            if (!MB.filtered) for (int o = 0; o < 2; o++) if ((MB.flags >> o) & 1) plan_orient(P, BL, LB, MB, o, lane, C);
+            if (!MA.filtered && !MB.filtered) {
+                // PairAlign::RunAlign (pairs.cpp:163-172)
+                const int maxi = max(MA.max_snp, MB.max_snp);
+                for (int i = 0; i <= maxi && !paired; i++) {
+                    if (i < MA.seedseg) snp_align(P, BL, LA, MA, SA, i, lane, C);
+                    if (i < MB.seedseg) snp_align(P, BL, LB, MB, SB, i, lane, C);
+                    if (i <= MA.max_snp) { sort_list(SA.list(0, i), n_of(MA, 0, i), SA.tmp, lane); sort_list(SA.list(1, i), n_of(MA, 1, i), SA.tmp, lane); }
+                    if (i <= MB.max_snp) { sort_list(SB.list(0, i), n_of(MB, 0, i), SB.tmp, lane); sort_list(SB.list(1, i), n_of(MB, 1, i), SB.tmp, lane); }
+                    int n = get_pairs(P, MA, MB, SA, SB, PS, pcnt_reg, i, i, lane);
+                    for (int j = 0; j < i; j++) n += get_pairs(P, MA, MB, SA, SB, PS, pcnt_reg, i, j, lane) + get_pairs(P, MA, MB, SA, SB, PS, pcnt_reg, j, i, lane);
+                    if (n > 0) paired = i + 1;
+                }
+            } else {
+                if (!MA.filtered) run_align_single(P, BL, LA, MA, SA, lane, C);
+                if (!MB.filtered) run_align_single(P, BL, LB, MB, SB, lane, C);
+            }
+            bsx_pair out;
+            out.a_chr = out.a_loc = out.b_chr = out.b_loc = 0; out.insert = 0; out.n_pairs = 0; out.pair_class = -1; out.chain = 0;
+            out.na = out.nb = 0; out.paired = (uint8_t)paired; out.unpaired_out = 1;
+            if (paired) {  // StringAlignPair (pairs.cpp:222-242)
+                for (int c = 0; c <= 2 * P.max_snp_num; c++) {
+                    const uint32_t n = rl(pcnt_reg, c);
+                    if (!n) continue;
+                    out.pair_class = (int8_t)c; out.n_pairs = (uint16_t)n;
+                    int j = -1;
+                    if (n == 1) j = 0;
+                    else if (P.report_repeat_hits == 1) j = (int)(bsx_myrand(MA.index, P.randseed) % n);
+                    if (j >= 0) {
+                        const uint32_t *o = PS.row(c) + (size_t)j * 6;
+                        out.chain = (uint8_t)(o[0] & 0xffff); out.na = (uint8_t)((o[0] >> 16) & 0xff); out.nb = (uint8_t)(o[0] >> 24);
+                        out.insert = (int32_t)o[1]; out.a_chr = o[2]; out.a_loc = o[3]; out.b_chr = o[4]; out.b_loc = o[5];
+                        out.unpaired_out = 0;
+                    }
+                    break;
+                }
+            }
+            if (P.rrbs && out.unpaired_out) { fix_unpaired_short_fragment(P, MA, SA, lane); fix_unpaired_short_fragment(P, MB, SB, lane); }  // pairs.cpp:250-253
+            select_hit(P, MA, SA, out.a, true);
+            select_hit(P, MB, SB, out.b, true);
+            if (lane == 0) A.pairs_out[unit] = out;
+            if (A.cc[0] && lane < 32) { ((uint16_t *)&A.cc[0][unit])[lane] = (uint16_t)MA.cnt_reg; ((uint16_t *)&A.cc[1][unit])[lane] = (uint16_t)MB.cnt_reg; }
+            if (A.npairs_out && lane < 32) A.npairs_out[(size_t)unit * 32 + lane] = (uint16_t)pcnt_reg;
+            if (A.debug && lane < 32) {
+                A.dbg_plan[(size_t)unit * 128 + lane] = LA.start[lane >> 4][lane & 15]; A.dbg_plan[(size_t)unit * 128 + 32 + lane] = LA.order[lane >> 4][lane & 15];
+                A.dbg_plan[(size_t)unit * 128 + 64 + lane] = LB.start[lane >> 4][lane & 15]; A.dbg_plan[(size_t)unit * 128 + 96 + lane] = LB.order[lane >> 4][lane & 15];
+            }
+            if (!out.unpaired_out) n_aligned_pairs++;
+            else {
+                if (out.a.n_best == 1 || (out.a.n_best > 1 && P.report_repeat_hits == 1)) n_aligned++;
+                if (out.b.n_best == 1 || (out.b.n_best > 1 && P.report_repeat_hits == 1)) n_aligned++;
+            }
+        }
+        wave_fence();
+    }
+    if (lane == 0) {
+        atomicAdd((u64 *)&A.counters[0], C.n_lookup); atomicAdd((u64 *)&A.counters[1], C.n_cand);
+        atomicAdd((u64 *)&A.counters[2], C.sum_w); atomicAdd((u64 *)&A.counters[3], C.n_orient);
+        atomicAdd((u64 *)&A.counters[4], n_units_done); atomicAdd((u64 *)&A.counters[5], n_aligned);
+        atomicAdd((u64 *)&A.counters[6], n_aligned_pairs);
+    }
+}
+
+}  // namespace
+
+void bsx_launch_align(const AlignArgs &A, int paired, int grid_blocks, hipStream_t stream)
+{
+    if (paired) hipLaunchKernelGGL(k_align<true>, dim3(grid_blocks), dim3(256), 0, stream, A);
+    else hipLaunchKernelGGL(k_align<false>, dim3(grid_blocks), dim3(256), 0, stream, A);
+}
+
+int bsx_align_occupancy(int paired)
+{
+    int nb = 0;
+    hipError_t e = paired ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_align<true>, 256, 0)
+                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_align<false>, 256, 0);
+    if (e != hipSuccess || nb < 1) nb = 2;
+    return nb;
+}

@@ -1,0 +1,476 @@
+// bsx_api.hip — C ABI glue of libbsx.so: handles, device memory, uploads/downloads, kernel launches.
+// See include/bsx.h for the reference interfaces each entry point stands in for.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <vector>
+
+#include "bsx_internal.h"
+#include "bsx_kernel_args.h"
+
+static int g_waves_per_cu = 0;
+
+extern "C" int bsx_set_waves_per_cu(int w) { g_waves_per_cu = w; return BSX_OK; }
+
+extern "C" int bsx_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+static int check_device(int device)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) { g_bsx_err = "no HIP device visible; libbsx has no CPU fallback"; return BSX_ERR_NODEVICE; }
+    if (device < 0 || device >= n) { g_bsx_err = "device ordinal out of range"; return BSX_ERR_NODEVICE; }
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        g_bsx_err = std::string("device is ") + prop.gcnArchName + ", libbsx is built for gfx950 only";
+        return BSX_ERR_NODEVICE;
+    }
+    HIP_TRY(hipSetDevice(device));
+    return BSX_OK;
+}
+
+template <class T> static int upload(T **dst, const T *src, size_t n)
+{
+    HIP_TRY(hipMalloc((void **)dst, (n ? n : 1) * sizeof(T)));
+    if (n) HIP_TRY(hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+    return BSX_OK;
+}
+
+static int finish_ref_upload(bsx_ref *r, const std::vector<uint32_t> &refcat, const std::vector<uint32_t> &crefcat)
+{
+    int rc;
+    // 64 spare words behind each copy so that 16-byte candidate loads never leave the allocation
+    HIP_TRY(hipMalloc((void **)&r->d_refcat, (r->n_words + 64) * 4));
+    HIP_TRY(hipMalloc((void **)&r->d_crefcat, (r->n_words + 64) * 4));
+    HIP_TRY(hipMemset(r->d_refcat, 0, (r->n_words + 64) * 4));
+    HIP_TRY(hipMemset(r->d_crefcat, 0, (r->n_words + 64) * 4));
+    HIP_TRY(hipMemcpy(r->d_refcat, refcat.data(), r->n_words * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(r->d_crefcat, crefcat.data(), r->n_words * 4, hipMemcpyHostToDevice));
+    if ((rc = upload(&r->d_anchor, r->anchor.data(), r->anchor.size()))) return rc;
+    if ((rc = upload(&r->d_chr_size, r->chr_size.data(), r->chr_size.size()))) return rc;
+    if ((rc = upload(&r->d_rc_offset, r->rc_offset.data(), r->rc_offset.size()))) return rc;
+    return BSX_OK;
+}
+
+extern "C" int bsx_ref_create_from_fasta(const bsx_params *p, const char *text, uint64_t n_bytes, int device, bsx_ref **out)
+{
+    if (!p || !text || !out) return BSX_ERR_ARG;
+    int rc = check_device(device);
+    if (rc) return rc;
+    bsx_ref *r = new bsx_ref();
+    r->P = *p; r->device = device;
+    std::vector<uint32_t> refcat, crefcat;
+    rc = bsx_pack_fasta(*p, text, n_bytes, *r, refcat, crefcat);
+    if (rc == BSX_OK && r->n_chr == 0) rc = BSX_ERR_IO;
+    if (rc == BSX_OK) rc = finish_ref_upload(r, refcat, crefcat);
+    if (rc == BSX_OK && p->rrbs) rc = bsx_index_build_rrbs(r, refcat, crefcat);
+    if (rc != BSX_OK) { bsx_ref_destroy(r); return rc; }
+    *out = r;
+    return BSX_OK;
+}
+
+extern "C" int bsx_ref_create_from_file(const bsx_params *p, const char *path, int device, bsx_ref **out)
+{
+    if (!path) return BSX_ERR_ARG;
+    std::ifstream f(path, std::ios::binary);
+    if (!f) { g_bsx_err = std::string("cannot open ") + path; return BSX_ERR_IO; }  // "fatal error: failed to open ref file" (main.cpp:458)
+    std::string text((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    return bsx_ref_create_from_fasta(p, text.data(), text.size(), device, out);
+}
+
+extern "C" void bsx_ref_destroy(bsx_ref *r)
+{
+    if (!r) return;
+    (void)hipSetDevice(r->device);
+    for (void *q : {(void *)r->d_refcat, (void *)r->d_crefcat, (void *)r->d_anchor, (void *)r->d_chr_size, (void *)r->d_rc_offset,
+                    (void *)r->d_bucket_off, (void *)r->d_bucket_nfwd, (void *)r->d_entries, (void *)r->d_sites, (void *)r->d_site_off})
+        if (q) (void)hipFree(q);
+    delete r;
+}
+
+extern "C" uint32_t bsx_ref_n_chr(const bsx_ref *r) { return r ? r->n_chr : 0; }
+extern "C" uint64_t bsx_ref_n_words(const bsx_ref *r) { return r ? r->n_words : 0; }
+extern "C" uint32_t bsx_ref_n_blocks(const bsx_ref *r) { return r ? (uint32_t)r->blocks.size() : 0; }
+extern "C" int bsx_ref_info(const bsx_ref *r, uint32_t *anchor, uint32_t *chr_size, uint32_t *rc_offset)
+{
+    if (!r) return BSX_ERR_ARG;
+    if (anchor) memcpy(anchor, r->anchor.data(), r->anchor.size() * 4);
+    if (chr_size) memcpy(chr_size, r->chr_size.data(), r->chr_size.size() * 4);
+    if (rc_offset) memcpy(rc_offset, r->rc_offset.data(), r->rc_offset.size() * 4);
+    return BSX_OK;
+}
+extern "C" const char *bsx_ref_chr_name(const bsx_ref *r, uint32_t c) { return (r && c < r->names.size()) ? r->names[c].c_str() : ""; }
+extern "C" int bsx_ref_blocks(const bsx_ref *r, uint32_t *id, uint32_t *begin, uint32_t *end)
+{
+    if (!r) return BSX_ERR_ARG;
+    for (size_t i = 0; i < r->blocks.size(); i++) { id[i] = r->blocks[i].id; begin[i] = r->blocks[i].begin; end[i] = r->blocks[i].end; }
+    return BSX_OK;
+}
+extern "C" int bsx_ref_download_words(const bsx_ref *r, uint32_t *refcat, uint32_t *crefcat)
+{
+    if (!r) return BSX_ERR_ARG;
+    HIP_TRY(hipSetDevice(r->device));
+    if (refcat) HIP_TRY(hipMemcpy(refcat, r->d_refcat, r->n_words * 4, hipMemcpyDeviceToHost));
+    if (crefcat) HIP_TRY(hipMemcpy(crefcat, r->d_crefcat, r->n_words * 4, hipMemcpyDeviceToHost));
+    return BSX_OK;
+}
+
+extern "C" int bsx_index_build(bsx_ref *r)
+{
+    if (!r) return BSX_ERR_ARG;
+    if (r->P.rrbs) return r->has_index ? BSX_OK : BSX_ERR_STATE;  // RRBS index is assembled with the reference
+    return bsx_index_build_wgbs(r);
+}
+extern "C" uint64_t bsx_index_n_entries(const bsx_ref *r) { return r ? r->n_entries : 0; }
+extern "C" int bsx_index_download(const bsx_ref *r, uint32_t *bucket_off, uint32_t *bucket_nfwd, uint32_t *entries)
+{
+    if (!r) return BSX_ERR_ARG;
+    if (!r->has_index) return BSX_ERR_STATE;
+    HIP_TRY(hipSetDevice(r->device));
+    const size_t K = r->P.total_kmers;
+    if (bucket_off) HIP_TRY(hipMemcpy(bucket_off, r->d_bucket_off, (K + 1) * 4, hipMemcpyDeviceToHost));
+    if (bucket_nfwd) HIP_TRY(hipMemcpy(bucket_nfwd, r->d_bucket_nfwd, K * 4, hipMemcpyDeviceToHost));
+    if (entries && r->n_entries) HIP_TRY(hipMemcpy(entries, r->d_entries, r->n_entries * (r->P.rrbs ? 8 : 4), hipMemcpyDeviceToHost));
+    return BSX_OK;
+}
+extern "C" uint32_t bsx_ref_n_sites(const bsx_ref *r, uint32_t c) { return (r && c < r->sites.size()) ? (uint32_t)r->sites[c].size() : 0; }
+extern "C" int bsx_ref_sites(const bsx_ref *r, uint32_t c, uint32_t *sites)
+{
+    if (!r || c >= r->sites.size()) return BSX_ERR_ARG;
+    memcpy(sites, r->sites[c].data(), r->sites[c].size() * 4);
+    return BSX_OK;
+}
+
+void bsx_fill_devparams(const bsx_ref *r, DevParams &d)
+{
+    const bsx_params &p = r->P;
+    memset(&d, 0, sizeof(d));
+    d.seed_size = p.seed_size; d.index_interval = p.index_interval; d.max_snp_num = p.max_snp_num; d.max_num_hits = p.max_num_hits;
+    d.chains = p.chains; d.pairend = p.pairend; d.min_insert = p.min_insert; d.max_insert = p.max_insert;
+    d.report_repeat_hits = p.report_repeat_hits; d.randseed = p.randseed; d.qual_threshold = p.qual_threshold; d.zero_qual = p.zero_qual;
+    d.max_ns = p.max_ns; d.max_readlen = p.max_readlen; d.rrbs = p.rrbs; d.n_adapter = p.n_adapter;
+    d.digest_len = (int)strlen(p.digest_site); d.digest_pos = p.digest_pos;
+    d.seed_bits = p.seed_bits;
+    d.bit_nt_packed = p.bit_nt[0] | (p.bit_nt[1] << 8) | (p.bit_nt[2] << 16) | ((uint32_t)p.bit_nt[3] << 24);
+    memcpy(d.profile_a, p.profile_a, sizeof(d.profile_a));
+    for (int i = 0; i < p.n_adapter; i++) {
+        size_t l = strlen(p.adapter[i]);
+        d.adapter_len[i] = (uint8_t)(l > 15 ? 15 : l);
+        memcpy(d.adapter[i], p.adapter[i], d.adapter_len[i]);
+    }
+    memcpy(d.digest_site, p.digest_site, 16);
+    d.n_chr = r->n_chr;
+    d.refcat = r->d_refcat; d.crefcat = r->d_crefcat; d.anchor = r->d_anchor; d.chr_size = r->d_chr_size; d.rc_offset = r->d_rc_offset;
+    d.bucket_off = r->d_bucket_off; d.bucket_nfwd = r->d_bucket_nfwd; d.entries = r->d_entries;
+    d.sites = r->d_sites; d.site_off = r->d_site_off;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// batches
+// ---------------------------------------------------------------------------------------------------------------
+struct bsx_batch {
+    bsx_ref *ref = nullptr;
+    int paired = 0, debug = 0, has_qual = 0;
+    uint32_t max_units = 0, n_units = 0, first_index = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    uint8_t *d_seq[2] = {nullptr, nullptr}, *d_qual[2] = {nullptr, nullptr};
+    uint64_t *d_off[2] = {nullptr, nullptr};
+    size_t seq_cap[2] = {0, 0};
+    bsx_hit *d_hits = nullptr;
+    bsx_pair *d_pairs = nullptr;
+    bsx_class_counts *d_cc[2] = {nullptr, nullptr};
+    uint16_t *d_npairs = nullptr;
+    uint8_t *d_scratch = nullptr, *d_dbg = nullptr;
+    size_t scratch_bytes = 0;
+    uint32_t *d_queue = nullptr;
+    uint64_t *d_counters = nullptr;
+    uint64_t slab_bytes = 0;
+    uint32_t rowcap = 0;
+    int grid_blocks = 0;
+    bool ran = false;
+};
+
+static uint64_t mate_bytes(const bsx_params &p, uint32_t rowcap)
+{
+    const uint64_t rows = (uint64_t)p.max_snp_num + 2;  // nclass + 1 spare row (see Slab in bsx_align.hip)
+    return 2 * rows * rowcap * 8 + rows * rowcap * 4 + (uint64_t)BSX_SORT_TMP * 8;
+}
+
+static uint64_t slab_size(const bsx_params &p, int paired, uint32_t rowcap)
+{
+    const uint64_t mate = mate_bytes(p, rowcap);
+    uint64_t s = mate;
+    if (paired) s = 2 * mate + (2 * (uint64_t)p.max_snp_num + 2) * rowcap * 24;
+    return (s + 255) & ~255ull;
+}
+
+static int ensure_scratch(bsx_batch *b)
+{
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, b->ref->device));
+    int blocks_per_cu = bsx_align_occupancy(b->paired);
+    if (g_waves_per_cu > 0) blocks_per_cu = std::max(1, std::min(blocks_per_cu, g_waves_per_cu / 4));
+    if (blocks_per_cu > 8) blocks_per_cu = 8;
+    int grid = prop.multiProcessorCount * blocks_per_cu;
+    const int need = (int)((b->max_units + 3) / 4);
+    if (grid > need) grid = need > 0 ? need : 1;
+    b->grid_blocks = grid;
+    const uint64_t slots = b->debug ? b->max_units : (uint64_t)grid * 4;
+    const size_t bytes = (size_t)(slots * b->slab_bytes);
+    if (bytes > b->scratch_bytes) {
+        if (b->d_scratch) (void)hipFree(b->d_scratch);
+        b->d_scratch = nullptr;
+        HIP_TRY(hipMalloc((void **)&b->d_scratch, bytes));
+        b->scratch_bytes = bytes;
+    }
+    return BSX_OK;
+}
+
+extern "C" int bsx_batch_create(bsx_ref *r, uint32_t max_units, int paired, bsx_batch **out)
+{
+    if (!r || !out || max_units == 0) return BSX_ERR_ARG;
+    if (!r->has_index) { g_bsx_err = "bsx_index_build must run before bsx_batch_create"; return BSX_ERR_STATE; }
+    HIP_TRY(hipSetDevice(r->device));
+    bsx_batch *b = new bsx_batch();
+    b->ref = r; b->paired = paired ? 1 : 0; b->max_units = max_units;
+    b->rowcap = BSX_ROWCAP;
+    b->slab_bytes = slab_size(r->P, b->paired, b->rowcap);
+    int rc = BSX_OK;
+    auto fail = [&](int code) { bsx_batch_destroy(b); return code; };
+    if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) return fail(BSX_ERR_DEVICE);
+    if (hipEventCreate(&b->ev0) != hipSuccess || hipEventCreate(&b->ev1) != hipSuccess) return fail(BSX_ERR_DEVICE);
+    const int nm = b->paired ? 2 : 1;
+    for (int m = 0; m < nm; m++) {
+        b->seq_cap[m] = (size_t)max_units * 160 + 256;
+        if (hipMalloc((void **)&b->d_seq[m], b->seq_cap[m]) != hipSuccess || hipMalloc((void **)&b->d_qual[m], b->seq_cap[m]) != hipSuccess ||
+            hipMalloc((void **)&b->d_off[m], ((size_t)max_units + 1) * 8) != hipSuccess || hipMalloc((void **)&b->d_cc[m], (size_t)max_units * sizeof(bsx_class_counts)) != hipSuccess)
+            return fail(BSX_ERR_NOMEM);
+    }
+    if (b->paired) {
+        if (hipMalloc((void **)&b->d_pairs, (size_t)max_units * sizeof(bsx_pair)) != hipSuccess || hipMalloc((void **)&b->d_npairs, (size_t)max_units * 64) != hipSuccess)
+            return fail(BSX_ERR_NOMEM);
+    } else if (hipMalloc((void **)&b->d_hits, (size_t)max_units * sizeof(bsx_hit)) != hipSuccess) return fail(BSX_ERR_NOMEM);
+    if (hipMalloc((void **)&b->d_queue, 256) != hipSuccess || hipMalloc((void **)&b->d_counters, BSX_N_COUNTERS * 8) != hipSuccess) return fail(BSX_ERR_NOMEM);
+    if (hipMemset(b->d_counters, 0, BSX_N_COUNTERS * 8) != hipSuccess) return fail(BSX_ERR_DEVICE);
+    if ((rc = ensure_scratch(b)) != BSX_OK) return fail(rc);
+    *out = b;
+    return BSX_OK;
+}
+
+extern "C" void bsx_batch_destroy(bsx_batch *b)
+{
+    if (!b) return;
+    (void)hipSetDevice(b->ref->device);
+    if (b->stream) (void)hipStreamSynchronize(b->stream);
+    for (int m = 0; m < 2; m++)
+        for (void *q : {(void *)b->d_seq[m], (void *)b->d_qual[m], (void *)b->d_off[m], (void *)b->d_cc[m]})
+            if (q) (void)hipFree(q);
+    for (void *q : {(void *)b->d_hits, (void *)b->d_pairs, (void *)b->d_npairs, (void *)b->d_scratch, (void *)b->d_dbg, (void *)b->d_queue, (void *)b->d_counters})
+        if (q) (void)hipFree(q);
+    if (b->ev0) (void)hipEventDestroy(b->ev0);
+    if (b->ev1) (void)hipEventDestroy(b->ev1);
+    if (b->stream) (void)hipStreamDestroy(b->stream);
+    delete b;
+}
+
+static int upload_mate(bsx_batch *b, int m, uint32_t n, const char *seqs, const uint64_t *off, const char *quals)
+{
+    const uint64_t bytes = off[n] - off[0];
+    if (off[0] != 0) { g_bsx_err = "off[0] must be 0"; return BSX_ERR_ARG; }
+    if (bytes + 256 > b->seq_cap[m]) {
+        (void)hipFree(b->d_seq[m]); (void)hipFree(b->d_qual[m]);
+        b->d_seq[m] = b->d_qual[m] = nullptr;
+        b->seq_cap[m] = bytes + 256;
+        HIP_TRY(hipMalloc((void **)&b->d_seq[m], b->seq_cap[m]));
+        HIP_TRY(hipMalloc((void **)&b->d_qual[m], b->seq_cap[m]));
+    }
+    HIP_TRY(hipMemcpyAsync(b->d_seq[m], seqs, bytes, hipMemcpyHostToDevice, b->stream));
+    if (quals) HIP_TRY(hipMemcpyAsync(b->d_qual[m], quals, bytes, hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(hipMemcpyAsync(b->d_off[m], off, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, b->stream));
+    return BSX_OK;
+}
+
+extern "C" int bsx_batch_upload_se(bsx_batch *b, uint32_t n, const char *seqs, const uint64_t *off, const char *quals, uint32_t first_index)
+{
+    if (!b || !seqs || !off || b->paired || n > b->max_units) return BSX_ERR_ARG;
+    HIP_TRY(hipSetDevice(b->ref->device));
+    int rc = upload_mate(b, 0, n, seqs, off, quals);
+    if (rc) return rc;
+    b->n_units = n; b->first_index = first_index; b->has_qual = quals != nullptr;
+    HIP_TRY(hipStreamSynchronize(b->stream));  // host buffers may be reused by the caller
+    return BSX_OK;
+}
+
+extern "C" int bsx_batch_upload_pe(bsx_batch *b, uint32_t n, const char *seqs_a, const uint64_t *off_a, const char *quals_a,
+                                   const char *seqs_b, const uint64_t *off_b, const char *quals_b, uint32_t first_index)
+{
+    if (!b || !seqs_a || !off_a || !seqs_b || !off_b || !b->paired || n > b->max_units) return BSX_ERR_ARG;
+    if ((quals_a == nullptr) != (quals_b == nullptr)) return BSX_ERR_ARG;
+    HIP_TRY(hipSetDevice(b->ref->device));
+    int rc = upload_mate(b, 0, n, seqs_a, off_a, quals_a);
+    if (rc == BSX_OK) rc = upload_mate(b, 1, n, seqs_b, off_b, quals_b);
+    if (rc) return rc;
+    b->n_units = n; b->first_index = first_index; b->has_qual = quals_a != nullptr;
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return BSX_OK;
+}
+
+extern "C" int bsx_batch_set_debug(bsx_batch *b, int keep)
+{
+    if (!b) return BSX_ERR_ARG;
+    HIP_TRY(hipSetDevice(b->ref->device));
+    b->debug = keep ? 1 : 0;
+    if (keep && !b->d_dbg) HIP_TRY(hipMalloc((void **)&b->d_dbg, (size_t)b->max_units * 128));
+    return ensure_scratch(b);
+}
+
+extern "C" int bsx_batch_run(bsx_batch *b)
+{
+    if (!b) return BSX_ERR_ARG;
+    if (b->n_units == 0) return BSX_ERR_STATE;
+    HIP_TRY(hipSetDevice(b->ref->device));
+    AlignArgs A;
+    memset(&A, 0, sizeof(A));
+    bsx_fill_devparams(b->ref, A.P);
+    A.n_units = b->n_units; A.first_index = b->first_index; A.debug = b->debug; A.rowcap = b->rowcap;
+    for (int m = 0; m < 2; m++) { A.seq[m] = b->d_seq[m]; A.off[m] = b->d_off[m]; A.qual[m] = b->has_qual ? b->d_qual[m] : nullptr; A.cc[m] = b->d_cc[m]; }
+    A.hits_out = b->d_hits; A.pairs_out = b->d_pairs; A.npairs_out = b->d_npairs;
+    A.scratch = b->d_scratch; A.slab_bytes = b->slab_bytes; A.queue = b->d_queue; A.counters = b->d_counters; A.dbg_plan = b->d_dbg;
+    HIP_TRY(hipMemsetAsync(b->d_queue, 0, 4, b->stream));
+    if (b->debug) HIP_TRY(hipMemsetAsync(b->d_scratch, 0, (size_t)b->max_units * b->slab_bytes, b->stream));
+    HIP_TRY(hipEventRecord(b->ev0, b->stream));
+    bsx_launch_align(A, b->paired, b->grid_blocks, b->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(b->ev1, b->stream));
+    b->ran = true;
+    return BSX_OK;
+}
+
+extern "C" int bsx_batch_sync(bsx_batch *b)
+{
+    if (!b) return BSX_ERR_ARG;
+    HIP_TRY(hipSetDevice(b->ref->device));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return BSX_OK;
+}
+
+extern "C" float bsx_batch_kernel_ms(bsx_batch *b)
+{
+    if (!b || !b->ran) return -1.f;
+    float ms = -1.f;
+    if (hipEventElapsedTime(&ms, b->ev0, b->ev1) != hipSuccess) return -1.f;
+    return ms;
+}
+
+extern "C" int bsx_batch_results_se(bsx_batch *b, bsx_hit *out, bsx_class_counts *counts)
+{
+    if (!b || b->paired || !out) return BSX_ERR_ARG;
+    if (!b->ran) return BSX_ERR_STATE;
+    HIP_TRY(hipSetDevice(b->ref->device));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(hipMemcpy(out, b->d_hits, (size_t)b->n_units * sizeof(bsx_hit), hipMemcpyDeviceToHost));
+    if (counts) HIP_TRY(hipMemcpy(counts, b->d_cc[0], (size_t)b->n_units * sizeof(bsx_class_counts), hipMemcpyDeviceToHost));
+    return BSX_OK;
+}
+
+extern "C" int bsx_batch_results_pe(bsx_batch *b, bsx_pair *out, bsx_class_counts *ca, bsx_class_counts *cb, uint16_t *n_pairs31)
+{
+    if (!b || !b->paired || !out) return BSX_ERR_ARG;
+    if (!b->ran) return BSX_ERR_STATE;
+    HIP_TRY(hipSetDevice(b->ref->device));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(hipMemcpy(out, b->d_pairs, (size_t)b->n_units * sizeof(bsx_pair), hipMemcpyDeviceToHost));
+    if (ca) HIP_TRY(hipMemcpy(ca, b->d_cc[0], (size_t)b->n_units * sizeof(bsx_class_counts), hipMemcpyDeviceToHost));
+    if (cb) HIP_TRY(hipMemcpy(cb, b->d_cc[1], (size_t)b->n_units * sizeof(bsx_class_counts), hipMemcpyDeviceToHost));
+    if (n_pairs31) {
+        std::vector<uint16_t> tmp((size_t)b->n_units * 32);
+        HIP_TRY(hipMemcpy(tmp.data(), b->d_npairs, tmp.size() * 2, hipMemcpyDeviceToHost));
+        for (uint32_t u = 0; u < b->n_units; u++) memcpy(n_pairs31 + (size_t)u * 31, tmp.data() + (size_t)u * 32, 62);
+    }
+    return BSX_OK;
+}
+
+extern "C" int bsx_batch_counters(bsx_batch *b, uint64_t c[BSX_N_COUNTERS])
+{
+    if (!b || !c) return BSX_ERR_ARG;
+    HIP_TRY(hipSetDevice(b->ref->device));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(hipMemcpy(c, b->d_counters, BSX_N_COUNTERS * 8, hipMemcpyDeviceToHost));
+    return BSX_OK;
+}
+extern "C" int bsx_batch_reset_counters(bsx_batch *b)
+{
+    if (!b) return BSX_ERR_ARG;
+    HIP_TRY(hipSetDevice(b->ref->device));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(hipMemset(b->d_counters, 0, BSX_N_COUNTERS * 8));
+    return BSX_OK;
+}
+
+extern "C" int bsx_batch_download_reads(bsx_batch *b, int mate, char *seqs, uint64_t *off)
+{
+    if (!b || mate < 0 || mate > (b->paired ? 1 : 0) || !off) return BSX_ERR_ARG;
+    HIP_TRY(hipSetDevice(b->ref->device));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(hipMemcpy(off, b->d_off[mate], ((size_t)b->n_units + 1) * 8, hipMemcpyDeviceToHost));
+    if (seqs) HIP_TRY(hipMemcpy(seqs, b->d_seq[mate], off[b->n_units], hipMemcpyDeviceToHost));
+    return BSX_OK;
+}
+
+// ---- debug readers (valid only after a run with bsx_batch_set_debug(b, 1)) -------------------------------------
+static uint8_t *unit_slab(bsx_batch *b, uint32_t unit) { return b->d_scratch + (size_t)unit * b->slab_bytes; }
+
+extern "C" int bsx_batch_debug_hits(bsx_batch *b, uint32_t unit, int mate, int orient, int w, uint32_t *chr_loc, uint32_t cap)
+{
+    if (!b || !b->debug || unit >= b->n_units || !b->ran) return BSX_ERR_STATE;
+    HIP_TRY(hipSetDevice(b->ref->device));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    const uint64_t nclass = (uint64_t)b->ref->P.max_snp_num + 1, rowcap = b->rowcap;
+    const uint64_t mbytes = mate_bytes(b->ref->P, b->rowcap);
+    bsx_class_counts cc;
+    HIP_TRY(hipMemcpy(&cc, b->d_cc[mate] + unit, sizeof(cc), hipMemcpyDeviceToHost));
+    uint32_t n = orient ? cc.n_chit[w] : cc.n_hit[w];
+    if (n > cap) n = cap;
+    std::vector<uint64_t> tmp(n);
+    const uint8_t *src = unit_slab(b, unit) + (mate ? mbytes : 0) + ((uint64_t)(orient * (nclass + 1) + w) * rowcap) * 8;
+    if (n) HIP_TRY(hipMemcpy(tmp.data(), src, (size_t)n * 8, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n; i++) { chr_loc[2 * i] = (uint32_t)(tmp[i] >> 32); chr_loc[2 * i + 1] = (uint32_t)tmp[i]; }
+    return (int)n;
+}
+
+extern "C" int bsx_batch_debug_pairs(bsx_batch *b, uint32_t unit, int w, uint32_t *pairhits6, uint32_t cap)
+{
+    if (!b || !b->debug || !b->paired || unit >= b->n_units || !b->ran) return BSX_ERR_STATE;
+    HIP_TRY(hipSetDevice(b->ref->device));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    const uint64_t rowcap = b->rowcap;
+    const uint64_t mbytes = mate_bytes(b->ref->P, b->rowcap);
+    uint16_t np[32];
+    HIP_TRY(hipMemcpy(np, b->d_npairs + (size_t)unit * 32, 64, hipMemcpyDeviceToHost));
+    uint32_t n = np[w];
+    if (n > cap) n = cap;
+    const uint8_t *src = unit_slab(b, unit) + 2 * mbytes + (uint64_t)w * rowcap * 24;
+    if (n) HIP_TRY(hipMemcpy(pairhits6, src, (size_t)n * 24, hipMemcpyDeviceToHost));
+    return (int)n;
+}
+
+extern "C" int bsx_batch_debug_plan(bsx_batch *b, uint32_t unit, int mate, int32_t *start32, int32_t *order32)
+{
+    if (!b || !b->debug || unit >= b->n_units || !b->ran) return BSX_ERR_STATE;
+    HIP_TRY(hipSetDevice(b->ref->device));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    uint8_t buf[64];
+    HIP_TRY(hipMemcpy(buf, b->d_dbg + (size_t)unit * 128 + (mate ? 64 : 0), 64, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 32; i++) { start32[i] = buf[i]; order32[i] = buf[32 + i]; }
+    return BSX_OK;
+}
+
+// synthetic workload generators live in bsx_synth.hip

@@ -1,0 +1,269 @@
+// bsx_host.cpp — host side of libbsx.so that needs no device code: option semantics, alphabet,
+// seed profile and the reference packer.
+//
+// Reference behaviour restated here (file:line in BSMAP v2.6):
+//   Param::Param / SetSeedSize / SetDigestionSite / SetAlign / InitMapping   param.cpp:6-121,187-231
+//   RefSeq::LoadNextSeq / BinSeq / cBinSeq / UnmaskRegion / Run_ConvertBinseq dbseq.cpp:18-142,215-282
+//   RefSeq::find_CCGG                                                          dbseq.cpp:144-211
+#include <algorithm>
+#include <cctype>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+
+#include "bsx_internal.h"
+
+thread_local std::string g_bsx_err;
+
+int bsx_hip_fail(hipError_t e, const char *what, const char *file, int line)
+{
+    char buf[512];
+    snprintf(buf, sizeof(buf), "%s:%d: %s -> %s", file, line, what, hipGetErrorString(e));
+    g_bsx_err = buf;
+    if (e == hipErrorOutOfMemory) return BSX_ERR_NOMEM;
+    if (e == hipErrorNoDevice || e == hipErrorInvalidDevice) return BSX_ERR_NODEVICE;
+    return BSX_ERR_DEVICE;
+}
+
+extern "C" const char *bsx_last_error_detail(void) { return g_bsx_err.c_str(); }
+
+extern "C" const char *bsx_strerror(int code)
+{
+    switch (code) {
+    case BSX_OK: return "ok";
+    case BSX_ERR_ARG: return "invalid argument";
+    case BSX_ERR_IO: return "cannot read input";
+    case BSX_ERR_NOMEM: return "out of memory";
+    case BSX_ERR_DEVICE: return "HIP runtime error";
+    case BSX_ERR_STATE: return "call order violated";
+    case BSX_ERR_LIMIT: return "reference limit exceeded";
+    case BSX_ERR_NODEVICE: return "no gfx950 device available (libbsx has no CPU fallback)";
+    }
+    return "unknown error";
+}
+
+extern "C" int bsx_params_default(bsx_params *p)
+{
+    if (!p) return BSX_ERR_ARG;
+    memset(p, 0, sizeof(*p));
+    p->seed_size = 16;              // param.cpp:44
+    p->index_interval = 4;          // param.cpp:76
+    p->max_snp_num = 2;             // param.cpp:49
+    p->max_num_hits = BSX_MAXHITS;  // param.cpp:50
+    p->min_insert = 28;             // param.cpp:40
+    p->max_insert = 500;            // param.cpp:41
+    p->report_repeat_hits = 1;      // param.cpp:56
+    p->zero_qual = '!';             // param.cpp:36
+    p->max_ns = 5;                  // param.cpp:33
+    p->max_readlen = BSX_MAX_READLEN;
+    p->read_nt = 'T';
+    p->ref_nt = 'C';                // param.cpp:81
+    return BSX_OK;
+}
+
+extern "C" int bsx_params_set_digest(bsx_params *p, const char *site)
+{
+    if (!p || !site) return BSX_ERR_ARG;
+    const char *dash = strchr(site, '-');
+    if (!dash) return BSX_ERR_ARG;  // "Digestion position not marked" (param.cpp:98-101)
+    size_t n = strlen(site);
+    if (n < 2 || n - 1 >= 16) return BSX_ERR_ARG;
+    p->digest_pos = (int)(dash - site);
+    memset(p->digest_site, 0, sizeof(p->digest_site));
+    memcpy(p->digest_site, site, p->digest_pos);
+    strcpy(p->digest_site + p->digest_pos, dash + 1);
+    p->rrbs = 1;
+    p->index_interval = 1;
+    p->seed_size = 12;
+    return BSX_OK;
+}
+
+static int nt_index(int c)
+{
+    switch (c) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; }
+    return -1;
+}
+
+extern "C" int bsx_params_finish(bsx_params *p)
+{
+    if (!p) return BSX_ERR_ARG;
+    if (p->rrbs) { p->seed_size = 12; p->index_interval = 1; }  // main.cpp:247,257
+    if (p->seed_size < 1 || p->seed_size > 16) return BSX_ERR_LIMIT;
+    if (p->index_interval < 1 || p->index_interval > 16) return BSX_ERR_LIMIT;      // main.cpp:258
+    if (p->max_snp_num < 0 || p->max_snp_num > BSX_MAXSNPS) return BSX_ERR_LIMIT;    // main.cpp:260-262
+    if (p->max_num_hits < 1 || p->max_num_hits > BSX_MAXHITS) return BSX_ERR_LIMIT;  // main.cpp:263-265
+    if (p->max_readlen < 1 || p->max_readlen > BSX_MAX_READLEN) p->max_readlen = BSX_MAX_READLEN;
+    if (p->n_adapter < 0 || p->n_adapter > 10) return BSX_ERR_ARG;
+    int rd = nt_index(p->read_nt), rf = nt_index(p->ref_nt);
+    if (rd < 0 || rf < 0) return BSX_ERR_ARG;  // "Unknown nucleotide."
+    if (rd == rf) return BSX_ERR_ARG;          // "Must specify different nucleotides for additional alignment."
+    // SetAlign: the read nucleotide gets code 3, the reference nucleotide code 1, the other two 0 and 2 in ACGT order
+    uint8_t other = 0;
+    for (int i = 0; i < 4; i++) {
+        if (i == rd) p->bit_nt[i] = 3;
+        else if (i == rf) p->bit_nt[i] = 1;
+        else { p->bit_nt[i] = other; other = 2; }
+    }
+    p->seed_bits = 0;
+    for (int i = 0; i < p->seed_size; i++) p->seed_bits |= 3u << (2 * i);
+    memset(p->profile_a, 0, sizeof(p->profile_a));
+    for (int ph = 0; ph < p->index_interval; ph++)
+        for (int seg = 0; seg <= BSX_MAXSNPS; seg++) {
+            int a = ((seg * p->seed_size + ph + p->index_interval - 1) / p->index_interval) * p->index_interval;
+            p->profile_a[seg][ph] = (uint8_t)a;  // bit8_t in the reference: wraps the same way
+        }
+    p->max_seedseg_num = 9 * 16 / p->seed_size;  // dbseq.cpp:217
+    p->total_kmers = 1;
+    for (int i = 0; i < p->seed_size; i++) p->total_kmers *= 3;
+    return BSX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// reference packer
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+inline bool is_space(char c) { return c == ' ' || (c >= '\t' && c <= '\r'); }
+inline bool is_useful(char c) { return nt_index(c) >= 0; }                       // Param::useful_nt
+inline bool is_nx(char c) { return c == 'N' || c == 'X' || c == 'n' || c == 'x'; } // Param::nx_nt
+
+struct Cursor {
+    const char *t; uint64_t n, i;
+    void skip_ws() { while (i < n && is_space(t[i])) i++; }
+    bool token(uint64_t &b, uint64_t &e) { skip_ws(); b = i; while (i < n && !is_space(t[i])) i++; e = i; return e > b; }
+};
+
+}  // namespace
+
+int bsx_pack_fasta(const bsx_params &P, const char *text, uint64_t n, bsx_ref &r, std::vector<uint32_t> &refcat,
+                   std::vector<uint32_t> &crefcat)
+{
+    // The reference reads records with operator>> (dbseq.cpp:18-54): the first non-blank character is consumed
+    // unchecked, the next token is the name, the rest of that line is ignored, then whitespace-separated tokens
+    // are concatenated until one begins with '>'.  The work string (_seq) is reused between records and never
+    // cleared, which matters only for where find_first_of may look past the end; `buf` plays that role here.
+    uint8_t code_f[256], code_r[256];
+    for (int c = 0; c < 256; c++) {
+        int k = nt_index(c);
+        code_f[c] = P.bit_nt[k < 0 ? 0 : k];          // alphabet[]: unknown -> code of 'A'
+        code_r[c] = P.bit_nt[k < 0 ? 3 : 3 - k];      // rev_alphabet[]: unknown -> code of 'T'
+    }
+    Cursor cur{text, n, 0};
+    std::string buf;
+    std::vector<std::vector<uint32_t>> fw, rc;
+    r.n_chr = 0; r.sum_length = 0;
+    r.anchor.clear(); r.chr_size.clear(); r.rc_offset.clear(); r.names.clear(); r.blocks.clear(); r.sites.clear();
+    r.ccgg_index.assign(P.rrbs ? P.max_seedseg_num : 0, {});
+    const size_t dl = strlen(P.digest_site);
+    for (;;) {
+        cur.skip_ws();
+        if (cur.i >= cur.n) break;
+        cur.i++;  // fin>>c
+        uint64_t b, e;
+        cur.token(b, e);
+        std::string name(text + b, text + e);
+        while (cur.i < cur.n && text[cur.i] != '\n') cur.i++;
+        if (cur.i < cur.n) cur.i++;
+        uint64_t len = 0;
+        for (;;) {
+            cur.skip_ws();
+            if (cur.i >= cur.n || text[cur.i] == '>') break;
+            cur.token(b, e);
+            if (buf.size() < len + (e - b)) buf.resize((len + (e - b)) * 2 + 1024, '\0');
+            memcpy(&buf[len], text + b, e - b);
+            len += e - b;
+        }
+        if (len == 0) break;  // LoadNextSeq returned 0
+        if (len >= 0xFFFFFFFFull - 64) return BSX_ERR_LIMIT;
+        const uint32_t L = (uint32_t)len;
+        const uint32_t nw = (L + BSX_SEGLEN - 1) / BSX_SEGLEN + 2;  // BinSeq: two spare words (dbseq.cpp:60)
+        const uint64_t padded = (uint64_t)nw * BSX_SEGLEN;
+        if (buf.size() < padded + 1) buf.resize(padded * 2 + 1024, '\0');
+        std::fill(buf.begin() + L, buf.begin() + padded, 'N');
+        std::vector<uint32_t> f(nw), c(nw);
+        for (uint32_t w = 0; w < nw; w++) {
+            uint32_t x = 0, y = 0;
+            const uint64_t base = (uint64_t)w * BSX_SEGLEN, rbase = padded - 1 - base;
+            for (uint32_t j = 0; j < BSX_SEGLEN; j++) {
+                x = (x << 2) | code_f[(uint8_t)buf[base + j]];
+                y = (y << 2) | code_r[(uint8_t)buf[rbase - j]];
+            }
+            f[w] = x; c[w] = y;
+        }
+        const uint32_t chr = r.n_chr;
+        // UnmaskRegion (dbseq.cpp:114-142): maximal runs between N/X characters that start at an ACGT letter and
+        // are >= 30 nt; each run is recorded on the forward copy (id 2c) and mirrored on the rc copy (id 2c+1).
+        {
+            uint32_t begin, end = 0;
+            while (end < L) {
+                uint64_t q = end;
+                while (q < buf.size() && !is_useful(buf[q])) q++;
+                if (q >= buf.size() || q > L) break;
+                begin = (uint32_t)q;
+                while (q < buf.size() && !is_nx(buf[q])) q++;
+                end = q <= L ? (uint32_t)q : L;
+                if (end - begin < 30) continue;
+                // (the reference's "merge with previous block if gap < 5" test compares against the rc twin pushed
+                //  last and therefore never fires; reproduced literally)
+                if (!r.blocks.empty() && r.blocks.back().id == 2 * chr && begin - r.blocks.back().end < 5) r.blocks.back().end = end;
+                else {
+                    r.blocks.push_back(Block{2 * chr, begin, end});
+                    r.blocks.push_back(Block{2 * chr + 1, (uint32_t)padded - end, (uint32_t)padded - begin});
+                }
+            }
+        }
+        r.names.push_back(name);
+        r.chr_size.push_back(L);
+        r.rc_offset.push_back((uint32_t)padded);
+        fw.push_back(std::move(f));
+        rc.push_back(std::move(c));
+        r.n_chr++;
+        r.sum_length += L;
+        if (P.rrbs) {
+            // find_CCGG (dbseq.cpp:144-211)
+            std::vector<uint32_t> sites;
+            for (uint64_t q = 0; q < L && q + dl <= buf.size(); q++) {
+                bool ok = true;
+                for (size_t k = 0; k < dl && ok; k++) ok = toupper((uint8_t)buf[q + k]) == P.digest_site[k];
+                if (ok) sites.push_back((uint32_t)q + P.digest_pos);
+            }
+            const uint32_t tmp_offset = (uint32_t)padded - P.seed_size, tmp_max = L - P.seed_size;
+            for (int s = 0; s < P.max_seedseg_num; s++) { r.ccgg_index[s].emplace_back(); r.ccgg_index[s].emplace_back(); }
+            if (sites.size() > 1) {
+                for (size_t k = 0; k + 1 < sites.size(); k++)
+                    if (sites[k + 1] - sites[k] <= (uint32_t)P.max_insert) {
+                        int seedloc = (int)sites[k];
+                        for (int s = 0; s < P.max_seedseg_num && (uint32_t)seedloc <= tmp_max; s++, seedloc += P.seed_size)
+                            r.ccgg_index[s][2 * chr].push_back((uint32_t)seedloc);
+                    }
+                for (size_t k = 1; k < sites.size(); k++)
+                    if (sites[k] - sites[k - 1] <= (uint32_t)P.max_insert) {
+                        int seedloc = (int)((size_t)sites[k] + dl - 2 * P.digest_pos - P.seed_size);
+                        for (int s = 0; s < P.max_seedseg_num && seedloc >= 0; s++, seedloc -= P.seed_size)
+                            r.ccgg_index[s][2 * chr + 1].push_back(tmp_offset - (uint32_t)seedloc);
+                    }
+            }
+            r.sites.push_back(std::move(sites));
+        }
+    }
+    std::sort(r.blocks.begin(), r.blocks.end(), [](const Block &a, const Block &b) { return a.id < b.id || (a.id == b.id && a.begin < b.begin); });
+    // concatenate with margins (dbseq.cpp:252-273); total nt coordinate space must stay below 2^32
+    uint64_t words = 0;
+    r.anchor.assign(1, BSX_REF_MARGIN * BSX_SEGLEN);
+    for (uint32_t c = 0; c < r.n_chr; c++) {
+        words += fw[c].size();
+        if ((words + 2 * BSX_REF_MARGIN) * BSX_SEGLEN >= 0xFFFFFFFFull) return BSX_ERR_LIMIT;
+        r.anchor.push_back((uint32_t)((words + BSX_REF_MARGIN) * BSX_SEGLEN));
+    }
+    r.n_words = words + 2 * BSX_REF_MARGIN;
+    refcat.assign(r.n_words, 0);   // margins are zero here (uninitialised memory in the reference; never observable)
+    crefcat.assign(r.n_words, 0);
+    uint64_t o = BSX_REF_MARGIN;
+    for (uint32_t c = 0; c < r.n_chr; c++) {
+        std::copy(fw[c].begin(), fw[c].end(), refcat.begin() + o);
+        std::copy(rc[c].begin(), rc[c].end(), crefcat.begin() + o);
+        o += fw[c].size();
+    }
+    return BSX_OK;
+}

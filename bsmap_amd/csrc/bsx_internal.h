@@ -1,0 +1,73 @@
+// bsx_internal.h — private structures shared by the translation units of libbsx.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/bsx.h"
+
+#define BSX_REF_MARGIN 400u  // words of padding either side of the concatenated reference (reference dbseq.h:15)
+#define BSX_SEGLEN 16u
+#define BSX_LDS_CHR 512
+#define BSX_ROWCAP (BSX_MAXHITS + 1)  // HitArray / PairArray row length (reference align.h:18, pairs.h:22)
+#define BSX_SORT_TMP 1280            // scratch entries for sorting one class list      // chromosomes whose anchors are staged in LDS by the align kernel
+
+// everything the align kernel needs, passed by value as the kernel argument
+struct DevParams {
+    int32_t seed_size, index_interval, max_snp_num, max_num_hits, chains, pairend, min_insert, max_insert;
+    int32_t report_repeat_hits, randseed, qual_threshold, zero_qual, max_ns, max_readlen, rrbs, n_adapter;
+    int32_t digest_len, digest_pos;
+    uint32_t seed_bits;
+    uint32_t bit_nt_packed;          // bit_nt[i] in byte i
+    uint8_t profile_a[16][16];
+    char adapter[10][16];            // only the first 15 characters are ever compared (reference align.cpp:414)
+    uint8_t adapter_len[10];
+    char digest_site[16];
+    // reference
+    uint32_t n_chr;
+    const uint32_t *refcat, *crefcat, *anchor, *chr_size, *rc_offset;
+    // index (CSR)
+    const uint32_t *bucket_off, *bucket_nfwd, *entries;
+    // RRBS site table
+    const uint32_t *sites, *site_off;
+};
+
+struct Block { uint32_t id, begin, end; };
+
+struct bsx_ref {
+    bsx_params P;
+    int device = 0;
+    uint32_t n_chr = 0;
+    uint64_t n_words = 0;
+    uint64_t sum_length = 0;
+    std::vector<uint32_t> anchor, chr_size, rc_offset;
+    std::vector<std::string> names;
+    std::vector<Block> blocks;
+    // RRBS (reference RefSeq::CCGG_sites / CCGG_index, dbseq.h:106-107)
+    std::vector<std::vector<uint32_t>> sites;
+    std::vector<std::vector<std::vector<uint32_t>>> ccgg_index;  // [seg][2*chr + strand]
+    // device
+    uint32_t *d_refcat = nullptr, *d_crefcat = nullptr, *d_anchor = nullptr, *d_chr_size = nullptr, *d_rc_offset = nullptr;
+    uint32_t *d_bucket_off = nullptr, *d_bucket_nfwd = nullptr, *d_entries = nullptr;
+    uint32_t *d_sites = nullptr, *d_site_off = nullptr;
+    uint64_t n_entries = 0;
+    bool has_index = false;
+};
+
+extern thread_local std::string g_bsx_err;
+int bsx_hip_fail(hipError_t e, const char *what, const char *file, int line);
+#define HIP_TRY(x)                                                            \
+    do {                                                                      \
+        hipError_t e_ = (x);                                                  \
+        if (e_ != hipSuccess) return bsx_hip_fail(e_, #x, __FILE__, __LINE__); \
+    } while (0)
+
+// bsx_refpack.cpp
+int bsx_pack_fasta(const bsx_params &P, const char *text, uint64_t n, bsx_ref &r, std::vector<uint32_t> &refcat,
+                   std::vector<uint32_t> &crefcat);
+// bsx_index.hip
+int bsx_index_build_wgbs(bsx_ref *r);
+int bsx_index_build_rrbs(bsx_ref *r, const std::vector<uint32_t> &refcat, const std::vector<uint32_t> &crefcat);
+// bsx_align.hip
+void bsx_fill_devparams(const bsx_ref *r, DevParams &d);

@@ -1,0 +1,172 @@
+/* bsx.h — C ABI of libbsx.so, the MI355X (gfx950) implementation of the BSMAP v2.6 alignment hot path.
+ *
+ * BSMAP has no plugin/FFI interface; the seam this library replaces is the per-thread C++ object call
+ *     a.ImportBatchReads(n, reads); a.Do_Batch(ref);          (reference main.cpp:57-64, :94-102)
+ * plus the two start-up calls that produce the data Do_Batch reads:
+ *     ref.Run_ConvertBinseq(fin_db); ref.CreateIndex();        (reference main.cpp:462, :174-178)
+ * Every entry point below cites the reference interface it stands in for (file:line in the BSMAP
+ * v2.6 tree).  Signatures carry plain pointers and sizes only; all device memory is owned by the
+ * library behind opaque handles; no call throws or aborts — errors are negative return codes.
+ *
+ * Host text formatting (SAM/BSP, reference align.cpp:631-765, pairs.cpp:288-498) stays on the host
+ * side of this boundary and consumes the numeric records returned here.
+ */
+#ifndef BSX_H
+#define BSX_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BSX_MAXSNPS 15    /* reference param.h:27 */
+#define BSX_MAXHITS 1000  /* reference makefile:4 (-DMAXHITS) */
+#define BSX_MAX_READLEN 144 /* reference param.cpp:80 (READ_144) */
+
+enum {
+    BSX_OK = 0,
+    BSX_ERR_ARG = -1,      /* bad argument / option value (reference: cerr + exit(1), main.cpp:260-265) */
+    BSX_ERR_IO = -2,       /* cannot open / parse file (reference main.cpp:457-461) */
+    BSX_ERR_NOMEM = -3,    /* host or device allocation failed */
+    BSX_ERR_DEVICE = -4,   /* HIP runtime error (see bsx_last_error_detail) */
+    BSX_ERR_STATE = -5,    /* call order violated (e.g. align before index build) */
+    BSX_ERR_LIMIT = -6,    /* reference limits exceeded (>= 2^32 nt, -v > 15, -w > 1000, -s > 16) */
+    BSX_ERR_NODEVICE = -7  /* no usable gfx950 device: the library has NO CPU fallback */
+};
+const char *bsx_strerror(int code);
+const char *bsx_last_error_detail(void); /* thread-local text of the last failing HIP call */
+
+/* ---- parameters: reference class Param (param.h:54-169), option parser main.cpp:234-289 ------- */
+typedef struct bsx_params {
+    int32_t seed_size;          /* -s  */
+    int32_t index_interval;     /* -I  */
+    int32_t max_snp_num;        /* -v  */
+    int32_t max_num_hits;       /* -w  */
+    int32_t chains;             /* -n  */
+    int32_t pairend;            /* -b given */
+    int32_t min_insert;         /* -m  */
+    int32_t max_insert;         /* -x  */
+    int32_t report_repeat_hits; /* -r  */
+    int32_t randseed;           /* -S  (0 = nondeterministic in the reference; here: treated as seed 0 of the same hash) */
+    int32_t qual_threshold;     /* -q  */
+    int32_t zero_qual;          /* -z  */
+    int32_t max_ns;             /* -f  */
+    int32_t max_readlen;        /* -L  */
+    int32_t out_sam;            /* affects TrimLowQual's quality rebasing only (align.cpp:64-67) */
+    int32_t rrbs;               /* set by bsx_params_set_digest */
+    int32_t digest_pos;
+    int32_t n_adapter;          /* -A (up to 10) */
+    char digest_site[32];
+    char adapter[10][128];
+    char read_nt, ref_nt;       /* -M */
+    char pad_[2];
+    /* derived (bsx_params_finish) */
+    uint8_t bit_nt[4];          /* 2-bit code of A,C,G,T (Param::SetAlign, param.cpp:187-231) */
+    uint8_t profile_a[BSX_MAXSNPS + 1][16]; /* SeedProfile.a (param.cpp:85-93) */
+    uint32_t seed_bits;
+    int32_t max_seedseg_num;
+    uint32_t total_kmers;
+} bsx_params;
+
+int bsx_params_default(bsx_params *p);                         /* Param::Param(), param.cpp:6-83 */
+int bsx_params_set_digest(bsx_params *p, const char *site);    /* Param::SetDigestionSite, param.cpp:95-106 ("C-CGG") */
+int bsx_params_finish(bsx_params *p);                          /* SetAlign + SetSeedSize + InitMapping; validates limits */
+
+/* ---- reference genome: RefSeq::Run_ConvertBinseq (dbseq.cpp:215-282) --------------------------- */
+typedef struct bsx_ref bsx_ref;
+int bsx_device_count(void);
+/* parse FASTA text on the host with the reference's tokenisation, pack both strands, upload to `device` */
+int bsx_ref_create_from_fasta(const bsx_params *p, const char *text, uint64_t n_bytes, int device, bsx_ref **out);
+int bsx_ref_create_from_file(const bsx_params *p, const char *path, int device, bsx_ref **out);
+/* deterministic synthetic genome generated ON the device (bench workload) */
+int bsx_ref_create_synthetic(const bsx_params *p, uint32_t n_chr, const uint32_t *chr_len, uint64_t seed, int device, bsx_ref **out);
+void bsx_ref_destroy(bsx_ref *r);
+uint32_t bsx_ref_n_chr(const bsx_ref *r);
+uint64_t bsx_ref_n_words(const bsx_ref *r);            /* words per strand copy incl. 2*400 margin (dbseq.h:15) */
+uint32_t bsx_ref_n_blocks(const bsx_ref *r);
+/* copies out: anchor[n_chr+1], chr_size[n_chr], rc_offset[n_chr]  (RefSeq::ref_anchor, RefTitle, dbseq.h:24-30,113) */
+int bsx_ref_info(const bsx_ref *r, uint32_t *anchor, uint32_t *chr_size, uint32_t *rc_offset);
+const char *bsx_ref_chr_name(const bsx_ref *r, uint32_t c);
+int bsx_ref_blocks(const bsx_ref *r, uint32_t *id, uint32_t *begin, uint32_t *end); /* RefSeq::_blocks, sorted */
+int bsx_ref_download_words(const bsx_ref *r, uint32_t *refcat, uint32_t *crefcat);  /* device -> host, n_words each */
+
+/* ---- seed index: RefSeq::CreateIndex (dbseq.cpp:516-539) ---------------------------------------- */
+int bsx_index_build(bsx_ref *r);                        /* built on the GPU; entry order identical to the reference */
+uint64_t bsx_index_n_entries(const bsx_ref *r);
+/* CSR copy-out: bucket_off[total_kmers+1], bucket_nfwd[total_kmers], entries[n_entries]
+ * (WGBS: u32 global positions, RefSeq::index2; RRBS: pairs {tag,loc}, RefSeq::index — 2 words per entry) */
+int bsx_index_download(const bsx_ref *r, uint32_t *bucket_off, uint32_t *bucket_nfwd, uint32_t *entries);
+uint32_t bsx_ref_n_sites(const bsx_ref *r, uint32_t c);                /* RRBS: RefSeq::CCGG_sites */
+int bsx_ref_sites(const bsx_ref *r, uint32_t c, uint32_t *sites);
+
+/* ---- read batches: SingleAlign / PairAlign ImportBatchReads + Do_Batch -------------------------- */
+typedef struct bsx_batch bsx_batch;
+
+/* per-read record == what SingleAlign::StringAlign (align.cpp:610-627) hands to the formatter */
+typedef struct bsx_hit {
+    uint32_t chr;        /* 2*c for the + reference strand copy, 2*c+1 for the - copy (Hit.chr) */
+    uint32_t loc;        /* 0-based forward coordinate of the first base (Hit.loc) */
+    uint16_t n_best;     /* hits in the best class, both read orientations (<= -w) */
+    int8_t best_class;   /* mismatches of the best class; -1 = no hit */
+    uint8_t flags;       /* BSX_F_* */
+    uint8_t len;         /* read length after trimming (FilterReads) */
+    uint8_t max_snp;     /* read_max_snp_num (align.cpp:586) */
+    uint8_t seedseg;     /* seedseg_num (align.cpp:440) */
+    uint8_t raw_len;     /* length before trimming */
+} bsx_hit;
+#define BSX_F_FILTERED 1u  /* FilterReads() rejected the read (QC) */
+#define BSX_F_CHAIN 2u     /* chosen hit is on the read's reverse-complement orientation (chits) */
+
+/* optional per-read class counts: _cur_n_hit[w] / _cur_n_chit[w] (align.h:85-86) */
+typedef struct bsx_class_counts { uint16_t n_hit[BSX_MAXSNPS + 1], n_chit[BSX_MAXSNPS + 1]; } bsx_class_counts;
+
+/* per-pair record == PairHit (pairs.h:13-20) chosen by StringAlignPair (pairs.cpp:222-242), plus the
+ * two single-mate records StringAlignUnpair (pairs.cpp:244-286) would use */
+typedef struct bsx_pair {
+    uint32_t a_chr, a_loc, b_chr, b_loc;
+    int32_t insert;
+    uint16_t n_pairs;    /* pairs in the best pair class */
+    int8_t pair_class;   /* na+nb of the best class, -1 none */
+    uint8_t chain;       /* PairHit.chain */
+    uint8_t na, nb;
+    uint8_t paired;      /* PairAlign::RunAlign return value (level+1, 0 = none) */
+    uint8_t unpaired_out;/* 1: pair not reported (tmp==1 || paired==0): use a/b below */
+    uint32_t pad_;
+    bsx_hit a, b;        /* per-mate records; n_best is ma/mb of StringAlignUnpair when unpaired_out */
+} bsx_pair;
+
+/* work counters, SURVEY §8(d): 0 n_lookup, 1 n_cand, 2 sum_w (64-bit reference words the reference
+ * algorithm touches), 3 n_orient, 4 reads/pairs processed, 5 aligned reads (n_aligned semantics), 6 aligned pairs, 7 spare */
+#define BSX_N_COUNTERS 8
+
+int bsx_batch_create(bsx_ref *r, uint32_t max_units, int paired, bsx_batch **out);
+void bsx_batch_destroy(bsx_batch *b);
+/* SoA upload (ImportBatchReads, align.cpp:42-46 / pairs.cpp:27-32): read i = seqs[off[i] .. off[i+1]);
+ * quals may be NULL (FASTA input: constant default quality, reads.cpp:108); reads longer than -L are truncated
+ * (reads.cpp:115-117).  first_index = ReadInf.index of unit 0 (reads.cpp:97). */
+int bsx_batch_upload_se(bsx_batch *b, uint32_t n, const char *seqs, const uint64_t *off, const char *quals, uint32_t first_index);
+int bsx_batch_upload_pe(bsx_batch *b, uint32_t n, const char *seqs_a, const uint64_t *off_a, const char *quals_a,
+                        const char *seqs_b, const uint64_t *off_b, const char *quals_b, uint32_t first_index);
+/* synthetic bisulfite reads sampled ON the device from the resident reference (bench workload) */
+int bsx_batch_synth_reads(bsx_batch *b, uint32_t n, uint32_t read_len, uint64_t seed, uint32_t first_index);
+/* Do_Batch (align.cpp:591-606 / pairs.cpp:192-218): asynchronous launch on the batch's HIP stream */
+int bsx_batch_run(bsx_batch *b);
+int bsx_batch_sync(bsx_batch *b);
+float bsx_batch_kernel_ms(bsx_batch *b);          /* HIP-event time of the last run's align kernel (after sync) */
+int bsx_batch_results_se(bsx_batch *b, bsx_hit *out, bsx_class_counts *counts /* may be NULL */);
+int bsx_batch_results_pe(bsx_batch *b, bsx_pair *out, bsx_class_counts *counts_a, bsx_class_counts *counts_b, uint16_t *n_pairs31);
+int bsx_batch_counters(bsx_batch *b, uint64_t c[BSX_N_COUNTERS]);   /* accumulated since creation / last reset */
+int bsx_batch_reset_counters(bsx_batch *b);
+/* download the device-resident input reads (for the CPU baseline on device-synthesised input) */
+int bsx_batch_download_reads(bsx_batch *b, int mate, char *seqs, uint64_t *off);
+/* test hook: keep every hit / pair list of every unit (needs max_units small); layout documented in DESIGN.md */
+int bsx_batch_set_debug(bsx_batch *b, int keep_lists);
+int bsx_batch_debug_hits(bsx_batch *b, uint32_t unit, int mate, int orient, int w, uint32_t *chr_loc_pairs, uint32_t cap);
+int bsx_batch_debug_pairs(bsx_batch *b, uint32_t unit, int w, uint32_t *pairhits6 /* chain|na<<16|nb<<24, insert, a.chr, a.loc, b.chr, b.loc */, uint32_t cap);
+int bsx_batch_debug_plan(bsx_batch *b, uint32_t unit, int mate, int32_t *start_arrays32 /* [2][16] */, int32_t *seedindex32 /* [2][16] */);
+/* tuning knob: resident waves per CU for the persistent align kernel (default chosen from register use) */
+int bsx_set_waves_per_cu(int waves);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,267 @@
+"""Parity of the HIP path (through the C ABI of libbsx.so) with the oracle and the golden vectors.  Needs an MI355X.
+
+Bar: bit-exact — packed reference words, block list, every index bucket, the planner state, every hit list, every
+pair list, the chosen hit / pair, and the work counters that feed the roofline numerator.
+"""
+import numpy as np
+import pytest
+
+import bsmap_amd as B
+import bsx_testdata as td
+import golden_util as G
+
+pytestmark = pytest.mark.gpu
+
+ADAPTER = "AGATCGGAAGAGC"
+
+
+def _leaky(length, kw):
+    """reads whose reference result depends on the previous read (SURVEY §7 hard part 2): (len-I+1) % S == 0"""
+    if "D" in kw:
+        return False
+    return (length - kw.get("I", 4) + 1) % kw.get("s", 16) == 0
+
+
+def _cmp_read(o, h, cc, kw, tag):
+    """o: oracle ReadResult, h: bsx_hit record, cc: class counts"""
+    nclass = kw["v"] + 1
+    assert bool(o.filtered) == bool(h["flags"] & B.F_FILTERED), tag
+    assert o.len == h["len"] and o.raw_len == h["raw_len"], tag
+    if o.filtered:
+        return
+    assert o.read_max_snp_num == h["max_snp"] and o.seedseg_num == h["seedseg"], tag
+    assert list(o.n_hit)[:nclass] == list(cc["n_hit"][:nclass]), (tag, list(o.n_hit)[:nclass], list(cc["n_hit"][:nclass]))
+    assert list(o.n_chit)[:nclass] == list(cc["n_chit"][:nclass]), (tag, list(o.n_chit)[:nclass], list(cc["n_chit"][:nclass]))
+
+
+def _cmp_pick(o, h, tag):
+    assert max(o.n_best, 0) == h["n_best"], tag
+    if o.n_best > 0:
+        assert (o.best_class, o.chr, o.loc, o.chain) == (h["best_class"], h["chr"], h["loc"], (h["flags"] >> 1) & 1), tag
+    else:
+        assert h["best_class"] == -1, tag
+
+
+@pytest.fixture(scope="module", params=G.CONFIGS)
+def case(request, oracle):
+    meta, arr, fasta = G.load(request.param)
+    kw = meta["kw"]
+    op = oracle.make_params(**kw)
+    oref = oracle.OracleRef(op, fasta_path=fasta)
+    gp = B.make_params(**kw)
+    gref = B.RefSeq(gp).Run_ConvertBinseq(fasta_path=fasta).CreateIndex()
+    yield meta, arr, oref, gref, oracle
+    gref.close()
+    oref.free()
+
+
+def test_reference_and_index(case):
+    meta, arr, oref, gref, O = case
+    a, s, r = gref.info()
+    assert np.array_equal(a, arr["anchor"]) and np.array_equal(s, arr["chr_size"]) and np.array_equal(r, arr["rc_offset"])
+    assert np.array_equal(gref.blocks(), arr["blocks"])
+    f, c = gref.words()
+    assert np.array_equal(f[400:-400], arr["refcat"]) and np.array_equal(c[400:-400], arr["crefcat"])
+    assert gref.names() == oref.names()
+    off, nf, ent = gref.index()
+    if "D" in meta["kw"]:
+        keys, n, _ = G.sparse_index(off)
+        assert np.array_equal(keys, arr["idx_keys"]) and np.array_equal(n, arr["idx_n"]) and np.array_equal(ent, arr["idx_entries"])
+        assert np.array_equal(gref.sites(0), arr["sites0"]) and np.array_equal(gref.sites(1), arr["sites1"])
+    else:
+        keys, n, nfk = G.sparse_index(off, nf)
+        assert np.array_equal(keys, arr["idx_keys"]) and np.array_equal(n, arr["idx_n"]) and np.array_equal(nfk, arr["idx_nfwd"])
+        assert np.array_equal(ent, arr["idx_entries"])
+        assert np.array_equal(off, oref.bucket_off()) and np.array_equal(nf, oref.bucket_nfwd())
+
+
+def test_alignment_vs_oracle_and_golden(case):
+    meta, arr, oref, gref, O = case
+    kw = meta["kw"]
+    nclass = kw["v"] + 1
+    reads = meta["reads"]
+    al = O.OracleAligner(oref, leak_mode=0)
+    if meta["kind"] == "se":
+        sa = B.SingleAlign(gref, len(reads), debug=True)
+        sa.ImportBatchReads([r["seq"] for r in reads], [r["qual"] for r in reads]).Do_Batch()
+        hits, cc = sa.results()
+        for i, r in enumerate(reads):
+            o = al.se(i, r["seq"], r["qual"])
+            _cmp_read(o, hits[i], cc[i], kw, (meta["config"], i))
+            if o.filtered:
+                continue
+            _cmp_pick(o, hits[i], i)
+            st, od = sa.debug_plan(i)
+            n = o.seedseg_num
+            if o.flag_chain:
+                assert list(st[0][:n]) == list(o.seed_start_array)[:n] and list(od[0][:n]) == list(o.seedindex)[:n], i
+            if o.cflag_chain:
+                assert list(st[1][:n]) == list(o.cseed_start_array)[:n] and list(od[1][:n]) == list(o.cseedindex)[:n], i
+            for w in range(nclass):
+                for orient in (0, 1):
+                    nn = (o.n_chit if orient else o.n_hit)[w]
+                    assert sa.debug_hits(i, 0, orient, w) == al.se_hits(orient, w, nn), (i, w, orient)
+            # golden record from the real reference (skip the reads whose reference result is call-order dependent)
+            e = meta["expected"][i]
+            if not e["filtered"] and not _leaky(e["len"], kw):
+                assert e["n_hit"][:nclass] == list(cc[i]["n_hit"][:nclass]) and e["n_chit"][:nclass] == list(cc[i]["n_chit"][:nclass]), i
+                for w in range(nclass):
+                    for orient in (0, 1):
+                        assert [tuple(x) for x in e["hits"][w][orient]] == sa.debug_hits(i, 0, orient, w), (i, w, orient)
+        c = sa.counters()
+        assert [int(x) for x in c[:4]] == al.counters(), (c, al.counters())
+        assert int(c[4]) == len(reads)
+        sa.close()
+    else:
+        pa = B.PairAlign(gref, len(reads), debug=True)
+        pa.ImportBatchReads([r["seq1"] for r in reads], [r["seq2"] for r in reads], [r["qual1"] for r in reads], [r["qual2"] for r in reads]).Do_Batch()
+        out, ca, cb, npairs = pa.results()
+        for i, r in enumerate(reads):
+            o = al.pe(i, r["seq1"], r["seq2"], r["qual1"], r["qual2"])
+            g = out[i]
+            _cmp_read(o.a, g["a"], ca[i], kw, (i, "a"))
+            _cmp_read(o.b, g["b"], cb[i], kw, (i, "b"))
+            assert o.paired == g["paired"], (i, o.paired, g["paired"])
+            assert list(o.n_pairs)[:2 * nclass - 1] == list(npairs[i][:2 * nclass - 1]), i
+            for mate, om in enumerate((o.a, o.b)):
+                if om.filtered:
+                    continue
+                for w in range(nclass):
+                    for orient in (0, 1):
+                        nn = (om.n_chit if orient else om.n_hit)[w]
+                        assert pa.debug_hits(i, mate, orient, w) == al.pe_hits(mate, orient, w, nn), (i, mate, w, orient)
+            for w in range(2 * nclass - 1):
+                assert pa.debug_pairs(i, w) == al.pe_pairs(w, o.n_pairs[w]), (i, w)
+            assert bool(g["unpaired_out"]) == bool(o.tmp == 1 or o.paired == 0), i
+            if not g["unpaired_out"]:
+                pk = o.pick
+                assert (pk.chain, pk.na, pk.nb, pk.insert, pk.a.chr, pk.a.loc, pk.b.chr, pk.b.loc) == \
+                       (g["chain"], g["na"], g["nb"], g["insert"], g["a_chr"], g["a_loc"], g["b_chr"], g["b_loc"]), i
+                assert (o.pair_class, o.pair_n) == (g["pair_class"], g["n_pairs"]), i
+            else:
+                _cmp_pick(o.a, g["a"], (i, "a")) if not o.a.filtered else None
+                _cmp_pick(o.b, g["b"], (i, "b")) if not o.b.filtered else None
+            e = meta["expected"][i]
+            if not e["a"]["filtered"] and not e["b"]["filtered"] and not _leaky(e["a"]["len"], kw) and not _leaky(e["b"]["len"], kw):
+                assert e["paired"] == g["paired"] and e["n_pairs"][:2 * nclass - 1] == list(npairs[i][:2 * nclass - 1]), i
+                for w, pl in enumerate(e["pairs"]):
+                    assert [tuple(x) for x in pl] == pa.debug_pairs(i, w), (i, w)
+        c = pa.counters()
+        assert [int(x) for x in c[:4]] == al.counters(), (c, al.counters())
+        pa.close()
+    al.free()
+
+
+# ---- seeded larger cases: edge conditions the golden sets are too small for --------------------------------
+EDGE = [
+    ("se_n1_var", dict(s=16, v=6, I=4, S=3, r=1, n=1, q=20, A=[ADAPTER]), dict(kind="se", n=4000, length=144, var=True, trim=True)),
+    ("se_w5", dict(s=14, v=5, I=2, S=3, r=1, n=1, w=5), dict(kind="se", n=3000, length=144, var=True)),
+    ("se_r0_w3", dict(s=10, v=3, I=1, S=3, r=0, n=1, w=3), dict(kind="se", n=3000, length=120, var=True)),
+    ("se_v15_I16_GA", dict(s=9, v=15, I=16, S=3, r=1, n=1, M="GA"), dict(kind="se", n=600, length=80)),
+    ("se_s12_c1", dict(s=12, v=2, I=4, S=1, r=1), dict(kind="se", n=10000, length=36, sub=0.02)),
+    ("pe_c3", dict(s=16, v=6, I=4, S=1, r=1, m=28, x=500), dict(kind="pe", n=3000, length=150)),
+    ("pe_trim_w4", dict(s=12, v=3, I=2, S=2, r=1, n=1, m=0, x=300, w=4), dict(kind="pe", n=2000, length=150, trim=True)),
+    ("pe_r0_q", dict(s=16, v=6, I=4, S=1, r=0, m=28, x=500, q=20, A=[ADAPTER]), dict(kind="pe", n=2000, length=150, trim=True)),
+]
+
+
+@pytest.fixture(scope="module")
+def edge_genome(tmp_path_factory):
+    g = td.make_genome(seed=1, chr_lens=(300_000, 150_000, 50_017), gc=0.51, microsats=25, repeats=60)
+    fa = str(tmp_path_factory.mktemp("edge") / "g.fa")
+    td.write_fasta(fa, g)
+    return g, fa
+
+
+@pytest.mark.parametrize("name,kw,spec", EDGE, ids=[e[0] for e in EDGE])
+def test_edge_cases_vs_oracle(name, kw, spec, edge_genome, oracle):
+    g, fa = edge_genome
+    if spec["kind"] == "pe":
+        kw = dict(kw, pairend=1)
+    op = oracle.make_params(**kw)
+    oref = oracle.OracleRef(op, fasta_path=fa)
+    gref = B.RefSeq(B.make_params(**kw)).Run_ConvertBinseq(fasta_path=fa).CreateIndex()
+    off, nf, ent = gref.index()
+    assert np.array_equal(off, oref.bucket_off()) and np.array_equal(nf, oref.bucket_nfwd()) and np.array_equal(ent, oref.entries())
+    trim = spec.get("trim", False)
+    if spec["kind"] == "se":
+        reads = td.make_se_reads(g, spec["n"], spec["length"], seed=7, sub_rate=spec.get("sub", 0.01), var_len=spec.get("var", False),
+                                 strands=("++", "-+", "+-", "--"), qual_tail=trim, adapter=ADAPTER if trim else None)
+        seqs, quals = [r["seq"] for r in reads], [r["qual"] for r in reads]
+        sbuf, soff = oracle.pack_reads(seqs)
+        qbuf, _ = oracle.pack_reads(quals)
+        ores, ocnt = oracle.se_batch(oref, sbuf, soff, qbuf, threads=4)
+        sa = B.SingleAlign(gref, len(reads))
+        sa.ImportBatchReads((sbuf, soff), qbuf).Do_Batch()
+        hits, cc = sa.results()
+        nclass = kw["v"] + 1
+        assert np.array_equal(ores["filtered"] != 0, (hits["flags"] & 1) != 0)
+        ok = ores["filtered"] == 0
+        assert np.array_equal(ores["len"], hits["len"]) and np.array_equal(ores["n_hit"][ok][:, :nclass], cc["n_hit"][ok][:, :nclass])
+        assert np.array_equal(ores["n_chit"][ok][:, :nclass], cc["n_chit"][ok][:, :nclass])
+        assert np.array_equal(np.maximum(ores["n_best"][ok], 0), hits["n_best"][ok])
+        has = ok & (ores["n_best"] > 0)
+        for f in ("chr", "loc", "best_class"):
+            assert np.array_equal(ores[f][has], hits[f][has]), f
+        assert np.array_equal(ores["chain"][has], (hits["flags"][has] >> 1) & 1)
+        assert [int(x) for x in sa.counters()[:4]] == ocnt
+        assert has.sum() > 0.2 * len(reads)
+        sa.close()
+    else:
+        pairs = td.make_pe_reads(g, spec["n"], spec["length"], seed=8, sub_rate=0.015, qual_tail=trim, adapter=ADAPTER if trim else None,
+                                 var_len=trim, ins_min=20 if trim else 50, ins_mean=200 if trim else 300, ins_sd=100 if trim else 50)
+        s1, o1 = oracle.pack_reads([p["seq1"] for p in pairs])
+        s2, o2 = oracle.pack_reads([p["seq2"] for p in pairs])
+        q1, _ = oracle.pack_reads([p["qual1"] for p in pairs])
+        q2, _ = oracle.pack_reads([p["qual2"] for p in pairs])
+        ores, ocnt = oracle.pe_batch(oref, s1, o1, s2, o2, q1, q2, threads=4)
+        pa = B.PairAlign(gref, len(pairs))
+        pa.ImportBatchReads((s1, o1), (s2, o2), q1, q2).Do_Batch()
+        out, ca, cb, npairs = pa.results()
+        nclass = kw["v"] + 1
+        assert np.array_equal(ores["paired"], out["paired"])
+        assert np.array_equal(ores["n_pairs"][:, :2 * nclass - 1], npairs[:, :2 * nclass - 1])
+        up = (ores["tmp"] == 1) | (ores["paired"] == 0)
+        assert np.array_equal(up, out["unpaired_out"] != 0)
+        pr = ~up
+        for f, gname in (("chain", "chain"), ("na", "na"), ("nb", "nb"), ("insert", "insert"), ("a_chr", "a_chr"), ("a_loc", "a_loc"),
+                         ("b_chr", "b_chr"), ("b_loc", "b_loc")):
+            assert np.array_equal(ores["pick"][f][pr], out[gname][pr]), f
+        for m, cnts in (("a", ca), ("b", cb)):
+            ok = ores[m]["filtered"] == 0
+            assert np.array_equal(ores[m]["n_hit"][ok][:, :nclass], cnts["n_hit"][ok][:, :nclass]), m
+            assert np.array_equal(ores[m]["n_chit"][ok][:, :nclass], cnts["n_chit"][ok][:, :nclass]), m
+            sel = up & ok & (ores[m]["n_best"] > 0)
+            for f in ("chr", "loc", "best_class"):
+                assert np.array_equal(ores[m][f][sel], out[m][f][sel]), (m, f)
+        assert [int(x) for x in pa.counters()[:4]] == ocnt
+        assert pr.sum() > 0.2 * len(pairs)
+        pa.close()
+    gref.close()
+    oref.free()
+
+
+def test_empty_and_degenerate_inputs(edge_genome, oracle):
+    """reads shorter than the seed, all-N reads, a read spanning a chromosome end, exact duplicates"""
+    g, fa = edge_genome
+    kw = dict(s=16, v=4, I=4, S=1, r=1, n=1)
+    oref = oracle.OracleRef(oracle.make_params(**kw), fasta_path=fa)
+    gref = B.RefSeq(B.make_params(**kw)).Run_ConvertBinseq(fasta_path=fa).CreateIndex()
+    c0 = g[0][1].upper()
+    tail = c0[-60:].replace("N", "A")
+    seqs = ["ACGT", "A" * 15, "N" * 100, "ACGTN" * 20, tail + "ACGTACGTACGTACGTACGTACGTACGTACGTACGTACGT", c0[5000:5100], c0[5000:5100],
+            td.revcomp(c0[7000:7100]), "T" * 144, "TG" * 72, c0[20000:20016], c0[30000:30200]]
+    al = oracle.OracleAligner(oref, leak_mode=0)
+    sa = B.SingleAlign(gref, len(seqs), debug=True)
+    sa.ImportBatchReads(seqs).Do_Batch()
+    hits, cc = sa.results()
+    for i, s in enumerate(seqs):
+        o = al.se(i, s)
+        _cmp_read(o, hits[i], cc[i], kw, i)
+        if not o.filtered:
+            _cmp_pick(o, hits[i], i)
+    assert hits[5]["n_best"] >= 1 and hits[5]["chr"] == 0 and hits[5]["loc"] == 5000
+    sa.close()
+    al.free()
+    gref.close()
+    oref.free()
