@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py — aligned reads/s of the HIP alignment hot path on BASELINE.json's headline configuration.
+
+Workload (config.workload = "C3"): 2x150 bp (stored as 144 nt, the reference's READ_144 cap) paired-end WGBS reads,
+-s 16 -v 6 -I 4 -m 28 -x 500, against an hg38-sized synthetic genome (24 sequences with hg38's chromosome lengths,
+3.09 Gbp; generator in bsmap_amd/csrc/bsx_synth.hip, because hg38 itself is not on the GPU box).  A step is one
+Do_Batch over --pairs-per-step read pairs that are already resident in HBM; value = reads (2 per pair) of all ranks /
+wall time of the K timed steps (max over ranks).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (one rank per GPU, reads sharded)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HG38 = [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636, 138394717, 133797422,
+        135086622, 133275309, 114364328, 107043718, 101991189, 90338345, 83257441, 80373285, 58617616, 64444167,
+        46709983, 50818468, 156040895, 57227415]
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def algorithmic_bytes(c, n_reads):
+    """8*N_lookup + sum_cand(4 + 8*W_c) + 80*N_orient + 16 per read"""
+    n_lookup, n_cand, sum_w, n_orient = (int(x) for x in c[:4])
+    return 8 * n_lookup + 4 * n_cand + 8 * sum_w + 80 * n_orient + 16 * n_reads
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--pairs-per-step", type=int, default=1 << 20)
+    ap.add_argument("--genome", default="hg38", help="hg38 (3.09 Gbp synthetic, the bench config) or a fraction like 0.05 for quick checks")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--waves-per-cu", type=int, default=0)
+    ap.add_argument("--mode", default="pe", choices=["pe", "se"], help="pe = C3 (default, the metric's config); se = C2 (1x100, -v 4)")
+    args = ap.parse_args()
+
+    import torch  # first: libbsx.so then binds to the HIP runtime torch has already loaded
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.init()
+    import numpy as np
+    import bsmap_amd as B
+
+    if args.waves_per_cu:
+        B.lib().bsx_set_waves_per_cu(args.waves_per_cu)
+    pe = args.mode == "pe"
+    kw = dict(s=16, v=6, I=4, m=28, x=500, S=1, r=1, pairend=1) if pe else dict(s=16, v=4, I=4, S=1, r=1)
+    read_len = 144 if pe else 100
+    lens = HG38 if args.genome == "hg38" else [max(200_000, int(x * float(args.genome))) for x in HG38]
+    t0 = time.time()
+    ref = B.RefSeq(B.make_params(**kw), device=local_rank).synthetic(lens, seed=38)
+    t_gen = time.time() - t0
+    t0 = time.time()
+    ref.CreateIndex()
+    t_index = time.time() - t0
+    B_ = args.pairs_per_step
+    n_total = B_ * (args.steps + args.warmup)
+    batch = (B.PairAlign if pe else B.SingleAlign)(ref, n_total)
+    # reads are sharded by rank: unit ids of rank r start at r * n_total (independent units, no data-path collective)
+    batch.synth_reads(n_total, read_len, seed=3, first_index=rank * n_total)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        batch.run_range(i * B_, B_, sync=True)
+    batch.reset_counters()
+    kernel_ms = []
+    sync_all()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, args.warmup + args.steps):
+        batch.run_range(i * B_, B_, sync=True)
+        kernel_ms.append(batch.kernel_ms())
+    sync_all()
+    dt = time.perf_counter() - t0
+    counters = batch.counters()
+    reads_per_unit = 2 if pe else 1
+    n_reads_rank = args.steps * B_ * reads_per_unit
+    # stats reduction: the only collective of the path (RCCL all-gather of 8 uint64 per rank + the max of the times)
+    stats = torch.tensor([float(dt)] + [float(x) for x in counters], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        gathered = [torch.zeros_like(stats) for _ in range(world)]
+        dist.all_gather(gathered, stats)
+        allstats = torch.stack(gathered).cpu().numpy()
+    else:
+        allstats = stats.cpu().numpy()[None, :]
+    dt_max = float(allstats[:, 0].max())
+    tot_counters = allstats[:, 1:].sum(0)
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    value = n_reads_rank * world / dt_max
+    alg_bytes_launch = algorithmic_bytes(counters, n_reads_rank) / args.steps
+    k_ms = float(np.mean(kernel_ms))
+    achieved = alg_bytes_launch / (k_ms * 1e-3) / 1e9
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    out = {
+        "metric": "aligned reads/sec (whole node), 2x150 bp hg38 WGBS -v 6 -s 16" if pe else "aligned reads/sec (whole node), 1x100 bp hg38 WGBS -v 4 -s 16",
+        "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u32", "data": "synthetic",
+        "config": {"workload": "C3: 2x150(->144) bp PE WGBS vs hg38-sized synthetic genome, -s 16 -v 6 -I 4 -m 28 -x 500" if pe
+                   else "C2: 1x100 bp SE WGBS vs hg38-sized synthetic genome, -s 16 -v 4 -I 4",
+                   "pairs_per_step" if pe else "reads_per_step": B_, "genome_bp": int(sum(lens)), "index_entries": int(ref.n_entries),
+                   "parallelism": f"read-sharded x{world}", "setup_s": {"genome": round(t_gen, 2), "index_build_gpu": round(t_index, 2)},
+                   "aligned_fraction": float((2 * tot_counters[6] + tot_counters[5]) / max(1.0, n_reads_rank * world)) if pe
+                   else float(tot_counters[5] / max(1.0, n_reads_rank * world))},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": traffic, "kernel": "k_align", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes_launch,
+                     "per_read": {"n_lookup": float(counters[0]) / n_reads_rank, "n_cand": float(counters[1]) / n_reads_rank,
+                                  "ref_words64": float(counters[2]) / n_reads_rank}},
+    }
+    if world == 1 and args.cpu_seconds > 0:
+        out["cpu_baseline"] = cpu_baseline(ref, batch, pe, kw, args.cpu_seconds, args.warmup * B_)
+    print(json.dumps(out), flush=True)
+    batch.close()
+    ref.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(ref, batch, pe, kw, target_s, first_unit):
+    """the oracle (plain-C port of the reference algorithm, pthread batch model of main.cpp:49-73) timed on this box's
+    host cores over a bounded sample of the SAME reads against the SAME reference + index (copied back from HBM)"""
+    import numpy as np
+    from oracle import oracle_ffi as O
+    cores = os.cpu_count() or 1
+    f, c = ref.words()
+    a, s, r = ref.info()
+    off, nf, ent = ref.index()
+    oref = O.OracleRef.wrap(O.make_params(**kw), f, c, a, s, r, off, nf, ent)
+    b1, o1 = batch.download_reads(0)
+    L = int(o1[1] - o1[0])
+    if pe:
+        b2, o2 = batch.download_reads(1)
+
+    def run(n):
+        lo = first_unit
+        oa = (o1[lo:lo + n + 1] - o1[lo]).copy()
+        sa = b1[int(o1[lo]):int(o1[lo + n])].copy()
+        t0 = time.perf_counter()
+        if pe:
+            sb = b2[int(o2[lo]):int(o2[lo + n])].copy()
+            ob = (o2[lo:lo + n + 1] - o2[lo]).copy()
+            t0 = time.perf_counter()
+            O.pe_batch(oref, sa, oa, sb, ob, first_index=lo, threads=cores)
+        else:
+            O.se_batch(oref, sa, oa, first_index=lo, threads=cores)
+        return time.perf_counter() - t0
+    n0 = min(20000, len(o1) - 1 - first_unit)
+    t_probe = run(n0)
+    n = int(min(len(o1) - 1 - first_unit, max(n0, n0 * target_s / max(t_probe, 1e-3))))
+    t = run(n)
+    reads = n * (2 if pe else 1)
+    return {"value": reads / t, "unit": "reads/s", "cores": cores, "kind": "port",
+            "sample": f"{n} {'pairs' if pe else 'reads'} of the timed workload ({L} nt), oracle/bsx_oracle.c with {cores} pthreads, {t:.1f} s"}
+
+
+if __name__ == "__main__":
+    main()

@@ -59,13 +59,13 @@ def build(force=False):
 
 EXPORTS = [
     "bsx_strerror", "bsx_last_error_detail", "bsx_params_default", "bsx_params_set_digest", "bsx_params_finish",
-    "bsx_device_count", "bsx_ref_create_from_fasta", "bsx_ref_create_from_file", "bsx_ref_create_synthetic", "bsx_ref_destroy",
+    "bsx_device_count", "bsx_ref_create_from_fasta", "bsx_ref_create_from_file", "bsx_ref_create_synthetic", "bsx_synth_chr_text", "bsx_ref_destroy",
     "bsx_ref_n_chr", "bsx_ref_n_words", "bsx_ref_n_blocks", "bsx_ref_info", "bsx_ref_chr_name", "bsx_ref_blocks",
     "bsx_ref_download_words", "bsx_index_build", "bsx_index_n_entries", "bsx_index_download", "bsx_ref_n_sites", "bsx_ref_sites",
     "bsx_batch_create", "bsx_batch_destroy", "bsx_batch_upload_se", "bsx_batch_upload_pe", "bsx_batch_synth_reads",
-    "bsx_batch_run", "bsx_batch_sync", "bsx_batch_kernel_ms", "bsx_batch_results_se", "bsx_batch_results_pe",
-    "bsx_batch_counters", "bsx_batch_reset_counters", "bsx_batch_download_reads", "bsx_batch_set_debug",
-    "bsx_batch_debug_hits", "bsx_batch_debug_pairs", "bsx_batch_debug_plan", "bsx_set_waves_per_cu",
+    "bsx_batch_run", "bsx_batch_run_range", "bsx_batch_sync", "bsx_batch_kernel_ms", "bsx_batch_results_se", "bsx_batch_results_pe",
+    "bsx_batch_counters", "bsx_batch_reset_counters", "bsx_batch_download_reads", "bsx_batch_set_debug", "bsx_batch_unit_cycles",
+    "bsx_batch_debug_hits", "bsx_batch_debug_pairs", "bsx_batch_debug_plan", "bsx_set_waves_per_cu", "bsx_set_heavy_threshold", "bsx_batch_last_heavy_units",
 ]
 
 
@@ -86,6 +86,7 @@ def lib():
         L.bsx_ref_create_from_file.argtypes = [C.POINTER(Params), C.c_char_p, i32, C.POINTER(vp)]
         L.bsx_ref_create_synthetic.argtypes = [C.POINTER(Params), u32, vp, u64, i32, C.POINTER(vp)]
         L.bsx_ref_destroy.argtypes = [vp]
+        L.bsx_synth_chr_text.argtypes = [vp, u32, u32, u32, vp]
         L.bsx_ref_n_chr.argtypes = [vp]
         L.bsx_ref_n_chr.restype = u32
         L.bsx_ref_n_words.argtypes = [vp]
@@ -110,6 +111,7 @@ def lib():
         L.bsx_batch_upload_pe.argtypes = [vp, u32, vp, vp, vp, vp, vp, vp, u32]
         L.bsx_batch_synth_reads.argtypes = [vp, u32, u32, u64, u32]
         L.bsx_batch_run.argtypes = [vp]
+        L.bsx_batch_run_range.argtypes = [vp, u32, u32]
         L.bsx_batch_sync.argtypes = [vp]
         L.bsx_batch_kernel_ms.argtypes = [vp]
         L.bsx_batch_kernel_ms.restype = C.c_float
@@ -119,10 +121,13 @@ def lib():
         L.bsx_batch_reset_counters.argtypes = [vp]
         L.bsx_batch_download_reads.argtypes = [vp, i32, vp, vp]
         L.bsx_batch_set_debug.argtypes = [vp, i32]
+        L.bsx_batch_unit_cycles.argtypes = [vp, vp]
         L.bsx_batch_debug_hits.argtypes = [vp, u32, i32, i32, i32, vp, u32]
         L.bsx_batch_debug_pairs.argtypes = [vp, u32, i32, vp, u32]
         L.bsx_batch_debug_plan.argtypes = [vp, u32, i32, vp, vp]
         L.bsx_set_waves_per_cu.argtypes = [i32]
+        L.bsx_set_heavy_threshold.argtypes = [i32]
+        L.bsx_batch_last_heavy_units.argtypes = [vp]
         _lib = L
     return _lib
 
@@ -182,6 +187,13 @@ class RefSeq:
         lens = np.asarray(chr_lens, dtype=np.uint32)
         _check(lib().bsx_ref_create_synthetic(C.byref(self.params), len(lens), lens.ctypes.data, seed, self.device, C.byref(self.h)))
         return self
+
+    def synth_text(self, c, start=0, n=None):
+        a, sz, _ = self.info()
+        n = int(sz[c]) - start if n is None else n
+        buf = C.create_string_buffer(n)
+        _check(lib().bsx_synth_chr_text(self.h, c, start, n, buf))
+        return buf.raw.decode()
 
     def CreateIndex(self):
         _check(lib().bsx_index_build(self.h))
@@ -261,6 +273,11 @@ class _Batch:
             _check(lib().bsx_batch_sync(self.h))
         return self
 
+    def run_range(self, first, n, sync=False):
+        _check(lib().bsx_batch_run_range(self.h, first, n))
+        if sync:
+            _check(lib().bsx_batch_sync(self.h))
+
     def sync(self): _check(lib().bsx_batch_sync(self.h))
     def kernel_ms(self): return float(lib().bsx_batch_kernel_ms(self.h))
 
@@ -270,6 +287,15 @@ class _Batch:
         return c
 
     def reset_counters(self): _check(lib().bsx_batch_reset_counters(self.h))
+
+    def heavy_units(self): return _check(lib().bsx_batch_last_heavy_units(self.h))
+
+    def set_debug(self, mode): _check(lib().bsx_batch_set_debug(self.h, mode))
+
+    def unit_cycles(self):
+        c = np.zeros(self.n, np.uint32)
+        _check(lib().bsx_batch_unit_cycles(self.h, c.ctypes.data))
+        return c
 
     def synth_reads(self, n, read_len, seed, first_index=0):
         _check(lib().bsx_batch_synth_reads(self.h, n, read_len, seed, first_index))

@@ -80,7 +80,9 @@ struct Mate {
     uint32_t nkeys;
     uint32_t cnt_reg;    // lane (orient*16+w) holds _cur_n_hit / _cur_n_chit
     uint32_t key_reg;    // lane i holds the i-th accepted forward coordinate (hitset, first 64)
+    uint32_t bloom0, bloom1;  // 4096-bit membership filter over all accepted coordinates (bit b of lane l)
     uint32_t index;      // ReadInf.index
+    int defer;           // main kernel: a candidate list exceeded heavy_threshold, redo this unit in the heavy kernel
 };
 
 struct Slab {
@@ -189,6 +191,8 @@ __device__ void load_and_filter(const AlignArgs &A, MateLds &L, Mate &M, int mat
     M.nkeys = 0;
     M.cnt_reg = 0;
     M.key_reg = 0;
+    M.bloom0 = M.bloom1 = 0;
+    M.defer = 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -316,17 +320,35 @@ __device__ __forceinline__ uint32_t chr_of(const DevParams &P, const BlockLds &B
     return (uint32_t)left;
 }
 
-// duplicate test against every hit accepted so far for this read (hitset, align.cpp:274)
+// duplicate test against every hit accepted so far for this read (hitset, align.cpp:274).  A 4096-bit filter held in
+// two VGPRs answers "certainly new" without touching memory; only on a filter hit are the exact keys compared
+// (first 64 in a register, the rest in the wave's HBM slab, 256 per round trip).
+__device__ __forceinline__ uint32_t bloom_slot(uint32_t key) { return (key * 0x9E3779B1u) >> 20; }  // 12 bits
+
 __device__ __forceinline__ bool seen_before(const Mate &M, const Slab &SL, uint32_t key, int lane)
 {
+    const uint32_t slot = bloom_slot(key);
+    const uint32_t word = (slot & 2048) ? rl(M.bloom1, (slot >> 5) & 63) : rl(M.bloom0, (slot >> 5) & 63);
+    if (!((word >> (slot & 31)) & 1)) return false;
     u64 dup = __ballot((uint32_t)lane < M.nkeys && M.key_reg == key);
-    if (M.nkeys > 64) {
-        for (uint32_t base = 64; base < M.nkeys && !dup; base += 64) {
-            const uint32_t i = base + lane;
-            dup = __ballot(i < M.nkeys && SL.keys[i] == key);
+    if (M.nkeys > 64 && !dup) {
+        for (uint32_t base = 64; base < M.nkeys && !dup; base += 256) {
+            const uint32_t i0 = base + lane, i1 = i0 + 64, i2 = i0 + 128, i3 = i0 + 192;
+            const uint32_t k0 = i0 < M.nkeys ? SL.keys[i0] : ~key, k1 = i1 < M.nkeys ? SL.keys[i1] : ~key,
+                           k2 = i2 < M.nkeys ? SL.keys[i2] : ~key, k3 = i3 < M.nkeys ? SL.keys[i3] : ~key;
+            dup = __ballot(k0 == key || k1 == key || k2 == key || k3 == key);
         }
     }
     return dup != 0;
+}
+
+__device__ __forceinline__ void remember_key(Mate &M, const Slab &SL, uint32_t key, int lane)
+{
+    if (M.nkeys < 64) { if ((uint32_t)lane == M.nkeys) M.key_reg = key; }
+    else if (lane == 0) SL.keys[M.nkeys] = key;
+    M.nkeys++;
+    const uint32_t slot = bloom_slot(key);
+    if ((uint32_t)lane == ((slot >> 5) & 63)) { if (slot & 2048) M.bloom1 |= 1u << (slot & 31); else M.bloom0 |= 1u << (slot & 31); }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -399,8 +421,120 @@ __device__ __forceinline__ CandEval eval_candidate(const DevParams &P, const uin
     return r;
 }
 
+// ---- cooperative scan of very large candidate lists (heavy kernel only) ---------------------------------------
+// A bucket of a low-complexity seed can hold millions of entries.  In the heavy kernel one workgroup of 16 waves owns
+// a unit: wave 0 runs the unit's control flow, and for big lists all 16 waves evaluate a window of 4096 candidates
+// at a time into an ordered survivor buffer that wave 0 then replays.  Any event that changes the threshold (or ends
+// the call) restarts the window right after the candidate that caused it, so every candidate is evaluated under
+// exactly the threshold the reference would have used — results and work counters stay bit-identical.
+#define COOP_WAVES 8
+#define COOP_CHUNKS 4
+#define COOP_WIN (COOP_WAVES * COOP_CHUNKS * 64)
+#define COOP_MIN 1024u  // lists at least this long are scanned cooperatively
+
+struct SurvRec { uint32_t w_ord, hchr, hloc, hkey; };  // w in bits 0-7, ordinal inside the window in bits 8+
+
+struct CoopLds {
+    uint32_t cmd;  // 0 scan window, 1 exit
+    uint32_t rw[9], rm[9];
+    int32_t nwords, len;
+    uint32_t thres, nsub, total, win_c0;
+    uint32_t sub_pre[32], sub_n[32], sub_base[32], sub_h[32];
+    uint32_t cnt[COOP_WAVES];
+    uint32_t acc[COOP_WAVES][4];
+    uint8_t wcls[COOP_WIN];
+};
+
+// hit coordinates of a WGBS candidate at global nt p of strand copy `strand`; false if it runs off the chromosome
+__device__ __forceinline__ bool hit_coords(const DevParams &P, const BlockLds &BL, uint32_t p, uint32_t strand, int len, uint32_t &hchr,
+                                           uint32_t &hloc, uint32_t &hkey)
+{
+    const bool lds_chr = P.n_chr <= BSX_LDS_CHR;
+    const uint32_t c = chr_of(P, BL, p);
+    const uint32_t an = lds_chr ? BL.anchor[c] : P.anchor[c], sz = lds_chr ? BL.chr_size[c] : P.chr_size[c];
+    uint32_t loc = p - an;
+    if (strand) loc = (lds_chr ? BL.rc_offset[c] : P.rc_offset[c]) - (uint32_t)len - loc;  // align.cpp:289
+    hchr = 2 * c + strand; hloc = loc; hkey = an + loc;
+    return !((u64)loc + (u64)len > (u64)sz);  // overflow the end of refseq (align.cpp:273)
+}
+
+__device__ void coop_scan_share(const DevParams &P, const BlockLds &BL, CoopLds &CL, SurvRec *surv, int wv, int lane)
+{
+    uint32_t rw[9], rm[9];
+#pragma unroll
+    for (int t = 0; t < 9; t++) { rw[t] = rfl(CL.rw[t]); rm[t] = rfl(CL.rm[t]); }
+    const uint32_t thres0 = CL.thres, total = CL.total, nsub = CL.nsub;
+    const int nwords = CL.nwords, len = CL.len;
+    const uint32_t w0 = CL.win_c0 + (uint32_t)wv * (COOP_CHUNKS * 64);
+    uint32_t idx[COOP_CHUNKS], e_idx[COOP_CHUNKS], hh[COOP_CHUNKS], strand[COOP_CHUNKS], p[COOP_CHUNKS];
+    bool valid[COOP_CHUNKS];
+#pragma unroll
+    for (int u = 0; u < COOP_CHUNKS; u++) {
+        idx[u] = w0 + u * 64 + lane;
+        valid[u] = idx[u] < total;
+        e_idx[u] = 0; hh[u] = 0; strand[u] = 0;
+        for (uint32_t sidx = 0; sidx < nsub; sidx++) {
+            const uint32_t ps = CL.sub_pre[sidx], ns = CL.sub_n[sidx];
+            if (idx[u] >= ps && idx[u] < ps + ns) { e_idx[u] = CL.sub_base[sidx] + (idx[u] - ps); hh[u] = CL.sub_h[sidx]; strand[u] = sidx & 1; }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < COOP_CHUNKS; u++) p[u] = valid[u] ? P.entries[e_idx[u]] + hh[u] : 0;
+    uint32_t nsurv = 0, a0 = 0, a1 = 0, a2 = 0, a5 = 0;
+#pragma unroll
+    for (int u = 0; u < COOP_CHUNKS; u++) {
+        CandEval ev = {0xffff, 0, 0, 0};
+        if (valid[u]) ev = eval_candidate(P, rw, rm, nwords, p[u], strand[u], thres0);
+        bool pass = valid[u] && ev.w <= thres0;
+        uint32_t hchr = 0, hloc = 0, hkey = 0;
+        if (pass) pass = hit_coords(P, BL, p[u], strand[u], len, hchr, hloc, hkey);
+        const u64 m = __ballot(pass);
+        if (pass) {
+            SurvRec r; r.w_ord = ev.w | ((idx[u] - CL.win_c0) << 8); r.hchr = hchr; r.hloc = hloc; r.hkey = hkey;
+            surv[(size_t)wv * (COOP_CHUNKS * 64) + nsurv + (uint32_t)__builtin_popcountll(m & lanemask_lt(lane))] = r;
+        }
+        nsurv += (uint32_t)__builtin_popcountll(m);
+        const bool one = valid[u] && ev.w0ref > thres0;
+        const bool two = valid[u] && !one && (ev.p48 > thres0 || ev.w01ref > thres0);
+        const bool five = valid[u] && !one && !two;
+        if (idx[u] - CL.win_c0 < COOP_WIN) CL.wcls[idx[u] - CL.win_c0] = one ? 1 : two ? 2 : five ? 5 : 0;
+        a0 += (uint32_t)__builtin_popcountll(__ballot(valid[u])); a1 += (uint32_t)__builtin_popcountll(__ballot(one));
+        a2 += (uint32_t)__builtin_popcountll(__ballot(two)); a5 += (uint32_t)__builtin_popcountll(__ballot(five));
+    }
+    if (lane == 0) { CL.cnt[wv] = nsurv; CL.acc[wv][0] = a0; CL.acc[wv][1] = a1; CL.acc[wv][2] = a2; CL.acc[wv][3] = a5; }
+}
+
+// One accepted-candidate step of the reference's inner loops (align.cpp:274-278 and the RRBS twin :201-212):
+// hitset.insert, optional fragment filter, append, -r 0 early return, -w cap.  Returns 0 nothing happened /
+// 1 threshold lowered / 2 SnpAlign returns.
+__device__ __forceinline__ int accept_survivor(const DevParams &P, Mate &M, const Slab &SL, int orient, int mode, uint32_t ws, uint32_t hchr,
+                                               uint32_t hloc, uint32_t hkey, int lane)
+{
+    if (ws > M.snp_thres) return 0;
+    if (seen_before(M, SL, hkey, lane)) return 0;
+    remember_key(M, SL, hkey, lane);  // hitset.insert
+    if (P.rrbs && !P.pairend && orient == 0) {  // fragment size filter, forward chain only (align.cpp:202-207)
+        const int sl = ccgg_seglen(P, hchr, hloc, M.len);
+        if (sl > P.max_insert || sl < P.min_insert) return 0;
+    }
+    const uint32_t n = n_of(M, orient, (int)ws);
+    if (lane == 0) SL.list(orient, (int)ws)[n] = ((u64)hchr << 32) | hloc;  // hits[w][n++] = hit
+    if (lane == orient * 16 + (int)ws) M.cnt_reg++;
+    const uint32_t both = n_of(M, 0, (int)ws) + n_of(M, 1, (int)ws);
+    if ((int)ws == mode && !P.pairend && P.report_repeat_hits == 0 && both > 1) return 2;
+    if (both >= (uint32_t)P.max_num_hits) {
+        if (ws == 0) return 2;
+        M.snp_thres = ws - 1;
+        return 1;
+    }
+    return 0;
+}
+
+// SnpAlign.  COOP = running as wave 0 of the heavy kernel (CL/surv valid).  In the main kernel a WGBS list longer than
+// heavy_threshold sets M.defer and returns: the unit is redone from scratch by the heavy kernel.
+template <bool COOP>
 __device__ void snp_align(const DevParams &P, const BlockLds &BL, const MateLds &L, Mate &M, const Slab &SL, int mode, int lane,
-                          Counters &C)
+                          Counters &C, uint32_t heavy_threshold, CoopLds *CL, SurvRec *surv)
 {
     const int I = P.index_interval;
     const int nwords = (M.len + 15) >> 4;
@@ -408,10 +542,6 @@ __device__ void snp_align(const DevParams &P, const BlockLds &BL, const MateLds 
     for (int orient = 0; orient < 2; orient++) {
         if (!((M.flags >> orient) & 1)) continue;
         const int seg = L.order[orient][mode];  // modeindex
-        // read words + masks into scalar registers
-        uint32_t rw[9], rm[9];
-#pragma unroll
-        for (int t = 0; t < 9; t++) { rw[t] = rfl(L.w[orient][t]); rm[t] = rfl(L.m[orient][t]); }
         // The candidate list of this call: WGBS = (phase x strand) sub-ranges of the index, sub-range s = 2*phase+strand
         // described by lane s; RRBS = one bucket of {tag,loc} pairs (align.cpp:175-252).
         uint32_t sub_base = 0, sub_n = 0, sub_h = 0;
@@ -439,6 +569,62 @@ __device__ void snp_align(const DevParams &P, const BlockLds &BL, const MateLds 
         for (int o = 1; o < 32; o <<= 1) { uint32_t t = __shfl_up(sub_pre, o); if (lane >= o) sub_pre += t; }
         const uint32_t total = rl(sub_pre, nsub - 1);
         sub_pre -= sub_n;
+        if (!COOP && !P.rrbs && heavy_threshold && total >= heavy_threshold) { M.defer = 1; return; }
+        if (COOP && !P.rrbs && total >= COOP_MIN) {
+            // ---- cooperative windows ----
+            if (lane < 32) { CL->sub_pre[lane] = sub_pre; CL->sub_n[lane] = sub_n; CL->sub_base[lane] = sub_base; CL->sub_h[lane] = sub_h; }
+            if (lane < 9) { CL->rw[lane] = L.w[orient][lane]; CL->rm[lane] = L.m[orient][lane]; }
+            if (lane == 0) { CL->nwords = nwords; CL->len = M.len; CL->nsub = (uint32_t)nsub; CL->total = total; }
+            uint32_t c = 0;
+            bool stop = false;
+            while (c < total && !stop) {
+                if (lane == 0) { CL->cmd = 0; CL->thres = M.snp_thres; CL->win_c0 = c; }
+                __syncthreads();
+                coop_scan_share(P, BL, *CL, surv, 0, lane);
+                __syncthreads();
+                const uint32_t win_n = min((uint32_t)COOP_WIN, total - c);
+                int event = 0; uint32_t X = 0;
+                for (int v = 0; v < COOP_WAVES && !event; v++) {
+                    const uint32_t nv = CL->cnt[v];
+                    for (uint32_t base = 0; base < nv && !event; base += 64) {
+                        const uint32_t i = base + lane;
+                        SurvRec r = {0, 0, 0, 0};
+                        if (i < nv) r = surv[(size_t)v * (COOP_CHUNKS * 64) + i];
+                        u64 m = __ballot(i < nv);
+                        while (m) {
+                            const int ls = (int)__builtin_ctzll(m);
+                            m &= m - 1;
+                            const uint32_t wo = rl(r.w_ord, ls);
+                            const int e = accept_survivor(P, M, SL, orient, mode, wo & 0xff, rl(r.hchr, ls), rl(r.hloc, ls), rl(r.hkey, ls), lane);
+                            if (e) { event = e; X = wo >> 8; break; }
+                        }
+                    }
+                }
+                if (!event) {
+                    const uint32_t v = lane < COOP_WAVES ? lane : 0;
+                    const bool on = lane < COOP_WAVES;
+                    C.n_cand += wave_sum(on ? CL->acc[v][0] : 0);
+                    C.sum_w += wave_sum(on ? CL->acc[v][1] + 2 * CL->acc[v][2] + 5 * CL->acc[v][3] : 0);
+                    c += win_n;
+                } else {  // count exactly the candidates up to and including the one that caused the event
+                    uint32_t nc = 0, sw = 0;
+                    for (uint32_t base = 0; base <= X; base += 64) {
+                        const uint32_t i = base + lane;
+                        const uint32_t cls = i <= X ? CL->wcls[i] : 0;
+                        nc += cls != 0; sw += cls;
+                    }
+                    C.n_cand += wave_sum(nc); C.sum_w += wave_sum(sw);
+                    if (event == 2) stop = true;
+                    c += X + 1;
+                }
+            }
+            if (stop) { wave_fence(); return; }
+            continue;
+        }
+        // ---- one wave, 64 candidates at a time ----
+        uint32_t rw[9], rm[9];  // read words + masks in scalar registers
+#pragma unroll
+        for (int t = 0; t < 9; t++) { rw[t] = rfl(L.w[orient][t]); rm[t] = rfl(L.m[orient][t]); }
         const int cmode = M.len / P.seed_size - 1 - seg;  // cmodeindex (align.cpp:221)
         for (uint32_t c0 = 0; c0 < total; c0 += 64) {
             const uint32_t idx = c0 + lane;
@@ -470,44 +656,25 @@ __device__ void snp_align(const DevParams &P, const BlockLds &BL, const MateLds 
             bool pass = valid && w <= thres0;
             uint32_t hchr = 0, hloc = 0, hkey = 0;
             if (pass) {
-                const uint32_t c = P.rrbs ? (rchr >> 1) : chr_of(P, BL, p);
-                const uint32_t an = lds_chr ? BL.anchor[c] : P.anchor[c], sz = lds_chr ? BL.chr_size[c] : P.chr_size[c];
-                uint32_t loc = p - an;
-                if (strand) loc = (lds_chr ? BL.rc_offset[c] : P.rc_offset[c]) - (uint32_t)M.len - loc;  // align.cpp:289
-                hchr = 2 * c + strand; hloc = loc; hkey = an + loc;
-                if ((u64)loc + (u64)M.len > (u64)sz) pass = false;  // overflow the end of refseq (align.cpp:273)
+                if (P.rrbs) {
+                    const uint32_t c = rchr >> 1;
+                    const uint32_t an = lds_chr ? BL.anchor[c] : P.anchor[c], sz = lds_chr ? BL.chr_size[c] : P.chr_size[c];
+                    uint32_t loc = p - an;
+                    if (strand) loc = (lds_chr ? BL.rc_offset[c] : P.rc_offset[c]) - (uint32_t)M.len - loc;
+                    hchr = 2 * c + strand; hloc = loc; hkey = an + loc;
+                    if ((u64)loc + (u64)M.len > (u64)sz) pass = false;
+                } else pass = hit_coords(P, BL, p, strand, M.len, hchr, hloc, hkey);
             }
-            // ordered replay of the survivors (align.cpp:274-278)
+            // ordered replay of the survivors
             uint32_t thr_eff = thres0;
             bool alive = valid, stop = false;
-            u64 surv = __ballot(pass);
-            while (surv) {
-                const int ls = (int)__builtin_ctzll(surv);
-                surv &= surv - 1;
-                const uint32_t ws = rl(w, ls);
-                if (ws > M.snp_thres) continue;
-                const uint32_t ks = rl(hkey, ls);
-                if (seen_before(M, SL, ks, lane)) continue;
-                // hitset.insert
-                if (M.nkeys < 64) { if ((uint32_t)lane == M.nkeys) M.key_reg = ks; }
-                else if (lane == 0) SL.keys[M.nkeys] = ks;
-                M.nkeys++;
-                if (P.rrbs && !P.pairend && orient == 0) {  // fragment size filter, forward chain only (align.cpp:202-207)
-                    const int sl = ccgg_seglen(P, rl(hchr, ls), rl(hloc, ls), M.len);
-                    if (sl > P.max_insert || sl < P.min_insert) continue;
-                }
-                // hits[w][n++] = hit
-                const uint32_t n = n_of(M, orient, (int)ws);
-                if (lane == ls) SL.list(orient, (int)ws)[n] = ((u64)hchr << 32) | hloc;
-                if (lane == orient * 16 + (int)ws) M.cnt_reg++;
-                const uint32_t both = n_of(M, 0, (int)ws) + n_of(M, 1, (int)ws);
-                bool ret = false;
-                if ((int)ws == mode && !P.pairend && P.report_repeat_hits == 0 && both > 1) ret = true;
-                else if (both >= (uint32_t)P.max_num_hits) {
-                    if (ws == 0) ret = true;
-                    else { M.snp_thres = ws - 1; if (lane > ls) thr_eff = M.snp_thres; }
-                }
-                if (ret) { if (lane > ls) alive = false; stop = true; break; }
+            u64 surv_m = __ballot(pass);
+            while (surv_m) {
+                const int ls = (int)__builtin_ctzll(surv_m);
+                surv_m &= surv_m - 1;
+                const int e = accept_survivor(P, M, SL, orient, mode, rl(w, ls), rl(hchr, ls), rl(hloc, ls), rl(hkey, ls), lane);
+                if (e == 1) { if (lane > ls) thr_eff = M.snp_thres; }
+                else if (e == 2) { if (lane > ls) alive = false; stop = true; break; }
             }
             // work accounting exactly as the reference's CountMismatch early-outs (align.h:189-197)
             {
@@ -524,10 +691,13 @@ __device__ void snp_align(const DevParams &P, const BlockLds &BL, const MateLds 
 }
 
 // SingleAlign::RunAlign (align.cpp:435-452) after packing/planning
-__device__ void run_align_single(const DevParams &P, const BlockLds &BL, const MateLds &L, Mate &M, const Slab &SL, int lane, Counters &C)
+template <bool COOP>
+__device__ void run_align_single(const DevParams &P, const BlockLds &BL, const MateLds &L, Mate &M, const Slab &SL, int lane, Counters &C,
+                                 uint32_t heavy_threshold, CoopLds *CL, SurvRec *surv)
 {
     for (int i = 0; i < M.seedseg; i++) {
-        snp_align(P, BL, L, M, SL, i, lane, C);
+        snp_align<COOP>(P, BL, L, M, SL, i, lane, C, heavy_threshold, CL, surv);
+        if (M.defer) return;
         if (!P.rrbs) {
             const u64 nz = __ballot(M.cnt_reg != 0 && (lane & 15) <= i && lane < 32);
             if (nz) return;
@@ -680,141 +850,221 @@ __device__ int get_pairs(const DevParams &P, const Mate &MA, const Mate &MB, con
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// the kernel
+// one unit (read or read pair) from load to result record; returns true if the unit was deferred to the heavy kernel
 // ---------------------------------------------------------------------------------------------------------------
+template <bool PE, bool COOP>
+__device__ bool process_unit(const AlignArgs &A, const BlockLds &BL, MateLds &LA, MateLds &LB, uint32_t unit, uint8_t *slab, int lane,
+                             Counters &C, u64 &n_aligned, u64 &n_aligned_pairs, CoopLds *CL, SurvRec *surv)
+{
+    const DevParams &P = A.P;
+    const uint32_t nclass = (uint32_t)P.max_snp_num + 1, rowcap = A.rowcap;
+    const uint32_t hthr = COOP ? 0u : A.heavy_threshold;
+    const Counters C0 = C;
+    Slab SA, SB;
+    SA.rowcap = SB.rowcap = rowcap; SA.nclass = SB.nclass = nclass;
+    SA.hits = (u64 *)slab;
+    SA.keys = (uint32_t *)(SA.hits + (size_t)2 * (nclass + 1) * rowcap);
+    SA.tmp = (u64 *)(SA.keys + (size_t)(nclass + 1) * rowcap);
+    uint8_t *after_a = (uint8_t *)(SA.tmp + BSX_SORT_TMP);
+    SB = SA;
+    PairSlab PS{nullptr, rowcap};
+    if (PE) {
+        SB.hits = (u64 *)after_a;
+        SB.keys = (uint32_t *)(SB.hits + (size_t)2 * (nclass + 1) * rowcap);
+        SB.tmp = (u64 *)(SB.keys + (size_t)(nclass + 1) * rowcap);
+        PS.rows = (uint32_t *)(SB.tmp + BSX_SORT_TMP);
+    }
+    Mate MA, MB;
+    MA.index = MB.index = A.first_index + unit;
+    load_and_filter(A, LA, MA, 0, unit, lane);
+    if (PE) load_and_filter(A, LB, MB, 1, unit, lane);
+    if (!PE) {
+        if (!MA.filtered) {
+            pack_read(P, LA, MA, 0, lane, C);
+            for (int o = 0; o < 2; o++) if ((MA.flags >> o) & 1) plan_orient(P, BL, LA, MA, o, lane, C);
+            run_align_single<COOP>(P, BL, LA, MA, SA, lane, C, hthr, CL, surv);
+            if (MA.defer) { C = C0; return true; }
+        }
+        bsx_hit out;
+        select_hit(P, MA, SA, out, false);
+        if (lane == 0) A.hits_out[unit] = out;
+        if (A.cc[0] && lane < 32) { uint16_t *cc = (uint16_t *)&A.cc[0][unit]; cc[lane] = (uint16_t)MA.cnt_reg; }
+        if (A.debug && lane < 32) { A.dbg_plan[(size_t)unit * 128 + lane] = LA.start[lane >> 4][lane & 15]; A.dbg_plan[(size_t)unit * 128 + 32 + lane] = LA.order[lane >> 4][lane & 15]; }
+        if (out.n_best == 1 || (out.n_best > 1 && P.report_repeat_hits == 1)) n_aligned++;
+        return false;
+    }
+    uint32_t pcnt_reg = 0;  // lane c holds _cur_n_hits[c]
+    int paired = 0;
+    if (!MA.filtered) { pack_read(P, LA, MA, 1, lane, C); }
+    if (!MB.filtered) { pack_read(P, LB, MB, 2, lane, C); }
+    // ReorderSeed for both mates (pairs.cpp:160) — also when only one mate survives (SingleAlign::RunAlign)
+    if (!MA.filtered) for (int o = 0; o < 2; o++) if ((MA.flags >> o) & 1) plan_orient(P, BL, LA, MA, o, lane, C);
+    if (!MB.filtered) for (int o = 0; o < 2; o++) if ((MB.flags >> o) & 1) plan_orient(P, BL, LB, MB, o, lane, C);
+    if (!MA.filtered && !MB.filtered) {
+        // PairAlign::RunAlign (pairs.cpp:163-172)
+        const int maxi = max(MA.max_snp, MB.max_snp);
+        for (int i = 0; i <= maxi && !paired; i++) {
+            if (i < MA.seedseg) snp_align<COOP>(P, BL, LA, MA, SA, i, lane, C, hthr, CL, surv);
+            if (MA.defer) { C = C0; return true; }
+            if (i < MB.seedseg) snp_align<COOP>(P, BL, LB, MB, SB, i, lane, C, hthr, CL, surv);
+            if (MB.defer) { C = C0; return true; }
+            if (i <= MA.max_snp) { sort_list(SA.list(0, i), n_of(MA, 0, i), SA.tmp, lane); sort_list(SA.list(1, i), n_of(MA, 1, i), SA.tmp, lane); }
+            if (i <= MB.max_snp) { sort_list(SB.list(0, i), n_of(MB, 0, i), SB.tmp, lane); sort_list(SB.list(1, i), n_of(MB, 1, i), SB.tmp, lane); }
+            int n = get_pairs(P, MA, MB, SA, SB, PS, pcnt_reg, i, i, lane);
+            for (int j = 0; j < i; j++) n += get_pairs(P, MA, MB, SA, SB, PS, pcnt_reg, i, j, lane) + get_pairs(P, MA, MB, SA, SB, PS, pcnt_reg, j, i, lane);
+            if (n > 0) paired = i + 1;
+        }
+    } else {
+        if (!MA.filtered) { run_align_single<COOP>(P, BL, LA, MA, SA, lane, C, hthr, CL, surv); if (MA.defer) { C = C0; return true; } }
+        if (!MB.filtered) { run_align_single<COOP>(P, BL, LB, MB, SB, lane, C, hthr, CL, surv); if (MB.defer) { C = C0; return true; } }
+    }
+    bsx_pair out;
+    out.a_chr = out.a_loc = out.b_chr = out.b_loc = 0; out.insert = 0; out.n_pairs = 0; out.pair_class = -1; out.chain = 0;
+    out.na = out.nb = 0; out.paired = (uint8_t)paired; out.unpaired_out = 1; out.pad_ = 0;
+    if (paired) {  // StringAlignPair (pairs.cpp:222-242)
+        for (int c = 0; c <= 2 * P.max_snp_num; c++) {
+            const uint32_t n = rl(pcnt_reg, c);
+            if (!n) continue;
+            out.pair_class = (int8_t)c; out.n_pairs = (uint16_t)n;
+            int j = -1;
+            if (n == 1) j = 0;
+            else if (P.report_repeat_hits == 1) j = (int)(bsx_myrand(MA.index, P.randseed) % n);
+            if (j >= 0) {
+                const uint32_t *o = PS.row(c) + (size_t)j * 6;
+                out.chain = (uint8_t)(o[0] & 0xffff); out.na = (uint8_t)((o[0] >> 16) & 0xff); out.nb = (uint8_t)(o[0] >> 24);
+                out.insert = (int32_t)o[1]; out.a_chr = o[2]; out.a_loc = o[3]; out.b_chr = o[4]; out.b_loc = o[5];
+                out.unpaired_out = 0;
+            }
+            break;
+        }
+    }
+    if (P.rrbs && out.unpaired_out) { fix_unpaired_short_fragment(P, MA, SA, lane); fix_unpaired_short_fragment(P, MB, SB, lane); }  // pairs.cpp:250-253
+    select_hit(P, MA, SA, out.a, true);
+    select_hit(P, MB, SB, out.b, true);
+    if (lane == 0) A.pairs_out[unit] = out;
+    if (A.cc[0] && lane < 32) { ((uint16_t *)&A.cc[0][unit])[lane] = (uint16_t)MA.cnt_reg; ((uint16_t *)&A.cc[1][unit])[lane] = (uint16_t)MB.cnt_reg; }
+    if (A.npairs_out && lane < 32) A.npairs_out[(size_t)unit * 32 + lane] = (uint16_t)pcnt_reg;
+    if (A.debug && lane < 32) {
+        A.dbg_plan[(size_t)unit * 128 + lane] = LA.start[lane >> 4][lane & 15]; A.dbg_plan[(size_t)unit * 128 + 32 + lane] = LA.order[lane >> 4][lane & 15];
+        A.dbg_plan[(size_t)unit * 128 + 64 + lane] = LB.start[lane >> 4][lane & 15]; A.dbg_plan[(size_t)unit * 128 + 96 + lane] = LB.order[lane >> 4][lane & 15];
+    }
+    if (!out.unpaired_out) n_aligned_pairs++;
+    else {
+        if (out.a.n_best == 1 || (out.a.n_best > 1 && P.report_repeat_hits == 1)) n_aligned++;
+        if (out.b.n_best == 1 || (out.b.n_best > 1 && P.report_repeat_hits == 1)) n_aligned++;
+    }
+    return false;
+}
+
+__device__ void init_block_lds(const DevParams &P, BlockLds &BL, int tid, int nthreads)
+{
+    for (int i = tid; i < 256; i += nthreads) ((uint8_t *)BL.prof)[i] = ((const uint8_t *)P.profile_a)[i];
+    if (P.n_chr <= BSX_LDS_CHR) {
+        for (uint32_t i = tid; i <= P.n_chr; i += nthreads) BL.anchor[i] = P.anchor[i];
+        for (uint32_t i = tid; i < P.n_chr; i += nthreads) { BL.chr_size[i] = P.chr_size[i]; BL.rc_offset[i] = P.rc_offset[i]; }
+    }
+}
+
+__device__ void flush_counters(const AlignArgs &A, const Counters &C, u64 n_units_done, u64 n_aligned, u64 n_aligned_pairs)
+{
+    atomicAdd((u64 *)&A.counters[0], C.n_lookup); atomicAdd((u64 *)&A.counters[1], C.n_cand);
+    atomicAdd((u64 *)&A.counters[2], C.sum_w); atomicAdd((u64 *)&A.counters[3], C.n_orient);
+    atomicAdd((u64 *)&A.counters[4], n_units_done); atomicAdd((u64 *)&A.counters[5], n_aligned);
+    atomicAdd((u64 *)&A.counters[6], n_aligned_pairs);
+}
+
+#ifndef BSX_WAVES_PER_EU_SE
+#define BSX_WAVES_PER_EU_SE 6
+#endif
+#ifndef BSX_WAVES_PER_EU_PE
+#define BSX_WAVES_PER_EU_PE 4
+#endif
+// main kernel: persistent waves, one unit per wave at a time
 template <bool PE>
-__global__ __launch_bounds__(256) void k_align(AlignArgs A)
+__global__ __launch_bounds__(256, PE ? BSX_WAVES_PER_EU_PE : BSX_WAVES_PER_EU_SE) void k_align(AlignArgs A)
 {
     __shared__ BlockLds BL;
     __shared__ WaveLds<PE> WL[4];
-    const DevParams &P = A.P;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < 256; i += 256) ((uint8_t *)BL.prof)[i] = ((const uint8_t *)P.profile_a)[i];
-    if (P.n_chr <= BSX_LDS_CHR) {
-        for (uint32_t i = threadIdx.x; i <= P.n_chr; i += 256) BL.anchor[i] = P.anchor[i];
-        for (uint32_t i = threadIdx.x; i < P.n_chr; i += 256) { BL.chr_size[i] = P.chr_size[i]; BL.rc_offset[i] = P.rc_offset[i]; }
-    }
+    init_block_lds(A.P, BL, threadIdx.x, 256);
     __syncthreads();
     const uint32_t slot = blockIdx.x * 4 + wv;
     MateLds &LA = WL[wv].mate[0];
     MateLds &LB = WL[wv].mate[PE ? 1 : 0];
     Counters C = {0, 0, 0, 0};
     u64 n_units_done = 0, n_aligned = 0, n_aligned_pairs = 0;
-    const uint32_t nclass = (uint32_t)P.max_snp_num + 1, rowcap = A.rowcap;
     for (;;) {
         uint32_t unit = 0;
         if (lane == 0) unit = atomicAdd(A.queue, 1u);
-        unit = rfl(unit);
+        unit = rfl(unit) + A.first_unit;
         if (unit >= A.n_units) break;
-        n_units_done++;
+        const u64 t_begin = A.dbg_cycles ? __builtin_readcyclecounter() : 0;
         uint8_t *slab = A.scratch + (size_t)(A.debug ? unit : slot) * A.slab_bytes;
-        Slab SA, SB;
-        SA.rowcap = SB.rowcap = rowcap; SA.nclass = SB.nclass = nclass;
-        SA.hits = (u64 *)slab;
-        SA.keys = (uint32_t *)(SA.hits + (size_t)2 * (nclass + 1) * rowcap);
-        SA.tmp = (u64 *)(SA.keys + (size_t)(nclass + 1) * rowcap);
-        uint8_t *after_a = (uint8_t *)(SA.tmp + BSX_SORT_TMP);
-        SB = SA;
-        PairSlab PS{nullptr, rowcap};
-        if (PE) {
-            SB.hits = (u64 *)after_a;
-            SB.keys = (uint32_t *)(SB.hits + (size_t)2 * (nclass + 1) * rowcap);
-            SB.tmp = (u64 *)(SB.keys + (size_t)(nclass + 1) * rowcap);
-            PS.rows = (uint32_t *)(SB.tmp + BSX_SORT_TMP);
-        }
-        Mate MA, MB;
-        MA.index = MB.index = A.first_index + unit;
-        load_and_filter(A, LA, MA, 0, unit, lane);
-        if (PE) load_and_filter(A, LB, MB, 1, unit, lane);
-        if (!PE) {
-            if (!MA.filtered) {
-                pack_read(P, LA, MA, 0, lane, C);
-                for (int o = 0; o < 2; o++) if ((MA.flags >> o) & 1) plan_orient(P, BL, LA, MA, o, lane, C);
-                run_align_single(P, BL, LA, MA, SA, lane, C);
-            }
-            bsx_hit out;
-            select_hit(P, MA, SA, out, false);
-            if (lane == 0) A.hits_out[unit] = out;
-            if (A.cc[0] && lane < 32) { uint16_t *cc = (uint16_t *)&A.cc[0][unit]; cc[lane] = (uint16_t)MA.cnt_reg; }
-            if (A.debug && lane < 32) { A.dbg_plan[(size_t)unit * 128 + lane] = LA.start[lane >> 4][lane & 15]; A.dbg_plan[(size_t)unit * 128 + 32 + lane] = LA.order[lane >> 4][lane & 15]; }
-            if (out.n_best == 1 || (out.n_best > 1 && P.report_repeat_hits == 1)) n_aligned++;
-        } else {
-            uint32_t pcnt_reg = 0;  // lane c holds _cur_n_hits[c]
-            int paired = 0;
-            if (!MA.filtered) { pack_read(P, LA, MA, 1, lane, C); }
-            if (!MB.filtered) { pack_read(P, LB, MB, 2, lane, C); }
-            // ReorderSeed for both mates (pairs.cpp:160) — also when only one mate survives (SingleAlign::RunAlign)
-            if (!MA.filtered) for (int o = 0; o < 2; o++) if ((MA.flags >> o) & 1) plan_orient(P, BL, LA, MA, o, lane, C);
-            if (!MB.filtered) for (int o = 0; o < 2; o++) if ((MB.flags >> o) & 1) plan_orient(P, BL, LB, MB, o, lane, C);
-            if (!MA.filtered && !MB.filtered) {
-                // PairAlign::RunAlign (pairs.cpp:163-172)
-                const int maxi = max(MA.max_snp, MB.max_snp);
-                for (int i = 0; i <= maxi && !paired; i++) {
-                    if (i < MA.seedseg) snp_align(P, BL, LA, MA, SA, i, lane, C);
-                    if (i < MB.seedseg) snp_align(P, BL, LB, MB, SB, i, lane, C);
-                    if (i <= MA.max_snp) { sort_list(SA.list(0, i), n_of(MA, 0, i), SA.tmp, lane); sort_list(SA.list(1, i), n_of(MA, 1, i), SA.tmp, lane); }
-                    if (i <= MB.max_snp) { sort_list(SB.list(0, i), n_of(MB, 0, i), SB.tmp, lane); sort_list(SB.list(1, i), n_of(MB, 1, i), SB.tmp, lane); }
-                    int n = get_pairs(P, MA, MB, SA, SB, PS, pcnt_reg, i, i, lane);
-                    for (int j = 0; j < i; j++) n += get_pairs(P, MA, MB, SA, SB, PS, pcnt_reg, i, j, lane) + get_pairs(P, MA, MB, SA, SB, PS, pcnt_reg, j, i, lane);
-                    if (n > 0) paired = i + 1;
-                }
-            } else {
-                if (!MA.filtered) run_align_single(P, BL, LA, MA, SA, lane, C);
-                if (!MB.filtered) run_align_single(P, BL, LB, MB, SB, lane, C);
-            }
-            bsx_pair out;
-            out.a_chr = out.a_loc = out.b_chr = out.b_loc = 0; out.insert = 0; out.n_pairs = 0; out.pair_class = -1; out.chain = 0;
-            out.na = out.nb = 0; out.paired = (uint8_t)paired; out.unpaired_out = 1;
-            if (paired) {  // StringAlignPair (pairs.cpp:222-242)
-                for (int c = 0; c <= 2 * P.max_snp_num; c++) {
-                    const uint32_t n = rl(pcnt_reg, c);
-                    if (!n) continue;
-                    out.pair_class = (int8_t)c; out.n_pairs = (uint16_t)n;
-                    int j = -1;
-                    if (n == 1) j = 0;
-                    else if (P.report_repeat_hits == 1) j = (int)(bsx_myrand(MA.index, P.randseed) % n);
-                    if (j >= 0) {
-                        const uint32_t *o = PS.row(c) + (size_t)j * 6;
-                        out.chain = (uint8_t)(o[0] & 0xffff); out.na = (uint8_t)((o[0] >> 16) & 0xff); out.nb = (uint8_t)(o[0] >> 24);
-                        out.insert = (int32_t)o[1]; out.a_chr = o[2]; out.a_loc = o[3]; out.b_chr = o[4]; out.b_loc = o[5];
-                        out.unpaired_out = 0;
-                    }
-                    break;
-                }
-            }
-            if (P.rrbs && out.unpaired_out) { fix_unpaired_short_fragment(P, MA, SA, lane); fix_unpaired_short_fragment(P, MB, SB, lane); }  // pairs.cpp:250-253
-            select_hit(P, MA, SA, out.a, true);
-            select_hit(P, MB, SB, out.b, true);
-            if (lane == 0) A.pairs_out[unit] = out;
-            if (A.cc[0] && lane < 32) { ((uint16_t *)&A.cc[0][unit])[lane] = (uint16_t)MA.cnt_reg; ((uint16_t *)&A.cc[1][unit])[lane] = (uint16_t)MB.cnt_reg; }
-            if (A.npairs_out && lane < 32) A.npairs_out[(size_t)unit * 32 + lane] = (uint16_t)pcnt_reg;
-            if (A.debug && lane < 32) {
-                A.dbg_plan[(size_t)unit * 128 + lane] = LA.start[lane >> 4][lane & 15]; A.dbg_plan[(size_t)unit * 128 + 32 + lane] = LA.order[lane >> 4][lane & 15];
-                A.dbg_plan[(size_t)unit * 128 + 64 + lane] = LB.start[lane >> 4][lane & 15]; A.dbg_plan[(size_t)unit * 128 + 96 + lane] = LB.order[lane >> 4][lane & 15];
-            }
-            if (!out.unpaired_out) n_aligned_pairs++;
-            else {
-                if (out.a.n_best == 1 || (out.a.n_best > 1 && P.report_repeat_hits == 1)) n_aligned++;
-                if (out.b.n_best == 1 || (out.b.n_best > 1 && P.report_repeat_hits == 1)) n_aligned++;
-            }
-        }
+        const bool deferred = process_unit<PE, false>(A, BL, LA, LB, unit, slab, lane, C, n_aligned, n_aligned_pairs, nullptr, nullptr);
+        if (deferred) { if (lane == 0) A.heavy_list[atomicAdd(A.heavy_count, 1u)] = unit; }
+        else n_units_done++;
+        if (A.dbg_cycles && lane == 0) A.dbg_cycles[unit] = (uint32_t)min((u64)0xffffffffull, (u64)__builtin_readcyclecounter() - t_begin);
         wave_fence();
     }
-    if (lane == 0) {
-        atomicAdd((u64 *)&A.counters[0], C.n_lookup); atomicAdd((u64 *)&A.counters[1], C.n_cand);
-        atomicAdd((u64 *)&A.counters[2], C.sum_w); atomicAdd((u64 *)&A.counters[3], C.n_orient);
-        atomicAdd((u64 *)&A.counters[4], n_units_done); atomicAdd((u64 *)&A.counters[5], n_aligned);
-        atomicAdd((u64 *)&A.counters[6], n_aligned_pairs);
+    if (lane == 0) flush_counters(A, C, n_units_done, n_aligned, n_aligned_pairs);
+}
+
+// heavy kernel: one 16-wave workgroup per deferred unit; wave 0 owns the unit, all waves scan big candidate lists
+template <bool PE>
+__global__ __launch_bounds__(COOP_WAVES * 64) void k_align_heavy(AlignArgs A)
+{
+    __shared__ BlockLds BL;
+    __shared__ WaveLds<PE> WL;
+    __shared__ CoopLds CL;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    init_block_lds(A.P, BL, threadIdx.x, COOP_WAVES * 64);
+    __syncthreads();
+    SurvRec *surv = (SurvRec *)(A.coop_surv + (size_t)blockIdx.x * COOP_WIN * sizeof(SurvRec));
+    if (wv != 0) {
+        for (;;) {
+            __syncthreads();
+            if (CL.cmd == 1) break;
+            coop_scan_share(A.P, BL, CL, surv, wv, lane);
+            __syncthreads();
+        }
+        return;
     }
+    MateLds &LA = WL.mate[0];
+    MateLds &LB = WL.mate[PE ? 1 : 0];
+    Counters C = {0, 0, 0, 0};
+    u64 n_units_done = 0, n_aligned = 0, n_aligned_pairs = 0;
+    const uint32_t n_heavy = *A.heavy_count;
+    for (;;) {
+        uint32_t i = 0;
+        if (lane == 0) i = atomicAdd(A.queue + 1, 1u);
+        i = rfl(i);
+        if (i >= n_heavy) break;
+        const uint32_t unit = A.heavy_list[i];
+        const u64 t_begin = A.dbg_cycles ? __builtin_readcyclecounter() : 0;
+        uint8_t *slab = A.debug ? A.scratch + (size_t)unit * A.slab_bytes : A.scratch_heavy + (size_t)blockIdx.x * A.slab_bytes;
+        process_unit<PE, true>(A, BL, LA, LB, unit, slab, lane, C, n_aligned, n_aligned_pairs, &CL, surv);
+        n_units_done++;
+        if (A.dbg_cycles && lane == 0) A.dbg_cycles[unit] = (uint32_t)min((u64)0xffffffffull, (u64)__builtin_readcyclecounter() - t_begin);
+        wave_fence();
+    }
+    if (lane == 0) CL.cmd = 1;
+    __syncthreads();
+    if (lane == 0) flush_counters(A, C, n_units_done, n_aligned, n_aligned_pairs);
 }
 
 }  // namespace
 
-void bsx_launch_align(const AlignArgs &A, int paired, int grid_blocks, hipStream_t stream)
+void bsx_launch_align(const AlignArgs &A, int paired, int grid_blocks, int heavy_blocks, hipStream_t stream)
 {
     if (paired) hipLaunchKernelGGL(k_align<true>, dim3(grid_blocks), dim3(256), 0, stream, A);
     else hipLaunchKernelGGL(k_align<false>, dim3(grid_blocks), dim3(256), 0, stream, A);
+    if (heavy_blocks > 0) {
+        if (paired) hipLaunchKernelGGL(k_align_heavy<true>, dim3(heavy_blocks), dim3(COOP_WAVES * 64), 0, stream, A);
+        else hipLaunchKernelGGL(k_align_heavy<false>, dim3(heavy_blocks), dim3(COOP_WAVES * 64), 0, stream, A);
+    }
 }
+
+size_t bsx_coop_surv_bytes(void) { return (size_t)COOP_WIN * sizeof(SurvRec); }
 
 int bsx_align_occupancy(int paired)
 {

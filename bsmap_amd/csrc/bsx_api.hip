@@ -10,8 +10,10 @@
 #include "bsx_kernel_args.h"
 
 static int g_waves_per_cu = 0;
+static int g_heavy_threshold = 8192;  // candidate-list length that sends a unit to the cooperative heavy kernel
 
 extern "C" int bsx_set_waves_per_cu(int w) { g_waves_per_cu = w; return BSX_OK; }
+extern "C" int bsx_set_heavy_threshold(int t) { g_heavy_threshold = t < 0 ? 0 : t; return BSX_OK; }
 
 extern "C" int bsx_device_count(void)
 {
@@ -189,6 +191,10 @@ struct bsx_batch {
     bsx_class_counts *d_cc[2] = {nullptr, nullptr};
     uint16_t *d_npairs = nullptr;
     uint8_t *d_scratch = nullptr, *d_dbg = nullptr;
+    uint32_t *d_cycles = nullptr;
+    uint8_t *d_scratch_heavy = nullptr, *d_coop_surv = nullptr;
+    uint32_t *d_heavy_list = nullptr, *d_heavy_count = nullptr;
+    int heavy_blocks = 0;
     size_t scratch_bytes = 0;
     uint32_t *d_queue = nullptr;
     uint64_t *d_counters = nullptr;
@@ -223,6 +229,13 @@ static int ensure_scratch(bsx_batch *b)
     const int need = (int)((b->max_units + 3) / 4);
     if (grid > need) grid = need > 0 ? need : 1;
     b->grid_blocks = grid;
+    b->heavy_blocks = prop.multiProcessorCount;  // one 16-wave workgroup per CU
+    if (!b->d_scratch_heavy) {
+        HIP_TRY(hipMalloc((void **)&b->d_scratch_heavy, (size_t)b->heavy_blocks * b->slab_bytes));
+        HIP_TRY(hipMalloc((void **)&b->d_coop_surv, (size_t)b->heavy_blocks * bsx_coop_surv_bytes()));
+        HIP_TRY(hipMalloc((void **)&b->d_heavy_list, ((size_t)b->max_units + 1) * 4));
+        HIP_TRY(hipMalloc((void **)&b->d_heavy_count, 256));
+    }
     const uint64_t slots = b->debug ? b->max_units : (uint64_t)grid * 4;
     const size_t bytes = (size_t)(slots * b->slab_bytes);
     if (bytes > b->scratch_bytes) {
@@ -273,7 +286,8 @@ extern "C" void bsx_batch_destroy(bsx_batch *b)
     for (int m = 0; m < 2; m++)
         for (void *q : {(void *)b->d_seq[m], (void *)b->d_qual[m], (void *)b->d_off[m], (void *)b->d_cc[m]})
             if (q) (void)hipFree(q);
-    for (void *q : {(void *)b->d_hits, (void *)b->d_pairs, (void *)b->d_npairs, (void *)b->d_scratch, (void *)b->d_dbg, (void *)b->d_queue, (void *)b->d_counters})
+    for (void *q : {(void *)b->d_hits, (void *)b->d_pairs, (void *)b->d_npairs, (void *)b->d_scratch, (void *)b->d_dbg, (void *)b->d_queue, (void *)b->d_counters, (void *)b->d_cycles, (void *)b->d_scratch_heavy,
+                    (void *)b->d_coop_surv, (void *)b->d_heavy_list, (void *)b->d_heavy_count})
         if (q) (void)hipFree(q);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
@@ -327,27 +341,36 @@ extern "C" int bsx_batch_set_debug(bsx_batch *b, int keep)
 {
     if (!b) return BSX_ERR_ARG;
     HIP_TRY(hipSetDevice(b->ref->device));
-    b->debug = keep ? 1 : 0;
-    if (keep && !b->d_dbg) HIP_TRY(hipMalloc((void **)&b->d_dbg, (size_t)b->max_units * 128));
+    b->debug = keep == 1 ? 1 : 0;
+    if (keep == 2 && !b->d_cycles) HIP_TRY(hipMalloc((void **)&b->d_cycles, (size_t)b->max_units * 4));
+    if (keep == 0 && b->d_cycles) { (void)hipFree(b->d_cycles); b->d_cycles = nullptr; }
+    if (keep == 1 && !b->d_dbg) HIP_TRY(hipMalloc((void **)&b->d_dbg, (size_t)b->max_units * 128));
     return ensure_scratch(b);
 }
 
-extern "C" int bsx_batch_run(bsx_batch *b)
+extern "C" int bsx_batch_run(bsx_batch *b) { return b ? bsx_batch_run_range(b, 0, b->n_units) : BSX_ERR_ARG; }
+
+extern "C" int bsx_batch_run_range(bsx_batch *b, uint32_t first_unit, uint32_t n_units)
 {
     if (!b) return BSX_ERR_ARG;
     if (b->n_units == 0) return BSX_ERR_STATE;
+    if (n_units == 0 || (uint64_t)first_unit + n_units > b->n_units) return BSX_ERR_ARG;
     HIP_TRY(hipSetDevice(b->ref->device));
     AlignArgs A;
     memset(&A, 0, sizeof(A));
     bsx_fill_devparams(b->ref, A.P);
-    A.n_units = b->n_units; A.first_index = b->first_index; A.debug = b->debug; A.rowcap = b->rowcap;
+    A.n_units = first_unit + n_units; A.first_index = b->first_index; A.debug = b->debug; A.rowcap = b->rowcap;
+    A.first_unit = first_unit;
     for (int m = 0; m < 2; m++) { A.seq[m] = b->d_seq[m]; A.off[m] = b->d_off[m]; A.qual[m] = b->has_qual ? b->d_qual[m] : nullptr; A.cc[m] = b->d_cc[m]; }
     A.hits_out = b->d_hits; A.pairs_out = b->d_pairs; A.npairs_out = b->d_npairs;
-    A.scratch = b->d_scratch; A.slab_bytes = b->slab_bytes; A.queue = b->d_queue; A.counters = b->d_counters; A.dbg_plan = b->d_dbg;
-    HIP_TRY(hipMemsetAsync(b->d_queue, 0, 4, b->stream));
+    A.scratch = b->d_scratch; A.slab_bytes = b->slab_bytes; A.queue = b->d_queue; A.counters = b->d_counters; A.dbg_plan = b->d_dbg; A.dbg_cycles = b->d_cycles;
+    A.scratch_heavy = b->d_scratch_heavy; A.coop_surv = b->d_coop_surv; A.heavy_list = b->d_heavy_list; A.heavy_count = b->d_heavy_count;
+    A.heavy_threshold = b->ref->P.rrbs ? 0u : (uint32_t)g_heavy_threshold;
+    HIP_TRY(hipMemsetAsync(b->d_queue, 0, 8, b->stream));
+    HIP_TRY(hipMemsetAsync(b->d_heavy_count, 0, 4, b->stream));
     if (b->debug) HIP_TRY(hipMemsetAsync(b->d_scratch, 0, (size_t)b->max_units * b->slab_bytes, b->stream));
     HIP_TRY(hipEventRecord(b->ev0, b->stream));
-    bsx_launch_align(A, b->paired, b->grid_blocks, b->stream);
+    bsx_launch_align(A, b->paired, b->grid_blocks, A.heavy_threshold ? b->heavy_blocks : 0, b->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(b->ev1, b->stream));
     b->ran = true;
@@ -462,6 +485,25 @@ extern "C" int bsx_batch_debug_pairs(bsx_batch *b, uint32_t unit, int w, uint32_
     return (int)n;
 }
 
+extern "C" int bsx_batch_last_heavy_units(bsx_batch *b)
+{
+    if (!b || !b->ran) return BSX_ERR_STATE;
+    HIP_TRY(hipSetDevice(b->ref->device));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    uint32_t n = 0;
+    HIP_TRY(hipMemcpy(&n, b->d_heavy_count, 4, hipMemcpyDeviceToHost));
+    return (int)n;
+}
+
+extern "C" int bsx_batch_unit_cycles(bsx_batch *b, uint32_t *out)
+{
+    if (!b || !b->d_cycles || !b->ran || !out) return BSX_ERR_STATE;
+    HIP_TRY(hipSetDevice(b->ref->device));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(hipMemcpy(out, b->d_cycles, (size_t)b->n_units * 4, hipMemcpyDeviceToHost));
+    return BSX_OK;
+}
+
 extern "C" int bsx_batch_debug_plan(bsx_batch *b, uint32_t unit, int mate, int32_t *start32, int32_t *order32)
 {
     if (!b || !b->debug || unit >= b->n_units || !b->ran) return BSX_ERR_STATE;
@@ -473,4 +515,19 @@ extern "C" int bsx_batch_debug_plan(bsx_batch *b, uint32_t unit, int mate, int32
     return BSX_OK;
 }
 
-// synthetic workload generators live in bsx_synth.hip
+extern "C" int bsx_batch_synth_reads(bsx_batch *b, uint32_t n, uint32_t read_len, uint64_t seed, uint32_t first_index)
+{
+    if (!b || n == 0 || n > b->max_units || read_len < 16 || read_len > 160) return BSX_ERR_ARG;
+    HIP_TRY(hipSetDevice(b->ref->device));
+    const int nm = b->paired ? 2 : 1;
+    std::vector<uint64_t> off((size_t)n + 1);
+    for (uint32_t i = 0; i <= n; i++) off[i] = (uint64_t)i * read_len;
+    for (int m = 0; m < nm; m++) {
+        if (off[n] + 256 > b->seq_cap[m]) return BSX_ERR_ARG;
+        HIP_TRY(hipMemcpy(b->d_off[m], off.data(), off.size() * 8, hipMemcpyHostToDevice));
+    }
+    int rc = bsx_synth_reads_launch(b->ref, n, read_len, b->paired, seed, first_index, b->d_seq[0], b->d_seq[1], b->stream);
+    if (rc) return rc;
+    b->n_units = n; b->first_index = first_index; b->has_qual = 0;
+    return BSX_OK;
+}

@@ -53,6 +53,7 @@ struct bsx_ref {
     uint32_t *d_sites = nullptr, *d_site_off = nullptr;
     uint64_t n_entries = 0;
     bool has_index = false;
+    uint64_t synth_seed = 0;
 };
 
 extern thread_local std::string g_bsx_err;
@@ -69,5 +70,8 @@ int bsx_pack_fasta(const bsx_params &P, const char *text, uint64_t n, bsx_ref &r
 // bsx_index.hip
 int bsx_index_build_wgbs(bsx_ref *r);
 int bsx_index_build_rrbs(bsx_ref *r, const std::vector<uint32_t> &refcat, const std::vector<uint32_t> &crefcat);
+// bsx_synth.hip
+int bsx_synth_reads_launch(const bsx_ref *r, uint32_t n, uint32_t read_len, int paired, uint64_t seed, uint32_t first_index, uint8_t *d_seq_a,
+                           uint8_t *d_seq_b, hipStream_t stream);
 // bsx_align.hip
 void bsx_fill_devparams(const bsx_ref *r, DevParams &d);

@@ -4,7 +4,8 @@
 
 struct AlignArgs {
     DevParams P;
-    uint32_t n_units, first_index;
+    uint32_t n_units, first_index;   // units [first_unit, n_units) are processed; ReadInf.index = first_index + unit
+    uint32_t first_unit;
     int32_t debug;             // 1: scratch slab per unit (lists kept for inspection) instead of per wave
     uint32_t rowcap;           // capacity of one hit / pair list row (= -w + 64, see DESIGN.md "cap overshoot")
     const uint8_t *seq[2];     // ASCII reads, mate 0 / 1
@@ -16,10 +17,17 @@ struct AlignArgs {
     uint16_t *npairs_out;      // [n_units][32], may be null
     uint8_t *scratch;
     uint64_t slab_bytes;
-    uint32_t *queue;           // work queue head (zeroed before launch)
+    uint8_t *scratch_heavy;    // one slab per heavy-kernel workgroup
+    uint8_t *coop_surv;        // survivor window per heavy-kernel workgroup
+    uint32_t heavy_threshold;  // candidate-list length from which a unit is deferred to the heavy kernel (0 = never)
+    uint32_t *heavy_list;      // [n_units] unit ids deferred by the main kernel
+    uint32_t *heavy_count;
+    uint32_t *queue;           // [2] work queue heads of the main and heavy kernels (zeroed before launch)
     uint64_t *counters;        // BSX_N_COUNTERS
+    uint32_t *dbg_cycles;      // [n_units] shader-clock cycles spent on each unit (diagnostic builds of a run only), may be null
     uint8_t *dbg_plan;         // [n_units][128]: start[2][16], order[2][16] for mate a then mate b
 };
 
-void bsx_launch_align(const AlignArgs &A, int paired, int grid_blocks, hipStream_t stream);
+void bsx_launch_align(const AlignArgs &A, int paired, int grid_blocks, int heavy_blocks, hipStream_t stream);
+size_t bsx_coop_surv_bytes(void);
 int bsx_align_occupancy(int paired);

@@ -79,6 +79,8 @@ int bsx_ref_create_from_fasta(const bsx_params *p, const char *text, uint64_t n_
 int bsx_ref_create_from_file(const bsx_params *p, const char *path, int device, bsx_ref **out);
 /* deterministic synthetic genome generated ON the device (bench workload) */
 int bsx_ref_create_synthetic(const bsx_params *p, uint32_t n_chr, const uint32_t *chr_len, uint64_t seed, int device, bsx_ref **out);
+/* text of a synthetic chromosome, positions [from, from+n) (lets tests run the oracle's packer on the same sequence) */
+int bsx_synth_chr_text(const bsx_ref *r, uint32_t c, uint32_t from, uint32_t n, char *out);
 void bsx_ref_destroy(bsx_ref *r);
 uint32_t bsx_ref_n_chr(const bsx_ref *r);
 uint64_t bsx_ref_n_words(const bsx_ref *r);            /* words per strand copy incl. 2*400 margin (dbseq.h:15) */
@@ -150,6 +152,8 @@ int bsx_batch_upload_pe(bsx_batch *b, uint32_t n, const char *seqs_a, const uint
 int bsx_batch_synth_reads(bsx_batch *b, uint32_t n, uint32_t read_len, uint64_t seed, uint32_t first_index);
 /* Do_Batch (align.cpp:591-606 / pairs.cpp:192-218): asynchronous launch on the batch's HIP stream */
 int bsx_batch_run(bsx_batch *b);
+/* the same over units [first_unit, first_unit+n_units) of the uploaded batch (ReadInf.index = first_index + unit) */
+int bsx_batch_run_range(bsx_batch *b, uint32_t first_unit, uint32_t n_units);
 int bsx_batch_sync(bsx_batch *b);
 float bsx_batch_kernel_ms(bsx_batch *b);          /* HIP-event time of the last run's align kernel (after sync) */
 int bsx_batch_results_se(bsx_batch *b, bsx_hit *out, bsx_class_counts *counts /* may be NULL */);
@@ -158,13 +162,19 @@ int bsx_batch_counters(bsx_batch *b, uint64_t c[BSX_N_COUNTERS]);   /* accumulat
 int bsx_batch_reset_counters(bsx_batch *b);
 /* download the device-resident input reads (for the CPU baseline on device-synthesised input) */
 int bsx_batch_download_reads(bsx_batch *b, int mate, char *seqs, uint64_t *off);
-/* test hook: keep every hit / pair list of every unit (needs max_units small); layout documented in DESIGN.md */
-int bsx_batch_set_debug(bsx_batch *b, int keep_lists);
+/* test hooks: mode 1 keeps every hit / pair list of every unit (needs max_units small; layout in DESIGN.md);
+ * mode 2 records the shader-clock cycles each unit took (diagnostic runs only); 0 switches both off */
+int bsx_batch_set_debug(bsx_batch *b, int mode);
+int bsx_batch_unit_cycles(bsx_batch *b, uint32_t *cycles_per_unit);
 int bsx_batch_debug_hits(bsx_batch *b, uint32_t unit, int mate, int orient, int w, uint32_t *chr_loc_pairs, uint32_t cap);
 int bsx_batch_debug_pairs(bsx_batch *b, uint32_t unit, int w, uint32_t *pairhits6 /* chain|na<<16|nb<<24, insert, a.chr, a.loc, b.chr, b.loc */, uint32_t cap);
 int bsx_batch_debug_plan(bsx_batch *b, uint32_t unit, int mate, int32_t *start_arrays32 /* [2][16] */, int32_t *seedindex32 /* [2][16] */);
 /* tuning knob: resident waves per CU for the persistent align kernel (default chosen from register use) */
 int bsx_set_waves_per_cu(int waves);
+/* tuning knob: candidate-list length (one SnpAlign call, one read orientation) from which a unit is handed to the
+ * cooperative 16-wave kernel; 0 = never.  Results do not depend on it. */
+int bsx_set_heavy_threshold(int n_candidates);
+int bsx_batch_last_heavy_units(bsx_batch *b);   /* units the last run handed to the cooperative kernel */
 
 #ifdef __cplusplus
 }
