@@ -90,7 +90,9 @@ struct Slab {
     // w*(MAXHITS+1).  A class may legally exceed -w by one entry per extra SnpAlign call (PE levels, RRBS rounds); with
     // the default -w 1000 those entries land in the first slots of row w+1 — in the reference and, by construction, here.
     u64 *hits;        // [2][nclass+1][rowcap]
-    uint32_t *keys;   // [(nclass+1)*rowcap] overflow of key_reg
+    uint32_t *keys;   // [(nclass+1)*rowcap] accepted coordinates beyond the 64 held in key_reg ...
+    uint32_t *kslot;  // ... and the hash-set slot each of them occupies (for the per-unit clean-up)
+    uint32_t *hset;   // [BSX_HSET_SLOTS] open-addressing set of (coordinate+1); all zero between units
     u64 *tmp;         // [BSX_SORT_TMP] sort scratch
     uint32_t rowcap, nclass;
     __device__ __forceinline__ u64 *list(int orient, int w) const { return hits + ((size_t)(orient * (nclass + 1) + w)) * rowcap; }
@@ -325,30 +327,48 @@ __device__ __forceinline__ uint32_t chr_of(const DevParams &P, const BlockLds &B
 // (first 64 in a register, the rest in the wave's HBM slab, 256 per round trip).
 __device__ __forceinline__ uint32_t bloom_slot(uint32_t key) { return (key * 0x9E3779B1u) >> 20; }  // 12 bits
 
+__device__ __forceinline__ uint32_t hset_home(uint32_t key) { return (key * 0x85EBCA6Bu) >> (32 - BSX_HSET_BITS); }
+
 __device__ __forceinline__ bool seen_before(const Mate &M, const Slab &SL, uint32_t key, int lane)
 {
     const uint32_t slot = bloom_slot(key);
     const uint32_t word = (slot & 2048) ? rl(M.bloom1, (slot >> 5) & 63) : rl(M.bloom0, (slot >> 5) & 63);
     if (!((word >> (slot & 31)) & 1)) return false;
-    u64 dup = __ballot((uint32_t)lane < M.nkeys && M.key_reg == key);
-    if (M.nkeys > 64 && !dup) {
-        for (uint32_t base = 64; base < M.nkeys && !dup; base += 256) {
-            const uint32_t i0 = base + lane, i1 = i0 + 64, i2 = i0 + 128, i3 = i0 + 192;
-            const uint32_t k0 = i0 < M.nkeys ? SL.keys[i0] : ~key, k1 = i1 < M.nkeys ? SL.keys[i1] : ~key,
-                           k2 = i2 < M.nkeys ? SL.keys[i2] : ~key, k3 = i3 < M.nkeys ? SL.keys[i3] : ~key;
-            dup = __ballot(k0 == key || k1 == key || k2 == key || k3 == key);
-        }
+    if (__ballot((uint32_t)lane < min(M.nkeys, 64u) && M.key_reg == key)) return true;
+    if (M.nkeys <= 64) return false;
+    // linear probing, 64 slots per step: found if the key shows up before the first empty slot
+    for (uint32_t h = hset_home(key);; h = (h + 64) & (BSX_HSET_SLOTS - 1)) {
+        const uint32_t v = SL.hset[(h + lane) & (BSX_HSET_SLOTS - 1)];
+        const u64 hit = __ballot(v == key + 1), empty = __ballot(v == 0);
+        if (hit && (!empty || __builtin_ctzll(hit) < __builtin_ctzll(empty))) return true;
+        if (empty) return false;
     }
-    return dup != 0;
 }
 
 __device__ __forceinline__ void remember_key(Mate &M, const Slab &SL, uint32_t key, int lane)
 {
     if (M.nkeys < 64) { if ((uint32_t)lane == M.nkeys) M.key_reg = key; }
-    else if (lane == 0) SL.keys[M.nkeys] = key;
+    else {
+        for (uint32_t h = hset_home(key);; h = (h + 64) & (BSX_HSET_SLOTS - 1)) {
+            const uint32_t sidx = (h + lane) & (BSX_HSET_SLOTS - 1);
+            const u64 empty = __ballot(SL.hset[sidx] == 0);
+            if (empty) {
+                if (lane == (int)__builtin_ctzll(empty)) { SL.hset[sidx] = key + 1; SL.keys[M.nkeys] = key; SL.kslot[M.nkeys] = sidx; }
+                break;
+            }
+        }
+        wave_fence();
+    }
     M.nkeys++;
     const uint32_t slot = bloom_slot(key);
     if ((uint32_t)lane == ((slot >> 5) & 63)) { if (slot & 2048) M.bloom1 |= 1u << (slot & 31); else M.bloom0 |= 1u << (slot & 31); }
+}
+
+// leave the hash set empty for the next unit that uses this slab
+__device__ __forceinline__ void forget_keys(const Mate &M, const Slab &SL, int lane)
+{
+    for (uint32_t i = 64 + lane; i < M.nkeys; i += 64) SL.hset[SL.kslot[i]] = 0;
+    wave_fence();
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -430,7 +450,6 @@ __device__ __forceinline__ CandEval eval_candidate(const DevParams &P, const uin
 #define COOP_WAVES 8
 #define COOP_CHUNKS 4
 #define COOP_WIN (COOP_WAVES * COOP_CHUNKS * 64)
-#define COOP_MIN 1024u  // lists at least this long are scanned cooperatively
 
 struct SurvRec { uint32_t w_ord, hchr, hloc, hkey; };  // w in bits 0-7, ordinal inside the window in bits 8+
 
@@ -536,6 +555,7 @@ template <bool COOP>
 __device__ void snp_align(const DevParams &P, const BlockLds &BL, const MateLds &L, Mate &M, const Slab &SL, int mode, int lane,
                           Counters &C, uint32_t heavy_threshold, CoopLds *CL, SurvRec *surv)
 {
+    const uint32_t coop_min = heavy_threshold < 1024u ? heavy_threshold : 1024u;  // heavy kernel: lists at least this long are scanned by all waves
     const int I = P.index_interval;
     const int nwords = (M.len + 15) >> 4;
     const bool lds_chr = P.n_chr <= BSX_LDS_CHR;
@@ -569,8 +589,8 @@ __device__ void snp_align(const DevParams &P, const BlockLds &BL, const MateLds 
         for (int o = 1; o < 32; o <<= 1) { uint32_t t = __shfl_up(sub_pre, o); if (lane >= o) sub_pre += t; }
         const uint32_t total = rl(sub_pre, nsub - 1);
         sub_pre -= sub_n;
-        if (!COOP && !P.rrbs && heavy_threshold && total >= heavy_threshold) { M.defer = 1; return; }
-        if (COOP && !P.rrbs && total >= COOP_MIN) {
+        if (!COOP && !P.rrbs && heavy_threshold && total >= heavy_threshold) { M.defer = 1; return; }  // M.defer is never set in the heavy kernel
+        if (COOP && !P.rrbs && total >= coop_min) {
             // ---- cooperative windows ----
             if (lane < 32) { CL->sub_pre[lane] = sub_pre; CL->sub_n[lane] = sub_n; CL->sub_base[lane] = sub_base; CL->sub_h[lane] = sub_h; }
             if (lane < 9) { CL->rw[lane] = L.w[orient][lane]; CL->rm[lane] = L.m[orient][lane]; }
@@ -858,20 +878,24 @@ __device__ bool process_unit(const AlignArgs &A, const BlockLds &BL, MateLds &LA
 {
     const DevParams &P = A.P;
     const uint32_t nclass = (uint32_t)P.max_snp_num + 1, rowcap = A.rowcap;
-    const uint32_t hthr = COOP ? 0u : A.heavy_threshold;
+    const uint32_t hthr = A.heavy_threshold;
     const Counters C0 = C;
     Slab SA, SB;
     SA.rowcap = SB.rowcap = rowcap; SA.nclass = SB.nclass = nclass;
     SA.hits = (u64 *)slab;
     SA.keys = (uint32_t *)(SA.hits + (size_t)2 * (nclass + 1) * rowcap);
-    SA.tmp = (u64 *)(SA.keys + (size_t)(nclass + 1) * rowcap);
+    SA.kslot = SA.keys + (size_t)(nclass + 1) * rowcap;
+    SA.hset = SA.kslot + (size_t)(nclass + 1) * rowcap;
+    SA.tmp = (u64 *)(SA.hset + BSX_HSET_SLOTS);
     uint8_t *after_a = (uint8_t *)(SA.tmp + BSX_SORT_TMP);
     SB = SA;
     PairSlab PS{nullptr, rowcap};
     if (PE) {
         SB.hits = (u64 *)after_a;
         SB.keys = (uint32_t *)(SB.hits + (size_t)2 * (nclass + 1) * rowcap);
-        SB.tmp = (u64 *)(SB.keys + (size_t)(nclass + 1) * rowcap);
+        SB.kslot = SB.keys + (size_t)(nclass + 1) * rowcap;
+        SB.hset = SB.kslot + (size_t)(nclass + 1) * rowcap;
+        SB.tmp = (u64 *)(SB.hset + BSX_HSET_SLOTS);
         PS.rows = (uint32_t *)(SB.tmp + BSX_SORT_TMP);
     }
     Mate MA, MB;
@@ -883,7 +907,7 @@ __device__ bool process_unit(const AlignArgs &A, const BlockLds &BL, MateLds &LA
             pack_read(P, LA, MA, 0, lane, C);
             for (int o = 0; o < 2; o++) if ((MA.flags >> o) & 1) plan_orient(P, BL, LA, MA, o, lane, C);
             run_align_single<COOP>(P, BL, LA, MA, SA, lane, C, hthr, CL, surv);
-            if (MA.defer) { C = C0; return true; }
+            if (MA.defer) { forget_keys(MA, SA, lane); if (PE) forget_keys(MB, SB, lane); C = C0; return true; }
         }
         bsx_hit out;
         select_hit(P, MA, SA, out, false);
@@ -891,6 +915,7 @@ __device__ bool process_unit(const AlignArgs &A, const BlockLds &BL, MateLds &LA
         if (A.cc[0] && lane < 32) { uint16_t *cc = (uint16_t *)&A.cc[0][unit]; cc[lane] = (uint16_t)MA.cnt_reg; }
         if (A.debug && lane < 32) { A.dbg_plan[(size_t)unit * 128 + lane] = LA.start[lane >> 4][lane & 15]; A.dbg_plan[(size_t)unit * 128 + 32 + lane] = LA.order[lane >> 4][lane & 15]; }
         if (out.n_best == 1 || (out.n_best > 1 && P.report_repeat_hits == 1)) n_aligned++;
+        forget_keys(MA, SA, lane);
         return false;
     }
     uint32_t pcnt_reg = 0;  // lane c holds _cur_n_hits[c]
@@ -905,9 +930,9 @@ __device__ bool process_unit(const AlignArgs &A, const BlockLds &BL, MateLds &LA
         const int maxi = max(MA.max_snp, MB.max_snp);
         for (int i = 0; i <= maxi && !paired; i++) {
             if (i < MA.seedseg) snp_align<COOP>(P, BL, LA, MA, SA, i, lane, C, hthr, CL, surv);
-            if (MA.defer) { C = C0; return true; }
+            if (MA.defer) { forget_keys(MA, SA, lane); if (PE) forget_keys(MB, SB, lane); C = C0; return true; }
             if (i < MB.seedseg) snp_align<COOP>(P, BL, LB, MB, SB, i, lane, C, hthr, CL, surv);
-            if (MB.defer) { C = C0; return true; }
+            if (MB.defer) { forget_keys(MA, SA, lane); forget_keys(MB, SB, lane); C = C0; return true; }
             if (i <= MA.max_snp) { sort_list(SA.list(0, i), n_of(MA, 0, i), SA.tmp, lane); sort_list(SA.list(1, i), n_of(MA, 1, i), SA.tmp, lane); }
             if (i <= MB.max_snp) { sort_list(SB.list(0, i), n_of(MB, 0, i), SB.tmp, lane); sort_list(SB.list(1, i), n_of(MB, 1, i), SB.tmp, lane); }
             int n = get_pairs(P, MA, MB, SA, SB, PS, pcnt_reg, i, i, lane);
@@ -915,8 +940,8 @@ __device__ bool process_unit(const AlignArgs &A, const BlockLds &BL, MateLds &LA
             if (n > 0) paired = i + 1;
         }
     } else {
-        if (!MA.filtered) { run_align_single<COOP>(P, BL, LA, MA, SA, lane, C, hthr, CL, surv); if (MA.defer) { C = C0; return true; } }
-        if (!MB.filtered) { run_align_single<COOP>(P, BL, LB, MB, SB, lane, C, hthr, CL, surv); if (MB.defer) { C = C0; return true; } }
+        if (!MA.filtered) { run_align_single<COOP>(P, BL, LA, MA, SA, lane, C, hthr, CL, surv); if (MA.defer) { forget_keys(MA, SA, lane); if (PE) forget_keys(MB, SB, lane); C = C0; return true; } }
+        if (!MB.filtered) { run_align_single<COOP>(P, BL, LB, MB, SB, lane, C, hthr, CL, surv); if (MB.defer) { forget_keys(MA, SA, lane); forget_keys(MB, SB, lane); C = C0; return true; } }
     }
     bsx_pair out;
     out.a_chr = out.a_loc = out.b_chr = out.b_loc = 0; out.insert = 0; out.n_pairs = 0; out.pair_class = -1; out.chain = 0;
@@ -953,6 +978,7 @@ __device__ bool process_unit(const AlignArgs &A, const BlockLds &BL, MateLds &LA
         if (out.a.n_best == 1 || (out.a.n_best > 1 && P.report_repeat_hits == 1)) n_aligned++;
         if (out.b.n_best == 1 || (out.b.n_best > 1 && P.report_repeat_hits == 1)) n_aligned++;
     }
+    forget_keys(MA, SA, lane); forget_keys(MB, SB, lane);
     return false;
 }
 

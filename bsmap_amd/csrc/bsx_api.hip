@@ -73,6 +73,7 @@ extern "C" int bsx_ref_create_from_fasta(const bsx_params *p, const char *text, 
     if (rc == BSX_OK && r->n_chr == 0) rc = BSX_ERR_IO;
     if (rc == BSX_OK) rc = finish_ref_upload(r, refcat, crefcat);
     if (rc == BSX_OK && p->rrbs) rc = bsx_index_build_rrbs(r, refcat, crefcat);
+    if (rc == BSX_OK && hipDeviceSynchronize() != hipSuccess) rc = BSX_ERR_DEVICE;  // null-stream memsets must land before any batch stream runs
     if (rc != BSX_OK) { bsx_ref_destroy(r); return rc; }
     *out = r;
     return BSX_OK;
@@ -207,7 +208,7 @@ struct bsx_batch {
 static uint64_t mate_bytes(const bsx_params &p, uint32_t rowcap)
 {
     const uint64_t rows = (uint64_t)p.max_snp_num + 2;  // nclass + 1 spare row (see Slab in bsx_align.hip)
-    return 2 * rows * rowcap * 8 + rows * rowcap * 4 + (uint64_t)BSX_SORT_TMP * 8;
+    return 2 * rows * rowcap * 8 + 2 * rows * rowcap * 4 + (uint64_t)BSX_HSET_SLOTS * 4 + (uint64_t)BSX_SORT_TMP * 8;
 }
 
 static uint64_t slab_size(const bsx_params &p, int paired, uint32_t rowcap)
@@ -232,6 +233,7 @@ static int ensure_scratch(bsx_batch *b)
     b->heavy_blocks = prop.multiProcessorCount;  // one 16-wave workgroup per CU
     if (!b->d_scratch_heavy) {
         HIP_TRY(hipMalloc((void **)&b->d_scratch_heavy, (size_t)b->heavy_blocks * b->slab_bytes));
+        HIP_TRY(hipMemsetAsync(b->d_scratch_heavy, 0, (size_t)b->heavy_blocks * b->slab_bytes, b->stream));
         HIP_TRY(hipMalloc((void **)&b->d_coop_surv, (size_t)b->heavy_blocks * bsx_coop_surv_bytes()));
         HIP_TRY(hipMalloc((void **)&b->d_heavy_list, ((size_t)b->max_units + 1) * 4));
         HIP_TRY(hipMalloc((void **)&b->d_heavy_count, 256));
@@ -242,6 +244,7 @@ static int ensure_scratch(bsx_batch *b)
         if (b->d_scratch) (void)hipFree(b->d_scratch);
         b->d_scratch = nullptr;
         HIP_TRY(hipMalloc((void **)&b->d_scratch, bytes));
+        HIP_TRY(hipMemsetAsync(b->d_scratch, 0, bytes, b->stream));  // the per-slab hash sets must start empty (same stream as the kernels)
         b->scratch_bytes = bytes;
     }
     return BSX_OK;
@@ -272,7 +275,7 @@ extern "C" int bsx_batch_create(bsx_ref *r, uint32_t max_units, int paired, bsx_
             return fail(BSX_ERR_NOMEM);
     } else if (hipMalloc((void **)&b->d_hits, (size_t)max_units * sizeof(bsx_hit)) != hipSuccess) return fail(BSX_ERR_NOMEM);
     if (hipMalloc((void **)&b->d_queue, 256) != hipSuccess || hipMalloc((void **)&b->d_counters, BSX_N_COUNTERS * 8) != hipSuccess) return fail(BSX_ERR_NOMEM);
-    if (hipMemset(b->d_counters, 0, BSX_N_COUNTERS * 8) != hipSuccess) return fail(BSX_ERR_DEVICE);
+    if (hipMemsetAsync(b->d_counters, 0, BSX_N_COUNTERS * 8, b->stream) != hipSuccess) return fail(BSX_ERR_DEVICE);
     if ((rc = ensure_scratch(b)) != BSX_OK) return fail(rc);
     *out = b;
     return BSX_OK;
@@ -433,8 +436,8 @@ extern "C" int bsx_batch_reset_counters(bsx_batch *b)
 {
     if (!b) return BSX_ERR_ARG;
     HIP_TRY(hipSetDevice(b->ref->device));
+    HIP_TRY(hipMemsetAsync(b->d_counters, 0, BSX_N_COUNTERS * 8, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
-    HIP_TRY(hipMemset(b->d_counters, 0, BSX_N_COUNTERS * 8));
     return BSX_OK;
 }
 

@@ -11,6 +11,8 @@
 #define BSX_SEGLEN 16u
 #define BSX_LDS_CHR 512
 #define BSX_ROWCAP (BSX_MAXHITS + 1)  // HitArray / PairArray row length (reference align.h:18, pairs.h:22)
+#define BSX_HSET_BITS 15
+#define BSX_HSET_SLOTS (1u << BSX_HSET_BITS)  // duplicate-suppression hash set, >= 2x the most hits a read can collect
 #define BSX_SORT_TMP 1280            // scratch entries for sorting one class list      // chromosomes whose anchors are staged in LDS by the align kernel
 
 // everything the align kernel needs, passed by value as the kernel argument
