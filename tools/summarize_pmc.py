@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 outputs into profiles/: per-kernel stats (from --kernel-trace --stats) and HBM traffic per launch
+from the FETCH_SIZE / WRITE_SIZE PMC passes (separate runs, as MI355X_MICROARCH.md prescribes).
+
+gfx950 correction applied (MI355X_MICROARCH.md §HBM): FETCH_SIZE reports half of the bytes of wide coalesced reads, so
+the read side is given both raw and doubled; rocprofv3 reports both counters in KiB.
+usage: summarize_pmc.py <tag> <stats_dir> <fetch_dir> <write_dir>"""
+import csv
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def per_kernel(dirname, counter):
+    out = {}
+    for f in glob.glob(os.path.join(dirname, "**", "*_counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if row["Counter_Name"] != counter:
+                continue
+            k = row["Kernel_Name"]
+            d = out.setdefault(k, {"launches": 0, "sum": 0.0, "ns": 0})
+            d["launches"] += 1
+            d["sum"] += float(row["Counter_Value"])
+            d["ns"] += int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
+    return out
+
+
+def main():
+    tag, stats_dir, fetch_dir, write_dir = sys.argv[1:5]
+    os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+    for f in glob.glob(os.path.join(stats_dir, "**", "*_kernel_stats.csv"), recursive=True):
+        rows = list(csv.reader(open(f)))
+        with open(os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv"), "w") as o:
+            w = csv.writer(o)
+            for r in rows:
+                r[0] = r[0][:120]
+                w.writerow(r)
+    fetch, write = per_kernel(fetch_dir, "FETCH_SIZE"), per_kernel(write_dir, "WRITE_SIZE")
+    summ = {}
+    for k in sorted(set(fetch) | set(write)):
+        if not any(t in k for t in ("k_align", "k_scan", "k_heavy", "k_ctrl")):
+            continue
+        f, w = fetch.get(k), write.get(k)
+        e = {"launches": (f or w)["launches"]}
+        if f:
+            e["FETCH_SIZE_KiB_per_launch"] = f["sum"] / f["launches"]
+            e["fetch_bytes_per_launch_raw"] = f["sum"] / f["launches"] * 1024
+            e["fetch_bytes_per_launch_x2_gfx950"] = 2 * f["sum"] / f["launches"] * 1024
+            e["avg_ms_in_pmc_pass"] = f["ns"] / f["launches"] / 1e6
+        if w:
+            e["WRITE_SIZE_KiB_per_launch"] = w["sum"] / w["launches"]
+            e["write_bytes_per_launch"] = w["sum"] / w["launches"] * 1024
+        summ[k[:100]] = e
+    tot = sum(e.get("fetch_bytes_per_launch_x2_gfx950", 0) + e.get("write_bytes_per_launch", 0) for e in summ.values())
+    out = {"tag": tag, "kernels": summ, "hbm_bytes_per_launch": tot,
+           "note": "per launch of the align kernels of one bench step; read side = 2 x FETCH_SIZE (gfx950 correction), write side = WRITE_SIZE"}
+    json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_pmc.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_latest.json"), "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
