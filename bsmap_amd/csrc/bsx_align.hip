@@ -441,28 +441,6 @@ __device__ __forceinline__ CandEval eval_candidate(const DevParams &P, const uin
     return r;
 }
 
-// ---- cooperative scan of very large candidate lists (heavy kernel only) ---------------------------------------
-// A bucket of a low-complexity seed can hold millions of entries.  In the heavy kernel one workgroup of 16 waves owns
-// a unit: wave 0 runs the unit's control flow, and for big lists all 16 waves evaluate a window of 4096 candidates
-// at a time into an ordered survivor buffer that wave 0 then replays.  Any event that changes the threshold (or ends
-// the call) restarts the window right after the candidate that caused it, so every candidate is evaluated under
-// exactly the threshold the reference would have used — results and work counters stay bit-identical.
-#define COOP_WAVES 8
-#define COOP_CHUNKS 4
-#define COOP_WIN (COOP_WAVES * COOP_CHUNKS * 64)
-
-struct SurvRec { uint32_t w_ord, hchr, hloc, hkey; };  // w in bits 0-7, ordinal inside the window in bits 8+
-
-struct CoopLds {
-    uint32_t cmd;  // 0 scan window, 1 exit
-    uint32_t rw[9], rm[9];
-    int32_t nwords, len;
-    uint32_t thres, nsub, total, win_c0;
-    uint32_t sub_pre[32], sub_n[32], sub_base[32], sub_h[32];
-    uint32_t cnt[COOP_WAVES];
-    uint32_t acc[COOP_WAVES][4];
-    uint8_t wcls[COOP_WIN];
-};
 
 // hit coordinates of a WGBS candidate at global nt p of strand copy `strand`; false if it runs off the chromosome
 __device__ __forceinline__ bool hit_coords(const DevParams &P, const BlockLds &BL, uint32_t p, uint32_t strand, int len, uint32_t &hchr,
@@ -475,52 +453,6 @@ __device__ __forceinline__ bool hit_coords(const DevParams &P, const BlockLds &B
     if (strand) loc = (lds_chr ? BL.rc_offset[c] : P.rc_offset[c]) - (uint32_t)len - loc;  // align.cpp:289
     hchr = 2 * c + strand; hloc = loc; hkey = an + loc;
     return !((u64)loc + (u64)len > (u64)sz);  // overflow the end of refseq (align.cpp:273)
-}
-
-__device__ void coop_scan_share(const DevParams &P, const BlockLds &BL, CoopLds &CL, SurvRec *surv, int wv, int lane)
-{
-    uint32_t rw[9], rm[9];
-#pragma unroll
-    for (int t = 0; t < 9; t++) { rw[t] = rfl(CL.rw[t]); rm[t] = rfl(CL.rm[t]); }
-    const uint32_t thres0 = CL.thres, total = CL.total, nsub = CL.nsub;
-    const int nwords = CL.nwords, len = CL.len;
-    const uint32_t w0 = CL.win_c0 + (uint32_t)wv * (COOP_CHUNKS * 64);
-    uint32_t idx[COOP_CHUNKS], e_idx[COOP_CHUNKS], hh[COOP_CHUNKS], strand[COOP_CHUNKS], p[COOP_CHUNKS];
-    bool valid[COOP_CHUNKS];
-#pragma unroll
-    for (int u = 0; u < COOP_CHUNKS; u++) {
-        idx[u] = w0 + u * 64 + lane;
-        valid[u] = idx[u] < total;
-        e_idx[u] = 0; hh[u] = 0; strand[u] = 0;
-        for (uint32_t sidx = 0; sidx < nsub; sidx++) {
-            const uint32_t ps = CL.sub_pre[sidx], ns = CL.sub_n[sidx];
-            if (idx[u] >= ps && idx[u] < ps + ns) { e_idx[u] = CL.sub_base[sidx] + (idx[u] - ps); hh[u] = CL.sub_h[sidx]; strand[u] = sidx & 1; }
-        }
-    }
-#pragma unroll
-    for (int u = 0; u < COOP_CHUNKS; u++) p[u] = valid[u] ? P.entries[e_idx[u]] + hh[u] : 0;
-    uint32_t nsurv = 0, a0 = 0, a1 = 0, a2 = 0, a5 = 0;
-#pragma unroll
-    for (int u = 0; u < COOP_CHUNKS; u++) {
-        CandEval ev = {0xffff, 0, 0, 0};
-        if (valid[u]) ev = eval_candidate(P, rw, rm, nwords, p[u], strand[u], thres0);
-        bool pass = valid[u] && ev.w <= thres0;
-        uint32_t hchr = 0, hloc = 0, hkey = 0;
-        if (pass) pass = hit_coords(P, BL, p[u], strand[u], len, hchr, hloc, hkey);
-        const u64 m = __ballot(pass);
-        if (pass) {
-            SurvRec r; r.w_ord = ev.w | ((idx[u] - CL.win_c0) << 8); r.hchr = hchr; r.hloc = hloc; r.hkey = hkey;
-            surv[(size_t)wv * (COOP_CHUNKS * 64) + nsurv + (uint32_t)__builtin_popcountll(m & lanemask_lt(lane))] = r;
-        }
-        nsurv += (uint32_t)__builtin_popcountll(m);
-        const bool one = valid[u] && ev.w0ref > thres0;
-        const bool two = valid[u] && !one && (ev.p48 > thres0 || ev.w01ref > thres0);
-        const bool five = valid[u] && !one && !two;
-        if (idx[u] - CL.win_c0 < COOP_WIN) CL.wcls[idx[u] - CL.win_c0] = one ? 1 : two ? 2 : five ? 5 : 0;
-        a0 += (uint32_t)__builtin_popcountll(__ballot(valid[u])); a1 += (uint32_t)__builtin_popcountll(__ballot(one));
-        a2 += (uint32_t)__builtin_popcountll(__ballot(two)); a5 += (uint32_t)__builtin_popcountll(__ballot(five));
-    }
-    if (lane == 0) { CL.cnt[wv] = nsurv; CL.acc[wv][0] = a0; CL.acc[wv][1] = a1; CL.acc[wv][2] = a2; CL.acc[wv][3] = a5; }
 }
 
 // One accepted-candidate step of the reference's inner loops (align.cpp:274-278 and the RRBS twin :201-212):
@@ -549,131 +481,91 @@ __device__ __forceinline__ int accept_survivor(const DevParams &P, Mate &M, cons
     return 0;
 }
 
-// SnpAlign.  COOP = running as wave 0 of the heavy kernel (CL/surv valid).  In the main kernel a WGBS list longer than
-// heavy_threshold sets M.defer and returns: the unit is redone from scratch by the heavy kernel.
-template <bool COOP>
-__device__ void snp_align(const DevParams &P, const BlockLds &BL, const MateLds &L, Mate &M, const Slab &SL, int mode, int lane,
-                          Counters &C, uint32_t heavy_threshold, CoopLds *CL, SurvRec *surv)
+// The candidate list of one SnpAlign call for one read orientation.  WGBS: the (phase x strand) sub-ranges of the
+// index, sub-range s = 2*phase+strand described by lane s (align.cpp:258-299); RRBS: one bucket of {tag,loc} pairs
+// (align.cpp:175-252).  Candidates are numbered 0..total-1 in the order the reference visits them.
+struct CandList {
+    uint32_t sub_base, sub_n, sub_h, sub_pre;  // lane s: first entry, size, h, first ordinal of sub-range s
+    uint32_t total;
+    int nsub;
+};
+
+__device__ __forceinline__ CandList make_list(const DevParams &P, const BlockLds &BL, const MateLds &L, const Mate &M, int orient, int seg, int lane)
 {
-    const uint32_t coop_min = heavy_threshold < 1024u ? heavy_threshold : 1024u;  // heavy kernel: lists at least this long are scanned by all waves
-    const int I = P.index_interval;
+    CandList cl;
+    cl.sub_base = cl.sub_n = cl.sub_h = 0;
+    cl.nsub = P.rrbs ? 1 : 2 * P.index_interval;
+    if (lane < cl.nsub) {
+        if (P.rrbs) {
+            const int a = BL.prof[seg][0];
+            const int coff = orient ? (M.len % P.seed_size) : 0;  // cseed_offset (align.cpp:443)
+            const uint32_t key = seed_key_at(P, L.w[orient], a + coff + L.start[orient][seg]);
+            const U2 b = *reinterpret_cast<const U2 *>(P.bucket_off + key);
+            cl.sub_base = b.a; cl.sub_n = b.b - b.a; cl.sub_h = (uint32_t)(a + coff);
+        } else {
+            const int ph = lane >> 1;
+            const int a = BL.prof[seg][ph], st = L.start[orient][seg];
+            const uint32_t key = seed_key_at(P, L.w[orient], a + st - ph);
+            const U2 b = *reinterpret_cast<const U2 *>(P.bucket_off + key);
+            const uint32_t nf = P.bucket_nfwd[key];
+            cl.sub_base = (lane & 1) ? b.a + nf : b.a;
+            cl.sub_n = (lane & 1) ? (b.b - b.a - nf) : nf;
+            cl.sub_h = (uint32_t)(-a + ph - st);  // h (align.cpp:263)
+        }
+    }
+    uint32_t pre = cl.sub_n;  // inclusive prefix over lanes
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) { uint32_t t = __shfl_up(pre, o); if (lane >= o) pre += t; }
+    cl.total = rl(pre, cl.nsub - 1);
+    cl.sub_pre = pre - cl.sub_n;
+    return cl;
+}
+
+// Scan candidates [c_begin, c_end) of a list with one wave, 64 at a time, replaying survivors in order.
+//   COUNT_ONLY: no replay; only the work counters are advanced, with the threshold frozen at thres_fixed (used to
+//   re-count the part of a pre-scanned task that precedes an event).
+// Returns 0 = range finished, 1 = range finished and the threshold was lowered on the way, 2 = SnpAlign returns.
+template <bool COUNT_ONLY>
+__device__ int wave_scan_range(const DevParams &P, const BlockLds &BL, const MateLds &L, Mate &M, const Slab &SL, const CandList &cl, int orient,
+                               int seg, int mode, uint32_t c_begin, uint32_t c_end, uint32_t thres_fixed, int lane, Counters &C)
+{
     const int nwords = (M.len + 15) >> 4;
     const bool lds_chr = P.n_chr <= BSX_LDS_CHR;
-    for (int orient = 0; orient < 2; orient++) {
-        if (!((M.flags >> orient) & 1)) continue;
-        const int seg = L.order[orient][mode];  // modeindex
-        // The candidate list of this call: WGBS = (phase x strand) sub-ranges of the index, sub-range s = 2*phase+strand
-        // described by lane s; RRBS = one bucket of {tag,loc} pairs (align.cpp:175-252).
-        uint32_t sub_base = 0, sub_n = 0, sub_h = 0;
-        const int nsub = P.rrbs ? 1 : 2 * I;
-        if (lane < nsub) {
-            if (P.rrbs) {
-                const int a = BL.prof[seg][0];
-                const int coff = orient ? (M.len % P.seed_size) : 0;  // cseed_offset (align.cpp:443)
-                const uint32_t key = seed_key_at(P, L.w[orient], a + coff + L.start[orient][seg]);
-                const U2 b = *reinterpret_cast<const U2 *>(P.bucket_off + key);
-                sub_base = b.a; sub_n = b.b - b.a; sub_h = (uint32_t)(a + coff);
-            } else {
-                const int ph = lane >> 1;
-                const int a = BL.prof[seg][ph], st = L.start[orient][seg];
-                const uint32_t key = seed_key_at(P, L.w[orient], a + st - ph);
-                const U2 b = *reinterpret_cast<const U2 *>(P.bucket_off + key);
-                const uint32_t nf = P.bucket_nfwd[key];
-                sub_base = (lane & 1) ? b.a + nf : b.a;
-                sub_n = (lane & 1) ? (b.b - b.a - nf) : nf;
-                sub_h = (uint32_t)(-a + ph - st);  // h (align.cpp:263)
-            }
-        }
-        uint32_t sub_pre = sub_n;  // inclusive prefix over lanes
+    uint32_t rw[9], rm[9];  // read words + masks in scalar registers
 #pragma unroll
-        for (int o = 1; o < 32; o <<= 1) { uint32_t t = __shfl_up(sub_pre, o); if (lane >= o) sub_pre += t; }
-        const uint32_t total = rl(sub_pre, nsub - 1);
-        sub_pre -= sub_n;
-        if (!COOP && !P.rrbs && heavy_threshold && total >= heavy_threshold) { M.defer = 1; return; }  // M.defer is never set in the heavy kernel
-        if (COOP && !P.rrbs && total >= coop_min) {
-            // ---- cooperative windows ----
-            if (lane < 32) { CL->sub_pre[lane] = sub_pre; CL->sub_n[lane] = sub_n; CL->sub_base[lane] = sub_base; CL->sub_h[lane] = sub_h; }
-            if (lane < 9) { CL->rw[lane] = L.w[orient][lane]; CL->rm[lane] = L.m[orient][lane]; }
-            if (lane == 0) { CL->nwords = nwords; CL->len = M.len; CL->nsub = (uint32_t)nsub; CL->total = total; }
-            uint32_t c = 0;
-            bool stop = false;
-            while (c < total && !stop) {
-                if (lane == 0) { CL->cmd = 0; CL->thres = M.snp_thres; CL->win_c0 = c; }
-                __syncthreads();
-                coop_scan_share(P, BL, *CL, surv, 0, lane);
-                __syncthreads();
-                const uint32_t win_n = min((uint32_t)COOP_WIN, total - c);
-                int event = 0; uint32_t X = 0;
-                for (int v = 0; v < COOP_WAVES && !event; v++) {
-                    const uint32_t nv = CL->cnt[v];
-                    for (uint32_t base = 0; base < nv && !event; base += 64) {
-                        const uint32_t i = base + lane;
-                        SurvRec r = {0, 0, 0, 0};
-                        if (i < nv) r = surv[(size_t)v * (COOP_CHUNKS * 64) + i];
-                        u64 m = __ballot(i < nv);
-                        while (m) {
-                            const int ls = (int)__builtin_ctzll(m);
-                            m &= m - 1;
-                            const uint32_t wo = rl(r.w_ord, ls);
-                            const int e = accept_survivor(P, M, SL, orient, mode, wo & 0xff, rl(r.hchr, ls), rl(r.hloc, ls), rl(r.hkey, ls), lane);
-                            if (e) { event = e; X = wo >> 8; break; }
-                        }
-                    }
-                }
-                if (!event) {
-                    const uint32_t v = lane < COOP_WAVES ? lane : 0;
-                    const bool on = lane < COOP_WAVES;
-                    C.n_cand += wave_sum(on ? CL->acc[v][0] : 0);
-                    C.sum_w += wave_sum(on ? CL->acc[v][1] + 2 * CL->acc[v][2] + 5 * CL->acc[v][3] : 0);
-                    c += win_n;
-                } else {  // count exactly the candidates up to and including the one that caused the event
-                    uint32_t nc = 0, sw = 0;
-                    for (uint32_t base = 0; base <= X; base += 64) {
-                        const uint32_t i = base + lane;
-                        const uint32_t cls = i <= X ? CL->wcls[i] : 0;
-                        nc += cls != 0; sw += cls;
-                    }
-                    C.n_cand += wave_sum(nc); C.sum_w += wave_sum(sw);
-                    if (event == 2) stop = true;
-                    c += X + 1;
-                }
+    for (int t = 0; t < 9; t++) { rw[t] = rfl(L.w[orient][t]); rm[t] = rfl(L.m[orient][t]); }
+    const int cmode = M.len / P.seed_size - 1 - seg;  // cmodeindex (align.cpp:221)
+    int status = 0;
+    for (uint32_t c0 = c_begin; c0 < c_end; c0 += 64) {
+        const uint32_t idx = c0 + lane;
+        bool valid = idx < c_end;
+        uint32_t p = 0, strand = 0, rchr = 0;
+        if (P.rrbs) {
+            if (valid) {
+                const U2 e = *reinterpret_cast<const U2 *>(P.entries + 2 * (size_t)(rl(cl.sub_base, 0) + idx));
+                const uint32_t h = rl(cl.sub_h, 0);
+                const bool tag_ok = orient ? (((e.a ^ 0x1000000u) >> 16) == (uint32_t)cmode) : ((e.a >> 16) == (uint32_t)seg);
+                rchr = e.a & 0xffff;
+                valid = tag_ok && e.b >= h;  // mode or strand not match / underflow the start of refseq
+                strand = rchr & 1;
+                p = (lds_chr ? BL.anchor[rchr >> 1] : P.anchor[rchr >> 1]) + (e.b - h);
             }
-            if (stop) { wave_fence(); return; }
-            continue;
+        } else {
+            uint32_t e_idx = 0, h = 0;
+            for (int s = 0; s < cl.nsub; s++) {
+                const uint32_t ps = rl(cl.sub_pre, s), ns = rl(cl.sub_n, s);
+                if (idx >= ps && idx < ps + ns) { e_idx = rl(cl.sub_base, s) + (idx - ps); h = rl(cl.sub_h, s); strand = s & 1; }
+            }
+            if (valid) p = P.entries[e_idx] + h;
         }
-        // ---- one wave, 64 candidates at a time ----
-        uint32_t rw[9], rm[9];  // read words + masks in scalar registers
-#pragma unroll
-        for (int t = 0; t < 9; t++) { rw[t] = rfl(L.w[orient][t]); rm[t] = rfl(L.m[orient][t]); }
-        const int cmode = M.len / P.seed_size - 1 - seg;  // cmodeindex (align.cpp:221)
-        for (uint32_t c0 = 0; c0 < total; c0 += 64) {
-            const uint32_t idx = c0 + lane;
-            bool valid = idx < total;
-            uint32_t p = 0, strand = 0, rchr = 0;
-            if (P.rrbs) {
-                if (valid) {
-                    const U2 e = *reinterpret_cast<const U2 *>(P.entries + 2 * (size_t)(rl(sub_base, 0) + idx));
-                    const uint32_t h = rl(sub_h, 0);
-                    const bool tag_ok = orient ? (((e.a ^ 0x1000000u) >> 16) == (uint32_t)cmode) : ((e.a >> 16) == (uint32_t)seg);
-                    rchr = e.a & 0xffff;
-                    valid = tag_ok && e.b >= h;  // mode or strand not match / underflow the start of refseq
-                    strand = rchr & 1;
-                    p = (lds_chr ? BL.anchor[rchr >> 1] : P.anchor[rchr >> 1]) + (e.b - h);
-                }
-            } else {
-                uint32_t e_idx = 0, h = 0;
-                for (int s = 0; s < 2 * I; s++) {
-                    const uint32_t ps = rl(sub_pre, s), ns = rl(sub_n, s);
-                    if (idx >= ps && idx < ps + ns) { e_idx = rl(sub_base, s) + (idx - ps); h = rl(sub_h, s); strand = s & 1; }
-                }
-                if (valid) p = P.entries[e_idx] + h;
-            }
-            CandEval ev = {0xffff, 0, 0, 0};
-            const uint32_t thres0 = M.snp_thres;
-            if (valid) ev = eval_candidate(P, rw, rm, nwords, p, strand, thres0);
+        CandEval ev = {0xffff, 0, 0, 0};
+        const uint32_t thres0 = COUNT_ONLY ? thres_fixed : M.snp_thres;
+        if (valid) ev = eval_candidate(P, rw, rm, nwords, p, strand, thres0);
+        uint32_t thr_eff = thres0;
+        bool alive = valid, stop = false;
+        if (!COUNT_ONLY) {
             const uint32_t w = ev.w;
-            // per-lane hit coordinates for lanes that pass the current threshold
-            bool pass = valid && w <= thres0;
+            bool pass = valid && w <= thres0;  // per-lane hit coordinates for lanes that pass the current threshold
             uint32_t hchr = 0, hloc = 0, hkey = 0;
             if (pass) {
                 if (P.rrbs) {
@@ -685,38 +577,49 @@ __device__ void snp_align(const DevParams &P, const BlockLds &BL, const MateLds 
                     if ((u64)loc + (u64)M.len > (u64)sz) pass = false;
                 } else pass = hit_coords(P, BL, p, strand, M.len, hchr, hloc, hkey);
             }
-            // ordered replay of the survivors
-            uint32_t thr_eff = thres0;
-            bool alive = valid, stop = false;
-            u64 surv_m = __ballot(pass);
+            u64 surv_m = __ballot(pass);  // ordered replay of the survivors
             while (surv_m) {
                 const int ls = (int)__builtin_ctzll(surv_m);
                 surv_m &= surv_m - 1;
                 const int e = accept_survivor(P, M, SL, orient, mode, rl(w, ls), rl(hchr, ls), rl(hloc, ls), rl(hkey, ls), lane);
-                if (e == 1) { if (lane > ls) thr_eff = M.snp_thres; }
+                if (e == 1) { status = 1; if (lane > ls) thr_eff = M.snp_thres; }
                 else if (e == 2) { if (lane > ls) alive = false; stop = true; break; }
             }
-            // work accounting exactly as the reference's CountMismatch early-outs (align.h:189-197)
-            {
-                const bool one = alive && ev.w0ref > thr_eff;
-                const bool two = alive && !one && (ev.p48 > thr_eff || ev.w01ref > thr_eff);
-                const bool five = alive && !one && !two;
-                C.n_cand += (u64)__builtin_popcountll(__ballot(alive));
-                C.sum_w += (u64)__builtin_popcountll(__ballot(one)) + 2ull * __builtin_popcountll(__ballot(two)) + 5ull * __builtin_popcountll(__ballot(five));
-            }
-            if (stop) { wave_fence(); return; }
         }
+        // work accounting exactly as the reference's CountMismatch early-outs (align.h:189-197)
+        {
+            const bool one = alive && ev.w0ref > thr_eff;
+            const bool two = alive && !one && (ev.p48 > thr_eff || ev.w01ref > thr_eff);
+            const bool five = alive && !one && !two;
+            C.n_cand += (u64)__builtin_popcountll(__ballot(alive));
+            C.sum_w += (u64)__builtin_popcountll(__ballot(one)) + 2ull * __builtin_popcountll(__ballot(two)) + 5ull * __builtin_popcountll(__ballot(five));
+        }
+        if (stop) return 2;
+    }
+    return status;
+}
+
+// SnpAlign (align.cpp:168-347) in the main kernel.  A WGBS list of heavy_threshold candidates or more sets M.defer and
+// returns: the unit is redone from scratch by the heavy pipeline, which scans such lists with the whole chip.
+__device__ void snp_align(const DevParams &P, const BlockLds &BL, const MateLds &L, Mate &M, const Slab &SL, int mode, int lane,
+                          Counters &C, uint32_t heavy_threshold)
+{
+    for (int orient = 0; orient < 2; orient++) {
+        if (!((M.flags >> orient) & 1)) continue;
+        const int seg = L.order[orient][mode];  // modeindex
+        const CandList cl = make_list(P, BL, L, M, orient, seg, lane);
+        if (!P.rrbs && heavy_threshold && cl.total >= heavy_threshold) { M.defer = 1; return; }
+        if (wave_scan_range<false>(P, BL, L, M, SL, cl, orient, seg, mode, 0, cl.total, 0, lane, C) == 2) { wave_fence(); return; }
     }
     wave_fence();
 }
 
 // SingleAlign::RunAlign (align.cpp:435-452) after packing/planning
-template <bool COOP>
 __device__ void run_align_single(const DevParams &P, const BlockLds &BL, const MateLds &L, Mate &M, const Slab &SL, int lane, Counters &C,
-                                 uint32_t heavy_threshold, CoopLds *CL, SurvRec *surv)
+                                 uint32_t heavy_threshold)
 {
     for (int i = 0; i < M.seedseg; i++) {
-        snp_align<COOP>(P, BL, L, M, SL, i, lane, C, heavy_threshold, CL, surv);
+        snp_align(P, BL, L, M, SL, i, lane, C, heavy_threshold);
         if (M.defer) return;
         if (!P.rrbs) {
             const u64 nz = __ballot(M.cnt_reg != 0 && (lane & 15) <= i && lane < 32);
@@ -870,78 +773,77 @@ __device__ int get_pairs(const DevParams &P, const Mate &MA, const Mate &MB, con
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// one unit (read or read pair) from load to result record; returns true if the unit was deferred to the heavy kernel
+// per-unit set-up and result record (shared by the main kernel and the heavy pipeline)
 // ---------------------------------------------------------------------------------------------------------------
-template <bool PE, bool COOP>
-__device__ bool process_unit(const AlignArgs &A, const BlockLds &BL, MateLds &LA, MateLds &LB, uint32_t unit, uint8_t *slab, int lane,
-                             Counters &C, u64 &n_aligned, u64 &n_aligned_pairs, CoopLds *CL, SurvRec *surv)
+struct UnitSlabs { Slab SA, SB; PairSlab PS; };
+
+__device__ __forceinline__ UnitSlabs carve_slab(uint8_t *slab, uint32_t nclass, uint32_t rowcap, bool pe)
+{
+    UnitSlabs U;
+    U.SA.rowcap = U.SB.rowcap = rowcap; U.SA.nclass = U.SB.nclass = nclass;
+    U.SA.hits = (u64 *)slab;
+    U.SA.keys = (uint32_t *)(U.SA.hits + (size_t)2 * (nclass + 1) * rowcap);
+    U.SA.kslot = U.SA.keys + (size_t)(nclass + 1) * rowcap;
+    U.SA.hset = U.SA.kslot + (size_t)(nclass + 1) * rowcap;
+    U.SA.tmp = (u64 *)(U.SA.hset + BSX_HSET_SLOTS);
+    uint8_t *after_a = (uint8_t *)(U.SA.tmp + BSX_SORT_TMP);
+    U.SB = U.SA;
+    U.PS.rows = nullptr; U.PS.rowcap = rowcap;
+    if (pe) {
+        U.SB.hits = (u64 *)after_a;
+        U.SB.keys = (uint32_t *)(U.SB.hits + (size_t)2 * (nclass + 1) * rowcap);
+        U.SB.kslot = U.SB.keys + (size_t)(nclass + 1) * rowcap;
+        U.SB.hset = U.SB.kslot + (size_t)(nclass + 1) * rowcap;
+        U.SB.tmp = (u64 *)(U.SB.hset + BSX_HSET_SLOTS);
+        U.PS.rows = (uint32_t *)(U.SB.tmp + BSX_SORT_TMP);
+    }
+    return U;
+}
+
+// FilterReads + ConvertBinaySeq + ReorderSeed for the mate(s) of a unit
+template <bool PE>
+__device__ void unit_prepare(const AlignArgs &A, const BlockLds &BL, MateLds &LA, MateLds &LB, Mate &MA, Mate &MB, uint32_t unit, int lane, Counters &C)
 {
     const DevParams &P = A.P;
-    const uint32_t nclass = (uint32_t)P.max_snp_num + 1, rowcap = A.rowcap;
-    const uint32_t hthr = A.heavy_threshold;
-    const Counters C0 = C;
-    Slab SA, SB;
-    SA.rowcap = SB.rowcap = rowcap; SA.nclass = SB.nclass = nclass;
-    SA.hits = (u64 *)slab;
-    SA.keys = (uint32_t *)(SA.hits + (size_t)2 * (nclass + 1) * rowcap);
-    SA.kslot = SA.keys + (size_t)(nclass + 1) * rowcap;
-    SA.hset = SA.kslot + (size_t)(nclass + 1) * rowcap;
-    SA.tmp = (u64 *)(SA.hset + BSX_HSET_SLOTS);
-    uint8_t *after_a = (uint8_t *)(SA.tmp + BSX_SORT_TMP);
-    SB = SA;
-    PairSlab PS{nullptr, rowcap};
-    if (PE) {
-        SB.hits = (u64 *)after_a;
-        SB.keys = (uint32_t *)(SB.hits + (size_t)2 * (nclass + 1) * rowcap);
-        SB.kslot = SB.keys + (size_t)(nclass + 1) * rowcap;
-        SB.hset = SB.kslot + (size_t)(nclass + 1) * rowcap;
-        SB.tmp = (u64 *)(SB.hset + BSX_HSET_SLOTS);
-        PS.rows = (uint32_t *)(SB.tmp + BSX_SORT_TMP);
-    }
-    Mate MA, MB;
     MA.index = MB.index = A.first_index + unit;
     load_and_filter(A, LA, MA, 0, unit, lane);
     if (PE) load_and_filter(A, LB, MB, 1, unit, lane);
+    else MB = MA;
+    if (!MA.filtered) {
+        pack_read(P, LA, MA, PE ? 1 : 0, lane, C);
+        for (int o = 0; o < 2; o++) if ((MA.flags >> o) & 1) plan_orient(P, BL, LA, MA, o, lane, C);  // pairs.cpp:160 / align.cpp:444
+    }
+    if (PE && !MB.filtered) {
+        pack_read(P, LB, MB, 2, lane, C);
+        for (int o = 0; o < 2; o++) if ((MB.flags >> o) & 1) plan_orient(P, BL, LB, MB, o, lane, C);
+    }
+}
+
+// one level of PairAlign::RunAlign after both SnpAlign calls (pairs.cpp:167-171): sort class `level`, join
+__device__ int pair_level_post(const DevParams &P, const Mate &MA, const Mate &MB, const UnitSlabs &U, uint32_t &pcnt_reg, int i, int lane)
+{
+    if (i <= MA.max_snp) { sort_list(U.SA.list(0, i), n_of(MA, 0, i), U.SA.tmp, lane); sort_list(U.SA.list(1, i), n_of(MA, 1, i), U.SA.tmp, lane); }
+    if (i <= MB.max_snp) { sort_list(U.SB.list(0, i), n_of(MB, 0, i), U.SB.tmp, lane); sort_list(U.SB.list(1, i), n_of(MB, 1, i), U.SB.tmp, lane); }
+    int n = get_pairs(P, MA, MB, U.SA, U.SB, U.PS, pcnt_reg, i, i, lane);
+    for (int j = 0; j < i; j++) n += get_pairs(P, MA, MB, U.SA, U.SB, U.PS, pcnt_reg, i, j, lane) + get_pairs(P, MA, MB, U.SA, U.SB, U.PS, pcnt_reg, j, i, lane);
+    return n;
+}
+
+// StringAlign / StringAlignPair / StringAlignUnpair selection, result records, clean-up
+template <bool PE>
+__device__ void unit_finish(const AlignArgs &A, const MateLds &LA, const MateLds &LB, Mate &MA, Mate &MB, const UnitSlabs &U, uint32_t pcnt_reg, int paired,
+                            uint32_t unit, int lane, u64 &n_aligned, u64 &n_aligned_pairs)
+{
+    const DevParams &P = A.P;
     if (!PE) {
-        if (!MA.filtered) {
-            pack_read(P, LA, MA, 0, lane, C);
-            for (int o = 0; o < 2; o++) if ((MA.flags >> o) & 1) plan_orient(P, BL, LA, MA, o, lane, C);
-            run_align_single<COOP>(P, BL, LA, MA, SA, lane, C, hthr, CL, surv);
-            if (MA.defer) { forget_keys(MA, SA, lane); if (PE) forget_keys(MB, SB, lane); C = C0; return true; }
-        }
         bsx_hit out;
-        select_hit(P, MA, SA, out, false);
+        select_hit(P, MA, U.SA, out, false);
         if (lane == 0) A.hits_out[unit] = out;
         if (A.cc[0] && lane < 32) { uint16_t *cc = (uint16_t *)&A.cc[0][unit]; cc[lane] = (uint16_t)MA.cnt_reg; }
         if (A.debug && lane < 32) { A.dbg_plan[(size_t)unit * 128 + lane] = LA.start[lane >> 4][lane & 15]; A.dbg_plan[(size_t)unit * 128 + 32 + lane] = LA.order[lane >> 4][lane & 15]; }
         if (out.n_best == 1 || (out.n_best > 1 && P.report_repeat_hits == 1)) n_aligned++;
-        forget_keys(MA, SA, lane);
-        return false;
-    }
-    uint32_t pcnt_reg = 0;  // lane c holds _cur_n_hits[c]
-    int paired = 0;
-    if (!MA.filtered) { pack_read(P, LA, MA, 1, lane, C); }
-    if (!MB.filtered) { pack_read(P, LB, MB, 2, lane, C); }
-    // ReorderSeed for both mates (pairs.cpp:160) — also when only one mate survives (SingleAlign::RunAlign)
-    if (!MA.filtered) for (int o = 0; o < 2; o++) if ((MA.flags >> o) & 1) plan_orient(P, BL, LA, MA, o, lane, C);
-    if (!MB.filtered) for (int o = 0; o < 2; o++) if ((MB.flags >> o) & 1) plan_orient(P, BL, LB, MB, o, lane, C);
-    if (!MA.filtered && !MB.filtered) {
-        // PairAlign::RunAlign (pairs.cpp:163-172)
-        const int maxi = max(MA.max_snp, MB.max_snp);
-        for (int i = 0; i <= maxi && !paired; i++) {
-            if (i < MA.seedseg) snp_align<COOP>(P, BL, LA, MA, SA, i, lane, C, hthr, CL, surv);
-            if (MA.defer) { forget_keys(MA, SA, lane); if (PE) forget_keys(MB, SB, lane); C = C0; return true; }
-            if (i < MB.seedseg) snp_align<COOP>(P, BL, LB, MB, SB, i, lane, C, hthr, CL, surv);
-            if (MB.defer) { forget_keys(MA, SA, lane); forget_keys(MB, SB, lane); C = C0; return true; }
-            if (i <= MA.max_snp) { sort_list(SA.list(0, i), n_of(MA, 0, i), SA.tmp, lane); sort_list(SA.list(1, i), n_of(MA, 1, i), SA.tmp, lane); }
-            if (i <= MB.max_snp) { sort_list(SB.list(0, i), n_of(MB, 0, i), SB.tmp, lane); sort_list(SB.list(1, i), n_of(MB, 1, i), SB.tmp, lane); }
-            int n = get_pairs(P, MA, MB, SA, SB, PS, pcnt_reg, i, i, lane);
-            for (int j = 0; j < i; j++) n += get_pairs(P, MA, MB, SA, SB, PS, pcnt_reg, i, j, lane) + get_pairs(P, MA, MB, SA, SB, PS, pcnt_reg, j, i, lane);
-            if (n > 0) paired = i + 1;
-        }
-    } else {
-        if (!MA.filtered) { run_align_single<COOP>(P, BL, LA, MA, SA, lane, C, hthr, CL, surv); if (MA.defer) { forget_keys(MA, SA, lane); if (PE) forget_keys(MB, SB, lane); C = C0; return true; } }
-        if (!MB.filtered) { run_align_single<COOP>(P, BL, LB, MB, SB, lane, C, hthr, CL, surv); if (MB.defer) { forget_keys(MA, SA, lane); forget_keys(MB, SB, lane); C = C0; return true; } }
+        forget_keys(MA, U.SA, lane);
+        return;
     }
     bsx_pair out;
     out.a_chr = out.a_loc = out.b_chr = out.b_loc = 0; out.insert = 0; out.n_pairs = 0; out.pair_class = -1; out.chain = 0;
@@ -955,7 +857,7 @@ __device__ bool process_unit(const AlignArgs &A, const BlockLds &BL, MateLds &LA
             if (n == 1) j = 0;
             else if (P.report_repeat_hits == 1) j = (int)(bsx_myrand(MA.index, P.randseed) % n);
             if (j >= 0) {
-                const uint32_t *o = PS.row(c) + (size_t)j * 6;
+                const uint32_t *o = U.PS.row(c) + (size_t)j * 6;
                 out.chain = (uint8_t)(o[0] & 0xffff); out.na = (uint8_t)((o[0] >> 16) & 0xff); out.nb = (uint8_t)(o[0] >> 24);
                 out.insert = (int32_t)o[1]; out.a_chr = o[2]; out.a_loc = o[3]; out.b_chr = o[4]; out.b_loc = o[5];
                 out.unpaired_out = 0;
@@ -963,9 +865,9 @@ __device__ bool process_unit(const AlignArgs &A, const BlockLds &BL, MateLds &LA
             break;
         }
     }
-    if (P.rrbs && out.unpaired_out) { fix_unpaired_short_fragment(P, MA, SA, lane); fix_unpaired_short_fragment(P, MB, SB, lane); }  // pairs.cpp:250-253
-    select_hit(P, MA, SA, out.a, true);
-    select_hit(P, MB, SB, out.b, true);
+    if (P.rrbs && out.unpaired_out) { fix_unpaired_short_fragment(P, MA, U.SA, lane); fix_unpaired_short_fragment(P, MB, U.SB, lane); }  // pairs.cpp:250-253
+    select_hit(P, MA, U.SA, out.a, true);
+    select_hit(P, MB, U.SB, out.b, true);
     if (lane == 0) A.pairs_out[unit] = out;
     if (A.cc[0] && lane < 32) { ((uint16_t *)&A.cc[0][unit])[lane] = (uint16_t)MA.cnt_reg; ((uint16_t *)&A.cc[1][unit])[lane] = (uint16_t)MB.cnt_reg; }
     if (A.npairs_out && lane < 32) A.npairs_out[(size_t)unit * 32 + lane] = (uint16_t)pcnt_reg;
@@ -978,7 +880,37 @@ __device__ bool process_unit(const AlignArgs &A, const BlockLds &BL, MateLds &LA
         if (out.a.n_best == 1 || (out.a.n_best > 1 && P.report_repeat_hits == 1)) n_aligned++;
         if (out.b.n_best == 1 || (out.b.n_best > 1 && P.report_repeat_hits == 1)) n_aligned++;
     }
-    forget_keys(MA, SA, lane); forget_keys(MB, SB, lane);
+    forget_keys(MA, U.SA, lane); forget_keys(MB, U.SB, lane);
+}
+
+// one unit in the main kernel; returns true if it was deferred to the heavy pipeline
+template <bool PE>
+__device__ bool process_unit(const AlignArgs &A, const BlockLds &BL, MateLds &LA, MateLds &LB, uint32_t unit, uint8_t *slab, int lane, Counters &C,
+                             u64 &n_aligned, u64 &n_aligned_pairs)
+{
+    const DevParams &P = A.P;
+    const uint32_t hthr = A.heavy_threshold;
+    const Counters C0 = C;
+    const UnitSlabs U = carve_slab(slab, (uint32_t)P.max_snp_num + 1, A.rowcap, PE);
+    Mate MA, MB;
+    unit_prepare<PE>(A, BL, LA, LB, MA, MB, unit, lane, C);
+    uint32_t pcnt_reg = 0;  // lane c holds _cur_n_hits[c]
+    int paired = 0;
+    bool defer = false;
+    if (PE && !MA.filtered && !MB.filtered) {
+        const int maxi = max(MA.max_snp, MB.max_snp);  // PairAlign::RunAlign (pairs.cpp:163-172)
+        for (int i = 0; i <= maxi && !paired && !defer; i++) {
+            if (i < MA.seedseg) snp_align(P, BL, LA, MA, U.SA, i, lane, C, hthr);
+            if (!MA.defer && i < MB.seedseg) snp_align(P, BL, LB, MB, U.SB, i, lane, C, hthr);
+            if (MA.defer || MB.defer) { defer = true; break; }
+            if (pair_level_post(P, MA, MB, U, pcnt_reg, i, lane) > 0) paired = i + 1;
+        }
+    } else {
+        if (!MA.filtered) { run_align_single(P, BL, LA, MA, U.SA, lane, C, hthr); defer = MA.defer; }
+        if (PE && !defer && !MB.filtered) { run_align_single(P, BL, LB, MB, U.SB, lane, C, hthr); defer = MB.defer; }
+    }
+    if (defer) { forget_keys(MA, U.SA, lane); if (PE) forget_keys(MB, U.SB, lane); C = C0; return true; }
+    unit_finish<PE>(A, LA, LB, MA, MB, U, pcnt_reg, paired, unit, lane, n_aligned, n_aligned_pairs);
     return false;
 }
 
@@ -1026,7 +958,7 @@ __global__ __launch_bounds__(256, PE ? BSX_WAVES_PER_EU_PE : BSX_WAVES_PER_EU_SE
         if (unit >= A.n_units) break;
         const u64 t_begin = A.dbg_cycles ? __builtin_readcyclecounter() : 0;
         uint8_t *slab = A.scratch + (size_t)(A.debug ? unit : slot) * A.slab_bytes;
-        const bool deferred = process_unit<PE, false>(A, BL, LA, LB, unit, slab, lane, C, n_aligned, n_aligned_pairs, nullptr, nullptr);
+        const bool deferred = process_unit<PE>(A, BL, LA, LB, unit, slab, lane, C, n_aligned, n_aligned_pairs);
         if (deferred) { if (lane == 0) A.heavy_list[atomicAdd(A.heavy_count, 1u)] = unit; }
         else n_units_done++;
         if (A.dbg_cycles && lane == 0) A.dbg_cycles[unit] = (uint32_t)min((u64)0xffffffffull, (u64)__builtin_readcyclecounter() - t_begin);
@@ -1035,62 +967,368 @@ __global__ __launch_bounds__(256, PE ? BSX_WAVES_PER_EU_PE : BSX_WAVES_PER_EU_SE
     if (lane == 0) flush_counters(A, C, n_units_done, n_aligned, n_aligned_pairs);
 }
 
-// heavy kernel: one 16-wave workgroup per deferred unit; wave 0 owns the unit, all waves scan big candidate lists
+// ---------------------------------------------------------------------------------------------------------------
+// heavy pipeline: units whose candidate lists are too long for one wave
+// ---------------------------------------------------------------------------------------------------------------
+// A bucket of a low-complexity seed holds up to millions of entries and the reference walks it candidate by candidate.
+// Deferred units advance in lock-step iterations of two kernels:
+//   k_hctrl : one wave per unit runs the unit's control flow (exactly the main kernel's logic) until it needs a long
+//             list scanned; it then publishes a window of that list as tasks of HS_TASK candidates and saves its state
+//   k_hscan : every wave of the chip pulls tasks, evaluates their candidates and leaves an ordered survivor record
+// The owner replays the survivors in order on the next k_hctrl pass.  An event that lowers the threshold or ends the
+// call cuts the window right after the candidate that caused it, so every candidate is still evaluated under exactly
+// the threshold the reference would have used: results and work counters are bit-identical to the one-wave path.
+// Windows grow geometrically (x4) so that an early exit wastes at most a bounded amount of scanning.
+#ifndef HS_TASK
+#define HS_TASK 8192u
+#endif
+#ifndef HS_SCAP
+#define HS_SCAP 128u
+#endif
+#ifndef HS_WIN0
+#define HS_WIN0 16384u
+#endif
+#ifndef HS_WINMAX
+#define HS_WINMAX (1u << 22)
+#endif
+
+struct SurvRec { uint32_t w_ord, hchr, hloc, hkey; };  // w in bits 0-7, ordinal inside the task in bits 8+
+
+struct ListReq { uint32_t nsub, total, nwords, len, thres, pad[3]; uint32_t sub_pre[32], sub_n[32], sub_base[32], sub_h[32]; uint32_t rw[12], rm[12]; };
+struct HMate {
+    int32_t len, raw_len, max_snp, seedseg, filtered;
+    uint32_t flags, snp_thres, nkeys, index, pad[7];
+    uint32_t cnt_reg[64], key_reg[64], bloom0[64], bloom1[64];
+    uint32_t w[2][10], m[2][10];
+    uint8_t start[2][16], order[2][16];
+};
+struct HState {
+    int32_t stage, level, sub, orient;
+    uint32_t c, W;
+    int32_t paired, have;
+    uint32_t t0, n_tasks, win_c0, win_n;  // the published window: tasks t0.. cover candidates [win_c0, win_c0+win_n)
+    Counters C;
+    uint32_t pcnt_reg[64];
+    HMate mate[2];
+    ListReq req;
+};
+struct HTask { uint32_t h, c0, n, pad; };
+struct HTaskOut { uint32_t count, overflow, acc[4], pad[2]; SurvRec surv[HS_SCAP]; };
+struct HeavyArgs {
+    HState *state; uint8_t *slabs; uint32_t *active_in, *active_out, *n_active_out; HTask *tasks; HTaskOut *tout; uint32_t *n_tasks, *queue;
+    uint32_t n_active_in, task_cap, fresh, list_base;
+};
+__host__ HeavyArgs typed(const HeavyArgsRaw &r)
+{
+    HeavyArgs h;
+    h.state = (HState *)r.state; h.slabs = r.slabs; h.active_in = r.active_in; h.active_out = r.active_out; h.n_active_out = r.n_active_out;
+    h.tasks = (HTask *)r.tasks; h.tout = (HTaskOut *)r.tout; h.n_tasks = r.n_tasks; h.queue = r.queue;
+    h.n_active_in = r.n_active_in; h.task_cap = r.task_cap; h.fresh = r.fresh; h.list_base = r.list_base;
+    return h;
+}
+
+__device__ void save_mate(HMate &d, const Mate &M, const MateLds &L, int lane)
+{
+    if (lane == 0) {
+        d.len = M.len; d.raw_len = M.raw_len; d.max_snp = M.max_snp; d.seedseg = M.seedseg; d.filtered = M.filtered;
+        d.flags = M.flags; d.snp_thres = M.snp_thres; d.nkeys = M.nkeys; d.index = M.index;
+    }
+    d.cnt_reg[lane] = M.cnt_reg; d.key_reg[lane] = M.key_reg; d.bloom0[lane] = M.bloom0; d.bloom1[lane] = M.bloom1;
+    if (lane < 20) { (&d.w[0][0])[lane] = (&L.w[0][0])[lane]; (&d.m[0][0])[lane] = (&L.m[0][0])[lane]; }
+    if (lane < 32) { (&d.start[0][0])[lane] = (&L.start[0][0])[lane]; (&d.order[0][0])[lane] = (&L.order[0][0])[lane]; }
+}
+
+__device__ void load_mate(const HMate &d, Mate &M, MateLds &L, int lane)
+{
+    M.len = (int)rfl((uint32_t)d.len); M.raw_len = (int)rfl((uint32_t)d.raw_len); M.max_snp = (int)rfl((uint32_t)d.max_snp);
+    M.seedseg = (int)rfl((uint32_t)d.seedseg); M.filtered = (int)rfl((uint32_t)d.filtered);
+    M.flags = rfl(d.flags); M.snp_thres = rfl(d.snp_thres); M.nkeys = rfl(d.nkeys); M.index = rfl(d.index);
+    M.defer = 0;
+    M.cnt_reg = d.cnt_reg[lane]; M.key_reg = d.key_reg[lane]; M.bloom0 = d.bloom0[lane]; M.bloom1 = d.bloom1[lane];
+    if (lane < 20) { (&L.w[0][0])[lane] = (&d.w[0][0])[lane]; (&L.m[0][0])[lane] = (&d.m[0][0])[lane]; }
+    if (lane < 32) { (&L.start[0][0])[lane] = (&d.start[0][0])[lane]; (&L.order[0][0])[lane] = (&d.order[0][0])[lane]; }
+    wave_fence();
+}
+
+struct HCursor { int level, sub, orient, have, paired; uint32_t c, W; };
+
+// resumable SnpAlign for a deferred unit: 0 = call complete, 1 = the reference's SnpAlign returned early, 2 = a window
+// of the current list was published and the unit must wait for k_hscan
+__device__ int snp_align_heavy(const AlignArgs &A, const HeavyArgs &H, HState *S, uint32_t hidx, const BlockLds &BL, const MateLds &L, Mate &M,
+                               const Slab &SL, int mode, HCursor &K, int lane, Counters &C)
+{
+    const DevParams &P = A.P;
+    for (; K.orient < 2; K.orient++, K.c = 0, K.W = HS_WIN0) {
+        const int orient = K.orient;
+        if (!((M.flags >> orient) & 1)) continue;
+        const int seg = L.order[orient][mode];
+        const CandList cl = make_list(P, BL, L, M, orient, seg, lane);
+        if (cl.total < A.heavy_threshold) {  // short list: the owning wave scans it itself
+            if (wave_scan_range<false>(P, BL, L, M, SL, cl, orient, seg, mode, 0, cl.total, 0, lane, C) == 2) { wave_fence(); return 1; }
+            continue;
+        }
+        while (K.c < cl.total) {
+            if (K.have) {
+                K.have = 0;
+                // (task descriptors in the pool may already have been reused by other units of this pass: the window is
+                //  reconstructed from the unit's own state, only the task OUTPUTS are read from the pool)
+                const uint32_t t0 = rfl(S->t0), nt = rfl(S->n_tasks), req_thres = rfl(S->req.thres), win_c0 = rfl(S->win_c0), win_n = rfl(S->win_n);
+                bool restart = false;
+                for (uint32_t t = 0; t < nt && !restart; t++) {
+                    const uint32_t tc0 = win_c0 + t * HS_TASK, tn = min((uint32_t)HS_TASK, win_n - t * HS_TASK);
+                    const HTaskOut *o = &H.tout[t0 + t];
+                    if (rfl(o->overflow)) {  // too many survivors for the record: redo this task with the one-wave path
+                        const int r = wave_scan_range<false>(P, BL, L, M, SL, cl, orient, seg, mode, tc0, tc0 + tn, 0, lane, C);
+                        if (r == 2) { wave_fence(); return 1; }
+                        K.c = tc0 + tn;
+                        if (r == 1) restart = true;  // later tasks were evaluated under the old threshold
+                        continue;
+                    }
+                    int event = 0; uint32_t X = 0;
+                    const uint32_t nv = rfl(o->count);
+                    for (uint32_t base = 0; base < nv && !event; base += 64) {
+                        const uint32_t i = base + lane;
+                        SurvRec r = {0, 0, 0, 0};
+                        if (i < nv) r = o->surv[i];
+                        u64 m = __ballot(i < nv);
+                        while (m) {
+                            const int ls = (int)__builtin_ctzll(m);
+                            m &= m - 1;
+                            const uint32_t wo = rl(r.w_ord, ls);
+                            const int e = accept_survivor(P, M, SL, orient, mode, wo & 0xff, rl(r.hchr, ls), rl(r.hloc, ls), rl(r.hkey, ls), lane);
+                            if (e) { event = e; X = tc0 + (wo >> 8); break; }
+                        }
+                    }
+                    if (!event) {
+                        C.n_cand += rfl(o->acc[0]);
+                        C.sum_w += (u64)rfl(o->acc[1]) + 2ull * rfl(o->acc[2]) + 5ull * rfl(o->acc[3]);
+                        K.c = tc0 + tn;
+                    } else {  // count exactly the candidates up to and including the one that caused the event
+                        wave_scan_range<true>(P, BL, L, M, SL, cl, orient, seg, mode, tc0, X + 1, req_thres, lane, C);
+                        K.c = X + 1;
+                        if (event == 2) { wave_fence(); return 1; }
+                        restart = true;
+                    }
+                }
+                if (!restart) K.W = min(K.W * 4, (uint32_t)HS_WINMAX);
+            } else {
+                const uint32_t wn = min(K.W, cl.total - K.c), nt = (wn + HS_TASK - 1) / HS_TASK;
+                uint32_t t0 = 0;
+                if (lane == 0) t0 = atomicAdd(H.n_tasks, nt);
+                t0 = rfl(t0);
+                if (t0 + nt <= H.task_cap) {
+                    for (uint32_t t = lane; t < nt; t += 64) {
+                        HTask tk; tk.h = hidx; tk.c0 = K.c + t * HS_TASK; tk.n = min((uint32_t)HS_TASK, wn - t * HS_TASK); tk.pad = 0;
+                        H.tasks[t0 + t] = tk;
+                    }
+                    ListReq &R = S->req;
+                    if (lane < 32) { R.sub_pre[lane] = cl.sub_pre; R.sub_n[lane] = cl.sub_n; R.sub_base[lane] = cl.sub_base; R.sub_h[lane] = cl.sub_h; }
+                    if (lane < 9) { R.rw[lane] = L.w[orient][lane]; R.rm[lane] = L.m[orient][lane]; }
+                    if (lane == 0) {
+                        R.nsub = (uint32_t)cl.nsub; R.total = cl.total; R.nwords = (uint32_t)((M.len + 15) >> 4); R.len = (uint32_t)M.len; R.thres = M.snp_thres;
+                        S->t0 = t0; S->n_tasks = nt; S->win_c0 = K.c; S->win_n = wn;
+                    }
+                    K.have = 1;
+                } else if (t0 < H.task_cap) {  // pool exhausted mid-way: neutralise the slots that were reserved
+                    for (uint32_t t = t0 + lane; t < H.task_cap; t += 64) { HTask tk; tk.h = hidx; tk.c0 = 0; tk.n = 0; tk.pad = 0; H.tasks[t] = tk; }
+                }  // the request is repeated in the next iteration
+                wave_fence();
+                return 2;
+            }
+        }
+    }
+    wave_fence();
+    return 0;
+}
+
+// advance a deferred unit as far as possible; true when it is finished
 template <bool PE>
-__global__ __launch_bounds__(COOP_WAVES * 64) void k_align_heavy(AlignArgs A)
+__device__ bool heavy_advance(const AlignArgs &A, const HeavyArgs &H, HState *S, uint32_t hidx, const BlockLds &BL, MateLds &LA, MateLds &LB, Mate &MA,
+                              Mate &MB, const UnitSlabs &U, uint32_t &pcnt_reg, HCursor &K, int lane, Counters &C)
+{
+    const DevParams &P = A.P;
+    if (PE && !MA.filtered && !MB.filtered) {
+        const int maxi = max(MA.max_snp, MB.max_snp);  // PairAlign::RunAlign (pairs.cpp:163-172)
+        for (;;) {
+            if (K.level > maxi) return true;
+            if (K.sub == 0) {
+                if (K.level < MA.seedseg && snp_align_heavy(A, H, S, hidx, BL, LA, MA, U.SA, K.level, K, lane, C) == 2) return false;
+                K.sub = 1; K.orient = 0; K.c = 0; K.W = HS_WIN0; K.have = 0;
+            }
+            if (K.sub == 1) {
+                if (K.level < MB.seedseg && snp_align_heavy(A, H, S, hidx, BL, LB, MB, U.SB, K.level, K, lane, C) == 2) return false;
+                K.sub = 2;
+            }
+            if (pair_level_post(P, MA, MB, U, pcnt_reg, K.level, lane) > 0) { K.paired = K.level + 1; return true; }
+            K.level++; K.sub = 0; K.orient = 0; K.c = 0; K.W = HS_WIN0; K.have = 0;
+        }
+    }
+    // SingleAlign::RunAlign (align.cpp:445-449) for each surviving mate in turn; K.sub selects the mate
+    for (;;) {
+        if (K.sub > (PE ? 1 : 0)) return true;
+        const bool second = K.sub == 1;
+        Mate &M = second ? MB : MA;
+        if (M.filtered || K.level >= M.seedseg) { K.sub++; K.level = 0; K.orient = 0; K.c = 0; K.W = HS_WIN0; K.have = 0; continue; }
+        if (snp_align_heavy(A, H, S, hidx, BL, second ? LB : LA, M, second ? U.SB : U.SA, K.level, K, lane, C) == 2) return false;
+        const u64 nz = __ballot(M.cnt_reg != 0 && (lane & 15) <= K.level && lane < 32);
+        if (nz) { K.sub++; K.level = 0; }
+        else K.level++;
+        K.orient = 0; K.c = 0; K.W = HS_WIN0; K.have = 0;
+    }
+}
+
+template <bool PE>
+__global__ __launch_bounds__(256) void k_hctrl(AlignArgs A, HeavyArgs H)
 {
     __shared__ BlockLds BL;
-    __shared__ WaveLds<PE> WL;
-    __shared__ CoopLds CL;
+    __shared__ WaveLds<PE> WL[4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    init_block_lds(A.P, BL, threadIdx.x, COOP_WAVES * 64);
+    init_block_lds(A.P, BL, threadIdx.x, 256);
     __syncthreads();
-    SurvRec *surv = (SurvRec *)(A.coop_surv + (size_t)blockIdx.x * COOP_WIN * sizeof(SurvRec));
-    if (wv != 0) {
-        for (;;) {
-            __syncthreads();
-            if (CL.cmd == 1) break;
-            coop_scan_share(A.P, BL, CL, surv, wv, lane);
-            __syncthreads();
-        }
-        return;
-    }
-    MateLds &LA = WL.mate[0];
-    MateLds &LB = WL.mate[PE ? 1 : 0];
-    Counters C = {0, 0, 0, 0};
+    MateLds &LA = WL[wv].mate[0];
+    MateLds &LB = WL[wv].mate[PE ? 1 : 0];
+    Counters Cflush = {0, 0, 0, 0};
     u64 n_units_done = 0, n_aligned = 0, n_aligned_pairs = 0;
-    const uint32_t n_heavy = *A.heavy_count;
     for (;;) {
         uint32_t i = 0;
-        if (lane == 0) i = atomicAdd(A.queue + 1, 1u);
+        if (lane == 0) i = atomicAdd(H.queue, 1u);
         i = rfl(i);
-        if (i >= n_heavy) break;
-        const uint32_t unit = A.heavy_list[i];
-        const u64 t_begin = A.dbg_cycles ? __builtin_readcyclecounter() : 0;
-        uint8_t *slab = A.debug ? A.scratch + (size_t)unit * A.slab_bytes : A.scratch_heavy + (size_t)blockIdx.x * A.slab_bytes;
-        process_unit<PE, true>(A, BL, LA, LB, unit, slab, lane, C, n_aligned, n_aligned_pairs, &CL, surv);
-        n_units_done++;
-        if (A.dbg_cycles && lane == 0) A.dbg_cycles[unit] = (uint32_t)min((u64)0xffffffffull, (u64)__builtin_readcyclecounter() - t_begin);
+        if (i >= H.n_active_in) break;
+        const uint32_t hidx = H.fresh ? i : rfl(H.active_in[i]);
+        const uint32_t unit = rfl(A.heavy_list[H.list_base + hidx]);
+        HState *S = &H.state[hidx];
+        uint8_t *slab = A.debug ? A.scratch + (size_t)unit * A.slab_bytes : H.slabs + (size_t)hidx * A.slab_bytes;
+        const UnitSlabs U = carve_slab(slab, (uint32_t)A.P.max_snp_num + 1, A.rowcap, PE);
+        Mate MA, MB;
+        Counters C = {0, 0, 0, 0};
+        HCursor K;
+        uint32_t pcnt_reg = 0;
+        if (H.fresh) {
+            unit_prepare<PE>(A, BL, LA, LB, MA, MB, unit, lane, C);
+            K.level = 0; K.sub = 0; K.orient = 0; K.have = 0; K.paired = 0; K.c = 0; K.W = HS_WIN0;
+        } else {
+            load_mate(S->mate[0], MA, LA, lane);
+            if (PE) load_mate(S->mate[1], MB, LB, lane); else MB = MA;
+            C = S->C;
+            C.n_lookup = (u64)rfl((uint32_t)(C.n_lookup >> 32)) << 32 | rfl((uint32_t)C.n_lookup); C.n_cand = (u64)rfl((uint32_t)(C.n_cand >> 32)) << 32 | rfl((uint32_t)C.n_cand);
+            C.sum_w = (u64)rfl((uint32_t)(C.sum_w >> 32)) << 32 | rfl((uint32_t)C.sum_w); C.n_orient = (u64)rfl((uint32_t)(C.n_orient >> 32)) << 32 | rfl((uint32_t)C.n_orient);
+            pcnt_reg = S->pcnt_reg[lane];
+            K.level = (int)rfl((uint32_t)S->level); K.sub = (int)rfl((uint32_t)S->sub); K.orient = (int)rfl((uint32_t)S->orient);
+            K.have = (int)rfl((uint32_t)S->have); K.paired = (int)rfl((uint32_t)S->paired); K.c = rfl(S->c); K.W = rfl(S->W);
+        }
+        const bool done = heavy_advance<PE>(A, H, S, hidx, BL, LA, LB, MA, MB, U, pcnt_reg, K, lane, C);
+        if (done) {
+            unit_finish<PE>(A, LA, LB, MA, MB, U, pcnt_reg, K.paired, unit, lane, n_aligned, n_aligned_pairs);
+            Cflush.n_lookup += C.n_lookup; Cflush.n_cand += C.n_cand; Cflush.sum_w += C.sum_w; Cflush.n_orient += C.n_orient;
+            n_units_done++;
+        } else {
+            save_mate(S->mate[0], MA, LA, lane);
+            if (PE) save_mate(S->mate[1], MB, LB, lane);
+            S->pcnt_reg[lane] = pcnt_reg;
+            if (lane == 0) {
+                S->C = C; S->level = K.level; S->sub = K.sub; S->orient = K.orient; S->have = K.have; S->paired = K.paired; S->c = K.c; S->W = K.W;
+                H.active_out[atomicAdd(H.n_active_out, 1u)] = hidx;
+            }
+        }
         wave_fence();
     }
-    if (lane == 0) CL.cmd = 1;
+    if (lane == 0) flush_counters(A, Cflush, n_units_done, n_aligned, n_aligned_pairs);
+}
+
+// every wave of the chip evaluates tasks: HS_TASK consecutive candidates of one published list window
+__global__ __launch_bounds__(256, 8) void k_hscan(AlignArgs A, HeavyArgs H)
+{
+    __shared__ BlockLds BL;
+    __shared__ uint32_t TAB[4][4][32];
+    const DevParams &P = A.P;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    init_block_lds(P, BL, threadIdx.x, 256);
     __syncthreads();
-    if (lane == 0) flush_counters(A, C, n_units_done, n_aligned, n_aligned_pairs);
+    const uint32_t n_tasks = min(*H.n_tasks, H.task_cap);
+    for (;;) {
+        uint32_t t = 0;
+        if (lane == 0) t = atomicAdd(H.queue + 1, 1u);
+        t = rfl(t);
+        if (t >= n_tasks) break;
+        const uint32_t hidx = rfl(H.tasks[t].h), tc0 = rfl(H.tasks[t].c0), tn = rfl(H.tasks[t].n);
+        const ListReq &R = H.state[hidx].req;
+        if (lane < 32) { TAB[wv][0][lane] = R.sub_pre[lane]; TAB[wv][1][lane] = R.sub_n[lane]; TAB[wv][2][lane] = R.sub_base[lane]; TAB[wv][3][lane] = R.sub_h[lane]; }
+        uint32_t rw[9], rm[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) { rw[k] = rfl(R.rw[k]); rm[k] = rfl(R.rm[k]); }
+        const uint32_t thres0 = rfl(R.thres), nsub = rfl(R.nsub);
+        const int nwords = (int)rfl(R.nwords), len = (int)rfl(R.len);
+        wave_fence();
+        HTaskOut *o = &H.tout[t];
+        uint32_t nsurv = 0, a0 = 0, a1 = 0, a2 = 0, a5 = 0;
+        bool overflow = false;
+        const uint32_t c_end = tc0 + tn;
+        for (uint32_t cb = tc0; cb < c_end; cb += 256) {
+            uint32_t idx[4], e_idx[4], hh[4], strand[4], p[4];
+            bool valid[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                idx[u] = cb + u * 64 + lane;
+                valid[u] = idx[u] < c_end;
+                e_idx[u] = 0; hh[u] = 0; strand[u] = 0;
+                for (uint32_t s = 0; s < nsub; s++) {
+                    const uint32_t ps = TAB[wv][0][s], ns = TAB[wv][1][s];
+                    if (idx[u] >= ps && idx[u] < ps + ns) { e_idx[u] = TAB[wv][2][s] + (idx[u] - ps); hh[u] = TAB[wv][3][s]; strand[u] = s & 1; }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) p[u] = valid[u] ? P.entries[e_idx[u]] + hh[u] : 0;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                CandEval ev = {0xffff, 0, 0, 0};
+                if (valid[u]) ev = eval_candidate(P, rw, rm, nwords, p[u], strand[u], thres0);
+                bool pass = valid[u] && ev.w <= thres0;
+                uint32_t hchr = 0, hloc = 0, hkey = 0;
+                if (pass) pass = hit_coords(P, BL, p[u], strand[u], len, hchr, hloc, hkey);
+                const u64 m = __ballot(pass);
+                if (m) {
+                    const uint32_t pos = nsurv + (uint32_t)__builtin_popcountll(m & lanemask_lt(lane));
+                    if (pass && pos < HS_SCAP) { SurvRec r; r.w_ord = ev.w | ((idx[u] - tc0) << 8); r.hchr = hchr; r.hloc = hloc; r.hkey = hkey; o->surv[pos] = r; }
+                    nsurv += (uint32_t)__builtin_popcountll(m);
+                    if (nsurv > HS_SCAP) overflow = true;
+                }
+                const bool one = valid[u] && ev.w0ref > thres0;
+                const bool two = valid[u] && !one && (ev.p48 > thres0 || ev.w01ref > thres0);
+                const bool five = valid[u] && !one && !two;
+                a0 += (uint32_t)__builtin_popcountll(__ballot(valid[u])); a1 += (uint32_t)__builtin_popcountll(__ballot(one));
+                a2 += (uint32_t)__builtin_popcountll(__ballot(two)); a5 += (uint32_t)__builtin_popcountll(__ballot(five));
+            }
+            if (overflow) break;
+        }
+        if (lane == 0) { o->count = overflow ? 0 : nsurv; o->overflow = overflow ? 1 : 0; o->acc[0] = a0; o->acc[1] = a1; o->acc[2] = a2; o->acc[3] = a5; }
+        wave_fence();
+    }
 }
 
 }  // namespace
 
-void bsx_launch_align(const AlignArgs &A, int paired, int grid_blocks, int heavy_blocks, hipStream_t stream)
+void bsx_launch_align(const AlignArgs &A, int paired, int grid_blocks, hipStream_t stream)
 {
     if (paired) hipLaunchKernelGGL(k_align<true>, dim3(grid_blocks), dim3(256), 0, stream, A);
     else hipLaunchKernelGGL(k_align<false>, dim3(grid_blocks), dim3(256), 0, stream, A);
-    if (heavy_blocks > 0) {
-        if (paired) hipLaunchKernelGGL(k_align_heavy<true>, dim3(heavy_blocks), dim3(COOP_WAVES * 64), 0, stream, A);
-        else hipLaunchKernelGGL(k_align_heavy<false>, dim3(heavy_blocks), dim3(COOP_WAVES * 64), 0, stream, A);
-    }
 }
 
-size_t bsx_coop_surv_bytes(void) { return (size_t)COOP_WIN * sizeof(SurvRec); }
+void bsx_launch_hctrl(const AlignArgs &A, const HeavyArgsRaw &R, int paired, int grid_blocks, hipStream_t stream)
+{
+    const HeavyArgs H = typed(R);
+    if (paired) hipLaunchKernelGGL(k_hctrl<true>, dim3(grid_blocks), dim3(256), 0, stream, A, H);
+    else hipLaunchKernelGGL(k_hctrl<false>, dim3(grid_blocks), dim3(256), 0, stream, A, H);
+}
+
+void bsx_launch_hscan(const AlignArgs &A, const HeavyArgsRaw &R, int grid_blocks, hipStream_t stream)
+{
+    const HeavyArgs H = typed(R);
+    hipLaunchKernelGGL(k_hscan, dim3(grid_blocks), dim3(256), 0, stream, A, H);
+}
+
+size_t bsx_hstate_bytes(void) { return sizeof(HState); }
+size_t bsx_htask_bytes(void) { return sizeof(HTask); }
+size_t bsx_htaskout_bytes(void) { return sizeof(HTaskOut); }
 
 int bsx_align_occupancy(int paired)
 {

@@ -193,9 +193,13 @@ struct bsx_batch {
     uint16_t *d_npairs = nullptr;
     uint8_t *d_scratch = nullptr, *d_dbg = nullptr;
     uint32_t *d_cycles = nullptr;
-    uint8_t *d_scratch_heavy = nullptr, *d_coop_surv = nullptr;
     uint32_t *d_heavy_list = nullptr, *d_heavy_count = nullptr;
-    int heavy_blocks = 0;
+    // heavy pipeline pools
+    uint8_t *d_hstate = nullptr, *d_hslabs = nullptr, *d_htasks = nullptr, *d_htout = nullptr;
+    uint32_t *d_hactive[2] = {nullptr, nullptr}, *d_hcnt = nullptr;  // d_hcnt: n_active_out, n_tasks, queue[2]
+    uint32_t hcap = 0, task_cap = 0;
+    int n_cu = 0;
+    uint32_t last_heavy = 0, last_heavy_iters = 0;
     size_t scratch_bytes = 0;
     uint32_t *d_queue = nullptr;
     uint64_t *d_counters = nullptr;
@@ -230,13 +234,20 @@ static int ensure_scratch(bsx_batch *b)
     const int need = (int)((b->max_units + 3) / 4);
     if (grid > need) grid = need > 0 ? need : 1;
     b->grid_blocks = grid;
-    b->heavy_blocks = prop.multiProcessorCount;  // one 16-wave workgroup per CU
-    if (!b->d_scratch_heavy) {
-        HIP_TRY(hipMalloc((void **)&b->d_scratch_heavy, (size_t)b->heavy_blocks * b->slab_bytes));
-        HIP_TRY(hipMemsetAsync(b->d_scratch_heavy, 0, (size_t)b->heavy_blocks * b->slab_bytes, b->stream));
-        HIP_TRY(hipMalloc((void **)&b->d_coop_surv, (size_t)b->heavy_blocks * bsx_coop_surv_bytes()));
+    b->n_cu = prop.multiProcessorCount;
+    if (!b->d_heavy_list) {
+        b->hcap = std::min<uint32_t>(b->max_units, std::max<uint32_t>(1024u, b->max_units / 32));
+        b->task_cap = 262144;
         HIP_TRY(hipMalloc((void **)&b->d_heavy_list, ((size_t)b->max_units + 1) * 4));
         HIP_TRY(hipMalloc((void **)&b->d_heavy_count, 256));
+        HIP_TRY(hipMalloc((void **)&b->d_hstate, (size_t)b->hcap * bsx_hstate_bytes()));
+        HIP_TRY(hipMalloc((void **)&b->d_hslabs, (size_t)b->hcap * b->slab_bytes));
+        HIP_TRY(hipMemsetAsync(b->d_hslabs, 0, (size_t)b->hcap * b->slab_bytes, b->stream));
+        HIP_TRY(hipMalloc((void **)&b->d_htasks, (size_t)b->task_cap * bsx_htask_bytes()));
+        HIP_TRY(hipMalloc((void **)&b->d_htout, (size_t)b->task_cap * bsx_htaskout_bytes()));
+        HIP_TRY(hipMalloc((void **)&b->d_hactive[0], (size_t)b->hcap * 4));
+        HIP_TRY(hipMalloc((void **)&b->d_hactive[1], (size_t)b->hcap * 4));
+        HIP_TRY(hipMalloc((void **)&b->d_hcnt, 256));
     }
     const uint64_t slots = b->debug ? b->max_units : (uint64_t)grid * 4;
     const size_t bytes = (size_t)(slots * b->slab_bytes);
@@ -289,8 +300,8 @@ extern "C" void bsx_batch_destroy(bsx_batch *b)
     for (int m = 0; m < 2; m++)
         for (void *q : {(void *)b->d_seq[m], (void *)b->d_qual[m], (void *)b->d_off[m], (void *)b->d_cc[m]})
             if (q) (void)hipFree(q);
-    for (void *q : {(void *)b->d_hits, (void *)b->d_pairs, (void *)b->d_npairs, (void *)b->d_scratch, (void *)b->d_dbg, (void *)b->d_queue, (void *)b->d_counters, (void *)b->d_cycles, (void *)b->d_scratch_heavy,
-                    (void *)b->d_coop_surv, (void *)b->d_heavy_list, (void *)b->d_heavy_count})
+    for (void *q : {(void *)b->d_hits, (void *)b->d_pairs, (void *)b->d_npairs, (void *)b->d_scratch, (void *)b->d_dbg, (void *)b->d_queue, (void *)b->d_counters, (void *)b->d_cycles, (void *)b->d_heavy_list, (void *)b->d_heavy_count,
+                    (void *)b->d_hstate, (void *)b->d_hslabs, (void *)b->d_htasks, (void *)b->d_htout, (void *)b->d_hactive[0], (void *)b->d_hactive[1], (void *)b->d_hcnt})
         if (q) (void)hipFree(q);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
@@ -367,14 +378,51 @@ extern "C" int bsx_batch_run_range(bsx_batch *b, uint32_t first_unit, uint32_t n
     for (int m = 0; m < 2; m++) { A.seq[m] = b->d_seq[m]; A.off[m] = b->d_off[m]; A.qual[m] = b->has_qual ? b->d_qual[m] : nullptr; A.cc[m] = b->d_cc[m]; }
     A.hits_out = b->d_hits; A.pairs_out = b->d_pairs; A.npairs_out = b->d_npairs;
     A.scratch = b->d_scratch; A.slab_bytes = b->slab_bytes; A.queue = b->d_queue; A.counters = b->d_counters; A.dbg_plan = b->d_dbg; A.dbg_cycles = b->d_cycles;
-    A.scratch_heavy = b->d_scratch_heavy; A.coop_surv = b->d_coop_surv; A.heavy_list = b->d_heavy_list; A.heavy_count = b->d_heavy_count;
+    A.heavy_list = b->d_heavy_list; A.heavy_count = b->d_heavy_count;
     A.heavy_threshold = b->ref->P.rrbs ? 0u : (uint32_t)g_heavy_threshold;
-    HIP_TRY(hipMemsetAsync(b->d_queue, 0, 8, b->stream));
+    HIP_TRY(hipMemsetAsync(b->d_queue, 0, 4, b->stream));
     HIP_TRY(hipMemsetAsync(b->d_heavy_count, 0, 4, b->stream));
     if (b->debug) HIP_TRY(hipMemsetAsync(b->d_scratch, 0, (size_t)b->max_units * b->slab_bytes, b->stream));
     HIP_TRY(hipEventRecord(b->ev0, b->stream));
-    bsx_launch_align(A, b->paired, b->grid_blocks, A.heavy_threshold ? b->heavy_blocks : 0, b->stream);
+    bsx_launch_align(A, b->paired, b->grid_blocks, b->stream);
     HIP_TRY(hipGetLastError());
+    b->last_heavy = 0; b->last_heavy_iters = 0;
+    if (A.heavy_threshold) {
+        // heavy pipeline: iterate k_hctrl / k_hscan until every deferred unit is finished (host-driven, so this call
+        // returns only after the deferred units are done; units that were not deferred are already complete)
+        uint32_t n_heavy = 0;
+        HIP_TRY(hipMemcpyAsync(&n_heavy, b->d_heavy_count, 4, hipMemcpyDeviceToHost, b->stream));
+        HIP_TRY(hipStreamSynchronize(b->stream));
+        b->last_heavy = n_heavy;
+        HeavyArgsRaw H;
+        memset(&H, 0, sizeof(H));
+        H.state = b->d_hstate; H.slabs = b->d_hslabs; H.tasks = b->d_htasks; H.tout = b->d_htout;
+        H.n_active_out = b->d_hcnt; H.n_tasks = b->d_hcnt + 1; H.queue = b->d_hcnt + 2; H.task_cap = b->task_cap;
+        for (uint32_t base = 0; base < n_heavy; base += b->hcap) {
+            uint32_t n_act = std::min(b->hcap, n_heavy - base);
+            int cur = 0;
+            H.fresh = 1; H.list_base = base;
+            for (uint32_t iter = 0; n_act > 0; iter++) {
+                if (iter > 100000) { g_bsx_err = "heavy pipeline did not converge"; return BSX_ERR_DEVICE; }
+                HIP_TRY(hipMemsetAsync(b->d_hcnt, 0, 16, b->stream));
+                H.active_in = b->d_hactive[cur]; H.active_out = b->d_hactive[cur ^ 1]; H.n_active_in = n_act;
+                bsx_launch_hctrl(A, H, b->paired, (int)std::min<uint32_t>((n_act + 3) / 4, (uint32_t)b->n_cu * 4), b->stream);
+                HIP_TRY(hipGetLastError());
+                uint32_t cnt[2] = {0, 0};
+                HIP_TRY(hipMemcpyAsync(cnt, b->d_hcnt, 8, hipMemcpyDeviceToHost, b->stream));
+                HIP_TRY(hipStreamSynchronize(b->stream));
+                b->last_heavy_iters++;
+                n_act = cnt[0];
+                if (n_act == 0) break;
+                const uint32_t n_tasks = std::min(cnt[1], b->task_cap);
+                if (n_tasks) {
+                    bsx_launch_hscan(A, H, (int)std::min<uint32_t>((n_tasks + 3) / 4, (uint32_t)b->n_cu * 8), b->stream);
+                    HIP_TRY(hipGetLastError());
+                }
+                cur ^= 1; H.fresh = 0;
+            }
+        }
+    }
     HIP_TRY(hipEventRecord(b->ev1, b->stream));
     b->ran = true;
     return BSX_OK;
@@ -493,9 +541,7 @@ extern "C" int bsx_batch_last_heavy_units(bsx_batch *b)
     if (!b || !b->ran) return BSX_ERR_STATE;
     HIP_TRY(hipSetDevice(b->ref->device));
     HIP_TRY(hipStreamSynchronize(b->stream));
-    uint32_t n = 0;
-    HIP_TRY(hipMemcpy(&n, b->d_heavy_count, 4, hipMemcpyDeviceToHost));
-    return (int)n;
+    return (int)b->last_heavy;
 }
 
 extern "C" int bsx_batch_unit_cycles(bsx_batch *b, uint32_t *out)

@@ -17,17 +17,30 @@ struct AlignArgs {
     uint16_t *npairs_out;      // [n_units][32], may be null
     uint8_t *scratch;
     uint64_t slab_bytes;
-    uint8_t *scratch_heavy;    // one slab per heavy-kernel workgroup
-    uint8_t *coop_surv;        // survivor window per heavy-kernel workgroup
-    uint32_t heavy_threshold;  // candidate-list length from which a unit is deferred to the heavy kernel (0 = never)
+    uint32_t heavy_threshold;  // candidate-list length from which a unit is deferred to the heavy pipeline (0 = never)
     uint32_t *heavy_list;      // [n_units] unit ids deferred by the main kernel
     uint32_t *heavy_count;
-    uint32_t *queue;           // [2] work queue heads of the main and heavy kernels (zeroed before launch)
+    uint32_t *queue;           // work queue head of the main kernel (zeroed before launch)
     uint64_t *counters;        // BSX_N_COUNTERS
     uint32_t *dbg_cycles;      // [n_units] shader-clock cycles spent on each unit (diagnostic builds of a run only), may be null
     uint8_t *dbg_plan;         // [n_units][128]: start[2][16], order[2][16] for mate a then mate b
 };
 
-void bsx_launch_align(const AlignArgs &A, int paired, int grid_blocks, int heavy_blocks, hipStream_t stream);
-size_t bsx_coop_surv_bytes(void);
+// heavy pipeline (see bsx_align.hip): untyped view used by the host side
+struct HeavyArgsRaw {
+    uint8_t *state;            // [cap] HState
+    uint8_t *slabs;            // [cap] one scratch slab per deferred unit of the current round
+    uint32_t *active_in, *active_out, *n_active_out;
+    uint8_t *tasks, *tout;     // [task_cap] HTask / HTaskOut
+    uint32_t *n_tasks;
+    uint32_t *queue;           // [2] work queue heads of k_hctrl and k_hscan
+    uint32_t n_active_in, task_cap, fresh, list_base;
+};
+
+void bsx_launch_align(const AlignArgs &A, int paired, int grid_blocks, hipStream_t stream);
+void bsx_launch_hctrl(const AlignArgs &A, const HeavyArgsRaw &H, int paired, int grid_blocks, hipStream_t stream);
+void bsx_launch_hscan(const AlignArgs &A, const HeavyArgsRaw &H, int grid_blocks, hipStream_t stream);
+size_t bsx_hstate_bytes(void);
+size_t bsx_htask_bytes(void);
+size_t bsx_htaskout_bytes(void);
 int bsx_align_occupancy(int paired);

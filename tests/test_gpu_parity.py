@@ -299,3 +299,56 @@ def test_cooperative_kernel_is_used(edge_genome, oracle):
     assert h1.tobytes() == h2.tobytes() and c1.tobytes() == c2.tobytes()
     sa.close()
     gref.close()
+
+
+@pytest.fixture(scope="module")
+def heavy_genome(tmp_path_factory):
+    """a third of this genome is microsatellite: 3-letter buckets of 10^5 entries, multi-window / multi-task scans"""
+    g = td.make_genome(seed=5, chr_lens=(2_000_000, 500_000), gc=0.45, microsats=3000, repeats=200, n_runs=4)
+    fa = str(tmp_path_factory.mktemp("heavy") / "g.fa")
+    td.write_fasta(fa, g)
+    return g, fa
+
+
+@pytest.mark.parametrize("pe", [False, True], ids=["se", "pe"])
+def test_heavy_pipeline_large_buckets(pe, heavy_genome, oracle):
+    g, fa = heavy_genome
+    kw = dict(s=16, v=6, I=4, S=1, r=1)
+    if pe:
+        kw.update(m=28, x=500, pairend=1)
+    oref = oracle.OracleRef(oracle.make_params(**kw), fasta_path=fa)
+    gref = B.RefSeq(B.make_params(**kw)).Run_ConvertBinseq(fasta_path=fa).CreateIndex()
+    assert np.diff(gref.index()[0].astype(np.int64)).max() > 50_000
+    if not pe:
+        reads = td.make_se_reads(g, 3000, 144, seed=8, sub_rate=0.03)
+        sb, so = oracle.pack_reads([r["seq"] for r in reads])
+        ores, ocnt = oracle.se_batch(oref, sb, so, threads=8)
+        sa = B.SingleAlign(gref, len(reads))
+        sa.ImportBatchReads((sb, so)).Do_Batch()
+        hits, cc = sa.results()
+        assert sa.heavy_units() > 500
+        assert np.array_equal(ores["n_hit"][:, :7], cc["n_hit"][:, :7]) and np.array_equal(ores["n_chit"][:, :7], cc["n_chit"][:, :7])
+        has = ores["n_best"] > 0
+        for f in ("chr", "loc", "best_class"):
+            assert np.array_equal(ores[f][has], hits[f][has]), f
+        assert [int(x) for x in sa.counters()[:4]] == ocnt
+        sa.close()
+    else:
+        pairs = td.make_pe_reads(g, 3000, 144, seed=8, sub_rate=0.01)
+        s1, o1 = oracle.pack_reads([p["seq1"] for p in pairs])
+        s2, o2 = oracle.pack_reads([p["seq2"] for p in pairs])
+        ores, ocnt = oracle.pe_batch(oref, s1, o1, s2, o2, threads=8)
+        pa = B.PairAlign(gref, len(pairs))
+        pa.ImportBatchReads((s1, o1), (s2, o2)).Do_Batch()
+        out, ca, cb, npairs = pa.results()
+        assert pa.heavy_units() > 500
+        assert np.array_equal(ores["paired"], out["paired"]) and np.array_equal(ores["n_pairs"][:, :13], npairs[:, :13])
+        for m, cnts in (("a", ca), ("b", cb)):
+            assert np.array_equal(ores[m]["n_hit"][:, :7], cnts["n_hit"][:, :7]) and np.array_equal(ores[m]["n_chit"][:, :7], cnts["n_chit"][:, :7]), m
+        pr = (ores["tmp"] == 0) & (ores["paired"] > 0)
+        for f in ("a_chr", "a_loc", "b_chr", "b_loc", "insert", "na", "nb", "chain"):
+            assert np.array_equal(ores["pick"][f][pr], out[f][pr]), f
+        assert [int(x) for x in pa.counters()[:4]] == ocnt
+        pa.close()
+    gref.close()
+    oref.free()
