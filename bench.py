@@ -132,7 +132,8 @@ def main():
                    "aligned_fraction": float((2 * tot_counters[6] + tot_counters[5]) / max(1.0, n_reads_rank * world)) if pe
                    else float(tot_counters[5] / max(1.0, n_reads_rank * world))},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "kernel": "k_align", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes_launch,
+                     "traffic": traffic, "kernel": "one Do_Batch = k_align + heavy pipeline (k_hctrl/k_hscan iterations)", "kernel_ms": k_ms,
+                     "heavy_units_last_step": int(batch.heavy_units()), "algorithmic_bytes_per_launch": alg_bytes_launch,
                      "per_read": {"n_lookup": float(counters[0]) / n_reads_rank, "n_cand": float(counters[1]) / n_reads_rank,
                                   "ref_words64": float(counters[2]) / n_reads_rank}},
     }

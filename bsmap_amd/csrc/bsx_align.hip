@@ -978,15 +978,18 @@ __global__ __launch_bounds__(256, PE ? BSX_WAVES_PER_EU_PE : BSX_WAVES_PER_EU_SE
 // The owner replays the survivors in order on the next k_hctrl pass.  An event that lowers the threshold or ends the
 // call cuts the window right after the candidate that caused it, so every candidate is still evaluated under exactly
 // the threshold the reference would have used: results and work counters are bit-identical to the one-wave path.
-// Windows grow geometrically (x4) so that an early exit wastes at most a bounded amount of scanning.
+// Windows grow geometrically so that an early exit wastes at most a bounded amount of scanning.
 #ifndef HS_TASK
 #define HS_TASK 8192u
 #endif
 #ifndef HS_SCAP
-#define HS_SCAP 128u
+#define HS_SCAP 512u
 #endif
 #ifndef HS_WIN0
-#define HS_WIN0 16384u
+#define HS_WIN0 32768u
+#endif
+#ifndef HS_GROW
+#define HS_GROW 8u
 #endif
 #ifndef HS_WINMAX
 #define HS_WINMAX (1u << 22)
@@ -1110,9 +1113,10 @@ __device__ int snp_align_heavy(const AlignArgs &A, const HeavyArgs &H, HState *S
                         restart = true;
                     }
                 }
-                if (!restart) K.W = min(K.W * 4, (uint32_t)HS_WINMAX);
+                if (!restart) K.W = min(K.W * HS_GROW, (uint32_t)HS_WINMAX);
             } else {
-                const uint32_t wn = min(K.W, cl.total - K.c), nt = (wn + HS_TASK - 1) / HS_TASK;
+                const uint32_t weff = H.n_active_in < 2048u ? (uint32_t)HS_WINMAX : K.W;  // few units left: scanning capacity is idle, speculate the whole list
+                const uint32_t wn = min(weff, cl.total - K.c), nt = (wn + HS_TASK - 1) / HS_TASK;
                 uint32_t t0 = 0;
                 if (lane == 0) t0 = atomicAdd(H.n_tasks, nt);
                 t0 = rfl(t0);

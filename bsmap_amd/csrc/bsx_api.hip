@@ -236,7 +236,7 @@ static int ensure_scratch(bsx_batch *b)
     b->grid_blocks = grid;
     b->n_cu = prop.multiProcessorCount;
     if (!b->d_heavy_list) {
-        b->hcap = std::min<uint32_t>(b->max_units, std::max<uint32_t>(1024u, b->max_units / 32));
+        b->hcap = std::min<uint32_t>(b->max_units, 32768u);  // deferred units handled per round (more than this: several rounds)
         b->task_cap = 262144;
         HIP_TRY(hipMalloc((void **)&b->d_heavy_list, ((size_t)b->max_units + 1) * 4));
         HIP_TRY(hipMalloc((void **)&b->d_heavy_count, 256));

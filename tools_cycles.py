@@ -1,6 +1,8 @@
 import sys, time, numpy as np
 sys.path.insert(0, "/root/repo")
+import os
 import bsmap_amd as B
+if os.environ.get("BSXLIB"): B.LIB_PATH=os.environ["BSXLIB"]
 frac = float(sys.argv[1]) if len(sys.argv) > 1 else 0.02
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
 HG38 = [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636, 138394717, 133797422, 135086622, 133275309, 114364328, 107043718, 101991189, 90338345, 83257441, 80373285, 58617616, 64444167, 46709983, 50818468, 156040895, 57227415]
