@@ -41,7 +41,7 @@ def main():
     fetch, write = per_kernel(fetch_dir, "FETCH_SIZE"), per_kernel(write_dir, "WRITE_SIZE")
     summ = {}
     for k in sorted(set(fetch) | set(write)):
-        if not any(t in k for t in ("k_align", "k_scan", "k_heavy", "k_ctrl")):
+        if not any(t in k for t in ("k_align", "k_hscan", "k_hctrl")):
             continue
         f, w = fetch.get(k), write.get(k)
         e = {"launches": (f or w)["launches"]}
@@ -54,9 +54,19 @@ def main():
             e["WRITE_SIZE_KiB_per_launch"] = w["sum"] / w["launches"]
             e["write_bytes_per_launch"] = w["sum"] / w["launches"] * 1024
         summ[k[:100]] = e
-    tot = sum(e.get("fetch_bytes_per_launch_x2_gfx950", 0) + e.get("write_bytes_per_launch", 0) for e in summ.values())
-    out = {"tag": tag, "kernels": summ, "hbm_bytes_per_launch": tot,
-           "note": "per launch of the align kernels of one bench step; read side = 2 x FETCH_SIZE (gfx950 correction), write side = WRITE_SIZE"}
+    # one bench step (= one Do_Batch) is one k_align launch plus all heavy-pipeline iterations that follow it
+    def steps(d):
+        return max([v["launches"] for k, v in d.items() if "k_align" in k] or [1])
+    fsteps, wsteps = steps(fetch), steps(write)
+    fetch_step = sum(v["sum"] for k, v in fetch.items() if k[:100] in summ) * 1024 / fsteps
+    write_step = sum(v["sum"] for k, v in write.items() if k[:100] in summ) * 1024 / wsteps
+    for k, e in summ.items():
+        e["launches_per_step"] = e["launches"] / fsteps
+    out = {"tag": tag, "steps_in_fetch_pass": fsteps, "steps_in_write_pass": wsteps, "kernels": summ,
+           "fetch_bytes_per_step_raw": fetch_step, "fetch_bytes_per_step_x2_gfx950": 2 * fetch_step, "write_bytes_per_step": write_step,
+           "hbm_bytes_per_launch": 2 * fetch_step + write_step,
+           "note": "per bench step (one Do_Batch = k_align + heavy-pipeline iterations); read side = 2 x FETCH_SIZE "
+                   "(gfx950 correction of MI355X_MICROARCH.md, uncalibrated for narrow random loads), write side = WRITE_SIZE"}
     json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_pmc.json"), "w"), indent=1)
     json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_latest.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
