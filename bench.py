@@ -95,16 +95,9 @@ def main():
     counters = batch.counters()
     reads_per_unit = 2 if pe else 1
     n_reads_rank = args.steps * B_ * reads_per_unit
-    # stats reduction: the only collective of the path (RCCL all-gather of 8 uint64 per rank + the max of the times)
-    stats = torch.tensor([float(dt)] + [float(x) for x in counters], dtype=torch.float64, device="cuda")
-    if dist is not None:
-        gathered = [torch.zeros_like(stats) for _ in range(world)]
-        dist.all_gather(gathered, stats)
-        allstats = torch.stack(gathered).cpu().numpy()
-    else:
-        allstats = stats.cpu().numpy()[None, :]
-    dt_max = float(allstats[:, 0].max())
-    tot_counters = allstats[:, 1:].sum(0)
+    # stats reduction: the only collective of the path (RCCL all-gather of 9 doubles per rank)
+    from bsmap_amd import sharding
+    dt_max, tot_counters, allstats = sharding.gather_stats(dt, counters, dist, device="cuda")
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
