@@ -405,13 +405,11 @@ struct CandEval { uint32_t w, w0ref, p48, w01ref; };
 // CountMismatch (align.h:167-200) for the candidate starting at global nt p of one strand copy.  The reference
 // compares a pre-shifted copy of the read with aligned reference words; here the reference words are funnel-shifted
 // into the read's frame instead.  w0ref / w01ref are the partial sums the reference's two early-outs look at.
-__device__ __forceinline__ CandEval eval_candidate(const DevParams &P, const uint32_t (&rw)[9], const uint32_t (&rm)[9], int nwords,
-                                                   uint32_t p, uint32_t strand, uint32_t thres0)
+__device__ __forceinline__ CandEval eval_loaded(const uint32_t *rp, const U4 r0, const uint32_t (&rw)[9], const uint32_t (&rm)[9], int nwords,
+                                                uint32_t p, uint32_t thres0)
 {
     CandEval r;
-    const uint32_t *rp = (strand ? P.crefcat : P.refcat) + (p >> 4);
     const uint32_t k = p & 15, sh = 32 - 2 * k;
-    const U4 r0 = *reinterpret_cast<const U4 *>(rp);
     const uint32_t f0 = (uint32_t)((((u64)r0.a << 32) | r0.b) >> sh), f1 = (uint32_t)((((u64)r0.b << 32) | r0.c) >> sh),
                    f2 = (uint32_t)((((u64)r0.c << 32) | r0.d) >> sh);
     const uint32_t m0 = bsx_mismatch_bits(rw[0], rm[0], f0), m1 = bsx_mismatch_bits(rw[1], rm[1], f1), m2 = bsx_mismatch_bits(rw[2], rm[2], f2);
@@ -441,6 +439,13 @@ __device__ __forceinline__ CandEval eval_candidate(const DevParams &P, const uin
     return r;
 }
 
+__device__ __forceinline__ CandEval eval_candidate(const DevParams &P, const uint32_t (&rw)[9], const uint32_t (&rm)[9], int nwords,
+                                                   uint32_t p, uint32_t strand, uint32_t thres0)
+{
+    const uint32_t *rp = (strand ? P.crefcat : P.refcat) + (p >> 4);
+    const U4 r0 = *reinterpret_cast<const U4 *>(rp);
+    return eval_loaded(rp, r0, rw, rm, nwords, p, thres0);
+}
 
 // hit coordinates of a WGBS candidate at global nt p of strand copy `strand`; false if it runs off the chromosome
 __device__ __forceinline__ bool hit_coords(const DevParams &P, const BlockLds &BL, uint32_t p, uint32_t strand, int len, uint32_t &hchr,
@@ -1267,42 +1272,46 @@ __global__ __launch_bounds__(256, 8) void k_hscan(AlignArgs A, HeavyArgs H)
         uint32_t nsurv = 0, a0 = 0, a1 = 0, a2 = 0, a5 = 0;
         bool overflow = false;
         const uint32_t c_end = tc0 + tn;
-        for (uint32_t cb = tc0; cb < c_end; cb += 256) {
-            uint32_t idx[4], e_idx[4], hh[4], strand[4], p[4];
-            bool valid[4];
+        // the task's candidates sub-range by sub-range (list order): inside one sub-range entry address, h and strand are
+        // wave-uniform; four chunks are in flight per step — entries first, then all four 16-byte reference loads
+        for (uint32_t sidx = 0; sidx < nsub && !overflow; sidx++) {
+            const uint32_t ps = TAB[wv][0][sidx], ns = TAB[wv][1][sidx];
+            const uint32_t lo = max(tc0, ps), hi = min(c_end, ps + ns);
+            if (lo >= hi) continue;
+            const uint32_t *ent = P.entries + TAB[wv][2][sidx];
+            const uint32_t hh = TAB[wv][3][sidx], strand = sidx & 1;
+            const uint32_t *refbase = strand ? P.crefcat : P.refcat;
+            for (uint32_t cb = lo; cb < hi && !overflow; cb += 256) {
+                uint32_t idx[4], p[4];
+                bool valid[4];
+                U4 r0[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                idx[u] = cb + u * 64 + lane;
-                valid[u] = idx[u] < c_end;
-                e_idx[u] = 0; hh[u] = 0; strand[u] = 0;
-                for (uint32_t s = 0; s < nsub; s++) {
-                    const uint32_t ps = TAB[wv][0][s], ns = TAB[wv][1][s];
-                    if (idx[u] >= ps && idx[u] < ps + ns) { e_idx[u] = TAB[wv][2][s] + (idx[u] - ps); hh[u] = TAB[wv][3][s]; strand[u] = s & 1; }
+                for (int u = 0; u < 4; u++) { idx[u] = cb + u * 64 + lane; valid[u] = idx[u] < hi; }
+#pragma unroll
+                for (int u = 0; u < 4; u++) p[u] = ent[valid[u] ? idx[u] - ps : lo - ps] + hh;
+#pragma unroll
+                for (int u = 0; u < 4; u++) r0[u] = *reinterpret_cast<const U4 *>(refbase + (p[u] >> 4));
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    CandEval ev = eval_loaded(refbase + (p[u] >> 4), r0[u], rw, rm, nwords, p[u], thres0);
+                    if (!valid[u]) { ev.w = 0xffff; ev.w0ref = ev.p48 = ev.w01ref = 0; }
+                    bool pass = valid[u] && ev.w <= thres0;
+                    uint32_t hchr = 0, hloc = 0, hkey = 0;
+                    if (pass) pass = hit_coords(P, BL, p[u], strand, len, hchr, hloc, hkey);
+                    const u64 m = __ballot(pass);
+                    if (m) {
+                        const uint32_t pos = nsurv + (uint32_t)__builtin_popcountll(m & lanemask_lt(lane));
+                        if (pass && pos < HS_SCAP) { SurvRec r; r.w_ord = ev.w | ((idx[u] - tc0) << 8); r.hchr = hchr; r.hloc = hloc; r.hkey = hkey; o->surv[pos] = r; }
+                        nsurv += (uint32_t)__builtin_popcountll(m);
+                        if (nsurv > HS_SCAP) overflow = true;
+                    }
+                    const bool one = valid[u] && ev.w0ref > thres0;
+                    const bool two = valid[u] && !one && (ev.p48 > thres0 || ev.w01ref > thres0);
+                    const bool five = valid[u] && !one && !two;
+                    a0 += (uint32_t)__builtin_popcountll(__ballot(valid[u])); a1 += (uint32_t)__builtin_popcountll(__ballot(one));
+                    a2 += (uint32_t)__builtin_popcountll(__ballot(two)); a5 += (uint32_t)__builtin_popcountll(__ballot(five));
                 }
             }
-#pragma unroll
-            for (int u = 0; u < 4; u++) p[u] = valid[u] ? P.entries[e_idx[u]] + hh[u] : 0;
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                CandEval ev = {0xffff, 0, 0, 0};
-                if (valid[u]) ev = eval_candidate(P, rw, rm, nwords, p[u], strand[u], thres0);
-                bool pass = valid[u] && ev.w <= thres0;
-                uint32_t hchr = 0, hloc = 0, hkey = 0;
-                if (pass) pass = hit_coords(P, BL, p[u], strand[u], len, hchr, hloc, hkey);
-                const u64 m = __ballot(pass);
-                if (m) {
-                    const uint32_t pos = nsurv + (uint32_t)__builtin_popcountll(m & lanemask_lt(lane));
-                    if (pass && pos < HS_SCAP) { SurvRec r; r.w_ord = ev.w | ((idx[u] - tc0) << 8); r.hchr = hchr; r.hloc = hloc; r.hkey = hkey; o->surv[pos] = r; }
-                    nsurv += (uint32_t)__builtin_popcountll(m);
-                    if (nsurv > HS_SCAP) overflow = true;
-                }
-                const bool one = valid[u] && ev.w0ref > thres0;
-                const bool two = valid[u] && !one && (ev.p48 > thres0 || ev.w01ref > thres0);
-                const bool five = valid[u] && !one && !two;
-                a0 += (uint32_t)__builtin_popcountll(__ballot(valid[u])); a1 += (uint32_t)__builtin_popcountll(__ballot(one));
-                a2 += (uint32_t)__builtin_popcountll(__ballot(two)); a5 += (uint32_t)__builtin_popcountll(__ballot(five));
-            }
-            if (overflow) break;
         }
         if (lane == 0) { o->count = overflow ? 0 : nsurv; o->overflow = overflow ? 1 : 0; o->acc[0] = a0; o->acc[1] = a1; o->acc[2] = a2; o->acc[3] = a5; }
         wave_fence();
