@@ -987,6 +987,9 @@ __global__ __launch_bounds__(256, PE ? BSX_WAVES_PER_EU_PE : BSX_WAVES_PER_EU_SE
 #ifndef HS_TASK
 #define HS_TASK 8192u
 #endif
+#ifndef HS_TASK_MIN
+#define HS_TASK_MIN 1024u  // inside the heavy pipeline even moderately long lists go to the scan kernel
+#endif
 #ifndef HS_SCAP
 #define HS_SCAP 512u
 #endif
@@ -1071,7 +1074,7 @@ __device__ int snp_align_heavy(const AlignArgs &A, const HeavyArgs &H, HState *S
         if (!((M.flags >> orient) & 1)) continue;
         const int seg = L.order[orient][mode];
         const CandList cl = make_list(P, BL, L, M, orient, seg, lane);
-        if (cl.total < A.heavy_threshold) {  // short list: the owning wave scans it itself
+        if (cl.total < min(A.heavy_threshold, (uint32_t)HS_TASK_MIN)) {  // short list: the owning wave scans it itself
             if (wave_scan_range<false>(P, BL, L, M, SL, cl, orient, seg, mode, 0, cl.total, 0, lane, C) == 2) { wave_fence(); return 1; }
             continue;
         }
@@ -1082,40 +1085,61 @@ __device__ int snp_align_heavy(const AlignArgs &A, const HeavyArgs &H, HState *S
                 //  reconstructed from the unit's own state, only the task OUTPUTS are read from the pool)
                 const uint32_t t0 = rfl(S->t0), nt = rfl(S->n_tasks), req_thres = rfl(S->req.thres), win_c0 = rfl(S->win_c0), win_n = rfl(S->win_n);
                 bool restart = false;
-                for (uint32_t t = 0; t < nt && !restart; t++) {
-                    const uint32_t tc0 = win_c0 + t * HS_TASK, tn = min((uint32_t)HS_TASK, win_n - t * HS_TASK);
-                    const HTaskOut *o = &H.tout[t0 + t];
-                    if (rfl(o->overflow)) {  // too many survivors for the record: redo this task with the one-wave path
-                        const int r = wave_scan_range<false>(P, BL, L, M, SL, cl, orient, seg, mode, tc0, tc0 + tn, 0, lane, C);
-                        if (r == 2) { wave_fence(); return 1; }
-                        K.c = tc0 + tn;
-                        if (r == 1) restart = true;  // later tasks were evaluated under the old threshold
-                        continue;
+                for (uint32_t tg = 0; tg < nt && !restart; tg += 64) {
+                    // 64 task headers at a time: tasks without survivors only contribute their work counters
+                    const uint32_t tl = tg + lane;
+                    uint32_t hc = 0, hov = 0, h0 = 0, hw = 0;
+                    if (tl < nt) {
+                        const HTaskOut *oh = &H.tout[t0 + tl];
+                        hc = oh->count; hov = oh->overflow; h0 = oh->acc[0]; hw = oh->acc[1] + 2 * oh->acc[2] + 5 * oh->acc[3];
                     }
-                    int event = 0; uint32_t X = 0;
-                    const uint32_t nv = rfl(o->count);
-                    for (uint32_t base = 0; base < nv && !event; base += 64) {
-                        const uint32_t i = base + lane;
-                        SurvRec r = {0, 0, 0, 0};
-                        if (i < nv) r = o->surv[i];
-                        u64 m = __ballot(i < nv);
-                        while (m) {
-                            const int ls = (int)__builtin_ctzll(m);
-                            m &= m - 1;
-                            const uint32_t wo = rl(r.w_ord, ls);
-                            const int e = accept_survivor(P, M, SL, orient, mode, wo & 0xff, rl(r.hchr, ls), rl(r.hloc, ls), rl(r.hkey, ls), lane);
-                            if (e) { event = e; X = tc0 + (wo >> 8); break; }
+                    u64 special = __ballot(tl < nt && (hc != 0 || hov != 0));
+                    uint32_t done_upto = 0;  // tasks [tg, tg+done_upto) of this group are fully accounted
+                    const uint32_t gn = min(64u, nt - tg);
+                    while (!restart) {
+                        const uint32_t nxt = special ? (uint32_t)__builtin_ctzll(special) : gn;  // next task needing a replay
+                        // plain tasks in [done_upto, nxt)
+                        const bool mine = (uint32_t)lane >= done_upto && (uint32_t)lane < nxt;
+                        C.n_cand += wave_sum(mine ? h0 : 0);
+                        C.sum_w += wave_sum(mine ? hw : 0);
+                        if (nxt >= gn) { K.c = win_c0 + min(win_n, (tg + gn) * HS_TASK); break; }
+                        special &= special - 1;
+                        done_upto = nxt + 1;
+                        const uint32_t t = tg + nxt;
+                        const uint32_t tc0 = win_c0 + t * HS_TASK, tn = min((uint32_t)HS_TASK, win_n - t * HS_TASK);
+                        const HTaskOut *o = &H.tout[t0 + t];
+                        if (rl(hov, (int)nxt)) {  // too many survivors for the record: redo this task with the one-wave path
+                            const int r = wave_scan_range<false>(P, BL, L, M, SL, cl, orient, seg, mode, tc0, tc0 + tn, 0, lane, C);
+                            if (r == 2) { wave_fence(); return 1; }
+                            K.c = tc0 + tn;
+                            if (r == 1) restart = true;  // later tasks were evaluated under the old threshold
+                            continue;
                         }
-                    }
-                    if (!event) {
-                        C.n_cand += rfl(o->acc[0]);
-                        C.sum_w += (u64)rfl(o->acc[1]) + 2ull * rfl(o->acc[2]) + 5ull * rfl(o->acc[3]);
-                        K.c = tc0 + tn;
-                    } else {  // count exactly the candidates up to and including the one that caused the event
-                        wave_scan_range<true>(P, BL, L, M, SL, cl, orient, seg, mode, tc0, X + 1, req_thres, lane, C);
-                        K.c = X + 1;
-                        if (event == 2) { wave_fence(); return 1; }
-                        restart = true;
+                        int event = 0; uint32_t X = 0;
+                        const uint32_t nv = rl(hc, (int)nxt);
+                        for (uint32_t base = 0; base < nv && !event; base += 64) {
+                            const uint32_t i = base + lane;
+                            SurvRec r = {0, 0, 0, 0};
+                            if (i < nv) r = o->surv[i];
+                            u64 m = __ballot(i < nv);
+                            while (m) {
+                                const int ls = (int)__builtin_ctzll(m);
+                                m &= m - 1;
+                                const uint32_t wo = rl(r.w_ord, ls);
+                                const int e = accept_survivor(P, M, SL, orient, mode, wo & 0xff, rl(r.hchr, ls), rl(r.hloc, ls), rl(r.hkey, ls), lane);
+                                if (e) { event = e; X = tc0 + (wo >> 8); break; }
+                            }
+                        }
+                        if (!event) {
+                            C.n_cand += rl(h0, (int)nxt);
+                            C.sum_w += rl(hw, (int)nxt);
+                            K.c = tc0 + tn;
+                        } else {  // count exactly the candidates up to and including the one that caused the event
+                            wave_scan_range<true>(P, BL, L, M, SL, cl, orient, seg, mode, tc0, X + 1, req_thres, lane, C);
+                            K.c = X + 1;
+                            if (event == 2) { wave_fence(); return 1; }
+                            restart = true;
+                        }
                     }
                 }
                 if (!restart) K.W = min(K.W * HS_GROW, (uint32_t)HS_WINMAX);
