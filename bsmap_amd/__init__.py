@@ -64,7 +64,7 @@ EXPORTS = [
     "bsx_ref_download_words", "bsx_index_build", "bsx_index_n_entries", "bsx_index_download", "bsx_ref_n_sites", "bsx_ref_sites",
     "bsx_batch_create", "bsx_batch_destroy", "bsx_batch_upload_se", "bsx_batch_upload_pe", "bsx_batch_synth_reads",
     "bsx_batch_run", "bsx_batch_run_range", "bsx_batch_sync", "bsx_batch_kernel_ms", "bsx_batch_results_se", "bsx_batch_results_pe",
-    "bsx_batch_counters", "bsx_batch_reset_counters", "bsx_batch_download_reads", "bsx_batch_set_debug", "bsx_batch_unit_cycles",
+    "bsx_batch_counters", "bsx_batch_reset_counters", "bsx_batch_download_reads", "bsx_batch_set_debug", "bsx_batch_unit_cycles", "bsx_batch_ctrl_clocks",
     "bsx_batch_debug_hits", "bsx_batch_debug_pairs", "bsx_batch_debug_plan", "bsx_set_waves_per_cu", "bsx_set_heavy_threshold", "bsx_batch_last_heavy_units",
 ]
 
@@ -122,6 +122,7 @@ def lib():
         L.bsx_batch_download_reads.argtypes = [vp, i32, vp, vp]
         L.bsx_batch_set_debug.argtypes = [vp, i32]
         L.bsx_batch_unit_cycles.argtypes = [vp, vp]
+        L.bsx_batch_ctrl_clocks.argtypes = [vp, vp]
         L.bsx_batch_debug_hits.argtypes = [vp, u32, i32, i32, i32, vp, u32]
         L.bsx_batch_debug_pairs.argtypes = [vp, u32, i32, vp, u32]
         L.bsx_batch_debug_plan.argtypes = [vp, u32, i32, vp, vp]
@@ -291,6 +292,11 @@ class _Batch:
     def heavy_units(self): return _check(lib().bsx_batch_last_heavy_units(self.h))
 
     def set_debug(self, mode): _check(lib().bsx_batch_set_debug(self.h, mode))
+
+    def ctrl_clocks(self):
+        c = np.zeros(8, np.uint64)
+        _check(lib().bsx_batch_ctrl_clocks(self.h, c.ctypes.data))
+        return c
 
     def unit_cycles(self):
         c = np.zeros(self.n, np.uint32)

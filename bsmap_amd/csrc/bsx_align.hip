@@ -994,10 +994,10 @@ __global__ __launch_bounds__(256, PE ? BSX_WAVES_PER_EU_PE : BSX_WAVES_PER_EU_SE
 #define HS_SCAP 512u
 #endif
 #ifndef HS_WIN0
-#define HS_WIN0 32768u
+#define HS_WIN0 1048576u  // early exits inside long lists are rare and a scanned candidate costs ~4 ps of chip time
 #endif
 #ifndef HS_GROW
-#define HS_GROW 8u
+#define HS_GROW 4u
 #endif
 #ifndef HS_WINMAX
 #define HS_WINMAX (1u << 22)
@@ -1026,15 +1026,17 @@ struct HState {
 struct HTask { uint32_t h, c0, n, pad; };
 struct HTaskOut { uint32_t count, overflow, acc[4], pad[2]; SurvRec surv[HS_SCAP]; };
 struct HeavyArgs {
-    HState *state; uint8_t *slabs; uint32_t *active_in, *active_out, *n_active_out; HTask *tasks; HTaskOut *tout; uint32_t *n_tasks, *queue;
-    uint32_t n_active_in, task_cap, fresh, list_base;
+    HState *state; uint8_t *slabs; uint32_t *active_in, *active_out, *n_active_out; HTask *tasks; HTaskOut *tout; uint32_t *n_tasks, *queue, *task_keys;
+    const uint32_t *task_order;
+    const uint32_t *n_active_in_ptr;
+    uint32_t n_active_in, task_cap, fresh, list_base, hidx_base;
 };
 __host__ HeavyArgs typed(const HeavyArgsRaw &r)
 {
     HeavyArgs h;
     h.state = (HState *)r.state; h.slabs = r.slabs; h.active_in = r.active_in; h.active_out = r.active_out; h.n_active_out = r.n_active_out;
-    h.tasks = (HTask *)r.tasks; h.tout = (HTaskOut *)r.tout; h.n_tasks = r.n_tasks; h.queue = r.queue;
-    h.n_active_in = r.n_active_in; h.task_cap = r.task_cap; h.fresh = r.fresh; h.list_base = r.list_base;
+    h.tasks = (HTask *)r.tasks; h.tout = (HTaskOut *)r.tout; h.n_tasks = r.n_tasks; h.queue = r.queue; h.task_keys = r.task_keys; h.task_order = r.task_order;
+    h.n_active_in_ptr = r.n_active_in_ptr; h.n_active_in = r.n_active_in; h.task_cap = r.task_cap; h.fresh = r.fresh; h.list_base = r.list_base; h.hidx_base = r.hidx_base;
     return h;
 }
 
@@ -1061,7 +1063,12 @@ __device__ void load_mate(const HMate &d, Mate &M, MateLds &L, int lane)
     wave_fence();
 }
 
-struct HCursor { int level, sub, orient, have, paired; uint32_t c, W; };
+struct HCursor { int level, sub, orient, have, paired; uint32_t c, W, n_active; };
+
+// diagnostic category clocks of k_hctrl (only when the caller asked for unit cycles): 0 prepare/restore, 1 inline scans,
+// 2 survivor replay, 3 sort+pairs, 4 save/finish, 5 recount after events
+#define CAT_BEGIN(A) const u64 cat_t0_ = (A).dbg_cat ? __builtin_readcyclecounter() : 0
+#define CAT_END(A, k) do { if ((A).dbg_cat && lane == 0) atomicAdd((u64 *)&(A).dbg_cat[k], (u64)__builtin_readcyclecounter() - cat_t0_); } while (0)
 
 // resumable SnpAlign for a deferred unit: 0 = call complete, 1 = the reference's SnpAlign returned early, 2 = a window
 // of the current list was published and the unit must wait for k_hscan
@@ -1075,7 +1082,10 @@ __device__ int snp_align_heavy(const AlignArgs &A, const HeavyArgs &H, HState *S
         const int seg = L.order[orient][mode];
         const CandList cl = make_list(P, BL, L, M, orient, seg, lane);
         if (cl.total < min(A.heavy_threshold, (uint32_t)HS_TASK_MIN)) {  // short list: the owning wave scans it itself
-            if (wave_scan_range<false>(P, BL, L, M, SL, cl, orient, seg, mode, 0, cl.total, 0, lane, C) == 2) { wave_fence(); return 1; }
+            CAT_BEGIN(A);
+            const int r_ = wave_scan_range<false>(P, BL, L, M, SL, cl, orient, seg, mode, 0, cl.total, 0, lane, C);
+            CAT_END(A, 1);
+            if (r_ == 2) { wave_fence(); return 1; }
             continue;
         }
         while (K.c < cl.total) {
@@ -1109,7 +1119,9 @@ __device__ int snp_align_heavy(const AlignArgs &A, const HeavyArgs &H, HState *S
                         const uint32_t tc0 = win_c0 + t * HS_TASK, tn = min((uint32_t)HS_TASK, win_n - t * HS_TASK);
                         const HTaskOut *o = &H.tout[t0 + t];
                         if (rl(hov, (int)nxt)) {  // too many survivors for the record: redo this task with the one-wave path
+                            CAT_BEGIN(A);
                             const int r = wave_scan_range<false>(P, BL, L, M, SL, cl, orient, seg, mode, tc0, tc0 + tn, 0, lane, C);
+                            CAT_END(A, 1);
                             if (r == 2) { wave_fence(); return 1; }
                             K.c = tc0 + tn;
                             if (r == 1) restart = true;  // later tasks were evaluated under the old threshold
@@ -1117,6 +1129,7 @@ __device__ int snp_align_heavy(const AlignArgs &A, const HeavyArgs &H, HState *S
                         }
                         int event = 0; uint32_t X = 0;
                         const uint32_t nv = rl(hc, (int)nxt);
+                        CAT_BEGIN(A);
                         for (uint32_t base = 0; base < nv && !event; base += 64) {
                             const uint32_t i = base + lane;
                             SurvRec r = {0, 0, 0, 0};
@@ -1130,12 +1143,13 @@ __device__ int snp_align_heavy(const AlignArgs &A, const HeavyArgs &H, HState *S
                                 if (e) { event = e; X = tc0 + (wo >> 8); break; }
                             }
                         }
+                        CAT_END(A, 2);
                         if (!event) {
                             C.n_cand += rl(h0, (int)nxt);
                             C.sum_w += rl(hw, (int)nxt);
                             K.c = tc0 + tn;
                         } else {  // count exactly the candidates up to and including the one that caused the event
-                            wave_scan_range<true>(P, BL, L, M, SL, cl, orient, seg, mode, tc0, X + 1, req_thres, lane, C);
+                            { CAT_BEGIN(A); wave_scan_range<true>(P, BL, L, M, SL, cl, orient, seg, mode, tc0, X + 1, req_thres, lane, C); CAT_END(A, 5); }
                             K.c = X + 1;
                             if (event == 2) { wave_fence(); return 1; }
                             restart = true;
@@ -1144,7 +1158,7 @@ __device__ int snp_align_heavy(const AlignArgs &A, const HeavyArgs &H, HState *S
                 }
                 if (!restart) K.W = min(K.W * HS_GROW, (uint32_t)HS_WINMAX);
             } else {
-                const uint32_t weff = H.n_active_in < 2048u ? (uint32_t)HS_WINMAX : K.W;  // few units left: scanning capacity is idle, speculate the whole list
+                const uint32_t weff = K.n_active < 2048u ? (uint32_t)HS_WINMAX : K.W;  // few units left: scanning capacity is idle, speculate the whole list
                 const uint32_t wn = min(weff, cl.total - K.c), nt = (wn + HS_TASK - 1) / HS_TASK;
                 uint32_t t0 = 0;
                 if (lane == 0) t0 = atomicAdd(H.n_tasks, nt);
@@ -1153,6 +1167,12 @@ __device__ int snp_align_heavy(const AlignArgs &A, const HeavyArgs &H, HState *S
                     for (uint32_t t = lane; t < nt; t += 64) {
                         HTask tk; tk.h = hidx; tk.c0 = K.c + t * HS_TASK; tk.n = min((uint32_t)HS_TASK, wn - t * HS_TASK); tk.pad = 0;
                         H.tasks[t0 + t] = tk;
+                        uint32_t key = 0;  // index-entry address of the task's first candidate
+                        for (int sx = 0; sx < cl.nsub; sx++) {
+                            const uint32_t ps = rl(cl.sub_pre, sx), ns = rl(cl.sub_n, sx);
+                            if (tk.c0 >= ps && tk.c0 < ps + ns) key = rl(cl.sub_base, sx) + (tk.c0 - ps);
+                        }
+                        H.task_keys[t0 + t] = key;
                     }
                     ListReq &R = S->req;
                     if (lane < 32) { R.sub_pre[lane] = cl.sub_pre; R.sub_n[lane] = cl.sub_n; R.sub_base[lane] = cl.sub_base; R.sub_h[lane] = cl.sub_h; }
@@ -1192,7 +1212,10 @@ __device__ bool heavy_advance(const AlignArgs &A, const HeavyArgs &H, HState *S,
                 if (K.level < MB.seedseg && snp_align_heavy(A, H, S, hidx, BL, LB, MB, U.SB, K.level, K, lane, C) == 2) return false;
                 K.sub = 2;
             }
-            if (pair_level_post(P, MA, MB, U, pcnt_reg, K.level, lane) > 0) { K.paired = K.level + 1; return true; }
+            CAT_BEGIN(A);
+            const int np_ = pair_level_post(P, MA, MB, U, pcnt_reg, K.level, lane);
+            CAT_END(A, 3);
+            if (np_ > 0) { K.paired = K.level + 1; return true; }
             K.level++; K.sub = 0; K.orient = 0; K.c = 0; K.W = HS_WIN0; K.have = 0;
         }
     }
@@ -1222,12 +1245,13 @@ __global__ __launch_bounds__(256) void k_hctrl(AlignArgs A, HeavyArgs H)
     MateLds &LB = WL[wv].mate[PE ? 1 : 0];
     Counters Cflush = {0, 0, 0, 0};
     u64 n_units_done = 0, n_aligned = 0, n_aligned_pairs = 0;
+    const uint32_t n_active_in = H.fresh ? H.n_active_in : rfl(*H.n_active_in_ptr);  // later passes: count left by the previous pass
     for (;;) {
         uint32_t i = 0;
         if (lane == 0) i = atomicAdd(H.queue, 1u);
         i = rfl(i);
-        if (i >= H.n_active_in) break;
-        const uint32_t hidx = H.fresh ? i : rfl(H.active_in[i]);
+        if (i >= n_active_in) break;
+        const uint32_t hidx = H.fresh ? H.hidx_base + i : rfl(H.active_in[i]);
         const uint32_t unit = rfl(A.heavy_list[H.list_base + hidx]);
         HState *S = &H.state[hidx];
         uint8_t *slab = A.debug ? A.scratch + (size_t)unit * A.slab_bytes : H.slabs + (size_t)hidx * A.slab_bytes;
@@ -1235,7 +1259,9 @@ __global__ __launch_bounds__(256) void k_hctrl(AlignArgs A, HeavyArgs H)
         Mate MA, MB;
         Counters C = {0, 0, 0, 0};
         HCursor K;
+        K.n_active = n_active_in;
         uint32_t pcnt_reg = 0;
+        const u64 cat_prep0 = A.dbg_cat ? __builtin_readcyclecounter() : 0;
         if (H.fresh) {
             unit_prepare<PE>(A, BL, LA, LB, MA, MB, unit, lane, C);
             K.level = 0; K.sub = 0; K.orient = 0; K.have = 0; K.paired = 0; K.c = 0; K.W = HS_WIN0;
@@ -1249,7 +1275,11 @@ __global__ __launch_bounds__(256) void k_hctrl(AlignArgs A, HeavyArgs H)
             K.level = (int)rfl((uint32_t)S->level); K.sub = (int)rfl((uint32_t)S->sub); K.orient = (int)rfl((uint32_t)S->orient);
             K.have = (int)rfl((uint32_t)S->have); K.paired = (int)rfl((uint32_t)S->paired); K.c = rfl(S->c); K.W = rfl(S->W);
         }
+        if (A.dbg_cat && lane == 0) atomicAdd((u64 *)&A.dbg_cat[0], (u64)__builtin_readcyclecounter() - cat_prep0);
+        const u64 cat_adv0 = A.dbg_cat ? __builtin_readcyclecounter() : 0;
         const bool done = heavy_advance<PE>(A, H, S, hidx, BL, LA, LB, MA, MB, U, pcnt_reg, K, lane, C);
+        if (A.dbg_cat && lane == 0) atomicAdd((u64 *)&A.dbg_cat[6], (u64)__builtin_readcyclecounter() - cat_adv0);
+        const u64 cat_fin0 = A.dbg_cat ? __builtin_readcyclecounter() : 0;
         if (done) {
             unit_finish<PE>(A, LA, LB, MA, MB, U, pcnt_reg, K.paired, unit, lane, n_aligned, n_aligned_pairs);
             Cflush.n_lookup += C.n_lookup; Cflush.n_cand += C.n_cand; Cflush.sum_w += C.sum_w; Cflush.n_orient += C.n_orient;
@@ -1263,6 +1293,7 @@ __global__ __launch_bounds__(256) void k_hctrl(AlignArgs A, HeavyArgs H)
                 H.active_out[atomicAdd(H.n_active_out, 1u)] = hidx;
             }
         }
+        if (A.dbg_cat && lane == 0) atomicAdd((u64 *)&A.dbg_cat[4], (u64)__builtin_readcyclecounter() - cat_fin0);
         wave_fence();
     }
     if (lane == 0) flush_counters(A, Cflush, n_units_done, n_aligned, n_aligned_pairs);
@@ -1278,11 +1309,13 @@ __global__ __launch_bounds__(256, 8) void k_hscan(AlignArgs A, HeavyArgs H)
     init_block_lds(P, BL, threadIdx.x, 256);
     __syncthreads();
     const uint32_t n_tasks = min(*H.n_tasks, H.task_cap);
+    u64 scanned = 0;
     for (;;) {
         uint32_t t = 0;
         if (lane == 0) t = atomicAdd(H.queue + 1, 1u);
         t = rfl(t);
         if (t >= n_tasks) break;
+        if (H.task_order) t = rfl(H.task_order[t]);
         const uint32_t hidx = rfl(H.tasks[t].h), tc0 = rfl(H.tasks[t].c0), tn = rfl(H.tasks[t].n);
         const ListReq &R = H.state[hidx].req;
         if (lane < 32) { TAB[wv][0][lane] = R.sub_pre[lane]; TAB[wv][1][lane] = R.sub_n[lane]; TAB[wv][2][lane] = R.sub_base[lane]; TAB[wv][3][lane] = R.sub_h[lane]; }
@@ -1338,8 +1371,10 @@ __global__ __launch_bounds__(256, 8) void k_hscan(AlignArgs A, HeavyArgs H)
             }
         }
         if (lane == 0) { o->count = overflow ? 0 : nsurv; o->overflow = overflow ? 1 : 0; o->acc[0] = a0; o->acc[1] = a1; o->acc[2] = a2; o->acc[3] = a5; }
+        scanned += a0;
         wave_fence();
     }
+    if (lane == 0 && scanned) atomicAdd((u64 *)&A.counters[7], scanned);  // candidates evaluated by the scan kernel (incl. speculation)
 }
 
 }  // namespace

@@ -11,6 +11,7 @@
 
 static int g_waves_per_cu = 0;
 static int g_heavy_threshold = 8192;  // candidate-list length that sends a unit to the cooperative heavy kernel
+static int g_sort_tasks = 0;  // ordering scan tasks by index address was measured neutral (k_hscan is not HBM-bound); kept as a knob
 
 extern "C" int bsx_set_waves_per_cu(int w) { g_waves_per_cu = w; return BSX_OK; }
 extern "C" int bsx_set_heavy_threshold(int t) { g_heavy_threshold = t < 0 ? 0 : t; return BSX_OK; }
@@ -196,7 +197,10 @@ struct bsx_batch {
     uint32_t *d_heavy_list = nullptr, *d_heavy_count = nullptr;
     // heavy pipeline pools
     uint8_t *d_hstate = nullptr, *d_hslabs = nullptr, *d_htasks = nullptr, *d_htout = nullptr;
-    uint32_t *d_hactive[2] = {nullptr, nullptr}, *d_hcnt = nullptr;  // d_hcnt: n_active_out, n_tasks, queue[2]
+    uint32_t *d_hactive[4] = {nullptr, nullptr, nullptr, nullptr}, *d_hcnt = nullptr;  // d_hcnt: per group two ping-pong blocks {n_active, n_tasks, queue[2]}
+    uint32_t *d_tkeys = nullptr, *d_tkeys_sorted = nullptr, *d_tiota = nullptr, *d_torder = nullptr;
+    void *d_sort_temp = nullptr;
+    size_t sort_temp_bytes = 0;
     uint32_t hcap = 0, task_cap = 0;
     int n_cu = 0;
     uint32_t last_heavy = 0, last_heavy_iters = 0;
@@ -245,9 +249,14 @@ static int ensure_scratch(bsx_batch *b)
         HIP_TRY(hipMemsetAsync(b->d_hslabs, 0, (size_t)b->hcap * b->slab_bytes, b->stream));
         HIP_TRY(hipMalloc((void **)&b->d_htasks, (size_t)b->task_cap * bsx_htask_bytes()));
         HIP_TRY(hipMalloc((void **)&b->d_htout, (size_t)b->task_cap * bsx_htaskout_bytes()));
-        HIP_TRY(hipMalloc((void **)&b->d_hactive[0], (size_t)b->hcap * 4));
-        HIP_TRY(hipMalloc((void **)&b->d_hactive[1], (size_t)b->hcap * 4));
+        for (int k = 0; k < 4; k++) HIP_TRY(hipMalloc((void **)&b->d_hactive[k], (size_t)b->hcap * 4));
         HIP_TRY(hipMalloc((void **)&b->d_hcnt, 256));
+        for (uint32_t **q : {&b->d_tkeys, &b->d_tkeys_sorted, &b->d_tiota, &b->d_torder}) HIP_TRY(hipMalloc((void **)q, (size_t)b->task_cap * 4));
+        {
+            std::vector<uint32_t> iota(b->task_cap);
+            for (uint32_t i = 0; i < b->task_cap; i++) iota[i] = i;
+            HIP_TRY(hipMemcpy(b->d_tiota, iota.data(), iota.size() * 4, hipMemcpyHostToDevice));
+        }
     }
     const uint64_t slots = b->debug ? b->max_units : (uint64_t)grid * 4;
     const size_t bytes = (size_t)(slots * b->slab_bytes);
@@ -285,8 +294,8 @@ extern "C" int bsx_batch_create(bsx_ref *r, uint32_t max_units, int paired, bsx_
         if (hipMalloc((void **)&b->d_pairs, (size_t)max_units * sizeof(bsx_pair)) != hipSuccess || hipMalloc((void **)&b->d_npairs, (size_t)max_units * 64) != hipSuccess)
             return fail(BSX_ERR_NOMEM);
     } else if (hipMalloc((void **)&b->d_hits, (size_t)max_units * sizeof(bsx_hit)) != hipSuccess) return fail(BSX_ERR_NOMEM);
-    if (hipMalloc((void **)&b->d_queue, 256) != hipSuccess || hipMalloc((void **)&b->d_counters, BSX_N_COUNTERS * 8) != hipSuccess) return fail(BSX_ERR_NOMEM);
-    if (hipMemsetAsync(b->d_counters, 0, BSX_N_COUNTERS * 8, b->stream) != hipSuccess) return fail(BSX_ERR_DEVICE);
+    if (hipMalloc((void **)&b->d_queue, 256) != hipSuccess || hipMalloc((void **)&b->d_counters, BSX_N_COUNTERS * 8 + 256) != hipSuccess) return fail(BSX_ERR_NOMEM);
+    if (hipMemsetAsync(b->d_counters, 0, BSX_N_COUNTERS * 8 + 256, b->stream) != hipSuccess) return fail(BSX_ERR_DEVICE);
     if ((rc = ensure_scratch(b)) != BSX_OK) return fail(rc);
     *out = b;
     return BSX_OK;
@@ -301,10 +310,11 @@ extern "C" void bsx_batch_destroy(bsx_batch *b)
         for (void *q : {(void *)b->d_seq[m], (void *)b->d_qual[m], (void *)b->d_off[m], (void *)b->d_cc[m]})
             if (q) (void)hipFree(q);
     for (void *q : {(void *)b->d_hits, (void *)b->d_pairs, (void *)b->d_npairs, (void *)b->d_scratch, (void *)b->d_dbg, (void *)b->d_queue, (void *)b->d_counters, (void *)b->d_cycles, (void *)b->d_heavy_list, (void *)b->d_heavy_count,
-                    (void *)b->d_hstate, (void *)b->d_hslabs, (void *)b->d_htasks, (void *)b->d_htout, (void *)b->d_hactive[0], (void *)b->d_hactive[1], (void *)b->d_hcnt})
+                    (void *)b->d_hstate, (void *)b->d_hslabs, (void *)b->d_htasks, (void *)b->d_htout, (void *)b->d_hactive[0], (void *)b->d_hactive[1], (void *)b->d_hactive[2], (void *)b->d_hactive[3], (void *)b->d_hcnt})
         if (q) (void)hipFree(q);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
+    for (void *q : {(void *)b->d_tkeys, (void *)b->d_tkeys_sorted, (void *)b->d_tiota, (void *)b->d_torder, b->d_sort_temp}) if (q) (void)hipFree(q);
     if (b->stream) (void)hipStreamDestroy(b->stream);
     delete b;
 }
@@ -377,7 +387,7 @@ extern "C" int bsx_batch_run_range(bsx_batch *b, uint32_t first_unit, uint32_t n
     A.first_unit = first_unit;
     for (int m = 0; m < 2; m++) { A.seq[m] = b->d_seq[m]; A.off[m] = b->d_off[m]; A.qual[m] = b->has_qual ? b->d_qual[m] : nullptr; A.cc[m] = b->d_cc[m]; }
     A.hits_out = b->d_hits; A.pairs_out = b->d_pairs; A.npairs_out = b->d_npairs;
-    A.scratch = b->d_scratch; A.slab_bytes = b->slab_bytes; A.queue = b->d_queue; A.counters = b->d_counters; A.dbg_plan = b->d_dbg; A.dbg_cycles = b->d_cycles;
+    A.scratch = b->d_scratch; A.slab_bytes = b->slab_bytes; A.queue = b->d_queue; A.counters = b->d_counters; A.dbg_plan = b->d_dbg; A.dbg_cycles = b->d_cycles; A.dbg_cat = b->d_cycles ? b->d_counters + 16 : nullptr;
     A.heavy_list = b->d_heavy_list; A.heavy_count = b->d_heavy_count;
     A.heavy_threshold = b->ref->P.rrbs ? 0u : (uint32_t)g_heavy_threshold;
     HIP_TRY(hipMemsetAsync(b->d_queue, 0, 4, b->stream));
@@ -394,28 +404,48 @@ extern "C" int bsx_batch_run_range(bsx_batch *b, uint32_t first_unit, uint32_t n
         HIP_TRY(hipMemcpyAsync(&n_heavy, b->d_heavy_count, 4, hipMemcpyDeviceToHost, b->stream));
         HIP_TRY(hipStreamSynchronize(b->stream));
         b->last_heavy = n_heavy;
-        HeavyArgsRaw H;
-        memset(&H, 0, sizeof(H));
-        H.state = b->d_hstate; H.slabs = b->d_hslabs; H.tasks = b->d_htasks; H.tout = b->d_htout;
-        H.n_active_out = b->d_hcnt; H.n_tasks = b->d_hcnt + 1; H.queue = b->d_hcnt + 2; H.task_cap = b->task_cap;
+        // Each round handles up to hcap deferred units.  One pass = k_hctrl (advance every active unit, publish scan
+        // tasks) -> read the two counts back -> order the tasks by the index address they start at, so that tasks walking
+        // the same part of a big bucket run together and share its cache lines -> k_hscan.
         for (uint32_t base = 0; base < n_heavy; base += b->hcap) {
             uint32_t n_act = std::min(b->hcap, n_heavy - base);
+            HeavyArgsRaw H;
+            memset(&H, 0, sizeof(H));
+            H.state = b->d_hstate; H.slabs = b->d_hslabs; H.tasks = b->d_htasks; H.tout = b->d_htout; H.task_keys = b->d_tkeys;
+            H.task_cap = b->task_cap; H.list_base = base; H.hidx_base = 0; H.fresh = 1;
+            uint32_t *blk[2] = {b->d_hcnt, b->d_hcnt + 8};
             int cur = 0;
-            H.fresh = 1; H.list_base = base;
             for (uint32_t iter = 0; n_act > 0; iter++) {
                 if (iter > 100000) { g_bsx_err = "heavy pipeline did not converge"; return BSX_ERR_DEVICE; }
-                HIP_TRY(hipMemsetAsync(b->d_hcnt, 0, 16, b->stream));
-                H.active_in = b->d_hactive[cur]; H.active_out = b->d_hactive[cur ^ 1]; H.n_active_in = n_act;
+                uint32_t *in = blk[cur], *out = blk[cur ^ 1];
+                HIP_TRY(hipMemsetAsync(out, 0, 16, b->stream));
+                H.active_in = b->d_hactive[cur]; H.active_out = b->d_hactive[cur ^ 1];
+                H.n_active_in_ptr = in; H.n_active_in = n_act; H.n_active_out = out; H.n_tasks = out + 1; H.queue = out + 2;
                 bsx_launch_hctrl(A, H, b->paired, (int)std::min<uint32_t>((n_act + 3) / 4, (uint32_t)b->n_cu * 4), b->stream);
                 HIP_TRY(hipGetLastError());
                 uint32_t cnt[2] = {0, 0};
-                HIP_TRY(hipMemcpyAsync(cnt, b->d_hcnt, 8, hipMemcpyDeviceToHost, b->stream));
+                HIP_TRY(hipMemcpyAsync(cnt, out, 8, hipMemcpyDeviceToHost, b->stream));
                 HIP_TRY(hipStreamSynchronize(b->stream));
                 b->last_heavy_iters++;
                 n_act = cnt[0];
                 if (n_act == 0) break;
                 const uint32_t n_tasks = std::min(cnt[1], b->task_cap);
                 if (n_tasks) {
+                    H.task_order = nullptr;
+                    if (n_tasks >= 4096 && g_sort_tasks) {
+                        size_t need = 0;
+                        int rc = bsx_sort_tasks(b->d_tkeys, b->d_tkeys_sorted, b->d_tiota, b->d_torder, n_tasks, nullptr, need, b->stream);
+                        if (rc) return rc;
+                        if (need > b->sort_temp_bytes) {
+                            if (b->d_sort_temp) (void)hipFree(b->d_sort_temp);
+                            b->d_sort_temp = nullptr; b->sort_temp_bytes = 0;
+                            HIP_TRY(hipMalloc(&b->d_sort_temp, need));
+                            b->sort_temp_bytes = need;
+                        }
+                        rc = bsx_sort_tasks(b->d_tkeys, b->d_tkeys_sorted, b->d_tiota, b->d_torder, n_tasks, b->d_sort_temp, need, b->stream);
+                        if (rc) return rc;
+                        H.task_order = b->d_torder;
+                    }
                     bsx_launch_hscan(A, H, (int)std::min<uint32_t>((n_tasks + 3) / 4, (uint32_t)b->n_cu * 8), b->stream);
                     HIP_TRY(hipGetLastError());
                 }
@@ -542,6 +572,15 @@ extern "C" int bsx_batch_last_heavy_units(bsx_batch *b)
     HIP_TRY(hipSetDevice(b->ref->device));
     HIP_TRY(hipStreamSynchronize(b->stream));
     return (int)b->last_heavy;
+}
+
+extern "C" int bsx_batch_ctrl_clocks(bsx_batch *b, uint64_t out[8])
+{
+    if (!b || !out) return BSX_ERR_ARG;
+    HIP_TRY(hipSetDevice(b->ref->device));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(hipMemcpy(out, b->d_counters + 16, 64, hipMemcpyDeviceToHost));
+    return BSX_OK;
 }
 
 extern "C" int bsx_batch_unit_cycles(bsx_batch *b, uint32_t *out)

@@ -20,3 +20,5 @@ for i in heavy: print(" unit", i, "cycles", c[i], "paired", out[i]["paired"], "n
 tot = c.sum(); srt = np.sort(c)[::-1]; print("share of cycles in top 1%% units: %.2f, top 5%%: %.2f" % (srt[:n // 100].sum() / tot, srt[:n // 20].sum() / tot))
 print("counters", pa.counters())
 print("heavy units", pa.heavy_units())
+
+cc = pa.ctrl_clocks().astype(float); print("ctrl clocks (Mcycles): prepare/restore %.0f inline-scan %.0f replay %.0f sort+pairs %.0f save/finish %.0f recount %.0f advance-total %.0f" % tuple(cc[[0,1,2,3,4,5,6]]/1e6))
