@@ -1,0 +1,87 @@
+"""The command-line driver (bsmap_amd/bsmap: C++ host over the C ABI) against the output files of the REAL bsmap binary
+recorded in tests/golden/cli_outputs.json.gz: SAM (-R -u and plain) and BSP (-u, with the -2 file for pairs) must be
+byte-identical, except for lines the reference itself does not determine (documented below)."""
+import gzip
+import json
+import os
+import subprocess
+
+import pytest
+
+import golden_util as G
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "bsmap_amd", "bsmap")
+CLI = json.load(gzip.open(os.path.join(G.GOLDEN, "cli_outputs.json.gz"), "rt"))
+
+
+def _leaky_names(meta):
+    """reads whose reference result depends on the previous read (uninitialised planner state)"""
+    kw = meta["kw"]
+    if "D" in kw:
+        return set()
+    S, I = kw.get("s", 16), kw.get("I", 4)
+    bad = set()
+    for r, e in zip(meta["reads"], meta["expected"]):
+        if meta["kind"] == "se":
+            if not e["filtered"] and (e["len"] - I + 1) % S == 0:
+                bad.add(r["name"])
+        else:
+            for m in ("a", "b"):
+                if not e[m]["filtered"] and (e[m]["len"] - I + 1) % S == 0:
+                    bad.add(r["name"])
+    return bad
+
+
+def _body(text):
+    return [ln for ln in text.split("\n") if ln and not ln.startswith("@PG")]
+
+
+@pytest.mark.parametrize("name", sorted(CLI))
+@pytest.mark.parametrize("tag", ["sam_plain", "sam_Ru", "bsp_u"])
+def test_cli_matches_reference_binary(name, tag, tmp_path):
+    meta, arr, fasta = G.load(name)
+    run = CLI[name][tag]
+    pe = meta["kind"] == "pe"
+    if pe:
+        f1, f2 = str(tmp_path / "r_1.fq"), str(tmp_path / "r_2.fq")
+        with open(f1, "w") as a, open(f2, "w") as b:
+            for r in meta["reads"]:
+                a.write(f"@{r['name']}/1\n{r['seq1']}\n+\n{r['qual1']}\n")
+                b.write(f"@{r['name']}/2\n{r['seq2']}\n+\n{r['qual2']}\n")
+        inputs = ["-a", f1, "-b", f2]
+    else:
+        f1 = str(tmp_path / "r.fq")
+        with open(f1, "w") as a:
+            for r in meta["reads"]:
+                a.write(f"@{r['name']}\n{r['seq']}\n+\n{r['qual']}\n")
+        inputs = ["-a", f1]
+    out, out2 = str(tmp_path / ("o" + run["ext"])), str(tmp_path / ("o2" + run["ext"]))
+    opts = list(run["options"])
+    cmd = [BIN] + (["-D", meta["kw"]["D"]] if "D" in meta["kw"] else []) + inputs + ["-d", fasta, "-o", out] + \
+        (["-2", out2] if pe and run["ext"] == ".bsp" else []) + [o for i, o in enumerate(opts) if not (o == "-D" or (i and opts[i - 1] == "-D"))]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-1500:]
+    leaky = _leaky_names(meta)
+
+    def keep(ln):
+        nm = ln.split("\t")[0]
+        nm = nm[:-2] if nm.endswith(("/1", "/2")) else nm
+        return nm not in leaky and not any(nm == x[:len(nm)] and len(nm) >= len(x) - 2 for x in leaky)
+
+    for got_path, exp_text in ((out, run["out"]), (out2, run["out2"])):
+        if exp_text is None:
+            continue
+        got, exp = [l for l in _body(open(got_path).read()) if keep(l)], [l for l in _body(exp_text) if keep(l)]
+        if run["ext"] == ".bsp":
+            # QC lines: the reference decides whether to print a filtered read reverse-complemented from a stale hit record
+            # of the previous read (align.cpp:712 with n = -1); compare those lines by name and status only
+            def norm(l):
+                f = l.split("\t")
+                return "\t".join([f[0], "QC"]) if len(f) >= 4 and f[3] == "QC" else l
+            got, exp = [norm(l) for l in got], [norm(l) for l in exp]
+        assert len(got) == len(exp), (len(got), len(exp))
+        for g, e in zip(got, exp):
+            assert g == e
+    assert "Total number of aligned reads" in res.stdout
