@@ -15,6 +15,13 @@ static int g_sort_tasks = 0;  // ordering scan tasks by index address was measur
 
 extern "C" int bsx_set_waves_per_cu(int w) { g_waves_per_cu = w; return BSX_OK; }
 extern "C" int bsx_set_heavy_threshold(int t) { g_heavy_threshold = t < 0 ? 0 : t; return BSX_OK; }
+static uint32_t g_hcap = 32768, g_task_cap = 262144;
+extern "C" int bsx_set_heavy_limits(uint32_t units_per_round, uint32_t task_pool)
+{
+    if (units_per_round < 1 || task_pool < 1) return BSX_ERR_ARG;
+    g_hcap = units_per_round; g_task_cap = task_pool;
+    return BSX_OK;
+}
 
 extern "C" int bsx_device_count(void)
 {
@@ -240,8 +247,8 @@ static int ensure_scratch(bsx_batch *b)
     b->grid_blocks = grid;
     b->n_cu = prop.multiProcessorCount;
     if (!b->d_heavy_list) {
-        b->hcap = std::min<uint32_t>(b->max_units, 32768u);  // deferred units handled per round (more than this: several rounds)
-        b->task_cap = 262144;
+        b->hcap = std::min<uint32_t>(b->max_units, g_hcap);  // deferred units handled per round (more than this: several rounds)
+        b->task_cap = g_task_cap;
         HIP_TRY(hipMalloc((void **)&b->d_heavy_list, ((size_t)b->max_units + 1) * 4));
         HIP_TRY(hipMalloc((void **)&b->d_heavy_count, 256));
         HIP_TRY(hipMalloc((void **)&b->d_hstate, (size_t)b->hcap * bsx_hstate_bytes()));

@@ -352,3 +352,13 @@ def test_heavy_pipeline_large_buckets(pe, heavy_genome, oracle):
         pa.close()
     gref.close()
     oref.free()
+
+
+def test_heavy_pipeline_small_pools(heavy_genome, oracle):
+    """tiny task pool and tiny per-round capacity: requests get refused and retried, deferred units take several rounds"""
+    B.lib().bsx_set_heavy_limits(97, 24)
+    try:
+        test_heavy_pipeline_large_buckets(True, heavy_genome, oracle)
+        test_heavy_pipeline_large_buckets(False, heavy_genome, oracle)
+    finally:
+        B.lib().bsx_set_heavy_limits(32768, 262144)
