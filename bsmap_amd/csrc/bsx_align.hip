@@ -1318,12 +1318,16 @@ __global__ __launch_bounds__(256, 8) void k_hscan(AlignArgs A, HeavyArgs H)
         if (t >= n_tasks) break;
         if (H.task_order) t = rfl(H.task_order[t]);
         const uint32_t hidx = rfl(H.tasks[t].h), tc0 = rfl(H.tasks[t].c0), tn = rfl(H.tasks[t].n);
+        if (tn == 0) {  // slot neutralised by a refused request: its unit has not published a list (ListReq may be stale)
+            if (lane == 0) { HTaskOut *oe = &H.tout[t]; oe->count = 0; oe->overflow = 0; oe->acc[0] = oe->acc[1] = oe->acc[2] = oe->acc[3] = 0; }
+            continue;
+        }
         const ListReq &R = H.state[hidx].req;
         if (lane < 32) { TAB[wv][0][lane] = R.sub_pre[lane]; TAB[wv][1][lane] = R.sub_n[lane]; TAB[wv][2][lane] = R.sub_base[lane]; TAB[wv][3][lane] = R.sub_h[lane]; }
         uint32_t rw[9], rm[9];
 #pragma unroll
         for (int k = 0; k < 9; k++) { rw[k] = rfl(R.rw[k]); rm[k] = rfl(R.rm[k]); }
-        const uint32_t thres0 = rfl(R.thres), nsub = rfl(R.nsub);
+        const uint32_t thres0 = rfl(R.thres), nsub = min(rfl(R.nsub), 32u);
         const int nwords = (int)rfl(R.nwords), len = (int)rfl(R.len);
         wave_fence();
         HTaskOut *o = &H.tout[t];

@@ -209,6 +209,7 @@ struct bsx_batch {
     void *d_sort_temp = nullptr;
     size_t sort_temp_bytes = 0;
     uint32_t hcap = 0, task_cap = 0;
+    uint32_t *h_pinned = nullptr;  // pinned host words for the per-pass count read-backs
     int n_cu = 0;
     uint32_t last_heavy = 0, last_heavy_iters = 0;
     size_t scratch_bytes = 0;
@@ -251,11 +252,17 @@ static int ensure_scratch(bsx_batch *b)
         b->task_cap = g_task_cap;
         HIP_TRY(hipMalloc((void **)&b->d_heavy_list, ((size_t)b->max_units + 1) * 4));
         HIP_TRY(hipMalloc((void **)&b->d_heavy_count, 256));
+        HIP_TRY(hipHostMalloc((void **)&b->h_pinned, 256, hipHostMallocDefault));
         HIP_TRY(hipMalloc((void **)&b->d_hstate, (size_t)b->hcap * bsx_hstate_bytes()));
+        if (getenv("BSX_POISON")) HIP_TRY(hipMemsetAsync(b->d_hstate, 0xA5, (size_t)b->hcap * bsx_hstate_bytes(), b->stream));  // test hook: recycled memory is not zero
         HIP_TRY(hipMalloc((void **)&b->d_hslabs, (size_t)b->hcap * b->slab_bytes));
         HIP_TRY(hipMemsetAsync(b->d_hslabs, 0, (size_t)b->hcap * b->slab_bytes, b->stream));
         HIP_TRY(hipMalloc((void **)&b->d_htasks, (size_t)b->task_cap * bsx_htask_bytes()));
         HIP_TRY(hipMalloc((void **)&b->d_htout, (size_t)b->task_cap * bsx_htaskout_bytes()));
+        if (getenv("BSX_POISON")) {
+            HIP_TRY(hipMemsetAsync(b->d_htout, 0xA5, (size_t)b->task_cap * bsx_htaskout_bytes(), b->stream));
+            HIP_TRY(hipMemsetAsync(b->d_htasks, 0xA5, (size_t)b->task_cap * bsx_htask_bytes(), b->stream));
+        }
         for (int k = 0; k < 4; k++) HIP_TRY(hipMalloc((void **)&b->d_hactive[k], (size_t)b->hcap * 4));
         HIP_TRY(hipMalloc((void **)&b->d_hcnt, 256));
         for (uint32_t **q : {&b->d_tkeys, &b->d_tkeys_sorted, &b->d_tiota, &b->d_torder}) HIP_TRY(hipMalloc((void **)q, (size_t)b->task_cap * 4));
@@ -319,6 +326,7 @@ extern "C" void bsx_batch_destroy(bsx_batch *b)
     for (void *q : {(void *)b->d_hits, (void *)b->d_pairs, (void *)b->d_npairs, (void *)b->d_scratch, (void *)b->d_dbg, (void *)b->d_queue, (void *)b->d_counters, (void *)b->d_cycles, (void *)b->d_heavy_list, (void *)b->d_heavy_count,
                     (void *)b->d_hstate, (void *)b->d_hslabs, (void *)b->d_htasks, (void *)b->d_htout, (void *)b->d_hactive[0], (void *)b->d_hactive[1], (void *)b->d_hactive[2], (void *)b->d_hactive[3], (void *)b->d_hcnt})
         if (q) (void)hipFree(q);
+    if (b->h_pinned) (void)hipHostFree(b->h_pinned);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
     for (void *q : {(void *)b->d_tkeys, (void *)b->d_tkeys_sorted, (void *)b->d_tiota, (void *)b->d_torder, b->d_sort_temp}) if (q) (void)hipFree(q);
@@ -407,9 +415,9 @@ extern "C" int bsx_batch_run_range(bsx_batch *b, uint32_t first_unit, uint32_t n
     if (A.heavy_threshold) {
         // heavy pipeline: iterate k_hctrl / k_hscan until every deferred unit is finished (host-driven, so this call
         // returns only after the deferred units are done; units that were not deferred are already complete)
-        uint32_t n_heavy = 0;
-        HIP_TRY(hipMemcpyAsync(&n_heavy, b->d_heavy_count, 4, hipMemcpyDeviceToHost, b->stream));
+        HIP_TRY(hipMemcpyAsync(b->h_pinned, b->d_heavy_count, 4, hipMemcpyDeviceToHost, b->stream));
         HIP_TRY(hipStreamSynchronize(b->stream));
+        const uint32_t n_heavy = b->h_pinned[0];
         b->last_heavy = n_heavy;
         // Each round handles up to hcap deferred units.  One pass = k_hctrl (advance every active unit, publish scan
         // tasks) -> read the two counts back -> order the tasks by the index address they start at, so that tasks walking
@@ -422,7 +430,9 @@ extern "C" int bsx_batch_run_range(bsx_batch *b, uint32_t first_unit, uint32_t n
             H.task_cap = b->task_cap; H.list_base = base; H.hidx_base = 0; H.fresh = 1;
             uint32_t *blk[2] = {b->d_hcnt, b->d_hcnt + 8};
             int cur = 0;
+            const bool trace = getenv("BSX_TRACE_HEAVY") != nullptr;
             for (uint32_t iter = 0; n_act > 0; iter++) {
+                if (trace && (iter < 40 || iter % 2000 == 0)) fprintf(stderr, "[bsx heavy] paired %d base %u iter %u active %u last_tasks %u t=%ld\n", b->paired, base, iter, n_act, b->h_pinned[5], (long)clock());
                 if (iter > 100000) { g_bsx_err = "heavy pipeline did not converge"; return BSX_ERR_DEVICE; }
                 uint32_t *in = blk[cur], *out = blk[cur ^ 1];
                 HIP_TRY(hipMemsetAsync(out, 0, 16, b->stream));
@@ -430,9 +440,9 @@ extern "C" int bsx_batch_run_range(bsx_batch *b, uint32_t first_unit, uint32_t n
                 H.n_active_in_ptr = in; H.n_active_in = n_act; H.n_active_out = out; H.n_tasks = out + 1; H.queue = out + 2;
                 bsx_launch_hctrl(A, H, b->paired, (int)std::min<uint32_t>((n_act + 3) / 4, (uint32_t)b->n_cu * 4), b->stream);
                 HIP_TRY(hipGetLastError());
-                uint32_t cnt[2] = {0, 0};
-                HIP_TRY(hipMemcpyAsync(cnt, out, 8, hipMemcpyDeviceToHost, b->stream));
+                HIP_TRY(hipMemcpyAsync(b->h_pinned + 4, out, 8, hipMemcpyDeviceToHost, b->stream));
                 HIP_TRY(hipStreamSynchronize(b->stream));
+                const uint32_t cnt[2] = {((volatile uint32_t *)b->h_pinned)[4], ((volatile uint32_t *)b->h_pinned)[5]};
                 b->last_heavy_iters++;
                 n_act = cnt[0];
                 if (n_act == 0) break;

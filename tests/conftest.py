@@ -9,6 +9,9 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+os.environ.setdefault("BSX_POISON", "1")  # libbsx fills its heavy-pipeline pools with 0xA5 so that tests never rely on zeroed fresh memory
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
