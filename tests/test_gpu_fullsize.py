@@ -1,0 +1,110 @@
+"""BASELINE-sized checks (hg38-sized synthetic genome, 3.09 Gbp, 1.48 G index entries; the bench workload).
+The oracle cannot chew the whole batch in test time, so parity at this size is shown through size-independent
+properties plus an oracle comparison on a sample:
+  * a sample of units (including the heaviest ones) equals the oracle run against the SAME reference + index copied
+    back from HBM — picks, class counts, pair lists' sizes;
+  * idempotence: the same batch twice gives byte-identical records and counters;
+  * partition invariance: aligning in two halves equals aligning the whole batch;
+  * path invariance: results do not depend on which units go through the heavy pipeline (threshold 8192 vs 1 M);
+  * geometry: reads were sampled as 50..480 nt fragments; reported pairs are same-chromosome, insert in range, >95 % unique;
+  * counter closure: units processed == units submitted."""
+import numpy as np
+import pytest
+
+import bsmap_amd as B
+
+pytestmark = pytest.mark.gpu
+
+HG38 = [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636, 138394717, 133797422,
+        135086622, 133275309, 114364328, 107043718, 101991189, 90338345, 83257441, 80373285, 58617616, 64444167,
+        46709983, 50818468, 156040895, 57227415]
+KW = dict(s=16, v=6, I=4, m=28, x=500, S=1, r=1, pairend=1)
+N = 131072
+
+
+@pytest.fixture(scope="module")
+def big():
+    ref = B.RefSeq(B.make_params(**KW)).synthetic(HG38, seed=38).CreateIndex()
+    pa = B.PairAlign(ref, N)
+    pa.synth_reads(N, 144, seed=11)
+    pa.Do_Batch()
+    out, ca, cb, npairs = pa.results()
+    cnt = pa.counters().copy()
+    yield ref, pa, out.copy(), ca.copy(), cb.copy(), npairs.copy(), cnt
+    pa.close()
+    ref.close()
+
+
+def test_sizes_and_closure(big):
+    ref, pa, out, ca, cb, npairs, cnt = big
+    assert ref.n_entries > 1_400_000_000 and ref.n_words > 190_000_000
+    assert int(cnt[4]) == N and pa.heavy_units() > N // 200
+    assert (out["unpaired_out"] == 0).mean() > 0.99
+
+
+def test_idempotent_and_partition_invariant(big):
+    ref, pa, out, ca, cb, npairs, cnt = big
+    pa.reset_counters()
+    pa.Do_Batch()
+    out2, ca2, cb2, np2 = pa.results()
+    assert out2.tobytes() == out.tobytes() and ca2.tobytes() == ca.tobytes() and np2.tobytes() == npairs.tobytes()
+    assert np.array_equal(pa.counters()[:7], cnt[:7])
+    pa.run_range(N // 2, N // 2, sync=True)
+    pa.run_range(0, N // 2, sync=True)
+    out3, ca3, cb3, np3 = pa.results()
+    assert out3.tobytes() == out.tobytes() and cb3.tobytes() == cb.tobytes()
+
+
+def test_heavy_path_invariance(big):
+    ref, pa, out, ca, cb, npairs, cnt = big
+    # 4096 units through the one-wave path only (threshold so high that nothing is deferred)
+    B.lib().bsx_set_heavy_threshold(1 << 30)
+    try:
+        pa.reset_counters()
+        pa.run_range(0, 2048, sync=True)
+        assert pa.heavy_units() == 0
+        o2, a2, b2, n2 = pa.results()
+    finally:
+        B.lib().bsx_set_heavy_threshold(8192)
+    assert o2[:2048].tobytes() == out[:2048].tobytes() and a2[:2048].tobytes() == ca[:2048].tobytes() and n2[:2048].tobytes() == npairs[:2048].tobytes()
+
+
+def test_sample_equals_oracle_on_the_same_index(big, oracle):
+    ref, pa, out, ca, cb, npairs, cnt = big
+    f, c = ref.words()
+    a, s, r = ref.info()
+    off, nf, ent = ref.index()
+    oref = oracle.OracleRef.wrap(oracle.make_params(**KW), f, c, a, s, r, off, nf, ent)
+    b1, o1 = pa.download_reads(0)
+    b2, o2 = pa.download_reads(1)
+    # first 1500 units + the 60 units with the most hits (the heavy tail)
+    load = ca["n_hit"].sum(1).astype(np.int64) + cb["n_chit"].sum(1) + ca["n_chit"].sum(1) + cb["n_hit"].sum(1)
+    sample = np.unique(np.concatenate([np.arange(1500), np.argsort(load)[-60:]]))
+    L = 144
+    s1 = np.concatenate([b1[int(o1[i]):int(o1[i + 1])] for i in sample])
+    s2 = np.concatenate([b2[int(o2[i]):int(o2[i + 1])] for i in sample])
+    oo = (np.arange(len(sample) + 1) * L).astype(np.uint64)
+    al = oracle.OracleAligner(oref, 0)
+    for k, u in enumerate(sample):
+        o = al.pe(int(u), bytes(b1[int(o1[u]):int(o1[u + 1])]).decode(), bytes(b2[int(o2[u]):int(o2[u + 1])]).decode())
+        g = out[u]
+        assert o.paired == g["paired"] and list(o.n_pairs)[:13] == list(npairs[u][:13]), u
+        assert list(o.a.n_hit)[:7] == list(ca[u]["n_hit"][:7]) and list(o.b.n_chit)[:7] == list(cb[u]["n_chit"][:7]), u
+        if o.paired and o.tmp == 0:
+            pk = o.pick
+            assert (pk.a.chr, pk.a.loc, pk.b.chr, pk.b.loc, pk.insert, pk.na, pk.nb) == \
+                   (g["a_chr"], g["a_loc"], g["b_chr"], g["b_loc"], g["insert"], g["na"], g["nb"]), u
+    al.free()
+    assert s1.size == s2.size == len(sample) * L and oo[-1] == s1.size
+
+
+def test_pair_geometry(big):
+    """the sampler draws fragments of 50..480 nt from one chromosome: reported pairs must respect that geometry"""
+    ref, pa, out, ca, cb, npairs, cnt = big
+    pr = out["unpaired_out"] == 0
+    # both mates on the same chromosome copy, insert within [50, 480] as sampled, mates facing each other
+    assert np.array_equal(out["a_chr"][pr], out["b_chr"][pr])
+    ins = out["insert"][pr]
+    assert ins.min() >= 28 and ins.max() <= 500 and 250 < np.median(ins) < 350
+    uniq = pr & (out["n_pairs"] == 1)
+    assert uniq.mean() > 0.95
