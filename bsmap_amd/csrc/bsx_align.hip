@@ -408,14 +408,17 @@ struct CandEval { uint32_t w, w0ref, p48, w01ref; };
 __device__ __forceinline__ CandEval eval_loaded(const uint32_t *rp, const U4 r0, const uint32_t (&rw)[9], const uint32_t (&rm)[9], int nwords,
                                                 uint32_t p, uint32_t thres0)
 {
+    // rp / r0 start at word (p-1)>>4: one word early when p is word-aligned, so that the funnel shift is a plain
+    // v_alignbit_b32 with a 5-bit amount (k = 0 -> amount 0 picks the second word of each pair)
     CandEval r;
-    const uint32_t k = p & 15, sh = 32 - 2 * k;
-    const uint32_t f0 = (uint32_t)((((u64)r0.a << 32) | r0.b) >> sh), f1 = (uint32_t)((((u64)r0.b << 32) | r0.c) >> sh),
-                   f2 = (uint32_t)((((u64)r0.c << 32) | r0.d) >> sh);
-    const uint32_t m0 = bsx_mismatch_bits(rw[0], rm[0], f0), m1 = bsx_mismatch_bits(rw[1], rm[1], f1), m2 = bsx_mismatch_bits(rw[2], rm[2], f2);
+    const uint32_t k = p & 15, sh = (32 - 2 * k) & 31;
+    const uint32_t f0 = __builtin_amdgcn_alignbit(r0.a, r0.b, sh), f1 = __builtin_amdgcn_alignbit(r0.b, r0.c, sh),
+                   f2 = __builtin_amdgcn_alignbit(r0.c, r0.d, sh);
+    const uint32_t m1 = bsx_mismatch_hi(rw[1], bsx_tmask(rw[1], rm[1]), f1);
+    const uint32_t c0 = __popc(bsx_mismatch_hi(rw[0], bsx_tmask(rw[0], rm[0]), f0));
     const uint32_t him = k ? ~(0xFFFFFFFFu >> (2 * (16 - k))) : 0xFFFFFFFFu;  // first 16-k nt of a word
-    r.w0ref = __popc(m0) + __popc(m1 & him);  // the reference's 1st 64-bit word holds read nt [0, 32-k)
-    r.p48 = __popc(m0) + __popc(m1) + __popc(m2);
+    r.w0ref = c0 + __popc(m1 & him);  // the reference's 1st 64-bit word holds read nt [0, 32-k)
+    r.p48 = c0 + __popc(m1) + __popc(bsx_mismatch_hi(rw[2], bsx_tmask(rw[2], rm[2]), f2));
     r.w = r.p48;
     r.w01ref = 0;
     if (r.p48 <= thres0) {
@@ -429,8 +432,8 @@ __device__ __forceinline__ CandEval eval_loaded(const uint32_t *rp, const U4 r0,
         r.w01ref = r.p48;
 #pragma unroll
         for (int t = 3; t < 9; t++) {
-            const uint32_t f = (uint32_t)((((u64)wd[t - 3] << 32) | wd[t - 2]) >> sh);
-            const uint32_t mm = bsx_mismatch_bits(rw[t], rm[t], f);
+            const uint32_t f = __builtin_amdgcn_alignbit(wd[t - 3], wd[t - 2], sh);
+            const uint32_t mm = bsx_mismatch_hi(rw[t], bsx_tmask(rw[t], rm[t]), f);
             tot += __popc(mm);
             if (t == 3) r.w01ref += __popc(mm & him);
         }
@@ -442,7 +445,7 @@ __device__ __forceinline__ CandEval eval_loaded(const uint32_t *rp, const U4 r0,
 __device__ __forceinline__ CandEval eval_candidate(const DevParams &P, const uint32_t (&rw)[9], const uint32_t (&rm)[9], int nwords,
                                                    uint32_t p, uint32_t strand, uint32_t thres0)
 {
-    const uint32_t *rp = (strand ? P.crefcat : P.refcat) + (p >> 4);
+    const uint32_t *rp = (strand ? P.crefcat : P.refcat) + ((p - 1) >> 4);
     const U4 r0 = *reinterpret_cast<const U4 *>(rp);
     return eval_loaded(rp, r0, rw, rm, nwords, p, thres0);
 }
@@ -1352,10 +1355,10 @@ __global__ __launch_bounds__(256, 8) void k_hscan(AlignArgs A, HeavyArgs H)
 #pragma unroll
                 for (int u = 0; u < 4; u++) p[u] = ent[valid[u] ? idx[u] - ps : lo - ps] + hh;
 #pragma unroll
-                for (int u = 0; u < 4; u++) r0[u] = *reinterpret_cast<const U4 *>(refbase + (p[u] >> 4));
+                for (int u = 0; u < 4; u++) r0[u] = *reinterpret_cast<const U4 *>(refbase + ((p[u] - 1) >> 4));
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
-                    CandEval ev = eval_loaded(refbase + (p[u] >> 4), r0[u], rw, rm, nwords, p[u], thres0);
+                    CandEval ev = eval_loaded(refbase + ((p[u] - 1) >> 4), r0[u], rw, rm, nwords, p[u], thres0);
                     if (!valid[u]) { ev.w = 0xffff; ev.w0ref = ev.p48 = ev.w01ref = 0; }
                     bool pass = valid[u] && ev.w <= thres0;
                     uint32_t hchr = 0, hloc = 0, hkey = 0;

@@ -27,6 +27,16 @@ __host__ __device__ inline uint32_t bsx_mismatch_bits(uint32_t read, uint32_t ma
     return (x | (x >> 1)) & 0x55555555u;
 }
 
+// the same rule with the reference-dependent mask moved to the read side, where it is wave-uniform: a nt mismatches iff
+// the low bit of read^ref is set, or the high bit is set and the read nt is not 'T' (read T over reference C gives 10).
+// tmask = read mask with the high bit cleared at the read's T positions (bsx_tmask); result bit 2i+1 set iff nt i mismatches.
+__host__ __device__ inline uint32_t bsx_tmask(uint32_t read, uint32_t mask) { return mask & ~(read & (read << 1) & 0xAAAAAAAAu); }
+__host__ __device__ inline uint32_t bsx_mismatch_hi(uint32_t read, uint32_t tmask, uint32_t ref)
+{
+    const uint32_t y = (read ^ ref) & tmask;
+    return ((y << 1) | y) & 0xAAAAAAAAu;
+}
+
 // deterministic pick used for equal-best hits: reference utilities.cpp:44-48 (the -S != 0 branch)
 __host__ __device__ inline uint32_t bsx_myrand(uint32_t index, int32_t randseed)
 {
