@@ -1340,26 +1340,29 @@ __global__ __launch_bounds__(256, 8) void k_hscan(AlignArgs A, HeavyArgs H)
         // the task's candidates sub-range by sub-range (list order): inside one sub-range entry address, h and strand are
         // wave-uniform; four chunks are in flight per step — entries first, then all four 16-byte reference loads
         for (uint32_t sidx = 0; sidx < nsub && !overflow; sidx++) {
-            const uint32_t ps = TAB[wv][0][sidx], ns = TAB[wv][1][sidx];
+            const uint32_t ps = rfl(TAB[wv][0][sidx]), ns = rfl(TAB[wv][1][sidx]);
             const uint32_t lo = max(tc0, ps), hi = min(c_end, ps + ns);
             if (lo >= hi) continue;
-            const uint32_t *ent = P.entries + TAB[wv][2][sidx];
-            const uint32_t hh = TAB[wv][3][sidx], strand = sidx & 1;
+            const uint32_t *ent = P.entries + rfl(TAB[wv][2][sidx]);
+            const uint32_t hh = rfl(TAB[wv][3][sidx]), strand = sidx & 1;
             const uint32_t *refbase = strand ? P.crefcat : P.refcat;
             for (uint32_t cb = lo; cb < hi && !overflow; cb += 256) {
-                uint32_t idx[4], p[4];
+                // four chunks of 64 consecutive candidates: entries come from one address + immediate offsets (the loads may
+                // run up to 255 entries past hi — other buckets' entries or the array's BSX_ENTRY_PAD, loaded but never used);
+                // neighbouring lanes hold neighbouring entries, so in a repeat bucket one reference gather touches few lines
+                const uint32_t *q = ent + (cb - ps) + lane;
+                uint32_t idx[4], p[4], e[4];
                 bool valid[4];
                 U4 r0[4];
 #pragma unroll
-                for (int u = 0; u < 4; u++) { idx[u] = cb + u * 64 + lane; valid[u] = idx[u] < hi; }
+                for (int u = 0; u < 4; u++) e[u] = q[u * 64];
 #pragma unroll
-                for (int u = 0; u < 4; u++) p[u] = ent[valid[u] ? idx[u] - ps : lo - ps] + hh;
+                for (int u = 0; u < 4; u++) { idx[u] = cb + u * 64 + lane; valid[u] = idx[u] < hi; p[u] = valid[u] ? e[u] + hh : 16u; }
 #pragma unroll
                 for (int u = 0; u < 4; u++) r0[u] = *reinterpret_cast<const U4 *>(refbase + ((p[u] - 1) >> 4));
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     CandEval ev = eval_loaded(refbase + ((p[u] - 1) >> 4), r0[u], rw, rm, nwords, p[u], thres0);
-                    if (!valid[u]) { ev.w = 0xffff; ev.w0ref = ev.p48 = ev.w01ref = 0; }
                     bool pass = valid[u] && ev.w <= thres0;
                     uint32_t hchr = 0, hloc = 0, hkey = 0;
                     if (pass) pass = hit_coords(P, BL, p[u], strand, len, hchr, hloc, hkey);

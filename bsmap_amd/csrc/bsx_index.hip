@@ -93,12 +93,12 @@ int bsx_index_build_wgbs(bsx_ref *r)
     const uint32_t K = P.total_kmers, nb = (uint32_t)first.size();
     DevBuf<uint32_t> d_off, d_nfwd, d_entries, d_keys, d_skeys, d_vals;
     DevBuf<uint64_t> d_prefix; DevBuf<uint32_t> d_first, d_word0, d_anchor; DevBuf<uint8_t> d_strand; DevBuf<char> d_temp;
-    if (d_off.alloc((size_t)K + 1) || d_nfwd.alloc(K) || d_entries.alloc(total + 64) || d_keys.alloc(total) || d_skeys.alloc(total) ||
+    if (d_off.alloc((size_t)K + 1) || d_nfwd.alloc(K) || d_entries.alloc(total + BSX_ENTRY_PAD) || d_keys.alloc(total) || d_skeys.alloc(total) ||
         d_vals.alloc(total) || d_prefix.alloc(nb + 1) || d_first.alloc(nb) || d_word0.alloc(nb) || d_anchor.alloc(nb) || d_strand.alloc(nb)) {
         g_bsx_err = "hipMalloc failed while building the index";
         return BSX_ERR_NOMEM;
     }
-    HIP_TRY(hipMemset(d_entries.p, 0, (total + 64) * 4));
+    HIP_TRY(hipMemset(d_entries.p, 0, (total + BSX_ENTRY_PAD) * 4));
     if (total) {
         HIP_TRY(hipMemcpy(d_prefix.p, prefix.data(), (nb + 1) * 8, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(d_first.p, first.data(), nb * 4, hipMemcpyHostToDevice));

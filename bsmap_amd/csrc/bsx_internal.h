@@ -13,6 +13,7 @@
 #define BSX_ROWCAP (BSX_MAXHITS + 1)  // HitArray / PairArray row length (reference align.h:18, pairs.h:22)
 #define BSX_HSET_BITS 15
 #define BSX_HSET_SLOTS (1u << BSX_HSET_BITS)  // duplicate-suppression hash set, >= 2x the most hits a read can collect
+#define BSX_ENTRY_PAD 512  /* zeroed words behind the index entries: k_hscan loads whole 256-entry chunks */
 #define BSX_SORT_TMP 1280            // scratch entries for sorting one class list      // chromosomes whose anchors are staged in LDS by the align kernel
 
 // everything the align kernel needs, passed by value as the kernel argument
