@@ -8,16 +8,26 @@
 //   s_OutHitPair / s_OutHitUnpair  pairs.cpp:288-498       (paired SAM + BSP lines, read-through trimming)
 //   FixPairReadName                pairs.cpp:535-555
 // The alignment itself (FilterReads ... StringAlign selection) happens behind the C ABI of include/bsx.h.
-// Not supported (reference features outside the hot path): SAM/BAM input and .bam output (samtools), -p is accepted
-// and ignored.  Output is always in input order (the reference's order is nondeterministic for -p > 1).
+// Not supported (reference features outside the hot path): SAM/BAM input and .bam output (samtools).
+// Parsing, the GPU, formatting (-p threads) and writing run as a pipeline over a ring of batches; the output is always
+// in input order (the reference's order is nondeterministic for -p > 1).
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
+#include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
 #include <fstream>
 #include <iostream>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/bsx.h"
@@ -29,7 +39,7 @@ namespace {
 struct Opts {
     bsx_params p;
     string a_file, b_file, ref_file, out_file, out_unpair;
-    int out_sam = 0, out_ref = 0, out_unmap = 0, num_procs = 1;
+    int out_sam = 0, out_ref = 0, out_unmap = 0, num_procs = 0;
     unsigned read_start = 1, read_end = ~0u;
     int device = 0;
     unsigned batch = 1u << 20;
@@ -46,7 +56,6 @@ char rev_char(char c)
     }
     return 'N';
 }
-void revcomp(string &s) { reverse(s.begin(), s.end()); for (size_t i = 0; i < s.size(); i++) s[i] = rev_char(s[i]); }
 
 void usage()
 {
@@ -61,7 +70,7 @@ void usage()
          << "       -B  <int>   start from the Nth read or read pair, default: 1\n"
          << "       -E  <int>   end at the Nth read or read pair, default: 4,294,967,295\n"
          << "       -I  <int>   index interval, default=4\n"
-         << "       -p  <int>   accepted for compatibility (the GPU path ignores it)\n"
+         << "       -p  <int>   number of host threads formatting the output, default=all cores (max 64)\n"
          << "       -D  <str>   activating RRBS mapping mode and set restriction enzyme digestion sites, example: -D C-CGG\n"
          << "       -S  <int>   seed for random number generation used in selecting multiple hits\n"
          << "       -n  [0,1]   set mapping strand information. default: -n 0\n"
@@ -149,51 +158,129 @@ int parse_options(int argc, char **argv, Opts &o)
 }
 
 // ---- reads (reads.cpp:13-117) -------------------------------------------------------------------------------------
-struct Read { string name, seq, qual; unsigned index; };
+// The reference reads with operator>> / getline on an ifstream; the same token rules are applied here to a memory map
+// of the file (whitespace-separated tokens, rest of the header line dropped, header remainder limited to 999
+// characters), which parses gigabytes per second instead of the iostream rate.
+inline bool is_ws(char c) { return c == ' ' || c == '\n' || c == '\t' || c == '\r' || c == '\v' || c == '\f'; }
 
 struct Reader {
-    ifstream fin;
+    const char *base = nullptr, *cur = nullptr, *end = nullptr;
+    size_t map_len = 0;
     int format = -1;  // 0 fastq, 1 fasta
     unsigned index = 0;
-    char line[1000];
+    bool failed = false;  // the stream's failbit: every later extraction yields nothing
+    bool eof_hit = false;
+
+    void skip_ws() { while (cur < end && is_ws(*cur)) cur++; }
+    // operator>>(string): false (and fail state) when no character could be extracted
+    bool token(const char *&t, size_t &n)
+    {
+        t = cur; n = 0;
+        if (failed) return false;
+        skip_ws();
+        if (cur >= end) { eof_hit = true; failed = true; return false; }
+        t = cur;
+        while (cur < end && !is_ws(*cur)) cur++;
+        if (cur >= end) eof_hit = true;
+        n = (size_t)(cur - t);
+        return true;
+    }
+    // getline(buf, 1000): up to 999 characters, the newline is consumed; longer lines set the fail state
+    void rest_of_line()
+    {
+        if (failed) return;
+        const char *nl = (const char *)memchr(cur, '\n', (size_t)(end - cur));
+        const size_t n = nl ? (size_t)(nl - cur) : (size_t)(end - cur);
+        if (n > 999) { cur += 999; failed = true; return; }
+        if (!nl) { cur = end; eof_hit = true; if (n == 0) failed = true; return; }
+        cur = nl + 1;
+    }
     void open(const string &path, const Opts &o)
     {
-        fin.open(path.c_str());
-        if (!fin) { cerr << "failed to open read file (check -a option): " << path << endl; exit(1); }
-        string s1, s2, s3, s4;
-        fin >> s1; fin.getline(line, 1000);
-        if (!s1.empty() && s1[0] == '>') format = 1;
-        else if (!s1.empty() && s1[0] == '@') {
-            fin >> s2; fin.getline(line, 1000); fin >> s3; fin.getline(line, 1000); fin >> s4; fin.getline(line, 1000);
+        const int fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) { cerr << "failed to open read file (check -a option): " << path << endl; exit(1); }
+        struct stat st;
+        fstat(fd, &st);
+        map_len = (size_t)st.st_size;
+        if (map_len) {
+            void *m = mmap(nullptr, map_len, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m == MAP_FAILED) { cerr << "failed to map read file: " << path << endl; exit(1); }
+            madvise(m, map_len, MADV_SEQUENTIAL);
+            base = (const char *)m;
+        }
+        ::close(fd);
+        cur = base; end = base + map_len;
+        const char *t; size_t n1 = 0, n2 = 0, n4 = 0;
+        token(t, n1); const char first = n1 ? t[0] : 0; rest_of_line();
+        if (first == '>') format = 1;
+        else if (first == '@') {
+            token(t, n2); rest_of_line(); token(t, n1); rest_of_line(); token(t, n4); rest_of_line();
             format = 0;
-            if (s2.size() != s4.size()) { cerr << "fatal error: fq format, sequence length not equal to quality length\n"; exit(1); }
+            if (n2 != n4) { cerr << "fatal error: fq format, sequence length not equal to quality length\n"; exit(1); }
         } else { cerr << "fatal error: unrecognizable format of reads file (SAM/BAM input is not supported by this build).\n"; exit(1); }
-        fin.clear(); fin.seekg(0);
+        cur = base; failed = false; eof_hit = false;
         const unsigned skip = (o.read_start - 1) * (format == 0 ? 4 : 2);
-        for (unsigned i = 0; i < skip; i++) { if (fin.eof()) break; fin.getline(line, 1000); }
+        for (unsigned i = 0; i < skip; i++) {  // getline(ch, 1000) per skipped line
+            if (eof_hit) break;
+            rest_of_line();
+        }
         index = o.read_start - 1;
     }
-    // one batch; returns number of reads loaded
-    size_t load(vector<Read> &out, size_t max_n, const Opts &o)
+};
+
+// one batch of reads in flat arrays: what the upload takes (sequence bytes + offsets) and what the formatters need
+struct ReadSet {
+    vector<char> names, seq, qual;
+    vector<uint64_t> noff, soff, qoff;
+    vector<char> qual_upload;  // only when some quality string differs in length from its sequence
+    bool qual_same = true;
+    unsigned first_index = 0;
+    size_t n() const { return soff.size() - 1; }
+    void clear() { names.clear(); seq.clear(); qual.clear(); noff.assign(1, 0); soff.assign(1, 0); qoff.assign(1, 0); qual_same = true; }
+    const char *upload_qual()
     {
-        out.clear();
-        char c;
-        while (out.size() < max_n && index < o.read_end) {
-            fin >> c;
-            if (fin.eof() || !fin) break;
-            Read r;
-            r.index = index;
-            fin >> r.name; fin.getline(line, 1000);
-            fin >> r.seq;
-            if (format == 0) { fin >> line; fin.getline(line, 1000); fin >> r.qual; }
-            else r.qual = string(r.seq.size(), (char)(o.p.zero_qual + 40));
-            if ((int)r.seq.size() > o.p.max_readlen) { r.seq.erase(o.p.max_readlen); r.qual.erase(o.p.max_readlen); }
-            out.push_back(r);
-            index++;
+        if (qual_same) return qual.data();
+        qual_upload.assign(seq.size(), 'I');
+        for (size_t i = 0; i + 1 < soff.size(); i++) {
+            const size_t sl = soff[i + 1] - soff[i], ql = qoff[i + 1] - qoff[i];
+            memcpy(qual_upload.data() + soff[i], qual.data() + qoff[i], min(sl, ql));
         }
-        return out.size();
+        return qual_upload.data();
     }
 };
+
+// ReadClass::LoadBatchReads (reads.cpp:83-117) for one file; returns the number of reads loaded
+size_t load_reads(Reader &rd, ReadSet &out, size_t max_n, const Opts &o)
+{
+    out.clear();
+    out.first_index = rd.index;
+    const size_t maxlen = (size_t)o.p.max_readlen;
+    while (out.n() < max_n && rd.index < o.read_end) {
+        const char *t; size_t n;
+        // fin >> c : the record marker ('@' or '>') is a single character, the name follows (possibly after blanks)
+        if (rd.failed) break;
+        rd.skip_ws();
+        if (rd.cur >= rd.end) break;
+        rd.cur++;
+        rd.token(t, n);
+        out.names.insert(out.names.end(), t, t + n); out.noff.push_back(out.names.size());
+        rd.rest_of_line();
+        rd.token(t, n);
+        const size_t sl = min(n, maxlen);
+        out.seq.insert(out.seq.end(), t, t + sl); out.soff.push_back(out.seq.size());
+        if (rd.format == 0) {
+            rd.token(t, n); rd.rest_of_line();  // '+' line
+            rd.token(t, n);
+            const size_t ql = min(n, maxlen);
+            out.qual.insert(out.qual.end(), t, t + ql); out.qoff.push_back(out.qual.size());
+            if (ql != sl) out.qual_same = false;
+        } else {
+            out.qual.insert(out.qual.end(), sl, (char)(o.p.zero_qual + 40)); out.qoff.push_back(out.qual.size());
+        }
+        rd.index++;
+    }
+    return out.n();
+}
 
 // ---- reference view for XR:Z and RRBS tags ------------------------------------------------------------------------
 struct RefView {
@@ -233,28 +320,59 @@ struct RefView {
     }
 };
 
-string map_seq(const RefView &rv, uint32_t chr, uint32_t loc, size_t len)  // align.cpp:671-680
-{
-    string m;
-    for (uint32_t ii = 2; ii > 0; ii--) {
-        if (loc < ii) { m += 'n'; continue; }  // the reference leaves this character uninitialised
-        m += (char)(rv.nt(chr >> 1, loc - ii) + 32);
+// ---- text output ----------------------------------------------------------------------------------------------------
+// working copy of one read for the formatters, which trim and reverse-complement in place as the reference does
+struct Rd {
+    const char *name; size_t nlen;
+    char seq[BSX_MAX_READLEN + 16], qual[BSX_MAX_READLEN + 16];
+    size_t slen, qlen;
+    void load(const ReadSet &R, size_t i)
+    {
+        name = R.names.data() + R.noff[i]; nlen = (size_t)(R.noff[i + 1] - R.noff[i]);
+        slen = (size_t)(R.soff[i + 1] - R.soff[i]); qlen = (size_t)(R.qoff[i + 1] - R.qoff[i]);
+        memcpy(seq, R.seq.data() + R.soff[i], slen); memcpy(qual, R.qual.data() + R.qoff[i], qlen);
     }
-    for (size_t ii = 0; ii < len + 2; ii++) m += rv.nt(chr >> 1, loc + (uint32_t)ii);
-    m[m.size() - 1] += 32; m[m.size() - 2] += 32;
-    return m;
-}
+    void revcomp_seq() { reverse(seq, seq + slen); for (size_t i = 0; i < slen; i++) seq[i] = rev_char(seq[i]); }
+    void reverse_qual() { reverse(qual, qual + qlen); }
+};
+
+// append-only text buffer with the few conversions the SAM/BSP lines need (same digits as printf's %d / %u)
+struct Text {
+    string s;
+    void put(const char *p, size_t n) { s.append(p, n); }
+    void put(const char *z) { s.append(z); }
+    void put(const string &z) { s.append(z); }
+    void put(char c) { s.push_back(c); }
+    void put_u(uint64_t v) { char b[24]; int n = 0; do { b[n++] = (char)('0' + v % 10); v /= 10; } while (v); while (n) s.push_back(b[--n]); }
+    void put_i(int64_t v) { if (v < 0) { s.push_back('-'); put_u((uint64_t)(-v)); } else put_u((uint64_t)v); }
+};
 
 struct Formatter {
     const Opts &o;
     const RefView &rv;
     unsigned n_aligned = 0, n_aligned_pairs = 0, n_aligned_a = 0, n_aligned_b = 0;
-    char buf[2048];
     Formatter(const Opts &oo, const RefView &r) : o(oo), rv(r) {}
 
+    void put_map_seq(uint32_t chr, uint32_t loc, size_t len, Text &os) const  // align.cpp:671-680
+    {
+        char m[BSX_MAX_READLEN + 8];
+        size_t k = 0;
+        for (uint32_t ii = 2; ii > 0; ii--) {
+            if (loc < ii) { m[k++] = 'n'; continue; }  // the reference leaves this character uninitialised
+            m[k++] = (char)(rv.nt(chr >> 1, loc - ii) + 32);
+        }
+        for (size_t ii = 0; ii < len + 2; ii++) m[k++] = rv.nt(chr >> 1, loc + (uint32_t)ii);
+        m[k - 1] += 32; m[k - 2] += 32;
+        os.put(m, k);
+    }
+    void put_unmapped(const Rd &r, int flag, Text &os) const
+    {
+        os.put(r.name, r.nlen); os.put('\t'); os.put_i(flag); os.put("\t*\t0\t0\t*\t*\t0\t0\t"); os.put(r.seq, r.slen); os.put('\t'); os.put(r.qual, r.qlen); os.put('\n');
+    }
+
     // SingleAlign::s_OutHit (align.cpp:631-765).  counts: _cur_n_hit+_cur_n_chit per class (BSP column 10)
-    void out_hit(Read &r, int readset, int chain, int n, int nsnps, uint32_t chr, uint32_t loc, int insert_size, int max_snp,
-                 const bsx_class_counts *cc, string &os)
+    void out_hit(Rd &r, int readset, int chain, int n, int nsnps, uint32_t chr, uint32_t loc, int insert_size, int max_snp,
+                 const bsx_class_counts *cc, Text &os)
     {
         const bsx_params &p = o.p;
         const bool rev = n > 0 && (chain ^ (int)(chr % 2));
@@ -263,68 +381,64 @@ struct Formatter {
             if (n < 0 || n == 0 || (n > 1 && p.report_repeat_hits == 0)) {
                 if (!o.out_unmap) return;
                 flag |= n < 0 ? 0x204 : n == 0 ? 0x4 : 0x104;
-                snprintf(buf, sizeof(buf), "%s\t%d\t*\t0\t0\t*\t*\t0\t0\t%s\t%s\n", r.name.c_str(), flag, r.seq.c_str(), r.qual.c_str());
-                os += buf;
+                put_unmapped(r, flag, os);
                 return;
             }
             n_aligned++;
             if (n > 1) flag |= 0x100;
-            if (rev) { flag |= 0x10; revcomp(r.seq); reverse(r.qual.begin(), r.qual.end()); }
-            snprintf(buf, sizeof(buf), "%s\t%d\t%s\t%u\t255\t%dM\t*\t0\t0\t%s\t%s\tNM:i:%d", r.name.c_str(), flag, rv.names[chr >> 1].c_str(), loc + 1,
-                     (int)r.seq.size(), r.seq.c_str(), r.qual.c_str(), nsnps);
-            os += buf;
-            if (o.out_ref) { os += "\tXR:Z:"; os += map_seq(rv, chr, loc, r.seq.size()); }
-            if (p.rrbs) { uint32_t f; int s; rv.seglen(chr, loc, (int)r.seq.size(), f, s); snprintf(buf, sizeof(buf), "\tZP:i:%d\tZL:i:%d", (int)f, s); os += buf; }
-            snprintf(buf, sizeof(buf), "\tZS:Z:%c%c\n", chain_flag[chr % 2], chain_flag[chain]);
-            os += buf;
+            if (rev) { flag |= 0x10; r.revcomp_seq(); r.reverse_qual(); }
+            os.put(r.name, r.nlen); os.put('\t'); os.put_i(flag); os.put('\t'); os.put(rv.names[chr >> 1]); os.put('\t'); os.put_u(loc + 1);
+            os.put("\t255\t"); os.put_u(r.slen); os.put("M\t*\t0\t0\t"); os.put(r.seq, r.slen); os.put('\t'); os.put(r.qual, r.qlen);
+            os.put("\tNM:i:"); os.put_i(nsnps);
+            if (o.out_ref) { os.put("\tXR:Z:"); put_map_seq(chr, loc, r.slen, os); }
+            if (p.rrbs) { uint32_t f; int s; rv.seglen(chr, loc, (int)r.slen, f, s); os.put("\tZP:i:"); os.put_i((int)f); os.put("\tZL:i:"); os.put_i(s); }
+            os.put("\tZS:Z:"); os.put(chain_flag[chr % 2]); os.put(chain_flag[chain]); os.put('\n');
             return;
         }
         // BSP
         if (!o.out_unmap && (n <= 0 || (n > 1 && p.report_repeat_hits == 0))) return;
-        os += r.name; os += '\t';
-        if (rev) { revcomp(r.seq); reverse(r.qual.begin(), r.qual.end()); }
-        os += r.seq; os += '\t'; os += r.qual; os += '\t';
-        if (n < 0) os += "QC"; else if (n == 0) os += "NM"; else if (n == 1) os += "UM"; else if (n >= p.max_num_hits) os += "OF"; else os += "MA";
+        os.put(r.name, r.nlen); os.put('\t');
+        if (rev) { r.revcomp_seq(); r.reverse_qual(); }
+        os.put(r.seq, r.slen); os.put('\t'); os.put(r.qual, r.qlen); os.put('\t');
+        if (n < 0) os.put("QC"); else if (n == 0) os.put("NM"); else if (n == 1) os.put("UM"); else if (n >= p.max_num_hits) os.put("OF"); else os.put("MA");
         if ((n > 0 && p.report_repeat_hits == 1) || (n == 1 && p.report_repeat_hits == 0)) {
             n_aligned++;
-            const string m = map_seq(rv, chr, loc, r.seq.size());
-            snprintf(buf, sizeof(buf), "\t%s\t%u\t%c%c\t%d\t%s\t%d\t", rv.names[chr >> 1].c_str(), loc + 1, chain_flag[chr % 2], chain_flag[chain], insert_size, m.c_str(), nsnps);
-            os += buf;
+            os.put('\t'); os.put(rv.names[chr >> 1]); os.put('\t'); os.put_u(loc + 1); os.put('\t'); os.put(chain_flag[chr % 2]); os.put(chain_flag[chain]);
+            os.put('\t'); os.put_i(insert_size); os.put('\t'); put_map_seq(chr, loc, r.slen, os); os.put('\t'); os.put_i(nsnps); os.put('\t');
             for (int ii = 0; ii <= max_snp; ii++) {
-                snprintf(buf, sizeof(buf), ii < max_snp ? "%d:" : "%d", cc ? (int)cc->n_hit[ii] + (int)cc->n_chit[ii] : 0);
-                os += buf;
+                os.put_i(cc ? (int)cc->n_hit[ii] + (int)cc->n_chit[ii] : 0);
+                if (ii < max_snp) os.put(':');
             }
         }
-        os += '\n';
-        if (rev) { revcomp(r.seq); reverse(r.qual.begin(), r.qual.end()); }
+        os.put('\n');
+        if (rev) { r.revcomp_seq(); r.reverse_qual(); }
     }
 
-    void sam_tail(const Read &r, uint32_t chr, uint32_t loc, bool pair_tags, uint32_t seg_start, int insert, int strand, int chain, string &os)
+    void sam_tail(const Rd &r, uint32_t chr, uint32_t loc, bool pair_tags, uint32_t seg_start, int insert, int strand, int chain, Text &os) const
     {
-        if (o.out_ref) { os += "\tXR:Z:"; os += map_seq(rv, chr, loc, r.seq.size()); }
+        if (o.out_ref) { os.put("\tXR:Z:"); put_map_seq(chr, loc, r.slen, os); }
         if (o.p.rrbs) {
-            if (pair_tags) snprintf(buf, sizeof(buf), "\tZP:i:%d\tZL:i:%d", (int)seg_start, insert);
-            else { uint32_t f; int s; rv.seglen(chr, loc, (int)r.seq.size(), f, s); snprintf(buf, sizeof(buf), "\tZP:i:%d\tZL:i:%d", (int)f, s); }
-            os += buf;
+            uint32_t f = seg_start; int s = insert;
+            if (!pair_tags) rv.seglen(chr, loc, (int)r.slen, f, s);
+            os.put("\tZP:i:"); os.put_i((int)f); os.put("\tZL:i:"); os.put_i(s);
         }
-        snprintf(buf, sizeof(buf), "\tZS:Z:%c%c\n", chain_flag[strand], chain_flag[chain]);
-        os += buf;
+        os.put("\tZS:Z:"); os.put(chain_flag[strand]); os.put(chain_flag[chain]); os.put('\n');
     }
 
     // PairAlign::s_OutHitPair (pairs.cpp:288-424)
-    void out_pair(Read &a, Read &b, bsx_pair pp, const bsx_class_counts *ca, const bsx_class_counts *cb, string &os)
+    void out_pair(Rd &a, Rd &b, bsx_pair pp, const bsx_class_counts *ca, const bsx_class_counts *cb, Text &os)
     {
         const int n = pp.n_pairs;
         n_aligned_pairs++;
-        if (pp.insert < (int)a.seq.size()) {  // fragment shorter than the read: cut the read-through
-            if (pp.chain ^ (pp.a_chr % 2)) pp.a_loc += (uint32_t)a.seq.size() - pp.insert;
-            a.seq.erase(pp.insert);
-            if ((int)a.qual.size() > pp.insert) a.qual.erase(pp.insert);
+        if (pp.insert < (int)a.slen) {  // fragment shorter than the read: cut the read-through
+            if (pp.chain ^ (pp.a_chr % 2)) pp.a_loc += (uint32_t)a.slen - pp.insert;
+            a.slen = (size_t)pp.insert;
+            if ((int)a.qlen > pp.insert) a.qlen = (size_t)pp.insert;
         }
-        if (pp.insert < (int)b.seq.size()) {
-            if ((!pp.chain) ^ (pp.b_chr % 2)) pp.b_loc += (uint32_t)b.seq.size() - pp.insert;
-            b.seq.erase(pp.insert);
-            if ((int)b.qual.size() > pp.insert) b.qual.erase(pp.insert);
+        if (pp.insert < (int)b.slen) {
+            if ((!pp.chain) ^ (pp.b_chr % 2)) pp.b_loc += (uint32_t)b.slen - pp.insert;
+            b.slen = (size_t)pp.insert;
+            if ((int)b.qlen > pp.insert) b.qlen = (size_t)pp.insert;
         }
         if (!o.out_sam) {
             out_hit(a, 1, pp.chain, n, pp.na, pp.a_chr, pp.a_loc, pp.insert, pp.a.max_snp, ca, os);
@@ -332,24 +446,24 @@ struct Formatter {
             return;
         }
         for (int mate = 0; mate < 2; mate++) {
-            Read &r = mate ? b : a;
+            Rd &r = mate ? b : a;
             const uint32_t chr = mate ? pp.b_chr : pp.a_chr, loc = mate ? pp.b_loc : pp.a_loc, mloc = mate ? pp.a_loc : pp.b_loc;
             const int chain = mate ? !pp.chain : pp.chain;
             int flag = 0x3, pp_insert;
             uint32_t seg_start;
             if (n > 1) flag |= 0x100;
-            if (chain ^ (int)(chr % 2)) { flag |= 0x10; seg_start = mloc + 1; pp_insert = -pp.insert; revcomp(r.seq); reverse(r.qual.begin(), r.qual.end()); }
+            if (chain ^ (int)(chr % 2)) { flag |= 0x10; seg_start = mloc + 1; pp_insert = -pp.insert; r.revcomp_seq(); r.reverse_qual(); }
             else { flag |= 0x20; seg_start = loc + 1; pp_insert = pp.insert; }
             flag |= 0x40 * (mate + 1);
-            snprintf(buf, sizeof(buf), "%s\t%d\t%s\t%u\t255\t%dM\t=\t%u\t%d\t%s\t%s\tNM:i:%d", r.name.c_str(), flag, rv.names[chr >> 1].c_str(), loc + 1,
-                     (int)r.seq.size(), mloc + 1, pp_insert, r.seq.c_str(), r.qual.c_str(), mate ? pp.nb : pp.na);
-            os += buf;
+            os.put(r.name, r.nlen); os.put('\t'); os.put_i(flag); os.put('\t'); os.put(rv.names[chr >> 1]); os.put('\t'); os.put_u(loc + 1);
+            os.put("\t255\t"); os.put_u(r.slen); os.put("M\t=\t"); os.put_u(mloc + 1); os.put('\t'); os.put_i(pp_insert); os.put('\t');
+            os.put(r.seq, r.slen); os.put('\t'); os.put(r.qual, r.qlen); os.put("\tNM:i:"); os.put_i(mate ? pp.nb : pp.na);
             sam_tail(r, chr, loc, true, seg_start, pp.insert, chr % 2, chain, os);
         }
     }
 
     // PairAlign::s_OutHitUnpair (pairs.cpp:426-498) for one mate
-    void out_unpair(Read &r, int readinpair, const bsx_hit &me, const bsx_hit &mate, const bsx_class_counts *cc, string &os)
+    void out_unpair(Rd &r, int readinpair, const bsx_hit &me, const bsx_hit &mate, const bsx_class_counts *cc, Text &os)
     {
         const bsx_params &p = o.p;
         const int ma = (me.flags & BSX_F_FILTERED) ? -1 : me.n_best, mb = (mate.flags & BSX_F_FILTERED) ? -1 : mate.n_best;
@@ -363,59 +477,53 @@ struct Formatter {
             if (ma < 0) flag |= 0x204;
             if (ma == 0) flag |= 0x004;
             if (ma > 1) flag |= 0x104;
-            if (mate_unmapped) {
-                flag |= 0x008;
-                snprintf(buf, sizeof(buf), "%s\t%d\t*\t0\t0\t*\t*\t0\t0\t%s\t%s\n", r.name.c_str(), flag, r.seq.c_str(), r.qual.c_str());
-            } else {
+            if (mate_unmapped) { flag |= 0x008; put_unmapped(r, flag, os); }
+            else {
                 if (chain_b ^ (int)(mate.chr % 2)) flag |= 0x020;
-                snprintf(buf, sizeof(buf), "%s\t%d\t*\t0\t0\t*\t%s\t%u\t0\t%s\t%s\n", r.name.c_str(), flag, rv.names[mate.chr >> 1].c_str(), mate.loc + 1, r.seq.c_str(), r.qual.c_str());
+                os.put(r.name, r.nlen); os.put('\t'); os.put_i(flag); os.put("\t*\t0\t0\t*\t"); os.put(rv.names[mate.chr >> 1]); os.put('\t'); os.put_u(mate.loc + 1);
+                os.put("\t0\t"); os.put(r.seq, r.slen); os.put('\t'); os.put(r.qual, r.qlen); os.put('\n');
             }
-            os += buf;
             return;
         }
         if (readinpair == 0) n_aligned_a++; else n_aligned_b++;
         if (ma > 1) flag |= 0x100;
-        if (chain_a ^ (int)(me.chr % 2)) { flag |= 0x010; revcomp(r.seq); reverse(r.qual.begin(), r.qual.end()); }
-        if (mate_unmapped) {
-            flag |= 0x008;
-            snprintf(buf, sizeof(buf), "%s\t%d\t%s\t%u\t255\t%dM\t*\t0\t0\t%s\t%s\tNM:i:%d", r.name.c_str(), flag, rv.names[me.chr >> 1].c_str(), me.loc + 1, (int)r.seq.size(),
-                     r.seq.c_str(), r.qual.c_str(), na);
-        } else {
-            if (chain_b ^ (int)(mate.chr % 2)) flag |= 0x020;
-            snprintf(buf, sizeof(buf), "%s\t%d\t%s\t%u\t255\t%dM\t%s\t%u\t0\t%s\t%s\tNM:i:%d", r.name.c_str(), flag, rv.names[me.chr >> 1].c_str(), me.loc + 1, (int)r.seq.size(),
-                     rv.names[mate.chr >> 1].c_str(), mate.loc + 1, r.seq.c_str(), r.qual.c_str(), na);
-        }
-        os += buf;
+        if (chain_a ^ (int)(me.chr % 2)) { flag |= 0x010; r.revcomp_seq(); r.reverse_qual(); }
+        if (mate_unmapped) flag |= 0x008;
+        else if (chain_b ^ (int)(mate.chr % 2)) flag |= 0x020;
+        os.put(r.name, r.nlen); os.put('\t'); os.put_i(flag); os.put('\t'); os.put(rv.names[me.chr >> 1]); os.put('\t'); os.put_u(me.loc + 1);
+        os.put("\t255\t"); os.put_u(r.slen); os.put("M\t");
+        if (mate_unmapped) os.put("*\t0");
+        else { os.put(rv.names[mate.chr >> 1]); os.put('\t'); os.put_u(mate.loc + 1); }
+        os.put("\t0\t"); os.put(r.seq, r.slen); os.put('\t'); os.put(r.qual, r.qlen); os.put("\tNM:i:"); os.put_i(na);
         sam_tail(r, me.chr, me.loc, false, 0, 0, me.chr % 2, chain_a, os);
     }
 };
 
 // PairAlign::FixPairReadName (pairs.cpp:535-555), SAM output only
-void fix_pair_name(Read &a, Read &b)
+void fix_pair_name(Rd &a, Rd &b)
 {
-    if (a.name == b.name) return;
-    int i, d = -1, i0 = (int)min(a.name.size(), b.name.size());
+    if (a.nlen == b.nlen && memcmp(a.name, b.name, a.nlen) == 0) return;
+    int i, d = -1, i0 = (int)min(a.nlen, b.nlen);
     for (i = 0; i < i0; i++) {
         if (a.name[i] != b.name[i]) break;
         else if (isdigit((unsigned char)a.name[i])) d = i;
     }
-    if (i > 0) { if (d < 0) d = i - 1; a.name.erase(d + 1); b.name.erase(d + 1); }
-    else { cerr << "Error: Paired reads name not match:\n" << a.name << endl << b.name << endl; exit(1); }
+    if (i > 0) { if (d < 0) d = i - 1; a.nlen = min(a.nlen, (size_t)d + 1); b.nlen = min(b.nlen, (size_t)d + 1); }
+    else { cerr << "Error: Paired reads name not match:\n" << string(a.name, a.nlen) << endl << string(b.name, b.nlen) << endl; exit(1); }
 }
 
 // what FilterReads did to the host copy of the read: TrimLowQual's quality rebasing (align.cpp:64-67) and the cut
-void apply_trim(Read &r, const bsx_hit &h, const Opts &o)
+void apply_trim(Rd &r, const bsx_hit &h, const Opts &o)
 {
     const bsx_params &p = o.p;
     // TrimAdapter / TrimLowQual erase seq and qual at the new length; rebasing happens before the scan whenever
     // TrimLowQual gets past its first test (qual_threshold != 0 and more than one quality character at that point)
-    size_t qlen_at_lowq = r.qual.size();
-    if (p.qual_threshold != 0 && qlen_at_lowq != 1 && o.out_sam && p.zero_qual != '!') {
+    if (p.qual_threshold != 0 && r.qlen != 1 && o.out_sam && p.zero_qual != '!') {
         // the adapter cut (if any) happened first: only the surviving part is rebased, but everything behind is erased anyway
-        for (size_t i = 0; i < r.qual.size(); i++) r.qual[i] = (char)(r.qual[i] - (p.zero_qual - '!'));
+        for (size_t i = 0; i < r.qlen; i++) r.qual[i] = (char)(r.qual[i] - (p.zero_qual - '!'));
     }
-    if (r.seq.size() > h.len) r.seq.erase(h.len);
-    if (r.qual.size() > h.len) r.qual.erase(h.len);
+    if (r.slen > h.len) r.slen = h.len;
+    if (r.qlen > h.len) r.qlen = h.len;
 }
 
 void die(int rc, const char *what)
@@ -424,6 +532,41 @@ void die(int rc, const char *what)
     exit(1);
 }
 
+// ---- the mapping pipeline ---------------------------------------------------------------------------------------------
+// Four stages run concurrently on a ring of batches, each stage taking the batches in input order:
+//   parse (one thread per read file)  ->  GPU (upload, Do_Batch, results)  ->  format (-p worker threads)  ->  write
+// so the output stays in input order whatever the thread count (the reference's order is only defined for -p 1).
+struct Slot {
+    ReadSet A, B;
+    size_t n = 0;
+    unsigned total_after = 0;
+    vector<bsx_hit> hits;
+    vector<bsx_pair> pairs;
+    vector<bsx_class_counts> cca, ccb;
+    vector<Text> out, out_unpair;
+    int stage = 0;  // 0 free, 1 parsed, 2 aligned, 3 formatted
+};
+
+struct Ring {
+    static const int NS = 3;
+    Slot slot[NS];
+    mutex mu;
+    condition_variable cv;
+    long n_batches = -1;  // known once the parser reaches the end of the input
+    Slot &at(long k) { return slot[k % NS]; }
+    // wait until batch k is in `stage`; false when the input ended before batch k
+    bool acquire(long k, int stage)
+    {
+        unique_lock<mutex> lk(mu);
+        cv.wait(lk, [&] { return (n_batches >= 0 && k >= n_batches) || at(k).stage == stage; });
+        return !(n_batches >= 0 && k >= n_batches);
+    }
+    void release(long k, int stage) { { lock_guard<mutex> lk(mu); at(k).stage = stage; } cv.notify_all(); }
+    void finish(long n) { { lock_guard<mutex> lk(mu); n_batches = n; } cv.notify_all(); }
+};
+
+double now_s() { return chrono::duration<double>(chrono::steady_clock::now().time_since_epoch()).count(); }
+
 }  // namespace
 
 int main(int argc, char **argv)
@@ -431,6 +574,7 @@ int main(int argc, char **argv)
     cout << "\nBSMAP v" << version << endl;
     if (argc == 1) usage();
     time_t t_begin = time(NULL);
+    const double t0 = now_s();
     cout << "Start at:  " << ctime(&t_begin) << endl;
     Opts o;
     bsx_params_default(&o.p);
@@ -440,6 +584,7 @@ int main(int argc, char **argv)
         else if (o.out_file.compare(o.out_file.size() - 4, 4, ".bam") == 0) { cerr << "BAM output needs samtools and is not supported by this build; use .sam\n"; exit(1); }
     }
     o.p.out_sam = o.out_sam;
+    if (const char *e = getenv("BSX_BATCH")) o.batch = (unsigned)max(1, atoi(e));  // units per batch (default 2^20)
     int rc = bsx_params_finish(&o.p);
     if (rc) die(rc, "bad option value");
     const bsx_params &p = o.p;
@@ -447,6 +592,7 @@ int main(int argc, char **argv)
     RefView rv;
     rc = bsx_ref_create_from_file(&o.p, o.ref_file.c_str(), o.device, &rv.ref);
     if (rc) die(rc, "loading the reference");
+    const double t_loaded = now_s();
     const uint32_t n_chr = bsx_ref_n_chr(rv.ref);
     rv.anchor.resize(n_chr + 1); rv.chr_size.resize(n_chr); rv.rc_offset.resize(n_chr);
     bsx_ref_info(rv.ref, rv.anchor.data(), rv.chr_size.data(), rv.rc_offset.data());
@@ -456,6 +602,7 @@ int main(int argc, char **argv)
     cout << "total_kmers: " << p.total_kmers << endl;
     rc = bsx_index_build(rv.ref);
     if (rc) die(rc, "building the seed index");
+    const double t_indexed = now_s();
     cout << "Create seed table. " << time(NULL) - t_begin << " secs passed\n";
     rv.refcat.resize(bsx_ref_n_words(rv.ref) + 64, 0);
     bsx_ref_download_words(rv.ref, rv.refcat.data(), nullptr);
@@ -471,80 +618,135 @@ int main(int argc, char **argv)
     cout << "additional alignment: " << (char)toupper(p.read_nt) << " in reads => " << (char)toupper(p.ref_nt) << " in reference" << endl;
     const bool pe = !o.a_file.empty() && !o.b_file.empty();
     if (o.a_file.empty()) { cerr << "missing query file(s)\n"; exit(1); }
-    ofstream fout(o.out_file.c_str());
+    FILE *fout = fopen(o.out_file.c_str(), "wb");
     if (!fout) { cerr << "failed to open output file (check -o option): " << o.out_file << endl; exit(1); }
-    ofstream fout_unpair;
+    FILE *fout_unpair = nullptr;
     if (o.out_sam) {
-        fout << "@HD\tVN:1.0\n";
-        for (uint32_t c = 0; c < n_chr; c++) fout << "@SQ\tSN:" << rv.names[c] << "\tLN:" << rv.chr_size[c] << "\n";
-        fout << "@PG\tID:BSMAP_" << version << endl;
+        Text h;
+        h.put("@HD\tVN:1.0\n");
+        for (uint32_t c = 0; c < n_chr; c++) { h.put("@SQ\tSN:"); h.put(rv.names[c]); h.put("\tLN:"); h.put_u(rv.chr_size[c]); h.put('\n'); }
+        h.put("@PG\tID:BSMAP_"); h.put(version); h.put('\n');
+        fwrite(h.s.data(), 1, h.s.size(), fout);
     } else if (pe) {
-        fout_unpair.open(o.out_unpair.c_str());
+        fout_unpair = fopen(o.out_unpair.c_str(), "wb");
         if (!fout_unpair) { cerr << "failed to open output file for unpaired hits (check -2 option): " << o.out_unpair << endl; exit(1); }
     }
-    Formatter fmt(o, rv);
     bsx_batch *batch = nullptr;
     rc = bsx_batch_create(rv.ref, o.batch, pe ? 1 : 0, &batch);
     if (rc) die(rc, "creating the batch");
     Reader ra, rb;
     ra.open(o.a_file, o);
     if (pe) rb.open(o.b_file, o);
-    vector<Read> A, B;
-    vector<uint64_t> offa, offb;
-    string sa, sb, qa, qb, os, os_unpair;
-    vector<bsx_hit> hits;
-    vector<bsx_pair> pairs;
-    vector<bsx_class_counts> cca, ccb;
-    unsigned total = 0;
-    auto pack = [](const vector<Read> &R, string &s, string &q, vector<uint64_t> &off) {
-        s.clear(); q.clear(); off.assign(1, 0);
-        for (const Read &r : R) { s += r.seq; q += r.qual; q.resize(s.size(), 'I'); off.push_back(s.size()); }
-    };
     if (pe) cout << "Pair-end alignment(GPU " << o.device << ")\n"; else cout << "Single read alignment(GPU " << o.device << ")\n";
-    for (;;) {
-        const size_t n1 = ra.load(A, o.batch, o);
-        if (pe) { const size_t n2 = rb.load(B, o.batch, o); if (!n1 || n1 != n2) break; }
-        else if (!n1) break;
-        pack(A, sa, qa, offa);
-        os.clear(); os_unpair.clear();
-        if (!pe) {
-            rc = bsx_batch_upload_se(batch, (uint32_t)n1, sa.data(), offa.data(), ra.format == 0 ? qa.data() : nullptr, A[0].index);
-            if (rc) die(rc, "uploading reads");
-            if ((rc = bsx_batch_run(batch))) die(rc, "aligning");
-            hits.resize(n1); cca.resize(n1);
-            if ((rc = bsx_batch_results_se(batch, hits.data(), cca.data()))) die(rc, "reading results");
-            for (size_t i = 0; i < n1; i++) {
-                const bsx_hit &h = hits[i];
-                apply_trim(A[i], h, o);
-                if (h.flags & BSX_F_FILTERED) { if (p.report_repeat_hits) fmt.out_hit(A[i], 0, 0, -1, 0, 0, 0, 0, 0, nullptr, os); }
-                else fmt.out_hit(A[i], 0, (h.flags & BSX_F_CHAIN) ? 1 : 0, h.n_best, h.best_class < 0 ? h.max_snp + 1 : h.best_class, h.chr, h.loc, 0, h.max_snp, &cca[i], os);
-            }
-        } else {
-            pack(B, sb, qb, offb);
-            const bool q = ra.format == 0 && rb.format == 0;
-            rc = bsx_batch_upload_pe(batch, (uint32_t)n1, sa.data(), offa.data(), q ? qa.data() : nullptr, sb.data(), offb.data(), q ? qb.data() : nullptr, A[0].index);
-            if (rc) die(rc, "uploading reads");
-            if ((rc = bsx_batch_run(batch))) die(rc, "aligning");
-            pairs.resize(n1); cca.resize(n1); ccb.resize(n1);
-            if ((rc = bsx_batch_results_pe(batch, pairs.data(), cca.data(), ccb.data(), nullptr))) die(rc, "reading results");
-            for (size_t i = 0; i < n1; i++) {
-                const bsx_pair &pp = pairs[i];
-                apply_trim(A[i], pp.a, o); apply_trim(B[i], pp.b, o);
-                if (o.out_sam) fix_pair_name(A[i], B[i]);
-                if (!pp.unpaired_out) fmt.out_pair(A[i], B[i], pp, &cca[i], &ccb[i], os);
-                else {
-                    string &dst = o.out_sam ? os : os_unpair;
-                    fmt.out_unpair(A[i], 0, pp.a, pp.b, &cca[i], dst);
-                    fmt.out_unpair(B[i], 1, pp.b, pp.a, &ccb[i], dst);
-                }
-            }
+    const int workers = o.num_procs > 0 ? o.num_procs : (int)min(64u, max(1u, thread::hardware_concurrency()));
+    Ring ring;
+    Formatter totals(o, rv);
+    unsigned total = 0;
+    double busy[4] = {0, 0, 0, 0};
+    const double t_map0 = now_s();
+
+    thread t_parse([&] {
+        long k = 0;
+        for (;; k++) {
+            ring.acquire(k, 0);
+            const double t = now_s();
+            Slot &s = ring.at(k);
+            size_t n2 = 0;
+            thread tb;
+            if (pe) tb = thread([&] { n2 = load_reads(rb, s.B, o.batch, o); });
+            const size_t n1 = load_reads(ra, s.A, o.batch, o);
+            if (pe) tb.join();
+            busy[0] += now_s() - t;
+            if (!n1 || (pe && n1 != n2)) break;
+            s.n = n1;
+            s.total_after = ra.index - o.read_start + 1;
+            ring.release(k, 1);
         }
-        fout << os;
-        if (pe && !o.out_sam) fout_unpair << os_unpair;
-        total = ra.index - o.read_start + 1;
+        ring.finish(k);
+    });
+    thread t_gpu([&] {
+        for (long k = 0; ring.acquire(k, 1); k++) {
+            const double t = now_s();
+            Slot &s = ring.at(k);
+            const uint32_t n = (uint32_t)s.n;
+            int r;
+            if (!pe) {
+                r = bsx_batch_upload_se(batch, n, s.A.seq.data(), s.A.soff.data(), ra.format == 0 ? s.A.upload_qual() : nullptr, s.A.first_index);
+                if (r) die(r, "uploading reads");
+                if ((r = bsx_batch_run(batch))) die(r, "aligning");
+                s.hits.resize(n); s.cca.resize(n);
+                if ((r = bsx_batch_results_se(batch, s.hits.data(), s.cca.data()))) die(r, "reading results");
+            } else {
+                const bool q = ra.format == 0 && rb.format == 0;
+                r = bsx_batch_upload_pe(batch, n, s.A.seq.data(), s.A.soff.data(), q ? s.A.upload_qual() : nullptr, s.B.seq.data(), s.B.soff.data(),
+                                        q ? s.B.upload_qual() : nullptr, s.A.first_index);
+                if (r) die(r, "uploading reads");
+                if ((r = bsx_batch_run(batch))) die(r, "aligning");
+                s.pairs.resize(n); s.cca.resize(n); s.ccb.resize(n);
+                if ((r = bsx_batch_results_pe(batch, s.pairs.data(), s.cca.data(), s.ccb.data(), nullptr))) die(r, "reading results");
+            }
+            busy[1] += now_s() - t;
+            ring.release(k, 2);
+        }
+    });
+    thread t_format([&] {
+        for (long k = 0; ring.acquire(k, 2); k++) {
+            const double t = now_s();
+            Slot &s = ring.at(k);
+            const int W = (int)min<size_t>((size_t)workers, max<size_t>(1, s.n / 1024));
+            s.out.assign(W, Text()); s.out_unpair.assign(W, Text());
+            vector<Formatter> fm(W, Formatter(o, rv));
+            auto work = [&](int w) {
+                const size_t lo = s.n * w / W, hi = s.n * (w + 1) / W;
+                Text &os = s.out[w], &os_unpair = s.out_unpair[w];
+                os.s.reserve((hi - lo) * (pe ? 900 : 450));
+                Formatter &fmt = fm[w];
+                Rd a, b;
+                for (size_t i = lo; i < hi; i++) {
+                    a.load(s.A, i);
+                    if (!pe) {
+                        const bsx_hit &h = s.hits[i];
+                        apply_trim(a, h, o);
+                        if (h.flags & BSX_F_FILTERED) { if (p.report_repeat_hits) fmt.out_hit(a, 0, 0, -1, 0, 0, 0, 0, 0, nullptr, os); }
+                        else fmt.out_hit(a, 0, (h.flags & BSX_F_CHAIN) ? 1 : 0, h.n_best, h.best_class < 0 ? h.max_snp + 1 : h.best_class, h.chr, h.loc, 0, h.max_snp, &s.cca[i], os);
+                    } else {
+                        b.load(s.B, i);
+                        const bsx_pair &pp = s.pairs[i];
+                        apply_trim(a, pp.a, o); apply_trim(b, pp.b, o);
+                        if (o.out_sam) fix_pair_name(a, b);
+                        if (!pp.unpaired_out) fmt.out_pair(a, b, pp, &s.cca[i], &s.ccb[i], os);
+                        else {
+                            Text &dst = o.out_sam ? os : os_unpair;
+                            fmt.out_unpair(a, 0, pp.a, pp.b, &s.cca[i], dst);
+                            fmt.out_unpair(b, 1, pp.b, pp.a, &s.ccb[i], dst);
+                        }
+                    }
+                }
+            };
+            vector<thread> th;
+            for (int w = 1; w < W; w++) th.emplace_back(work, w);
+            work(0);
+            for (thread &x : th) x.join();
+            for (const Formatter &f : fm) { totals.n_aligned += f.n_aligned; totals.n_aligned_pairs += f.n_aligned_pairs; totals.n_aligned_a += f.n_aligned_a; totals.n_aligned_b += f.n_aligned_b; }
+            busy[2] += now_s() - t;
+            ring.release(k, 3);
+        }
+    });
+    for (long k = 0; ring.acquire(k, 3); k++) {  // write stage on the main thread
+        const double t = now_s();
+        Slot &s = ring.at(k);
+        for (const Text &x : s.out) if (!x.s.empty()) fwrite(x.s.data(), 1, x.s.size(), fout);
+        if (fout_unpair) for (const Text &x : s.out_unpair) if (!x.s.empty()) fwrite(x.s.data(), 1, x.s.size(), fout_unpair);
+        total = s.total_after;
+        busy[3] += now_s() - t;
         cout << total << " reads finished. " << time(NULL) - t_begin << " secs passed" << endl;
+        ring.release(k, 0);
     }
-    fout.close();
+    t_parse.join(); t_gpu.join(); t_format.join();
+    fclose(fout);
+    if (fout_unpair) fclose(fout_unpair);
+    const double t_map1 = now_s();
+    const Formatter &fmt = totals;
     char pct[64];
     if (pe) {
         cout << "Total number of aligned reads: \n";
@@ -562,6 +764,10 @@ int main(int argc, char **argv)
     time_t t_end = time(NULL);
     cout << "Finished at " << ctime(&t_end);
     cout << "Total time consumed:  " << t_end - t_begin << " secs\n";
+    if (getenv("BSX_TIMING"))  // machine-readable phase times (extension; stderr so that stdout keeps the reference's lines)
+        fprintf(stderr, "{\"load_reference_s\": %.3f, \"index_build_s\": %.3f, \"mapping_s\": %.3f, \"units\": %u, \"reads\": %u, \"workers\": %d, "
+                        "\"stage_busy_s\": {\"parse\": %.3f, \"gpu\": %.3f, \"format\": %.3f, \"write\": %.3f}}\n",
+                t_loaded - t0, t_indexed - t_loaded, t_map1 - t_map0, total, pe ? 2 * total : total, workers, busy[0], busy[1], busy[2], busy[3]);
     bsx_batch_destroy(batch);
     bsx_ref_destroy(rv.ref);
     return 0;

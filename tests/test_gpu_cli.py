@@ -85,3 +85,39 @@ def test_cli_matches_reference_binary(name, tag, tmp_path):
         for g, e in zip(got, exp):
             assert g == e
     assert "Total number of aligned reads" in res.stdout
+
+
+@pytest.mark.parametrize("name", [n for n in sorted(CLI) if CLI[n]["sam_Ru"]["out"]][:4])
+def test_cli_pipeline_is_batch_and_thread_invariant(name, tmp_path):
+    """the parse -> GPU -> format -> write pipeline over many small batches with several formatting threads writes the
+    same bytes (and the same summary) as one batch with one thread; odd FASTQ layouts go through the token rules of
+    reads.cpp (blank lines between records, text after the name, CRLF)"""
+    meta, arr, fasta = G.load(name)
+    pe = meta["kind"] == "pe"
+    run = CLI[name]["sam_Ru"]
+
+    def write(path, mate, eol="\n", gap=""):
+        with open(path, "w", newline="") as f:
+            for i, r in enumerate(meta["reads"]):
+                nm = r["name"] + (f"/{mate}" if pe else "")
+                seq, qual = (r[f"seq{mate}"], r[f"qual{mate}"]) if pe else (r["seq"], r["qual"])
+                f.write(f"@{nm} extra words {i}{eol}{seq}{eol}+{nm if i % 2 else ''}{eol}{qual}{eol}{gap}")
+
+    outs = []
+    for tag, env, eol, gap in (("one", {"BSX_BATCH": "1048576"}, "\n", ""), ("many", {"BSX_BATCH": "37"}, "\r\n", "\n\n")):
+        files = [str(tmp_path / f"{tag}_{m}.fq") for m in ((1, 2) if pe else (1,))]
+        for m, fpath in enumerate(files):
+            write(fpath, m + 1, eol, gap)
+        out = str(tmp_path / f"{tag}.sam")
+        opts = list(run["options"])
+        cmd = [BIN] + (["-D", meta["kw"]["D"]] if "D" in meta["kw"] else []) + ["-a", files[0]] + (["-b", files[1]] if pe else []) + \
+            ["-d", fasta, "-o", out, "-p", "1" if tag == "one" else "5"] + [o for i, o in enumerate(opts) if not (o == "-D" or (i and opts[i - 1] == "-D"))]
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+        assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-1500:]
+        outs.append((open(out, "rb").read(), [l for l in res.stdout.split("\n") if "aligned" in l or l.startswith(("pairs", "single"))]))
+    assert outs[0][0] == outs[1][0] and len(outs[0][0]) > 1000
+    assert outs[0][1] == outs[1][1]
+    # and the plain layout equals the reference binary's file (same comparison as above, whole file, leaky reads excluded)
+    leaky = _leaky_names(meta)
+    if not leaky:
+        assert _body(outs[0][0].decode()) == _body(run["out"])
