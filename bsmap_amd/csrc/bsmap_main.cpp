@@ -11,11 +11,6 @@
 // Not supported (reference features outside the hot path): SAM/BAM input and .bam output (samtools).
 // Parsing, the GPU, formatting (-p threads) and writing run as a pipeline over a ring of batches; the output is always
 // in input order (the reference's order is nondeterministic for -p > 1).
-#include <fcntl.h>
-#include <sys/mman.h>
-#include <sys/stat.h>
-#include <unistd.h>
-
 #include <algorithm>
 #include <chrono>
 #include <condition_variable>
@@ -31,8 +26,10 @@
 #include <vector>
 
 #include "../../include/bsx.h"
+#include "bsx_reads.h"
 
 using namespace std;
+using bsx_reads::Reader; using bsx_reads::ReadSet; using bsx_reads::ReadOpts; using bsx_reads::load_reads;
 
 namespace {
 
@@ -155,131 +152,6 @@ int parse_options(int argc, char **argv, Opts &o)
         }
     }
     return 0;
-}
-
-// ---- reads (reads.cpp:13-117) -------------------------------------------------------------------------------------
-// The reference reads with operator>> / getline on an ifstream; the same token rules are applied here to a memory map
-// of the file (whitespace-separated tokens, rest of the header line dropped, header remainder limited to 999
-// characters), which parses gigabytes per second instead of the iostream rate.
-inline bool is_ws(char c) { return c == ' ' || c == '\n' || c == '\t' || c == '\r' || c == '\v' || c == '\f'; }
-
-struct Reader {
-    const char *base = nullptr, *cur = nullptr, *end = nullptr;
-    size_t map_len = 0;
-    int format = -1;  // 0 fastq, 1 fasta
-    unsigned index = 0;
-    bool failed = false;  // the stream's failbit: every later extraction yields nothing
-    bool eof_hit = false;
-
-    void skip_ws() { while (cur < end && is_ws(*cur)) cur++; }
-    // operator>>(string): false (and fail state) when no character could be extracted
-    bool token(const char *&t, size_t &n)
-    {
-        t = cur; n = 0;
-        if (failed) return false;
-        skip_ws();
-        if (cur >= end) { eof_hit = true; failed = true; return false; }
-        t = cur;
-        while (cur < end && !is_ws(*cur)) cur++;
-        if (cur >= end) eof_hit = true;
-        n = (size_t)(cur - t);
-        return true;
-    }
-    // getline(buf, 1000): up to 999 characters, the newline is consumed; longer lines set the fail state
-    void rest_of_line()
-    {
-        if (failed) return;
-        const char *nl = (const char *)memchr(cur, '\n', (size_t)(end - cur));
-        const size_t n = nl ? (size_t)(nl - cur) : (size_t)(end - cur);
-        if (n > 999) { cur += 999; failed = true; return; }
-        if (!nl) { cur = end; eof_hit = true; if (n == 0) failed = true; return; }
-        cur = nl + 1;
-    }
-    void open(const string &path, const Opts &o)
-    {
-        const int fd = ::open(path.c_str(), O_RDONLY);
-        if (fd < 0) { cerr << "failed to open read file (check -a option): " << path << endl; exit(1); }
-        struct stat st;
-        fstat(fd, &st);
-        map_len = (size_t)st.st_size;
-        if (map_len) {
-            void *m = mmap(nullptr, map_len, PROT_READ, MAP_PRIVATE, fd, 0);
-            if (m == MAP_FAILED) { cerr << "failed to map read file: " << path << endl; exit(1); }
-            madvise(m, map_len, MADV_SEQUENTIAL);
-            base = (const char *)m;
-        }
-        ::close(fd);
-        cur = base; end = base + map_len;
-        const char *t; size_t n1 = 0, n2 = 0, n4 = 0;
-        token(t, n1); const char first = n1 ? t[0] : 0; rest_of_line();
-        if (first == '>') format = 1;
-        else if (first == '@') {
-            token(t, n2); rest_of_line(); token(t, n1); rest_of_line(); token(t, n4); rest_of_line();
-            format = 0;
-            if (n2 != n4) { cerr << "fatal error: fq format, sequence length not equal to quality length\n"; exit(1); }
-        } else { cerr << "fatal error: unrecognizable format of reads file (SAM/BAM input is not supported by this build).\n"; exit(1); }
-        cur = base; failed = false; eof_hit = false;
-        const unsigned skip = (o.read_start - 1) * (format == 0 ? 4 : 2);
-        for (unsigned i = 0; i < skip; i++) {  // getline(ch, 1000) per skipped line
-            if (eof_hit) break;
-            rest_of_line();
-        }
-        index = o.read_start - 1;
-    }
-};
-
-// one batch of reads in flat arrays: what the upload takes (sequence bytes + offsets) and what the formatters need
-struct ReadSet {
-    vector<char> names, seq, qual;
-    vector<uint64_t> noff, soff, qoff;
-    vector<char> qual_upload;  // only when some quality string differs in length from its sequence
-    bool qual_same = true;
-    unsigned first_index = 0;
-    size_t n() const { return soff.size() - 1; }
-    void clear() { names.clear(); seq.clear(); qual.clear(); noff.assign(1, 0); soff.assign(1, 0); qoff.assign(1, 0); qual_same = true; }
-    const char *upload_qual()
-    {
-        if (qual_same) return qual.data();
-        qual_upload.assign(seq.size(), 'I');
-        for (size_t i = 0; i + 1 < soff.size(); i++) {
-            const size_t sl = soff[i + 1] - soff[i], ql = qoff[i + 1] - qoff[i];
-            memcpy(qual_upload.data() + soff[i], qual.data() + qoff[i], min(sl, ql));
-        }
-        return qual_upload.data();
-    }
-};
-
-// ReadClass::LoadBatchReads (reads.cpp:83-117) for one file; returns the number of reads loaded
-size_t load_reads(Reader &rd, ReadSet &out, size_t max_n, const Opts &o)
-{
-    out.clear();
-    out.first_index = rd.index;
-    const size_t maxlen = (size_t)o.p.max_readlen;
-    while (out.n() < max_n && rd.index < o.read_end) {
-        const char *t; size_t n;
-        // fin >> c : the record marker ('@' or '>') is a single character, the name follows (possibly after blanks)
-        if (rd.failed) break;
-        rd.skip_ws();
-        if (rd.cur >= rd.end) break;
-        rd.cur++;
-        rd.token(t, n);
-        out.names.insert(out.names.end(), t, t + n); out.noff.push_back(out.names.size());
-        rd.rest_of_line();
-        rd.token(t, n);
-        const size_t sl = min(n, maxlen);
-        out.seq.insert(out.seq.end(), t, t + sl); out.soff.push_back(out.seq.size());
-        if (rd.format == 0) {
-            rd.token(t, n); rd.rest_of_line();  // '+' line
-            rd.token(t, n);
-            const size_t ql = min(n, maxlen);
-            out.qual.insert(out.qual.end(), t, t + ql); out.qoff.push_back(out.qual.size());
-            if (ql != sl) out.qual_same = false;
-        } else {
-            out.qual.insert(out.qual.end(), sl, (char)(o.p.zero_qual + 40)); out.qoff.push_back(out.qual.size());
-        }
-        rd.index++;
-    }
-    return out.n();
 }
 
 // ---- reference view for XR:Z and RRBS tags ------------------------------------------------------------------------
@@ -536,6 +408,8 @@ void die(int rc, const char *what)
 // Four stages run concurrently on a ring of batches, each stage taking the batches in input order:
 //   parse (one thread per read file)  ->  GPU (upload, Do_Batch, results)  ->  format (-p worker threads)  ->  write
 // so the output stays in input order whatever the thread count (the reference's order is only defined for -p 1).
+// The GPU stage has two device batches driven by two threads: kernels of one batch run while the other batch's reads
+// go up and its records come down.
 struct Slot {
     ReadSet A, B;
     size_t n = 0;
@@ -548,7 +422,7 @@ struct Slot {
 };
 
 struct Ring {
-    static const int NS = 3;
+    static const int NS = 6;
     Slot slot[NS];
     mutex mu;
     condition_variable cv;
@@ -631,12 +505,16 @@ int main(int argc, char **argv)
         fout_unpair = fopen(o.out_unpair.c_str(), "wb");
         if (!fout_unpair) { cerr << "failed to open output file for unpaired hits (check -2 option): " << o.out_unpair << endl; exit(1); }
     }
-    bsx_batch *batch = nullptr;
-    rc = bsx_batch_create(rv.ref, o.batch, pe ? 1 : 0, &batch);
-    if (rc) die(rc, "creating the batch");
+    bsx_batch *batches[2] = {nullptr, nullptr};
+    for (int g = 0; g < 2; g++) {
+        rc = bsx_batch_create(rv.ref, o.batch, pe ? 1 : 0, &batches[g]);
+        if (rc) die(rc, "creating the batch");
+    }
+    ReadOpts ro;
+    ro.read_start = o.read_start; ro.read_end = o.read_end; ro.max_readlen = p.max_readlen; ro.zero_qual = p.zero_qual;
     Reader ra, rb;
-    ra.open(o.a_file, o);
-    if (pe) rb.open(o.b_file, o);
+    ra.open(o.a_file, ro);
+    if (pe) rb.open(o.b_file, ro);
     if (pe) cout << "Pair-end alignment(GPU " << o.device << ")\n"; else cout << "Single read alignment(GPU " << o.device << ")\n";
     const int workers = o.num_procs > 0 ? o.num_procs : (int)min(64u, max(1u, thread::hardware_concurrency()));
     Ring ring;
@@ -653,8 +531,8 @@ int main(int argc, char **argv)
             Slot &s = ring.at(k);
             size_t n2 = 0;
             thread tb;
-            if (pe) tb = thread([&] { n2 = load_reads(rb, s.B, o.batch, o); });
-            const size_t n1 = load_reads(ra, s.A, o.batch, o);
+            if (pe) tb = thread([&] { n2 = load_reads(rb, s.B, o.batch, ro); });
+            const size_t n1 = load_reads(ra, s.A, o.batch, ro);
             if (pe) tb.join();
             busy[0] += now_s() - t;
             if (!n1 || (pe && n1 != n2)) break;
@@ -664,8 +542,10 @@ int main(int argc, char **argv)
         }
         ring.finish(k);
     });
-    thread t_gpu([&] {
-        for (long k = 0; ring.acquire(k, 1); k++) {
+    mutex mu_run, mu_busy;
+    auto gpu_stage = [&](int g) {
+        bsx_batch *batch = batches[g];
+        for (long k = g; ring.acquire(k, 1); k += 2) {
             const double t = now_s();
             Slot &s = ring.at(k);
             const uint32_t n = (uint32_t)s.n;
@@ -673,7 +553,7 @@ int main(int argc, char **argv)
             if (!pe) {
                 r = bsx_batch_upload_se(batch, n, s.A.seq.data(), s.A.soff.data(), ra.format == 0 ? s.A.upload_qual() : nullptr, s.A.first_index);
                 if (r) die(r, "uploading reads");
-                if ((r = bsx_batch_run(batch))) die(r, "aligning");
+                { lock_guard<mutex> lk(mu_run); if ((r = bsx_batch_run(batch)) || (r = bsx_batch_sync(batch))) die(r, "aligning"); }
                 s.hits.resize(n); s.cca.resize(n);
                 if ((r = bsx_batch_results_se(batch, s.hits.data(), s.cca.data()))) die(r, "reading results");
             } else {
@@ -681,14 +561,15 @@ int main(int argc, char **argv)
                 r = bsx_batch_upload_pe(batch, n, s.A.seq.data(), s.A.soff.data(), q ? s.A.upload_qual() : nullptr, s.B.seq.data(), s.B.soff.data(),
                                         q ? s.B.upload_qual() : nullptr, s.A.first_index);
                 if (r) die(r, "uploading reads");
-                if ((r = bsx_batch_run(batch))) die(r, "aligning");
+                { lock_guard<mutex> lk(mu_run); if ((r = bsx_batch_run(batch)) || (r = bsx_batch_sync(batch))) die(r, "aligning"); }
                 s.pairs.resize(n); s.cca.resize(n); s.ccb.resize(n);
                 if ((r = bsx_batch_results_pe(batch, s.pairs.data(), s.cca.data(), s.ccb.data(), nullptr))) die(r, "reading results");
             }
-            busy[1] += now_s() - t;
+            { lock_guard<mutex> lk(mu_busy); busy[1] += now_s() - t; }
             ring.release(k, 2);
         }
-    });
+    };
+    thread t_gpu(gpu_stage, 0), t_gpu2(gpu_stage, 1);
     thread t_format([&] {
         for (long k = 0; ring.acquire(k, 2); k++) {
             const double t = now_s();
@@ -742,7 +623,7 @@ int main(int argc, char **argv)
         cout << total << " reads finished. " << time(NULL) - t_begin << " secs passed" << endl;
         ring.release(k, 0);
     }
-    t_parse.join(); t_gpu.join(); t_format.join();
+    t_parse.join(); t_gpu.join(); t_gpu2.join(); t_format.join();
     fclose(fout);
     if (fout_unpair) fclose(fout_unpair);
     const double t_map1 = now_s();
@@ -768,7 +649,7 @@ int main(int argc, char **argv)
         fprintf(stderr, "{\"load_reference_s\": %.3f, \"index_build_s\": %.3f, \"mapping_s\": %.3f, \"units\": %u, \"reads\": %u, \"workers\": %d, "
                         "\"stage_busy_s\": {\"parse\": %.3f, \"gpu\": %.3f, \"format\": %.3f, \"write\": %.3f}}\n",
                 t_loaded - t0, t_indexed - t_loaded, t_map1 - t_map0, total, pe ? 2 * total : total, workers, busy[0], busy[1], busy[2], busy[3]);
-    bsx_batch_destroy(batch);
+    for (int g = 0; g < 2; g++) bsx_batch_destroy(batches[g]);
     bsx_ref_destroy(rv.ref);
     return 0;
 }

@@ -1,5 +1,10 @@
 // bsx_api.hip — C ABI glue of libbsx.so: handles, device memory, uploads/downloads, kernel launches.
 // See include/bsx.h for the reference interfaces each entry point stands in for.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -90,10 +95,16 @@ extern "C" int bsx_ref_create_from_fasta(const bsx_params *p, const char *text, 
 extern "C" int bsx_ref_create_from_file(const bsx_params *p, const char *path, int device, bsx_ref **out)
 {
     if (!path) return BSX_ERR_ARG;
-    std::ifstream f(path, std::ios::binary);
-    if (!f) { g_bsx_err = std::string("cannot open ") + path; return BSX_ERR_IO; }  // "fatal error: failed to open ref file" (main.cpp:458)
-    std::string text((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
-    return bsx_ref_create_from_fasta(p, text.data(), text.size(), device, out);
+    const int fd = ::open(path, O_RDONLY);
+    if (fd < 0) { g_bsx_err = std::string("cannot open ") + path; return BSX_ERR_IO; }  // "fatal error: failed to open ref file" (main.cpp:458)
+    struct stat st;
+    if (fstat(fd, &st) != 0 || st.st_size <= 0) { ::close(fd); g_bsx_err = std::string("cannot read ") + path; return BSX_ERR_IO; }
+    void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    ::close(fd);
+    if (m == MAP_FAILED) { g_bsx_err = std::string("cannot map ") + path; return BSX_ERR_IO; }
+    const int rc = bsx_ref_create_from_fasta(p, (const char *)m, (uint64_t)st.st_size, device, out);
+    munmap(m, (size_t)st.st_size);
+    return rc;
 }
 
 extern "C" void bsx_ref_destroy(bsx_ref *r)

@@ -6,11 +6,13 @@
 //   RefSeq::LoadNextSeq / BinSeq / cBinSeq / UnmaskRegion / Run_ConvertBinseq dbseq.cpp:18-142,215-282
 //   RefSeq::find_CCGG                                                          dbseq.cpp:144-211
 #include <algorithm>
+#include <atomic>
 #include <cctype>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
 #include <sstream>
+#include <thread>
 
 #include "bsx_internal.h"
 
@@ -125,14 +127,97 @@ extern "C" int bsx_params_finish(bsx_params *p)
 namespace {
 
 inline bool is_space(char c) { return c == ' ' || (c >= '\t' && c <= '\r'); }
-inline bool is_useful(char c) { return nt_index(c) >= 0; }                       // Param::useful_nt
-inline bool is_nx(char c) { return c == 'N' || c == 'X' || c == 'n' || c == 'x'; } // Param::nx_nt
 
 struct Cursor {
     const char *t; uint64_t n, i;
     void skip_ws() { while (i < n && is_space(t[i])) i++; }
     bool token(uint64_t &b, uint64_t &e) { skip_ws(); b = i; while (i < n && !is_space(t[i])) i++; e = i; return e > b; }
 };
+
+// one FASTA record: its name and the text region holding the sequence tokens
+struct Rec { std::string name; uint64_t sb, se; };
+
+// everything derived from one record; records are independent, so they are packed by a pool of threads
+struct Packed {
+    int rc = BSX_OK;
+    uint32_t L = 0, padded = 0;
+    std::vector<uint32_t> f, c;
+    std::vector<Block> blocks;
+    std::vector<uint32_t> sites;
+    std::vector<std::vector<uint32_t>> ccgg_f, ccgg_r;  // [segment]
+};
+
+void pack_record(const bsx_params &P, const char *text, const Rec &R, uint32_t chr, const uint8_t *code_f, const uint8_t *code_r,
+                 const uint8_t *cls, Packed &o)
+{
+    // concatenate the whitespace-separated tokens (dbseq.cpp:40-50)
+    std::vector<char> buf((size_t)(R.se - R.sb) + 4 * BSX_SEGLEN + 8);
+    uint64_t len = 0;
+    for (uint64_t i = R.sb; i < R.se; i++) { const char ch = text[i]; buf[len] = ch; len += !(cls[(uint8_t)ch] & 4); }
+    if (len >= 0xFFFFFFFFull - 64) { o.rc = BSX_ERR_LIMIT; return; }
+    const uint32_t L = (uint32_t)len;
+    const uint32_t nw = (L + BSX_SEGLEN - 1) / BSX_SEGLEN + 2;  // BinSeq: two spare words (dbseq.cpp:60)
+    const uint64_t padded = (uint64_t)nw * BSX_SEGLEN;
+    std::fill(buf.begin() + L, buf.begin() + padded, 'N');
+    o.L = L; o.padded = (uint32_t)padded;
+    o.f.resize(nw); o.c.resize(nw);
+    for (uint32_t w = 0; w < nw; w++) {
+        uint32_t x = 0, y = 0;
+        const uint64_t base = (uint64_t)w * BSX_SEGLEN, rbase = padded - 1 - base;
+        for (uint32_t j = 0; j < BSX_SEGLEN; j++) {
+            x = (x << 2) | code_f[(uint8_t)buf[base + j]];
+            y = (y << 2) | code_r[(uint8_t)buf[rbase - j]];
+        }
+        o.f[w] = x; o.c[w] = y;
+    }
+    // UnmaskRegion (dbseq.cpp:114-142): maximal runs between N/X characters that start at an ACGT letter and are
+    // >= 30 nt; each run is recorded on the forward copy (id 2c) and mirrored on the rc copy (id 2c+1).  The
+    // reference scans a work string that still holds older records behind this one; the 'N' padding written above
+    // stops both scans before that tail, so the record alone decides.
+    {
+        uint32_t begin, end = 0;
+        while (end < L) {
+            uint64_t q = end;
+            while (q < padded && !(cls[(uint8_t)buf[q]] & 1)) q++;
+            if (q >= padded || q > L) break;
+            begin = (uint32_t)q;
+            while (q < padded && !(cls[(uint8_t)buf[q]] & 2)) q++;
+            end = q <= L ? (uint32_t)q : L;
+            if (end - begin < 30) continue;
+            // (the reference's "merge with previous block if gap < 5" test compares against the rc twin pushed
+            //  last and therefore never fires)
+            o.blocks.push_back(Block{2 * chr, begin, end});
+            o.blocks.push_back(Block{2 * chr + 1, (uint32_t)padded - end, (uint32_t)padded - begin});
+        }
+    }
+    if (P.rrbs) {
+        // find_CCGG (dbseq.cpp:144-211)
+        const size_t dl = strlen(P.digest_site);
+        const uint64_t bs = buf.size();
+        for (uint64_t q = 0; q < L && q + dl <= bs; q++) {
+            bool ok = true;
+            for (size_t k = 0; k < dl && ok; k++) ok = toupper((uint8_t)buf[q + k]) == P.digest_site[k];
+            if (ok) o.sites.push_back((uint32_t)q + P.digest_pos);
+        }
+        const uint32_t tmp_offset = (uint32_t)padded - P.seed_size, tmp_max = L - P.seed_size;
+        o.ccgg_f.assign(P.max_seedseg_num, {}); o.ccgg_r.assign(P.max_seedseg_num, {});
+        const std::vector<uint32_t> &sites = o.sites;
+        if (sites.size() > 1) {
+            for (size_t k = 0; k + 1 < sites.size(); k++)
+                if (sites[k + 1] - sites[k] <= (uint32_t)P.max_insert) {
+                    int seedloc = (int)sites[k];
+                    for (int sg = 0; sg < P.max_seedseg_num && (uint32_t)seedloc <= tmp_max; sg++, seedloc += P.seed_size)
+                        o.ccgg_f[sg].push_back((uint32_t)seedloc);
+                }
+            for (size_t k = 1; k < sites.size(); k++)
+                if (sites[k] - sites[k - 1] <= (uint32_t)P.max_insert) {
+                    int seedloc = (int)((size_t)sites[k] + dl - 2 * P.digest_pos - P.seed_size);
+                    for (int sg = 0; sg < P.max_seedseg_num && seedloc >= 0; sg++, seedloc -= P.seed_size)
+                        o.ccgg_r[sg].push_back(tmp_offset - (uint32_t)seedloc);
+                }
+        }
+    }
+}
 
 }  // namespace
 
@@ -141,110 +226,71 @@ int bsx_pack_fasta(const bsx_params &P, const char *text, uint64_t n, bsx_ref &r
 {
     // The reference reads records with operator>> (dbseq.cpp:18-54): the first non-blank character is consumed
     // unchecked, the next token is the name, the rest of that line is ignored, then whitespace-separated tokens
-    // are concatenated until one begins with '>'.  The work string (_seq) is reused between records and never
-    // cleared, which matters only for where find_first_of may look past the end; `buf` plays that role here.
-    uint8_t code_f[256], code_r[256];
+    // are concatenated until one begins with '>'.  Records are located in one sequential pass and packed in parallel.
+    uint8_t code_f[256], code_r[256], cls[256];  // cls: 1 = Param::useful_nt, 2 = Param::nx_nt, 4 = whitespace
     for (int c = 0; c < 256; c++) {
         int k = nt_index(c);
         code_f[c] = P.bit_nt[k < 0 ? 0 : k];          // alphabet[]: unknown -> code of 'A'
         code_r[c] = P.bit_nt[k < 0 ? 3 : 3 - k];      // rev_alphabet[]: unknown -> code of 'T'
+        cls[c] = (uint8_t)((k >= 0 ? 1 : 0) | ((c == 'N' || c == 'X' || c == 'n' || c == 'x') ? 2 : 0) | (is_space((char)c) ? 4 : 0));
     }
     Cursor cur{text, n, 0};
-    std::string buf;
-    std::vector<std::vector<uint32_t>> fw, rc;
-    r.n_chr = 0; r.sum_length = 0;
-    r.anchor.clear(); r.chr_size.clear(); r.rc_offset.clear(); r.names.clear(); r.blocks.clear(); r.sites.clear();
-    r.ccgg_index.assign(P.rrbs ? P.max_seedseg_num : 0, {});
-    const size_t dl = strlen(P.digest_site);
+    std::vector<Rec> recs;
     for (;;) {
         cur.skip_ws();
         if (cur.i >= cur.n) break;
         cur.i++;  // fin>>c
         uint64_t b, e;
         cur.token(b, e);
-        std::string name(text + b, text + e);
-        while (cur.i < cur.n && text[cur.i] != '\n') cur.i++;
-        if (cur.i < cur.n) cur.i++;
-        uint64_t len = 0;
+        Rec R;
+        R.name.assign(text + b, text + e);
+        const char *nl = (const char *)memchr(text + cur.i, '\n', cur.n - cur.i);
+        cur.i = nl ? (uint64_t)(nl - text) + 1 : cur.n;
+        cur.skip_ws();
+        if (cur.i >= cur.n || text[cur.i] == '>') break;  // empty sequence: LoadNextSeq returned 0, loading stops
+        R.sb = cur.i;
+        // the record ends in front of the next token that starts with '>'
+        uint64_t q = cur.i;
         for (;;) {
-            cur.skip_ws();
-            if (cur.i >= cur.n || text[cur.i] == '>') break;
-            cur.token(b, e);
-            if (buf.size() < len + (e - b)) buf.resize((len + (e - b)) * 2 + 1024, '\0');
-            memcpy(&buf[len], text + b, e - b);
-            len += e - b;
+            const char *g = (const char *)memchr(text + q, '>', cur.n - q);
+            if (!g) { q = cur.n; break; }
+            q = (uint64_t)(g - text);
+            if (is_space(text[q - 1])) break;
+            q++;
         }
-        if (len == 0) break;  // LoadNextSeq returned 0
-        if (len >= 0xFFFFFFFFull - 64) return BSX_ERR_LIMIT;
-        const uint32_t L = (uint32_t)len;
-        const uint32_t nw = (L + BSX_SEGLEN - 1) / BSX_SEGLEN + 2;  // BinSeq: two spare words (dbseq.cpp:60)
-        const uint64_t padded = (uint64_t)nw * BSX_SEGLEN;
-        if (buf.size() < padded + 1) buf.resize(padded * 2 + 1024, '\0');
-        std::fill(buf.begin() + L, buf.begin() + padded, 'N');
-        std::vector<uint32_t> f(nw), c(nw);
-        for (uint32_t w = 0; w < nw; w++) {
-            uint32_t x = 0, y = 0;
-            const uint64_t base = (uint64_t)w * BSX_SEGLEN, rbase = padded - 1 - base;
-            for (uint32_t j = 0; j < BSX_SEGLEN; j++) {
-                x = (x << 2) | code_f[(uint8_t)buf[base + j]];
-                y = (y << 2) | code_r[(uint8_t)buf[rbase - j]];
-            }
-            f[w] = x; c[w] = y;
-        }
-        const uint32_t chr = r.n_chr;
-        // UnmaskRegion (dbseq.cpp:114-142): maximal runs between N/X characters that start at an ACGT letter and
-        // are >= 30 nt; each run is recorded on the forward copy (id 2c) and mirrored on the rc copy (id 2c+1).
-        {
-            uint32_t begin, end = 0;
-            while (end < L) {
-                uint64_t q = end;
-                while (q < buf.size() && !is_useful(buf[q])) q++;
-                if (q >= buf.size() || q > L) break;
-                begin = (uint32_t)q;
-                while (q < buf.size() && !is_nx(buf[q])) q++;
-                end = q <= L ? (uint32_t)q : L;
-                if (end - begin < 30) continue;
-                // (the reference's "merge with previous block if gap < 5" test compares against the rc twin pushed
-                //  last and therefore never fires; reproduced literally)
-                if (!r.blocks.empty() && r.blocks.back().id == 2 * chr && begin - r.blocks.back().end < 5) r.blocks.back().end = end;
-                else {
-                    r.blocks.push_back(Block{2 * chr, begin, end});
-                    r.blocks.push_back(Block{2 * chr + 1, (uint32_t)padded - end, (uint32_t)padded - begin});
-                }
-            }
-        }
-        r.names.push_back(name);
-        r.chr_size.push_back(L);
-        r.rc_offset.push_back((uint32_t)padded);
-        fw.push_back(std::move(f));
-        rc.push_back(std::move(c));
+        R.se = q;
+        cur.i = q;
+        recs.push_back(std::move(R));
+    }
+    r.n_chr = 0; r.sum_length = 0;
+    r.anchor.clear(); r.chr_size.clear(); r.rc_offset.clear(); r.names.clear(); r.blocks.clear(); r.sites.clear();
+    r.ccgg_index.assign(P.rrbs ? P.max_seedseg_num : 0, {});
+    std::vector<Packed> pk(recs.size());
+    {
+        std::atomic<size_t> next(0);
+        auto work = [&] { for (size_t i; (i = next.fetch_add(1)) < recs.size();) pack_record(P, text, recs[i], (uint32_t)i, code_f, code_r, cls, pk[i]); };
+        // large records first would balance better, but FASTA files list the long chromosomes first anyway
+        const size_t nt = std::min<size_t>(recs.size(), n < (8u << 20) ? 1 : std::max(1u, std::min(32u, std::thread::hardware_concurrency())));
+        std::vector<std::thread> th;
+        for (size_t t = 1; t < nt; t++) th.emplace_back(work);
+        work();
+        for (std::thread &t : th) t.join();
+    }
+    std::vector<std::vector<uint32_t>> fw, rc;
+    for (size_t i = 0; i < recs.size(); i++) {
+        Packed &o = pk[i];
+        if (o.rc != BSX_OK) return o.rc;
+        r.names.push_back(recs[i].name);
+        r.chr_size.push_back(o.L);
+        r.rc_offset.push_back(o.padded);
+        r.blocks.insert(r.blocks.end(), o.blocks.begin(), o.blocks.end());
+        fw.push_back(std::move(o.f));
+        rc.push_back(std::move(o.c));
         r.n_chr++;
-        r.sum_length += L;
+        r.sum_length += o.L;
         if (P.rrbs) {
-            // find_CCGG (dbseq.cpp:144-211)
-            std::vector<uint32_t> sites;
-            for (uint64_t q = 0; q < L && q + dl <= buf.size(); q++) {
-                bool ok = true;
-                for (size_t k = 0; k < dl && ok; k++) ok = toupper((uint8_t)buf[q + k]) == P.digest_site[k];
-                if (ok) sites.push_back((uint32_t)q + P.digest_pos);
-            }
-            const uint32_t tmp_offset = (uint32_t)padded - P.seed_size, tmp_max = L - P.seed_size;
-            for (int s = 0; s < P.max_seedseg_num; s++) { r.ccgg_index[s].emplace_back(); r.ccgg_index[s].emplace_back(); }
-            if (sites.size() > 1) {
-                for (size_t k = 0; k + 1 < sites.size(); k++)
-                    if (sites[k + 1] - sites[k] <= (uint32_t)P.max_insert) {
-                        int seedloc = (int)sites[k];
-                        for (int s = 0; s < P.max_seedseg_num && (uint32_t)seedloc <= tmp_max; s++, seedloc += P.seed_size)
-                            r.ccgg_index[s][2 * chr].push_back((uint32_t)seedloc);
-                    }
-                for (size_t k = 1; k < sites.size(); k++)
-                    if (sites[k] - sites[k - 1] <= (uint32_t)P.max_insert) {
-                        int seedloc = (int)((size_t)sites[k] + dl - 2 * P.digest_pos - P.seed_size);
-                        for (int s = 0; s < P.max_seedseg_num && seedloc >= 0; s++, seedloc -= P.seed_size)
-                            r.ccgg_index[s][2 * chr + 1].push_back(tmp_offset - (uint32_t)seedloc);
-                    }
-            }
-            r.sites.push_back(std::move(sites));
+            for (int sg = 0; sg < P.max_seedseg_num; sg++) { r.ccgg_index[sg].push_back(std::move(o.ccgg_f[sg])); r.ccgg_index[sg].push_back(std::move(o.ccgg_r[sg])); }
+            r.sites.push_back(std::move(o.sites));
         }
     }
     std::sort(r.blocks.begin(), r.blocks.end(), [](const Block &a, const Block &b) { return a.id < b.id || (a.id == b.id && a.begin < b.begin); });

@@ -1,0 +1,161 @@
+// bsx_reads.h — FASTA/FASTQ batch reader of the command-line driver (header-only so that the test harness can drive it
+// without a GPU).  Reference: ReadClass::CheckFile / LoadBatchReads, reads.cpp:13-117.
+#pragma once
+#include <emmintrin.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <string>
+#include <vector>
+
+namespace bsx_reads {
+
+using std::cerr; using std::endl; using std::min; using std::string; using std::vector;
+
+struct ReadOpts { unsigned read_start = 1, read_end = ~0u; int max_readlen = 144; int zero_qual = 33; };
+
+// ---- reads (reads.cpp:13-117) -------------------------------------------------------------------------------------
+// The reference reads with operator>> / getline on an ifstream; the same token rules are applied here to a memory map
+// of the file (whitespace-separated tokens, rest of the header line dropped, header remainder limited to 999
+// characters), which parses gigabytes per second instead of the iostream rate.
+inline bool is_ws(char c) { return c == ' ' || c == '\n' || c == '\t' || c == '\r' || c == '\v' || c == '\f'; }
+
+struct Reader {
+    const char *base = nullptr, *cur = nullptr, *end = nullptr;
+    size_t map_len = 0;
+    int format = -1;  // 0 fastq, 1 fasta
+    unsigned index = 0;
+    bool failed = false;  // the stream's failbit: every later extraction yields nothing
+    bool eof_hit = false;
+
+    void skip_ws() { while (cur < end && is_ws(*cur)) cur++; }
+    // operator>>(string): false (and fail state) when no character could be extracted
+    bool token(const char *&t, size_t &n)
+    {
+        t = cur; n = 0;
+        if (failed) return false;
+        skip_ws();
+        if (cur >= end) { eof_hit = true; failed = true; return false; }
+        t = cur;
+        // tokens are long (a read, its qualities): look at 16 bytes at a time for anything <= ' ' (or >= 0x80),
+        // then let the exact whitespace test decide
+        for (;;) {
+            while (end - cur >= 16) {
+                const __m128i x = _mm_loadu_si128((const __m128i *)cur);
+                const int m = _mm_movemask_epi8(_mm_cmpgt_epi8(_mm_set1_epi8(0x21), x));
+                if (m) { cur += __builtin_ctz((unsigned)m); break; }
+                cur += 16;
+            }
+            while (cur < end && (unsigned char)*cur > 0x20 && (unsigned char)*cur < 0x80 && end - cur < 16) cur++;
+            if (cur >= end || is_ws(*cur)) break;
+            cur++;  // a control or non-ASCII byte inside the token
+        }
+        if (cur >= end) eof_hit = true;
+        n = (size_t)(cur - t);
+        return true;
+    }
+    // getline(buf, 1000): up to 999 characters, the newline is consumed; longer lines set the fail state
+    void rest_of_line()
+    {
+        if (failed) return;
+        const char *nl = (const char *)memchr(cur, '\n', (size_t)(end - cur));
+        const size_t n = nl ? (size_t)(nl - cur) : (size_t)(end - cur);
+        if (n > 999) { cur += 999; failed = true; return; }
+        if (!nl) { cur = end; eof_hit = true; if (n == 0) failed = true; return; }
+        cur = nl + 1;
+    }
+    void open(const string &path, const ReadOpts &o)
+    {
+        const int fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) { cerr << "failed to open read file (check -a option): " << path << endl; exit(1); }
+        struct stat st;
+        fstat(fd, &st);
+        map_len = (size_t)st.st_size;
+        if (map_len) {
+            void *m = mmap(nullptr, map_len, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m == MAP_FAILED) { cerr << "failed to map read file: " << path << endl; exit(1); }
+            madvise(m, map_len, MADV_SEQUENTIAL);
+            base = (const char *)m;
+        }
+        ::close(fd);
+        cur = base; end = base + map_len;
+        const char *t; size_t n1 = 0, n2 = 0, n4 = 0;
+        token(t, n1); const char first = n1 ? t[0] : 0; rest_of_line();
+        if (first == '>') format = 1;
+        else if (first == '@') {
+            token(t, n2); rest_of_line(); token(t, n1); rest_of_line(); token(t, n4); rest_of_line();
+            format = 0;
+            if (n2 != n4) { cerr << "fatal error: fq format, sequence length not equal to quality length\n"; exit(1); }
+        } else { cerr << "fatal error: unrecognizable format of reads file (SAM/BAM input is not supported by this build).\n"; exit(1); }
+        cur = base; failed = false; eof_hit = false;
+        const unsigned skip = (o.read_start - 1) * (format == 0 ? 4 : 2);
+        for (unsigned i = 0; i < skip; i++) {  // getline(ch, 1000) per skipped line
+            if (eof_hit) break;
+            rest_of_line();
+        }
+        index = o.read_start - 1;
+    }
+};
+
+// one batch of reads in flat arrays: what the upload takes (sequence bytes + offsets) and what the formatters need
+struct ReadSet {
+    vector<char> names, seq, qual;
+    vector<uint64_t> noff, soff, qoff;
+    vector<char> qual_upload;  // only when some quality string differs in length from its sequence
+    bool qual_same = true;
+    unsigned first_index = 0;
+    size_t n() const { return soff.size() - 1; }
+    void clear() { names.clear(); seq.clear(); qual.clear(); noff.assign(1, 0); soff.assign(1, 0); qoff.assign(1, 0); qual_same = true; }
+    const char *upload_qual()
+    {
+        if (qual_same) return qual.data();
+        qual_upload.assign(seq.size(), 'I');
+        for (size_t i = 0; i + 1 < soff.size(); i++) {
+            const size_t sl = soff[i + 1] - soff[i], ql = qoff[i + 1] - qoff[i];
+            memcpy(qual_upload.data() + soff[i], qual.data() + qoff[i], min(sl, ql));
+        }
+        return qual_upload.data();
+    }
+};
+
+// ReadClass::LoadBatchReads (reads.cpp:83-117) for one file; returns the number of reads loaded
+inline size_t load_reads(Reader &rd, ReadSet &out, size_t max_n, const ReadOpts &o)
+{
+    out.clear();
+    out.first_index = rd.index;
+    const size_t maxlen = (size_t)o.max_readlen;
+    while (out.n() < max_n && rd.index < o.read_end) {
+        const char *t; size_t n;
+        // fin >> c : the record marker ('@' or '>') is a single character, the name follows (possibly after blanks)
+        if (rd.failed) break;
+        rd.skip_ws();
+        if (rd.cur >= rd.end) break;
+        rd.cur++;
+        rd.token(t, n);
+        out.names.insert(out.names.end(), t, t + n); out.noff.push_back(out.names.size());
+        rd.rest_of_line();
+        rd.token(t, n);
+        const size_t sl = min(n, maxlen);
+        out.seq.insert(out.seq.end(), t, t + sl); out.soff.push_back(out.seq.size());
+        if (rd.format == 0) {
+            rd.token(t, n); rd.rest_of_line();  // '+' line
+            rd.token(t, n);
+            const size_t ql = min(n, maxlen);
+            out.qual.insert(out.qual.end(), t, t + ql); out.qoff.push_back(out.qual.size());
+            if (ql != sl) out.qual_same = false;
+        } else {
+            out.qual.insert(out.qual.end(), sl, (char)(o.zero_qual + 40)); out.qoff.push_back(out.qual.size());
+        }
+        rd.index++;
+    }
+    return out.n();
+}
+
+}  // namespace bsx_reads
