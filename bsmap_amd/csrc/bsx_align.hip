@@ -533,7 +533,7 @@ __device__ __forceinline__ CandList make_list(const DevParams &P, const BlockLds
 //   COUNT_ONLY: no replay; only the work counters are advanced, with the threshold frozen at thres_fixed (used to
 //   re-count the part of a pre-scanned task that precedes an event).
 // Returns 0 = range finished, 1 = range finished and the threshold was lowered on the way, 2 = SnpAlign returns.
-template <bool COUNT_ONLY>
+template <bool COUNT_ONLY, int BSX_SCAN_NB>
 __device__ int wave_scan_range(const DevParams &P, const BlockLds &BL, const MateLds &L, Mate &M, const Slab &SL, const CandList &cl, int orient,
                                int seg, int mode, uint32_t c_begin, uint32_t c_end, uint32_t thres_fixed, int lane, Counters &C)
 {
@@ -544,10 +544,20 @@ __device__ int wave_scan_range(const DevParams &P, const BlockLds &BL, const Mat
     for (int t = 0; t < 9; t++) { rw[t] = rfl(L.w[orient][t]); rm[t] = rfl(L.m[orient][t]); }
     const int cmode = M.len / P.seed_size - 1 - seg;  // cmodeindex (align.cpp:221)
     int status = 0;
-    for (uint32_t c0 = c_begin; c0 < c_end; c0 += 64) {
-        const uint32_t idx = c0 + lane;
+    // BSX_SCAN_NB chunks of 64 candidates per step: all their index entries are requested together, then all their
+    // first reference words, and only then are the chunks evaluated one after the other in list order (two memory
+    // round trips per step instead of two per chunk; the threshold each chunk sees is still the one left by its
+    // predecessors, and a chunk behind an early return is simply dropped).  The main kernel uses 1 (its lists are
+    // short and its register budget is tight), the control kernel of the heavy pipeline 4.
+    for (uint32_t cs = c_begin; cs < c_end; cs += 64 * BSX_SCAN_NB) {
+      uint32_t p_[BSX_SCAN_NB], aux_[BSX_SCAN_NB];  // aux: WGBS strand / RRBS chromosome id
+      bool valid_[BSX_SCAN_NB];
+      U4 r0_[BSX_SCAN_NB];
+#pragma unroll
+      for (int u = 0; u < BSX_SCAN_NB; u++) {
+        const uint32_t idx = cs + 64 * u + lane;
         bool valid = idx < c_end;
-        uint32_t p = 0, strand = 0, rchr = 0;
+        uint32_t p = 16, strand = 0, rchr = 0;
         if (P.rrbs) {
             if (valid) {
                 const U2 e = *reinterpret_cast<const U2 *>(P.entries + 2 * (size_t)(rl(cl.sub_base, 0) + idx));
@@ -556,7 +566,7 @@ __device__ int wave_scan_range(const DevParams &P, const BlockLds &BL, const Mat
                 rchr = e.a & 0xffff;
                 valid = tag_ok && e.b >= h;  // mode or strand not match / underflow the start of refseq
                 strand = rchr & 1;
-                p = (lds_chr ? BL.anchor[rchr >> 1] : P.anchor[rchr >> 1]) + (e.b - h);
+                if (valid) p = (lds_chr ? BL.anchor[rchr >> 1] : P.anchor[rchr >> 1]) + (e.b - h);
             }
         } else {
             uint32_t e_idx = 0, h = 0;
@@ -564,11 +574,23 @@ __device__ int wave_scan_range(const DevParams &P, const BlockLds &BL, const Mat
                 const uint32_t ps = rl(cl.sub_pre, s), ns = rl(cl.sub_n, s);
                 if (idx >= ps && idx < ps + ns) { e_idx = rl(cl.sub_base, s) + (idx - ps); h = rl(cl.sub_h, s); strand = s & 1; }
             }
-            if (valid) p = P.entries[e_idx] + h;
+            const uint32_t e = P.entries[e_idx];
+            if (valid) p = e + h;
         }
+        p_[u] = p; aux_[u] = P.rrbs ? rchr : strand; valid_[u] = valid;
+      }
+#pragma unroll
+      for (int u = 0; u < BSX_SCAN_NB; u++)
+        r0_[u] = *reinterpret_cast<const U4 *>(((P.rrbs ? (aux_[u] & 1) : aux_[u]) ? P.crefcat : P.refcat) + ((p_[u] - 1) >> 4));
+#pragma unroll
+      for (int u = 0; u < BSX_SCAN_NB; u++) {
+        const uint32_t c0 = cs + 64 * u;
+        if (c0 >= c_end) break;
+        const bool valid = valid_[u];
+        const uint32_t p = p_[u], rchr = aux_[u], strand = P.rrbs ? (aux_[u] & 1) : aux_[u];
         CandEval ev = {0xffff, 0, 0, 0};
         const uint32_t thres0 = COUNT_ONLY ? thres_fixed : M.snp_thres;
-        if (valid) ev = eval_candidate(P, rw, rm, nwords, p, strand, thres0);
+        if (valid) ev = eval_loaded((strand ? P.crefcat : P.refcat) + ((p - 1) >> 4), r0_[u], rw, rm, nwords, p, thres0);
         uint32_t thr_eff = thres0;
         bool alive = valid, stop = false;
         if (!COUNT_ONLY) {
@@ -603,6 +625,7 @@ __device__ int wave_scan_range(const DevParams &P, const BlockLds &BL, const Mat
             C.sum_w += (u64)__builtin_popcountll(__ballot(one)) + 2ull * __builtin_popcountll(__ballot(two)) + 5ull * __builtin_popcountll(__ballot(five));
         }
         if (stop) return 2;
+      }
     }
     return status;
 }
@@ -617,7 +640,7 @@ __device__ void snp_align(const DevParams &P, const BlockLds &BL, const MateLds 
         const int seg = L.order[orient][mode];  // modeindex
         const CandList cl = make_list(P, BL, L, M, orient, seg, lane);
         if (!P.rrbs && heavy_threshold && cl.total >= heavy_threshold) { M.defer = 1; return; }
-        if (wave_scan_range<false>(P, BL, L, M, SL, cl, orient, seg, mode, 0, cl.total, 0, lane, C) == 2) { wave_fence(); return; }
+        if (wave_scan_range<false, 1>(P, BL, L, M, SL, cl, orient, seg, mode, 0, cl.total, 0, lane, C) == 2) { wave_fence(); return; }
     }
     wave_fence();
 }
@@ -1086,7 +1109,7 @@ __device__ int snp_align_heavy(const AlignArgs &A, const HeavyArgs &H, HState *S
         const CandList cl = make_list(P, BL, L, M, orient, seg, lane);
         if (cl.total < min(A.heavy_threshold, (uint32_t)HS_TASK_MIN)) {  // short list: the owning wave scans it itself
             CAT_BEGIN(A);
-            const int r_ = wave_scan_range<false>(P, BL, L, M, SL, cl, orient, seg, mode, 0, cl.total, 0, lane, C);
+            const int r_ = wave_scan_range<false, 4>(P, BL, L, M, SL, cl, orient, seg, mode, 0, cl.total, 0, lane, C);
             CAT_END(A, 1);
             if (r_ == 2) { wave_fence(); return 1; }
             continue;
@@ -1123,7 +1146,7 @@ __device__ int snp_align_heavy(const AlignArgs &A, const HeavyArgs &H, HState *S
                         const HTaskOut *o = &H.tout[t0 + t];
                         if (rl(hov, (int)nxt)) {  // too many survivors for the record: redo this task with the one-wave path
                             CAT_BEGIN(A);
-                            const int r = wave_scan_range<false>(P, BL, L, M, SL, cl, orient, seg, mode, tc0, tc0 + tn, 0, lane, C);
+                            const int r = wave_scan_range<false, 4>(P, BL, L, M, SL, cl, orient, seg, mode, tc0, tc0 + tn, 0, lane, C);
                             CAT_END(A, 1);
                             if (r == 2) { wave_fence(); return 1; }
                             K.c = tc0 + tn;
@@ -1152,7 +1175,7 @@ __device__ int snp_align_heavy(const AlignArgs &A, const HeavyArgs &H, HState *S
                             C.sum_w += rl(hw, (int)nxt);
                             K.c = tc0 + tn;
                         } else {  // count exactly the candidates up to and including the one that caused the event
-                            { CAT_BEGIN(A); wave_scan_range<true>(P, BL, L, M, SL, cl, orient, seg, mode, tc0, X + 1, req_thres, lane, C); CAT_END(A, 5); }
+                            { CAT_BEGIN(A); wave_scan_range<true, 4>(P, BL, L, M, SL, cl, orient, seg, mode, tc0, X + 1, req_thres, lane, C); CAT_END(A, 5); }
                             K.c = X + 1;
                             if (event == 2) { wave_fence(); return 1; }
                             restart = true;

@@ -15,14 +15,8 @@ HG38 = [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345
         46709983, 50818468, 156040895, 57227415]
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--pairs", type=int, default=4 << 20)
-    ap.add_argument("--genome", type=float, default=1.0)
-    ap.add_argument("--dir", default="/dev/shm/bsx_e2e")
-    ap.add_argument("--threads", type=int, default=0)
-    ap.add_argument("--keep", action="store_true")
-    a = ap.parse_args()
+def run(a):
+    """a: namespace with pairs, genome, dir, threads, keep; returns the result dict"""
     os.makedirs(a.dir, exist_ok=True)
     lens = [max(200000, int(x * a.genome)) for x in HG38]
     kw = dict(s=16, v=6, I=4, m=28, x=500, S=1, r=1, pairend=1)
@@ -83,16 +77,26 @@ def main():
     res = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, BSX_TIMING="1"))
     wall = time.time() - t0
     if res.returncode != 0:
-        print(res.stdout[-2000:], res.stderr[-2000:]); sys.exit(1)
+        raise RuntimeError("bsmap failed: " + res.stdout[-2000:] + res.stderr[-2000:])
     tim = json.loads([l for l in res.stderr.split("\n") if l.startswith("{")][-1])
     sam_bytes = os.path.getsize(out)
     summary = [l for l in res.stdout.split("\n") if l.startswith(("pairs", "single"))]
     r = {"pairs": n, "genome_bp": int(sum(lens)), "fasta_bytes": os.path.getsize(fa), "fastq_bytes": sum(os.path.getsize(p) for p in fq), "sam_bytes": sam_bytes,
          "cli_wall_s": round(wall, 2), "timing": tim, "reads_per_s_mapping_phase": round(2 * n / tim["mapping_s"]), "reads_per_s_whole_process": round(2 * n / wall),
          "summary": summary, "prep_s": {"fasta": round(t_fa, 1), "fastq": round(t_fq, 1)}, "cpus": os.cpu_count()}
-    print(json.dumps(r))
     if not a.keep:
         shutil.rmtree(a.dir, ignore_errors=True)
+    return r
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--pairs", type=int, default=4 << 20)
+    ap.add_argument("--genome", type=float, default=1.0)
+    ap.add_argument("--dir", default="/dev/shm/bsx_e2e")
+    ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--keep", action="store_true")
+    print(json.dumps(run(ap.parse_args())))
 
 
 if __name__ == "__main__":
