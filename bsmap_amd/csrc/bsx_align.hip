@@ -489,6 +489,100 @@ __device__ __forceinline__ int accept_survivor(const DevParams &P, Mate &M, cons
     return 0;
 }
 
+// accept_survivor for up to 64 survivors of one list at once — lane l holds survivor l of `act`, in list order.  Used
+// where a read collects hundreds of hits (the heavy pipeline): the one-at-a-time form pays a dependent memory round
+// trip or two per survivor, this one a handful per 64.  It stops behind the first survivor that causes an event, exactly
+// where the sequential loop would: that survivor is committed, the ones behind it are untouched, and its lane is
+// returned in ev_lane (return value as accept_survivor: 0 none / 1 threshold lowered / 2 SnpAlign returns).
+#define BSX_GROUP_MIN 6  /* fewer survivors than this are cheaper one at a time */
+__device__ int accept_group(const DevParams &P, Mate &M, const Slab &SL, int orient, int mode, u64 act, uint32_t ws, uint32_t hchr, uint32_t hloc,
+                            uint32_t hkey, int lane, int &ev_lane)
+{
+    ev_lane = -1;
+    bool cand = ((act >> lane) & 1) && ws <= M.snp_thres;
+    // already in the hitset?  filter bits live in other lanes' registers: fetch the word, then the exact tests
+    {
+        const uint32_t slot = bloom_slot(hkey);
+        const int src = (int)((slot >> 5) & 63) * 4;
+        const uint32_t w0 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)M.bloom0), w1 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)M.bloom1);
+        const bool maybe = cand && ((((slot & 2048) ? w1 : w0) >> (slot & 31)) & 1);
+        if (__ballot(maybe)) {
+            bool found = false;
+            const uint32_t nk = min(M.nkeys, 64u);
+            for (uint32_t j = 0; j < nk; j++) found |= rl(M.key_reg, (int)j) == hkey;
+            bool probing = maybe && !found && M.nkeys > 64;
+            uint32_t h = hset_home(hkey);
+            while (__ballot(probing)) {
+                if (probing) {
+                    const uint32_t v = SL.hset[h];
+                    if (v == hkey + 1) { found = true; probing = false; }
+                    else if (v == 0) probing = false;
+                    else h = (h + 1) & (BSX_HSET_SLOTS - 1);
+                }
+            }
+            if (maybe && found) cand = false;
+        }
+    }
+    // the same coordinate twice inside the group: the first occurrence wins
+    for (u64 t = __ballot(cand); t; t &= t - 1) {
+        const int j = (int)__builtin_ctzll(t);
+        if (lane > j && rl(hkey, j) == hkey) cand = false;
+    }
+    if (!__ballot(cand)) return 0;
+    // position inside the class list and the first event
+    uint32_t rank = 0, mine = 0, other = 0;
+    const uint32_t cmax = min(M.snp_thres, (uint32_t)BSX_MAXSNPS);
+    for (uint32_t c = 0; c <= cmax; c++) {
+        const u64 mc = __ballot(cand && ws == c);
+        if (!mc) continue;
+        const uint32_t a = n_of(M, orient, (int)c), b = n_of(M, 1 - orient, (int)c);
+        if (cand && ws == c) { rank = (uint32_t)__builtin_popcountll(mc & (lanemask_lt(lane) | (1ull << lane))); mine = a; other = b; }
+    }
+    const uint32_t both = mine + other + rank;
+    const bool ev2 = cand && (((int)ws == mode && !P.pairend && P.report_repeat_hits == 0 && both > 1) || (both >= (uint32_t)P.max_num_hits && ws == 0));
+    const bool ev1 = cand && !ev2 && both >= (uint32_t)P.max_num_hits;
+    const u64 em2 = __ballot(ev2), em = em2 | __ballot(ev1);
+    const int E = em ? (int)__builtin_ctzll(em) : 64;
+    const bool commit = cand && lane <= E;
+    const u64 km = __ballot(commit);
+    if (commit) SL.list(orient, (int)ws)[mine + rank - 1] = ((u64)hchr << 32) | hloc;  // hits[w][n++] = hit
+    for (uint32_t c = 0; c <= cmax; c++) {
+        const u64 mc = __ballot(commit && ws == c);
+        if (mc && lane == orient * 16 + (int)c) M.cnt_reg += (uint32_t)__builtin_popcountll(mc);
+    }
+    // hitset.insert: registers for the first 64 coordinates, the slab's hash set beyond, filter bits for all
+    const uint32_t kidx = M.nkeys + (uint32_t)__builtin_popcountll(km & lanemask_lt(lane));
+    {
+        uint32_t k = M.nkeys;
+        for (u64 t = km; t; t &= t - 1, k++) {
+            const int j = (int)__builtin_ctzll(t);
+            const uint32_t kv = rl(hkey, j), slot = bloom_slot(kv);
+            if (k < 64 && (uint32_t)lane == k) M.key_reg = kv;
+            if ((uint32_t)lane == ((slot >> 5) & 63)) { if (slot & 2048) M.bloom1 |= 1u << (slot & 31); else M.bloom0 |= 1u << (slot & 31); }
+        }
+    }
+    {
+        bool pending = commit && kidx >= 64;
+        uint32_t h = hset_home(hkey);
+        while (__ballot(pending)) {  // claim by write-then-verify: lanes racing for one empty slot see who landed
+            if (pending && SL.hset[h] == 0) SL.hset[h] = hkey + 1;
+            wave_fence();
+            if (pending) {
+                if (SL.hset[h] == hkey + 1) { pending = false; SL.keys[kidx] = hkey; SL.kslot[kidx] = h; }
+                else h = (h + 1) & (BSX_HSET_SLOTS - 1);
+            }
+            wave_fence();
+        }
+    }
+    M.nkeys += (uint32_t)__builtin_popcountll(km);
+    wave_fence();
+    if (!em) return 0;
+    ev_lane = E;
+    if ((em2 >> E) & 1) return 2;
+    M.snp_thres = rl(ws, E) - 1;
+    return 1;
+}
+
 // The candidate list of one SnpAlign call for one read orientation.  WGBS: the (phase x strand) sub-ranges of the
 // index, sub-range s = 2*phase+strand described by lane s (align.cpp:258-299); RRBS: one bucket of {tag,loc} pairs
 // (align.cpp:175-252).  Candidates are numbered 0..total-1 in the order the reference visits them.
@@ -608,6 +702,16 @@ __device__ int wave_scan_range(const DevParams &P, const BlockLds &BL, const Mat
                 } else pass = hit_coords(P, BL, p, strand, M.len, hchr, hloc, hkey);
             }
             u64 surv_m = __ballot(pass);  // ordered replay of the survivors
+            if (BSX_SCAN_NB > 1 && !P.rrbs && __builtin_popcountll(surv_m) > BSX_GROUP_MIN) {  // heavy pipeline: 64 at a time, resuming behind every threshold change
+                while (surv_m) {
+                    int ls;
+                    const int e = accept_group(P, M, SL, orient, mode, surv_m, w, hchr, hloc, hkey, lane, ls);
+                    if (e == 0) break;
+                    if (e == 1) { status = 1; if (lane > ls) thr_eff = M.snp_thres; surv_m &= ~(lanemask_lt(ls) | (1ull << ls)); }
+                    else { if (lane > ls) alive = false; stop = true; break; }
+                }
+                surv_m = 0;
+            }
             while (surv_m) {
                 const int ls = (int)__builtin_ctzll(surv_m);
                 surv_m &= surv_m - 1;
@@ -1161,6 +1265,12 @@ __device__ int snp_align_heavy(const AlignArgs &A, const HeavyArgs &H, HState *S
                             SurvRec r = {0, 0, 0, 0};
                             if (i < nv) r = o->surv[i];
                             u64 m = __ballot(i < nv);
+                            if (__builtin_popcountll(m) > BSX_GROUP_MIN) {
+                                int ls;
+                                const int e = accept_group(P, M, SL, orient, mode, m, r.w_ord & 0xff, r.hchr, r.hloc, r.hkey, lane, ls);
+                                if (e) { event = e; X = tc0 + (rl(r.w_ord, ls) >> 8); }
+                                m = 0;
+                            }
                             while (m) {
                                 const int ls = (int)__builtin_ctzll(m);
                                 m &= m - 1;
