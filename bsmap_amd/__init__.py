@@ -295,7 +295,7 @@ class _Batch:
     def set_debug(self, mode): _check(lib().bsx_batch_set_debug(self.h, mode))
 
     def ctrl_clocks(self):
-        c = np.zeros(8, np.uint64)
+        c = np.zeros(24, np.uint64)
         _check(lib().bsx_batch_ctrl_clocks(self.h, c.ctypes.data))
         return c
 

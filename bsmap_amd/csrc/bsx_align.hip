@@ -815,7 +815,8 @@ __device__ void select_hit(const DevParams &P, const Mate &M, const Slab &SL, bs
 // paired-end pieces
 // ---------------------------------------------------------------------------------------------------------------
 // sort(hits, hits+n, HitComp) (align.cpp:363-368): keys (chr<<32|loc) are unique inside a list, so ranks are positions
-__device__ void sort_list(u64 *list, uint32_t n, u64 *tmp, int lane)
+#define BSX_LDS_SORT 1024  /* elements of the per-wave LDS sort buffer of the heavy control kernel */
+__device__ void sort_list(u64 *list, uint32_t n, u64 *tmp, int lane, u64 *lds = nullptr)
 {
     if (n <= 1) return;
     if (n <= 64) {
@@ -823,6 +824,22 @@ __device__ void sort_list(u64 *list, uint32_t n, u64 *tmp, int lane)
         uint32_t rank = 0;
         for (uint32_t j = 0; j < n; j++) rank += rl64(v, (int)j) < v;
         if ((uint32_t)lane < n) list[rank] = v;
+    } else if (lds && n <= BSX_LDS_SORT) {
+        // heavy units sort lists of up to -w hits at every level: bitonic network in LDS, one wave, keys are unique
+        uint32_t N = 128;
+        while (N < n) N <<= 1;
+        for (uint32_t i = lane; i < N; i += 64) lds[i] = i < n ? list[i] : ~0ull;
+        wave_fence();
+        for (uint32_t k = 2; k <= N; k <<= 1)
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                for (uint32_t t = lane; t < N / 2; t += 64) {
+                    const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
+                    const u64 a = lds[i], b = lds[l];
+                    if ((a > b) == ((i & k) == 0)) { lds[i] = b; lds[l] = a; }
+                }
+                wave_fence();
+            }
+        for (uint32_t i = lane; i < n; i += 64) list[i] = lds[i];
     } else {
         for (uint32_t base = 0; base < n; base += 64) {
             const uint32_t i = base + lane;
@@ -867,18 +884,27 @@ __device__ int get_pairs(const DevParams &P, const Mate &MA, const Mate &MB, con
         const u64 *al = SA.list(pass, na), *bl = SB.list(1 - pass, nb);
         const uint32_t n_a = n_of(MA, pass, na), n_b = n_of(MB, 1 - pass, nb);
         uint32_t chra = 0xffffffffu, bstart = 0, bend = 0;
-        for (uint32_t i = 0; i < n_a && result < 0; i++) {
-            const u64 ha = al[i];
+        u64 hb_cache = 0;     // the b hits of the current chromosome, when there are at most 64 of them
+        bool cached = false;
+        for (uint32_t a_base = 0; a_base < n_a && result < 0; a_base += 64) {
+          // 64 a hits per load; the loops below then run out of registers (the lists live in HBM: a load per a hit and
+          // per 64 b hits made this join the longest span of the heavy control passes)
+          const u64 hav = a_base + lane < n_a ? al[a_base + lane] : 0;
+          const uint32_t na_chunk = min(64u, n_a - a_base);
+          for (uint32_t ii = 0; ii < na_chunk && result < 0; ii++) {
+            const u64 ha = rl64(hav, (int)ii);
             const uint32_t achr = (uint32_t)(ha >> 32), aloc = (uint32_t)ha;
             if (chra != achr) {
                 chra = achr;
                 bstart = first_chr_ge(bl, bend, n_b, chra, false, lane);
                 bend = first_chr_ge(bl, bstart, n_b, chra, true, lane);
+                cached = bend - bstart <= 64;
+                if (cached) hb_cache = bstart + lane < bend ? bl[bstart + lane] : 0;
             }
             for (uint32_t jb = bstart; jb < bend && result < 0; jb += 64) {
                 const uint32_t j = jb + lane;
                 const bool valid = j < bend;
-                const u64 hb = valid ? bl[j] : 0;
+                const u64 hb = cached ? hb_cache : (valid ? bl[j] : 0);
                 const uint32_t bloc = (uint32_t)hb;
                 uint32_t seg_start, seg_end;
                 const bool odd = (chra & 1) != 0;
@@ -899,6 +925,7 @@ __device__ int get_pairs(const DevParams &P, const Mate &MA, const Mate &MB, con
                     if (cnt >= (uint32_t)P.max_num_hits) { result = 1; break; }
                 }
             }
+          }
         }
     }
     if (lane == cls) pcnt_reg = cnt;
@@ -955,10 +982,10 @@ __device__ void unit_prepare(const AlignArgs &A, const BlockLds &BL, MateLds &LA
 }
 
 // one level of PairAlign::RunAlign after both SnpAlign calls (pairs.cpp:167-171): sort class `level`, join
-__device__ int pair_level_post(const DevParams &P, const Mate &MA, const Mate &MB, const UnitSlabs &U, uint32_t &pcnt_reg, int i, int lane)
+__device__ int pair_level_post(const DevParams &P, const Mate &MA, const Mate &MB, const UnitSlabs &U, uint32_t &pcnt_reg, int i, int lane, u64 *lds_sort = nullptr)
 {
-    if (i <= MA.max_snp) { sort_list(U.SA.list(0, i), n_of(MA, 0, i), U.SA.tmp, lane); sort_list(U.SA.list(1, i), n_of(MA, 1, i), U.SA.tmp, lane); }
-    if (i <= MB.max_snp) { sort_list(U.SB.list(0, i), n_of(MB, 0, i), U.SB.tmp, lane); sort_list(U.SB.list(1, i), n_of(MB, 1, i), U.SB.tmp, lane); }
+    if (i <= MA.max_snp) { sort_list(U.SA.list(0, i), n_of(MA, 0, i), U.SA.tmp, lane, lds_sort); sort_list(U.SA.list(1, i), n_of(MA, 1, i), U.SA.tmp, lane, lds_sort); }
+    if (i <= MB.max_snp) { sort_list(U.SB.list(0, i), n_of(MB, 0, i), U.SB.tmp, lane, lds_sort); sort_list(U.SB.list(1, i), n_of(MB, 1, i), U.SB.tmp, lane, lds_sort); }
     int n = get_pairs(P, MA, MB, U.SA, U.SB, U.PS, pcnt_reg, i, i, lane);
     for (int j = 0; j < i; j++) n += get_pairs(P, MA, MB, U.SA, U.SB, U.PS, pcnt_reg, i, j, lane) + get_pairs(P, MA, MB, U.SA, U.SB, U.PS, pcnt_reg, j, i, lane);
     return n;
@@ -1144,7 +1171,8 @@ struct HMate {
     uint8_t start[2][16], order[2][16];
 };
 struct HState {
-    int32_t stage, level, sub, orient;
+    uint32_t want;  // tasks of a request the pool refused (0: none): the unit is only restored once that many are free
+    int32_t level, sub, orient;
     uint32_t c, W;
     int32_t paired, have;
     uint32_t t0, n_tasks, win_c0, win_n;  // the published window: tasks t0.. cover candidates [win_c0, win_c0+win_n)
@@ -1156,8 +1184,7 @@ struct HState {
 struct HTask { uint32_t h, c0, n, pad; };
 struct HTaskOut { uint32_t count, overflow, acc[4], pad[2]; SurvRec surv[HS_SCAP]; };
 struct HeavyArgs {
-    HState *state; uint8_t *slabs; uint32_t *active_in, *active_out, *n_active_out; HTask *tasks; HTaskOut *tout; uint32_t *n_tasks, *queue, *task_keys;
-    const uint32_t *task_order;
+    HState *state; uint8_t *slabs; uint32_t *active_in, *active_out, *n_active_out; HTask *tasks; HTaskOut *tout; uint32_t *n_tasks, *queue;
     const uint32_t *n_active_in_ptr;
     uint32_t n_active_in, task_cap, fresh, list_base, hidx_base;
 };
@@ -1165,7 +1192,7 @@ __host__ HeavyArgs typed(const HeavyArgsRaw &r)
 {
     HeavyArgs h;
     h.state = (HState *)r.state; h.slabs = r.slabs; h.active_in = r.active_in; h.active_out = r.active_out; h.n_active_out = r.n_active_out;
-    h.tasks = (HTask *)r.tasks; h.tout = (HTaskOut *)r.tout; h.n_tasks = r.n_tasks; h.queue = r.queue; h.task_keys = r.task_keys; h.task_order = r.task_order;
+    h.tasks = (HTask *)r.tasks; h.tout = (HTaskOut *)r.tout; h.n_tasks = r.n_tasks; h.queue = r.queue;
     h.n_active_in_ptr = r.n_active_in_ptr; h.n_active_in = r.n_active_in; h.task_cap = r.task_cap; h.fresh = r.fresh; h.list_base = r.list_base; h.hidx_base = r.hidx_base;
     return h;
 }
@@ -1193,12 +1220,12 @@ __device__ void load_mate(const HMate &d, Mate &M, MateLds &L, int lane)
     wave_fence();
 }
 
-struct HCursor { int level, sub, orient, have, paired; uint32_t c, W, n_active; };
+struct HCursor { int level, sub, orient, have, paired; uint32_t c, W, n_active, want; u64 vc[6]; uint32_t vn[6]; };  // vc/vn: per-visit category clocks and counts (diagnostics)
 
 // diagnostic category clocks of k_hctrl (only when the caller asked for unit cycles): 0 prepare/restore, 1 inline scans,
 // 2 survivor replay, 3 sort+pairs, 4 save/finish, 5 recount after events
 #define CAT_BEGIN(A) const u64 cat_t0_ = (A).dbg_cat ? __builtin_readcyclecounter() : 0
-#define CAT_END(A, k) do { if ((A).dbg_cat && lane == 0) atomicAdd((u64 *)&(A).dbg_cat[k], (u64)__builtin_readcyclecounter() - cat_t0_); } while (0)
+#define CAT_END(A, k) do { if ((A).dbg_cat) { const u64 d_ = (u64)__builtin_readcyclecounter() - cat_t0_; K.vc[k] += d_; K.vn[k]++; if (lane == 0) { atomicAdd((u64 *)&(A).dbg_cat[k], d_); atomicMax((u64 *)&(A).dbg_cat[8 + (k)], d_); } } } while (0)
 
 // resumable SnpAlign for a deferred unit: 0 = call complete, 1 = the reference's SnpAlign returned early, 2 = a window
 // of the current list was published and the unit must wait for k_hscan
@@ -1237,7 +1264,61 @@ __device__ int snp_align_heavy(const AlignArgs &A, const HeavyArgs &H, HState *S
                     uint32_t done_upto = 0;  // tasks [tg, tg+done_upto) of this group are fully accounted
                     const uint32_t gn = min(64u, nt - tg);
                     while (!restart) {
-                        const uint32_t nxt = special ? (uint32_t)__builtin_ctzll(special) : gn;  // next task needing a replay
+                        {
+                            // consecutive tasks from done_upto whose survivor records fit one 64-lane group (none overflowed)
+                            // are replayed together: one round of record loads and hitset probes instead of one per task
+                            const bool inr = (uint32_t)lane >= done_upto && (uint32_t)lane < gn;
+                            const u64 ovm = __ballot(inr && hov != 0);
+                            const uint32_t first_ov = ovm ? (uint32_t)__builtin_ctzll(ovm) : gn;
+                            uint32_t ps = inr ? hc : 0;  // inclusive prefix sum of the survivor counts
+                            for (int o_ = 1; o_ < 64; o_ <<= 1) { const uint32_t v_ = __shfl_up(ps, o_); if (lane >= o_) ps += v_; }
+                            const u64 fit = __ballot(inr && (uint32_t)lane < first_ov && ps <= 64);
+                            const uint32_t bend = done_upto + (uint32_t)__builtin_popcountll(fit);
+                            if (bend > done_upto) {
+                                const uint32_t total = rl(ps, (int)bend - 1);
+                                int e = 0, ls = -1;
+                                uint32_t my_t = 0;
+                                SurvRec r = {0, 0, 0, 0};
+                                if (total) {
+                                    CAT_BEGIN(A);
+                                    uint32_t my_i = 0;
+                                    for (u64 sm = __ballot(inr && (uint32_t)lane < bend && hc != 0); sm; sm &= sm - 1) {
+                                        const int t_ = (int)__builtin_ctzll(sm);
+                                        const uint32_t end_ = rl(ps, t_), beg_ = end_ - rl(hc, t_);
+                                        if ((uint32_t)lane >= beg_ && (uint32_t)lane < end_) { my_t = (uint32_t)t_; my_i = (uint32_t)lane - beg_; }
+                                    }
+                                    if ((uint32_t)lane < total) r = H.tout[t0 + tg + my_t].surv[my_i];
+                                    u64 m = total >= 64 ? ~0ull : ((1ull << total) - 1);
+                                    if (total > BSX_GROUP_MIN) e = accept_group(P, M, SL, orient, mode, m, r.w_ord & 0xff, r.hchr, r.hloc, r.hkey, lane, ls);
+                                    else
+                                        while (m) {
+                                            const int l1 = (int)__builtin_ctzll(m);
+                                            m &= m - 1;
+                                            e = accept_survivor(P, M, SL, orient, mode, rl(r.w_ord, l1) & 0xff, rl(r.hchr, l1), rl(r.hloc, l1), rl(r.hkey, l1), lane);
+                                            if (e) { ls = l1; break; }
+                                        }
+                                    CAT_END(A, 2);
+                                }
+                                const uint32_t upto = e ? rl(my_t, ls) : bend;  // tasks [done_upto, upto) are complete
+                                const bool mine_b = (uint32_t)lane >= done_upto && (uint32_t)lane < upto;
+                                C.n_cand += wave_sum(mine_b ? h0 : 0);
+                                C.sum_w += wave_sum(mine_b ? hw : 0);
+                                if (!e) {
+                                    done_upto = bend;
+                                    special &= bend >= 64 ? 0ull : ~((1ull << bend) - 1);
+                                    if (bend >= gn) { K.c = win_c0 + min(win_n, (tg + gn) * HS_TASK); break; }
+                                    continue;
+                                }
+                                // count exactly the candidates of the event's task up to and including the one that caused it
+                                const uint32_t tc0e = win_c0 + (tg + upto) * HS_TASK, Xe = tc0e + (rl(r.w_ord, ls) >> 8);
+                                { CAT_BEGIN(A); wave_scan_range<true, 4>(P, BL, L, M, SL, cl, orient, seg, mode, tc0e, Xe + 1, req_thres, lane, C); CAT_END(A, 5); }
+                                K.c = Xe + 1;
+                                if (e == 2) { wave_fence(); return 1; }
+                                restart = true;
+                                continue;
+                            }
+                        }
+                        const uint32_t nxt = special ? (uint32_t)__builtin_ctzll(special) : gn;  // next task needing a replay (overflowed, or more than 64 survivors)
                         // plain tasks in [done_upto, nxt)
                         const bool mine = (uint32_t)lane >= done_upto && (uint32_t)lane < nxt;
                         C.n_cand += wave_sum(mine ? h0 : 0);
@@ -1304,12 +1385,6 @@ __device__ int snp_align_heavy(const AlignArgs &A, const HeavyArgs &H, HState *S
                     for (uint32_t t = lane; t < nt; t += 64) {
                         HTask tk; tk.h = hidx; tk.c0 = K.c + t * HS_TASK; tk.n = min((uint32_t)HS_TASK, wn - t * HS_TASK); tk.pad = 0;
                         H.tasks[t0 + t] = tk;
-                        uint32_t key = 0;  // index-entry address of the task's first candidate
-                        for (int sx = 0; sx < cl.nsub; sx++) {
-                            const uint32_t ps = rl(cl.sub_pre, sx), ns = rl(cl.sub_n, sx);
-                            if (tk.c0 >= ps && tk.c0 < ps + ns) key = rl(cl.sub_base, sx) + (tk.c0 - ps);
-                        }
-                        H.task_keys[t0 + t] = key;
                     }
                     ListReq &R = S->req;
                     if (lane < 32) { R.sub_pre[lane] = cl.sub_pre; R.sub_n[lane] = cl.sub_n; R.sub_base[lane] = cl.sub_base; R.sub_h[lane] = cl.sub_h; }
@@ -1319,9 +1394,11 @@ __device__ int snp_align_heavy(const AlignArgs &A, const HeavyArgs &H, HState *S
                         S->t0 = t0; S->n_tasks = nt; S->win_c0 = K.c; S->win_n = wn;
                     }
                     K.have = 1;
-                } else if (t0 < H.task_cap) {  // pool exhausted mid-way: neutralise the slots that were reserved
-                    for (uint32_t t = t0 + lane; t < H.task_cap; t += 64) { HTask tk; tk.h = hidx; tk.c0 = 0; tk.n = 0; tk.pad = 0; H.tasks[t] = tk; }
-                }  // the request is repeated in the next iteration
+                } else {
+                    K.want = nt;  // the request is repeated in a later iteration, once the pool can take it
+                    if (t0 < H.task_cap)  // pool exhausted mid-way: neutralise the slots that were reserved
+                        for (uint32_t t = t0 + lane; t < H.task_cap; t += 64) { HTask tk; tk.h = hidx; tk.c0 = 0; tk.n = 0; tk.pad = 0; H.tasks[t] = tk; }
+                }
                 wave_fence();
                 return 2;
             }
@@ -1334,7 +1411,7 @@ __device__ int snp_align_heavy(const AlignArgs &A, const HeavyArgs &H, HState *S
 // advance a deferred unit as far as possible; true when it is finished
 template <bool PE>
 __device__ bool heavy_advance(const AlignArgs &A, const HeavyArgs &H, HState *S, uint32_t hidx, const BlockLds &BL, MateLds &LA, MateLds &LB, Mate &MA,
-                              Mate &MB, const UnitSlabs &U, uint32_t &pcnt_reg, HCursor &K, int lane, Counters &C)
+                              Mate &MB, const UnitSlabs &U, uint32_t &pcnt_reg, HCursor &K, int lane, Counters &C, u64 *lds_sort)
 {
     const DevParams &P = A.P;
     if (PE && !MA.filtered && !MB.filtered) {
@@ -1350,7 +1427,7 @@ __device__ bool heavy_advance(const AlignArgs &A, const HeavyArgs &H, HState *S,
                 K.sub = 2;
             }
             CAT_BEGIN(A);
-            const int np_ = pair_level_post(P, MA, MB, U, pcnt_reg, K.level, lane);
+            const int np_ = pair_level_post(P, MA, MB, U, pcnt_reg, K.level, lane, lds_sort);
             CAT_END(A, 3);
             if (np_ > 0) { K.paired = K.level + 1; return true; }
             K.level++; K.sub = 0; K.orient = 0; K.c = 0; K.W = HS_WIN0; K.have = 0;
@@ -1375,6 +1452,7 @@ __global__ __launch_bounds__(256) void k_hctrl(AlignArgs A, HeavyArgs H)
 {
     __shared__ BlockLds BL;
     __shared__ WaveLds<PE> WL[4];
+    __shared__ u64 SORTBUF[4][BSX_LDS_SORT];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     init_block_lds(A.P, BL, threadIdx.x, 256);
     __syncthreads();
@@ -1391,12 +1469,22 @@ __global__ __launch_bounds__(256) void k_hctrl(AlignArgs A, HeavyArgs H)
         const uint32_t hidx = H.fresh ? H.hidx_base + i : rfl(H.active_in[i]);
         const uint32_t unit = rfl(A.heavy_list[H.list_base + hidx]);
         HState *S = &H.state[hidx];
+        if (!H.fresh) {
+            // a unit whose last request was refused stays parked (no state restore / save) while the pool cannot take it:
+            // n_tasks only grows during a pass, so the reservation below would be refused again
+            const uint32_t want = rfl(S->want);
+            if (want && rfl(__hip_atomic_load(H.n_tasks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) + want > H.task_cap) {
+                if (lane == 0) H.active_out[atomicAdd(H.n_active_out, 1u)] = hidx;
+                continue;
+            }
+        }
         uint8_t *slab = A.debug ? A.scratch + (size_t)unit * A.slab_bytes : H.slabs + (size_t)hidx * A.slab_bytes;
         const UnitSlabs U = carve_slab(slab, (uint32_t)A.P.max_snp_num + 1, A.rowcap, PE);
         Mate MA, MB;
         Counters C = {0, 0, 0, 0};
         HCursor K;
-        K.n_active = n_active_in;
+        K.n_active = n_active_in; K.want = 0;
+        for (int k_ = 0; k_ < 6; k_++) { K.vc[k_] = 0; K.vn[k_] = 0; }
         uint32_t pcnt_reg = 0;
         const u64 cat_prep0 = A.dbg_cat ? __builtin_readcyclecounter() : 0;
         if (H.fresh) {
@@ -1412,10 +1500,15 @@ __global__ __launch_bounds__(256) void k_hctrl(AlignArgs A, HeavyArgs H)
             K.level = (int)rfl((uint32_t)S->level); K.sub = (int)rfl((uint32_t)S->sub); K.orient = (int)rfl((uint32_t)S->orient);
             K.have = (int)rfl((uint32_t)S->have); K.paired = (int)rfl((uint32_t)S->paired); K.c = rfl(S->c); K.W = rfl(S->W);
         }
-        if (A.dbg_cat && lane == 0) atomicAdd((u64 *)&A.dbg_cat[0], (u64)__builtin_readcyclecounter() - cat_prep0);
+        if (A.dbg_cat && lane == 0) { const u64 d_ = (u64)__builtin_readcyclecounter() - cat_prep0; atomicAdd((u64 *)&A.dbg_cat[0], d_); atomicMax((u64 *)&A.dbg_cat[8], d_); }
         const u64 cat_adv0 = A.dbg_cat ? __builtin_readcyclecounter() : 0;
-        const bool done = heavy_advance<PE>(A, H, S, hidx, BL, LA, LB, MA, MB, U, pcnt_reg, K, lane, C);
-        if (A.dbg_cat && lane == 0) atomicAdd((u64 *)&A.dbg_cat[6], (u64)__builtin_readcyclecounter() - cat_adv0);
+        const bool done = heavy_advance<PE>(A, H, S, hidx, BL, LA, LB, MA, MB, U, pcnt_reg, K, lane, C, SORTBUF[threadIdx.x >> 6]);
+        if (A.dbg_cat && lane == 0) {
+            const u64 d_ = (u64)__builtin_readcyclecounter() - cat_adv0;
+            atomicAdd((u64 *)&A.dbg_cat[6], d_);
+            if (atomicMax((u64 *)&A.dbg_cat[14], d_) < d_)  // the longest visit so far: leave its break-down (racy, diagnostics only)
+                for (int k_ = 0; k_ < 6; k_++) A.dbg_cat[16 + k_] = (K.vc[k_] << 16) | min(K.vn[k_], 0xffffu);
+        }
         const u64 cat_fin0 = A.dbg_cat ? __builtin_readcyclecounter() : 0;
         if (done) {
             unit_finish<PE>(A, LA, LB, MA, MB, U, pcnt_reg, K.paired, unit, lane, n_aligned, n_aligned_pairs);
@@ -1426,11 +1519,11 @@ __global__ __launch_bounds__(256) void k_hctrl(AlignArgs A, HeavyArgs H)
             if (PE) save_mate(S->mate[1], MB, LB, lane);
             S->pcnt_reg[lane] = pcnt_reg;
             if (lane == 0) {
-                S->C = C; S->level = K.level; S->sub = K.sub; S->orient = K.orient; S->have = K.have; S->paired = K.paired; S->c = K.c; S->W = K.W;
+                S->want = K.want; S->C = C; S->level = K.level; S->sub = K.sub; S->orient = K.orient; S->have = K.have; S->paired = K.paired; S->c = K.c; S->W = K.W;
                 H.active_out[atomicAdd(H.n_active_out, 1u)] = hidx;
             }
         }
-        if (A.dbg_cat && lane == 0) atomicAdd((u64 *)&A.dbg_cat[4], (u64)__builtin_readcyclecounter() - cat_fin0);
+        if (A.dbg_cat && lane == 0) { const u64 d_ = (u64)__builtin_readcyclecounter() - cat_fin0; atomicAdd((u64 *)&A.dbg_cat[4], d_); atomicMax((u64 *)&A.dbg_cat[12], d_); }
         wave_fence();
     }
     if (lane == 0) flush_counters(A, Cflush, n_units_done, n_aligned, n_aligned_pairs);
@@ -1445,14 +1538,13 @@ __global__ __launch_bounds__(256, 8) void k_hscan(AlignArgs A, HeavyArgs H)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     init_block_lds(P, BL, threadIdx.x, 256);
     __syncthreads();
+    // one task per wave, no queue: the blocks of a pass retire one by one, so the control kernel of the other unit
+    // group (high-priority stream) finds free slots while this kernel is still running
     const uint32_t n_tasks = min(*H.n_tasks, H.task_cap);
     u64 scanned = 0;
-    for (;;) {
-        uint32_t t = 0;
-        if (lane == 0) t = atomicAdd(H.queue + 1, 1u);
-        t = rfl(t);
+    for (bool once = true; once; once = false) {
+        const uint32_t t = blockIdx.x * 4 + (uint32_t)wv;
         if (t >= n_tasks) break;
-        if (H.task_order) t = rfl(H.task_order[t]);
         const uint32_t hidx = rfl(H.tasks[t].h), tc0 = rfl(H.tasks[t].c0), tn = rfl(H.tasks[t].n);
         if (tn == 0) {  // slot neutralised by a refused request: its unit has not published a list (ListReq may be stale)
             if (lane == 0) { HTaskOut *oe = &H.tout[t]; oe->count = 0; oe->overflow = 0; oe->acc[0] = oe->acc[1] = oe->acc[2] = oe->acc[3] = 0; }

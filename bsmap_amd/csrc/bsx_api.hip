@@ -15,8 +15,8 @@
 #include "bsx_kernel_args.h"
 
 static int g_waves_per_cu = 0;
+static int g_heavy_groups = 2;      // unit groups of the heavy pipeline that run out of phase (1 = strictly alternating passes)
 static int g_heavy_threshold = 8192;  // candidate-list length that sends a unit to the cooperative heavy kernel
-static int g_sort_tasks = 0;  // ordering scan tasks by index address was measured neutral (k_hscan is not HBM-bound); kept as a knob
 
 extern "C" int bsx_set_waves_per_cu(int w) { g_waves_per_cu = w; return BSX_OK; }
 extern "C" int bsx_set_heavy_threshold(int t) { g_heavy_threshold = t < 0 ? 0 : t; return BSX_OK; }
@@ -201,7 +201,8 @@ struct bsx_batch {
     bsx_ref *ref = nullptr;
     int paired = 0, debug = 0, has_qual = 0;
     uint32_t max_units = 0, n_units = 0, first_index = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, stream_hi = nullptr;  // stream_hi: control passes of the heavy pipeline
+    hipEvent_t ev_ctrl[2] = {nullptr, nullptr}, ev_scan[2] = {nullptr, nullptr}, ev_sync = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     uint8_t *d_seq[2] = {nullptr, nullptr}, *d_qual[2] = {nullptr, nullptr};
     uint64_t *d_off[2] = {nullptr, nullptr};
@@ -216,9 +217,6 @@ struct bsx_batch {
     // heavy pipeline pools
     uint8_t *d_hstate = nullptr, *d_hslabs = nullptr, *d_htasks = nullptr, *d_htout = nullptr;
     uint32_t *d_hactive[4] = {nullptr, nullptr, nullptr, nullptr}, *d_hcnt = nullptr;  // d_hcnt: per group two ping-pong blocks {n_active, n_tasks, queue[2]}
-    uint32_t *d_tkeys = nullptr, *d_tkeys_sorted = nullptr, *d_tiota = nullptr, *d_torder = nullptr;
-    void *d_sort_temp = nullptr;
-    size_t sort_temp_bytes = 0;
     uint32_t hcap = 0, task_cap = 0;
     uint32_t *h_pinned = nullptr;  // pinned host words for the per-pass count read-backs
     int n_cu = 0;
@@ -276,12 +274,6 @@ static int ensure_scratch(bsx_batch *b)
         }
         for (int k = 0; k < 4; k++) HIP_TRY(hipMalloc((void **)&b->d_hactive[k], (size_t)b->hcap * 4));
         HIP_TRY(hipMalloc((void **)&b->d_hcnt, 256));
-        for (uint32_t **q : {&b->d_tkeys, &b->d_tkeys_sorted, &b->d_tiota, &b->d_torder}) HIP_TRY(hipMalloc((void **)q, (size_t)b->task_cap * 4));
-        {
-            std::vector<uint32_t> iota(b->task_cap);
-            for (uint32_t i = 0; i < b->task_cap; i++) iota[i] = i;
-            HIP_TRY(hipMemcpy(b->d_tiota, iota.data(), iota.size() * 4, hipMemcpyHostToDevice));
-        }
     }
     const uint64_t slots = b->debug ? b->max_units : (uint64_t)grid * 4;
     const size_t bytes = (size_t)(slots * b->slab_bytes);
@@ -306,7 +298,15 @@ extern "C" int bsx_batch_create(bsx_ref *r, uint32_t max_units, int paired, bsx_
     b->slab_bytes = slab_size(r->P, b->paired, b->rowcap);
     int rc = BSX_OK;
     auto fail = [&](int code) { bsx_batch_destroy(b); return code; };
+    if (const char *e = getenv("BSX_HEAVY_GROUPS")) g_heavy_groups = atoi(e) == 1 ? 1 : 2;  // diagnostic: 1 = alternate control and scan passes strictly
     if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) return fail(BSX_ERR_DEVICE);
+    {
+        int lo_p = 0, hi_p = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo_p, &hi_p);
+        if (hipStreamCreateWithPriority(&b->stream_hi, hipStreamNonBlocking, hi_p) != hipSuccess) return fail(BSX_ERR_DEVICE);
+        for (hipEvent_t *e : {&b->ev_ctrl[0], &b->ev_ctrl[1], &b->ev_scan[0], &b->ev_scan[1], &b->ev_sync})
+            if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) return fail(BSX_ERR_DEVICE);
+    }
     if (hipEventCreate(&b->ev0) != hipSuccess || hipEventCreate(&b->ev1) != hipSuccess) return fail(BSX_ERR_DEVICE);
     const int nm = b->paired ? 2 : 1;
     for (int m = 0; m < nm; m++) {
@@ -340,7 +340,8 @@ extern "C" void bsx_batch_destroy(bsx_batch *b)
     if (b->h_pinned) (void)hipHostFree(b->h_pinned);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
-    for (void *q : {(void *)b->d_tkeys, (void *)b->d_tkeys_sorted, (void *)b->d_tiota, (void *)b->d_torder, b->d_sort_temp}) if (q) (void)hipFree(q);
+    if (b->stream_hi) { (void)hipStreamSynchronize(b->stream_hi); (void)hipStreamDestroy(b->stream_hi); }
+    for (hipEvent_t e : {b->ev_ctrl[0], b->ev_ctrl[1], b->ev_scan[0], b->ev_scan[1], b->ev_sync}) if (e) (void)hipEventDestroy(e);
     if (b->stream) (void)hipStreamDestroy(b->stream);
     delete b;
 }
@@ -433,52 +434,75 @@ extern "C" int bsx_batch_run_range(bsx_batch *b, uint32_t first_unit, uint32_t n
         // Each round handles up to hcap deferred units.  One pass = k_hctrl (advance every active unit, publish scan
         // tasks) -> read the two counts back -> order the tasks by the index address they start at, so that tasks walking
         // the same part of a big bucket run together and share its cache lines -> k_hscan.
+        // Each round handles up to hcap deferred units, split into two groups that run their passes out of phase: while
+        // k_hscan evaluates the tasks of one group (main stream), k_hctrl advances the other group (high-priority
+        // stream) — control passes are latency-bound chains of a few thousand waves and disappear beside the scan.
+        // One pass of a group = k_hctrl (advance every active unit, publish scan tasks) -> counts read back -> k_hscan.
+        const bool trace = getenv("BSX_TRACE_HEAVY") != nullptr;
+        const int n_groups = g_heavy_groups;
+        struct Group { uint32_t n_act = 0, iter = 0; int cur = 0; bool done = true, scan_pending = false; HeavyArgsRaw H; uint32_t *blk[2]; };
         for (uint32_t base = 0; base < n_heavy; base += b->hcap) {
-            uint32_t n_act = std::min(b->hcap, n_heavy - base);
-            HeavyArgsRaw H;
-            memset(&H, 0, sizeof(H));
-            H.state = b->d_hstate; H.slabs = b->d_hslabs; H.tasks = b->d_htasks; H.tout = b->d_htout; H.task_keys = b->d_tkeys;
-            H.task_cap = b->task_cap; H.list_base = base; H.hidx_base = 0; H.fresh = 1;
-            uint32_t *blk[2] = {b->d_hcnt, b->d_hcnt + 8};
-            int cur = 0;
-            const bool trace = getenv("BSX_TRACE_HEAVY") != nullptr;
-            for (uint32_t iter = 0; n_act > 0; iter++) {
-                if (trace && (iter < 40 || iter % 2000 == 0)) fprintf(stderr, "[bsx heavy] paired %d base %u iter %u active %u last_tasks %u t=%ld\n", b->paired, base, iter, n_act, b->h_pinned[5], (long)clock());
-                if (iter > 100000) { g_bsx_err = "heavy pipeline did not converge"; return BSX_ERR_DEVICE; }
-                uint32_t *in = blk[cur], *out = blk[cur ^ 1];
-                HIP_TRY(hipMemsetAsync(out, 0, 16, b->stream));
-                H.active_in = b->d_hactive[cur]; H.active_out = b->d_hactive[cur ^ 1];
-                H.n_active_in_ptr = in; H.n_active_in = n_act; H.n_active_out = out; H.n_tasks = out + 1; H.queue = out + 2;
-                bsx_launch_hctrl(A, H, b->paired, (int)std::min<uint32_t>((n_act + 3) / 4, (uint32_t)b->n_cu * 4), b->stream);
+            const uint32_t n_round = std::min(b->hcap, n_heavy - base);
+            Group G[2];
+            HIP_TRY(hipEventRecord(b->ev_sync, b->stream));             // everything queued so far (k_align, earlier rounds)
+            HIP_TRY(hipStreamWaitEvent(b->stream_hi, b->ev_sync, 0));
+            auto launch_ctrl = [&](int g) -> int {
+                Group &q = G[g];
+                uint32_t *out = q.blk[q.cur ^ 1];
+                if (q.scan_pending) { HIP_TRY(hipStreamWaitEvent(b->stream_hi, b->ev_scan[g], 0)); q.scan_pending = false; }
+                HIP_TRY(hipMemsetAsync(out, 0, 16, b->stream_hi));
+                q.H.active_in = b->d_hactive[q.cur] + q.H.hidx_base; q.H.active_out = b->d_hactive[q.cur ^ 1] + q.H.hidx_base;
+                q.H.n_active_in_ptr = q.blk[q.cur]; q.H.n_active_in = q.n_act; q.H.n_active_out = out; q.H.n_tasks = out + 1; q.H.queue = out + 2;
+                bsx_launch_hctrl(A, q.H, b->paired, (int)std::min<uint32_t>((q.n_act + 3) / 4, (uint32_t)b->n_cu * 4), b->stream_hi);
                 HIP_TRY(hipGetLastError());
-                HIP_TRY(hipMemcpyAsync(b->h_pinned + 4, out, 8, hipMemcpyDeviceToHost, b->stream));
-                HIP_TRY(hipStreamSynchronize(b->stream));
-                const uint32_t cnt[2] = {((volatile uint32_t *)b->h_pinned)[4], ((volatile uint32_t *)b->h_pinned)[5]};
-                b->last_heavy_iters++;
-                n_act = cnt[0];
-                if (n_act == 0) break;
-                const uint32_t n_tasks = std::min(cnt[1], b->task_cap);
-                if (n_tasks) {
-                    H.task_order = nullptr;
-                    if (n_tasks >= 4096 && g_sort_tasks) {
-                        size_t need = 0;
-                        int rc = bsx_sort_tasks(b->d_tkeys, b->d_tkeys_sorted, b->d_tiota, b->d_torder, n_tasks, nullptr, need, b->stream);
-                        if (rc) return rc;
-                        if (need > b->sort_temp_bytes) {
-                            if (b->d_sort_temp) (void)hipFree(b->d_sort_temp);
-                            b->d_sort_temp = nullptr; b->sort_temp_bytes = 0;
-                            HIP_TRY(hipMalloc(&b->d_sort_temp, need));
-                            b->sort_temp_bytes = need;
-                        }
-                        rc = bsx_sort_tasks(b->d_tkeys, b->d_tkeys_sorted, b->d_tiota, b->d_torder, n_tasks, b->d_sort_temp, need, b->stream);
-                        if (rc) return rc;
-                        H.task_order = b->d_torder;
-                    }
-                    bsx_launch_hscan(A, H, (int)std::min<uint32_t>((n_tasks + 3) / 4, (uint32_t)b->n_cu * 8), b->stream);
-                    HIP_TRY(hipGetLastError());
-                }
-                cur ^= 1; H.fresh = 0;
+                HIP_TRY(hipMemcpyAsync(b->h_pinned + 8 + 4 * g, out, 8, hipMemcpyDeviceToHost, b->stream_hi));
+                HIP_TRY(hipEventRecord(b->ev_ctrl[g], b->stream_hi));
+                return BSX_OK;
+            };
+            for (int g = 0; g < n_groups; g++) {
+                Group &q = G[g];
+                const uint32_t lo = (uint32_t)((uint64_t)n_round * g / n_groups), hi = (uint32_t)((uint64_t)n_round * (g + 1) / n_groups);
+                q.n_act = hi - lo; q.done = q.n_act == 0;
+                memset(&q.H, 0, sizeof(q.H));
+                const uint32_t tcap = b->task_cap / n_groups, toff = tcap * g;
+                q.H.state = b->d_hstate; q.H.slabs = b->d_hslabs;
+                q.H.tasks = b->d_htasks + (size_t)toff * bsx_htask_bytes(); q.H.tout = b->d_htout + (size_t)toff * bsx_htaskout_bytes();
+                q.H.task_cap = tcap; q.H.list_base = base; q.H.hidx_base = lo; q.H.fresh = 1;
+                q.blk[0] = b->d_hcnt + 16 * g; q.blk[1] = b->d_hcnt + 16 * g + 8;
+                if (!q.done) { int rc = launch_ctrl(g); if (rc) return rc; }
             }
+            for (;;) {
+                bool any = false;
+                for (int g = 0; g < n_groups; g++) {
+                    Group &q = G[g];
+                    if (q.done) continue;
+                    any = true;
+                    HIP_TRY(hipEventSynchronize(b->ev_ctrl[g]));
+                    const uint32_t cnt[2] = {((volatile uint32_t *)b->h_pinned)[8 + 4 * g], ((volatile uint32_t *)b->h_pinned)[9 + 4 * g]};
+                    if (trace && (q.iter < 40 || q.iter % 2000 == 0))
+                        fprintf(stderr, "[bsx heavy] paired %d base %u group %d iter %u active %u -> %u tasks %u t=%ld\n", b->paired, base, g, q.iter, q.n_act, cnt[0], cnt[1], (long)clock());
+                    if (++q.iter > 100000) { g_bsx_err = "heavy pipeline did not converge"; return BSX_ERR_DEVICE; }
+                    b->last_heavy_iters++;
+                    q.n_act = cnt[0];
+                    q.cur ^= 1; q.H.fresh = 0;
+                    if (q.n_act == 0) { q.done = true; continue; }
+                    const uint32_t n_tasks = std::min(cnt[1], q.H.task_cap);
+                    if (n_tasks) {
+                        // (the counters of this pass live in the block the control kernel just wrote: blk[cur] after the flip)
+                        q.H.n_tasks = q.blk[q.cur] + 1; q.H.queue = q.blk[q.cur] + 2;
+                        HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_ctrl[g], 0));
+                        bsx_launch_hscan(A, q.H, (int)((n_tasks + 3) / 4), b->stream);
+                        HIP_TRY(hipGetLastError());
+                        HIP_TRY(hipEventRecord(b->ev_scan[g], b->stream));
+                        q.scan_pending = true;
+                    }
+                    int rc = launch_ctrl(g);
+                    if (rc) return rc;
+                }
+                if (!any) break;
+            }
+            HIP_TRY(hipEventRecord(b->ev_sync, b->stream_hi));            // the main stream continues behind the last control pass
+            HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_sync, 0));
         }
     }
     HIP_TRY(hipEventRecord(b->ev1, b->stream));
@@ -602,12 +626,12 @@ extern "C" int bsx_batch_last_heavy_units(bsx_batch *b)
     return (int)b->last_heavy;
 }
 
-extern "C" int bsx_batch_ctrl_clocks(bsx_batch *b, uint64_t out[8])
+extern "C" int bsx_batch_ctrl_clocks(bsx_batch *b, uint64_t out[24])
 {
     if (!b || !out) return BSX_ERR_ARG;
     HIP_TRY(hipSetDevice(b->ref->device));
     HIP_TRY(hipStreamSynchronize(b->stream));
-    HIP_TRY(hipMemcpy(out, b->d_counters + 16, 64, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, b->d_counters + 16, 192, hipMemcpyDeviceToHost));
     return BSX_OK;
 }
 

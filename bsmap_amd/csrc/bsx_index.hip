@@ -188,12 +188,3 @@ int bsx_index_build_rrbs(bsx_ref *r, const std::vector<uint32_t> &refcat, const 
     r->has_index = true;
     return BSX_OK;
 }
-
-// argsort of the heavy pipeline's scan tasks by the address of their first index entry (see bsx_api.hip): tasks that
-// walk the same part of a big bucket then run at the same time and share its cache lines
-int bsx_sort_tasks(const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *ids_in, uint32_t *ids_out, uint32_t n, void *temp, size_t &temp_bytes,
-                   hipStream_t stream)
-{
-    HIP_TRY(rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, ids_in, ids_out, (size_t)n, 0u, 32u, stream));
-    return BSX_OK;
-}

@@ -73,8 +73,6 @@ int bsx_pack_fasta(const bsx_params &P, const char *text, uint64_t n, bsx_ref &r
 // bsx_index.hip
 int bsx_index_build_wgbs(bsx_ref *r);
 int bsx_index_build_rrbs(bsx_ref *r, const std::vector<uint32_t> &refcat, const std::vector<uint32_t> &crefcat);
-int bsx_sort_tasks(const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *ids_in, uint32_t *ids_out, uint32_t n, void *temp, size_t &temp_bytes,
-                   hipStream_t stream);
 // bsx_synth.hip
 int bsx_synth_reads_launch(const bsx_ref *r, uint32_t n, uint32_t read_len, int paired, uint64_t seed, uint32_t first_index, uint8_t *d_seq_a,
                            uint8_t *d_seq_b, hipStream_t stream);

@@ -23,7 +23,7 @@ struct AlignArgs {
     uint32_t *queue;           // work queue head of the main kernel (zeroed before launch)
     uint64_t *counters;        // BSX_N_COUNTERS
     uint32_t *dbg_cycles;      // [n_units] shader-clock cycles spent on each unit (diagnostic builds of a run only), may be null
-    uint64_t *dbg_cat;         // [8] category clocks of the heavy control kernel (diagnostic runs only), may be null
+    uint64_t *dbg_cat;         // [16] category clocks (sums, then the longest single span of each) of the heavy control kernel (diagnostic runs only), may be null
     uint8_t *dbg_plan;         // [n_units][128]: start[2][16], order[2][16] for mate a then mate b
 };
 
@@ -34,8 +34,6 @@ struct HeavyArgsRaw {
     uint32_t *active_in, *active_out, *n_active_out;
     uint8_t *tasks, *tout;     // [task_cap] HTask / HTaskOut
     uint32_t *n_tasks;
-    uint32_t *task_keys;       // [task_cap] index-entry address of each task's first candidate (sort key)
-    const uint32_t *task_order; // [n_tasks] task ids in scan order, or null
     uint32_t *queue;           // [2] work queue heads of k_hctrl and k_hscan
     const uint32_t *n_active_in_ptr;  // device count of active_in (passes after the first)
     uint32_t n_active_in, task_cap, fresh, list_base, hidx_base;

@@ -166,7 +166,7 @@ int bsx_batch_download_reads(bsx_batch *b, int mate, char *seqs, uint64_t *off);
  * mode 2 records the shader-clock cycles each unit took (diagnostic runs only); 0 switches both off */
 int bsx_batch_set_debug(bsx_batch *b, int mode);
 int bsx_batch_unit_cycles(bsx_batch *b, uint32_t *cycles_per_unit);
-int bsx_batch_ctrl_clocks(bsx_batch *b, uint64_t clocks[8]);  /* mode 2: summed wave cycles of the heavy control kernel by category */
+int bsx_batch_ctrl_clocks(bsx_batch *b, uint64_t clocks[24]); /* mode 2: heavy control kernel, wave cycles by category: [0..7] sums, [8..15] longest single span, [16..21] break-down of the longest visit (cycles << 16 | spans) */
 int bsx_batch_debug_hits(bsx_batch *b, uint32_t unit, int mate, int orient, int w, uint32_t *chr_loc_pairs, uint32_t cap);
 int bsx_batch_debug_pairs(bsx_batch *b, uint32_t unit, int w, uint32_t *pairhits6 /* chain|na<<16|nb<<24, insert, a.chr, a.loc, b.chr, b.loc */, uint32_t cap);
 int bsx_batch_debug_plan(bsx_batch *b, uint32_t unit, int mate, int32_t *start_arrays32 /* [2][16] */, int32_t *seedindex32 /* [2][16] */);

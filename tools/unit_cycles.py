@@ -22,3 +22,5 @@ print("counters", pa.counters())
 print("heavy units", pa.heavy_units())
 
 cc = pa.ctrl_clocks().astype(float); print("ctrl clocks (Mcycles): prepare/restore %.0f inline-scan %.0f replay %.0f sort+pairs %.0f save/finish %.0f recount %.0f advance-total %.0f" % tuple(cc[[0,1,2,3,4,5,6]]/1e6))
+print("longest single span (kcycles): prepare/restore %.0f inline-scan %.0f replay %.0f sort+pairs %.0f save/finish %.0f recount %.0f advance %.0f" % tuple(cc[[8,9,10,11,12,13,14]]/1e3))
+print("longest visit break-down (kcycles x spans): " + " ".join("%s %.0f x%d" % (n, (int(v) >> 16) / 1e3, int(v) & 0xffff) for n, v in zip(["restore", "inline-scan", "replay", "sort+pairs", "save", "recount"], cc[16:22])))
