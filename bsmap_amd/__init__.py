@@ -12,7 +12,7 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libbsx.so")
+LIB_PATH = os.environ.get("BSX_LIB") or os.path.join(HERE, "libbsx.so")  # BSX_LIB: alternative build of the same library (kernel tuning experiments)
 CSRC = os.path.join(HERE, "csrc")
 
 BSX_N_COUNTERS = 8

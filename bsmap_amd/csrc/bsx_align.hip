@@ -450,6 +450,41 @@ __device__ __forceinline__ CandEval eval_candidate(const DevParams &P, const uin
     return eval_loaded(rp, r0, rw, rm, nwords, p, thres0);
 }
 
+// the same evaluation in two steps, for k_hscan: the first 48 nt decide for most candidates, and the words behind them
+// are requested for all four chunks of a step at once instead of chunk by chunk
+struct HeadEval { uint32_t p48, w0ref; };
+__device__ __forceinline__ HeadEval eval_head(const U4 r0, const uint32_t (&rw)[9], const uint32_t (&rm)[9], uint32_t p)
+{
+    HeadEval r;
+    const uint32_t k = p & 15, sh = (32 - 2 * k) & 31;
+    const uint32_t f0 = __builtin_amdgcn_alignbit(r0.a, r0.b, sh), f1 = __builtin_amdgcn_alignbit(r0.b, r0.c, sh),
+                   f2 = __builtin_amdgcn_alignbit(r0.c, r0.d, sh);
+    const uint32_t m1 = bsx_mismatch_hi(rw[1], bsx_tmask(rw[1], rm[1]), f1);
+    const uint32_t c0 = __popc(bsx_mismatch_hi(rw[0], bsx_tmask(rw[0], rm[0]), f0));
+    const uint32_t him = k ? ~(0xFFFFFFFFu >> (2 * (16 - k))) : 0xFFFFFFFFu;
+    r.w0ref = c0 + __popc(m1 & him);
+    r.p48 = c0 + __popc(m1) + __popc(bsx_mismatch_hi(rw[2], bsx_tmask(rw[2], rm[2]), f2));
+    return r;
+}
+// words 3..8: d = fourth word of the first load, r1 / r2 = the six words behind it (zero where the read is shorter)
+__device__ __forceinline__ void eval_tail(uint32_t d, const U4 r1, const U2 r2, const uint32_t (&rw)[9], const uint32_t (&rm)[9], uint32_t p, uint32_t p48,
+                                          uint32_t &w, uint32_t &w01ref)
+{
+    const uint32_t k = p & 15, sh = (32 - 2 * k) & 31;
+    const uint32_t him = k ? ~(0xFFFFFFFFu >> (2 * (16 - k))) : 0xFFFFFFFFu;
+    const uint32_t wd[7] = {d, r1.a, r1.b, r1.c, r1.d, r2.a, r2.b};
+    uint32_t tot = p48;
+    w01ref = p48;
+#pragma unroll
+    for (int t = 3; t < 9; t++) {
+        const uint32_t f = __builtin_amdgcn_alignbit(wd[t - 3], wd[t - 2], sh);
+        const uint32_t mm = bsx_mismatch_hi(rw[t], bsx_tmask(rw[t], rm[t]), f);
+        tot += __popc(mm);
+        if (t == 3) w01ref += __popc(mm & him);
+    }
+    w = tot;
+}
+
 // hit coordinates of a WGBS candidate at global nt p of strand copy `strand`; false if it runs off the chromosome
 __device__ __forceinline__ bool hit_coords(const DevParams &P, const BlockLds &BL, uint32_t p, uint32_t strand, int len, uint32_t &hchr,
                                            uint32_t &hloc, uint32_t &hkey)
@@ -1530,7 +1565,10 @@ __global__ __launch_bounds__(256) void k_hctrl(AlignArgs A, HeavyArgs H)
 }
 
 // every wave of the chip evaluates tasks: HS_TASK consecutive candidates of one published list window
-__global__ __launch_bounds__(256, 8) void k_hscan(AlignArgs A, HeavyArgs H)
+#ifndef BSX_HSCAN_WAVES
+#define BSX_HSCAN_WAVES 6  /* 80 VGPRs: the batched tail loads need more than the 64 of 8 waves; measured equal from 4 to 7 (the kernel is VALU-bound) */
+#endif
+__global__ __launch_bounds__(256, BSX_HSCAN_WAVES) void k_hscan(AlignArgs A, HeavyArgs H)
 {
     __shared__ BlockLds BL;
     __shared__ uint32_t TAB[4][4][32];
@@ -1585,21 +1623,43 @@ __global__ __launch_bounds__(256, 8) void k_hscan(AlignArgs A, HeavyArgs H)
                 for (int u = 0; u < 4; u++) { idx[u] = cb + u * 64 + lane; valid[u] = idx[u] < hi; p[u] = valid[u] ? e[u] + hh : 16u; }
 #pragma unroll
                 for (int u = 0; u < 4; u++) r0[u] = *reinterpret_cast<const U4 *>(refbase + ((p[u] - 1) >> 4));
+                // the first 48 nt of all four chunks, then — in one round trip — the remaining words of every candidate
+                // that is still within the threshold, then the verdicts in list order
+                uint32_t p48[4], w0ref[4], d3[4];
+                bool need[4];
+                U4 r1[4];
+                U2 r2[4];
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
-                    CandEval ev = eval_loaded(refbase + ((p[u] - 1) >> 4), r0[u], rw, rm, nwords, p[u], thres0);
-                    bool pass = valid[u] && ev.w <= thres0;
+                    const HeadEval h = eval_head(r0[u], rw, rm, p[u]);
+                    p48[u] = h.p48; w0ref[u] = h.w0ref; d3[u] = r0[u].d;
+                    need[u] = valid[u] && h.p48 <= thres0;
+                    r1[u].a = r1[u].b = r1[u].c = r1[u].d = 0; r2[u].a = r2[u].b = 0;
+                }
+                if (__ballot(need[0] | need[1] | need[2] | need[3])) {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const uint32_t *rp = refbase + ((p[u] - 1) >> 4);
+                        if (need[u] && nwords > 3) r1[u] = *reinterpret_cast<const U4 *>(rp + 4);
+                        if (need[u] && nwords > 7) r2[u] = *reinterpret_cast<const U2 *>(rp + 8);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    uint32_t w = p48[u], w01ref = 0;
+                    if (need[u]) eval_tail(d3[u], r1[u], r2[u], rw, rm, p[u], p48[u], w, w01ref);
+                    bool pass = valid[u] && w <= thres0;
                     uint32_t hchr = 0, hloc = 0, hkey = 0;
                     if (pass) pass = hit_coords(P, BL, p[u], strand, len, hchr, hloc, hkey);
                     const u64 m = __ballot(pass);
                     if (m) {
                         const uint32_t pos = nsurv + (uint32_t)__builtin_popcountll(m & lanemask_lt(lane));
-                        if (pass && pos < HS_SCAP) { SurvRec r; r.w_ord = ev.w | ((idx[u] - tc0) << 8); r.hchr = hchr; r.hloc = hloc; r.hkey = hkey; o->surv[pos] = r; }
+                        if (pass && pos < HS_SCAP) { SurvRec r; r.w_ord = w | ((idx[u] - tc0) << 8); r.hchr = hchr; r.hloc = hloc; r.hkey = hkey; o->surv[pos] = r; }
                         nsurv += (uint32_t)__builtin_popcountll(m);
                         if (nsurv > HS_SCAP) overflow = true;
                     }
-                    const bool one = valid[u] && ev.w0ref > thres0;
-                    const bool two = valid[u] && !one && (ev.p48 > thres0 || ev.w01ref > thres0);
+                    const bool one = valid[u] && w0ref[u] > thres0;
+                    const bool two = valid[u] && !one && (p48[u] > thres0 || w01ref > thres0);
                     const bool five = valid[u] && !one && !two;
                     a0 += (uint32_t)__builtin_popcountll(__ballot(valid[u])); a1 += (uint32_t)__builtin_popcountll(__ballot(one));
                     a2 += (uint32_t)__builtin_popcountll(__ballot(two)); a5 += (uint32_t)__builtin_popcountll(__ballot(five));
