@@ -29,7 +29,7 @@
 #include "bsx_reads.h"
 
 using namespace std;
-using bsx_reads::Reader; using bsx_reads::ReadSet; using bsx_reads::ReadOpts; using bsx_reads::load_reads;
+using bsx_reads::Reader; using bsx_reads::ReadSet; using bsx_reads::ReadOpts; using bsx_reads::load_reads; using bsx_reads::Buf; using bsx_reads::RawAlloc;
 
 namespace {
 
@@ -408,15 +408,15 @@ void die(int rc, const char *what)
 // Four stages run concurrently on a ring of batches, each stage taking the batches in input order:
 //   parse (one thread per read file)  ->  GPU (upload, Do_Batch, results)  ->  format (-p worker threads)  ->  write
 // so the output stays in input order whatever the thread count (the reference's order is only defined for -p 1).
-// The GPU stage has two device batches driven by two threads: kernels of one batch run while the other batch's reads
-// go up and its records come down.
+// The GPU stage has two device batches driven by two threads: while one batch is in its scan passes (VALU-bound) the
+// other one's reads go up, its latency-bound main kernel runs, and its records come down.
 struct Slot {
     ReadSet A, B;
     size_t n = 0;
     unsigned total_after = 0;
-    vector<bsx_hit> hits;
-    vector<bsx_pair> pairs;
-    vector<bsx_class_counts> cca, ccb;
+    Buf<bsx_hit> hits;
+    Buf<bsx_pair> pairs;
+    Buf<bsx_class_counts> cca, ccb;
     vector<Text> out, out_unpair;
     int stage = 0;  // 0 free, 1 parsed, 2 aligned, 3 formatted
 };
@@ -463,6 +463,26 @@ int main(int argc, char **argv)
     if (rc) die(rc, "bad option value");
     const bsx_params &p = o.p;
     { ifstream t(o.ref_file.c_str()); if (!t) { cerr << "fatal error: failed to open ref file\n"; exit(1); } }
+    // The ring's upload / download buffers are page-locked (the transfers are then plain DMA).  Locking gigabytes of pages
+    // takes seconds, so it happens on a side thread while the reference is loaded and indexed.
+    static const RawAlloc pinned = {bsx_pinned_alloc, bsx_pinned_free};
+    Ring &ring = *new Ring;  // never freed: error paths exit() while side threads may still touch it
+    const bool pe = !o.a_file.empty() && !o.b_file.empty();
+    thread t_pin([&] {
+        auto fsize = [](const string &f) { struct stat st; return (!f.empty() && stat(f.c_str(), &st) == 0) ? (size_t)st.st_size : (size_t)0; };
+        const size_t fa = fsize(o.a_file), fb = fsize(o.b_file);
+        const size_t units = min<size_t>(o.batch, max(fa, fb) / 2 + 1);
+        for (int k = 0; k < Ring::NS; k++) {
+            Slot &s = ring.slot[k];
+            s.A.set_alloc(&pinned); s.B.set_alloc(&pinned);
+            s.hits.set_alloc(&pinned); s.pairs.set_alloc(&pinned); s.cca.set_alloc(&pinned); s.ccb.set_alloc(&pinned);
+            if ((size_t)k * o.batch * 100 > max(fa, fb)) continue;  // short input: the later slots are never used
+            const size_t ca = min<size_t>(units * (size_t)p.max_readlen, fa), cb = min<size_t>(units * (size_t)p.max_readlen, fb);
+            s.A.seq.reserve(ca); s.A.qual.reserve(ca); s.A.soff.reserve(units + 1); s.cca.reserve(units);
+            if (pe) { s.B.seq.reserve(cb); s.B.qual.reserve(cb); s.B.soff.reserve(units + 1); s.pairs.reserve(units); s.ccb.reserve(units); }
+            else s.hits.reserve(units);
+        }
+    });
     RefView rv;
     rc = bsx_ref_create_from_file(&o.p, o.ref_file.c_str(), o.device, &rv.ref);
     if (rc) die(rc, "loading the reference");
@@ -490,7 +510,6 @@ int main(int argc, char **argv)
     cout << "min fragment size:" << p.min_insert << "\tmax fragemt size:" << p.max_insert << endl;
     cout << "start from read #" << o.read_start << "\tend at read #" << o.read_end << endl;
     cout << "additional alignment: " << (char)toupper(p.read_nt) << " in reads => " << (char)toupper(p.ref_nt) << " in reference" << endl;
-    const bool pe = !o.a_file.empty() && !o.b_file.empty();
     if (o.a_file.empty()) { cerr << "missing query file(s)\n"; exit(1); }
     FILE *fout = fopen(o.out_file.c_str(), "wb");
     if (!fout) { cerr << "failed to open output file (check -o option): " << o.out_file << endl; exit(1); }
@@ -517,10 +536,10 @@ int main(int argc, char **argv)
     if (pe) rb.open(o.b_file, ro);
     if (pe) cout << "Pair-end alignment(GPU " << o.device << ")\n"; else cout << "Single read alignment(GPU " << o.device << ")\n";
     const int workers = o.num_procs > 0 ? o.num_procs : (int)min(64u, max(1u, thread::hardware_concurrency()));
-    Ring ring;
     Formatter totals(o, rv);
     unsigned total = 0;
     double busy[4] = {0, 0, 0, 0};
+    t_pin.join();
     const double t_map0 = now_s();
 
     thread t_parse([&] {
@@ -542,7 +561,7 @@ int main(int argc, char **argv)
         }
         ring.finish(k);
     });
-    mutex mu_run, mu_busy;
+    mutex mu_busy;
     auto gpu_stage = [&](int g) {
         bsx_batch *batch = batches[g];
         for (long k = g; ring.acquire(k, 1); k += 2) {
@@ -553,7 +572,7 @@ int main(int argc, char **argv)
             if (!pe) {
                 r = bsx_batch_upload_se(batch, n, s.A.seq.data(), s.A.soff.data(), ra.format == 0 ? s.A.upload_qual() : nullptr, s.A.first_index);
                 if (r) die(r, "uploading reads");
-                { lock_guard<mutex> lk(mu_run); if ((r = bsx_batch_run(batch)) || (r = bsx_batch_sync(batch))) die(r, "aligning"); }
+                if ((r = bsx_batch_run(batch)) || (r = bsx_batch_sync(batch))) die(r, "aligning");
                 s.hits.resize(n); s.cca.resize(n);
                 if ((r = bsx_batch_results_se(batch, s.hits.data(), s.cca.data()))) die(r, "reading results");
             } else {
@@ -561,7 +580,7 @@ int main(int argc, char **argv)
                 r = bsx_batch_upload_pe(batch, n, s.A.seq.data(), s.A.soff.data(), q ? s.A.upload_qual() : nullptr, s.B.seq.data(), s.B.soff.data(),
                                         q ? s.B.upload_qual() : nullptr, s.A.first_index);
                 if (r) die(r, "uploading reads");
-                { lock_guard<mutex> lk(mu_run); if ((r = bsx_batch_run(batch)) || (r = bsx_batch_sync(batch))) die(r, "aligning"); }
+                if ((r = bsx_batch_run(batch)) || (r = bsx_batch_sync(batch))) die(r, "aligning");
                 s.pairs.resize(n); s.cca.resize(n); s.ccb.resize(n);
                 if ((r = bsx_batch_results_pe(batch, s.pairs.data(), s.cca.data(), s.ccb.data(), nullptr))) die(r, "reading results");
             }

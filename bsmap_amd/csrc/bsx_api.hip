@@ -363,6 +363,14 @@ static int upload_mate(bsx_batch *b, int m, uint32_t n, const char *seqs, const 
     return BSX_OK;
 }
 
+extern "C" void *bsx_pinned_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+extern "C" void bsx_pinned_free(void *p) { if (p) (void)hipHostFree(p); }
+
 extern "C" int bsx_batch_upload_se(bsx_batch *b, uint32_t n, const char *seqs, const uint64_t *off, const char *quals, uint32_t first_index)
 {
     if (!b || !seqs || !off || b->paired || n > b->max_units) return BSX_ERR_ARG;

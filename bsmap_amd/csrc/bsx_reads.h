@@ -21,6 +21,42 @@ using std::cerr; using std::endl; using std::min; using std::string; using std::
 
 struct ReadOpts { unsigned read_start = 1, read_end = ~0u; int max_readlen = 144; int zero_qual = 33; };
 
+// Growable array over a pluggable allocator: the driver passes the library's page-locked allocator (bsx_pinned_alloc) so
+// that the upload is a straight DMA from these buffers; the default is malloc.
+struct RawAlloc { void *(*alloc)(size_t); void (*release)(void *); };
+inline const RawAlloc *default_alloc() { static const RawAlloc a = {::malloc, ::free}; return &a; }
+template <class T> struct Buf {
+    T *p = nullptr;
+    size_t n = 0, cap = 0;
+    const RawAlloc *a = default_alloc();
+    Buf() {}
+    Buf(const Buf &) = delete;
+    Buf &operator=(const Buf &) = delete;
+    ~Buf() { if (p) a->release(p); }
+    void set_alloc(const RawAlloc *x) { if (p) { a->release(p); p = nullptr; n = cap = 0; } a = x; }
+    void reserve(size_t c)
+    {
+        if (c <= cap) return;
+        size_t nc = cap ? cap : 1024;
+        while (nc < c) nc *= 2;
+        T *q = (T *)a->alloc(nc * sizeof(T));
+        if (!q) { cerr << "out of memory (host buffer)\n"; exit(1); }
+        if (n) memcpy(q, p, n * sizeof(T));
+        if (p) a->release(p);
+        p = q; cap = nc;
+    }
+    void clear() { n = 0; }
+    void resize(size_t c) { reserve(c); n = c; }
+    void push_back(const T &v) { if (n == cap) reserve(n + 1); p[n++] = v; }
+    void append(const T *src, size_t c) { if (n + c > cap) reserve(n + c); memcpy(p + n, src, c * sizeof(T)); n += c; }
+    void append_fill(size_t c, T v) { if (n + c > cap) reserve(n + c); for (size_t i = 0; i < c; i++) p[n + i] = v; n += c; }
+    T *data() { return p; }
+    const T *data() const { return p; }
+    size_t size() const { return n; }
+    T &operator[](size_t i) { return p[i]; }
+    const T &operator[](size_t i) const { return p[i]; }
+};
+
 // ---- reads (reads.cpp:13-117) -------------------------------------------------------------------------------------
 // The reference reads with operator>> / getline on an ifstream; the same token rules are applied here to a memory map
 // of the file (whitespace-separated tokens, rest of the header line dropped, header remainder limited to 999
@@ -106,17 +142,18 @@ struct Reader {
 
 // one batch of reads in flat arrays: what the upload takes (sequence bytes + offsets) and what the formatters need
 struct ReadSet {
-    vector<char> names, seq, qual;
-    vector<uint64_t> noff, soff, qoff;
-    vector<char> qual_upload;  // only when some quality string differs in length from its sequence
+    Buf<char> names, seq, qual;
+    Buf<uint64_t> noff, soff, qoff;
+    Buf<char> qual_upload;  // only when some quality string differs in length from its sequence
+    void set_alloc(const RawAlloc *a) { seq.set_alloc(a); qual.set_alloc(a); soff.set_alloc(a); qual_upload.set_alloc(a); }
     bool qual_same = true;
     unsigned first_index = 0;
     size_t n() const { return soff.size() - 1; }
-    void clear() { names.clear(); seq.clear(); qual.clear(); noff.assign(1, 0); soff.assign(1, 0); qoff.assign(1, 0); qual_same = true; }
+    void clear() { names.clear(); seq.clear(); qual.clear(); noff.clear(); soff.clear(); qoff.clear(); noff.push_back(0); soff.push_back(0); qoff.push_back(0); qual_same = true; }
     const char *upload_qual()
     {
         if (qual_same) return qual.data();
-        qual_upload.assign(seq.size(), 'I');
+        qual_upload.clear(); qual_upload.append_fill(seq.size(), 'I');
         for (size_t i = 0; i + 1 < soff.size(); i++) {
             const size_t sl = soff[i + 1] - soff[i], ql = qoff[i + 1] - qoff[i];
             memcpy(qual_upload.data() + soff[i], qual.data() + qoff[i], min(sl, ql));
@@ -139,19 +176,19 @@ inline size_t load_reads(Reader &rd, ReadSet &out, size_t max_n, const ReadOpts 
         if (rd.cur >= rd.end) break;
         rd.cur++;
         rd.token(t, n);
-        out.names.insert(out.names.end(), t, t + n); out.noff.push_back(out.names.size());
+        out.names.append(t, n); out.noff.push_back(out.names.size());
         rd.rest_of_line();
         rd.token(t, n);
         const size_t sl = min(n, maxlen);
-        out.seq.insert(out.seq.end(), t, t + sl); out.soff.push_back(out.seq.size());
+        out.seq.append(t, sl); out.soff.push_back(out.seq.size());
         if (rd.format == 0) {
             rd.token(t, n); rd.rest_of_line();  // '+' line
             rd.token(t, n);
             const size_t ql = min(n, maxlen);
-            out.qual.insert(out.qual.end(), t, t + ql); out.qoff.push_back(out.qual.size());
+            out.qual.append(t, ql); out.qoff.push_back(out.qual.size());
             if (ql != sl) out.qual_same = false;
         } else {
-            out.qual.insert(out.qual.end(), sl, (char)(o.zero_qual + 40)); out.qoff.push_back(out.qual.size());
+            out.qual.append_fill(sl, (char)(o.zero_qual + 40)); out.qoff.push_back(out.qual.size());
         }
         rd.index++;
     }

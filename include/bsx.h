@@ -13,6 +13,7 @@
  */
 #ifndef BSX_H
 #define BSX_H
+#include <stddef.h>
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
@@ -142,6 +143,11 @@ typedef struct bsx_pair {
 
 int bsx_batch_create(bsx_ref *r, uint32_t max_units, int paired, bsx_batch **out);
 void bsx_batch_destroy(bsx_batch *b);
+/* Page-locked host buffers for the arrays handed to bsx_batch_upload_* / bsx_batch_results_*: with them the transfers
+ * are plain DMA (the reference has no counterpart: its reads never leave host memory).  Ordinary malloc memory works too. */
+void *bsx_pinned_alloc(size_t bytes);
+void bsx_pinned_free(void *p);
+
 /* SoA upload (ImportBatchReads, align.cpp:42-46 / pairs.cpp:27-32): read i = seqs[off[i] .. off[i+1]);
  * quals may be NULL (FASTA input: constant default quality, reads.cpp:108); reads longer than -L are truncated
  * (reads.cpp:115-117).  first_index = ReadInf.index of unit 0 (reads.cpp:97). */

@@ -108,3 +108,32 @@ def test_pair_geometry(big):
     assert ins.min() >= 28 and ins.max() <= 500 and 250 < np.median(ins) < 350
     uniq = pr & (out["n_pairs"] == 1)
     assert uniq.mean() > 0.95
+
+
+def test_two_batches_in_flight(big):
+    """two device batches driven by two host threads at the same time (what bench.py and the command-line driver do):
+    same records as the batch that ran alone"""
+    import threading
+    ref, pa, out, ca, cb, npairs, cnt = big
+    others = [B.PairAlign(ref, N) for _ in range(2)]
+    res = [None, None]
+    try:
+        for o in others:
+            o.synth_reads(N, 144, seed=11)
+
+        def work(j):
+            for _ in range(2):
+                others[j].Do_Batch()
+            res[j] = tuple(x.copy() for x in others[j].results())
+
+        th = [threading.Thread(target=work, args=(j,)) for j in range(2)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        for j in range(2):
+            o2, a2, b2, n2 = res[j]
+            assert o2.tobytes() == out.tobytes() and a2.tobytes() == ca.tobytes() and b2.tobytes() == cb.tobytes() and n2.tobytes() == npairs.tobytes()
+    finally:
+        for o in others:
+            o.close()
