@@ -311,11 +311,12 @@ def heavy_genome(tmp_path_factory):
 
 
 @pytest.mark.parametrize("pe", [False, True], ids=["se", "pe"])
-def test_heavy_pipeline_large_buckets(pe, heavy_genome, oracle):
+def test_heavy_pipeline_large_buckets(pe, heavy_genome, oracle, extra=None):
     g, fa = heavy_genome
     kw = dict(s=16, v=6, I=4, S=1, r=1)
     if pe:
         kw.update(m=28, x=500, pairend=1)
+    kw.update(extra or {})
     oref = oracle.OracleRef(oracle.make_params(**kw), fasta_path=fa)
     gref = B.RefSeq(B.make_params(**kw)).Run_ConvertBinseq(fasta_path=fa).CreateIndex()
     assert np.diff(gref.index()[0].astype(np.int64)).max() > 50_000
@@ -352,6 +353,48 @@ def test_heavy_pipeline_large_buckets(pe, heavy_genome, oracle):
         pa.close()
     gref.close()
     oref.free()
+
+
+@pytest.mark.parametrize("extra", [dict(w=20), dict(w=3, r=0), dict(w=150, n=1), dict(r=0, v=3)], ids=["w20", "w3_r0", "w150_n1", "r0_v3"])
+def test_heavy_pipeline_caps_and_early_returns(extra, heavy_genome, oracle):
+    """-w caps and -r 0 on reads with hundreds of hits: the 64-at-a-time survivor acceptance has to cut its groups at
+    the first survivor that lowers the threshold or ends the call, and re-publish the rest of the window"""
+    test_heavy_pipeline_large_buckets(False, heavy_genome, oracle, extra)
+    if "n" not in extra:
+        test_heavy_pipeline_large_buckets(True, heavy_genome, oracle, extra)
+
+
+def test_batch_reuse_and_argument_checks(edge_genome, oracle):
+    """one device batch used for batches of different sizes, and the error codes of calls made out of order"""
+    g, fa = edge_genome
+    kw = dict(s=16, v=4, I=4, S=1, r=1)
+    gref = B.RefSeq(B.make_params(**kw)).Run_ConvertBinseq(fasta_path=fa).CreateIndex()
+    oref = oracle.OracleRef(oracle.make_params(**kw), fasta_path=fa)
+    L = B.lib()
+    sa = B.SingleAlign(gref, 500)
+    assert L.bsx_batch_run(sa.h) != 0                                           # nothing uploaded yet
+    assert L.bsx_batch_results_se(sa.h, np.zeros(4, B.HIT_DTYPE).ctypes.data, None) != 0  # nothing has run yet
+    reads = td.make_se_reads(g, 500, 100, seed=21)
+    al = oracle.OracleAligner(oref, leak_mode=0)
+    for n in (500, 37, 1, 260):
+        seqs = [r["seq"] for r in reads[:n]]
+        sa.ImportBatchReads(seqs).Do_Batch()
+        h, cc = sa.results()
+        assert len(h) == n
+        for i in (0, n // 2, n - 1):
+            o = al.se(i, seqs[i])
+            _cmp_read(o, h[i], cc[i], kw, i)
+    with pytest.raises(Exception):
+        sa.ImportBatchReads([r["seq"] for r in reads] + ["ACGT"])             # more units than the batch was created for
+    with pytest.raises(Exception):
+        sa.run_range(400, 200, sync=True)                                       # range past the uploaded units
+    with pytest.raises(Exception):
+        L2 = B.PairAlign(gref, 10)
+        try:
+            B._check(L.bsx_batch_upload_se(L2.h, 1, b"ACGT", np.array([0, 4], np.uint64).ctypes.data, None, 0))  # paired batch, single-end upload
+        finally:
+            L2.close()
+    al.free(); sa.close(); gref.close(); oref.free()
 
 
 def test_heavy_pipeline_small_pools(heavy_genome, oracle):
