@@ -67,7 +67,13 @@ def main():
     read_len = 144 if pe else 100
     lens = HG38 if args.genome == "hg38" else [max(200_000, int(x * float(args.genome))) for x in HG38]
     t0 = time.time()
-    ref = B.RefSeq(B.make_params(**kw), device=local_rank).synthetic(lens, seed=38)
+    real_fa = os.environ.get("BSX_HG38")  # a real genome FASTA if one is at hand (never on the driver's box); reads are
+    if real_fa and os.path.exists(real_fa):  # still sampled on the device from the resident reference
+        ref = B.RefSeq(B.make_params(**kw), device=local_rank).Run_ConvertBinseq(fasta_path=real_fa)
+        lens = [int(x) for x in ref.info()[1]]
+    else:
+        real_fa = None
+        ref = B.RefSeq(B.make_params(**kw), device=local_rank).synthetic(lens, seed=38)
     t_gen = time.time() - t0
     t0 = time.time()
     ref.CreateIndex()
@@ -139,7 +145,7 @@ def main():
         "metric": "aligned reads/sec (whole node), 2x150 bp hg38 WGBS -v 6 -s 16" if pe else "aligned reads/sec (whole node), 1x100 bp hg38 WGBS -v 4 -s 16",
         "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "u32", "data": "synthetic",
+        "dtype": "u32", "data": "synthetic" if not real_fa else "synthetic reads sampled from " + os.path.basename(real_fa),
         "config": {"workload": "C3: 2x150(->144) bp PE WGBS vs hg38-sized synthetic genome, -s 16 -v 6 -I 4 -m 28 -x 500" if pe
                    else "C2: 1x100 bp SE WGBS vs hg38-sized synthetic genome, -s 16 -v 4 -I 4",
                    "pairs_per_step" if pe else "reads_per_step": B_, "genome_bp": int(sum(lens)), "index_entries": int(ref.n_entries),
