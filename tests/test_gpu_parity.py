@@ -269,9 +269,9 @@ def test_empty_and_degenerate_inputs(edge_genome, oracle):
 
 @pytest.mark.parametrize("name,kw,spec", [e for e in EDGE if e[0] in ("se_n1_var", "se_w5", "se_r0_w3", "pe_c3", "pe_trim_w4")],
                          ids=lambda x: x if isinstance(x, str) else "")
-def test_cooperative_kernel_path(name, kw, spec, edge_genome, oracle):
+def test_heavy_pipeline_forced_on_edge_cases(name, kw, spec, edge_genome, oracle):
     """the same cases with the heavy-unit threshold forced down to 48 candidates so that most units go through the
-    16-wave cooperative kernel (windowed scan, event restarts, exact work accounting)"""
+    heavy pipeline (windowed scans, event restarts, exact work accounting)"""
     B.lib().bsx_set_heavy_threshold(48)
     try:
         test_edge_cases_vs_oracle(name, kw, spec, edge_genome, oracle)
@@ -279,7 +279,7 @@ def test_cooperative_kernel_path(name, kw, spec, edge_genome, oracle):
         B.lib().bsx_set_heavy_threshold(8192)
 
 
-def test_cooperative_kernel_is_used(edge_genome, oracle):
+def test_heavy_pipeline_is_used(edge_genome, oracle):
     g, fa = edge_genome
     kw = dict(s=16, v=4, I=4, S=1, r=1, n=1)
     gref = B.RefSeq(B.make_params(**kw)).Run_ConvertBinseq(fasta_path=fa).CreateIndex()
