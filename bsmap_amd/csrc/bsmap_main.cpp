@@ -8,7 +8,8 @@
 //   s_OutHitPair / s_OutHitUnpair  pairs.cpp:288-498       (paired SAM + BSP lines, read-through trimming)
 //   FixPairReadName                pairs.cpp:535-555
 // The alignment itself (FilterReads ... StringAlign selection) happens behind the C ABI of include/bsx.h.
-// Not supported (reference features outside the hot path): SAM/BAM input and .bam output (samtools).
+// BAM input is read natively (BGZF + BAM records, bsx_reads.h).  Not supported: .bam output (the reference pipes its SAM
+// through samtools view / sort / index, sam2bam.sh).
 // Parsing, the GPU, formatting (-p threads) and writing run as a pipeline over a ring of batches; the output is always
 // in input order (the reference's order is nondeterministic for -p > 1).
 #include <algorithm>
@@ -550,8 +551,8 @@ int main(int argc, char **argv)
             Slot &s = ring.at(k);
             size_t n2 = 0;
             thread tb;
-            if (pe) tb = thread([&] { n2 = load_reads(rb, s.B, o.batch, ro); });
-            const size_t n1 = load_reads(ra, s.A, o.batch, ro);
+            if (pe) tb = thread([&] { n2 = load_reads(rb, s.B, o.batch, ro, 2); });
+            const size_t n1 = load_reads(ra, s.A, o.batch, ro, pe ? 1 : 0);
             if (pe) tb.join();
             busy[0] += now_s() - t;
             if (!n1 || (pe && n1 != n2)) break;
@@ -570,13 +571,13 @@ int main(int argc, char **argv)
             const uint32_t n = (uint32_t)s.n;
             int r;
             if (!pe) {
-                r = bsx_batch_upload_se(batch, n, s.A.seq.data(), s.A.soff.data(), ra.format == 0 ? s.A.upload_qual() : nullptr, s.A.first_index);
+                r = bsx_batch_upload_se(batch, n, s.A.seq.data(), s.A.soff.data(), ra.format != 1 ? s.A.upload_qual() : nullptr, s.A.first_index);
                 if (r) die(r, "uploading reads");
                 if ((r = bsx_batch_run(batch)) || (r = bsx_batch_sync(batch))) die(r, "aligning");
                 s.hits.resize(n); s.cca.resize(n);
                 if ((r = bsx_batch_results_se(batch, s.hits.data(), s.cca.data()))) die(r, "reading results");
             } else {
-                const bool q = ra.format == 0 && rb.format == 0;
+                const bool q = ra.format != 1 && rb.format != 1;
                 r = bsx_batch_upload_pe(batch, n, s.A.seq.data(), s.A.soff.data(), q ? s.A.upload_qual() : nullptr, s.B.seq.data(), s.B.soff.data(),
                                         q ? s.B.upload_qual() : nullptr, s.A.first_index);
                 if (r) die(r, "uploading reads");

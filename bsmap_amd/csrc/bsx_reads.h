@@ -6,6 +6,7 @@
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <zlib.h>
 
 #include <algorithm>
 #include <cstdint>
@@ -66,7 +67,7 @@ inline bool is_ws(char c) { return c == ' ' || c == '\n' || c == '\t' || c == '\
 struct Reader {
     const char *base = nullptr, *cur = nullptr, *end = nullptr;
     size_t map_len = 0;
-    int format = -1;  // 0 fastq, 1 fasta
+    int format = -1;  // 0 fastq, 1 fasta, 3 BAM (the reference's numbering, reads.cpp:23-45; its SAM-text branch is unreachable)
     unsigned index = 0;
     bool failed = false;  // the stream's failbit: every later extraction yields nothing
     bool eof_hit = false;
@@ -107,6 +108,74 @@ struct Reader {
         if (!nl) { cur = end; eof_hit = true; if (n == 0) failed = true; return; }
         cur = nl + 1;
     }
+    // ---- BAM input (samtools' bam_read1 on a BGZF stream, as reads.cpp:120-142 uses it) ----
+    vector<unsigned char> blk;  // current inflated BGZF block
+    size_t blk_pos = 0;
+    const unsigned char *zcur = nullptr;  // next compressed block
+    bool next_block()
+    {
+        const unsigned char *e = (const unsigned char *)end;
+        for (;;) {
+            if (!zcur || e - zcur < 18 || zcur[0] != 0x1f || zcur[1] != 0x8b || zcur[2] != 8 || !(zcur[3] & 4)) return false;
+            const unsigned xlen = zcur[10] | (zcur[11] << 8);
+            if ((size_t)(e - zcur) < 12 + xlen) return false;
+            unsigned bsize = 0;
+            for (unsigned x = 0; x + 4 <= xlen;) {  // the 'BC' extra subfield carries the block size
+                const unsigned char *f = zcur + 12 + x;
+                const unsigned slen = f[2] | (f[3] << 8);
+                if (f[0] == 'B' && f[1] == 'C' && slen == 2) bsize = (f[4] | (f[5] << 8)) + 1;
+                x += 4 + slen;
+            }
+            if (bsize < 12 + xlen + 8 || (size_t)(e - zcur) < bsize) return false;
+            const unsigned isize = zcur[bsize - 4] | (zcur[bsize - 3] << 8) | (zcur[bsize - 2] << 16) | ((unsigned)zcur[bsize - 1] << 24);
+            blk.resize(isize); blk_pos = 0;
+            if (isize) {
+                z_stream z;
+                memset(&z, 0, sizeof(z));
+                if (inflateInit2(&z, -15) != Z_OK) return false;
+                z.next_in = const_cast<unsigned char *>(zcur + 12 + xlen); z.avail_in = bsize - 12 - xlen - 8;
+                z.next_out = blk.data(); z.avail_out = isize;
+                const int rc = inflate(&z, Z_FINISH);
+                inflateEnd(&z);
+                if (rc != Z_STREAM_END) return false;
+            }
+            zcur += bsize;
+            if (isize) return true;  // (empty blocks, e.g. the EOF marker, are skipped)
+        }
+    }
+    bool bam_bytes(void *dst, size_t n)
+    {
+        unsigned char *d = (unsigned char *)dst;
+        while (n) {
+            if (blk_pos == blk.size() && !next_block()) return false;
+            const size_t c = std::min(n, blk.size() - blk_pos);
+            if (d) { memcpy(d, blk.data() + blk_pos, c); d += c; }
+            blk_pos += c; n -= c;
+        }
+        return true;
+    }
+    bool bam_open()
+    {
+        zcur = (const unsigned char *)base; blk.clear(); blk_pos = 0;
+        char magic[4];
+        int32_t l_text = 0, n_ref = 0;
+        if (!bam_bytes(magic, 4) || memcmp(magic, "BAM\1", 4) != 0) return false;
+        if (!bam_bytes(&l_text, 4) || l_text < 0 || !bam_bytes(nullptr, (size_t)l_text) || !bam_bytes(&n_ref, 4) || n_ref < 0) return false;
+        for (int32_t r = 0; r < n_ref; r++) {
+            int32_t l_name = 0;
+            if (!bam_bytes(&l_name, 4) || l_name < 0 || !bam_bytes(nullptr, (size_t)l_name + 4)) return false;
+        }
+        return true;
+    }
+    vector<unsigned char> rec;  // one alignment record (without its length word)
+    bool bam_next()
+    {
+        int32_t bs = 0;
+        if (!bam_bytes(&bs, 4) || bs < 32) return false;
+        rec.resize((size_t)bs);
+        return bam_bytes(rec.data(), (size_t)bs);
+    }
+
     void open(const string &path, const ReadOpts &o)
     {
         const int fd = ::open(path.c_str(), O_RDONLY);
@@ -129,7 +198,13 @@ struct Reader {
             token(t, n2); rest_of_line(); token(t, n1); rest_of_line(); token(t, n4); rest_of_line();
             format = 0;
             if (n2 != n4) { cerr << "fatal error: fq format, sequence length not equal to quality length\n"; exit(1); }
-        } else { cerr << "fatal error: unrecognizable format of reads file (SAM/BAM input is not supported by this build).\n"; exit(1); }
+        } else if (bam_open()) {
+            // BAM (reads.cpp:38-41).  The reference's -B skip only exists for its unreachable SAM-text case (the switch in
+            // CheckFile tests format 2, BAM is 3): with BAM input no record is skipped, only the index starts at -B.
+            format = 3;
+            index = o.read_start - 1;
+            return;
+        } else { cerr << "fatal error: unrecognizable format of reads file.\n"; exit(1); }
         cur = base; failed = false; eof_hit = false;
         const unsigned skip = (o.read_start - 1) * (format == 0 ? 4 : 2);
         for (unsigned i = 0; i < skip; i++) {  // getline(ch, 1000) per skipped line
@@ -163,11 +238,39 @@ struct ReadSet {
 };
 
 // ReadClass::LoadBatchReads (reads.cpp:83-117) for one file; returns the number of reads loaded
-inline size_t load_reads(Reader &rd, ReadSet &out, size_t max_n, const ReadOpts &o)
+inline size_t load_reads(Reader &rd, ReadSet &out, size_t max_n, const ReadOpts &o, int readset = 0)
 {
     out.clear();
     out.first_index = rd.index;
     const size_t maxlen = (size_t)o.max_readlen;
+    if (rd.format == 3) {
+        // BAM (reads.cpp:120-142): records as stored (no reverse-complementing by flag); a paired run reads both mates from
+        // alternating records — set 1 takes a record and skips one, set 2 skips one and takes one
+        static const char nt16[] = "=ACMGRSVTWYHKDBN";
+        while (out.n() < max_n && rd.index < o.read_end) {
+            if (readset == 2 && !rd.bam_next()) break;
+            if (!rd.bam_next()) break;
+            const unsigned char *r = rd.rec.data();
+            const size_t l_name = r[8], n_cigar = r[12] | (r[13] << 8);
+            int32_t l_qseq; memcpy(&l_qseq, r + 16, 4);
+            const unsigned char *qn = r + 32, *sq = qn + l_name + 4 * n_cigar, *ql = sq + ((size_t)l_qseq + 1) / 2;
+            if (l_qseq < 0 || (size_t)(ql - r) + (size_t)l_qseq > rd.rec.size()) break;
+            const size_t nl = strnlen((const char *)qn, l_name), sl = min((size_t)l_qseq, maxlen);
+            const size_t n_names = out.names.size(), n_seq = out.seq.size(), n_qual = out.qual.size();
+            out.names.append((const char *)qn, nl);
+            for (size_t i = 0; i < sl; i++) {
+                out.seq.push_back(nt16[(sq[i >> 1] >> ((~i & 1) << 2)) & 0xf]);
+                out.qual.push_back((char)(ql[i] + 33));
+            }
+            if (readset == 1 && !rd.bam_next()) {  // the mate's record is missing: the reference drops this read as well
+                out.names.n = n_names; out.seq.n = n_seq; out.qual.n = n_qual;
+                break;
+            }
+            out.noff.push_back(out.names.size()); out.soff.push_back(out.seq.size()); out.qoff.push_back(out.qual.size());
+            rd.index++;
+        }
+        return out.n();
+    }
     while (out.n() < max_n && rd.index < o.read_end) {
         const char *t; size_t n;
         // fin >> c : the record marker ('@' or '>') is a single character, the name follows (possibly after blanks)

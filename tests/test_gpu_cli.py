@@ -121,3 +121,36 @@ def test_cli_pipeline_is_batch_and_thread_invariant(name, tmp_path):
     leaky = _leaky_names(meta)
     if not leaky:
         assert _body(outs[0][0].decode()) == _body(run["out"])
+
+
+BAMCLI = json.load(gzip.open(os.path.join(G.GOLDEN, "cli_bam_outputs.json.gz"), "rt"))
+
+
+@pytest.mark.parametrize("name", sorted(BAMCLI))
+@pytest.mark.parametrize("tag", ["sam_Ru", "sam_B3"])
+def test_cli_bam_input_matches_reference_binary(name, tag, tmp_path):
+    """-a x.bam (and -b x.bam for pairs: mates in alternating records) read natively from BGZF/BAM: same SAM as the real
+    binary, including its -B behaviour on BAM input (the index moves, no record is skipped)"""
+    sys_path = os.path.join(ROOT, "tests", "golden")
+    import sys
+    sys.path.insert(0, sys_path)
+    import bam_util
+    from make_golden_bam import bam_records
+    meta, arr, fasta = G.load(name)
+    run = BAMCLI[name][tag]
+    pe = meta["kind"] == "pe"
+    bam = str(tmp_path / "r.bam")
+    bam_util.write_bam(bam, bam_records(meta), block=7000)
+    out = str(tmp_path / "o.sam")
+    cmd = [BIN, "-a", bam] + (["-b", bam] if pe else []) + ["-d", fasta, "-o", out] + list(run["options"])
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, BSX_BATCH="97"))
+    assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-1500:]
+    leaky = _leaky_names(meta)
+
+    def keep(ln):
+        return ln.split("\t")[0] not in leaky
+
+    got, exp = [l for l in _body(open(out).read()) if keep(l)], [l for l in _body(run["out"]) if keep(l)]
+    assert len(got) == len(exp) and len(got) > 30
+    for g_, e_ in zip(got, exp):
+        assert g_ == e_

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.fixture(scope="module")
 def harness(tmp_path_factory):
     exe = str(tmp_path_factory.mktemp("rh") / "reader_check")
-    subprocess.run(["g++", "-O1", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "harness", "reader_check.cpp")], check=True)
+    subprocess.run(["g++", "-O1", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "harness", "reader_check.cpp"), "-lz"], check=True)
     return exe
 
 
@@ -75,3 +75,27 @@ def test_reader_large_random(harness, tmp_path):
         f.write(_fastq(rng, 5000, odd=True))
     fast, stream = _run(harness, path, 512)
     assert fast == stream and fast.count(b"\n") > 5000
+
+
+def test_reader_bam_records(harness, tmp_path):
+    """BAM input (BGZF blocks + alignment records) read natively: names, bases (4-bit codes), qualities (+33), truncation to
+    the read-length cap, record boundaries that straddle BGZF blocks; paired mode takes alternating records"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import bam_util
+    rng = random.Random(5)
+    reads = []
+    for i in range(300):
+        L = rng.randint(1, 180)
+        reads.append((f"r{i}", "".join(rng.choice("ACGTN") for _ in range(L)), "".join(chr(rng.randint(33, 73)) for _ in range(L))))
+    path = str(tmp_path / "r.bam")
+    bam_util.write_bam(path, [bam_util.record(n, s, q) for n, s, q in reads], block=997)
+    fast, stream = _run(harness, path, batch=64, maxlen=144)
+    lines = [l.split(b"\t") for l in fast.split(b"\n") if l and not l.startswith(b"--")]
+    assert len(lines) == len(reads)
+    for (i, (n, s, q)), l in zip(enumerate(reads), lines):
+        assert (int(l[0]), l[1].decode(), l[2].decode(), l[3].decode()) == (i, n, s[:144], q[:144])
+    # -B 5 -E 20 on BAM: the index starts at 4, no record is skipped (the reference's behaviour)
+    fast, _ = _run(harness, path, batch=64, start=5, end=20, maxlen=144)
+    lines = [l.split(b"\t") for l in fast.split(b"\n") if l and not l.startswith(b"--")]
+    assert [int(l[0]) for l in lines] == list(range(4, 20)) and lines[0][1] == b"r0"
