@@ -58,7 +58,7 @@ char rev_char(char c)
 void usage()
 {
     cout << "Usage:\tbsmap [options]\n"
-         << "       -a  <str>   query a file, FASTA/FASTQ format\n"
+         << "       -a  <str>   query a file, FASTA/FASTQ/BAM format\n"
          << "       -d  <str>   reference sequences file, FASTA format\n"
          << "       -o  <str>   output alignment file, BSP/SAM format\n"
          << "\n  Options for alignment:\n"
@@ -512,18 +512,28 @@ int main(int argc, char **argv)
     cout << "start from read #" << o.read_start << "\tend at read #" << o.read_end << endl;
     cout << "additional alignment: " << (char)toupper(p.read_nt) << " in reads => " << (char)toupper(p.ref_nt) << " in reference" << endl;
     if (o.a_file.empty()) { cerr << "missing query file(s)\n"; exit(1); }
-    FILE *fout = fopen(o.out_file.c_str(), "wb");
-    if (!fout) { cerr << "failed to open output file (check -o option): " << o.out_file << endl; exit(1); }
-    FILE *fout_unpair = nullptr;
+    // output files are written with pwrite at running offsets: the chunks of a batch go out in parallel
+    const int fout = ::open(o.out_file.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (fout < 0) { cerr << "failed to open output file (check -o option): " << o.out_file << endl; exit(1); }
+    int fout_unpair = -1;
+    off_t off_out = 0, off_unpair = 0;
+    auto write_all = [](int fd, const char *p_, size_t n_, off_t at) {
+        while (n_) {
+            const ssize_t w = pwrite(fd, p_, n_, at);
+            if (w <= 0) { cerr << "write error on the output file\n"; exit(1); }
+            p_ += w; n_ -= (size_t)w; at += w;
+        }
+    };
     if (o.out_sam) {
         Text h;
         h.put("@HD\tVN:1.0\n");
         for (uint32_t c = 0; c < n_chr; c++) { h.put("@SQ\tSN:"); h.put(rv.names[c]); h.put("\tLN:"); h.put_u(rv.chr_size[c]); h.put('\n'); }
         h.put("@PG\tID:BSMAP_"); h.put(version); h.put('\n');
-        fwrite(h.s.data(), 1, h.s.size(), fout);
+        write_all(fout, h.s.data(), h.s.size(), 0);
+        off_out = (off_t)h.s.size();
     } else if (pe) {
-        fout_unpair = fopen(o.out_unpair.c_str(), "wb");
-        if (!fout_unpair) { cerr << "failed to open output file for unpaired hits (check -2 option): " << o.out_unpair << endl; exit(1); }
+        fout_unpair = ::open(o.out_unpair.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+        if (fout_unpair < 0) { cerr << "failed to open output file for unpaired hits (check -2 option): " << o.out_unpair << endl; exit(1); }
     }
     bsx_batch *batches[2] = {nullptr, nullptr};
     for (int g = 0; g < 2; g++) {
@@ -636,16 +646,31 @@ int main(int argc, char **argv)
     for (long k = 0; ring.acquire(k, 3); k++) {  // write stage on the main thread
         const double t = now_s();
         Slot &s = ring.at(k);
-        for (const Text &x : s.out) if (!x.s.empty()) fwrite(x.s.data(), 1, x.s.size(), fout);
-        if (fout_unpair) for (const Text &x : s.out_unpair) if (!x.s.empty()) fwrite(x.s.data(), 1, x.s.size(), fout_unpair);
+        {
+            vector<thread> wt;
+            for (const Text &x : s.out) {
+                if (x.s.empty()) continue;
+                const off_t at = off_out;
+                off_out += (off_t)x.s.size();
+                wt.emplace_back([&write_all, &x, at, fout] { write_all(fout, x.s.data(), x.s.size(), at); });
+            }
+            if (fout_unpair >= 0)
+                for (const Text &x : s.out_unpair) {
+                    if (x.s.empty()) continue;
+                    const off_t at = off_unpair;
+                    off_unpair += (off_t)x.s.size();
+                    wt.emplace_back([&write_all, &x, at, fout_unpair] { write_all(fout_unpair, x.s.data(), x.s.size(), at); });
+                }
+            for (thread &t : wt) t.join();
+        }
         total = s.total_after;
         busy[3] += now_s() - t;
         cout << total << " reads finished. " << time(NULL) - t_begin << " secs passed" << endl;
         ring.release(k, 0);
     }
     t_parse.join(); t_gpu.join(); t_gpu2.join(); t_format.join();
-    fclose(fout);
-    if (fout_unpair) fclose(fout_unpair);
+    ::close(fout);
+    if (fout_unpair >= 0) ::close(fout_unpair);
     const double t_map1 = now_s();
     const Formatter &fmt = totals;
     char pct[64];
