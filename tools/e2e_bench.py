@@ -17,6 +17,14 @@ HG38 = [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345
 
 def run(a):
     """a: namespace with pairs, genome, dir, threads, keep; returns the result dict"""
+    try:
+        return _run(a)
+    finally:
+        if not a.keep:
+            shutil.rmtree(a.dir, ignore_errors=True)
+
+
+def _run(a):
     os.makedirs(a.dir, exist_ok=True)
     lens = [max(200000, int(x * a.genome)) for x in HG38]
     kw = dict(s=16, v=6, I=4, m=28, x=500, S=1, r=1, pairend=1)
@@ -84,8 +92,6 @@ def run(a):
     r = {"pairs": n, "genome_bp": int(sum(lens)), "fasta_bytes": os.path.getsize(fa), "fastq_bytes": sum(os.path.getsize(p) for p in fq), "sam_bytes": sam_bytes,
          "cli_wall_s": round(wall, 2), "timing": tim, "reads_per_s_mapping_phase": round(2 * n / tim["mapping_s"]), "reads_per_s_whole_process": round(2 * n / wall),
          "summary": summary, "prep_s": {"fasta": round(t_fa, 1), "fastq": round(t_fq, 1)}, "cpus": os.cpu_count()}
-    if not a.keep:
-        shutil.rmtree(a.dir, ignore_errors=True)
     return r
 
 
