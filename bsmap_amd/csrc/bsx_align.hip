@@ -1262,6 +1262,19 @@ struct HCursor { int level, sub, orient, have, paired; uint32_t c, W, n_active, 
 #define CAT_BEGIN(A) const u64 cat_t0_ = (A).dbg_cat ? __builtin_readcyclecounter() : 0
 #define CAT_END(A, k) do { if ((A).dbg_cat) { const u64 d_ = (u64)__builtin_readcyclecounter() - cat_t0_; K.vc[k] += d_; K.vn[k]++; if (lane == 0) { atomicAdd((u64 *)&(A).dbg_cat[k], d_); atomicMax((u64 *)&(A).dbg_cat[8 + (k)], d_); } } } while (0)
 
+// a survivor record as k_hscan leaves it (strand copy in hchr, global position in hloc) -> hit coordinates in place;
+// returns the lanes of `act` whose candidate lies inside its chromosome (align.cpp:273)
+__device__ __forceinline__ u64 surv_coords(const DevParams &P, const BlockLds &BL, SurvRec &r, int len, int lane, u64 act)
+{
+    bool ok = (act >> lane) & 1;
+    if (ok) {
+        uint32_t hchr, hloc, hkey;
+        ok = hit_coords(P, BL, r.hloc, r.hchr, len, hchr, hloc, hkey);
+        r.hchr = hchr; r.hloc = hloc; r.hkey = hkey;
+    }
+    return __ballot(ok);
+}
+
 // resumable SnpAlign for a deferred unit: 0 = call complete, 1 = the reference's SnpAlign returned early, 2 = a window
 // of the current list was published and the unit must wait for k_hscan
 __device__ int snp_align_heavy(const AlignArgs &A, const HeavyArgs &H, HState *S, uint32_t hidx, const BlockLds &BL, const MateLds &L, Mate &M,
@@ -1324,6 +1337,7 @@ __device__ int snp_align_heavy(const AlignArgs &A, const HeavyArgs &H, HState *S
                                     }
                                     if ((uint32_t)lane < total) r = H.tout[t0 + tg + my_t].surv[my_i];
                                     u64 m = total >= 64 ? ~0ull : ((1ull << total) - 1);
+                                    m &= surv_coords(P, BL, r, M.len, lane, m);
                                     if (total > BSX_GROUP_MIN) e = accept_group(P, M, SL, orient, mode, m, r.w_ord & 0xff, r.hchr, r.hloc, r.hkey, lane, ls);
                                     else
                                         while (m) {
@@ -1381,6 +1395,7 @@ __device__ int snp_align_heavy(const AlignArgs &A, const HeavyArgs &H, HState *S
                             SurvRec r = {0, 0, 0, 0};
                             if (i < nv) r = o->surv[i];
                             u64 m = __ballot(i < nv);
+                            m &= surv_coords(P, BL, r, M.len, lane, m);
                             if (__builtin_popcountll(m) > BSX_GROUP_MIN) {
                                 int ls;
                                 const int e = accept_group(P, M, SL, orient, mode, m, r.w_ord & 0xff, r.hchr, r.hloc, r.hkey, lane, ls);
@@ -1648,13 +1663,13 @@ __global__ __launch_bounds__(256, BSX_HSCAN_WAVES) void k_hscan(AlignArgs A, Hea
                 for (int u = 0; u < 4; u++) {
                     uint32_t w = p48[u], w01ref = 0;
                     if (need[u]) eval_tail(d3[u], r1[u], r2[u], rw, rm, p[u], p48[u], w, w01ref);
-                    bool pass = valid[u] && w <= thres0;
-                    uint32_t hchr = 0, hloc = 0, hkey = 0;
-                    if (pass) pass = hit_coords(P, BL, p[u], strand, len, hchr, hloc, hkey);
+                    // (chromosome / end-of-sequence test and hit coordinates are left to the control kernel's replay: the
+                    //  record carries the strand copy and the global position)
+                    const bool pass = valid[u] && w <= thres0;
                     const u64 m = __ballot(pass);
                     if (m) {
                         const uint32_t pos = nsurv + (uint32_t)__builtin_popcountll(m & lanemask_lt(lane));
-                        if (pass && pos < HS_SCAP) { SurvRec r; r.w_ord = w | ((idx[u] - tc0) << 8); r.hchr = hchr; r.hloc = hloc; r.hkey = hkey; o->surv[pos] = r; }
+                        if (pass && pos < HS_SCAP) { SurvRec r; r.w_ord = w | ((idx[u] - tc0) << 8); r.hchr = strand; r.hloc = p[u]; r.hkey = 0; o->surv[pos] = r; }
                         nsurv += (uint32_t)__builtin_popcountll(m);
                         if (nsurv > HS_SCAP) overflow = true;
                     }
