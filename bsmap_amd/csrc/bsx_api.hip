@@ -16,7 +16,7 @@
 
 static int g_waves_per_cu = 0;
 static int g_heavy_groups = 2;      // unit groups of the heavy pipeline that run out of phase (1 = strictly alternating passes)
-static int g_heavy_threshold = 8192;  // candidate-list length that sends a unit to the heavy pipeline
+static int g_heavy_threshold = 32768;  // candidate-list length that sends a unit to the heavy pipeline
 
 extern "C" int bsx_set_waves_per_cu(int w) { g_waves_per_cu = w; return BSX_OK; }
 extern "C" int bsx_set_heavy_threshold(int t) { g_heavy_threshold = t < 0 ? 0 : t; return BSX_OK; }

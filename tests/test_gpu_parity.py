@@ -276,7 +276,7 @@ def test_heavy_pipeline_forced_on_edge_cases(name, kw, spec, edge_genome, oracle
     try:
         test_edge_cases_vs_oracle(name, kw, spec, edge_genome, oracle)
     finally:
-        B.lib().bsx_set_heavy_threshold(8192)
+        B.lib().bsx_set_heavy_threshold(32768)
 
 
 def test_heavy_pipeline_is_used(edge_genome, oracle):
@@ -292,7 +292,7 @@ def test_heavy_pipeline_is_used(edge_genome, oracle):
         h1, c1 = sa.results()
         n_heavy = sa.heavy_units()
     finally:
-        B.lib().bsx_set_heavy_threshold(8192)
+        B.lib().bsx_set_heavy_threshold(32768)
     sa.Do_Batch()
     h2, c2 = sa.results()
     assert n_heavy > 20 and sa.heavy_units() == 0
