@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--in-flight", type=int, default=2, help="batches in flight per GPU (host threads, one device batch each): the latency-bound main "
                     "kernel of one batch overlaps the VALU-bound scan passes of the other; 1 = strictly one Do_Batch at a time")
     ap.add_argument("--waves-per-cu", type=int, default=0)
+    ap.add_argument("--heavy-limits", default="", help="tuning: units per round,scan-task pool of the heavy pipeline (library default 32768,524288)")
     ap.add_argument("--heavy-threshold", type=int, default=0, help="tuning: candidate-list length that defers a unit to the heavy pipeline (0 = library default)")
     ap.add_argument("--mode", default="pe", choices=["pe", "se"], help="pe = C3 (default, the metric's config); se = C2 (1x100, -v 4)")
     args = ap.parse_args()
@@ -65,6 +66,9 @@ def main():
         B.lib().bsx_set_waves_per_cu(args.waves_per_cu)
     if args.heavy_threshold:
         B.lib().bsx_set_heavy_threshold(args.heavy_threshold)
+    if args.heavy_limits:
+        u_, t_ = (int(x) for x in args.heavy_limits.split(","))
+        B.lib().bsx_set_heavy_limits(u_, t_)
     pe = args.mode == "pe"
     kw = dict(s=16, v=6, I=4, m=28, x=500, S=1, r=1, pairend=1) if pe else dict(s=16, v=4, I=4, S=1, r=1)
     read_len = 144 if pe else 100

@@ -1426,7 +1426,7 @@ __device__ int snp_align_heavy(const AlignArgs &A, const HeavyArgs &H, HState *S
                 if (!restart) K.W = min(K.W * HS_GROW, (uint32_t)HS_WINMAX);
             } else {
                 const uint32_t weff = K.n_active < 2048u ? (uint32_t)HS_WINMAX : K.W;  // few units left: scanning capacity is idle, speculate the whole list
-                const uint32_t wpool = H.task_cap * HS_TASK < weff ? H.task_cap * HS_TASK : weff;  // a window must fit the task pool
+                const uint32_t wpool = (u64)H.task_cap * HS_TASK < (u64)weff ? H.task_cap * HS_TASK : weff;  // a window must fit the task pool
                 const uint32_t wn = min(wpool, cl.total - K.c), nt = (wn + HS_TASK - 1) / HS_TASK;
                 uint32_t t0 = 0;
                 if (lane == 0) t0 = atomicAdd(H.n_tasks, nt);

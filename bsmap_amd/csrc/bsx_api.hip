@@ -20,10 +20,10 @@ static int g_heavy_threshold = 32768;  // candidate-list length that sends a uni
 
 extern "C" int bsx_set_waves_per_cu(int w) { g_waves_per_cu = w; return BSX_OK; }
 extern "C" int bsx_set_heavy_threshold(int t) { g_heavy_threshold = t < 0 ? 0 : t; return BSX_OK; }
-static uint32_t g_hcap = 32768, g_task_cap = 262144;
+static uint32_t g_hcap = 32768, g_task_cap = 524288;
 extern "C" int bsx_set_heavy_limits(uint32_t units_per_round, uint32_t task_pool)
 {
-    if (units_per_round < 1 || task_pool < 1) return BSX_ERR_ARG;
+    if (units_per_round < 1 || task_pool < 2 || task_pool > (1u << 22)) return BSX_ERR_ARG;  // (a task record is 8 KB: 2^22 tasks = 34 GB)
     g_hcap = units_per_round; g_task_cap = task_pool;
     return BSX_OK;
 }

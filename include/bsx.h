@@ -181,7 +181,7 @@ int bsx_set_waves_per_cu(int waves);
 /* tuning knob: candidate-list length (one SnpAlign call, one read orientation) from which a unit is handed to the
  * heavy pipeline (chip-wide scan tasks + resumable control passes); 0 = never.  Results do not depend on it. */
 int bsx_set_heavy_threshold(int n_candidates);
-/* pool sizes of the heavy pipeline for batches created afterwards (defaults 32768 units per round, 262144 scan tasks);
+/* pool sizes of the heavy pipeline for batches created afterwards (defaults 32768 units per round, 524288 scan tasks; at most 2^22);
  * small values only make it take more rounds / passes — used by the tests to exercise those paths */
 int bsx_set_heavy_limits(uint32_t units_per_round, uint32_t task_pool);
 int bsx_batch_last_heavy_units(bsx_batch *b);   /* units the last run handed to the heavy pipeline */

@@ -404,4 +404,4 @@ def test_heavy_pipeline_small_pools(heavy_genome, oracle):
         test_heavy_pipeline_large_buckets(True, heavy_genome, oracle)
         test_heavy_pipeline_large_buckets(False, heavy_genome, oracle)
     finally:
-        B.lib().bsx_set_heavy_limits(32768, 262144)
+        B.lib().bsx_set_heavy_limits(32768, 524288)
