@@ -205,7 +205,7 @@ def test_edge_cases_vs_oracle(name, kw, spec, edge_genome, oracle):
             assert np.array_equal(ores[f][has], hits[f][has]), f
         assert np.array_equal(ores["chain"][has], (hits["flags"][has] >> 1) & 1)
         assert [int(x) for x in sa.counters()[:4]] == ocnt
-        assert has.sum() > 0.2 * len(reads)
+        assert has.sum() > spec.get("min_frac", 0.2) * len(reads)
         sa.close()
     else:
         pairs = td.make_pe_reads(g, spec["n"], spec["length"], seed=8, sub_rate=0.015, qual_tail=trim, adapter=ADAPTER if trim else None,
@@ -235,10 +235,39 @@ def test_edge_cases_vs_oracle(name, kw, spec, edge_genome, oracle):
             for f in ("chr", "loc", "best_class"):
                 assert np.array_equal(ores[m][f][sel], out[m][f][sel]), (m, f)
         assert [int(x) for x in pa.counters()[:4]] == ocnt
-        assert pr.sum() > 0.2 * len(pairs)
+        assert pr.sum() > spec.get("min_frac", 0.2) * len(pairs)
         pa.close()
     gref.close()
     oref.free()
+
+
+def _random_config(seed):
+    """a seeded draw from the option space of the command line (main.cpp:234-289)"""
+    import random
+    rng = random.Random(seed)
+    pe = rng.random() < 0.5
+    kw = dict(s=rng.randint(9, 16), v=rng.choice([0, 1, 2, 3, 4, 5, 6, 8, 11]), I=rng.choice([1, 2, 3, 4, 4, 5, 8]), S=rng.randint(1, 99),
+              r=rng.choice([0, 1, 1]), n=rng.choice([0, 1]), w=rng.choice([1, 2, 7, 50, 1000]), f=rng.choice([0, 2, 5]),
+              L=rng.choice([144, 144, 100, 61]))
+    if rng.random() < 0.3:
+        kw["M"] = rng.choice(["GA", "CT", "AG", "TG"])
+    trim = rng.random() < 0.4
+    if trim:
+        kw.update(q=rng.choice([5, 20, 30]), A=[ADAPTER])
+    if pe:
+        kw.update(m=rng.choice([0, 28, 120]), x=rng.choice([250, 500, 900]))
+        kw.pop("n")  # (-n only changes single-end strand coverage in the paired driver: both mates are always placed)
+    spec = dict(kind="pe" if pe else "se", n=1500 if pe else 2500, length=rng.choice([150, 120, 80]), var=rng.random() < 0.5, trim=trim,
+                sub=0.004, min_frac=-1 if ("M" in kw or kw["v"] == 0) else 0.02)  # (the reads are C->T converted and carry errors: with another -M pair or -v 0 few align)
+    return kw, spec
+
+
+@pytest.mark.parametrize("seed", list(range(101, 221)))
+def test_random_option_combinations_vs_oracle(seed, edge_genome, oracle):
+    """120 seeded draws from the option space (seed size, mismatches, interval, -w, -r, -n, -M, -f, -L, trimming, insert
+    range, single / paired) through the same comparison as the edge cases: index, every count, every pick, work counters"""
+    kw, spec = _random_config(seed)
+    test_edge_cases_vs_oracle(f"fuzz{seed}", kw, spec, edge_genome, oracle)
 
 
 def test_empty_and_degenerate_inputs(edge_genome, oracle):
