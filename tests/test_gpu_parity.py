@@ -393,6 +393,21 @@ def test_heavy_pipeline_caps_and_early_returns(extra, heavy_genome, oracle):
         test_heavy_pipeline_large_buckets(True, heavy_genome, oracle, extra)
 
 
+@pytest.mark.parametrize("seed", list(range(1, 9)))
+def test_heavy_pipeline_random_options(seed, heavy_genome, oracle):
+    """seeded option draws on the microsatellite genome: windows, restarts, grouped acceptance and caps under other
+    thresholds, hit caps, strand modes, read-length caps and insert ranges"""
+    import random
+    rng = random.Random(1000 + seed)
+    extra = dict(v=rng.choice([3, 4, 5, 6, 8]), w=rng.choice([1, 5, 40, 300, 1000]), r=rng.choice([0, 1, 1]), S=rng.randint(1, 50), L=rng.choice([144, 144, 110]))
+    pe = seed % 2 == 0
+    if pe:
+        extra.update(m=rng.choice([0, 28, 150]), x=rng.choice([300, 500, 800]))
+    else:
+        extra.update(n=rng.choice([0, 1]))
+    test_heavy_pipeline_large_buckets(pe, heavy_genome, oracle, extra)
+
+
 def test_batch_reuse_and_argument_checks(edge_genome, oracle):
     """one device batch used for batches of different sizes, and the error codes of calls made out of order"""
     g, fa = edge_genome
