@@ -270,6 +270,73 @@ def test_random_option_combinations_vs_oracle(seed, edge_genome, oracle):
     test_edge_cases_vs_oracle(f"fuzz{seed}", kw, spec, edge_genome, oracle)
 
 
+@pytest.mark.parametrize("seed", list(range(1, 25)))
+def test_rrbs_random_options_vs_oracle(seed, oracle, tmp_path_factory):
+    """RRBS mode (-D, site-anchored index, segment tags, fragment-size filter, short-fragment fix) under seeded option draws,
+    single reads (with and without -n 1) and pairs; reads start at digestion sites of a CpG-rich genome"""
+    import random
+    rng = random.Random(500 + seed)
+    if not hasattr(test_rrbs_random_options_vs_oracle, "_g"):
+        g = td.make_genome(seed=11, chr_lens=(400_000, 120_000), gc=0.55, cpg_sites=900, repeats=30, microsats=10)
+        fa = str(tmp_path_factory.mktemp("rrbs") / "g.fa")
+        td.write_fasta(fa, g)
+        test_rrbs_random_options_vs_oracle._g = (g, fa)
+    g, fa = test_rrbs_random_options_vs_oracle._g
+    pe = seed % 3 == 0
+    kw = dict(D=rng.choice(["C-CGG", "C-CGG", "CCG-G", "-CCGG"]), v=rng.choice([0, 1, 2, 3, 5]), S=rng.randint(1, 90), r=rng.choice([0, 1, 1]), w=rng.choice([1, 3, 100, 1000]),
+              m=rng.choice([20, 40, 80]), x=rng.choice([150, 220, 400]), L=rng.choice([144, 75, 50]))
+    if not pe:
+        kw["n"] = rng.choice([0, 1])
+    else:
+        kw["pairend"] = 1
+    oref = oracle.OracleRef(oracle.make_params(**kw), fasta_path=fa)
+    gref = B.RefSeq(B.make_params(**kw)).Run_ConvertBinseq(fasta_path=fa).CreateIndex()
+    off, nf, ent = gref.index()
+    assert np.array_equal(off, oref.bucket_off()) and np.array_equal(np.asarray(ent).reshape(-1, 2), oref.rrbs_entries())
+    reads = td.make_rrbs_reads(g, 1500, rng.choice([75, 100, 36]), seed=seed, digest="CCGG", digest_pos=kw["D"].index("-"), sub_rate=0.006)
+    nclass = kw["v"] + 1
+    if not pe:
+        sb, so = oracle.pack_reads([r["seq"] for r in reads])
+        ores, ocnt = oracle.se_batch(oref, sb, so, threads=4)
+        sa = B.SingleAlign(gref, len(reads))
+        sa.ImportBatchReads((sb, so)).Do_Batch()
+        hits, cc = sa.results()
+        ok = ores["filtered"] == 0
+        assert np.array_equal(ores["filtered"] != 0, (hits["flags"] & 1) != 0) and np.array_equal(ores["len"], hits["len"])
+        assert np.array_equal(ores["n_hit"][ok][:, :nclass], cc["n_hit"][ok][:, :nclass]) and np.array_equal(ores["n_chit"][ok][:, :nclass], cc["n_chit"][ok][:, :nclass])
+        has = ok & (ores["n_best"] > 0)
+        for f in ("chr", "loc", "best_class"):
+            assert np.array_equal(ores[f][has], hits[f][has]), f
+        assert [int(x) for x in sa.counters()[:4]] == ocnt
+        if kw["D"] == "C-CGG" and kw["v"] >= 2 and kw["L"] >= 75:
+            assert has.sum() > 300, has.sum()  # the reads really are site-anchored fragments
+        sa.close()
+    else:
+        # mates: the read and the reverse complement of the fragment's other end are not generated here; pair each read with
+        # the next one — pairing mostly fails, which exercises the unpaired / short-fragment branches
+        s1, o1 = oracle.pack_reads([r["seq"] for r in reads])
+        s2, o2 = oracle.pack_reads([td.revcomp(r["seq"]) for r in reads[1:] + reads[:1]])
+        ores, ocnt = oracle.pe_batch(oref, s1, o1, s2, o2, threads=4)
+        pa = B.PairAlign(gref, len(reads))
+        pa.ImportBatchReads((s1, o1), (s2, o2)).Do_Batch()
+        out, ca, cb, npairs = pa.results()
+        assert np.array_equal(ores["paired"], out["paired"]) and np.array_equal(ores["n_pairs"][:, :2 * nclass - 1], npairs[:, :2 * nclass - 1])
+        up = (ores["tmp"] == 1) | (ores["paired"] == 0)
+        assert np.array_equal(up, out["unpaired_out"] != 0)
+        for f in ("chain", "na", "nb", "insert", "a_chr", "a_loc", "b_chr", "b_loc"):
+            assert np.array_equal(ores["pick"][f][~up], out[f][~up]), f
+        for m_, cnts in (("a", ca), ("b", cb)):
+            ok = ores[m_]["filtered"] == 0
+            assert np.array_equal(ores[m_]["n_hit"][ok][:, :nclass], cnts["n_hit"][ok][:, :nclass]) and np.array_equal(ores[m_]["n_chit"][ok][:, :nclass], cnts["n_chit"][ok][:, :nclass]), m_
+            sel = up & ok & (ores[m_]["n_best"] > 0)
+            for f in ("chr", "loc", "best_class"):
+                assert np.array_equal(ores[m_][f][sel], out[m_][f][sel]), (m_, f)
+        assert [int(x) for x in pa.counters()[:4]] == ocnt
+        pa.close()
+    gref.close()
+    oref.free()
+
+
 def test_empty_and_degenerate_inputs(edge_genome, oracle):
     """reads shorter than the seed, all-N reads, a read spanning a chromosome end, exact duplicates"""
     g, fa = edge_genome
