@@ -158,3 +158,43 @@ def test_rrbs(kw, genome, oracle):
                 assert ref.se_hits(orient, w, n) == al.se_hits(orient, w, n)
     al.free()
     o.free()
+
+
+def _random_case(seed):
+    """a seeded draw from the option space of the command line (main.cpp:234-289) — the same space the GPU path is
+    fuzzed over in tests/test_gpu_parity.py"""
+    import random
+    rng = random.Random(seed)
+    kw = dict(s=rng.randint(9, 16), v=rng.choice([0, 1, 2, 3, 4, 5, 6, 8, 11]), I=rng.choice([1, 2, 3, 4, 4, 5, 8]), S=rng.randint(1, 99),
+              r=rng.choice([0, 1, 1]), n=rng.choice([0, 1]), w=rng.choice([1, 2, 7, 50, 1000]), f=rng.choice([0, 2, 5]),
+              L=rng.choice([144, 144, 100, 61]), out_sam=1)
+    if rng.random() < 0.3:
+        kw["M"] = rng.choice(["GA", "CT", "AG", "TG"])
+    trim = rng.random() < 0.4
+    if trim:
+        kw.update(q=rng.choice([5, 20, 30]), A=[ADAPTER])
+    return kw, trim, rng
+
+
+@pytest.mark.parametrize("seed", list(range(301, 321)))
+def test_se_random_options(seed, genome, oracle):
+    kw, trim, rng = _random_case(seed)
+    test_se(dict(kw=kw, length=rng.choice([150, 120, 80, 40]), sub=0.006, var=rng.random() < 0.5, trim=trim, n=500), genome, oracle)
+
+
+@pytest.mark.parametrize("seed", list(range(401, 413)))
+def test_pe_random_options(seed, genome, oracle):
+    kw, trim, rng = _random_case(seed)
+    kw.pop("n")
+    kw.update(m=rng.choice([0, 28, 120]), x=rng.choice([250, 500, 900]))
+    test_pe(dict(kw=kw, length=rng.choice([150, 120, 80]), trim=trim), genome, oracle)
+
+
+@pytest.mark.parametrize("seed", list(range(501, 509)))
+def test_rrbs_random_options(seed, genome, oracle):
+    import random
+    rng = random.Random(seed)
+    kw = dict(D=rng.choice(["C-CGG", "C-CGG", "CCG-G", "-CCGG"]), v=rng.choice([0, 1, 2, 3, 5]), S=rng.randint(1, 90), r=rng.choice([0, 1, 1]),
+              w=rng.choice([1, 3, 100, 1000]), m=rng.choice([20, 40, 80]), x=rng.choice([150, 220, 400]), L=rng.choice([144, 75, 50]),
+              n=rng.choice([0, 1]), out_sam=1)
+    test_rrbs(kw, genome, oracle)
