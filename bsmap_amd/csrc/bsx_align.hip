@@ -1609,7 +1609,7 @@ __global__ __launch_bounds__(256, BSX_HSCAN_WAVES) void k_hscan(AlignArgs A, Hea
 #pragma unroll
         for (int k = 0; k < 9; k++) { rw[k] = rfl(R.rw[k]); rm[k] = rfl(R.rm[k]); }
         const uint32_t thres0 = rfl(R.thres), nsub = min(rfl(R.nsub), 32u);
-        const int nwords = (int)rfl(R.nwords), len = (int)rfl(R.len);
+        const int nwords = (int)rfl(R.nwords);
         wave_fence();
         HTaskOut *o = &H.tout[t];
         uint32_t nsurv = 0, a0 = 0, a1 = 0, a2 = 0, a5 = 0;
