@@ -1,0 +1,353 @@
+// bsx_meth.hip — methylation-ratio pile-up on the GPU (reference: methratio.py of the BSMAP tree).
+//
+// The reference walks the alignments one by one in Python: duplicate removal by fragment end (methratio.py:50-54),
+// fill-in trimming (:55-63), then for every reference C (G on the minus strand) under the read one or two counter
+// increments (:104-114), optionally folding CpG pairs (:118-128), and a table of the covered cytosines (:135-151).
+// Here the per-alignment part runs as one wave per alignment with atomic counters in HBM:
+//   k_meth_first   input-order duplicate removal: atomicMin of the alignment's global index on its fragment-end slot
+//   k_meth_pile    trim, bounds test, compare read and reference letters, atomicAdd on depth / methylated counters
+//   k_meth_cpg     fold the G of every CG into its C
+//   k_meth_count / k_meth_emit   ordered compaction of the positions the table will list
+// The host side (bsmap_amd/methratio.py) parses the option surface, the FASTA and the BSP / SAM lines, and prints the
+// table with the reference's arithmetic.  All counters are integers: results are exact.
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+
+#include "bsx_internal.h"
+
+namespace {
+
+typedef unsigned long long u64;
+
+struct MethDev {
+    const uint8_t *ref;      // all chromosomes, upper-case letters, concatenated
+    const u64 *chr_off;      // [n_chr+1] offsets into ref / depth / meth
+    uint32_t *depth, *meth;  // per reference position
+    uint32_t *first;         // [2][total] fragment-end slots of the duplicate filter (direction 1, 2), or null
+    u64 total;
+    uint32_t n_chr;
+};
+
+struct AlnBatch {
+    const uint32_t *chr;
+    const int64_t *pos;        // 0-based leftmost reference position of the (untrimmed) read
+    const uint8_t *strand;     // 0 '++', 1 '-+', 2 '+-', 3 '--'   (first char: reference strand, second: read orientation)
+    const int32_t *insert;     // BSP column 8 / SAM TLEN
+    const int64_t *cut_at;     // SAM with insert > 0: PNEXT-1 (the read is cut where its mate starts); -1 otherwise
+    const uint8_t *seq;
+    const u64 *seq_off;
+    uint32_t n, index_base, trim_fillin;
+};
+
+// Python's s[a:b] on a string of length n (a, b may be negative or past the ends) as [lo, hi)
+__device__ __forceinline__ void py_slice(int64_t n, bool has_a, int64_t a, bool has_b, int64_t b, int64_t &lo, int64_t &hi)
+{
+    lo = 0; hi = n;
+    if (has_a) { if (a < 0) a += n; lo = a < 0 ? 0 : (a > n ? n : a); }
+    if (has_b) { if (b < 0) b += n; hi = b < 0 ? 0 : (b > n ? n : b); }
+    if (hi < lo) hi = lo;
+}
+
+__device__ __forceinline__ bool dup_slot(const MethDev &M, const AlnBatch &B, uint32_t i, u64 &slot)
+{
+    const uint32_t c = B.chr[i];
+    const int64_t len = (int64_t)(B.seq_off[i + 1] - B.seq_off[i]), clen = (int64_t)(M.chr_off[c + 1] - M.chr_off[c]);
+    const uint32_t st = B.strand[i];
+    const bool end_side = st == 2 || st == 1;  // '+-' or '-+': the fragment end is the read's right end (methratio.py:51)
+    const int64_t fe = end_side ? B.pos[i] + len : B.pos[i];
+    if (fe < 0 || fe >= clen) return false;    // (the reference would index outside its coverage array here)
+    slot = (end_side ? M.total : 0) + M.chr_off[c] + (u64)fe;
+    return true;
+}
+
+__global__ void k_meth_first(MethDev M, AlnBatch B)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B.n) return;
+    u64 slot;
+    if (dup_slot(M, B, i, slot)) atomicMin(&M.first[slot], B.index_base + i);
+}
+
+// one wave per alignment
+__global__ __launch_bounds__(256) void k_meth_pile(MethDev M, AlnBatch B, u64 *n_valid)
+{
+    const uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (i >= B.n) return;
+    if (M.first) {
+        u64 slot;
+        if (dup_slot(M, B, i, slot) && M.first[slot] != B.index_base + i) return;  // an earlier alignment owns this fragment end
+    }
+    const uint32_t c = B.chr[i], st = B.strand[i];
+    const int64_t n0 = (int64_t)(B.seq_off[i + 1] - B.seq_off[i]), clen = (int64_t)(M.chr_off[c + 1] - M.chr_off[c]);
+    int64_t pos = B.pos[i], lo = 0, hi = n0;  // the read letters that survive are seq[lo:hi), aligned at pos
+    const int64_t t = (int64_t)B.trim_fillin, ins = B.insert[i];
+    if (t > 0) {  // methratio.py:55-63
+        if (st == 2) py_slice(n0, false, 0, true, -t, lo, hi);                         // '+-': seq[:-t]
+        else if (st == 3) { py_slice(n0, true, t, false, 0, lo, hi); pos += t; }       // '--': seq[t:], pos + t
+        else if (ins != 0 && n0 > (ins < 0 ? -ins : ins) - t) {
+            const int64_t trim_nt = n0 - ((ins < 0 ? -ins : ins) - t);
+            if (st == 0) py_slice(n0, false, 0, true, -trim_nt, lo, hi);               // '++': seq[:-trim_nt]
+            else if (st == 1) { py_slice(n0, true, trim_nt, false, 0, lo, hi); pos += trim_nt; }  // '-+': seq[trim_nt:]
+        }
+    }
+    if (B.cut_at[i] >= 0) {  // SAM, insert > 0: seq[:PNEXT-1-pos]  (methratio.py:64)
+        int64_t l2, h2;
+        py_slice(hi - lo, false, 0, true, B.cut_at[i] - pos, l2, h2);
+        hi = lo + h2;
+    }
+    const int64_t len = hi - lo;
+    if (pos + len > clen) return;  // methratio.py:100
+    if (lane == 0) atomicAdd(n_valid, 1ull);
+    if (pos < 0) return;           // (a negative position would make the reference slice from the chromosome's end: never produced by bsmap)
+    const uint8_t match = (st & 1) ? 'G' : 'C', convert = (st & 1) ? 'A' : 'T';  // strand[0]: '+' -> C/T, '-' -> G/A
+    const uint8_t *s = B.seq + B.seq_off[i] + lo;
+    const u64 g0 = M.chr_off[c] + (u64)pos;
+    for (int64_t k = lane; k < len; k += 64) {
+        if (M.ref[g0 + k] != match) continue;
+        const uint8_t ch = s[k];
+        if (ch == convert) atomicAdd(&M.depth[g0 + k], 1u);
+        else if (ch == match) { atomicAdd(&M.meth[g0 + k], 1u); atomicAdd(&M.depth[g0 + k], 1u); }
+    }
+}
+
+__global__ void k_meth_cpg(MethDev M)
+{
+    // every "CG" of every chromosome (occurrences cannot overlap): the G's counters move onto the C  (methratio.py:118-128)
+    for (u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x; g + 1 < M.total; g += (u64)gridDim.x * blockDim.x) {
+        if (M.ref[g] != 'C' || M.ref[g + 1] != 'G') continue;
+        // (a C that is the last letter of a chromosome must not pair with the first letter of the next one)
+        uint32_t lo = 0, hi = M.n_chr;
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) / 2; if (M.chr_off[mid] <= g) lo = mid; else hi = mid; }
+        if (g + 1 >= M.chr_off[lo + 1]) continue;
+        M.depth[g] += M.depth[g + 1]; M.meth[g] += M.meth[g + 1];
+        M.depth[g + 1] = 0; M.meth[g + 1] = 0;
+    }
+}
+
+// table rows of one chromosome, in position order: blocks of 1024 positions are counted, scanned, and emitted
+__global__ __launch_bounds__(256) void k_meth_count(MethDev M, u64 g0, u64 n, uint32_t min_depth, int meth0, uint32_t *blk_rows, u64 *nc_nd)
+{
+    __shared__ uint32_t s_rows;
+    __shared__ u64 s_nc, s_nd;
+    if (threadIdx.x == 0) { s_rows = 0; s_nc = 0; s_nd = 0; }
+    __syncthreads();
+    uint32_t rows = 0; u64 nc = 0, nd = 0;
+    for (int r = 0; r < 4; r++) {
+        const u64 k = (u64)blockIdx.x * 1024 + (u64)r * 256 + threadIdx.x;
+        if (k >= n) continue;
+        const uint32_t d = M.depth[g0 + k], m = M.meth[g0 + k];
+        if (d < min_depth) continue;
+        nc++; nd += d;
+        if (m != 0 || meth0) rows++;
+    }
+    atomicAdd(&s_rows, rows); atomicAdd(&s_nc, nc); atomicAdd(&s_nd, nd);
+    __syncthreads();
+    if (threadIdx.x == 0) { blk_rows[blockIdx.x] = s_rows; if (s_nc) { atomicAdd(&nc_nd[0], s_nc); atomicAdd(&nc_nd[1], s_nd); } }
+}
+
+__global__ __launch_bounds__(256) void k_meth_emit(MethDev M, u64 g0, u64 n, uint32_t min_depth, int meth0, const uint32_t *blk_start, uint32_t *out_pos,
+                                                   uint32_t *out_depth, uint32_t *out_meth)
+{
+    __shared__ uint32_t s_wave[4];
+    uint32_t base = blk_start[blockIdx.x];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int r = 0; r < 4; r++) {  // positions blockIdx*1024 + r*256 + thread: ascending with (r, thread)
+        const u64 k = (u64)blockIdx.x * 1024 + (u64)r * 256 + threadIdx.x;
+        uint32_t d = 0, m = 0;
+        bool row = false;
+        if (k < n) { d = M.depth[g0 + k]; m = M.meth[g0 + k]; row = d >= min_depth && (m != 0 || meth0); }
+        const u64 bal = __ballot(row);
+        if (lane == 0) s_wave[wv] = (uint32_t)__builtin_popcountll(bal);
+        __syncthreads();
+        uint32_t off = base;
+        for (int w = 0; w < wv; w++) off += s_wave[w];
+        if (row) {
+            const uint32_t o = off + (uint32_t)__builtin_popcountll(bal & ((1ull << lane) - 1));
+            out_pos[o] = (uint32_t)k; out_depth[o] = d; out_meth[o] = m;
+        }
+        base += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+struct bsx_meth {
+    int device = 0;
+    uint32_t n_chr = 0;
+    std::vector<u64> chr_off;
+    uint8_t *d_ref = nullptr;
+    u64 *d_chr_off = nullptr, *d_counts = nullptr;  // d_counts: [0] valid alignments, [1] nc, [2] nd
+    uint32_t *d_depth = nullptr, *d_meth = nullptr, *d_first = nullptr;
+    uint32_t index_base = 0;
+    hipStream_t stream = nullptr;
+    // report buffers of the last bsx_meth_report_chr
+    uint32_t *d_blk = nullptr, *d_blk_start = nullptr, *d_out[3] = {nullptr, nullptr, nullptr};
+    size_t blk_cap = 0, out_cap = 0;
+    void *d_temp = nullptr; size_t temp_cap = 0;
+    uint32_t last_rows = 0;
+    MethDev dev() const { MethDev M; M.ref = d_ref; M.chr_off = d_chr_off; M.depth = d_depth; M.meth = d_meth; M.first = d_first; M.total = chr_off.back(); M.n_chr = n_chr; return M; }
+};
+
+extern "C" void bsx_meth_destroy(bsx_meth *m)
+{
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    for (void *q : {(void *)m->d_ref, (void *)m->d_chr_off, (void *)m->d_counts, (void *)m->d_depth, (void *)m->d_meth, (void *)m->d_first, (void *)m->d_blk,
+                    (void *)m->d_blk_start, (void *)m->d_out[0], (void *)m->d_out[1], (void *)m->d_out[2], m->d_temp})
+        if (q) (void)hipFree(q);
+    if (m->stream) (void)hipStreamDestroy(m->stream);
+    delete m;
+}
+
+extern "C" int bsx_meth_create(uint32_t n_chr, const uint64_t *chr_len, int rm_dup, int device, bsx_meth **out)
+{
+    if (!n_chr || !chr_len || !out) return BSX_ERR_ARG;
+    int nd = 0;
+    if (hipGetDeviceCount(&nd) != hipSuccess || nd <= 0) { g_bsx_err = "no HIP device visible; libbsx has no CPU fallback"; return BSX_ERR_NODEVICE; }
+    if (device < 0 || device >= nd) return BSX_ERR_NODEVICE;
+    HIP_TRY(hipSetDevice(device));
+    bsx_meth *m = new bsx_meth();
+    m->device = device; m->n_chr = n_chr;
+    m->chr_off.assign(1, 0);
+    for (uint32_t c = 0; c < n_chr; c++) m->chr_off.push_back(m->chr_off.back() + chr_len[c]);
+    const u64 total = m->chr_off.back();
+    auto fail = [&](int rc) { bsx_meth_destroy(m); return rc; };
+    if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) return fail(BSX_ERR_DEVICE);
+    if (hipMalloc((void **)&m->d_ref, total + 16) != hipSuccess || hipMalloc((void **)&m->d_depth, (total + 16) * 4) != hipSuccess ||
+        hipMalloc((void **)&m->d_meth, (total + 16) * 4) != hipSuccess || hipMalloc((void **)&m->d_chr_off, (n_chr + 1) * 8) != hipSuccess ||
+        hipMalloc((void **)&m->d_counts, 64) != hipSuccess)
+        return fail(BSX_ERR_NOMEM);
+    if (rm_dup && hipMalloc((void **)&m->d_first, 2 * (total + 16) * 4) != hipSuccess) return fail(BSX_ERR_NOMEM);
+    if (hipMemsetAsync(m->d_ref, 0, total + 16, m->stream) != hipSuccess || hipMemsetAsync(m->d_depth, 0, (total + 16) * 4, m->stream) != hipSuccess ||
+        hipMemsetAsync(m->d_meth, 0, (total + 16) * 4, m->stream) != hipSuccess || hipMemsetAsync(m->d_counts, 0, 64, m->stream) != hipSuccess)
+        return fail(BSX_ERR_DEVICE);
+    if (rm_dup && hipMemsetAsync(m->d_first, 0xff, 2 * (total + 16) * 4, m->stream) != hipSuccess) return fail(BSX_ERR_DEVICE);
+    if (hipMemcpyAsync(m->d_chr_off, m->chr_off.data(), (n_chr + 1) * 8, hipMemcpyHostToDevice, m->stream) != hipSuccess) return fail(BSX_ERR_DEVICE);
+    if (hipStreamSynchronize(m->stream) != hipSuccess) return fail(BSX_ERR_DEVICE);
+    *out = m;
+    return BSX_OK;
+}
+
+extern "C" int bsx_meth_set_reference(bsx_meth *m, uint32_t chr, const char *upper_seq)
+{
+    if (!m || chr >= m->n_chr || !upper_seq) return BSX_ERR_ARG;
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipMemcpy(m->d_ref + m->chr_off[chr], upper_seq, m->chr_off[chr + 1] - m->chr_off[chr], hipMemcpyHostToDevice));
+    return BSX_OK;
+}
+
+extern "C" int bsx_meth_add(bsx_meth *m, uint32_t n, const uint32_t *chr, const int64_t *pos, const uint8_t *strand, const int32_t *insert, const int64_t *cut_at,
+                            const char *seqs, const uint64_t *seq_off, uint32_t trim_fillin)
+{
+    if (!m || (n && (!chr || !pos || !strand || !insert || !cut_at || !seqs || !seq_off))) return BSX_ERR_ARG;
+    if (!n) return BSX_OK;
+    if ((u64)m->index_base + n >= 0xFFFFFFFFull) return BSX_ERR_LIMIT;
+    for (uint32_t i = 0; i < n; i++) if (chr[i] >= m->n_chr || strand[i] > 3) return BSX_ERR_ARG;
+    HIP_TRY(hipSetDevice(m->device));
+    const u64 nbytes = seq_off[n];
+    uint32_t *d_chr = nullptr; int64_t *d_pos = nullptr, *d_cut = nullptr; uint8_t *d_strand = nullptr, *d_seq = nullptr; int32_t *d_ins = nullptr; u64 *d_off = nullptr;
+    int rc = BSX_OK;
+    auto chk = [&](hipError_t e) { if (e != hipSuccess && rc == BSX_OK) rc = bsx_hip_fail(e, "bsx_meth_add", __FILE__, __LINE__); };
+    chk(hipMalloc((void **)&d_chr, (size_t)n * 4)); chk(hipMalloc((void **)&d_pos, (size_t)n * 8)); chk(hipMalloc((void **)&d_cut, (size_t)n * 8));
+    chk(hipMalloc((void **)&d_strand, n)); chk(hipMalloc((void **)&d_ins, (size_t)n * 4)); chk(hipMalloc((void **)&d_seq, nbytes + 16)); chk(hipMalloc((void **)&d_off, ((size_t)n + 1) * 8));
+    if (rc == BSX_OK) {
+        chk(hipMemcpyAsync(d_chr, chr, (size_t)n * 4, hipMemcpyHostToDevice, m->stream)); chk(hipMemcpyAsync(d_pos, pos, (size_t)n * 8, hipMemcpyHostToDevice, m->stream));
+        chk(hipMemcpyAsync(d_cut, cut_at, (size_t)n * 8, hipMemcpyHostToDevice, m->stream)); chk(hipMemcpyAsync(d_strand, strand, n, hipMemcpyHostToDevice, m->stream));
+        chk(hipMemcpyAsync(d_ins, insert, (size_t)n * 4, hipMemcpyHostToDevice, m->stream)); chk(hipMemcpyAsync(d_seq, seqs, nbytes, hipMemcpyHostToDevice, m->stream));
+        chk(hipMemcpyAsync(d_off, seq_off, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, m->stream));
+    }
+    if (rc == BSX_OK) {
+        AlnBatch B; B.chr = d_chr; B.pos = d_pos; B.strand = d_strand; B.insert = d_ins; B.cut_at = d_cut; B.seq = d_seq; B.seq_off = d_off;
+        B.n = n; B.index_base = m->index_base; B.trim_fillin = trim_fillin;
+        const MethDev M = m->dev();
+        if (m->d_first) hipLaunchKernelGGL(k_meth_first, dim3((n + 255) / 256), dim3(256), 0, m->stream, M, B);
+        hipLaunchKernelGGL(k_meth_pile, dim3((n + 3) / 4), dim3(256), 0, m->stream, M, B, m->d_counts);
+        chk(hipGetLastError());
+        chk(hipStreamSynchronize(m->stream));
+        m->index_base += n;
+    }
+    for (void *q : {(void *)d_chr, (void *)d_pos, (void *)d_cut, (void *)d_strand, (void *)d_ins, (void *)d_seq, (void *)d_off}) if (q) (void)hipFree(q);
+    return rc;
+}
+
+extern "C" int bsx_meth_combine_cpg(bsx_meth *m)
+{
+    if (!m) return BSX_ERR_ARG;
+    HIP_TRY(hipSetDevice(m->device));
+    hipLaunchKernelGGL(k_meth_cpg, dim3(4096), dim3(256), 0, m->stream, m->dev());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    return BSX_OK;
+}
+
+extern "C" int bsx_meth_valid_mappings(bsx_meth *m, uint64_t *n)
+{
+    if (!m || !n) return BSX_ERR_ARG;
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipMemcpy(n, m->d_counts, 8, hipMemcpyDeviceToHost));
+    return BSX_OK;
+}
+
+extern "C" int bsx_meth_report_chr(bsx_meth *m, uint32_t chr, uint32_t min_depth, int meth0, uint32_t *n_rows, uint64_t *n_covered, uint64_t *sum_depth)
+{
+    if (!m || chr >= m->n_chr || !n_rows) return BSX_ERR_ARG;
+    HIP_TRY(hipSetDevice(m->device));
+    const u64 g0 = m->chr_off[chr], n = m->chr_off[chr + 1] - g0;
+    const size_t nblk = (size_t)((n + 1023) / 1024);
+    *n_rows = 0; m->last_rows = 0;
+    if (n_covered) *n_covered = 0;
+    if (sum_depth) *sum_depth = 0;
+    if (!nblk) return BSX_OK;
+    if (nblk + 1 > m->blk_cap) {
+        if (m->d_blk) (void)hipFree(m->d_blk);
+        if (m->d_blk_start) (void)hipFree(m->d_blk_start);
+        m->d_blk = m->d_blk_start = nullptr; m->blk_cap = 0;
+        HIP_TRY(hipMalloc((void **)&m->d_blk, (nblk + 1) * 4)); HIP_TRY(hipMalloc((void **)&m->d_blk_start, (nblk + 1) * 4));
+        m->blk_cap = nblk + 1;
+    }
+    HIP_TRY(hipMemsetAsync(m->d_counts + 1, 0, 16, m->stream));
+    HIP_TRY(hipMemsetAsync(m->d_blk + nblk, 0, 4, m->stream));
+    const MethDev M = m->dev();
+    hipLaunchKernelGGL(k_meth_count, dim3((unsigned)nblk), dim3(256), 0, m->stream, M, g0, n, min_depth, meth0, m->d_blk, m->d_counts + 1);
+    HIP_TRY(hipGetLastError());
+    size_t need = 0;
+    HIP_TRY(rocprim::exclusive_scan(nullptr, need, m->d_blk, m->d_blk_start, 0u, nblk + 1, rocprim::plus<uint32_t>(), m->stream));
+    if (need > m->temp_cap) { if (m->d_temp) (void)hipFree(m->d_temp); m->d_temp = nullptr; m->temp_cap = 0; HIP_TRY(hipMalloc(&m->d_temp, need)); m->temp_cap = need; }
+    HIP_TRY(rocprim::exclusive_scan(m->d_temp, need, m->d_blk, m->d_blk_start, 0u, nblk + 1, rocprim::plus<uint32_t>(), m->stream));
+    uint32_t rows = 0; u64 cnt[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(&rows, m->d_blk_start + nblk, 4, hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipMemcpyAsync(cnt, m->d_counts + 1, 16, hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    if (rows > m->out_cap) {
+        for (int k = 0; k < 3; k++) { if (m->d_out[k]) (void)hipFree(m->d_out[k]); m->d_out[k] = nullptr; }
+        m->out_cap = 0;
+        for (int k = 0; k < 3; k++) HIP_TRY(hipMalloc((void **)&m->d_out[k], (size_t)rows * 4));
+        m->out_cap = rows;
+    }
+    if (rows) {
+        hipLaunchKernelGGL(k_meth_emit, dim3((unsigned)nblk), dim3(256), 0, m->stream, M, g0, n, min_depth, meth0, m->d_blk_start, m->d_out[0], m->d_out[1], m->d_out[2]);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(m->stream));
+    }
+    *n_rows = rows; m->last_rows = rows;
+    if (n_covered) *n_covered = cnt[0];
+    if (sum_depth) *sum_depth = cnt[1];
+    return BSX_OK;
+}
+
+extern "C" int bsx_meth_fetch_rows(bsx_meth *m, uint32_t *pos, uint32_t *depth, uint32_t *meth)
+{
+    if (!m || !pos || !depth || !meth) return BSX_ERR_ARG;
+    HIP_TRY(hipSetDevice(m->device));
+    if (!m->last_rows) return BSX_OK;
+    HIP_TRY(hipMemcpy(pos, m->d_out[0], (size_t)m->last_rows * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(depth, m->d_out[1], (size_t)m->last_rows * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(meth, m->d_out[2], (size_t)m->last_rows * 4, hipMemcpyDeviceToHost));
+    return BSX_OK;
+}

@@ -186,6 +186,29 @@ int bsx_set_heavy_threshold(int n_candidates);
 int bsx_set_heavy_limits(uint32_t units_per_round, uint32_t task_pool);
 int bsx_batch_last_heavy_units(bsx_batch *b);   /* units the last run handed to the heavy pipeline */
 
+/* ---- methylation-ratio pile-up (reference: methratio.py of the BSMAP tree) ---------------------------
+ * The reference walks the alignments in Python and increments two per-position counters; here that part runs on the
+ * GPU with atomic counters in HBM.  The caller (bsmap_amd/methratio.py) keeps the reference's option parsing, FASTA and
+ * BSP/SAM line parsing (get_alignment's filters, methratio.py:31-48) and prints the table (methratio.py:130-151). */
+typedef struct bsx_meth bsx_meth;
+/* meth/depth arrays for chromosomes of the given lengths (methratio.py:79-83); rm_dup != 0 also allocates the
+ * fragment-end table of -r (methratio.py:50-54) */
+int bsx_meth_create(uint32_t n_chr, const uint64_t *chr_len, int rm_dup, int device, bsx_meth **out);
+void bsx_meth_destroy(bsx_meth *m);
+int bsx_meth_set_reference(bsx_meth *m, uint32_t chr, const char *upper_seq /* chr_len[chr] letters, upper case */);
+/* n alignments in input order: chromosome id, 0-based position, strand code (0 "++", 1 "-+", 2 "+-", 3 "--"), insert size
+ * (BSP column 8 / SAM TLEN), cut_at (SAM with insert > 0: PNEXT-1, methratio.py:64; otherwise -1), read letters as
+ * concatenated bytes + offsets.  Duplicate removal (first alignment in input order wins), fill-in trimming with
+ * trim_fillin, the bounds test and the counter updates of methratio.py:50-63,100-114 happen on the device. */
+int bsx_meth_add(bsx_meth *m, uint32_t n, const uint32_t *chr, const int64_t *pos, const uint8_t *strand, const int32_t *insert, const int64_t *cut_at,
+                 const char *seqs, const uint64_t *seq_off, uint32_t trim_fillin);
+int bsx_meth_combine_cpg(bsx_meth *m);                      /* -g, methratio.py:118-128 */
+int bsx_meth_valid_mappings(bsx_meth *m, uint64_t *n);      /* "total %d valid mappings" */
+/* rows of one chromosome's table in position order: positions with depth >= min_depth and (methylated > 0 or meth0);
+ * n_covered / sum_depth count every position with depth >= min_depth (methratio.py:138-142) */
+int bsx_meth_report_chr(bsx_meth *m, uint32_t chr, uint32_t min_depth, int meth0, uint32_t *n_rows, uint64_t *n_covered, uint64_t *sum_depth);
+int bsx_meth_fetch_rows(bsx_meth *m, uint32_t *pos0, uint32_t *depth, uint32_t *meth);   /* the rows of the last report_chr */
+
 #ifdef __cplusplus
 }
 #endif
