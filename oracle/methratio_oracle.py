@@ -1,8 +1,8 @@
 """CPU restatement of the reference's methylation-ratio pile-up (methratio.py) — TEST INFRASTRUCTURE ONLY: imported by
 tests/ (and by nothing under bsmap_amd/).  Pinned against tests/golden/methratio.json.gz, which holds the output of the
 reference script itself (converted with lib2to3 at generation time, tests/golden/make_golden_methratio.py) on BSP files
-written by the real bsmap binary.  The SAM branch of the reference needs `samtools view -X` and cannot be run in this
-image: BSP input is pinned, SAM input is restated from the same code but unpinned.
+and SAM files written by the real bsmap binary (the script reads SAM through `samtools view -X`: the vendored samtools
+0.1.7a front end is built for that by `make -C oracle samtools`).  Parity pinned for both input formats.
 
 Plain Python, small inputs only.  Citations: methratio.py line numbers of the reference tree."""
 import numpy as np

@@ -2,7 +2,7 @@
 """Golden vectors for the methylation-ratio pile-up.  Build container only.
 Inputs: BSP alignment files written by the REAL bsmap binary (oracle/_ref/bsmap) for seeded reads on a small genome —
 single-end, paired (+ its -2 file) and RRBS.  Outputs: what the reference's methratio.py prints for a set of option
-combinations.  That script is Python 2; it is converted with lib2to3 into a temporary directory at generation time and
+combinations; the single-end and paired reads also as SAM files, which the script reads through the vendored samtools.  That script is Python 2; it is converted with lib2to3 into a temporary directory at generation time and
 run with this interpreter — nothing of it is stored.  Stored: genome FASTA, the BSP inputs, option lists, output tables
 and the summary line (tests/golden/methratio.json.gz)."""
 import gzip
@@ -54,14 +54,24 @@ def main():
     rr_bsp = os.path.join(tmp, "rr.bsp")
     R.run_bsmap(["-D", "C-CGG", "-a", fr, "-d", fa, "-o", rr_bsp, "-v", 3, "-S", 1, "-p", 1])
     cases["rrbs"] = dict(files={"rr.bsp": open(rr_bsp).read()}, infiles=["rr.bsp"])
+    # the same reads as SAM files: the reference script reads those through `samtools view -XS` (vendored samtools 0.1.7a,
+    # built by `make -C oracle samtools`); mates of a pair overlap -> the PNEXT cut of methratio.py:64
+    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "samtools"], check=True, capture_output=True)
+    sam_dir = os.path.join(ROOT, "oracle", "_ref")
+    se_sam, pe_sam = os.path.join(tmp, "se.sam"), os.path.join(tmp, "pe.sam")
+    R.run_bsmap(["-a", fq, "-d", fa, "-o", se_sam, "-s", 16, "-v", 4, "-n", 1, "-S", 1, "-p", 1, "-u"])
+    R.run_bsmap(["-a", f1, "-b", f2, "-d", fa, "-o", pe_sam, "-s", 16, "-v", 4, "-m", 20, "-x", 500, "-S", 1, "-p", 1, "-u"])
+    cases["se_sam"] = dict(files={"se.sam": open(se_sam).read()}, infiles=["se.sam"], option_sets=[[], ["-u"], ["-r"], ["-z", "-g"], ["-t", "0"]])
+    cases["pe_sam"] = dict(files={"pe.sam": open(pe_sam).read()}, infiles=["pe.sam"], option_sets=[[], ["-u"], ["-p"], ["-r"], ["-z", "-g"], ["-t", "0"], ["-t", "5"]])
     for name, c in cases.items():
         d = os.path.join(tmp, name); os.makedirs(d)
         for fn, txt in c["files"].items():
             open(os.path.join(d, fn), "w").write(txt)
         c["runs"] = []
-        for opts in OPTION_SETS:
+        for opts in c.pop("option_sets", OPTION_SETS):
             out = os.path.join(d, "out.txt")
-            res = subprocess.run([sys.executable, script, "-q", "-o", out, "-d", fa] + opts + [os.path.join(d, f) for f in c["infiles"]],
+            sam_opt = ["-s", sam_dir] if name.endswith("_sam") else []
+            res = subprocess.run([sys.executable, script, "-q", "-o", out, "-d", fa] + sam_opt + opts + [os.path.join(d, f) for f in c["infiles"]],
                                  capture_output=True, text=True)
             # (with nothing covered the reference dies in its final print, division by zero, after writing the table)
             c["runs"].append(dict(options=opts, table=open(out).read(), stdout=res.stdout, crashed=res.returncode != 0))
