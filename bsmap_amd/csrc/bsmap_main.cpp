@@ -535,8 +535,9 @@ int main(int argc, char **argv)
         fout_unpair = ::open(o.out_unpair.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
         if (fout_unpair < 0) { cerr << "failed to open output file for unpaired hits (check -2 option): " << o.out_unpair << endl; exit(1); }
     }
-    bsx_batch *batches[2] = {nullptr, nullptr};
-    for (int g = 0; g < 2; g++) {
+    const int NG = getenv("BSX_GPU_BATCHES") ? max(1, min(4, atoi(getenv("BSX_GPU_BATCHES")))) : 2;  // device batches in flight
+    bsx_batch *batches[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (int g = 0; g < NG; g++) {
         rc = bsx_batch_create(rv.ref, o.batch, pe ? 1 : 0, &batches[g]);
         if (rc) die(rc, "creating the batch");
     }
@@ -575,7 +576,7 @@ int main(int argc, char **argv)
     mutex mu_busy;
     auto gpu_stage = [&](int g) {
         bsx_batch *batch = batches[g];
-        for (long k = g; ring.acquire(k, 1); k += 2) {
+        for (long k = g; ring.acquire(k, 1); k += NG) {
             const double t = now_s();
             Slot &s = ring.at(k);
             const uint32_t n = (uint32_t)s.n;
@@ -599,7 +600,8 @@ int main(int argc, char **argv)
             ring.release(k, 2);
         }
     };
-    thread t_gpu(gpu_stage, 0), t_gpu2(gpu_stage, 1);
+    vector<thread> t_gpu;
+    for (int g = 0; g < NG; g++) t_gpu.emplace_back(gpu_stage, g);
     thread t_format([&] {
         for (long k = 0; ring.acquire(k, 2); k++) {
             const double t = now_s();
@@ -668,7 +670,9 @@ int main(int argc, char **argv)
         cout << total << " reads finished. " << time(NULL) - t_begin << " secs passed" << endl;
         ring.release(k, 0);
     }
-    t_parse.join(); t_gpu.join(); t_gpu2.join(); t_format.join();
+    t_parse.join();
+    for (thread &t : t_gpu) t.join();
+    t_format.join();
     ::close(fout);
     if (fout_unpair >= 0) ::close(fout_unpair);
     const double t_map1 = now_s();
@@ -694,7 +698,7 @@ int main(int argc, char **argv)
         fprintf(stderr, "{\"load_reference_s\": %.3f, \"index_build_s\": %.3f, \"mapping_s\": %.3f, \"units\": %u, \"reads\": %u, \"workers\": %d, "
                         "\"stage_busy_s\": {\"parse\": %.3f, \"gpu\": %.3f, \"format\": %.3f, \"write\": %.3f}}\n",
                 t_loaded - t0, t_indexed - t_loaded, t_map1 - t_map0, total, pe ? 2 * total : total, workers, busy[0], busy[1], busy[2], busy[3]);
-    for (int g = 0; g < 2; g++) bsx_batch_destroy(batches[g]);
+    for (int g = 0; g < NG; g++) bsx_batch_destroy(batches[g]);
     bsx_ref_destroy(rv.ref);
     return 0;
 }
