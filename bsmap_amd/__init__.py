@@ -67,7 +67,7 @@ EXPORTS = [
     "bsx_batch_counters", "bsx_batch_reset_counters", "bsx_batch_download_reads", "bsx_batch_set_debug", "bsx_batch_unit_cycles", "bsx_batch_ctrl_clocks",
     "bsx_batch_debug_hits", "bsx_batch_debug_pairs", "bsx_batch_debug_plan", "bsx_set_waves_per_cu", "bsx_set_heavy_threshold", "bsx_set_heavy_limits", "bsx_batch_last_heavy_units", "bsx_pinned_alloc", "bsx_pinned_free",
     "bsx_meth_create", "bsx_meth_destroy", "bsx_meth_set_reference", "bsx_meth_add", "bsx_meth_combine_cpg", "bsx_meth_valid_mappings",
-    "bsx_meth_report_chr", "bsx_meth_fetch_rows",
+    "bsx_meth_report_chr", "bsx_meth_fetch_rows", "bsx_meth_add_file", "bsx_meth_write_table", "bsx_meth_create_from_fasta", "bsx_meth_n_chr", "bsx_meth_chr_name",
 ]
 
 

@@ -10,8 +10,20 @@
 //   k_meth_count / k_meth_emit   ordered compaction of the positions the table will list
 // The host side (bsmap_amd/methratio.py) parses the option surface, the FASTA and the BSP / SAM lines, and prints the
 // table with the reference's arithmetic.  All counters are integers: results are exact.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include <hip/hip_runtime.h>
@@ -151,7 +163,7 @@ __global__ __launch_bounds__(256) void k_meth_count(MethDev M, u64 g0, u64 n, ui
 }
 
 __global__ __launch_bounds__(256) void k_meth_emit(MethDev M, u64 g0, u64 n, uint32_t min_depth, int meth0, const uint32_t *blk_start, uint32_t *out_pos,
-                                                   uint32_t *out_depth, uint32_t *out_meth)
+                                                   uint32_t *out_depth, uint32_t *out_meth, u64 *out_ctx)
 {
     __shared__ uint32_t s_wave[4];
     uint32_t base = blk_start[blockIdx.x];
@@ -169,6 +181,12 @@ __global__ __launch_bounds__(256) void k_meth_emit(MethDev M, u64 g0, u64 n, uin
         if (row) {
             const uint32_t o = off + (uint32_t)__builtin_popcountll(bal & ((1ull << lane) - 1));
             out_pos[o] = (uint32_t)k; out_depth[o] = d; out_meth[o] = m;
+            if (out_ctx) {  // refcr[i-2:i+3] with Python's slice rules (empty for i < 2 on any chromosome longer than five letters), byte 7 = the letter at i
+                u64 ctx = 0;
+                int nb = 0;
+                if (k >= 2) for (u64 q = k - 2; q < k + 3 && q < n; q++) ctx |= (u64)M.ref[g0 + q] << (8 * nb++);
+                out_ctx[o] = ctx | ((u64)M.ref[g0 + k] << 56);
+            }
         }
         base += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
         __syncthreads();
@@ -188,9 +206,11 @@ struct bsx_meth {
     hipStream_t stream = nullptr;
     // report buffers of the last bsx_meth_report_chr
     uint32_t *d_blk = nullptr, *d_blk_start = nullptr, *d_out[3] = {nullptr, nullptr, nullptr};
+    u64 *d_ctx = nullptr;
     size_t blk_cap = 0, out_cap = 0;
     void *d_temp = nullptr; size_t temp_cap = 0;
     uint32_t last_rows = 0;
+    std::vector<std::string> names;  // filled by bsx_meth_create_from_fasta
     MethDev dev() const { MethDev M; M.ref = d_ref; M.chr_off = d_chr_off; M.depth = d_depth; M.meth = d_meth; M.first = d_first; M.total = chr_off.back(); M.n_chr = n_chr; return M; }
 };
 
@@ -199,7 +219,7 @@ extern "C" void bsx_meth_destroy(bsx_meth *m)
     if (!m) return;
     (void)hipSetDevice(m->device);
     for (void *q : {(void *)m->d_ref, (void *)m->d_chr_off, (void *)m->d_counts, (void *)m->d_depth, (void *)m->d_meth, (void *)m->d_first, (void *)m->d_blk,
-                    (void *)m->d_blk_start, (void *)m->d_out[0], (void *)m->d_out[1], (void *)m->d_out[2], m->d_temp})
+                    (void *)m->d_blk_start, (void *)m->d_out[0], (void *)m->d_out[1], (void *)m->d_out[2], (void *)m->d_ctx, m->d_temp})
         if (q) (void)hipFree(q);
     if (m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
@@ -326,12 +346,15 @@ extern "C" int bsx_meth_report_chr(bsx_meth *m, uint32_t chr, uint32_t min_depth
     HIP_TRY(hipStreamSynchronize(m->stream));
     if (rows > m->out_cap) {
         for (int k = 0; k < 3; k++) { if (m->d_out[k]) (void)hipFree(m->d_out[k]); m->d_out[k] = nullptr; }
+        if (m->d_ctx) (void)hipFree(m->d_ctx);
+        m->d_ctx = nullptr;
         m->out_cap = 0;
         for (int k = 0; k < 3; k++) HIP_TRY(hipMalloc((void **)&m->d_out[k], (size_t)rows * 4));
+        HIP_TRY(hipMalloc((void **)&m->d_ctx, (size_t)rows * 8));
         m->out_cap = rows;
     }
     if (rows) {
-        hipLaunchKernelGGL(k_meth_emit, dim3((unsigned)nblk), dim3(256), 0, m->stream, M, g0, n, min_depth, meth0, m->d_blk_start, m->d_out[0], m->d_out[1], m->d_out[2]);
+        hipLaunchKernelGGL(k_meth_emit, dim3((unsigned)nblk), dim3(256), 0, m->stream, M, g0, n, min_depth, meth0, m->d_blk_start, m->d_out[0], m->d_out[1], m->d_out[2], m->d_ctx);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(m->stream));
     }
@@ -351,3 +374,290 @@ extern "C" int bsx_meth_fetch_rows(bsx_meth *m, uint32_t *pos, uint32_t *depth, 
     HIP_TRY(hipMemcpy(meth, m->d_out[2], (size_t)m->last_rows * 4, hipMemcpyDeviceToHost));
     return BSX_OK;
 }
+
+// ---- host side for whole files: the reference's per-line Python is the slow part of the tool once the pile-up is on the GPU ----
+namespace {
+
+struct ParsedChunk {
+    std::vector<uint32_t> chr; std::vector<int64_t> pos, cut; std::vector<uint8_t> strand; std::vector<int32_t> insert;
+    std::vector<char> seq; std::vector<u64> off{0};
+    u64 lines = 0;
+    int bad = 0;
+};
+
+inline bool field(const char *&p, const char *e, const char *&b, size_t &n)  // next tab-separated column of the line [p, e)
+{
+    if (p > e) return false;
+    b = p;
+    const char *t = (const char *)memchr(p, '\t', (size_t)(e - p));
+    if (!t) { n = (size_t)(e - p); p = e + 1; }
+    else { n = (size_t)(t - p); p = t + 1; }
+    return true;
+}
+
+// get_alignment's filters (methratio.py:31-48) for the lines of [b, e)
+void parse_chunk(const char *b, const char *e, int sam, const std::unordered_map<std::string, uint32_t> &cid, int unique, int pair, ParsedChunk &o)
+{
+    std::string key;
+    while (b < e) {
+        const char *nl = (const char *)memchr(b, '\n', (size_t)(e - b));
+        const char *le = nl ? nl : e;  // line without its newline
+        const char *p = b;
+        b = nl ? nl + 1 : e;
+        o.lines++;
+        const char *c[12]; size_t n[12];
+        int nc = 0;
+        while (nc < 12 && field(p, le, c[nc], n[nc])) nc++;
+        if (sam) {
+            if (n[0] && c[0][0] == '@') { o.lines--; continue; }
+            if (nc < 11) { o.bad = 1; continue; }
+            const long flag = strtol(std::string(c[1], n[1]).c_str(), nullptr, 10);
+            if ((flag & 0x4) || (unique && (flag & 0x100)) || (pair && !(flag & 0x2))) continue;
+            key.assign(c[2], n[2]);
+            auto it = cid.find(key);
+            if (it == cid.end()) continue;
+            const long long pos = strtoll(std::string(c[3], n[3]).c_str(), nullptr, 10) - 1, insert = strtoll(std::string(c[8], n[8]).c_str(), nullptr, 10);
+            // strand from the first ZS:Z: tag among the optional fields
+            const char *q = c[10] + n[10] + 1;
+            int st = -1;
+            while (q <= le) {
+                const char *fb; size_t fn;
+                if (!field(q, le, fb, fn)) break;
+                if (fn >= 7 && memcmp(fb, "ZS:Z:", 5) == 0) { st = (fb[5] == '-' ? 1 : 0) | (fb[6] == '-' ? 2 : 0); break; }
+            }
+            if (st < 0) { o.bad = 2; continue; }
+            o.chr.push_back(it->second); o.pos.push_back(pos); o.strand.push_back((uint8_t)st); o.insert.push_back((int32_t)insert);
+            o.cut.push_back(insert > 0 ? strtoll(std::string(c[7], n[7]).c_str(), nullptr, 10) - 1 : -1);
+            o.seq.insert(o.seq.end(), c[9], c[9] + n[9]); o.off.push_back(o.seq.size());
+        } else {
+            if (nc < 4) { o.bad = 1; continue; }
+            const char f0 = n[3] > 0 ? c[3][0] : 0, f1 = n[3] > 1 ? c[3][1] : 0;
+            if ((f0 == 'N' && f1 == 'M') || (f0 == 'Q' && f1 == 'C')) continue;
+            if (unique && !(f0 == 'U' && f1 == 'M')) continue;
+            if (nc < 8) { o.bad = 1; continue; }
+            if (pair && n[7] == 1 && c[7][0] == '0') continue;
+            key.assign(c[4], n[4]);
+            auto it = cid.find(key);
+            if (it == cid.end()) continue;
+            if (n[6] < 2) { o.bad = 2; continue; }
+            o.chr.push_back(it->second); o.pos.push_back(strtoll(std::string(c[5], n[5]).c_str(), nullptr, 10) - 1);
+            o.strand.push_back((uint8_t)((c[6][0] == '-' ? 1 : 0) | (c[6][1] == '-' ? 2 : 0)));
+            o.insert.push_back((int32_t)strtoll(std::string(c[7], n[7]).c_str(), nullptr, 10)); o.cut.push_back(-1);
+            o.seq.insert(o.seq.end(), c[1], c[1] + n[1]); o.off.push_back(o.seq.size());
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int bsx_meth_add_file(bsx_meth *m, const char *path, int sam, const char *const *chr_names, int unique, int pair, uint32_t trim_fillin, uint64_t *n_lines)
+{
+    if (!m || !path || (!chr_names && m->names.size() != m->n_chr)) return BSX_ERR_ARG;
+    const int fd = ::open(path, O_RDONLY);
+    if (fd < 0) { g_bsx_err = std::string("cannot open ") + path; return BSX_ERR_IO; }
+    struct stat st;
+    fstat(fd, &st);
+    const size_t len = (size_t)st.st_size;
+    if (n_lines) *n_lines = 0;
+    if (!len) { ::close(fd); return BSX_OK; }
+    const char *base = (const char *)mmap(nullptr, len, PROT_READ, MAP_PRIVATE, fd, 0);
+    ::close(fd);
+    if (base == MAP_FAILED) { g_bsx_err = std::string("cannot map ") + path; return BSX_ERR_IO; }
+    std::unordered_map<std::string, uint32_t> cid;
+    for (uint32_t c = 0; c < m->n_chr; c++) cid.emplace(chr_names ? std::string(chr_names[c]) : m->names[c], c);
+    // pieces of ~256 MB (bounded host memory), each cut into per-thread chunks at line starts; alignments keep the file's order
+    const size_t piece = 256u << 20;
+    int rc = BSX_OK;
+    for (size_t p0 = 0; p0 < len && rc == BSX_OK;) {
+        size_t p1 = std::min(len, p0 + piece);
+        if (p1 < len) { const char *nl = (const char *)memchr(base + p1, '\n', len - p1); p1 = nl ? (size_t)(nl - base) + 1 : len; }
+        const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min(32u, std::max(1u, std::thread::hardware_concurrency())), (p1 - p0) / (1u << 20) + 1));
+        std::vector<size_t> cut(nt + 1, p1);
+        cut[0] = p0;
+        for (unsigned t = 1; t < nt; t++) {
+            const size_t g = p0 + (p1 - p0) * t / nt;
+            const char *nl = (const char *)memchr(base + g, '\n', p1 - g);
+            cut[t] = nl ? (size_t)(nl - base) + 1 : p1;
+        }
+        std::vector<ParsedChunk> pc(nt);
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nt; t++) th.emplace_back([&, t] { parse_chunk(base + cut[t], base + cut[t + 1], sam, cid, unique, pair, pc[t]); });
+        parse_chunk(base + cut[0], base + cut[1], sam, cid, unique, pair, pc[0]);
+        for (std::thread &x : th) x.join();
+        ParsedChunk all;
+        for (ParsedChunk &q : pc) {
+            if (q.bad == 2) { g_bsx_err = "alignment line without strand information"; rc = BSX_ERR_ARG; }
+            if (n_lines) *n_lines += q.lines;
+            const u64 b0 = all.seq.size();
+            all.chr.insert(all.chr.end(), q.chr.begin(), q.chr.end()); all.pos.insert(all.pos.end(), q.pos.begin(), q.pos.end());
+            all.cut.insert(all.cut.end(), q.cut.begin(), q.cut.end()); all.strand.insert(all.strand.end(), q.strand.begin(), q.strand.end());
+            all.insert.insert(all.insert.end(), q.insert.begin(), q.insert.end()); all.seq.insert(all.seq.end(), q.seq.begin(), q.seq.end());
+            for (size_t i = 1; i < q.off.size(); i++) all.off.push_back(b0 + q.off[i]);
+        }
+        if (rc == BSX_OK && !all.chr.empty()) {
+            all.seq.push_back(0);
+            rc = bsx_meth_add(m, (uint32_t)all.chr.size(), all.chr.data(), all.pos.data(), all.strand.data(), all.insert.data(), all.cut.data(), all.seq.data(), (const uint64_t *)all.off.data(), trim_fillin);
+        }
+        p0 = p1;
+    }
+    munmap((void *)base, len);
+    return rc;
+}
+
+// the table of methratio.py:130-151 for the chromosomes in `order` (the reference sorts the names), same arithmetic and formats
+extern "C" int bsx_meth_write_table(bsx_meth *m, const char *path, uint32_t n_order, const uint32_t *order, const char *const *chr_names, uint32_t min_depth, int meth0,
+                                    uint64_t *n_covered, uint64_t *sum_depth)
+{
+    if (!m || !path || (!chr_names && m->names.size() != m->n_chr)) return BSX_ERR_ARG;
+    std::vector<uint32_t> sorted_order;
+    if (!order) {  // the reference writes the chromosomes in sorted name order
+        for (uint32_t c = 0; c < m->n_chr; c++) sorted_order.push_back(c);
+        std::sort(sorted_order.begin(), sorted_order.end(), [&](uint32_t a, uint32_t b) {
+            return (chr_names ? std::string(chr_names[a]) : m->names[a]) < (chr_names ? std::string(chr_names[b]) : m->names[b]); });
+        order = sorted_order.data(); n_order = m->n_chr;
+    }
+    FILE *f = fopen(path, "w");
+    if (!f) { g_bsx_err = std::string("cannot write ") + path; return BSX_ERR_IO; }
+    fputs("chr\tpos\tstrand\tcontext\tratio\ttotal_C\tmethy_C\tCI_lower\tCI_upper\n", f);
+    u64 nc = 0, nd = 0;
+    int rc = BSX_OK;
+    const double z95 = 1.96, z95sq = 1.96 * 1.96;
+    std::vector<uint32_t> pos, dep, met; std::vector<u64> ctx;
+    std::string buf;
+    for (uint32_t k = 0; k < n_order && rc == BSX_OK; k++) {
+        const uint32_t c = order[k];
+        if (c >= m->n_chr) { rc = BSX_ERR_ARG; break; }
+        uint32_t rows = 0; uint64_t cov = 0, sd_ = 0;
+        rc = bsx_meth_report_chr(m, c, min_depth, meth0, &rows, &cov, &sd_);
+        if (rc) break;
+        nc += cov; nd += sd_;
+        if (!rows) continue;
+        pos.resize(rows); dep.resize(rows); met.resize(rows); ctx.resize(rows);
+        rc = bsx_meth_fetch_rows(m, pos.data(), dep.data(), met.data());
+        if (rc) break;
+        if (hipMemcpy(ctx.data(), m->d_ctx, (size_t)rows * 8, hipMemcpyDeviceToHost) != hipSuccess) { rc = BSX_ERR_DEVICE; break; }
+        const char *name = chr_names ? chr_names[c] : m->names[c].c_str();
+        // rows are formatted by a pool of threads, each a contiguous range, and written in order
+        const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min(32u, std::max(1u, std::thread::hardware_concurrency())), rows / 65536 + 1));
+        std::vector<std::string> parts(nt);
+        auto fmt = [&](unsigned t) {
+            std::string &o = parts[t];
+            const size_t lo = (size_t)rows * t / nt, hi = (size_t)rows * (t + 1) / nt;
+            o.reserve((hi - lo) * 56);
+            char line[256];
+            for (size_t i = lo; i < hi; i++) {
+                const double d = dep[i], mm = met[i];
+                const double ratio = mm / d;
+                const double pmid = ratio + z95sq / (2 * d);
+                const double sd = z95 * pow(ratio * (1 - ratio) / d + z95sq / (4 * d * d), 0.5);
+                const double norminator = 1 + z95sq / d;
+                char cx[8]; int nb = 0;
+                for (; nb < 5; nb++) { const char ch = (char)((ctx[i] >> (8 * nb)) & 0xff); if (!ch) break; cx[nb] = ch; }
+                cx[nb] = 0;
+                const char letter = (char)(ctx[i] >> 56);
+                const int w = snprintf(line, sizeof(line), "%s\t%u\t%c\t%s\t%.3f\t%u\t%u\t%.3f\t%.3f\n", name, pos[i] + 1, letter == 'C' ? '+' : '-', cx, ratio, dep[i], met[i],
+                                       (pmid - sd) / norminator, (pmid + sd) / norminator);
+                o.append(line, (size_t)w);
+            }
+        };
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nt; t++) th.emplace_back(fmt, t);
+        fmt(0);
+        for (std::thread &x : th) x.join();
+        for (const std::string &o : parts) fwrite(o.data(), 1, o.size(), f);
+    }
+    fclose(f);
+    if (n_covered) *n_covered = nc;
+    if (sum_depth) *sum_depth = nd;
+    return rc;
+}
+
+// methratio.py:67-77 on a memory map: a record starts at a line whose first character is '>', its name is the first
+// token of line[1:-1], its sequence the concatenation of the stripped lines, upper-cased; `chroms_csv` is the -c filter
+extern "C" int bsx_meth_create_from_fasta(const char *path, const char *chroms_csv, int rm_dup, int device, bsx_meth **out)
+{
+    if (!path || !out) return BSX_ERR_ARG;
+    const int fd = ::open(path, O_RDONLY);
+    if (fd < 0) { g_bsx_err = std::string("cannot open ") + path; return BSX_ERR_IO; }
+    struct stat st;
+    fstat(fd, &st);
+    const size_t len = (size_t)st.st_size;
+    if (!len) { ::close(fd); return BSX_ERR_IO; }
+    const char *base = (const char *)mmap(nullptr, len, PROT_READ, MAP_PRIVATE, fd, 0);
+    ::close(fd);
+    if (base == MAP_FAILED) return BSX_ERR_IO;
+    std::vector<std::string> want;
+    if (chroms_csv && *chroms_csv) { std::string t(chroms_csv); size_t a = 0; for (;;) { const size_t c = t.find(',', a); want.push_back(t.substr(a, c == std::string::npos ? c : c - a)); if (c == std::string::npos) break; a = c + 1; } }
+    auto wanted = [&](const std::string &n) { if (want.empty()) return true; for (const std::string &w : want) if (w == n) return true; return false; };
+    struct Rec { std::string name; size_t b, e; };
+    std::vector<Rec> recs;
+    {   // header lines
+        size_t p = 0;
+        std::string cur; bool have = false; size_t sb = 0;
+        while (p < len) {
+            const char *nl = (const char *)memchr(base + p, '\n', len - p);
+            const size_t le = nl ? (size_t)(nl - base) + 1 : len;  // line including its newline
+            if (base[p] == '>') {
+                if (have && wanted(cur)) recs.push_back(Rec{cur, sb, p});
+                // name = line[1:-1].split()[0]
+                size_t a = p + 1, z = le > p + 1 ? le - 1 : p + 1;
+                while (a < z && (base[a] == ' ' || (base[a] >= '\t' && base[a] <= '\r'))) a++;
+                size_t q = a;
+                while (q < z && !(base[q] == ' ' || (base[q] >= '\t' && base[q] <= '\r'))) q++;
+                cur.assign(base + a, q - a); have = true; sb = le;
+                p = le;
+                continue;
+            }
+            // jump to the next header line
+            const char *g = p < len ? (const char *)memmem(base + p, len - p, "\n>", 2) : nullptr;
+            p = g ? (size_t)(g - base) + 1 : len;
+        }
+        if (have && wanted(cur)) recs.push_back(Rec{cur, sb, len});
+    }
+    // (a name given twice keeps its last record, as the reference's dict does)
+    for (size_t i = 0; i < recs.size(); i++) for (size_t j = i + 1; j < recs.size(); j++) if (recs[i].name == recs[j].name) { recs.erase(recs.begin() + (long)i); i--; break; }
+    if (recs.empty()) { munmap((void *)base, len); g_bsx_err = "no sequence selected from the reference file"; return BSX_ERR_ARG; }
+    std::vector<std::vector<char>> seqs(recs.size());
+    {
+        std::atomic<size_t> next(0);
+        auto work = [&] {
+            for (size_t i; (i = next.fetch_add(1)) < recs.size();) {
+                std::vector<char> &o = seqs[i];
+                o.reserve(recs[i].e - recs[i].b);
+                size_t p = recs[i].b;
+                while (p < recs[i].e) {
+                    const char *nl = (const char *)memchr(base + p, '\n', recs[i].e - p);
+                    size_t a = p, z = nl ? (size_t)(nl - base) : recs[i].e;
+                    p = nl ? (size_t)(nl - base) + 1 : recs[i].e;
+                    while (a < z && (base[a] == ' ' || (base[a] >= '\t' && base[a] <= '\r'))) a++;     // line.strip()
+                    while (z > a && (base[z - 1] == ' ' || (base[z - 1] >= '\t' && base[z - 1] <= '\r'))) z--;
+                    const size_t o0 = o.size();
+                    o.insert(o.end(), base + a, base + z);
+                    for (size_t k = o0; k < o.size(); k++) if (o[k] >= 'a' && o[k] <= 'z') o[k] = (char)(o[k] - 32);
+                }
+            }
+        };
+        const size_t nt = std::min<size_t>(recs.size(), std::max(1u, std::min(32u, std::thread::hardware_concurrency())));
+        std::vector<std::thread> th;
+        for (size_t t = 1; t < nt; t++) th.emplace_back(work);
+        work();
+        for (std::thread &x : th) x.join();
+    }
+    munmap((void *)base, len);
+    std::vector<uint64_t> lens;
+    for (const std::vector<char> &q : seqs) lens.push_back(q.size());
+    bsx_meth *m = nullptr;
+    int rc = bsx_meth_create((uint32_t)recs.size(), lens.data(), rm_dup, device, &m);
+    if (rc) return rc;
+    for (size_t i = 0; i < recs.size() && rc == BSX_OK; i++) {
+        m->names.push_back(recs[i].name);
+        if (!seqs[i].empty() && hipMemcpy(m->d_ref + m->chr_off[i], seqs[i].data(), seqs[i].size(), hipMemcpyHostToDevice) != hipSuccess) rc = BSX_ERR_DEVICE;
+        std::vector<char>().swap(seqs[i]);
+    }
+    if (rc) { bsx_meth_destroy(m); return rc; }
+    *out = m;
+    return BSX_OK;
+}
+
+extern "C" uint32_t bsx_meth_n_chr(const bsx_meth *m) { return m ? m->n_chr : 0; }
+extern "C" const char *bsx_meth_chr_name(const bsx_meth *m, uint32_t c) { return (m && c < m->names.size()) ? m->names[c].c_str() : ""; }

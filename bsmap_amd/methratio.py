@@ -2,8 +2,10 @@
 """methratio — methylation ratios from BSMAP alignments, pile-up on the GPU.
 
 Host-side mirror of the reference's methratio.py (same option letters, same input formats, same table, same summary
-line); the per-alignment work — duplicate removal, fill-in trimming, the counter updates under every reference C/G —
-and the selection of table rows run in HIP kernels behind the C ABI (include/bsx.h, bsx_meth_*).  There is no CPU
+line).  This file keeps the option surface; the FASTA and the mapping files are parsed by host threads inside
+libbsx.so (bsx_meth_create_from_fasta, bsx_meth_add_file), the per-alignment work — duplicate removal, fill-in trimming, the counter updates under
+every reference C/G — and the selection of table rows run in HIP kernels, and the table is formatted by host threads
+(bsx_meth_write_table), all behind the C ABI of include/bsx.h.  There is no CPU
 fallback: without the library and a gfx950 device this fails.
 
     python -m bsmap_amd.methratio -o out.txt -d genome.fa [options] alignments.bsp|.sam [...]
@@ -19,9 +21,6 @@ import numpy as np
 
 from . import lib, _check
 
-_STRAND = {"++": 0, "-+": 1, "+-": 2, "--": 3}
-
-
 def _bind():
     L = lib()
     if getattr(L, "_meth_bound", False):
@@ -35,6 +34,9 @@ def _bind():
     L.bsx_meth_valid_mappings.argtypes = [vp, vp]
     L.bsx_meth_report_chr.argtypes = [vp, u32, u32, i32, vp, vp, vp]
     L.bsx_meth_fetch_rows.argtypes = [vp, vp, vp, vp]
+    L.bsx_meth_create_from_fasta.argtypes = [C.c_char_p, C.c_char_p, i32, i32, C.POINTER(vp)]
+    L.bsx_meth_add_file.argtypes = [vp, C.c_char_p, i32, vp, i32, i32, u32, vp]
+    L.bsx_meth_write_table.argtypes = [vp, C.c_char_p, u32, vp, vp, u32, i32, vp, vp]
     L._meth_bound = True
     return L
 
@@ -55,20 +57,8 @@ def load_reference(path, chroms):
     return ref
 
 
-class _Batch:
-    def __init__(self):
-        self.chr, self.pos, self.strand, self.insert, self.cut, self.seqs, self.off = [], [], [], [], [], [], [0]
-
-    def add(self, c, pos, st, ins, cut, seq):
-        self.chr.append(c); self.pos.append(pos); self.strand.append(st); self.insert.append(ins); self.cut.append(cut)
-        self.seqs.append(seq); self.off.append(self.off[-1] + len(seq))
-
-    def __len__(self):
-        return len(self.chr)
-
-
 def run(reffile, infiles, outfile, chroms=None, unique=False, pair=False, meth0=False, rm_dup=False, trim_fillin=2, combine_CpG=False,
-        min_depth=1, device=0, quiet=True, batch=1 << 20):
+        min_depth=1, device=0, quiet=True):
     """returns the summary line the reference prints on stdout"""
     def disp(txt):
         if not quiet:
@@ -76,94 +66,28 @@ def run(reffile, infiles, outfile, chroms=None, unique=False, pair=False, meth0=
 
     L = _bind()
     disp("reading reference %s ..." % reffile)
-    ref = load_reference(reffile, chroms or [])
-    names = list(ref.keys())                      # ids follow the FASTA order; the table is written in sorted order
-    cid = {n: i for i, n in enumerate(names)}
-    lens = np.array([len(ref[n]) for n in names], np.uint64)
     h = C.c_void_p()
-    _check(L.bsx_meth_create(len(names), lens.ctypes.data, 1 if rm_dup else 0, device, C.byref(h)))
+    _check(L.bsx_meth_create_from_fasta(reffile.encode(), ",".join(chroms).encode() if chroms else None, 1 if rm_dup else 0, device, C.byref(h)))
     try:
-        for n in names:
-            _check(L.bsx_meth_set_reference(h, cid[n], ref[n].encode("latin-1")))
-
-        def flush(b):
-            if not len(b):
-                return
-            arr = [np.array(b.chr, np.uint32), np.array(b.pos, np.int64), np.array(b.strand, np.uint8), np.array(b.insert, np.int32),
-                   np.array(b.cut, np.int64), np.frombuffer("".join(b.seqs).encode("latin-1") + b"\0", np.uint8), np.array(b.off, np.uint64)]
-            _check(L.bsx_meth_add(h, len(b), *[a.ctypes.data for a in arr], max(0, trim_fillin)))
-
         for infile in infiles:
             disp("reading %s ..." % infile)
             ext = infile[-4:].upper()
             if ext == ".BAM":
                 raise SystemExit("BAM input is not supported; convert to SAM (the reference pipes it through samtools view)")
-            sam = ext == ".SAM"
-            b = _Batch()
-            with open(infile) as fin:
-                for line in fin:  # get_alignment's filters (methratio.py:31-48); the rest of it runs on the device
-                    col = line.split("\t")
-                    if sam:
-                        if line[0] == "@":
-                            continue
-                        flag = int(col[1])
-                        if flag & 0x4 or (unique and flag & 0x100) or (pair and not flag & 0x2):
-                            continue
-                        cr, pos, seq, strand, insert = col[2], int(col[3]) - 1, col[9], "", int(col[8])
-                        if cr not in cid:
-                            continue
-                        for aux in col[11:]:
-                            if aux[:5] == "ZS:Z:":
-                                strand = aux[5:7]
-                                break
-                        if strand == "":
-                            raise ValueError("alignment without ZS:Z: tag")
-                        cut = int(col[7]) - 1 if insert > 0 else -1
-                    else:
-                        flag = col[3][:2]
-                        if flag == "NM" or flag == "QC" or (unique and flag != "UM") or (pair and col[7] == "0"):
-                            continue
-                        seq, strand, cr, pos, insert, cut = col[1], col[6], col[4], int(col[5]) - 1, int(col[7]), -1
-                        if cr not in cid:
-                            continue
-                    b.add(cid[cr], pos, _STRAND[strand], insert, cut, seq)
-                    if len(b) >= batch:
-                        flush(b); b = _Batch()
-            flush(b)
+            nl = C.c_uint64()
+            _check(L.bsx_meth_add_file(h, infile.encode(), 1 if ext == ".SAM" else 0, None, 1 if unique else 0, 1 if pair else 0, max(0, trim_fillin), C.byref(nl)))
         if combine_CpG:
             disp("combining CpG methylation from both strands ...")
             _check(L.bsx_meth_combine_cpg(h))
         disp("writing %s ..." % outfile)
-        ss = {"C": "+", "G": "-"}
-        z95, z95sq = 1.96, 1.96 * 1.96
-        nc = nd = 0
-        with open(outfile, "w") as fout:
-            fout.write("chr\tpos\tstrand\tcontext\tratio\ttotal_C\tmethy_C\tCI_lower\tCI_upper\n")
-            for cr in sorted(names):
-                n_rows, cov, sdep = C.c_uint32(), C.c_uint64(), C.c_uint64()
-                _check(L.bsx_meth_report_chr(h, cid[cr], min_depth, 1 if meth0 else 0, C.byref(n_rows), C.byref(cov), C.byref(sdep)))
-                nc += cov.value; nd += sdep.value
-                if not n_rows.value:
-                    continue
-                pos, dep, met = (np.zeros(n_rows.value, np.uint32) for _ in range(3))
-                _check(L.bsx_meth_fetch_rows(h, pos.ctypes.data, dep.ctypes.data, met.ctypes.data))
-                refcr = ref[cr]
-                out = []
-                for i, d, m in zip(pos.tolist(), dep.tolist(), met.tolist()):  # methratio.py:143-151, same arithmetic
-                    ratio = float(m) / d
-                    pmid = ratio + z95sq / (2 * d)
-                    sd = z95 * ((ratio * (1 - ratio) / d + z95sq / (4 * d * d)) ** 0.5)
-                    norminator = 1 + z95sq / d
-                    out.append("%s\t%d\t%c\t%s\t%.3f\t%d\t%d\t%.3f\t%.3f\n" % (cr, i + 1, ss[refcr[i]], refcr[i - 2:i + 3], ratio, d, m,
-                                                                              (pmid - sd) / norminator, (pmid + sd) / norminator))
-                fout.write("".join(out))
-        nmap = C.c_uint64()
+        nc, nd, nmap = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _check(L.bsx_meth_write_table(h, outfile.encode(), 0, None, None, min_depth, 1 if meth0 else 0, C.byref(nc), C.byref(nd)))
         _check(L.bsx_meth_valid_mappings(h, C.byref(nmap)))
         disp("done.")
         # (with nothing covered the reference dies here on a division by zero; that is reported instead)
-        if nc == 0:
+        if nc.value == 0:
             return "total %d valid mappings, 0 covered cytosines.\n" % nmap.value
-        return "total %d valid mappings, %d covered cytosines, average coverage: %.2f fold.\n" % (nmap.value, nc, float(nd) / nc)
+        return "total %d valid mappings, %d covered cytosines, average coverage: %.2f fold.\n" % (nmap.value, nc.value, float(nd.value) / nc.value)
     finally:
         L.bsx_meth_destroy(h)
 

@@ -194,6 +194,11 @@ typedef struct bsx_meth bsx_meth;
 /* meth/depth arrays for chromosomes of the given lengths (methratio.py:79-83); rm_dup != 0 also allocates the
  * fragment-end table of -r (methratio.py:50-54) */
 int bsx_meth_create(uint32_t n_chr, const uint64_t *chr_len, int rm_dup, int device, bsx_meth **out);
+/* the same from the reference FASTA (methratio.py:67-77: name = first token of the header, lines stripped and joined, upper case);
+ * chroms_csv = the -c list or NULL.  The names are kept: chr_names / order may then be NULL in the calls below. */
+int bsx_meth_create_from_fasta(const char *path, const char *chroms_csv, int rm_dup, int device, bsx_meth **out);
+uint32_t bsx_meth_n_chr(const bsx_meth *m);
+const char *bsx_meth_chr_name(const bsx_meth *m, uint32_t chr);
 void bsx_meth_destroy(bsx_meth *m);
 int bsx_meth_set_reference(bsx_meth *m, uint32_t chr, const char *upper_seq /* chr_len[chr] letters, upper case */);
 /* n alignments in input order: chromosome id, 0-based position, strand code (0 "++", 1 "-+", 2 "+-", 3 "--"), insert size
@@ -202,12 +207,20 @@ int bsx_meth_set_reference(bsx_meth *m, uint32_t chr, const char *upper_seq /* c
  * trim_fillin, the bounds test and the counter updates of methratio.py:50-63,100-114 happen on the device. */
 int bsx_meth_add(bsx_meth *m, uint32_t n, const uint32_t *chr, const int64_t *pos, const uint8_t *strand, const int32_t *insert, const int64_t *cut_at,
                  const char *seqs, const uint64_t *seq_off, uint32_t trim_fillin);
+/* the same for a whole BSMAP mapping file (BSP text, or SAM text when sam != 0): the file is memory-mapped and parsed by host
+ * threads with get_alignment's filters (NM/QC or unmapped, -u unique, -p pair, chromosome known; methratio.py:31-48), alignments
+ * keep the file's order; chr_names[n_chr] in id order */
+int bsx_meth_add_file(bsx_meth *m, const char *path, int sam, const char *const *chr_names, int unique, int pair, uint32_t trim_fillin, uint64_t *n_lines);
 int bsx_meth_combine_cpg(bsx_meth *m);                      /* -g, methratio.py:118-128 */
 int bsx_meth_valid_mappings(bsx_meth *m, uint64_t *n);      /* "total %d valid mappings" */
 /* rows of one chromosome's table in position order: positions with depth >= min_depth and (methylated > 0 or meth0);
  * n_covered / sum_depth count every position with depth >= min_depth (methratio.py:138-142) */
 int bsx_meth_report_chr(bsx_meth *m, uint32_t chr, uint32_t min_depth, int meth0, uint32_t *n_rows, uint64_t *n_covered, uint64_t *sum_depth);
 int bsx_meth_fetch_rows(bsx_meth *m, uint32_t *pos0, uint32_t *depth, uint32_t *meth);   /* the rows of the last report_chr */
+/* the whole table file of methratio.py:130-151 (header, chromosomes in the given order — the reference sorts the names —,
+ * ratio and Wilson interval with the reference's arithmetic, "%.3f"); returns the counts of the summary line */
+int bsx_meth_write_table(bsx_meth *m, const char *path, uint32_t n_order, const uint32_t *order, const char *const *chr_names, uint32_t min_depth, int meth0,
+                         uint64_t *n_covered, uint64_t *sum_depth);
 
 #ifdef __cplusplus
 }

@@ -39,13 +39,45 @@ def test_methratio_matches_reference_script(case, i, files, capsys):
         assert stdout == run["stdout"]
 
 
-def test_methratio_batches_do_not_matter(files):
-    """duplicate removal is defined by input order: many small device batches give the same table as one"""
-    from bsmap_amd import methratio
+def test_methratio_low_level_calls_agree_with_the_file_path(files):
+    """bsx_meth_add with explicit arrays in many small batches (duplicate removal is defined by input order across calls)
+    gives the same rows as the file-level call"""
+    import ctypes as C
+    import numpy as np
+    from bsmap_amd import methratio, _check
     fa, paths, d = files
-    outs = []
-    for b in (1 << 20, 97):
-        out = str(d / f"b{b}.txt")
-        s = methratio.run(fa, paths["pe"], out, rm_dup=True, meth0=True, combine_CpG=True, batch=b)
-        outs.append((open(out).read(), s))
-    assert outs[0] == outs[1] and outs[0][0].count("\n") > 1000
+    out = str(d / "file.txt")
+    methratio.run(fa, paths["pe"], out, rm_dup=True, meth0=True)
+    L = methratio._bind()
+    ref = methratio.load_reference(fa, [])
+    names = list(ref)
+    lens = np.array([len(ref[n]) for n in names], np.uint64)
+    h = C.c_void_p()
+    _check(L.bsx_meth_create(len(names), lens.ctypes.data, 1, 0, C.byref(h)))
+    for i, n in enumerate(names):
+        _check(L.bsx_meth_set_reference(h, i, ref[n].encode()))
+    st = {"++": 0, "-+": 1, "+-": 2, "--": 3}
+    rows = []
+    for p_ in paths["pe"]:
+        for line in open(p_):
+            col = line.split("\t")
+            if col[3][:2] in ("NM", "QC"):
+                continue
+            rows.append((names.index(col[4]), int(col[5]) - 1, st[col[6]], int(col[7]), col[1]))
+    for b0 in range(0, len(rows), 53):
+        part = rows[b0:b0 + 53]
+        off = np.cumsum([0] + [len(r[4]) for r in part]).astype(np.uint64)
+        seq = np.frombuffer(("".join(r[4] for r in part)).encode() + b"\0", np.uint8)
+        arr = [np.array([r[0] for r in part], np.uint32), np.array([r[1] for r in part], np.int64), np.array([r[2] for r in part], np.uint8),
+               np.array([r[3] for r in part], np.int32), np.full(len(part), -1, np.int64), seq, off]
+        _check(L.bsx_meth_add(h, len(part), *[a.ctypes.data for a in arr], 2))
+    got = []
+    for i, n in enumerate(names):
+        nr = C.c_uint32()
+        _check(L.bsx_meth_report_chr(h, i, 1, 1, C.byref(nr), None, None))
+        pos, dep, met = (np.zeros(nr.value, np.uint32) for _ in range(3))
+        _check(L.bsx_meth_fetch_rows(h, pos.ctypes.data, dep.ctypes.data, met.ctypes.data))
+        got += [(n, int(a) + 1, int(b), int(c)) for a, b, c in zip(pos, dep, met)]
+    L.bsx_meth_destroy(h)
+    exp = [(f[0], int(f[1]), int(f[5]), int(f[6])) for f in (l.split("\t") for l in open(out).read().split("\n")[1:] if l)]
+    assert sorted(got) == sorted(exp) and len(got) > 1000
