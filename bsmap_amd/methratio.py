@@ -13,7 +13,6 @@ fallback: without the library and a gfx950 device this fails.
 Differences from the reference: SAM files are read directly (numeric flags: 0x4 = 'u', 0x100 = 's', 0x2 = 'P' of
 `samtools view -X`), no samtools is spawned and `-s` is accepted and ignored; BAM input is not supported."""
 import ctypes as C
-import optparse
 import sys
 import time
 
@@ -93,25 +92,25 @@ def run(reffile, infiles, outfile, chroms=None, unique=False, pair=False, meth0=
 
 
 def main(argv=None):
-    parser = optparse.OptionParser(usage="usage: %prog [options] BSMAP_MAPPING_FILES")
-    parser.add_option("-o", "--out", dest="outfile", metavar="FILE", help="output file name. (required)", default="")
-    parser.add_option("-d", "--ref", dest="reffile", metavar="FILE", help="reference genome fasta file. (required)", default="")
-    parser.add_option("-c", "--chr", dest="chroms", metavar="CHR", help="process only specified chromosomes, separated by ','. [default: all]", default="")
-    parser.add_option("-s", "--sam-path", dest="sam_path", metavar="PATH", help="accepted for compatibility (SAM files are read directly)", default="")
-    parser.add_option("-u", "--unique", action="store_true", dest="unique", help="process only unique mappings/pairs.", default=False)
-    parser.add_option("-p", "--pair", action="store_true", dest="pair", help="process only properly paired mappings.", default=False)
-    parser.add_option("-z", "--zero-meth", action="store_true", dest="meth0", help="report loci with zero methylation ratios.", default=False)
-    parser.add_option("-q", "--quiet", action="store_true", dest="quiet", help="don't print progress on stderr.", default=False)
-    parser.add_option("-r", "--remove-duplicate", action="store_true", dest="rm_dup", help="remove duplicated reads.", default=False)
-    parser.add_option("-t", "--trim-fillin", dest="trim_fillin", type="int", metavar="N", help="trim N end-repairing fill-in nucleotides. [default: 2]", default=2)
-    parser.add_option("-g", "--combine-CpG", action="store_true", dest="combine_CpG", help="combine CpG methylaion ratios on both strands.", default=False)
-    parser.add_option("-m", "--min-depth", dest="min_depth", type="int", metavar="FOLD", help="report loci with sequencing depth>=FOLD. [default: 1]", default=1)
-    parser.add_option("-G", "--gpu", dest="device", type="int", metavar="N", help="GPU ordinal (extension). [default: 0]", default=0)
-    o, infiles = parser.parse_args(argv)
-    if len(o.reffile) == 0: parser.error("Missing reference file, use -d or --ref option.")
-    if len(o.outfile) == 0: parser.error("Missing output file name, use -o or --out option.")
-    if len(infiles) == 0: parser.error("Require at least one BSMAP_MAPPING_FILE.")
-    sys.stdout.write(run(o.reffile, infiles, o.outfile, chroms=o.chroms.split(",") if o.chroms else None, unique=o.unique, pair=o.pair, meth0=o.meth0,
+    """command line with the reference's option letters (methratio.py:3-17)"""
+    import argparse
+    ap = argparse.ArgumentParser(prog="methratio", description="methylation ratios from BSMAP mapping files (BSP or SAM text), pile-up on the GPU")
+    ap.add_argument("-o", "--out", dest="outfile", required=True, help="table to write")
+    ap.add_argument("-d", "--ref", dest="reffile", required=True, help="reference FASTA the reads were mapped to")
+    ap.add_argument("-c", "--chr", dest="chroms", default="", help="comma-separated sequence names to keep (default: every sequence)")
+    ap.add_argument("-s", "--sam-path", dest="sam_path", default="", help="ignored: SAM files are parsed directly, samtools is not needed")
+    ap.add_argument("-u", "--unique", action="store_true", help="use uniquely mapped reads / pairs only")
+    ap.add_argument("-p", "--pair", action="store_true", help="use properly paired mappings only")
+    ap.add_argument("-z", "--zero-meth", dest="meth0", action="store_true", help="also list covered cytosines without a methylated read")
+    ap.add_argument("-q", "--quiet", action="store_true", help="no progress lines on stderr")
+    ap.add_argument("-r", "--remove-duplicate", dest="rm_dup", action="store_true", help="keep the first read per fragment end and direction")
+    ap.add_argument("-t", "--trim-fillin", dest="trim_fillin", type=int, default=2, help="end-repair nucleotides to ignore at fragment ends (default 2)")
+    ap.add_argument("-g", "--combine-CpG", dest="combine_CpG", action="store_true", help="add the counts of the G of each CpG to its C")
+    ap.add_argument("-m", "--min-depth", dest="min_depth", type=int, default=1, help="lowest depth a listed cytosine must have (default 1)")
+    ap.add_argument("-G", "--gpu", dest="device", type=int, default=0, help="GPU ordinal (extension)")
+    ap.add_argument("infiles", nargs="+", help="mapping files written by bsmap: *.sam is read as SAM, anything else as BSP")
+    o = ap.parse_args(argv)
+    sys.stdout.write(run(o.reffile, o.infiles, o.outfile, chroms=o.chroms.split(",") if o.chroms else None, unique=o.unique, pair=o.pair, meth0=o.meth0,
                          rm_dup=o.rm_dup, trim_fillin=o.trim_fillin, combine_CpG=o.combine_CpG, min_depth=o.min_depth, device=o.device, quiet=o.quiet))
 
 
