@@ -1155,9 +1155,10 @@ int bso_pe_align(bso_aligner *sa, bso_aligner *sb, uint32_t index, const char *s
 typedef struct {
     const bso_params *p; const bso_ref *r; uint32_t n; const char *sa; const uint64_t *oa; const char *qa;
     const char *sb; const uint64_t *ob; const char *qb; uint32_t first; void *res; int pe;
-    volatile uint32_t *next; uint64_t cnt[4];
+    volatile uint32_t *next; uint32_t chunk; uint64_t cnt[4];
 } batch_job;
-#define CHUNK 2048
+/* units per grab: fine enough that every thread gets work even on a bounded sample (the reference's threads grab 50 000
+ * reads at a time, main.cpp:49-73 — far coarser) */
 
 static void *batch_worker(void *arg)
 {
@@ -1165,9 +1166,9 @@ static void *batch_worker(void *arg)
     bso_aligner *a = bso_aligner_new(jb->p, jb->r, 0), *b = jb->pe ? bso_aligner_new(jb->p, jb->r, 0) : NULL;
     char s1[FIXSIZE + 64], q1[FIXSIZE + 64], s2[FIXSIZE + 64], q2[FIXSIZE + 64];
     while (1) {
-        uint32_t lo = __sync_fetch_and_add(jb->next, CHUNK);
+        uint32_t lo = __sync_fetch_and_add(jb->next, jb->chunk);
         if (lo >= jb->n) break;
-        uint32_t hi = lo + CHUNK < jb->n ? lo + CHUNK : jb->n;
+        uint32_t hi = lo + jb->chunk < jb->n ? lo + jb->chunk : jb->n;
         for (uint32_t i = lo; i < hi; i++) {
             uint64_t l = jb->oa[i + 1] - jb->oa[i]; if (l > FIXSIZE) l = FIXSIZE;
             memcpy(s1, jb->sa + jb->oa[i], l); s1[l] = 0;
@@ -1192,6 +1193,8 @@ static int run_batch(batch_job *proto, int n_threads, uint64_t counters[4])
     if (n_threads < 1) n_threads = 1;
     if (n_threads > 512) n_threads = 512;
     volatile uint32_t next = 0;
+    uint32_t chunk = proto->n / ((uint32_t)n_threads * 8u);
+    proto->chunk = chunk < 16 ? 16 : chunk > 2048 ? 2048 : chunk;
     batch_job *jobs = calloc(n_threads, sizeof(batch_job));
     pthread_t *th = calloc(n_threads, sizeof(pthread_t));
     for (int t = 0; t < n_threads; t++) { jobs[t] = *proto; jobs[t].next = &next; }
