@@ -10,8 +10,8 @@ fallback: without the library and a gfx950 device this fails.
 
     python -m bsmap_amd.methratio -o out.txt -d genome.fa [options] alignments.bsp|.sam [...]
 
-Differences from the reference: SAM files are read directly (numeric flags: 0x4 = 'u', 0x100 = 's', 0x2 = 'P' of
-`samtools view -X`), no samtools is spawned and `-s` is accepted and ignored; BAM input is not supported."""
+Differences from the reference: SAM and BAM files are read directly (numeric flags: 0x4 = 'u', 0x100 = 's', 0x2 = 'P' of
+`samtools view -X`; BGZF through zlib), no samtools is spawned and `-s` is accepted and ignored."""
 import ctypes as C
 import sys
 import time
@@ -71,10 +71,8 @@ def run(reffile, infiles, outfile, chroms=None, unique=False, pair=False, meth0=
         for infile in infiles:
             disp("reading %s ..." % infile)
             ext = infile[-4:].upper()
-            if ext == ".BAM":
-                raise SystemExit("BAM input is not supported; convert to SAM (the reference pipes it through samtools view)")
             nl = C.c_uint64()
-            _check(L.bsx_meth_add_file(h, infile.encode(), 1 if ext == ".SAM" else 0, None, 1 if unique else 0, 1 if pair else 0, max(0, trim_fillin), C.byref(nl)))
+            _check(L.bsx_meth_add_file(h, infile.encode(), 2 if ext == ".BAM" else 1 if ext == ".SAM" else 0, None, 1 if unique else 0, 1 if pair else 0, max(0, trim_fillin), C.byref(nl)))
         if combine_CpG:
             disp("combining CpG methylation from both strands ...")
             _check(L.bsx_meth_combine_cpg(h))
@@ -94,7 +92,7 @@ def run(reffile, infiles, outfile, chroms=None, unique=False, pair=False, meth0=
 def main(argv=None):
     """command line with the reference's option letters (methratio.py:3-17)"""
     import argparse
-    ap = argparse.ArgumentParser(prog="methratio", description="methylation ratios from BSMAP mapping files (BSP or SAM text), pile-up on the GPU")
+    ap = argparse.ArgumentParser(prog="methratio", description="methylation ratios from BSMAP mapping files (BSP, SAM or BAM), pile-up on the GPU")
     ap.add_argument("-o", "--out", dest="outfile", required=True, help="table to write")
     ap.add_argument("-d", "--ref", dest="reffile", required=True, help="reference FASTA the reads were mapped to")
     ap.add_argument("-c", "--chr", dest="chroms", default="", help="comma-separated sequence names to keep (default: every sequence)")
@@ -108,7 +106,7 @@ def main(argv=None):
     ap.add_argument("-g", "--combine-CpG", dest="combine_CpG", action="store_true", help="add the counts of the G of each CpG to its C")
     ap.add_argument("-m", "--min-depth", dest="min_depth", type=int, default=1, help="lowest depth a listed cytosine must have (default 1)")
     ap.add_argument("-G", "--gpu", dest="device", type=int, default=0, help="GPU ordinal (extension)")
-    ap.add_argument("infiles", nargs="+", help="mapping files written by bsmap: *.sam is read as SAM, anything else as BSP")
+    ap.add_argument("infiles", nargs="+", help="mapping files written by bsmap: *.sam / *.bam by their format, anything else as BSP")
     o = ap.parse_args(argv)
     sys.stdout.write(run(o.reffile, o.infiles, o.outfile, chroms=o.chroms.split(",") if o.chroms else None, unique=o.unique, pair=o.pair, meth0=o.meth0,
                          rm_dup=o.rm_dup, trim_fillin=o.trim_fillin, combine_CpG=o.combine_CpG, min_depth=o.min_depth, device=o.device, quiet=o.quiet))

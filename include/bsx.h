@@ -207,7 +207,7 @@ int bsx_meth_set_reference(bsx_meth *m, uint32_t chr, const char *upper_seq /* c
  * trim_fillin, the bounds test and the counter updates of methratio.py:50-63,100-114 happen on the device. */
 int bsx_meth_add(bsx_meth *m, uint32_t n, const uint32_t *chr, const int64_t *pos, const uint8_t *strand, const int32_t *insert, const int64_t *cut_at,
                  const char *seqs, const uint64_t *seq_off, uint32_t trim_fillin);
-/* the same for a whole BSMAP mapping file (BSP text, or SAM text when sam != 0): the file is memory-mapped and parsed by host
+/* the same for a whole BSMAP mapping file (sam = 0 BSP text, 1 SAM text, 2 BAM): the file is memory-mapped and parsed by host
  * threads with get_alignment's filters (NM/QC or unmapped, -u unique, -p pair, chromosome known; methratio.py:31-48), alignments
  * keep the file's order; chr_names[n_chr] in id order */
 int bsx_meth_add_file(bsx_meth *m, const char *path, int sam, const char *const *chr_names, int unique, int pair, uint32_t trim_fillin, uint64_t *n_lines);

@@ -63,19 +63,34 @@ def main():
     R.run_bsmap(["-a", f1, "-b", f2, "-d", fa, "-o", pe_sam, "-s", 16, "-v", 4, "-m", 20, "-x", 500, "-S", 1, "-p", 1, "-u"])
     cases["se_sam"] = dict(files={"se.sam": open(se_sam).read()}, infiles=["se.sam"], option_sets=[[], ["-u"], ["-r"], ["-z", "-g"], ["-t", "0"]])
     cases["pe_sam"] = dict(files={"pe.sam": open(pe_sam).read()}, infiles=["pe.sam"], option_sets=[[], ["-u"], ["-p"], ["-r"], ["-z", "-g"], ["-t", "0"], ["-t", "5"]])
+    # ... and as a BAM file made from that SAM by the vendored `samtools view -bS` (stored base64; the script reads it through
+    # `samtools view -X`)
+    import base64
+    pe_bam = os.path.join(tmp, "pe.bam")
+    with open(pe_bam, "wb") as fb:
+        subprocess.run([os.path.join(sam_dir, "samtools"), "view", "-bS", pe_sam], check=True, stdout=fb, stderr=subprocess.DEVNULL)
+    cases["pe_bam"] = dict(files_b64={"pe.bam": base64.b64encode(open(pe_bam, "rb").read()).decode()}, files={}, infiles=["pe.bam"],
+                           option_sets=[[], ["-u"], ["-p"], ["-r"], ["-z", "-g"], ["-t", "0"]])
     for name, c in cases.items():
         d = os.path.join(tmp, name); os.makedirs(d)
         for fn, txt in c["files"].items():
             open(os.path.join(d, fn), "w").write(txt)
+        for fn, b64 in c.get("files_b64", {}).items():
+            open(os.path.join(d, fn), "wb").write(base64.b64decode(b64))
         c["runs"] = []
         for opts in c.pop("option_sets", OPTION_SETS):
             out = os.path.join(d, "out.txt")
-            sam_opt = ["-s", sam_dir] if name.endswith("_sam") else []
+            sam_opt = ["-s", sam_dir] if name.endswith(("_sam", "_bam")) else []
             res = subprocess.run([sys.executable, script, "-q", "-o", out, "-d", fa] + sam_opt + opts + [os.path.join(d, f) for f in c["infiles"]],
                                  capture_output=True, text=True)
             # (with nothing covered the reference dies in its final print, division by zero, after writing the table)
             c["runs"].append(dict(options=opts, table=open(out).read(), stdout=res.stdout, crashed=res.returncode != 0))
         print(name, {" ".join(r["options"]) or "-": r["table"].count("\n") for r in c["runs"]}, c["runs"][0]["stdout"].strip())
+    # the BAM runs must equal the SAM runs they were converted from: keep only a pointer to those
+    for r in cases["pe_bam"]["runs"]:
+        twin = [x for x in cases["pe_sam"]["runs"] if x["options"] == r["options"]][0]
+        assert (r["table"], r["stdout"], r["crashed"]) == (twin["table"], twin["stdout"], twin["crashed"])
+    cases["pe_bam"]["runs"] = [dict(options=r["options"], same_as="pe_sam") for r in cases["pe_bam"]["runs"]]
     json.dump(dict(fasta=open(fa).read(), cases=cases), gzip.open(os.path.join(HERE, "methratio.json.gz"), "wt"))
 
 

@@ -22,6 +22,9 @@ def files(tmp_path_factory):
     for c, case in GOLD["cases"].items():
         for fn, txt in case["files"].items():
             open(str(d / fn), "w").write(txt)
+        for fn, b64 in case.get("files_b64", {}).items():
+            import base64
+            open(str(d / fn), "wb").write(base64.b64decode(b64))
         paths[c] = [str(d / fn) for fn in case["infiles"]]
     return fa, paths, d
 
@@ -31,6 +34,8 @@ def test_methratio_matches_reference_script(case, i, files, capsys):
     from bsmap_amd import methratio
     fa, paths, d = files
     run = GOLD["cases"][case]["runs"][i]
+    if "same_as" in run:  # the BAM file was converted from that case's SAM file by the vendored samtools: same expected output
+        run = [r for r in GOLD["cases"][run["same_as"]]["runs"] if r["options"] == run["options"]][0]
     out = str(d / f"{case}_{i}.txt")
     methratio.main(["-q", "-o", out, "-d", fa] + list(run["options"]) + paths[case])
     assert open(out).read() == run["table"]

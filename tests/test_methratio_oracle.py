@@ -10,7 +10,8 @@ import golden_util as G
 from oracle import methratio_oracle as MO
 
 GOLD = json.load(gzip.open(os.path.join(G.GOLDEN, "methratio.json.gz"), "rt"))
-RUNS = [(c, i) for c in sorted(GOLD["cases"]) for i in range(len(GOLD["cases"][c]["runs"]))]
+# (the BAM case is the paired SAM case in another container: the oracle reads text, the GPU tool decodes the BAM itself)
+RUNS = [(c, i) for c in sorted(GOLD["cases"]) if not c.endswith("_bam") for i in range(len(GOLD["cases"][c]["runs"]))]
 
 
 @pytest.mark.parametrize("case,i", RUNS, ids=[f"{c}-{'_'.join(GOLD['cases'][c]['runs'][i]['options']) or 'default'}" for c, i in RUNS])
