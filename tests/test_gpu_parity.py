@@ -475,6 +475,60 @@ def test_heavy_pipeline_random_options(seed, heavy_genome, oracle):
     test_heavy_pipeline_large_buckets(pe, heavy_genome, oracle, extra)
 
 
+def test_heavy_pipeline_degenerate_genome(oracle, tmp_path):
+    """worst case for the scan: a genome that is almost one microsatellite with a poly-T and a poly-A arm — every read hits
+    buckets of 10^5..10^6 entries on both strands, thousands of equal hits, caps and threshold lowering all the time"""
+    import random
+    rng = random.Random(3)
+    def mutate(s, rate):
+        return "".join(c if rng.random() > rate else rng.choice("ACGT") for c in s)
+    chr1 = mutate("TG" * 300_000, 0.01) + "".join(rng.choice("ACGT") for _ in range(20_000)) + mutate("T" * 150_000, 0.02)
+    chr2 = mutate("CA" * 200_000, 0.01) + mutate("A" * 100_000, 0.02) + mutate("TTG" * 60_000, 0.01)
+    g = [("chr1", chr1), ("chr2", chr2)]
+    fa = str(tmp_path / "g.fa")
+    td.write_fasta(fa, g)
+    for pe, extra in ((False, dict(n=1)), (True, dict(m=28, x=500, pairend=1)), (False, dict(w=30, r=0))):
+        kw = dict(s=16, v=6, I=4, S=1, r=1)
+        kw.update(extra)
+        oref = oracle.OracleRef(oracle.make_params(**kw), fasta_path=fa)
+        gref = B.RefSeq(B.make_params(**kw)).Run_ConvertBinseq(fasta_path=fa).CreateIndex()
+        assert np.diff(gref.index()[0].astype(np.int64)).max() > 100_000
+        if not pe:
+            reads = td.make_se_reads(g, 400, 144, seed=8, sub_rate=0.02, strands=("++", "-+", "+-", "--"))
+            sb, so = oracle.pack_reads([r["seq"] for r in reads])
+            ores, ocnt = oracle.se_batch(oref, sb, so, threads=8)
+            sa = B.SingleAlign(gref, len(reads))
+            sa.ImportBatchReads((sb, so)).Do_Batch()
+            hits, cc = sa.results()
+            assert sa.heavy_units() > 100
+            assert np.array_equal(ores["n_hit"][:, :7], cc["n_hit"][:, :7]) and np.array_equal(ores["n_chit"][:, :7], cc["n_chit"][:, :7])
+            has = ores["n_best"] > 0
+            for f in ("chr", "loc", "best_class"):
+                assert np.array_equal(ores[f][has], hits[f][has]), f
+            assert np.array_equal(np.maximum(ores["n_best"], 0), hits["n_best"])
+            assert [int(x) for x in sa.counters()[:4]] == ocnt
+            sa.close()
+        else:
+            pairs = td.make_pe_reads(g, 300, 144, seed=9, sub_rate=0.02)
+            s1, o1 = oracle.pack_reads([p["seq1"] for p in pairs])
+            s2, o2 = oracle.pack_reads([p["seq2"] for p in pairs])
+            ores, ocnt = oracle.pe_batch(oref, s1, o1, s2, o2, threads=8)
+            pa = B.PairAlign(gref, len(pairs))
+            pa.ImportBatchReads((s1, o1), (s2, o2)).Do_Batch()
+            out, ca, cb, npairs = pa.results()
+            assert pa.heavy_units() > 80
+            assert np.array_equal(ores["paired"], out["paired"]) and np.array_equal(ores["n_pairs"][:, :13], npairs[:, :13])
+            for m, cnts in (("a", ca), ("b", cb)):
+                assert np.array_equal(ores[m]["n_hit"][:, :7], cnts["n_hit"][:, :7]) and np.array_equal(ores[m]["n_chit"][:, :7], cnts["n_chit"][:, :7]), m
+            pr = (ores["tmp"] == 0) & (ores["paired"] > 0)
+            for f in ("a_chr", "a_loc", "b_chr", "b_loc", "insert", "na", "nb", "chain"):
+                assert np.array_equal(ores["pick"][f][pr], out[f][pr]), f
+            assert [int(x) for x in pa.counters()[:4]] == ocnt
+            pa.close()
+        gref.close()
+        oref.free()
+
+
 def test_batch_reuse_and_argument_checks(edge_genome, oracle):
     """one device batch used for batches of different sizes, and the error codes of calls made out of order"""
     g, fa = edge_genome
