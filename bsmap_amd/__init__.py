@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BSX_LIB") or os.path.join(HERE, "libbsx.so")  # BSX_LIB: alternative build of the same library (kernel tuning experiments)
 CSRC = os.path.join(HERE, "csrc")
 
-BSX_N_COUNTERS = 8
+BSX_N_COUNTERS = 10
 F_FILTERED, F_CHAIN = 1, 2
 
 
@@ -63,7 +63,7 @@ EXPORTS = [
     "bsx_ref_n_chr", "bsx_ref_n_words", "bsx_ref_n_blocks", "bsx_ref_info", "bsx_ref_chr_name", "bsx_ref_blocks",
     "bsx_ref_download_words", "bsx_index_build", "bsx_index_n_entries", "bsx_index_download", "bsx_ref_n_sites", "bsx_ref_sites",
     "bsx_batch_create", "bsx_batch_destroy", "bsx_batch_upload_se", "bsx_batch_upload_pe", "bsx_batch_synth_reads",
-    "bsx_batch_run", "bsx_batch_run_range", "bsx_batch_sync", "bsx_batch_kernel_ms", "bsx_batch_results_se", "bsx_batch_results_pe",
+    "bsx_batch_run", "bsx_batch_run_range", "bsx_batch_sync", "bsx_batch_kernel_ms", "bsx_batch_scan_ms", "bsx_batch_results_se", "bsx_batch_results_pe",
     "bsx_batch_counters", "bsx_batch_reset_counters", "bsx_batch_download_reads", "bsx_batch_set_debug", "bsx_batch_unit_cycles", "bsx_batch_ctrl_clocks",
     "bsx_batch_debug_hits", "bsx_batch_debug_pairs", "bsx_batch_debug_plan", "bsx_set_waves_per_cu", "bsx_set_heavy_threshold", "bsx_set_heavy_limits", "bsx_batch_last_heavy_units", "bsx_pinned_alloc", "bsx_pinned_free",
     "bsx_meth_create", "bsx_meth_destroy", "bsx_meth_set_reference", "bsx_meth_add", "bsx_meth_combine_cpg", "bsx_meth_valid_mappings",
@@ -283,6 +283,12 @@ class _Batch:
             _check(lib().bsx_batch_sync(self.h))
 
     def sync(self): _check(lib().bsx_batch_sync(self.h))
+    def scan_ms(self):
+        """(sum of the k_hscan launch durations of the last run in ms, number of launches)"""
+        t, n = C.c_float(), C.c_uint32()
+        _check(lib().bsx_batch_scan_ms(self.h, C.byref(t), C.byref(n)))
+        return t.value, n.value
+
     def kernel_ms(self): return float(lib().bsx_batch_kernel_ms(self.h))
 
     def counters(self):

@@ -1594,7 +1594,7 @@ __global__ __launch_bounds__(256, BSX_HSCAN_WAVES) void k_hscan(AlignArgs A, Hea
     // one task per wave, no queue: the blocks of a pass retire one by one, so the control kernel of the other unit
     // group (high-priority stream) finds free slots while this kernel is still running
     const uint32_t n_tasks = min(*H.n_tasks, H.task_cap);
-    u64 scanned = 0;
+    u64 scanned = 0, scanned_w = 0;
     for (bool once = true; once; once = false) {
         const uint32_t t = blockIdx.x * 4 + (uint32_t)wv;
         if (t >= n_tasks) break;
@@ -1682,10 +1682,10 @@ __global__ __launch_bounds__(256, BSX_HSCAN_WAVES) void k_hscan(AlignArgs A, Hea
             }
         }
         if (lane == 0) { o->count = overflow ? 0 : nsurv; o->overflow = overflow ? 1 : 0; o->acc[0] = a0; o->acc[1] = a1; o->acc[2] = a2; o->acc[3] = a5; }
-        scanned += a0;
+        scanned += a0; scanned_w += a1 + 2 * a2 + 5 * a5;
         wave_fence();
     }
-    if (lane == 0 && scanned) atomicAdd((u64 *)&A.counters[7], scanned);  // candidates evaluated by the scan kernel (incl. speculation)
+    if (lane == 0 && scanned) { atomicAdd((u64 *)&A.counters[7], scanned); atomicAdd((u64 *)&A.counters[8], scanned_w); }  // work of the scan kernel (incl. speculation)
 }
 
 }  // namespace

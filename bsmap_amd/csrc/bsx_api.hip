@@ -203,6 +203,8 @@ struct bsx_batch {
     uint32_t max_units = 0, n_units = 0, first_index = 0;
     hipStream_t stream = nullptr, stream_hi = nullptr;  // stream_hi: control passes of the heavy pipeline
     hipEvent_t ev_ctrl[2] = {nullptr, nullptr}, ev_scan[2] = {nullptr, nullptr}, ev_sync = nullptr;
+    std::vector<hipEvent_t> scan_ev;  // pairs of timing events around every k_hscan launch of the last run (pool grows on demand)
+    size_t scan_ev_used = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     uint8_t *d_seq[2] = {nullptr, nullptr}, *d_qual[2] = {nullptr, nullptr};
     uint64_t *d_off[2] = {nullptr, nullptr};
@@ -342,6 +344,7 @@ extern "C" void bsx_batch_destroy(bsx_batch *b)
     if (b->ev1) (void)hipEventDestroy(b->ev1);
     if (b->stream_hi) { (void)hipStreamSynchronize(b->stream_hi); (void)hipStreamDestroy(b->stream_hi); }
     for (hipEvent_t e : {b->ev_ctrl[0], b->ev_ctrl[1], b->ev_scan[0], b->ev_scan[1], b->ev_sync}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : b->scan_ev) (void)hipEventDestroy(e);
     if (b->stream) (void)hipStreamDestroy(b->stream);
     delete b;
 }
@@ -431,7 +434,7 @@ extern "C" int bsx_batch_run_range(bsx_batch *b, uint32_t first_unit, uint32_t n
     HIP_TRY(hipEventRecord(b->ev0, b->stream));
     bsx_launch_align(A, b->paired, b->grid_blocks, b->stream);
     HIP_TRY(hipGetLastError());
-    b->last_heavy = 0; b->last_heavy_iters = 0;
+    b->last_heavy = 0; b->last_heavy_iters = 0; b->scan_ev_used = 0;
     if (A.heavy_threshold) {
         // heavy pipeline: iterate k_hctrl / k_hscan until every deferred unit is finished (host-driven, so this call
         // returns only after the deferred units are done; units that were not deferred are already complete)
@@ -499,8 +502,16 @@ extern "C" int bsx_batch_run_range(bsx_batch *b, uint32_t first_unit, uint32_t n
                         // (the counters of this pass live in the block the control kernel just wrote: blk[cur] after the flip)
                         q.H.n_tasks = q.blk[q.cur] + 1; q.H.queue = q.blk[q.cur] + 2;
                         HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_ctrl[g], 0));
+                        if (b->scan_ev_used + 2 > b->scan_ev.size()) {
+                            hipEvent_t e0, e1;
+                            HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+                            b->scan_ev.push_back(e0); b->scan_ev.push_back(e1);
+                        }
+                        HIP_TRY(hipEventRecord(b->scan_ev[b->scan_ev_used], b->stream));
                         bsx_launch_hscan(A, q.H, (int)((n_tasks + 3) / 4), b->stream);
                         HIP_TRY(hipGetLastError());
+                        HIP_TRY(hipEventRecord(b->scan_ev[b->scan_ev_used + 1], b->stream));
+                        b->scan_ev_used += 2;
                         HIP_TRY(hipEventRecord(b->ev_scan[g], b->stream));
                         q.scan_pending = true;
                     }
@@ -532,6 +543,18 @@ extern "C" float bsx_batch_kernel_ms(bsx_batch *b)
     float ms = -1.f;
     if (hipEventElapsedTime(&ms, b->ev0, b->ev1) != hipSuccess) return -1.f;
     return ms;
+}
+
+extern "C" int bsx_batch_scan_ms(bsx_batch *b, float *total_ms, uint32_t *launches)
+{
+    if (!b || !total_ms || !launches) return BSX_ERR_ARG;
+    if (!b->ran) return BSX_ERR_STATE;
+    HIP_TRY(hipSetDevice(b->ref->device));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    float sum = 0.f;
+    for (size_t i = 0; i + 1 < b->scan_ev_used; i += 2) { float ms = 0.f; HIP_TRY(hipEventElapsedTime(&ms, b->scan_ev[i], b->scan_ev[i + 1])); sum += ms; }
+    *total_ms = sum; *launches = (uint32_t)(b->scan_ev_used / 2);
+    return BSX_OK;
 }
 
 extern "C" int bsx_batch_results_se(bsx_batch *b, bsx_hit *out, bsx_class_counts *counts)

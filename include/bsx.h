@@ -138,8 +138,10 @@ typedef struct bsx_pair {
 } bsx_pair;
 
 /* work counters, SURVEY §8(d): 0 n_lookup, 1 n_cand, 2 sum_w (64-bit reference words the reference
- * algorithm touches), 3 n_orient, 4 reads/pairs processed, 5 aligned reads (n_aligned semantics), 6 aligned pairs, 7 spare */
-#define BSX_N_COUNTERS 8
+ * algorithm touches), 3 n_orient, 4 reads/pairs processed, 5 aligned reads (n_aligned semantics), 6 aligned pairs,
+ * 7 candidates evaluated by the scan kernel of the heavy pipeline (k_hscan; a subset of 1 plus the little it evaluates
+ * speculatively), 8 their reference words (as 2), 9 spare */
+#define BSX_N_COUNTERS 10
 
 int bsx_batch_create(bsx_ref *r, uint32_t max_units, int paired, bsx_batch **out);
 void bsx_batch_destroy(bsx_batch *b);
@@ -162,6 +164,9 @@ int bsx_batch_run(bsx_batch *b);
 int bsx_batch_run_range(bsx_batch *b, uint32_t first_unit, uint32_t n_units);
 int bsx_batch_sync(bsx_batch *b);
 float bsx_batch_kernel_ms(bsx_batch *b);          /* HIP-event time of the last run's align kernel (after sync) */
+/* the scan kernel's launches of the last run: their number and the sum of their HIP-event durations on the stream they
+ * were launched on (control kernels of the other unit group may run beside them on another stream) */
+int bsx_batch_scan_ms(bsx_batch *b, float *total_ms, uint32_t *launches);
 int bsx_batch_results_se(bsx_batch *b, bsx_hit *out, bsx_class_counts *counts /* may be NULL */);
 int bsx_batch_results_pe(bsx_batch *b, bsx_pair *out, bsx_class_counts *counts_a, bsx_class_counts *counts_b, uint16_t *n_pairs31);
 int bsx_batch_counters(bsx_batch *b, uint64_t c[BSX_N_COUNTERS]);   /* accumulated since creation / last reset */
