@@ -39,7 +39,7 @@ def main():
     ap.add_argument("--pairs-per-step", type=int, default=1 << 20)
     ap.add_argument("--genome", default="hg38", help="hg38 (3.09 Gbp synthetic, the bench config) or a fraction like 0.05 for quick checks")
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
-    ap.add_argument("--e2e-pairs", type=int, default=4 << 20, help="pairs of the end-to-end CLI run (FASTQ -> SAM in /dev/shm) reported beside the metric; 0 = skip")
+    ap.add_argument("--e2e-pairs", type=int, default=8 << 20, help="pairs of the end-to-end CLI run (FASTQ -> SAM in /dev/shm) reported beside the metric; 0 = skip")
     ap.add_argument("--in-flight", type=int, default=2, help="batches in flight per GPU (host threads, one device batch each): the latency-bound main "
                     "kernel of one batch overlaps the VALU-bound scan passes of the other; 1 = strictly one Do_Batch at a time")
     ap.add_argument("--waves-per-cu", type=int, default=0)
