@@ -1583,20 +1583,23 @@ __global__ __launch_bounds__(256) void k_hctrl(AlignArgs A, HeavyArgs H)
 #ifndef BSX_HSCAN_WAVES
 #define BSX_HSCAN_WAVES 6  /* 80 VGPRs: the batched tail loads need more than the 64 of 8 waves; measured equal from 4 to 7 (the kernel is VALU-bound) */
 #endif
-__global__ __launch_bounds__(256, BSX_HSCAN_WAVES) void k_hscan(AlignArgs A, HeavyArgs H)
+#ifndef BSX_HSCAN_WPB
+#define BSX_HSCAN_WPB 4  /* waves (= tasks) per block */
+#endif
+__global__ __launch_bounds__(64 * BSX_HSCAN_WPB, BSX_HSCAN_WAVES) void k_hscan(AlignArgs A, HeavyArgs H)
 {
     __shared__ BlockLds BL;
-    __shared__ uint32_t TAB[4][4][32];
+    __shared__ uint32_t TAB[BSX_HSCAN_WPB][4][32];
     const DevParams &P = A.P;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    init_block_lds(P, BL, threadIdx.x, 256);
+    init_block_lds(P, BL, threadIdx.x, 64 * BSX_HSCAN_WPB);
     __syncthreads();
     // one task per wave, no queue: the blocks of a pass retire one by one, so the control kernel of the other unit
     // group (high-priority stream) finds free slots while this kernel is still running
     const uint32_t n_tasks = min(*H.n_tasks, H.task_cap);
     u64 scanned = 0, scanned_w = 0;
     for (bool once = true; once; once = false) {
-        const uint32_t t = blockIdx.x * 4 + (uint32_t)wv;
+        const uint32_t t = blockIdx.x * BSX_HSCAN_WPB + (uint32_t)wv;
         if (t >= n_tasks) break;
         const uint32_t hidx = rfl(H.tasks[t].h), tc0 = rfl(H.tasks[t].c0), tn = rfl(H.tasks[t].n);
         if (tn == 0) {  // slot neutralised by a refused request: its unit has not published a list (ListReq may be stale)
@@ -1703,10 +1706,10 @@ void bsx_launch_hctrl(const AlignArgs &A, const HeavyArgsRaw &R, int paired, int
     else hipLaunchKernelGGL(k_hctrl<false>, dim3(grid_blocks), dim3(256), 0, stream, A, H);
 }
 
-void bsx_launch_hscan(const AlignArgs &A, const HeavyArgsRaw &R, int grid_blocks, hipStream_t stream)
+void bsx_launch_hscan(const AlignArgs &A, const HeavyArgsRaw &R, uint32_t n_tasks, hipStream_t stream)
 {
     const HeavyArgs H = typed(R);
-    hipLaunchKernelGGL(k_hscan, dim3(grid_blocks), dim3(256), 0, stream, A, H);
+    hipLaunchKernelGGL(k_hscan, dim3((n_tasks + BSX_HSCAN_WPB - 1) / BSX_HSCAN_WPB), dim3(64 * BSX_HSCAN_WPB), 0, stream, A, H);
 }
 
 size_t bsx_hstate_bytes(void) { return sizeof(HState); }

@@ -508,7 +508,7 @@ extern "C" int bsx_batch_run_range(bsx_batch *b, uint32_t first_unit, uint32_t n
                             b->scan_ev.push_back(e0); b->scan_ev.push_back(e1);
                         }
                         HIP_TRY(hipEventRecord(b->scan_ev[b->scan_ev_used], b->stream));
-                        bsx_launch_hscan(A, q.H, (int)((n_tasks + 3) / 4), b->stream);
+                        bsx_launch_hscan(A, q.H, n_tasks, b->stream);
                         HIP_TRY(hipGetLastError());
                         HIP_TRY(hipEventRecord(b->scan_ev[b->scan_ev_used + 1], b->stream));
                         b->scan_ev_used += 2;

@@ -41,7 +41,7 @@ struct HeavyArgsRaw {
 
 void bsx_launch_align(const AlignArgs &A, int paired, int grid_blocks, hipStream_t stream);
 void bsx_launch_hctrl(const AlignArgs &A, const HeavyArgsRaw &H, int paired, int grid_blocks, hipStream_t stream);
-void bsx_launch_hscan(const AlignArgs &A, const HeavyArgsRaw &H, int grid_blocks, hipStream_t stream);
+void bsx_launch_hscan(const AlignArgs &A, const HeavyArgsRaw &H, uint32_t n_tasks, hipStream_t stream);
 size_t bsx_hstate_bytes(void);
 size_t bsx_htask_bytes(void);
 size_t bsx_htaskout_bytes(void);
