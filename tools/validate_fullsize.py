@@ -19,11 +19,15 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--pairs", type=int, default=1 << 20)
     ap.add_argument("--check", type=int, default=200000)
+    ap.add_argument("--genome-seed", type=int, default=38)
+    ap.add_argument("--read-seed", type=int, default=77)
+    ap.add_argument("--opts", default="", help="extra option letters as k=v,k=v (e.g. v=4,w=50,r=0)")
     a = ap.parse_args()
     kw = dict(s=16, v=6, I=4, m=28, x=500, S=1, r=1, pairend=1)
-    ref = B.RefSeq(B.make_params(**kw)).synthetic(HG38, seed=38).CreateIndex()
+    kw.update({k: int(v) for k, v in (kv.split("=") for kv in a.opts.split(",") if kv)})
+    ref = B.RefSeq(B.make_params(**kw)).synthetic(HG38, seed=a.genome_seed).CreateIndex()
     pa = B.PairAlign(ref, a.pairs)
-    pa.synth_reads(a.pairs, 144, seed=77)
+    pa.synth_reads(a.pairs, 144, seed=a.read_seed)
     pa.Do_Batch()
     out, ca, cb, npairs = pa.results()
     K = min(a.check, a.pairs)
@@ -39,7 +43,8 @@ def main():
         n = int((np.asarray(x) != np.asarray(y)).sum())
         if n: bad[name] = n
     chk("paired", ores["paired"], out["paired"][:K])
-    chk("n_pairs", ores["n_pairs"][:, :13], npairs[:K, :13])
+    nc_ = kw["v"] + 1
+    chk("n_pairs", ores["n_pairs"][:, :2 * nc_ - 1], npairs[:K, :2 * nc_ - 1])
     up = (ores["tmp"] == 1) | (ores["paired"] == 0)
     chk("unpaired_out", up, out["unpaired_out"][:K] != 0)
     pr = ~up
@@ -47,14 +52,15 @@ def main():
         chk("pick." + fld, ores["pick"][fld][pr], out[fld][:K][pr])
     for m_, cnts in (("a", ca), ("b", cb)):
         ok = ores[m_]["filtered"] == 0
-        chk(m_ + ".n_hit", ores[m_]["n_hit"][ok][:, :7], cnts["n_hit"][:K][ok][:, :7])
-        chk(m_ + ".n_chit", ores[m_]["n_chit"][ok][:, :7], cnts["n_chit"][:K][ok][:, :7])
+        chk(m_ + ".n_hit", ores[m_]["n_hit"][ok][:, :nc_], cnts["n_hit"][:K][ok][:, :nc_])
+        chk(m_ + ".n_chit", ores[m_]["n_chit"][ok][:, :nc_], cnts["n_chit"][:K][ok][:, :nc_])
         sel = up & ok & (ores[m_]["n_best"] > 0)
         for fld in ("chr", "loc", "best_class"):
             chk(f"{m_}.{fld}", ores[m_][fld][sel], out[m_][fld][:K][sel])
     load = ca["n_hit"][:K].sum(1).astype(np.int64) + cb["n_chit"][:K].sum(1)
     print(json.dumps({"pairs_on_gpu": a.pairs, "pairs_checked": K, "paired": int(pr.sum()), "heavy_units_in_batch": int(pa.heavy_units()),
-                      "max_hits_in_checked_unit": int(load.max()), "oracle_s": round(t_cpu, 1), "mismatching_fields": bad}))
+                      "max_hits_in_checked_unit": int(load.max()), "oracle_s": round(t_cpu, 1), "options": kw,
+                      "genome_seed": a.genome_seed, "read_seed": a.read_seed, "mismatching_fields": bad}))
     pa.close(); ref.close()
     sys.exit(1 if bad else 0)
 
