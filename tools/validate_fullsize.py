@@ -21,10 +21,15 @@ def main():
     ap.add_argument("--check", type=int, default=200000)
     ap.add_argument("--genome-seed", type=int, default=38)
     ap.add_argument("--read-seed", type=int, default=77)
+    ap.add_argument("--se", action="store_true", help="single reads of 100 nt with the C2 options (-v 4) instead of pairs")
     ap.add_argument("--opts", default="", help="extra option letters as k=v,k=v (e.g. v=4,w=50,r=0)")
     a = ap.parse_args()
     kw = dict(s=16, v=6, I=4, m=28, x=500, S=1, r=1, pairend=1)
+    if a.se:
+        kw = dict(s=16, v=4, I=4, S=1, r=1)
     kw.update({k: int(v) for k, v in (kv.split("=") for kv in a.opts.split(",") if kv)})
+    if a.se:
+        return validate_se(a, kw)
     ref = B.RefSeq(B.make_params(**kw)).synthetic(HG38, seed=a.genome_seed).CreateIndex()
     pa = B.PairAlign(ref, a.pairs)
     pa.synth_reads(a.pairs, 144, seed=a.read_seed)
@@ -62,6 +67,35 @@ def main():
                       "max_hits_in_checked_unit": int(load.max()), "oracle_s": round(t_cpu, 1), "options": kw,
                       "genome_seed": a.genome_seed, "read_seed": a.read_seed, "mismatching_fields": bad}))
     pa.close(); ref.close()
+    sys.exit(1 if bad else 0)
+
+
+def validate_se(a, kw):
+    ref = B.RefSeq(B.make_params(**kw)).synthetic(HG38, seed=a.genome_seed).CreateIndex()
+    sa = B.SingleAlign(ref, a.pairs)
+    sa.synth_reads(a.pairs, 100, seed=a.read_seed)
+    sa.Do_Batch()
+    hits, cc = sa.results()
+    K = min(a.check, a.pairs)
+    f, c = ref.words(); an, sz, rc = ref.info(); off, nf, ent = ref.index()
+    oref = O.OracleRef.wrap(O.make_params(**kw), f, c, an, sz, rc, off, nf, ent)
+    b1, o1 = sa.download_reads(0)
+    t0 = time.time()
+    ores, ocnt = O.se_batch(oref, b1[:int(o1[K])], o1[:K + 1].copy(), threads=os.cpu_count() or 8)
+    t_cpu = time.time() - t0
+    nc_ = kw["v"] + 1
+    bad = {}
+    for name, x, y in (("n_hit", ores["n_hit"][:, :nc_], cc["n_hit"][:K, :nc_]), ("n_chit", ores["n_chit"][:, :nc_], cc["n_chit"][:K, :nc_]),
+                       ("n_best", np.maximum(ores["n_best"], 0), hits["n_best"][:K])):
+        n = int((np.asarray(x) != np.asarray(y)).sum())
+        if n: bad[name] = n
+    has = ores["n_best"] > 0
+    for fld in ("chr", "loc", "best_class"):
+        n = int((ores[fld][has] != hits[fld][:K][has]).sum())
+        if n: bad[fld] = n
+    print(json.dumps({"reads_on_gpu": a.pairs, "reads_checked": K, "placed": int(has.sum()), "heavy_units_in_batch": int(sa.heavy_units()), "oracle_s": round(t_cpu, 1),
+                      "options": kw, "genome_seed": a.genome_seed, "read_seed": a.read_seed, "mismatching_fields": bad}))
+    sa.close(); ref.close()
     sys.exit(1 if bad else 0)
 
 
