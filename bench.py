@@ -7,7 +7,7 @@ Workload (config.workload = "C3"): 2x150 bp (stored as 144 nt, the reference's R
 Do_Batch over --pairs-per-step read pairs that are already resident in HBM; value = reads (2 per pair) of all ranks /
 wall time of the K timed steps (max over ranks).
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W        (N > 1 without a launcher: spawns the N ranks itself, see launch_ranks)
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (one rank per GPU, reads sharded)
 """
 import argparse
@@ -31,6 +31,35 @@ def algorithmic_bytes(c, n_reads):
     return 8 * n_lookup + 4 * n_cand + 8 * sum_w + 80 * n_orient + 16 * n_reads
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: start `python -m torch.distributed.run` with one rank
+    per GPU as a CHILD process — before torch or libbsx is imported here, so this process never touches a GPU — relay its
+    output (rank 0 prints the one JSON line) and return its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
+def selftest_launch():
+    """what the ranks do under --selftest-launch (CPU test of the launcher path): gloo rendezvous, the same stats
+    reduction as the real run, one JSON line from rank 0"""
+    import torch.distributed as dist
+    from bsmap_amd import sharding
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    mx, tot, table = sharding.gather_stats(0.5 * (rank + 1), [rank + 1, 10], dist)
+    if rank == 0:
+        print(json.dumps({"selftest": "launch", "n_gpus": world, "max_elapsed": mx, "sum": [float(x) for x in tot], "rows": int(table.shape[0])}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -46,7 +75,17 @@ def main():
     ap.add_argument("--heavy-limits", default="", help="tuning: units per round,scan-task pool of the heavy pipeline (library default 32768,524288)")
     ap.add_argument("--heavy-threshold", type=int, default=0, help="tuning: candidate-list length that defers a unit to the heavy pipeline (0 = library default)")
     ap.add_argument("--mode", default="pe", choices=["pe", "se"], help="pe = C3 (default, the metric's config); se = C2 (1x100, -v 4)")
+    ap.add_argument("--profile-serial", action="store_true", help="profiling mode: one batch in flight, one unit group (control and scan passes "
+                    "strictly alternate), no CPU / end-to-end legs — no two kernels overlap, so per-kernel durations add up to at most the step time")
+    ap.add_argument("--selftest-launch", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    if args.selftest_launch:
+        return selftest_launch()
+    if args.profile_serial:
+        args.in_flight, args.cpu_seconds, args.e2e_pairs = 1, 0.0, 0
+        os.environ["BSX_HEAVY_GROUPS"] = "1"  # read by bsx_batch_create
 
     import torch  # first: libbsx.so then binds to the HIP runtime torch has already loaded
     rank = int(os.environ.get("RANK", "0"))

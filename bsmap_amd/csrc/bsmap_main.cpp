@@ -39,8 +39,8 @@ struct Opts {
     string a_file, b_file, ref_file, out_file, out_unpair;
     int out_sam = 0, out_ref = 0, out_unmap = 0, num_procs = 0;
     unsigned read_start = 1, read_end = ~0u;
-    int device = 0;
-    unsigned batch = 1u << 20;
+    vector<int> devices;            // -G: ordinals, or every visible device for "all" (extension; default {0})
+    unsigned batch = 1050000;       // units per batch: a multiple of the reference's BatchNum 50000 (see the parse stage)
 };
 
 const char chain_flag[2] = {'+', '-'};
@@ -88,7 +88,7 @@ void usage()
          << "       -m  <int>   minimal insert size allowed, default=28\n"
          << "       -x  <int>   maximal insert size allowed, default=500\n"
          << "       -2  <str>   output file of unpaired alignment hits\n"
-         << "       -G  <int>   GPU ordinal, default 0 (extension)\n"
+         << "       -G  <str>   GPU ordinal(s): N, a list N,M,... or 'all'; batches are dealt to the GPUs in turn, default 0 (extension)\n"
          << "       -h          help\n\n";
     exit(1);
 }
@@ -147,7 +147,11 @@ int parse_options(int argc, char **argv, Opts &o)
         case 'M': p.read_nt = val[0]; p.ref_nt = val[1]; break;
         case 'L': p.max_readlen = atoi(val); break;
         case 'S': p.randseed = atoi(val); break;
-        case 'G': o.device = atoi(val); break;
+        case 'G':
+            o.devices.clear();
+            if (!strcmp(val, "all")) { const int n = bsx_device_count(); for (int d = 0; d < n; d++) o.devices.push_back(d); }
+            else for (const char *q = val; *q;) { o.devices.push_back(atoi(q)); while (*q && *q != ',') q++; if (*q == ',') q++; }
+            break;
         case 'h': usage(); break;
         default: return i;
         }
@@ -420,23 +424,27 @@ struct Slot {
     Buf<bsx_class_counts> cca, ccb;
     vector<Text> out, out_unpair;
     int stage = 0;  // 0 free, 1 parsed, 2 aligned, 3 formatted
+    long batch = -1;  // ordinal of the batch the slot holds while stage != 0
 };
 
 struct Ring {
-    static const int NS = 6;
-    Slot slot[NS];
+    const int NS;
+    vector<Slot> slot;
+    explicit Ring(int ns) : NS(ns), slot(ns) {}
     mutex mu;
     condition_variable cv;
     long n_batches = -1;  // known once the parser reaches the end of the input
     Slot &at(long k) { return slot[k % NS]; }
-    // wait until batch k is in `stage`; false when the input ended before batch k
+    // wait until batch k is in `stage`; false when the input ended before batch k.  A slot is shared by the batches
+    // k, k+NS, ...: a consumer must not mistake an older batch that is still in the same stage for its own, so the slot
+    // carries the ordinal of the batch it holds (stage 0 = free: the parser takes it for whatever batch comes next).
     bool acquire(long k, int stage)
     {
         unique_lock<mutex> lk(mu);
-        cv.wait(lk, [&] { return (n_batches >= 0 && k >= n_batches) || at(k).stage == stage; });
+        cv.wait(lk, [&] { return (n_batches >= 0 && k >= n_batches) || (at(k).stage == stage && (stage == 0 || at(k).batch == k)); });
         return !(n_batches >= 0 && k >= n_batches);
     }
-    void release(long k, int stage) { { lock_guard<mutex> lk(mu); at(k).stage = stage; } cv.notify_all(); }
+    void release(long k, int stage) { { lock_guard<mutex> lk(mu); at(k).stage = stage; at(k).batch = stage ? k : -1; } cv.notify_all(); }
     void finish(long n) { { lock_guard<mutex> lk(mu); n_batches = n; } cv.notify_all(); }
 };
 
@@ -467,13 +475,18 @@ int main(int argc, char **argv)
     // The ring's upload / download buffers are page-locked (the transfers are then plain DMA).  Locking gigabytes of pages
     // takes seconds, so it happens on a side thread while the reference is loaded and indexed.
     static const RawAlloc pinned = {bsx_pinned_alloc, bsx_pinned_free};
-    Ring &ring = *new Ring;  // never freed: error paths exit() while side threads may still touch it
+    if (o.devices.empty()) o.devices.push_back(0);
+    const int ND = (int)o.devices.size();
+    const int NB = getenv("BSX_GPU_BATCHES") ? max(1, min(4, atoi(getenv("BSX_GPU_BATCHES")))) : 2;  // device batches in flight per GPU
+    const int NG = ND * NB;                                                                          // GPU-stage threads
+    Ring &ring = *new Ring(max(6, NG + 4));  // never freed: error paths exit() while side threads may still touch it
     const bool pe = !o.a_file.empty() && !o.b_file.empty();
     thread t_pin([&] {
+        bsx_thread_device(o.devices[0]);  // the page-locked ring belongs to a context: not implicitly device 0's
         auto fsize = [](const string &f) { struct stat st; return (!f.empty() && stat(f.c_str(), &st) == 0) ? (size_t)st.st_size : (size_t)0; };
         const size_t fa = fsize(o.a_file), fb = fsize(o.b_file);
         const size_t units = min<size_t>(o.batch, max(fa, fb) / 2 + 1);
-        for (int k = 0; k < Ring::NS; k++) {
+        for (int k = 0; k < ring.NS; k++) {
             Slot &s = ring.slot[k];
             s.A.set_alloc(&pinned); s.B.set_alloc(&pinned);
             s.hits.set_alloc(&pinned); s.pairs.set_alloc(&pinned); s.cca.set_alloc(&pinned); s.ccb.set_alloc(&pinned);
@@ -484,10 +497,27 @@ int main(int argc, char **argv)
             else s.hits.reserve(units);
         }
     });
+    // One replica of reference + index per GPU (7.8 GB of 288 at hg38 size); the replicas load and index concurrently.
     RefView rv;
-    rc = bsx_ref_create_from_file(&o.p, o.ref_file.c_str(), o.device, &rv.ref);
-    if (rc) die(rc, "loading the reference");
-    const double t_loaded = now_s();
+    vector<bsx_ref *> refs(ND, nullptr);
+    vector<double> t_loaded_d(ND, 0.0);
+    {
+        vector<int> rcs(ND, 0), rci(ND, 0);
+        vector<thread> tl;
+        for (int d = 1; d < ND; d++)
+            tl.emplace_back([&, d] {
+                rcs[d] = bsx_ref_create_from_file(&o.p, o.ref_file.c_str(), o.devices[d], &refs[d]);
+                if (!rcs[d]) rci[d] = bsx_index_build(refs[d]);
+            });
+        rcs[0] = bsx_ref_create_from_file(&o.p, o.ref_file.c_str(), o.devices[0], &refs[0]);
+        t_loaded_d[0] = now_s();
+        if (rcs[0]) die(rcs[0], "loading the reference");
+        rv.ref = refs[0];
+        // (the replicas keep loading while device 0 goes on to print its lines and build its index below)
+        for (thread &t : tl) t.join();
+        for (int d = 1; d < ND; d++) { if (rcs[d]) die(rcs[d], "loading the reference"); if (rci[d]) die(rci[d], "building the seed index"); }
+    }
+    const double t_loaded = t_loaded_d[0];
     const uint32_t n_chr = bsx_ref_n_chr(rv.ref);
     rv.anchor.resize(n_chr + 1); rv.chr_size.resize(n_chr); rv.rc_offset.resize(n_chr);
     bsx_ref_info(rv.ref, rv.anchor.data(), rv.chr_size.data(), rv.rc_offset.data());
@@ -535,10 +565,11 @@ int main(int argc, char **argv)
         fout_unpair = ::open(o.out_unpair.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
         if (fout_unpair < 0) { cerr << "failed to open output file for unpaired hits (check -2 option): " << o.out_unpair << endl; exit(1); }
     }
-    const int NG = getenv("BSX_GPU_BATCHES") ? max(1, min(4, atoi(getenv("BSX_GPU_BATCHES")))) : 2;  // device batches in flight
-    bsx_batch *batches[4] = {nullptr, nullptr, nullptr, nullptr};
+    // GPU-stage thread g drives device batch g: batches k = g, g+NG, ... of the input; thread g works on GPU g % ND, so
+    // consecutive batches go to different GPUs (the reference's worker pool, main.cpp:74-84,116-131, with GPUs for threads)
+    vector<bsx_batch *> batches(NG, nullptr);
     for (int g = 0; g < NG; g++) {
-        rc = bsx_batch_create(rv.ref, o.batch, pe ? 1 : 0, &batches[g]);
+        rc = bsx_batch_create(refs[g % ND], o.batch, pe ? 1 : 0, &batches[g]);
         if (rc) die(rc, "creating the batch");
     }
     ReadOpts ro;
@@ -546,7 +577,11 @@ int main(int argc, char **argv)
     Reader ra, rb;
     ra.open(o.a_file, ro);
     if (pe) rb.open(o.b_file, ro);
-    if (pe) cout << "Pair-end alignment(GPU " << o.device << ")\n"; else cout << "Single read alignment(GPU " << o.device << ")\n";
+    {
+        string dl;
+        for (int d = 0; d < ND; d++) dl += (d ? "," : "") + to_string(o.devices[d]);
+        if (pe) cout << "Pair-end alignment(GPU " << dl << ")\n"; else cout << "Single read alignment(GPU " << dl << ")\n";
+    }
     const int workers = o.num_procs > 0 ? o.num_procs : (int)min(64u, max(1u, thread::hardware_concurrency()));
     Formatter totals(o, rv);
     unsigned total = 0;
@@ -566,9 +601,21 @@ int main(int argc, char **argv)
             const size_t n1 = load_reads(ra, s.A, o.batch, ro, pe ? 1 : 0);
             if (pe) tb.join();
             busy[0] += now_s() - t;
-            if (!n1 || (pe && n1 != n2)) break;
+            if (!n1) break;
             s.n = n1;
             s.total_after = ra.index - o.read_start + 1;
+            if (pe && n1 != n2) {
+                // Mate files of unequal length.  The reference reads 50000 pairs per batch and stops at the first batch whose
+                // two counts differ (main.cpp:88-93): it maps the first floor(min(N1,N2)/50000)*50000 pairs.  The batches here
+                // are larger, so the same cut is applied inside the last one (exact whenever the batch size is a multiple of
+                // 50000, as the default is), and the loss is reported instead of silent.
+                const size_t g0 = (size_t)k * o.batch, m = min(n1, n2);
+                const size_t keep_global = (g0 + m) / 50000 * 50000, keep = keep_global > g0 ? keep_global - g0 : 0;
+                cerr << "warning: mate files differ in length (" << g0 + n1 << " vs " << g0 + n2 << " reads so far); like the reference, mapping stops after pair "
+                     << g0 + keep << endl;
+                if (keep) { s.n = keep; s.total_after = (unsigned)(g0 + keep); ring.release(k, 1); k++; }
+                break;
+            }
             ring.release(k, 1);
         }
         ring.finish(k);
@@ -699,6 +746,6 @@ int main(int argc, char **argv)
                         "\"stage_busy_s\": {\"parse\": %.3f, \"gpu\": %.3f, \"format\": %.3f, \"write\": %.3f}}\n",
                 t_loaded - t0, t_indexed - t_loaded, t_map1 - t_map0, total, pe ? 2 * total : total, workers, busy[0], busy[1], busy[2], busy[3]);
     for (int g = 0; g < NG; g++) bsx_batch_destroy(batches[g]);
-    bsx_ref_destroy(rv.ref);
+    for (bsx_ref *r : refs) bsx_ref_destroy(r);
     return 0;
 }

@@ -366,10 +366,18 @@ static int upload_mate(bsx_batch *b, int m, uint32_t n, const char *seqs, const 
     return BSX_OK;
 }
 
+extern "C" int bsx_thread_device(int device)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) { g_bsx_err = "device ordinal out of range"; return BSX_ERR_NODEVICE; }
+    HIP_TRY(hipSetDevice(device));
+    return BSX_OK;
+}
+
 extern "C" void *bsx_pinned_alloc(size_t bytes)
 {
     void *p = nullptr;
-    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) return nullptr;  // portable: every GPU of a -G list copies from / to it
     return p;
 }
 extern "C" void bsx_pinned_free(void *p) { if (p) (void)hipHostFree(p); }

@@ -147,6 +147,7 @@ int bsx_batch_create(bsx_ref *r, uint32_t max_units, int paired, bsx_batch **out
 void bsx_batch_destroy(bsx_batch *b);
 /* Page-locked host buffers for the arrays handed to bsx_batch_upload_* / bsx_batch_results_*: with them the transfers
  * are plain DMA (the reference has no counterpart: its reads never leave host memory).  Ordinary malloc memory works too. */
+int bsx_thread_device(int device);   /* make `device` the calling thread's current GPU (for bsx_pinned_alloc from a helper thread) */
 void *bsx_pinned_alloc(size_t bytes);
 void bsx_pinned_free(void *p);
 
@@ -190,6 +191,13 @@ int bsx_set_heavy_threshold(int n_candidates);
  * small values only make it take more rounds / passes — used by the tests to exercise those paths */
 int bsx_set_heavy_limits(uint32_t units_per_round, uint32_t task_pool);
 int bsx_batch_last_heavy_units(bsx_batch *b);   /* units the last run handed to the heavy pipeline */
+
+/* ---- measurement aid ("report both peak and a measured ceiling") -----------------------------------
+ * Memory rates of `device` in GB/s (1e9 bytes): streaming read of `bytes`, streaming copy (read + write counted), and
+ * 16-byte loads at random 4-byte-aligned addresses inside a window of `gather_window_bytes` — the access pattern of the
+ * candidate scan (useful bytes = 16 per load; *_Gloads_per_s = 1e9 loads/s).  Not on the alignment path. */
+int bsx_probe_memory(int device, uint64_t bytes, uint64_t gather_window_bytes, double *read_GBps, double *copy_GBps, double *gather16_GBps,
+                     double *gather16_Gloads_per_s);
 
 /* ---- methylation-ratio pile-up (reference: methratio.py of the BSMAP tree) ---------------------------
  * The reference walks the alignments in Python and increments two per-position counters; here that part runs on the

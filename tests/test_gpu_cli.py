@@ -154,3 +154,60 @@ def test_cli_bam_input_matches_reference_binary(name, tag, tmp_path):
     assert len(got) == len(exp) and len(got) > 30
     for g_, e_ in zip(got, exp):
         assert g_ == e_
+
+
+def _write_fastq(meta, tmp_path, tag, n_b=None):
+    pe = meta["kind"] == "pe"
+    files = [str(tmp_path / f"{tag}_{m}.fq") for m in ((1, 2) if pe else (1,))]
+    for m, fpath in enumerate(files):
+        with open(fpath, "w") as f:
+            reads = meta["reads"] if (m == 0 or n_b is None) else meta["reads"][:n_b]
+            for r in reads:
+                nm = r["name"] + (f"/{m + 1}" if pe else "")
+                seq, qual = (r[f"seq{m + 1}"], r[f"qual{m + 1}"]) if pe else (r["seq"], r["qual"])
+                f.write(f"@{nm}\n{seq}\n+\n{qual}\n")
+    return files
+
+
+def _run_cli(meta, fasta, files, out, extra, env):
+    opts = list(extra)
+    cmd = [BIN] + (["-D", meta["kw"]["D"]] if "D" in meta["kw"] else []) + ["-a", files[0]] + (["-b", files[1]] if len(files) > 1 else []) + ["-d", fasta, "-o", out] + opts
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+    assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-1500:]
+    return res
+
+
+@pytest.mark.parametrize("name", [n for n in sorted(CLI) if CLI[n]["sam_Ru"]["out"]][:3])
+def test_cli_device_batches_and_gpu_lists(name, tmp_path):
+    """1 / 3 / 4 device batches in flight over a ring of small batches (a ring slot is shared by batches k and k + slots:
+    with 4 GPU threads a thread used to be able to take another thread's batch), and -G lists: `-G 0,0` deals the batches
+    to two replicas of reference + index in turn (the multi-GPU path of the driver, here on one device), `-G all` = every
+    visible GPU.  All write the bytes of the plain run."""
+    meta, arr, fasta = G.load(name)
+    run = CLI[name]["sam_Ru"]
+    opts = [o for i, o in enumerate(run["options"]) if not (o == "-D" or (i and run["options"][i - 1] == "-D"))]
+    files = _write_fastq(meta, tmp_path, "in")
+    base = str(tmp_path / "base.sam")
+    r0 = _run_cli(meta, fasta, files, base, opts + ["-p", "1"], {"BSX_BATCH": "1048576"})
+    want = open(base, "rb").read()
+    summary = [l for l in r0.stdout.split("\n") if "aligned" in l or l.startswith(("pairs", "single"))]
+    assert len(want) > 1000
+    for tag, extra, env in (("nb1", [], {"BSX_GPU_BATCHES": "1", "BSX_BATCH": "23"}), ("nb3", [], {"BSX_GPU_BATCHES": "3", "BSX_BATCH": "7"}),
+                            ("nb4", [], {"BSX_GPU_BATCHES": "4", "BSX_BATCH": "5"}), ("g00", ["-G", "0,0"], {"BSX_BATCH": "11"}),
+                            ("gall", ["-G", "all"], {"BSX_BATCH": "13"})):
+        out = str(tmp_path / f"{tag}.sam")
+        r = _run_cli(meta, fasta, files, out, opts + ["-p", "3"] + extra, env)
+        assert open(out, "rb").read() == want, tag
+        assert [l for l in r.stdout.split("\n") if "aligned" in l or l.startswith(("pairs", "single"))] == summary, tag
+
+
+def test_cli_unequal_mate_files_cut_like_the_reference(tmp_path):
+    """mate files of different length: the reference maps whole batches of 50000 pairs until the counts of a batch differ
+    (main.cpp:88-93) — fewer than 50000 common pairs give an empty mapping; the driver says so on stderr"""
+    name = [n for n in sorted(CLI) if G.load(n)[0]["kind"] == "pe"][0]
+    meta, arr, fasta = G.load(name)
+    files = _write_fastq(meta, tmp_path, "uneq", n_b=len(meta["reads"]) - 7)
+    out = str(tmp_path / "o.sam")
+    r = _run_cli(meta, fasta, files, out, ["-p", "2"], {})  # default batch size: a multiple of 50000, so the cut is the reference's
+    assert "mate files differ in length" in r.stderr
+    assert [l for l in open(out).read().split("\n") if l and not l.startswith("@")] == []

@@ -73,3 +73,16 @@ def test_two_rank_gloo_matches_single_rank(tmp_path, oracle):
     assert got["rows"] == 2 and got["max"] == 0.5
     assert got["tot"] == [float(x) for x in cnt] + [float(len(seqs)), float(aligned)]
     oref.free()
+
+
+def test_bench_launcher_spawns_ranks_itself():
+    """`python bench.py --gpus 2` without torchrun: the launcher path of bench.py starts the two ranks as a child process
+    (gloo here, RCCL on GPUs) and rank 0 prints exactly one JSON line"""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--selftest-launch"], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    got = json.loads(lines[0])
+    assert got == {"selftest": "launch", "n_gpus": 2, "max_elapsed": 1.0, "sum": [3.0, 20.0], "rows": 2}

@@ -1,0 +1,108 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc SQ/TA/TCC counter passes per kernel into profiles/<tag>_sq.json.
+
+usage: summarize_sq.py <tag> <pass_dir> [<pass_dir> ...]        (each dir = one `rocprofv3 --pmc ... --kernel-trace -d <dir>` run,
+                                                                 CSV (`--output-format csv`) or the default rocpd .db)
+Derived per kernel (units per MI355X_MICROARCH.md: SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles;
+GRBM_GUI_ACTIVE is summed over the 8 XCDs):
+  clock_GHz            = GRBM_GUI_ACTIVE / 8 / kernel time
+  valu_instr_per_s     = SQ_INSTS_VALU / kernel time
+  valu_busy_frac_4cyc  = SQ_INSTS_VALU * 4 / (n_simd * GRBM_GUI_ACTIVE / 8)   (issue cost measured by tools/microbench/valu_issue)
+  valu_busy_frac_2cyc  = the same at 2 cycles per wave64 instruction
+  wait_inst_frac       = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES,   wait_any_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES
+  ta_busy_frac         = TA_TA_BUSY_sum / (n_cu * GRBM_GUI_ACTIVE / 8)
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sqlite3
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KERNELS = ("k_align", "k_hscan", "k_hctrl", "k_plan", "k_scan")
+N_CU, N_SIMD = 256, 1024
+
+
+def short(name):
+    for k in KERNELS:
+        if k in name:
+            t = "<true>" if "<true>" in name else "<false>" if "<false>" in name else ""
+            return k + t
+    return None
+
+
+def read_pass(d):
+    """-> {kernel: {counter: sum}}, {kernel: (launches, total_ns)}"""
+    acc = collections.defaultdict(lambda: collections.defaultdict(float))
+    disp = collections.defaultdict(dict)
+    csvs = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+    if csvs:
+        for f in csvs:
+            for r in csv.DictReader(open(f)):
+                k = short(r["Kernel_Name"])
+                if not k:
+                    continue
+                acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+                disp[k][r["Dispatch_Id"]] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    else:
+        for f in glob.glob(os.path.join(d, "**", "*.db"), recursive=True):
+            c = sqlite3.connect(f)
+            for name, ctr, val, did, s, e in c.execute("select kernel_name, counter_name, value, dispatch_id, start, end from counters_collection"):
+                k = short(name)
+                if not k:
+                    continue
+                acc[k][ctr] += float(val)
+                disp[k][did] = int(e) - int(s)
+    return acc, {k: (len(v), sum(v.values())) for k, v in disp.items()}
+
+
+def main():
+    tag, dirs = sys.argv[1], sys.argv[2:]
+    out = {"tag": tag, "passes": [], "kernels": {}}
+    merged = collections.defaultdict(dict)
+    for d in dirs:
+        acc, disp = read_pass(d)
+        out["passes"].append({"dir": os.path.basename(d.rstrip("/")), "counters": sorted({c for v in acc.values() for c in v})})
+        for k, ctrs in acc.items():
+            n, ns = disp[k]
+            for c, v in ctrs.items():
+                merged[k][c] = {"sum": v, "launches": n, "kernel_ms": ns / 1e6}
+    for k, ctrs in sorted(merged.items()):
+        e = {"counters": {c: v["sum"] for c, v in sorted(ctrs.items())}}
+        g = lambda c: ctrs[c]["sum"] if c in ctrs else None
+        t = lambda c: ctrs[c]["kernel_ms"] * 1e-3 if c in ctrs else None
+        e["launches"] = max(v["launches"] for v in ctrs.values())
+        e["kernel_ms_total"] = {c: round(v["kernel_ms"], 3) for c, v in ctrs.items() if c in ("SQ_INSTS_VALU", "GRBM_GUI_ACTIVE", "TA_TA_BUSY_sum", "SQ_WAIT_INST_ANY")}
+        d = {}
+        if g("GRBM_GUI_ACTIVE"):
+            d["clock_GHz"] = g("GRBM_GUI_ACTIVE") / 8 / t("GRBM_GUI_ACTIVE") / 1e9
+        clk = d.get("clock_GHz", 2.2) * 1e9
+        if g("SQ_INSTS_VALU"):
+            rate = g("SQ_INSTS_VALU") / t("SQ_INSTS_VALU")
+            d["valu_instr_per_s"] = rate
+            d["valu_busy_frac_4cyc"] = rate * 4 / (N_SIMD * clk)
+            d["valu_busy_frac_2cyc"] = rate * 2 / (N_SIMD * clk)
+        for c, name in (("SQ_INSTS_SALU", "salu_per_valu"), ("SQ_INSTS_VMEM_RD", "vmem_rd_per_valu"), ("SQ_INSTS_LDS", "lds_per_valu")):
+            if g(c) is not None and g("SQ_INSTS_VALU"):
+                d[name] = g(c) / g("SQ_INSTS_VALU")
+        if g("SQ_WAVE_CYCLES"):
+            for c, name in (("SQ_WAIT_INST_ANY", "wait_inst_frac"), ("SQ_WAIT_ANY", "wait_any_frac"), ("SQ_ACTIVE_INST_VALU", "active_valu_frac")):
+                if g(c) is not None:
+                    d[name] = g(c) / g("SQ_WAVE_CYCLES")  # (different passes: same kernel, same work)
+            if g("SQ_WAVES"):
+                d["quad_cycles_per_wave"] = g("SQ_WAVE_CYCLES") / g("SQ_WAVES")
+        if g("TA_TA_BUSY_sum"):
+            d["ta_busy_frac"] = g("TA_TA_BUSY_sum") / (N_CU * clk * t("TA_TA_BUSY_sum"))
+        if g("TCC_HIT_sum") is not None and g("TCC_MISS_sum") is not None and g("TCC_HIT_sum") + g("TCC_MISS_sum") > 0:
+            d["l2_hit_frac"] = g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum"))
+        e["derived"] = d
+        out["kernels"][k] = e
+    os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+    json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_sq.json"), "w"), indent=1)
+    print(json.dumps({k: v["derived"] for k, v in out["kernels"].items()}, indent=1))
+
+
+if __name__ == "__main__":
+    main()
