@@ -33,6 +33,11 @@ typedef unsigned long long u64;
 struct __attribute__((packed, aligned(4))) U4 { uint32_t a, b, c, d; };
 struct __attribute__((packed, aligned(4))) U2 { uint32_t a, b; };
 
+// wave64 ballot straight from the condition bit (HIP's __ballot(int) goes through a 0/1 VGPR and a compare)
+__device__ __forceinline__ unsigned long long bsx_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+// x * 30 + c on the low 24 bits of x in one full-rate instruction (a plain 32-bit multiply is quarter rate); only the
+// low 5 bits of the result are used (shift amounts), and 30 = -2 mod 32
+#define mad30(x, c) ({ uint32_t d_; asm("v_mad_u32_u24 %0, %1, 30, " #c : "=v"(d_) : "v"(x)); d_; })  /* x * 30 + c (low 24 bits of x) */
 __device__ __forceinline__ uint32_t rfl(uint32_t x) { return __builtin_amdgcn_readfirstlane(x); }
 __device__ __forceinline__ uint32_t rl(uint32_t x, int l) { return __builtin_amdgcn_readlane(x, l); }
 __device__ __forceinline__ u64 rl64(u64 x, int l) { return ((u64)rl((uint32_t)(x >> 32), l) << 32) | rl((uint32_t)x, l); }
@@ -157,7 +162,7 @@ __device__ void load_and_filter(const AlignArgs &A, MateLds &L, Mate &M, int mat
                         }
                     }
                 }
-                const u64 mask = __ballot(hit);
+                const u64 mask = bsx_ballot(hit);
                 if (mask) { len = base + (int)__builtin_ctzll(mask); done = true; }
             }
         }
@@ -170,7 +175,7 @@ __device__ void load_and_filter(const AlignArgs &A, MateLds &L, Mate &M, int mat
         for (int base = 0; base < qlen; base += 64) {
             const int i = base + lane;
             const bool good = i < qlen && (int)(int8_t)L.qual[i] > P.zero_qual + P.qual_threshold;
-            const u64 mask = __ballot(good);
+            const u64 mask = bsx_ballot(good);
             if (mask) best = base + 64 - (int)__builtin_clzll(mask);
         }
         if (best >= P.seed_size) len = min(len, best);
@@ -181,7 +186,7 @@ __device__ void load_and_filter(const AlignArgs &A, MateLds &L, Mate &M, int mat
         uint32_t ns = 0;  // CountNs (align.cpp:48-55)
         for (int base = 0; base < len; base += 64) {
             const int i = base + lane;
-            ns += (uint32_t)__builtin_popcountll(__ballot(i < len && nt_idx(L.seq[i]) < 0));
+            ns += (uint32_t)__builtin_popcountll(bsx_ballot(i < len && nt_idx(L.seq[i]) < 0));
         }
         if ((int)ns > P.max_ns) M.filtered = 1;
     }
@@ -334,12 +339,12 @@ __device__ __forceinline__ bool seen_before(const Mate &M, const Slab &SL, uint3
     const uint32_t slot = bloom_slot(key);
     const uint32_t word = (slot & 2048) ? rl(M.bloom1, (slot >> 5) & 63) : rl(M.bloom0, (slot >> 5) & 63);
     if (!((word >> (slot & 31)) & 1)) return false;
-    if (__ballot((uint32_t)lane < min(M.nkeys, 64u) && M.key_reg == key)) return true;
+    if (bsx_ballot((uint32_t)lane < min(M.nkeys, 64u) && M.key_reg == key)) return true;
     if (M.nkeys <= 64) return false;
     // linear probing, 64 slots per step: found if the key shows up before the first empty slot
     for (uint32_t h = hset_home(key);; h = (h + 64) & (BSX_HSET_SLOTS - 1)) {
         const uint32_t v = SL.hset[(h + lane) & (BSX_HSET_SLOTS - 1)];
-        const u64 hit = __ballot(v == key + 1), empty = __ballot(v == 0);
+        const u64 hit = bsx_ballot(v == key + 1), empty = bsx_ballot(v == 0);
         if (hit && (!empty || __builtin_ctzll(hit) < __builtin_ctzll(empty))) return true;
         if (empty) return false;
     }
@@ -351,7 +356,7 @@ __device__ __forceinline__ void remember_key(Mate &M, const Slab &SL, uint32_t k
     else {
         for (uint32_t h = hset_home(key);; h = (h + 64) & (BSX_HSET_SLOTS - 1)) {
             const uint32_t sidx = (h + lane) & (BSX_HSET_SLOTS - 1);
-            const u64 empty = __ballot(SL.hset[sidx] == 0);
+            const u64 empty = bsx_ballot(SL.hset[sidx] == 0);
             if (empty) {
                 if (lane == (int)__builtin_ctzll(empty)) { SL.hset[sidx] = key + 1; SL.keys[M.nkeys] = key; SL.kslot[M.nkeys] = sidx; }
                 break;
@@ -541,13 +546,13 @@ __device__ int accept_group(const DevParams &P, Mate &M, const Slab &SL, int ori
         const int src = (int)((slot >> 5) & 63) * 4;
         const uint32_t w0 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)M.bloom0), w1 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)M.bloom1);
         const bool maybe = cand && ((((slot & 2048) ? w1 : w0) >> (slot & 31)) & 1);
-        if (__ballot(maybe)) {
+        if (bsx_ballot(maybe)) {
             bool found = false;
             const uint32_t nk = min(M.nkeys, 64u);
             for (uint32_t j = 0; j < nk; j++) found |= rl(M.key_reg, (int)j) == hkey;
             bool probing = maybe && !found && M.nkeys > 64;
             uint32_t h = hset_home(hkey);
-            while (__ballot(probing)) {
+            while (bsx_ballot(probing)) {
                 if (probing) {
                     const uint32_t v = SL.hset[h];
                     if (v == hkey + 1) { found = true; probing = false; }
@@ -559,16 +564,16 @@ __device__ int accept_group(const DevParams &P, Mate &M, const Slab &SL, int ori
         }
     }
     // the same coordinate twice inside the group: the first occurrence wins
-    for (u64 t = __ballot(cand); t; t &= t - 1) {
+    for (u64 t = bsx_ballot(cand); t; t &= t - 1) {
         const int j = (int)__builtin_ctzll(t);
         if (lane > j && rl(hkey, j) == hkey) cand = false;
     }
-    if (!__ballot(cand)) return 0;
+    if (!bsx_ballot(cand)) return 0;
     // position inside the class list and the first event
     uint32_t rank = 0, mine = 0, other = 0;
     const uint32_t cmax = min(M.snp_thres, (uint32_t)BSX_MAXSNPS);
     for (uint32_t c = 0; c <= cmax; c++) {
-        const u64 mc = __ballot(cand && ws == c);
+        const u64 mc = bsx_ballot(cand && ws == c);
         if (!mc) continue;
         const uint32_t a = n_of(M, orient, (int)c), b = n_of(M, 1 - orient, (int)c);
         if (cand && ws == c) { rank = (uint32_t)__builtin_popcountll(mc & (lanemask_lt(lane) | (1ull << lane))); mine = a; other = b; }
@@ -576,13 +581,13 @@ __device__ int accept_group(const DevParams &P, Mate &M, const Slab &SL, int ori
     const uint32_t both = mine + other + rank;
     const bool ev2 = cand && (((int)ws == mode && !P.pairend && P.report_repeat_hits == 0 && both > 1) || (both >= (uint32_t)P.max_num_hits && ws == 0));
     const bool ev1 = cand && !ev2 && both >= (uint32_t)P.max_num_hits;
-    const u64 em2 = __ballot(ev2), em = em2 | __ballot(ev1);
+    const u64 em2 = bsx_ballot(ev2), em = em2 | bsx_ballot(ev1);
     const int E = em ? (int)__builtin_ctzll(em) : 64;
     const bool commit = cand && lane <= E;
-    const u64 km = __ballot(commit);
+    const u64 km = bsx_ballot(commit);
     if (commit) SL.list(orient, (int)ws)[mine + rank - 1] = ((u64)hchr << 32) | hloc;  // hits[w][n++] = hit
     for (uint32_t c = 0; c <= cmax; c++) {
-        const u64 mc = __ballot(commit && ws == c);
+        const u64 mc = bsx_ballot(commit && ws == c);
         if (mc && lane == orient * 16 + (int)c) M.cnt_reg += (uint32_t)__builtin_popcountll(mc);
     }
     // hitset.insert: registers for the first 64 coordinates, the slab's hash set beyond, filter bits for all
@@ -599,7 +604,7 @@ __device__ int accept_group(const DevParams &P, Mate &M, const Slab &SL, int ori
     {
         bool pending = commit && kidx >= 64;
         uint32_t h = hset_home(hkey);
-        while (__ballot(pending)) {  // claim by write-then-verify: lanes racing for one empty slot see who landed
+        while (bsx_ballot(pending)) {  // claim by write-then-verify: lanes racing for one empty slot see who landed
             if (pending && SL.hset[h] == 0) SL.hset[h] = hkey + 1;
             wave_fence();
             if (pending) {
@@ -736,7 +741,7 @@ __device__ int wave_scan_range(const DevParams &P, const BlockLds &BL, const Mat
                     if ((u64)loc + (u64)M.len > (u64)sz) pass = false;
                 } else pass = hit_coords(P, BL, p, strand, M.len, hchr, hloc, hkey);
             }
-            u64 surv_m = __ballot(pass);  // ordered replay of the survivors
+            u64 surv_m = bsx_ballot(pass);  // ordered replay of the survivors
             if (BSX_SCAN_NB > 1 && !P.rrbs && __builtin_popcountll(surv_m) > BSX_GROUP_MIN) {  // heavy pipeline: 64 at a time, resuming behind every threshold change
                 while (surv_m) {
                     int ls;
@@ -760,8 +765,8 @@ __device__ int wave_scan_range(const DevParams &P, const BlockLds &BL, const Mat
             const bool one = alive && ev.w0ref > thr_eff;
             const bool two = alive && !one && (ev.p48 > thr_eff || ev.w01ref > thr_eff);
             const bool five = alive && !one && !two;
-            C.n_cand += (u64)__builtin_popcountll(__ballot(alive));
-            C.sum_w += (u64)__builtin_popcountll(__ballot(one)) + 2ull * __builtin_popcountll(__ballot(two)) + 5ull * __builtin_popcountll(__ballot(five));
+            C.n_cand += (u64)__builtin_popcountll(bsx_ballot(alive));
+            C.sum_w += (u64)__builtin_popcountll(bsx_ballot(one)) + 2ull * __builtin_popcountll(bsx_ballot(two)) + 5ull * __builtin_popcountll(bsx_ballot(five));
         }
         if (stop) return 2;
       }
@@ -792,7 +797,7 @@ __device__ void run_align_single(const DevParams &P, const BlockLds &BL, const M
         snp_align(P, BL, L, M, SL, i, lane, C, heavy_threshold);
         if (M.defer) return;
         if (!P.rrbs) {
-            const u64 nz = __ballot(M.cnt_reg != 0 && (lane & 15) <= i && lane < 32);
+            const u64 nz = bsx_ballot(M.cnt_reg != 0 && (lane & 15) <= i && lane < 32);
             if (nz) return;
         }
     }
@@ -813,7 +818,7 @@ __device__ void fix_unpaired_short_fragment(const DevParams &P, Mate &M, const S
                 const u64 h = i < n ? lst[i] : 0;
                 bool keep = false;
                 if (i < n) { const int sl = ccgg_seglen(P, (uint32_t)(h >> 32), (uint32_t)h, M.len); keep = !(sl < P.min_insert || sl > P.max_insert); }
-                const u64 m = __ballot(keep);
+                const u64 m = bsx_ballot(keep);
                 if (keep) lst[kept + (uint32_t)__builtin_popcountll(m & lanemask_lt(lane))] = h;
                 kept += (uint32_t)__builtin_popcountll(m);
             }
@@ -900,7 +905,7 @@ __device__ __forceinline__ uint32_t first_chr_ge(const u64 *lst, uint32_t from, 
     for (uint32_t base = from; base < n; base += 64) {
         const uint32_t i = base + lane;
         const uint32_t c = i < n ? (uint32_t)(lst[i] >> 32) : 0xffffffffu;
-        const u64 m = __ballot(i < n && (strict ? c > chr : c >= chr));
+        const u64 m = bsx_ballot(i < n && (strict ? c > chr : c >= chr));
         if (m) return base + (uint32_t)__builtin_ctzll(m);
     }
     return n;
@@ -947,7 +952,7 @@ __device__ int get_pairs(const DevParams &P, const Mate &MA, const Mate &MB, con
                 else { seg_start = aloc; seg_end = bloc + (uint32_t)MB.len; }                          // pairs.cpp:73,100
                 const int insert = (int)(seg_end - seg_start);
                 const bool ok = valid && insert >= P.min_insert && insert <= P.max_insert;
-                u64 m = __ballot(ok);
+                u64 m = bsx_ballot(ok);
                 while (m) {  // appends happen one at a time in the reference, each followed by the cap test
                     const int ls = (int)__builtin_ctzll(m);
                     m &= m - 1;
@@ -1216,12 +1221,14 @@ struct HState {
     HMate mate[2];
     ListReq req;
 };
-struct HTask { uint32_t h, c0, n, pad; };
+struct HTask { uint32_t h, c0, n, key; };  // key: index entry the task starts at (tasks are scanned in key order, see bsx_api.hip)
 struct HTaskOut { uint32_t count, overflow, acc[4], pad[2]; SurvRec surv[HS_SCAP]; };
 struct HeavyArgs {
     HState *state; uint8_t *slabs; uint32_t *active_in, *active_out, *n_active_out; HTask *tasks; HTaskOut *tout; uint32_t *n_tasks, *queue;
     const uint32_t *n_active_in_ptr;
     uint32_t n_active_in, task_cap, fresh, list_base, hidx_base;
+    const uint32_t *order;  // scan order of the tasks (task ids sorted by key), null = pool order
+    uint32_t xcd_map;       // 1: blocks of one XCD take a contiguous part of the order
 };
 __host__ HeavyArgs typed(const HeavyArgsRaw &r)
 {
@@ -1229,6 +1236,7 @@ __host__ HeavyArgs typed(const HeavyArgsRaw &r)
     h.state = (HState *)r.state; h.slabs = r.slabs; h.active_in = r.active_in; h.active_out = r.active_out; h.n_active_out = r.n_active_out;
     h.tasks = (HTask *)r.tasks; h.tout = (HTaskOut *)r.tout; h.n_tasks = r.n_tasks; h.queue = r.queue;
     h.n_active_in_ptr = r.n_active_in_ptr; h.n_active_in = r.n_active_in; h.task_cap = r.task_cap; h.fresh = r.fresh; h.list_base = r.list_base; h.hidx_base = r.hidx_base;
+    h.order = r.order; h.xcd_map = r.xcd_map;
     return h;
 }
 
@@ -1272,7 +1280,7 @@ __device__ __forceinline__ u64 surv_coords(const DevParams &P, const BlockLds &B
         ok = hit_coords(P, BL, r.hloc, r.hchr, len, hchr, hloc, hkey);
         r.hchr = hchr; r.hloc = hloc; r.hkey = hkey;
     }
-    return __ballot(ok);
+    return bsx_ballot(ok);
 }
 
 // resumable SnpAlign for a deferred unit: 0 = call complete, 1 = the reference's SnpAlign returned early, 2 = a window
@@ -1308,7 +1316,7 @@ __device__ int snp_align_heavy(const AlignArgs &A, const HeavyArgs &H, HState *S
                         const HTaskOut *oh = &H.tout[t0 + tl];
                         hc = oh->count; hov = oh->overflow; h0 = oh->acc[0]; hw = oh->acc[1] + 2 * oh->acc[2] + 5 * oh->acc[3];
                     }
-                    u64 special = __ballot(tl < nt && (hc != 0 || hov != 0));
+                    u64 special = bsx_ballot(tl < nt && (hc != 0 || hov != 0));
                     uint32_t done_upto = 0;  // tasks [tg, tg+done_upto) of this group are fully accounted
                     const uint32_t gn = min(64u, nt - tg);
                     while (!restart) {
@@ -1316,11 +1324,11 @@ __device__ int snp_align_heavy(const AlignArgs &A, const HeavyArgs &H, HState *S
                             // consecutive tasks from done_upto whose survivor records fit one 64-lane group (none overflowed)
                             // are replayed together: one round of record loads and hitset probes instead of one per task
                             const bool inr = (uint32_t)lane >= done_upto && (uint32_t)lane < gn;
-                            const u64 ovm = __ballot(inr && hov != 0);
+                            const u64 ovm = bsx_ballot(inr && hov != 0);
                             const uint32_t first_ov = ovm ? (uint32_t)__builtin_ctzll(ovm) : gn;
                             uint32_t ps = inr ? hc : 0;  // inclusive prefix sum of the survivor counts
                             for (int o_ = 1; o_ < 64; o_ <<= 1) { const uint32_t v_ = __shfl_up(ps, o_); if (lane >= o_) ps += v_; }
-                            const u64 fit = __ballot(inr && (uint32_t)lane < first_ov && ps <= 64);
+                            const u64 fit = bsx_ballot(inr && (uint32_t)lane < first_ov && ps <= 64);
                             const uint32_t bend = done_upto + (uint32_t)__builtin_popcountll(fit);
                             if (bend > done_upto) {
                                 const uint32_t total = rl(ps, (int)bend - 1);
@@ -1330,7 +1338,7 @@ __device__ int snp_align_heavy(const AlignArgs &A, const HeavyArgs &H, HState *S
                                 if (total) {
                                     CAT_BEGIN(A);
                                     uint32_t my_i = 0;
-                                    for (u64 sm = __ballot(inr && (uint32_t)lane < bend && hc != 0); sm; sm &= sm - 1) {
+                                    for (u64 sm = bsx_ballot(inr && (uint32_t)lane < bend && hc != 0); sm; sm &= sm - 1) {
                                         const int t_ = (int)__builtin_ctzll(sm);
                                         const uint32_t end_ = rl(ps, t_), beg_ = end_ - rl(hc, t_);
                                         if ((uint32_t)lane >= beg_ && (uint32_t)lane < end_) { my_t = (uint32_t)t_; my_i = (uint32_t)lane - beg_; }
@@ -1394,7 +1402,7 @@ __device__ int snp_align_heavy(const AlignArgs &A, const HeavyArgs &H, HState *S
                             const uint32_t i = base + lane;
                             SurvRec r = {0, 0, 0, 0};
                             if (i < nv) r = o->surv[i];
-                            u64 m = __ballot(i < nv);
+                            u64 m = bsx_ballot(i < nv);
                             m &= surv_coords(P, BL, r, M.len, lane, m);
                             if (__builtin_popcountll(m) > BSX_GROUP_MIN) {
                                 int ls;
@@ -1432,9 +1440,14 @@ __device__ int snp_align_heavy(const AlignArgs &A, const HeavyArgs &H, HState *S
                 if (lane == 0) t0 = atomicAdd(H.n_tasks, nt);
                 t0 = rfl(t0);
                 if (t0 + nt <= H.task_cap) {
-                    for (uint32_t t = lane; t < nt; t += 64) {
-                        HTask tk; tk.h = hidx; tk.c0 = K.c + t * HS_TASK; tk.n = min((uint32_t)HS_TASK, wn - t * HS_TASK); tk.pad = 0;
-                        H.tasks[t0 + t] = tk;
+                    for (uint32_t tb = 0; tb < nt; tb += 64) {
+                        const uint32_t t = tb + lane;
+                        HTask tk; tk.h = hidx; tk.c0 = K.c + t * HS_TASK; tk.n = min((uint32_t)HS_TASK, wn - t * HS_TASK); tk.key = 0;
+                        for (int s_ = 0; s_ < cl.nsub; s_++) {  // the index entry the task starts at
+                            const uint32_t ps_ = rl(cl.sub_pre, s_), ns_ = rl(cl.sub_n, s_), sb_ = rl(cl.sub_base, s_);
+                            if (tk.c0 >= ps_ && tk.c0 < ps_ + ns_) tk.key = sb_ + (tk.c0 - ps_);
+                        }
+                        if (t < nt) H.tasks[t0 + t] = tk;
                     }
                     ListReq &R = S->req;
                     if (lane < 32) { R.sub_pre[lane] = cl.sub_pre; R.sub_n[lane] = cl.sub_n; R.sub_base[lane] = cl.sub_base; R.sub_h[lane] = cl.sub_h; }
@@ -1447,7 +1460,7 @@ __device__ int snp_align_heavy(const AlignArgs &A, const HeavyArgs &H, HState *S
                 } else {
                     K.want = nt;  // the request is repeated in a later iteration, once the pool can take it
                     if (t0 < H.task_cap)  // pool exhausted mid-way: neutralise the slots that were reserved
-                        for (uint32_t t = t0 + lane; t < H.task_cap; t += 64) { HTask tk; tk.h = hidx; tk.c0 = 0; tk.n = 0; tk.pad = 0; H.tasks[t] = tk; }
+                        for (uint32_t t = t0 + lane; t < H.task_cap; t += 64) { HTask tk; tk.h = hidx; tk.c0 = 0; tk.n = 0; tk.key = 0xffffffffu; H.tasks[t] = tk; }
                 }
                 wave_fence();
                 return 2;
@@ -1490,7 +1503,7 @@ __device__ bool heavy_advance(const AlignArgs &A, const HeavyArgs &H, HState *S,
         Mate &M = second ? MB : MA;
         if (M.filtered || K.level >= M.seedseg) { K.sub++; K.level = 0; K.orient = 0; K.c = 0; K.W = HS_WIN0; K.have = 0; continue; }
         if (snp_align_heavy(A, H, S, hidx, BL, second ? LB : LA, M, second ? U.SB : U.SA, K.level, K, lane, C) == 2) return false;
-        const u64 nz = __ballot(M.cnt_reg != 0 && (lane & 15) <= K.level && lane < 32);
+        const u64 nz = bsx_ballot(M.cnt_reg != 0 && (lane & 15) <= K.level && lane < 32);
         if (nz) { K.sub++; K.level = 0; }
         else K.level++;
         K.orient = 0; K.c = 0; K.W = HS_WIN0; K.have = 0;
@@ -1581,114 +1594,165 @@ __global__ __launch_bounds__(256) void k_hctrl(AlignArgs A, HeavyArgs H)
 
 // every wave of the chip evaluates tasks: HS_TASK consecutive candidates of one published list window
 #ifndef BSX_HSCAN_WAVES
-#define BSX_HSCAN_WAVES 6  /* 80 VGPRs: the batched tail loads need more than the 64 of 8 waves; measured equal from 4 to 7 (the kernel is VALU-bound) */
+#define BSX_HSCAN_WAVES 6  /* waves per SIMD the register budget is set for */
 #endif
 #ifndef BSX_HSCAN_WPB
 #define BSX_HSCAN_WPB 4  /* waves (= tasks) per block */
 #endif
+
+// One step of k_hscan: 256 consecutive candidates of one sub-range (four chunks of 64; lane l of chunk u holds candidate
+// cb + 64u + l).  Everything a candidate needs is derived from pm1 = p - 1 (p = entry + h, its global nt position):
+//   reference word index        pm1 >> 4              (one word early when p is word-aligned, see eval_loaded)
+//   funnel-shift amount         (30 pm1 + 30) mod 32  = (32 - 2 (p & 15)) & 31   (v_alignbit uses the low 5 bits)
+//   mask of the first 16-k nt   0x80000000 >>arith ((30 pm1 + 29) mod 32)        (k = p & 15)
+// The work accounting of the reference's two early-outs (align.h:189-197; 1, 2 or 5 64-bit words per candidate) needs no
+// ballots: with w0ref <= p48 <= w01ref, a task of n candidates touches  2 n - #(w0ref > thres) + 3 #(w01ref <= thres)
+// words; both counts are accumulated per lane and reduced once per task.
+// FULL: all 256 candidates exist (every step of a sub-range but its last).
+struct ScanAcc { uint32_t c1, f5; };  // per lane: candidates with w0ref > thres / candidates evaluated in full with w01ref <= thres
+template <bool FULL>
+__device__ __forceinline__ void hscan_step(const uint32_t *__restrict__ q, const uint32_t *__restrict__ refbase, uint32_t hm1, uint32_t n_here, uint32_t ord0,
+                                           uint32_t strand, const uint32_t (&rw)[9], const uint32_t (&rm)[9], uint32_t thres0, int nwords, int lane,
+                                           HTaskOut *o, uint32_t &nsurv, bool &overflow, ScanAcc &acc)
+{
+    uint32_t e[4], pm1[4];
+    bool valid[4];
+    U4 r0[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) e[u] = q[u * 64];  // one address + immediate offsets (may run up to 255 entries past the sub-range: loaded, never used)
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        valid[u] = FULL || (uint32_t)(u * 64 + lane) < n_here;
+        pm1[u] = (FULL || valid[u]) ? e[u] + hm1 : 15u;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) r0[u] = *reinterpret_cast<const U4 *>(refbase + (pm1[u] >> 4));
+    // the first 48 nt of all four chunks, then — in one round trip — the remaining words of every candidate that is still
+    // within the threshold, then the verdicts in list order
+    uint32_t p48[4], sh[4];
+    bool need[4];
+    U4 r1[4];
+    U2 r2[4];
+    bool any = false;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        sh[u] = mad30(pm1[u], 30);
+        const uint32_t him = (uint32_t)((int32_t)0x80000000 >> (mad30(pm1[u], 29) & 31u));
+        const uint32_t f0 = __builtin_amdgcn_alignbit(r0[u].a, r0[u].b, sh[u]), f1 = __builtin_amdgcn_alignbit(r0[u].b, r0[u].c, sh[u]),
+                       f2 = __builtin_amdgcn_alignbit(r0[u].c, r0[u].d, sh[u]);
+        const uint32_t m1 = bsx_mismatch_hi(rw[1], bsx_tmask(rw[1], rm[1]), f1);
+        const uint32_t c0 = __popc(bsx_mismatch_hi(rw[0], bsx_tmask(rw[0], rm[0]), f0));
+        const uint32_t w0ref = __popc(m1 & him) + c0;
+        p48[u] = __popc(bsx_mismatch_hi(rw[2], bsx_tmask(rw[2], rm[2]), f2)) + (__popc(m1) + c0);
+        need[u] = (FULL || valid[u]) && p48[u] <= thres0;
+        acc.c1 += ((FULL || valid[u]) && w0ref > thres0) ? 1u : 0u;
+        any |= need[u];
+        r1[u].a = r1[u].b = r1[u].c = r1[u].d = 0; r2[u].a = r2[u].b = 0;
+    }
+    if (!bsx_ballot(any)) return;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const uint32_t *rp = refbase + (pm1[u] >> 4);
+        if (need[u] && nwords > 3) r1[u] = *reinterpret_cast<const U4 *>(rp + 4);
+        if (need[u] && nwords > 7) r2[u] = *reinterpret_cast<const U2 *>(rp + 8);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        if (!bsx_ballot(need[u])) continue;
+        uint32_t w = 0xffffu, w01ref = 0xffffu;
+        if (need[u]) {
+            const uint32_t him = (uint32_t)((int32_t)0x80000000 >> (mad30(pm1[u], 29) & 31u));
+            const uint32_t wd[7] = {r0[u].d, r1[u].a, r1[u].b, r1[u].c, r1[u].d, r2[u].a, r2[u].b};
+            uint32_t tot = p48[u];
+            w01ref = p48[u];
+#pragma unroll
+            for (int t = 3; t < 9; t++) {
+                const uint32_t f = __builtin_amdgcn_alignbit(wd[t - 3], wd[t - 2], sh[u]);
+                const uint32_t mm = bsx_mismatch_hi(rw[t], bsx_tmask(rw[t], rm[t]), f);
+                tot += __popc(mm);
+                if (t == 3) w01ref += __popc(mm & him);
+            }
+            w = tot;
+            acc.f5 += w01ref <= thres0 ? 1u : 0u;
+        }
+        // (chromosome / end-of-sequence test and hit coordinates are left to the control kernel's replay: the record
+        //  carries the strand copy and the global position)
+        const bool pass = need[u] && w <= thres0;
+        const u64 m = bsx_ballot(pass);
+        if (m) {
+            const uint32_t pos = nsurv + (uint32_t)__builtin_popcountll(m & lanemask_lt(lane));
+            if (pass && pos < HS_SCAP) { SurvRec r; r.w_ord = w | ((ord0 + (uint32_t)(u * 64 + lane)) << 8); r.hchr = strand; r.hloc = pm1[u] + 1; r.hkey = 0; o->surv[pos] = r; }
+            nsurv += (uint32_t)__builtin_popcountll(m);
+            if (nsurv > HS_SCAP) overflow = true;
+        }
+    }
+}
+
 __global__ __launch_bounds__(64 * BSX_HSCAN_WPB, BSX_HSCAN_WAVES) void k_hscan(AlignArgs A, HeavyArgs H)
 {
-    __shared__ BlockLds BL;
     __shared__ uint32_t TAB[BSX_HSCAN_WPB][4][32];
+#ifdef BSX_HSCAN_PAD  /* occupancy experiments: extra LDS per block limits the resident waves */
+    __shared__ uint32_t PAD[BSX_HSCAN_PAD / 4];
+    if (threadIdx.x == 0 && A.n_units == 0xffffffffu) PAD[0] = 1;
+#endif
     const DevParams &P = A.P;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    init_block_lds(P, BL, threadIdx.x, 64 * BSX_HSCAN_WPB);
-    __syncthreads();
     // one task per wave, no queue: the blocks of a pass retire one by one, so the control kernel of the other unit
     // group (high-priority stream) finds free slots while this kernel is still running
     const uint32_t n_tasks = min(*H.n_tasks, H.task_cap);
-    u64 scanned = 0, scanned_w = 0;
-    for (bool once = true; once; once = false) {
-        const uint32_t t = blockIdx.x * BSX_HSCAN_WPB + (uint32_t)wv;
-        if (t >= n_tasks) break;
-        const uint32_t hidx = rfl(H.tasks[t].h), tc0 = rfl(H.tasks[t].c0), tn = rfl(H.tasks[t].n);
-        if (tn == 0) {  // slot neutralised by a refused request: its unit has not published a list (ListReq may be stale)
-            if (lane == 0) { HTaskOut *oe = &H.tout[t]; oe->count = 0; oe->overflow = 0; oe->acc[0] = oe->acc[1] = oe->acc[2] = oe->acc[3] = 0; }
-            continue;
-        }
-        const ListReq &R = H.state[hidx].req;
-        if (lane < 32) { TAB[wv][0][lane] = R.sub_pre[lane]; TAB[wv][1][lane] = R.sub_n[lane]; TAB[wv][2][lane] = R.sub_base[lane]; TAB[wv][3][lane] = R.sub_h[lane]; }
-        uint32_t rw[9], rm[9];
-#pragma unroll
-        for (int k = 0; k < 9; k++) { rw[k] = rfl(R.rw[k]); rm[k] = rfl(R.rm[k]); }
-        const uint32_t thres0 = rfl(R.thres), nsub = min(rfl(R.nsub), 32u);
-        const int nwords = (int)rfl(R.nwords);
-        wave_fence();
-        HTaskOut *o = &H.tout[t];
-        uint32_t nsurv = 0, a0 = 0, a1 = 0, a2 = 0, a5 = 0;
-        bool overflow = false;
-        const uint32_t c_end = tc0 + tn;
-        // the task's candidates sub-range by sub-range (list order): inside one sub-range entry address, h and strand are
-        // wave-uniform; four chunks are in flight per step — entries first, then all four 16-byte reference loads
-        for (uint32_t sidx = 0; sidx < nsub && !overflow; sidx++) {
-            const uint32_t ps = rfl(TAB[wv][0][sidx]), ns = rfl(TAB[wv][1][sidx]);
-            const uint32_t lo = max(tc0, ps), hi = min(c_end, ps + ns);
-            if (lo >= hi) continue;
-            const uint32_t *ent = P.entries + rfl(TAB[wv][2][sidx]);
-            const uint32_t hh = rfl(TAB[wv][3][sidx]), strand = sidx & 1;
-            const uint32_t *refbase = strand ? P.crefcat : P.refcat;
-            for (uint32_t cb = lo; cb < hi && !overflow; cb += 256) {
-                // four chunks of 64 consecutive candidates: entries come from one address + immediate offsets (the loads may
-                // run up to 255 entries past hi — other buckets' entries or the array's BSX_ENTRY_PAD, loaded but never used);
-                // neighbouring lanes hold neighbouring entries, so in a repeat bucket one reference gather touches few lines
-                const uint32_t *q = ent + (cb - ps) + lane;
-                uint32_t idx[4], p[4], e[4];
-                bool valid[4];
-                U4 r0[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) e[u] = q[u * 64];
-#pragma unroll
-                for (int u = 0; u < 4; u++) { idx[u] = cb + u * 64 + lane; valid[u] = idx[u] < hi; p[u] = valid[u] ? e[u] + hh : 16u; }
-#pragma unroll
-                for (int u = 0; u < 4; u++) r0[u] = *reinterpret_cast<const U4 *>(refbase + ((p[u] - 1) >> 4));
-                // the first 48 nt of all four chunks, then — in one round trip — the remaining words of every candidate
-                // that is still within the threshold, then the verdicts in list order
-                uint32_t p48[4], w0ref[4], d3[4];
-                bool need[4];
-                U4 r1[4];
-                U2 r2[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const HeadEval h = eval_head(r0[u], rw, rm, p[u]);
-                    p48[u] = h.p48; w0ref[u] = h.w0ref; d3[u] = r0[u].d;
-                    need[u] = valid[u] && h.p48 <= thres0;
-                    r1[u].a = r1[u].b = r1[u].c = r1[u].d = 0; r2[u].a = r2[u].b = 0;
-                }
-                if (__ballot(need[0] | need[1] | need[2] | need[3])) {
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        const uint32_t *rp = refbase + ((p[u] - 1) >> 4);
-                        if (need[u] && nwords > 3) r1[u] = *reinterpret_cast<const U4 *>(rp + 4);
-                        if (need[u] && nwords > 7) r2[u] = *reinterpret_cast<const U2 *>(rp + 8);
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    uint32_t w = p48[u], w01ref = 0;
-                    if (need[u]) eval_tail(d3[u], r1[u], r2[u], rw, rm, p[u], p48[u], w, w01ref);
-                    // (chromosome / end-of-sequence test and hit coordinates are left to the control kernel's replay: the
-                    //  record carries the strand copy and the global position)
-                    const bool pass = valid[u] && w <= thres0;
-                    const u64 m = __ballot(pass);
-                    if (m) {
-                        const uint32_t pos = nsurv + (uint32_t)__builtin_popcountll(m & lanemask_lt(lane));
-                        if (pass && pos < HS_SCAP) { SurvRec r; r.w_ord = w | ((idx[u] - tc0) << 8); r.hchr = strand; r.hloc = p[u]; r.hkey = 0; o->surv[pos] = r; }
-                        nsurv += (uint32_t)__builtin_popcountll(m);
-                        if (nsurv > HS_SCAP) overflow = true;
-                    }
-                    const bool one = valid[u] && w0ref[u] > thres0;
-                    const bool two = valid[u] && !one && (p48[u] > thres0 || w01ref > thres0);
-                    const bool five = valid[u] && !one && !two;
-                    a0 += (uint32_t)__builtin_popcountll(__ballot(valid[u])); a1 += (uint32_t)__builtin_popcountll(__ballot(one));
-                    a2 += (uint32_t)__builtin_popcountll(__ballot(two)); a5 += (uint32_t)__builtin_popcountll(__ballot(five));
-                }
-            }
-        }
-        if (lane == 0) { o->count = overflow ? 0 : nsurv; o->overflow = overflow ? 1 : 0; o->acc[0] = a0; o->acc[1] = a1; o->acc[2] = a2; o->acc[3] = a5; }
-        scanned += a0; scanned_w += a1 + 2 * a2 + 5 * a5;
-        wave_fence();
+    // Tasks are taken in key order (= by the index entries they walk), and the blocks of one XCD take a contiguous part of
+    // that order (blocks are dealt to the 8 XCDs in turn): the reads that walk the same giant bucket then do so at the same
+    // time behind the same L2, which fetches each line of entries / reference once for all of them
+    uint32_t slot = blockIdx.x * BSX_HSCAN_WPB + (uint32_t)wv;
+    if (H.xcd_map) slot = ((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3)) * BSX_HSCAN_WPB + (uint32_t)wv;
+    if (slot >= n_tasks) return;
+    const uint32_t t = H.order ? rfl(H.order[slot]) : slot;
+    const uint32_t hidx = rfl(H.tasks[t].h), tc0 = rfl(H.tasks[t].c0), tn = rfl(H.tasks[t].n);
+    HTaskOut *o = &H.tout[t];
+    if (tn == 0) {  // slot neutralised by a refused request: its unit has not published a list (ListReq may be stale)
+        if (lane == 0) { o->count = 0; o->overflow = 0; o->acc[0] = o->acc[1] = o->acc[2] = o->acc[3] = 0; }
+        return;
     }
-    if (lane == 0 && scanned) { atomicAdd((u64 *)&A.counters[7], scanned); atomicAdd((u64 *)&A.counters[8], scanned_w); }  // work of the scan kernel (incl. speculation)
+    const ListReq &R = H.state[hidx].req;
+    if (lane < 32) { TAB[wv][0][lane] = R.sub_pre[lane]; TAB[wv][1][lane] = R.sub_n[lane]; TAB[wv][2][lane] = R.sub_base[lane]; TAB[wv][3][lane] = R.sub_h[lane]; }
+    uint32_t rw[9], rm[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) { rw[k] = rfl(R.rw[k]); rm[k] = rfl(R.rm[k]); }
+    const uint32_t thres0 = rfl(R.thres), nsub = min(rfl(R.nsub), 32u);
+    const int nwords = (int)rfl(R.nwords);
+    wave_fence();
+    uint32_t nsurv = 0;
+    bool overflow = false;
+    ScanAcc acc = {0, 0};
+    const uint32_t c_end = tc0 + tn;
+    // the task's candidates sub-range by sub-range (list order): inside one sub-range entry address, h and strand are
+    // wave-uniform; four chunks are in flight per step — entries first, then all four 16-byte reference loads.
+    // Neighbouring lanes hold neighbouring entries, so in a repeat bucket one reference gather touches few lines.
+    for (uint32_t sidx = 0; sidx < nsub && !overflow; sidx++) {
+        const uint32_t ps = rfl(TAB[wv][0][sidx]), ns = rfl(TAB[wv][1][sidx]);
+        const uint32_t lo = max(tc0, ps), hi = min(c_end, ps + ns);
+        if (lo >= hi) continue;
+        const uint32_t *ent = P.entries + rfl(TAB[wv][2][sidx]);
+        const uint32_t hm1 = rfl(TAB[wv][3][sidx]) - 1u, strand = sidx & 1;
+        const uint32_t *refbase = strand ? P.crefcat : P.refcat;
+        uint32_t cb = lo;
+        for (; cb + 256 <= hi && !overflow; cb += 256)
+            hscan_step<true>(ent + (cb - ps) + lane, refbase, hm1, 256, cb - tc0, strand, rw, rm, thres0, nwords, lane, o, nsurv, overflow, acc);
+        if (cb < hi && !overflow)
+            hscan_step<false>(ent + (cb - ps) + lane, refbase, hm1, hi - cb, cb - tc0, strand, rw, rm, thres0, nwords, lane, o, nsurv, overflow, acc);
+    }
+    const uint32_t n1 = wave_sum(acc.c1), n5 = wave_sum(acc.f5);
+    const uint32_t words = 2u * tn - n1 + 3u * n5;  // 1, 2 or 5 words per candidate (see hscan_step)
+    if (lane == 0) {
+        o->count = overflow ? 0 : nsurv; o->overflow = overflow ? 1 : 0; o->acc[0] = tn; o->acc[1] = words; o->acc[2] = 0; o->acc[3] = 0;
+        if (!overflow) {  // work of the scan kernel (incl. speculation); an overflowed task is redone by the control kernel.
+            // Millions of tasks per batch: one counter word takes ~88 atomics per microsecond, so these statistics are
+            // sharded over 64 cache lines (summed by bsx_batch_counters) instead of being added to four hot words
+            u64 *sh = (u64 *)A.scan_stats + (size_t)(blockIdx.x & 63u) * 8;
+            atomicAdd((u64 *)&sh[0], (u64)tn); atomicAdd((u64 *)&sh[1], (u64)words);
+            atomicAdd((u64 *)&sh[2], (u64)n1); atomicAdd((u64 *)&sh[3], (u64)n5);
+        }
+    }
 }
 
 }  // namespace
@@ -1709,7 +1773,21 @@ void bsx_launch_hctrl(const AlignArgs &A, const HeavyArgsRaw &R, int paired, int
 void bsx_launch_hscan(const AlignArgs &A, const HeavyArgsRaw &R, uint32_t n_tasks, hipStream_t stream)
 {
     const HeavyArgs H = typed(R);
-    hipLaunchKernelGGL(k_hscan, dim3((n_tasks + BSX_HSCAN_WPB - 1) / BSX_HSCAN_WPB), dim3(64 * BSX_HSCAN_WPB), 0, stream, A, H);
+    uint32_t blocks = (n_tasks + BSX_HSCAN_WPB - 1) / BSX_HSCAN_WPB;
+    if (H.xcd_map) blocks = (blocks + 7u) & ~7u;  // the same number of blocks for each of the 8 XCDs
+    hipLaunchKernelGGL(k_hscan, dim3(blocks), dim3(64 * BSX_HSCAN_WPB), 0, stream, A, H);
+}
+
+namespace {
+__global__ void k_task_keys(const HTask *tasks, const uint32_t *n_tasks_ptr, uint32_t cap, uint32_t *keys, uint32_t *ids)
+{
+    const uint32_t n = min(*n_tasks_ptr, cap), i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { keys[i] = tasks[i].key; ids[i] = i; }
+}
+}  // namespace
+void bsx_launch_task_keys(const HeavyArgsRaw &R, uint32_t n_tasks, uint32_t *keys, uint32_t *ids, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_task_keys, dim3((n_tasks + 255) / 256), dim3(256), 0, stream, (const HTask *)R.tasks, R.n_tasks, R.task_cap, keys, ids);
 }
 
 size_t bsx_hstate_bytes(void) { return sizeof(HState); }

@@ -218,6 +218,8 @@ struct bsx_batch {
     uint32_t *d_heavy_list = nullptr, *d_heavy_count = nullptr;
     // heavy pipeline pools
     uint8_t *d_hstate = nullptr, *d_hslabs = nullptr, *d_htasks = nullptr, *d_htout = nullptr;
+    uint32_t *d_tsort[4] = {nullptr, nullptr, nullptr, nullptr};  // keys in / out, ids in / out of the task sort
+    void *d_sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
     uint32_t *d_hactive[4] = {nullptr, nullptr, nullptr, nullptr}, *d_hcnt = nullptr;  // d_hcnt: per group two ping-pong blocks {n_active, n_tasks, queue[2]}
     uint32_t hcap = 0, task_cap = 0;
     uint32_t *h_pinned = nullptr;  // pinned host words for the per-pass count read-backs
@@ -225,7 +227,7 @@ struct bsx_batch {
     uint32_t last_heavy = 0, last_heavy_iters = 0;
     size_t scratch_bytes = 0;
     uint32_t *d_queue = nullptr;
-    uint64_t *d_counters = nullptr;
+    uint64_t *d_counters = nullptr, *d_scan_stats = nullptr;
     uint64_t slab_bytes = 0;
     uint32_t rowcap = 0;
     int grid_blocks = 0;
@@ -275,6 +277,7 @@ static int ensure_scratch(bsx_batch *b)
             HIP_TRY(hipMemsetAsync(b->d_htasks, 0xA5, (size_t)b->task_cap * bsx_htask_bytes(), b->stream));
         }
         for (int k = 0; k < 4; k++) HIP_TRY(hipMalloc((void **)&b->d_hactive[k], (size_t)b->hcap * 4));
+        for (int k = 0; k < 4; k++) HIP_TRY(hipMalloc((void **)&b->d_tsort[k], (size_t)b->task_cap * 4));
         HIP_TRY(hipMalloc((void **)&b->d_hcnt, 256));
     }
     const uint64_t slots = b->debug ? b->max_units : (uint64_t)grid * 4;
@@ -323,6 +326,8 @@ extern "C" int bsx_batch_create(bsx_ref *r, uint32_t max_units, int paired, bsx_
     } else if (hipMalloc((void **)&b->d_hits, (size_t)max_units * sizeof(bsx_hit)) != hipSuccess) return fail(BSX_ERR_NOMEM);
     if (hipMalloc((void **)&b->d_queue, 256) != hipSuccess || hipMalloc((void **)&b->d_counters, BSX_N_COUNTERS * 8 + 256) != hipSuccess) return fail(BSX_ERR_NOMEM);
     if (hipMemsetAsync(b->d_counters, 0, BSX_N_COUNTERS * 8 + 256, b->stream) != hipSuccess) return fail(BSX_ERR_DEVICE);
+    if (hipMalloc((void **)&b->d_scan_stats, 64 * 64) != hipSuccess) return fail(BSX_ERR_NOMEM);
+    if (hipMemsetAsync(b->d_scan_stats, 0, 64 * 64, b->stream) != hipSuccess) return fail(BSX_ERR_DEVICE);
     if ((rc = ensure_scratch(b)) != BSX_OK) return fail(rc);
     *out = b;
     return BSX_OK;
@@ -336,8 +341,8 @@ extern "C" void bsx_batch_destroy(bsx_batch *b)
     for (int m = 0; m < 2; m++)
         for (void *q : {(void *)b->d_seq[m], (void *)b->d_qual[m], (void *)b->d_off[m], (void *)b->d_cc[m]})
             if (q) (void)hipFree(q);
-    for (void *q : {(void *)b->d_hits, (void *)b->d_pairs, (void *)b->d_npairs, (void *)b->d_scratch, (void *)b->d_dbg, (void *)b->d_queue, (void *)b->d_counters, (void *)b->d_cycles, (void *)b->d_heavy_list, (void *)b->d_heavy_count,
-                    (void *)b->d_hstate, (void *)b->d_hslabs, (void *)b->d_htasks, (void *)b->d_htout, (void *)b->d_hactive[0], (void *)b->d_hactive[1], (void *)b->d_hactive[2], (void *)b->d_hactive[3], (void *)b->d_hcnt})
+    for (void *q : {(void *)b->d_hits, (void *)b->d_pairs, (void *)b->d_npairs, (void *)b->d_scratch, (void *)b->d_dbg, (void *)b->d_queue, (void *)b->d_counters, (void *)b->d_scan_stats, (void *)b->d_cycles, (void *)b->d_heavy_list, (void *)b->d_heavy_count,
+                    (void *)b->d_hstate, (void *)b->d_hslabs, (void *)b->d_htasks, (void *)b->d_htout, (void *)b->d_hactive[0], (void *)b->d_hactive[1], (void *)b->d_hactive[2], (void *)b->d_hactive[3], (void *)b->d_hcnt, (void *)b->d_tsort[0], (void *)b->d_tsort[1], (void *)b->d_tsort[2], (void *)b->d_tsort[3], b->d_sort_tmp})
         if (q) (void)hipFree(q);
     if (b->h_pinned) (void)hipHostFree(b->h_pinned);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
@@ -433,7 +438,7 @@ extern "C" int bsx_batch_run_range(bsx_batch *b, uint32_t first_unit, uint32_t n
     A.first_unit = first_unit;
     for (int m = 0; m < 2; m++) { A.seq[m] = b->d_seq[m]; A.off[m] = b->d_off[m]; A.qual[m] = b->has_qual ? b->d_qual[m] : nullptr; A.cc[m] = b->d_cc[m]; }
     A.hits_out = b->d_hits; A.pairs_out = b->d_pairs; A.npairs_out = b->d_npairs;
-    A.scratch = b->d_scratch; A.slab_bytes = b->slab_bytes; A.queue = b->d_queue; A.counters = b->d_counters; A.dbg_plan = b->d_dbg; A.dbg_cycles = b->d_cycles; A.dbg_cat = b->d_cycles ? b->d_counters + 16 : nullptr;
+    A.scratch = b->d_scratch; A.slab_bytes = b->slab_bytes; A.queue = b->d_queue; A.counters = b->d_counters; A.scan_stats = b->d_scan_stats; A.dbg_plan = b->d_dbg; A.dbg_cycles = b->d_cycles; A.dbg_cat = b->d_cycles ? b->d_counters + 16 : nullptr;
     A.heavy_list = b->d_heavy_list; A.heavy_count = b->d_heavy_count;
     A.heavy_threshold = b->ref->P.rrbs ? 0u : (uint32_t)g_heavy_threshold;
     HIP_TRY(hipMemsetAsync(b->d_queue, 0, 4, b->stream));
@@ -458,6 +463,8 @@ extern "C" int bsx_batch_run_range(bsx_batch *b, uint32_t first_unit, uint32_t n
         // stream) — control passes are latency-bound chains of a few thousand waves and disappear beside the scan.
         // One pass of a group = k_hctrl (advance every active unit, publish scan tasks) -> counts read back -> k_hscan.
         const bool trace = getenv("BSX_TRACE_HEAVY") != nullptr;
+        const bool sort_tasks = !getenv("BSX_SORT_TASKS") || atoi(getenv("BSX_SORT_TASKS")) != 0;
+        const bool xcd_map = !getenv("BSX_XCD_MAP") || atoi(getenv("BSX_XCD_MAP")) != 0;
         const int n_groups = g_heavy_groups;
         struct Group { uint32_t n_act = 0, iter = 0; int cur = 0; bool done = true, scan_pending = false; HeavyArgsRaw H; uint32_t *blk[2]; };
         for (uint32_t base = 0; base < n_heavy; base += b->hcap) {
@@ -514,6 +521,14 @@ extern "C" int bsx_batch_run_range(bsx_batch *b, uint32_t first_unit, uint32_t n
                             hipEvent_t e0, e1;
                             HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
                             b->scan_ev.push_back(e0); b->scan_ev.push_back(e1);
+                        }
+                        q.H.order = nullptr; q.H.xcd_map = xcd_map ? 1 : 0;
+                        if (sort_tasks && n_tasks > 64) {
+                            // (two groups share the four sort arrays: their sorts and scans are ordered on the main stream)
+                            bsx_launch_task_keys(q.H, n_tasks, b->d_tsort[0], b->d_tsort[2], b->stream);
+                            int rcs = bsx_sort_pairs_u32(&b->d_sort_tmp, &b->sort_tmp_bytes, b->d_tsort[0], b->d_tsort[1], b->d_tsort[2], b->d_tsort[3], n_tasks, b->stream);
+                            if (rcs) return rcs;
+                            q.H.order = b->d_tsort[3];
                         }
                         HIP_TRY(hipEventRecord(b->scan_ev[b->scan_ev_used], b->stream));
                         bsx_launch_hscan(A, q.H, n_tasks, b->stream);
@@ -599,6 +614,9 @@ extern "C" int bsx_batch_counters(bsx_batch *b, uint64_t c[BSX_N_COUNTERS])
     HIP_TRY(hipSetDevice(b->ref->device));
     HIP_TRY(hipStreamSynchronize(b->stream));
     HIP_TRY(hipMemcpy(c, b->d_counters, BSX_N_COUNTERS * 8, hipMemcpyDeviceToHost));
+    uint64_t sh[64 * 8];
+    HIP_TRY(hipMemcpy(sh, b->d_scan_stats, sizeof(sh), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 64; i++) for (int k = 0; k < 4; k++) c[7 + k] += sh[i * 8 + k];
     return BSX_OK;
 }
 extern "C" int bsx_batch_reset_counters(bsx_batch *b)
@@ -606,6 +624,7 @@ extern "C" int bsx_batch_reset_counters(bsx_batch *b)
     if (!b) return BSX_ERR_ARG;
     HIP_TRY(hipSetDevice(b->ref->device));
     HIP_TRY(hipMemsetAsync(b->d_counters, 0, BSX_N_COUNTERS * 8, b->stream));
+    HIP_TRY(hipMemsetAsync(b->d_scan_stats, 0, 64 * 64, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
     return BSX_OK;
 }

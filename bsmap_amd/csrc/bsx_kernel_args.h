@@ -22,6 +22,7 @@ struct AlignArgs {
     uint32_t *heavy_count;
     uint32_t *queue;           // work queue head of the main kernel (zeroed before launch)
     uint64_t *counters;        // BSX_N_COUNTERS
+    uint64_t *scan_stats;      // [64][8] sharded statistics of the scan kernel: candidates, reference words, class-one, class-five (counters 7-10)
     uint32_t *dbg_cycles;      // [n_units] shader-clock cycles spent on each unit (diagnostic builds of a run only), may be null
     uint64_t *dbg_cat;         // [16] category clocks (sums, then the longest single span of each) of the heavy control kernel (diagnostic runs only), may be null
     uint8_t *dbg_plan;         // [n_units][128]: start[2][16], order[2][16] for mate a then mate b
@@ -37,11 +38,16 @@ struct HeavyArgsRaw {
     uint32_t *queue;           // [2] work queue heads of k_hctrl and k_hscan
     const uint32_t *n_active_in_ptr;  // device count of active_in (passes after the first)
     uint32_t n_active_in, task_cap, fresh, list_base, hidx_base;
+    const uint32_t *order;     // task ids in scan order (sorted by the index entry they start at), or null
+    uint32_t xcd_map;
 };
 
 void bsx_launch_align(const AlignArgs &A, int paired, int grid_blocks, hipStream_t stream);
 void bsx_launch_hctrl(const AlignArgs &A, const HeavyArgsRaw &H, int paired, int grid_blocks, hipStream_t stream);
 void bsx_launch_hscan(const AlignArgs &A, const HeavyArgsRaw &H, uint32_t n_tasks, hipStream_t stream);
+void bsx_launch_task_keys(const HeavyArgsRaw &H, uint32_t n_tasks, uint32_t *keys, uint32_t *ids, hipStream_t stream);
+// bsx_index.hip: stable radix sort of (key, id) pairs (rocPRIM); temp grows on demand
+int bsx_sort_pairs_u32(void **temp, size_t *temp_bytes, const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *vals_in, uint32_t *vals_out, uint32_t n, hipStream_t stream);
 size_t bsx_hstate_bytes(void);
 size_t bsx_htask_bytes(void);
 size_t bsx_htaskout_bytes(void);

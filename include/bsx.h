@@ -140,8 +140,9 @@ typedef struct bsx_pair {
 /* work counters, SURVEY §8(d): 0 n_lookup, 1 n_cand, 2 sum_w (64-bit reference words the reference
  * algorithm touches), 3 n_orient, 4 reads/pairs processed, 5 aligned reads (n_aligned semantics), 6 aligned pairs,
  * 7 candidates evaluated by the scan kernel of the heavy pipeline (k_hscan; a subset of 1 plus the little it evaluates
- * speculatively), 8 their reference words (as 2), 9 spare */
-#define BSX_N_COUNTERS 10
+ * speculatively), 8 their reference words (as 2), 9 / 10 how many of them stopped after the first word / went through all
+ * five, 11 spare */
+#define BSX_N_COUNTERS 12
 
 int bsx_batch_create(bsx_ref *r, uint32_t max_units, int paired, bsx_batch **out);
 void bsx_batch_destroy(bsx_batch *b);
