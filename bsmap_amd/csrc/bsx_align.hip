@@ -1600,22 +1600,103 @@ __global__ __launch_bounds__(256) void k_hctrl(AlignArgs A, HeavyArgs H)
 #define BSX_HSCAN_WPB 4  /* waves (= tasks) per block */
 #endif
 
-// One step of k_hscan: 256 consecutive candidates of one sub-range (four chunks of 64; lane l of chunk u holds candidate
-// cb + 64u + l).  Everything a candidate needs is derived from pm1 = p - 1 (p = entry + h, its global nt position):
+// k_hscan evaluates a candidate in two stages.  Stage 1 (every candidate): the first 48 nt from one 16-byte reference
+// gather, which settle the reference's first early-out and, for most candidates, the second.  Stage 2 (the 40 % that are
+// still within the threshold after 48 nt): the remaining words.  Run lane by lane, stage 2 would execute for nearly every
+// chunk of 64 with most lanes idle; instead stage 1 pushes its survivors into a per-wave FIFO in LDS and stage 2 pops
+// them 64 at a time, so both its loads and its arithmetic run with full lanes.  The FIFO keeps list order, so the
+// survivor records still come out in list order.
+// Everything a candidate needs is derived from pm1 = p - 1 (p = entry + h, its global nt position):
 //   reference word index        pm1 >> 4              (one word early when p is word-aligned, see eval_loaded)
 //   funnel-shift amount         (30 pm1 + 30) mod 32  = (32 - 2 (p & 15)) & 31   (v_alignbit uses the low 5 bits)
 //   mask of the first 16-k nt   0x80000000 >>arith ((30 pm1 + 29) mod 32)        (k = p & 15)
 // The work accounting of the reference's two early-outs (align.h:189-197; 1, 2 or 5 64-bit words per candidate) needs no
 // ballots: with w0ref <= p48 <= w01ref, a task of n candidates touches  2 n - #(w0ref > thres) + 3 #(w01ref <= thres)
 // words; both counts are accumulated per lane and reduced once per task.
-// FULL: all 256 candidates exist (every step of a sub-range but its last).
+#define HS_QCAP 256u  /* FIFO slots per wave (16 bytes each): at most 63 left over + 2 chunks of 64 pushed between drains */
 struct ScanAcc { uint32_t c1, f5; };  // per lane: candidates with w0ref > thres / candidates evaluated in full with w01ref <= thres
-template <bool FULL>
-__device__ __forceinline__ void hscan_step(const uint32_t *__restrict__ q, const uint32_t *__restrict__ refbase, uint32_t hm1, uint32_t n_here, uint32_t ord0,
-                                           uint32_t strand, const uint32_t (&rw)[9], const uint32_t (&rm)[9], uint32_t thres0, int nwords, int lane,
-                                           HTaskOut *o, uint32_t &nsurv, bool &overflow, ScanAcc &acc)
+struct ScanCtx {
+    const uint32_t *refall;  // forward copy; the rc copy follows it in the same allocation
+    uint4 *Q;                // this wave's FIFO
+    uint32_t qh, qn;         // head slot, items queued (wave-uniform)
+    uint32_t thres0, nsurv;
+    int nwords, lane;
+    bool overflow;
+    HTaskOut *o;
+    ScanAcc acc;
+#ifdef BSX_SPAN_STATS
+    uint32_t span[4];
+#endif
+};
+
+// stage 2 for the first n (<= 64) queued candidates
+__device__ __forceinline__ void hscan_drain(ScanCtx &X, uint32_t n, const uint32_t (&rw)[9], const uint32_t (&rm)[9])
 {
-    uint32_t e[4], pm1[4];
+    const bool act = (uint32_t)X.lane < n;
+    const uint4 it = X.Q[(X.qh + (uint32_t)X.lane) & (HS_QCAP - 1)];  // x byte offset of the candidate's first word, y p48 | ordinal << 8 | strand << 31, z word 3, w pm1
+    X.qh = (X.qh + n) & (HS_QCAP - 1); X.qn -= n;
+    const uint32_t *rp = reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(X.refall) + it.x);
+    U4 r1; U2 r2;
+    r1.a = r1.b = r1.c = r1.d = 0; r2.a = r2.b = 0;
+    if (act && X.nwords > 3) r1 = *reinterpret_cast<const U4 *>(rp + 4);
+    if (act && X.nwords > 7) r2 = *reinterpret_cast<const U2 *>(rp + 8);
+#if defined(BSX_DUP) && BSX_DUP == 2  /* timing diagnostic (results unchanged): the second stage's loads twice */
+    {
+        const uint32_t *rq = rp; asm volatile("" : "+v"(rq));
+        U4 d1; U2 d2; d1.a = d1.b = d1.c = d1.d = 0; d2.a = d2.b = 0;
+        if (act && X.nwords > 3) d1 = *reinterpret_cast<const U4 *>(rq + 4);
+        if (act && X.nwords > 7) d2 = *reinterpret_cast<const U2 *>(rq + 8);
+        r1.a |= (d1.a ^ r1.a) | (d1.d ^ r1.d); r2.b |= d2.b ^ r2.b;
+    }
+#endif
+    const uint32_t sh = mad30(it.w, 30);
+    const uint32_t him = (uint32_t)((int32_t)0x80000000 >> (mad30(it.w, 29) & 31u));
+    const uint32_t p48 = it.y & 0xffu;
+    const uint32_t wd[7] = {it.z, r1.a, r1.b, r1.c, r1.d, r2.a, r2.b};
+    uint32_t tot = p48, w01ref = p48;
+#pragma unroll
+    for (int t = 3; t < 9; t++) {
+        const uint32_t f = __builtin_amdgcn_alignbit(wd[t - 3], wd[t - 2], sh);
+        const uint32_t mm = bsx_mismatch_hi(rw[t], bsx_tmask(rw[t], rm[t]), f);
+        tot += __popc(mm);
+        if (t == 3) w01ref += __popc(mm & him);
+    }
+#if defined(BSX_DUP) && BSX_DUP == 1  /* timing diagnostic: the second stage's arithmetic twice */
+    {
+        uint32_t v_[7];
+        for (int t = 0; t < 7; t++) { v_[t] = wd[t]; asm volatile("" : "+v"(v_[t])); }
+        uint32_t tot2 = p48;
+#pragma unroll
+        for (int t = 3; t < 9; t++) {
+            const uint32_t f = __builtin_amdgcn_alignbit(v_[t - 3], v_[t - 2], sh);
+            const uint32_t mm = bsx_mismatch_hi(rw[t], bsx_tmask(rw[t], rm[t]), f);
+            tot2 += __popc(mm);
+            if (t == 3) tot2 += __popc(mm & him) & 0u;
+        }
+        tot |= tot2 ^ tot;
+    }
+#endif
+    X.acc.f5 += (act && w01ref <= X.thres0) ? 1u : 0u;
+    // (chromosome / end-of-sequence test and hit coordinates are left to the control kernel's replay: the record carries
+    //  the strand copy and the global position)
+    const bool pass = act && tot <= X.thres0;
+    const u64 m = bsx_ballot(pass);
+    if (m) {
+        const uint32_t pos = X.nsurv + (uint32_t)__builtin_popcountll(m & lanemask_lt(X.lane));
+        if (pass && pos < HS_SCAP) { SurvRec r; r.w_ord = tot | ((it.y & 0x7fffff00u)); r.hchr = it.y >> 31; r.hloc = it.w + 1; r.hkey = 0; X.o->surv[pos] = r; }
+        X.nsurv += (uint32_t)__builtin_popcountll(m);
+        if (X.nsurv > HS_SCAP) X.overflow = true;
+    }
+}
+
+// stage 1 for 256 consecutive candidates of one sub-range (four chunks of 64; lane l of chunk u holds candidate
+// cb + 64u + l).  FULL: all 256 exist (every step of a sub-range but its last).
+template <bool FULL>
+__device__ __forceinline__ void hscan_step(ScanCtx &X, const uint32_t *__restrict__ q, uint32_t ref_off, uint32_t hm1, uint32_t n_here, uint32_t ord0,
+                                           uint32_t strand, const uint32_t (&rw)[9], const uint32_t (&rm)[9])
+{
+    const int lane = X.lane;
+    uint32_t e[4], pm1[4], boff[4];
     bool valid[4];
     U4 r0[4];
 #pragma unroll
@@ -1624,66 +1705,59 @@ __device__ __forceinline__ void hscan_step(const uint32_t *__restrict__ q, const
     for (int u = 0; u < 4; u++) {
         valid[u] = FULL || (uint32_t)(u * 64 + lane) < n_here;
         pm1[u] = (FULL || valid[u]) ? e[u] + hm1 : 15u;
+        boff[u] = ((pm1[u] >> 2) & 0x3ffffffcu) + ref_off;
     }
 #pragma unroll
-    for (int u = 0; u < 4; u++) r0[u] = *reinterpret_cast<const U4 *>(refbase + (pm1[u] >> 4));
-    // the first 48 nt of all four chunks, then — in one round trip — the remaining words of every candidate that is still
-    // within the threshold, then the verdicts in list order
-    uint32_t p48[4], sh[4];
-    bool need[4];
-    U4 r1[4];
-    U2 r2[4];
-    bool any = false;
+    for (int u = 0; u < 4; u++) r0[u] = *reinterpret_cast<const U4 *>(reinterpret_cast<const uint8_t *>(X.refall) + boff[u]);
+#if defined(BSX_DUP) && BSX_DUP == 3  /* timing diagnostic: the first stage's gathers twice */
 #pragma unroll
     for (int u = 0; u < 4; u++) {
-        sh[u] = mad30(pm1[u], 30);
+        uint32_t bo = boff[u]; asm volatile("" : "+v"(bo));
+        const U4 d = *reinterpret_cast<const U4 *>(reinterpret_cast<const uint8_t *>(X.refall) + bo);
+        r0[u].a |= d.a ^ r0[u].a; r0[u].d |= d.d ^ r0[u].d;
+    }
+#endif
+    const uint32_t tag = (ord0 + (uint32_t)lane) << 8 | strand << 31;
+#ifdef BSX_SPAN_STATS  /* diagnostic build: how tightly clustered are the 64 candidates of a chunk? */
+    if (FULL) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t span = rl(e[u], 63) - rl(e[u], 0);
+            X.span[0]++; X.span[1] += span <= 848; X.span[2] += span <= 1872; X.span[3] += span <= 3920;
+        }
+    }
+#endif
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const uint32_t sh = mad30(pm1[u], 30);
         const uint32_t him = (uint32_t)((int32_t)0x80000000 >> (mad30(pm1[u], 29) & 31u));
-        const uint32_t f0 = __builtin_amdgcn_alignbit(r0[u].a, r0[u].b, sh[u]), f1 = __builtin_amdgcn_alignbit(r0[u].b, r0[u].c, sh[u]),
-                       f2 = __builtin_amdgcn_alignbit(r0[u].c, r0[u].d, sh[u]);
+        const uint32_t f0 = __builtin_amdgcn_alignbit(r0[u].a, r0[u].b, sh), f1 = __builtin_amdgcn_alignbit(r0[u].b, r0[u].c, sh),
+                       f2 = __builtin_amdgcn_alignbit(r0[u].c, r0[u].d, sh);
         const uint32_t m1 = bsx_mismatch_hi(rw[1], bsx_tmask(rw[1], rm[1]), f1);
         const uint32_t c0 = __popc(bsx_mismatch_hi(rw[0], bsx_tmask(rw[0], rm[0]), f0));
         const uint32_t w0ref = __popc(m1 & him) + c0;
-        p48[u] = __popc(bsx_mismatch_hi(rw[2], bsx_tmask(rw[2], rm[2]), f2)) + (__popc(m1) + c0);
-        need[u] = (FULL || valid[u]) && p48[u] <= thres0;
-        acc.c1 += ((FULL || valid[u]) && w0ref > thres0) ? 1u : 0u;
-        any |= need[u];
-        r1[u].a = r1[u].b = r1[u].c = r1[u].d = 0; r2[u].a = r2[u].b = 0;
-    }
-    if (!bsx_ballot(any)) return;
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-        const uint32_t *rp = refbase + (pm1[u] >> 4);
-        if (need[u] && nwords > 3) r1[u] = *reinterpret_cast<const U4 *>(rp + 4);
-        if (need[u] && nwords > 7) r2[u] = *reinterpret_cast<const U2 *>(rp + 8);
-    }
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-        if (!bsx_ballot(need[u])) continue;
-        uint32_t w = 0xffffu, w01ref = 0xffffu;
-        if (need[u]) {
-            const uint32_t him = (uint32_t)((int32_t)0x80000000 >> (mad30(pm1[u], 29) & 31u));
-            const uint32_t wd[7] = {r0[u].d, r1[u].a, r1[u].b, r1[u].c, r1[u].d, r2[u].a, r2[u].b};
-            uint32_t tot = p48[u];
-            w01ref = p48[u];
-#pragma unroll
-            for (int t = 3; t < 9; t++) {
-                const uint32_t f = __builtin_amdgcn_alignbit(wd[t - 3], wd[t - 2], sh[u]);
-                const uint32_t mm = bsx_mismatch_hi(rw[t], bsx_tmask(rw[t], rm[t]), f);
-                tot += __popc(mm);
-                if (t == 3) w01ref += __popc(mm & him);
-            }
-            w = tot;
-            acc.f5 += w01ref <= thres0 ? 1u : 0u;
+        uint32_t p48 = __popc(bsx_mismatch_hi(rw[2], bsx_tmask(rw[2], rm[2]), f2)) + (__popc(m1) + c0);
+#if defined(BSX_DUP) && BSX_DUP == 4  /* timing diagnostic: the first stage's arithmetic twice */
+        {
+            uint32_t a_ = r0[u].a, b_ = r0[u].b, c_ = r0[u].c, d_ = r0[u].d; asm volatile("" : "+v"(a_), "+v"(b_), "+v"(c_), "+v"(d_));
+            const uint32_t g0 = __builtin_amdgcn_alignbit(a_, b_, sh), g1 = __builtin_amdgcn_alignbit(b_, c_, sh), g2 = __builtin_amdgcn_alignbit(c_, d_, sh);
+            const uint32_t n1_ = bsx_mismatch_hi(rw[1], bsx_tmask(rw[1], rm[1]), g1);
+            const uint32_t q48 = __popc(bsx_mismatch_hi(rw[2], bsx_tmask(rw[2], rm[2]), g2)) + (__popc(n1_) + __popc(bsx_mismatch_hi(rw[0], bsx_tmask(rw[0], rm[0]), g0))) + __popc(n1_ & him);
+            p48 |= (q48 - w0ref) ^ p48;
         }
-        // (chromosome / end-of-sequence test and hit coordinates are left to the control kernel's replay: the record
-        //  carries the strand copy and the global position)
-        const bool pass = need[u] && w <= thres0;
-        const u64 m = bsx_ballot(pass);
-        if (m) {
-            const uint32_t pos = nsurv + (uint32_t)__builtin_popcountll(m & lanemask_lt(lane));
-            if (pass && pos < HS_SCAP) { SurvRec r; r.w_ord = w | ((ord0 + (uint32_t)(u * 64 + lane)) << 8); r.hchr = strand; r.hloc = pm1[u] + 1; r.hkey = 0; o->surv[pos] = r; }
-            nsurv += (uint32_t)__builtin_popcountll(m);
-            if (nsurv > HS_SCAP) overflow = true;
+#endif
+        const bool need = (FULL || valid[u]) && p48 <= X.thres0;
+        X.acc.c1 += ((FULL || valid[u]) && w0ref > X.thres0) ? 1u : 0u;
+        const u64 nm = bsx_ballot(need);
+        if (nm) {
+            if (need) {
+                const uint32_t pos = X.qh + X.qn + (uint32_t)__builtin_popcountll(nm & lanemask_lt(lane));
+                X.Q[pos & (HS_QCAP - 1)] = make_uint4(boff[u], p48 | (tag + ((uint32_t)u << 14)), r0[u].d, pm1[u]);
+            }
+            X.qn += (uint32_t)__builtin_popcountll(nm);
+        }
+        if (u & 1) {  // (FIFO writes and reads of a wave are ordered: same wave, same LDS)
+            while (X.qn >= 64 && !X.overflow) hscan_drain(X, 64, rw, rm);
         }
     }
 }
@@ -1691,6 +1765,7 @@ __device__ __forceinline__ void hscan_step(const uint32_t *__restrict__ q, const
 __global__ __launch_bounds__(64 * BSX_HSCAN_WPB, BSX_HSCAN_WAVES) void k_hscan(AlignArgs A, HeavyArgs H)
 {
     __shared__ uint32_t TAB[BSX_HSCAN_WPB][4][32];
+    __shared__ uint4 QBUF[BSX_HSCAN_WPB][HS_QCAP];
 #ifdef BSX_HSCAN_PAD  /* occupancy experiments: extra LDS per block limits the resident waves */
     __shared__ uint32_t PAD[BSX_HSCAN_PAD / 4];
     if (threadIdx.x == 0 && A.n_units == 0xffffffffu) PAD[0] = 1;
@@ -1700,9 +1775,8 @@ __global__ __launch_bounds__(64 * BSX_HSCAN_WPB, BSX_HSCAN_WAVES) void k_hscan(A
     // one task per wave, no queue: the blocks of a pass retire one by one, so the control kernel of the other unit
     // group (high-priority stream) finds free slots while this kernel is still running
     const uint32_t n_tasks = min(*H.n_tasks, H.task_cap);
-    // Tasks are taken in key order (= by the index entries they walk), and the blocks of one XCD take a contiguous part of
-    // that order (blocks are dealt to the 8 XCDs in turn): the reads that walk the same giant bucket then do so at the same
-    // time behind the same L2, which fetches each line of entries / reference once for all of them
+    // Tasks are taken in key order (= by the index entries they walk): the reads that walk the same giant bucket then do
+    // so at the same time, and each line of entries / reference is fetched from memory once for all of them
     uint32_t slot = blockIdx.x * BSX_HSCAN_WPB + (uint32_t)wv;
     if (H.xcd_map) slot = ((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3)) * BSX_HSCAN_WPB + (uint32_t)wv;
     if (slot >= n_tasks) return;
@@ -1718,39 +1792,44 @@ __global__ __launch_bounds__(64 * BSX_HSCAN_WPB, BSX_HSCAN_WAVES) void k_hscan(A
     uint32_t rw[9], rm[9];
 #pragma unroll
     for (int k = 0; k < 9; k++) { rw[k] = rfl(R.rw[k]); rm[k] = rfl(R.rm[k]); }
-    const uint32_t thres0 = rfl(R.thres), nsub = min(rfl(R.nsub), 32u);
-    const int nwords = (int)rfl(R.nwords);
+    const uint32_t nsub = min(rfl(R.nsub), 32u);
     wave_fence();
-    uint32_t nsurv = 0;
-    bool overflow = false;
-    ScanAcc acc = {0, 0};
+    ScanCtx X;
+    X.refall = P.refcat; X.Q = QBUF[wv]; X.qh = 0; X.qn = 0; X.thres0 = rfl(R.thres); X.nsurv = 0; X.nwords = (int)rfl(R.nwords); X.lane = lane;
+    X.overflow = false; X.o = o; X.acc.c1 = 0; X.acc.f5 = 0;
+#ifdef BSX_SPAN_STATS
+    X.span[0] = X.span[1] = X.span[2] = X.span[3] = 0;
+#endif
+    const uint32_t cref_off = (uint32_t)((const uint8_t *)P.crefcat - (const uint8_t *)P.refcat);  // both copies live in one allocation (bsx_api.hip)
     const uint32_t c_end = tc0 + tn;
     // the task's candidates sub-range by sub-range (list order): inside one sub-range entry address, h and strand are
     // wave-uniform; four chunks are in flight per step — entries first, then all four 16-byte reference loads.
     // Neighbouring lanes hold neighbouring entries, so in a repeat bucket one reference gather touches few lines.
-    for (uint32_t sidx = 0; sidx < nsub && !overflow; sidx++) {
+    for (uint32_t sidx = 0; sidx < nsub && !X.overflow; sidx++) {
         const uint32_t ps = rfl(TAB[wv][0][sidx]), ns = rfl(TAB[wv][1][sidx]);
         const uint32_t lo = max(tc0, ps), hi = min(c_end, ps + ns);
         if (lo >= hi) continue;
         const uint32_t *ent = P.entries + rfl(TAB[wv][2][sidx]);
         const uint32_t hm1 = rfl(TAB[wv][3][sidx]) - 1u, strand = sidx & 1;
-        const uint32_t *refbase = strand ? P.crefcat : P.refcat;
+        const uint32_t ref_off = strand ? cref_off : 0u;
         uint32_t cb = lo;
-        for (; cb + 256 <= hi && !overflow; cb += 256)
-            hscan_step<true>(ent + (cb - ps) + lane, refbase, hm1, 256, cb - tc0, strand, rw, rm, thres0, nwords, lane, o, nsurv, overflow, acc);
-        if (cb < hi && !overflow)
-            hscan_step<false>(ent + (cb - ps) + lane, refbase, hm1, hi - cb, cb - tc0, strand, rw, rm, thres0, nwords, lane, o, nsurv, overflow, acc);
+        for (; cb + 256 <= hi && !X.overflow; cb += 256) hscan_step<true>(X, ent + (cb - ps) + lane, ref_off, hm1, 256, cb - tc0, strand, rw, rm);
+        if (cb < hi && !X.overflow) hscan_step<false>(X, ent + (cb - ps) + lane, ref_off, hm1, hi - cb, cb - tc0, strand, rw, rm);
     }
-    const uint32_t n1 = wave_sum(acc.c1), n5 = wave_sum(acc.f5);
-    const uint32_t words = 2u * tn - n1 + 3u * n5;  // 1, 2 or 5 words per candidate (see hscan_step)
+    while (X.qn && !X.overflow) hscan_drain(X, min(X.qn, 64u), rw, rm);
+    const uint32_t n1 = wave_sum(X.acc.c1), n5 = wave_sum(X.acc.f5);
+    const uint32_t words = 2u * tn - n1 + 3u * n5;  // 1, 2 or 5 words per candidate (see above)
     if (lane == 0) {
-        o->count = overflow ? 0 : nsurv; o->overflow = overflow ? 1 : 0; o->acc[0] = tn; o->acc[1] = words; o->acc[2] = 0; o->acc[3] = 0;
-        if (!overflow) {  // work of the scan kernel (incl. speculation); an overflowed task is redone by the control kernel.
+        o->count = X.overflow ? 0 : X.nsurv; o->overflow = X.overflow ? 1 : 0; o->acc[0] = tn; o->acc[1] = words; o->acc[2] = 0; o->acc[3] = 0;
+        if (!X.overflow) {  // work of the scan kernel (incl. speculation); an overflowed task is redone by the control kernel.
             // Millions of tasks per batch: one counter word takes ~88 atomics per microsecond, so these statistics are
             // sharded over 64 cache lines (summed by bsx_batch_counters) instead of being added to four hot words
             u64 *sh = (u64 *)A.scan_stats + (size_t)(blockIdx.x & 63u) * 8;
             atomicAdd((u64 *)&sh[0], (u64)tn); atomicAdd((u64 *)&sh[1], (u64)words);
             atomicAdd((u64 *)&sh[2], (u64)n1); atomicAdd((u64 *)&sh[3], (u64)n5);
+#ifdef BSX_SPAN_STATS
+            for (int k_ = 0; k_ < 4; k_++) atomicAdd((u64 *)&sh[4 + k_], (u64)X.span[k_]);
+#endif
         }
     }
 }

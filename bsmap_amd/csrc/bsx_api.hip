@@ -62,10 +62,11 @@ static int finish_ref_upload(bsx_ref *r, const std::vector<uint32_t> &refcat, co
 {
     int rc;
     // 64 spare words behind each copy so that 16-byte candidate loads never leave the allocation
-    HIP_TRY(hipMalloc((void **)&r->d_refcat, (r->n_words + 64) * 4));
-    HIP_TRY(hipMalloc((void **)&r->d_crefcat, (r->n_words + 64) * 4));
-    HIP_TRY(hipMemset(r->d_refcat, 0, (r->n_words + 64) * 4));
-    HIP_TRY(hipMemset(r->d_crefcat, 0, (r->n_words + 64) * 4));
+    // (both strand copies in one allocation, the rc copy right behind the forward one: a candidate's reference words are
+    //  then addressed by one 32-bit byte offset whatever its strand — the scan kernel's tail queue relies on that)
+    HIP_TRY(hipMalloc((void **)&r->d_refcat, 2 * (r->n_words + 64) * 4));
+    r->d_crefcat = r->d_refcat + r->n_words + 64;
+    HIP_TRY(hipMemset(r->d_refcat, 0, 2 * (r->n_words + 64) * 4));
     HIP_TRY(hipMemcpy(r->d_refcat, refcat.data(), r->n_words * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(r->d_crefcat, crefcat.data(), r->n_words * 4, hipMemcpyHostToDevice));
     if ((rc = upload(&r->d_anchor, r->anchor.data(), r->anchor.size()))) return rc;
@@ -111,7 +112,7 @@ extern "C" void bsx_ref_destroy(bsx_ref *r)
 {
     if (!r) return;
     (void)hipSetDevice(r->device);
-    for (void *q : {(void *)r->d_refcat, (void *)r->d_crefcat, (void *)r->d_anchor, (void *)r->d_chr_size, (void *)r->d_rc_offset,
+    for (void *q : {(void *)r->d_refcat, (void *)r->d_anchor, (void *)r->d_chr_size, (void *)r->d_rc_offset,
                     (void *)r->d_bucket_off, (void *)r->d_bucket_nfwd, (void *)r->d_entries, (void *)r->d_sites, (void *)r->d_site_off})
         if (q) (void)hipFree(q);
     delete r;
@@ -617,6 +618,11 @@ extern "C" int bsx_batch_counters(bsx_batch *b, uint64_t c[BSX_N_COUNTERS])
     uint64_t sh[64 * 8];
     HIP_TRY(hipMemcpy(sh, b->d_scan_stats, sizeof(sh), hipMemcpyDeviceToHost));
     for (int i = 0; i < 64; i++) for (int k = 0; k < 4; k++) c[7 + k] += sh[i * 8 + k];
+    if (getenv("BSX_SPAN_STATS")) {  // diagnostic builds (-DBSX_SPAN_STATS): chunks of 64 candidates by the span of their index entries
+        uint64_t t[4] = {0, 0, 0, 0};
+        for (int i = 0; i < 64; i++) for (int k = 0; k < 4; k++) t[k] += sh[i * 8 + 4 + k];
+        fprintf(stderr, "[bsx span] full chunks %llu, span <= 848 nt %llu, <= 1872 %llu, <= 3920 %llu\n", (unsigned long long)t[0], (unsigned long long)t[1], (unsigned long long)t[2], (unsigned long long)t[3]);
+    }
     return BSX_OK;
 }
 extern "C" int bsx_batch_reset_counters(bsx_batch *b)

@@ -250,8 +250,9 @@ extern "C" int bsx_ref_create_synthetic(const bsx_params *p, uint32_t n_chr, con
     std::sort(r->blocks.begin(), r->blocks.end(), [](const Block &a, const Block &b) { return a.id < b.id || (a.id == b.id && a.begin < b.begin); });
     r->n_words = words + 2 * BSX_REF_MARGIN;
     auto fail = [&](int rc) { bsx_ref_destroy(r); return rc; };
-    if (hipMalloc((void **)&r->d_refcat, (r->n_words + 64) * 4) != hipSuccess || hipMalloc((void **)&r->d_crefcat, (r->n_words + 64) * 4) != hipSuccess) return fail(BSX_ERR_NOMEM);
-    if (hipMemset(r->d_refcat, 0, (r->n_words + 64) * 4) != hipSuccess || hipMemset(r->d_crefcat, 0, (r->n_words + 64) * 4) != hipSuccess) return fail(BSX_ERR_DEVICE);
+    if (hipMalloc((void **)&r->d_refcat, 2 * (r->n_words + 64) * 4) != hipSuccess) return fail(BSX_ERR_NOMEM);  // one allocation, see finish_ref_upload
+    r->d_crefcat = r->d_refcat + r->n_words + 64;
+    if (hipMemset(r->d_refcat, 0, 2 * (r->n_words + 64) * 4) != hipSuccess) return fail(BSX_ERR_DEVICE);
     const uint32_t bnp = p->bit_nt[0] | (p->bit_nt[1] << 8) | (p->bit_nt[2] << 16) | ((uint32_t)p->bit_nt[3] << 24);
     for (uint32_t c = 0; c < n_chr; c++) {
         const uint32_t nw = r->rc_offset[c] / 16, w0 = r->anchor[c] / 16;
