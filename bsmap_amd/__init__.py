@@ -62,7 +62,7 @@ EXPORTS = [
     "bsx_device_count", "bsx_ref_create_from_fasta", "bsx_ref_create_from_file", "bsx_ref_create_synthetic", "bsx_synth_chr_text", "bsx_ref_destroy",
     "bsx_ref_n_chr", "bsx_ref_n_words", "bsx_ref_n_blocks", "bsx_ref_info", "bsx_ref_chr_name", "bsx_ref_blocks",
     "bsx_ref_download_words", "bsx_index_build", "bsx_index_n_entries", "bsx_index_download", "bsx_ref_n_sites", "bsx_ref_sites",
-    "bsx_batch_create", "bsx_batch_destroy", "bsx_batch_upload_se", "bsx_batch_upload_pe", "bsx_batch_synth_reads",
+    "bsx_batch_create", "bsx_batch_destroy", "bsx_batch_upload_se", "bsx_batch_upload_pe", "bsx_batch_synth_reads", "bsx_batch_synth_reads_kind", "bsx_batch_download_quals",
     "bsx_batch_run", "bsx_batch_run_range", "bsx_batch_sync", "bsx_batch_kernel_ms", "bsx_batch_scan_ms", "bsx_batch_results_se", "bsx_batch_results_pe",
     "bsx_batch_counters", "bsx_batch_reset_counters", "bsx_batch_download_reads", "bsx_batch_set_debug", "bsx_batch_unit_cycles", "bsx_batch_ctrl_clocks",
     "bsx_batch_debug_hits", "bsx_batch_debug_pairs", "bsx_batch_debug_plan", "bsx_set_waves_per_cu", "bsx_set_heavy_threshold", "bsx_set_heavy_limits", "bsx_batch_last_heavy_units", "bsx_pinned_alloc", "bsx_pinned_free", "bsx_probe_memory", "bsx_thread_device",
@@ -112,6 +112,8 @@ def lib():
         L.bsx_batch_upload_se.argtypes = [vp, u32, vp, vp, vp, u32]
         L.bsx_batch_upload_pe.argtypes = [vp, u32, vp, vp, vp, vp, vp, vp, u32]
         L.bsx_batch_synth_reads.argtypes = [vp, u32, u32, u64, u32]
+        L.bsx_batch_synth_reads_kind.argtypes = [vp, u32, u32, u64, u32, i32]
+        L.bsx_batch_download_quals.argtypes = [vp, i32, vp]
         L.bsx_batch_run.argtypes = [vp]
         L.bsx_batch_run_range.argtypes = [vp, u32, u32]
         L.bsx_batch_sync.argtypes = [vp]
@@ -206,6 +208,14 @@ class RefSeq:
         buf = C.create_string_buffer(n)
         _check(lib().bsx_synth_chr_text(self.h, c, start, n, buf))
         return buf.raw.decode()
+
+    def synth_bytes(self, c, start=0, n=None):
+        """the same as a uint8 array (whole chromosomes of the hg38-sized genome without a Python string in between)"""
+        a, sz, _ = self.info()
+        n = int(sz[c]) - start if n is None else n
+        buf = np.zeros(n, np.uint8)
+        _check(lib().bsx_synth_chr_text(self.h, c, start, n, buf.ctypes.data))
+        return buf
 
     def CreateIndex(self):
         _check(lib().bsx_index_build(self.h))
@@ -320,9 +330,16 @@ class _Batch:
         _check(lib().bsx_batch_unit_cycles(self.h, c.ctypes.data))
         return c
 
-    def synth_reads(self, n, read_len, seed, first_index=0):
-        _check(lib().bsx_batch_synth_reads(self.h, n, read_len, seed, first_index))
+    def synth_reads(self, n, read_len, seed, first_index=0, kind=0):
+        """kind 0 plain, 1 trimming workload (qualities with low 3' tails, adapter read-through), 2 RRBS (reads at digestion sites)"""
+        _check(lib().bsx_batch_synth_reads_kind(self.h, n, read_len, seed, first_index, kind))
         self.n = n
+
+    def download_quals(self, mate=0):
+        _, off = self.download_reads(mate)
+        buf = np.zeros(max(1, int(off[-1])), np.uint8)
+        _check(lib().bsx_batch_download_quals(self.h, mate, buf.ctypes.data))
+        return buf
 
     def download_reads(self, mate=0):
         off = np.zeros(self.n + 1, np.uint64)

@@ -719,9 +719,9 @@ extern "C" int bsx_batch_debug_plan(bsx_batch *b, uint32_t unit, int mate, int32
     return BSX_OK;
 }
 
-extern "C" int bsx_batch_synth_reads(bsx_batch *b, uint32_t n, uint32_t read_len, uint64_t seed, uint32_t first_index)
+extern "C" int bsx_batch_synth_reads_kind(bsx_batch *b, uint32_t n, uint32_t read_len, uint64_t seed, uint32_t first_index, int kind)
 {
-    if (!b || n == 0 || n > b->max_units || read_len < 16 || read_len > 160) return BSX_ERR_ARG;
+    if (!b || n == 0 || n > b->max_units || read_len < 16 || read_len > 160 || kind < 0 || kind > 2) return BSX_ERR_ARG;
     HIP_TRY(hipSetDevice(b->ref->device));
     const int nm = b->paired ? 2 : 1;
     std::vector<uint64_t> off((size_t)n + 1);
@@ -730,8 +730,27 @@ extern "C" int bsx_batch_synth_reads(bsx_batch *b, uint32_t n, uint32_t read_len
         if (off[n] + 256 > b->seq_cap[m]) return BSX_ERR_ARG;
         HIP_TRY(hipMemcpy(b->d_off[m], off.data(), off.size() * 8, hipMemcpyHostToDevice));
     }
-    int rc = bsx_synth_reads_launch(b->ref, n, read_len, b->paired, seed, first_index, b->d_seq[0], b->d_seq[1], b->stream);
+    const bool q = kind == 1;  // the trimming workload carries qualities (low-quality 3' tails)
+    int rc = bsx_synth_reads_launch(b->ref, n, read_len, b->paired, seed, first_index, b->d_seq[0], b->d_seq[1], b->stream, kind, q ? b->d_qual[0] : nullptr,
+                                    q && b->paired ? b->d_qual[1] : nullptr);
     if (rc) return rc;
-    b->n_units = n; b->first_index = first_index; b->has_qual = 0;
+    b->n_units = n; b->first_index = first_index; b->has_qual = q ? 1 : 0;
+    return BSX_OK;
+}
+
+extern "C" int bsx_batch_synth_reads(bsx_batch *b, uint32_t n, uint32_t read_len, uint64_t seed, uint32_t first_index)
+{
+    return bsx_batch_synth_reads_kind(b, n, read_len, seed, first_index, 0);
+}
+
+extern "C" int bsx_batch_download_quals(bsx_batch *b, int mate, char *quals)
+{
+    if (!b || mate < 0 || mate > (b->paired ? 1 : 0) || !quals) return BSX_ERR_ARG;
+    if (!b->has_qual) return BSX_ERR_STATE;
+    HIP_TRY(hipSetDevice(b->ref->device));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    uint64_t end = 0;
+    HIP_TRY(hipMemcpy(&end, b->d_off[mate] + b->n_units, 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(quals, b->d_qual[mate], end, hipMemcpyDeviceToHost));
     return BSX_OK;
 }

@@ -75,6 +75,6 @@ int bsx_index_build_wgbs(bsx_ref *r);
 int bsx_index_build_rrbs(bsx_ref *r, const std::vector<uint32_t> &refcat, const std::vector<uint32_t> &crefcat);
 // bsx_synth.hip
 int bsx_synth_reads_launch(const bsx_ref *r, uint32_t n, uint32_t read_len, int paired, uint64_t seed, uint32_t first_index, uint8_t *d_seq_a,
-                           uint8_t *d_seq_b, hipStream_t stream);
+                           uint8_t *d_seq_b, hipStream_t stream, int kind = 0, uint8_t *d_qual_a = nullptr, uint8_t *d_qual_b = nullptr);
 // bsx_align.hip
 void bsx_fill_devparams(const bsx_ref *r, DevParams &d);

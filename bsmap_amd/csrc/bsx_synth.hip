@@ -146,6 +146,9 @@ struct ReadGen {
     uint32_t bit_nt_packed;
     u64 seed;
     uint32_t read_len, paired, first_unit;
+    uint32_t kind;               // 0 plain, 1 trimming workload (low-quality 3' tails, adapter read-through), 2 RRBS (reads start at digestion sites)
+    const uint32_t *sites, *site_off, *anchor;  // RRBS: digestion sites per chromosome (flat + offsets), chromosome anchors
+    uint32_t n_chr, digest_len, digest_pos;
 };
 
 __device__ inline int ref_nt(const ReadGen &g, uint32_t gpos)
@@ -156,19 +159,57 @@ __device__ inline int ref_nt(const ReadGen &g, uint32_t gpos)
 }
 
 // one thread per unit: bench input generation is not on the timed path
-__global__ void k_synth_reads(ReadGen g, uint32_t n, uint8_t *__restrict__ seq_a, uint8_t *__restrict__ seq_b)
+__global__ void k_synth_reads(ReadGen g, uint32_t n, uint8_t *__restrict__ seq_a, uint8_t *__restrict__ seq_b, uint8_t *__restrict__ qual_a,
+                              uint8_t *__restrict__ qual_b)
 {
     const char ADAPTER[] = "AGATCGGAAGAGCACACGTCTGAACTCCAGTCA";
     for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < n; u += gridDim.x * blockDim.x) {
         const u64 id = g.first_unit + (u64)u;
-        const u64 r0 = h3(g.seed, id, 1);
+        u64 r0 = h3(g.seed, id, 1);
         uint32_t ins = g.read_len;
+        if (g.kind == 2) {
+            // RRBS: the read starts at a digestion site; fragment = [site_k, site_k+1 + len(site) - 2 pos) as a
+            // C-CGG digest leaves it, kept when it is read_len..220 nt long; Watson or Crick strand of the fragment
+            const uint32_t n_sites = g.site_off[g.n_chr];
+            uint32_t a = 0, b = 0;
+            bool found = false;
+            for (int tries = 0; tries < 64 && !found; tries++) {
+                const uint32_t gi = (uint32_t)(h3(g.seed, id, 100 + tries) % (u64)n_sites);
+                uint32_t lo = 0, hi = g.n_chr;
+                while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (g.site_off[mid] <= gi) lo = mid; else hi = mid; }
+                if (gi + 1 >= g.site_off[lo + 1]) continue;
+                const uint32_t fa = g.sites[gi], fb = g.sites[gi + 1] + g.digest_len - 2 * g.digest_pos;
+                if (fb - fa < g.read_len || fb - fa > 220) continue;
+                a = g.anchor[lo] + fa; b = g.anchor[lo] + fb; found = true;
+            }
+            if (!found) { a = g.anchor[0] + g.sites[0]; b = a + g.read_len; }  // (a genome without a usable fragment: any site)
+            const bool watson = (r0 >> 63) == 0;
+            uint8_t *out = seq_a + (size_t)u * g.read_len;
+            for (uint32_t k = 0; k < g.read_len; k++) {
+                int base, next;
+                if (watson) { base = ref_nt(g, a + k); next = ref_nt(g, a + k + 1); }
+                else { base = 3 - ref_nt(g, b - 1 - k); next = b - 2 - k >= a ? 3 - ref_nt(g, b - 2 - k) : 0; }
+                if (base == 1) {
+                    const uint32_t uc = u01_24(h3(g.seed ^ 0xB15, id, k));
+                    if (uc < (next == 2 ? (uint32_t)(0.25 * 16777216.0) : (uint32_t)(0.995 * 16777216.0))) base = 3;
+                }
+                const u64 rk = h3(g.seed ^ 0x5EED, id * 2, k);
+                if (u01_24(rk) < (uint32_t)(0.005 * 16777216.0)) base = mutate_base(base, rk);
+                out[k] = "ACGT"[base];
+                if (qual_a) qual_a[(size_t)u * g.read_len + k] = 'I';
+            }
+            continue;
+        }
         if (g.paired) {  // ~N(300,50) from 4 uniforms, clipped
             const u64 r1 = h3(g.seed, id, 2);
             const int s4 = (int)(r1 & 0xFFFF) + (int)((r1 >> 16) & 0xFFFF) + (int)((r1 >> 32) & 0xFFFF) + (int)((r1 >> 48) & 0xFFFF);
             int v = 300 + (int)(((long long)(s4 - 131070) * 50) / 37837);  // sd of the 4-uniform sum = 37837
             v = v < 50 ? 50 : (v > 480 ? 480 : v);
             ins = (uint32_t)v;
+        }
+        if (g.kind == 1) {  // trimming workload: 30 % of the fragments are 30-149 nt long, so the reads run into the adapter
+            const u64 r2 = h3(g.seed, id, 3);
+            if (u01_24(r2) < (uint32_t)(0.30 * 16777216.0)) ins = 30 + (uint32_t)((r2 & 0xffffff) % 120);
         }
         // uniform fragment start over positions where the whole fragment stays inside a block
         const u64 total = g.blk_prefix[g.n_blk];
@@ -181,8 +222,11 @@ __global__ void k_synth_reads(ReadGen g, uint32_t n, uint8_t *__restrict__ seq_a
         const int nm = g.paired ? 2 : 1;
         for (int m = 0; m < nm; m++) {
             uint8_t *out = (m ? seq_b : seq_a) + (size_t)u * g.read_len;
+            uint8_t *qout = (m ? qual_b : qual_a) ? (m ? qual_b : qual_a) + (size_t)u * g.read_len : nullptr;
+            const uint32_t tail = g.kind == 1 ? 10 + (uint32_t)(h3(g.seed, id * 2 + m, 4) % 51) : 0;  // 3' tail of 10-60 nt with Q2-Q15
             for (uint32_t k = 0; k < g.read_len; k++) {
                 int b;
+                if (qout) qout[k] = (k + tail >= g.read_len) ? (uint8_t)(33 + 2 + (h3(g.seed ^ 0x9A1, id * 2 + m, k) % 14)) : (uint8_t)'I';
                 const u64 rk = h3(g.seed ^ 0x5EED, id * 2 + m, k);
                 const bool inside = m == 0 ? k < ins : k < ins;
                 if (inside) {
@@ -226,7 +270,33 @@ static void synth_blocks(uint32_t c, uint32_t len, uint32_t padded, std::vector<
 
 extern "C" int bsx_ref_create_synthetic(const bsx_params *p, uint32_t n_chr, const uint32_t *chr_len, uint64_t seed, int device, bsx_ref **out)
 {
-    if (!p || !chr_len || !out || n_chr == 0 || p->rrbs) return BSX_ERR_ARG;
+    if (!p || !chr_len || !out || n_chr == 0) return BSX_ERR_ARG;
+    if (p->rrbs) {
+        // RRBS mode needs the digestion-site tables and the site-anchored index, which the host packer builds from the
+        // text: generate the same genome as text (on the device), hand it to the ordinary loader as a FASTA image
+        bsx_params q = *p;
+        q.rrbs = 0;
+        bsx_ref *tmp = nullptr;
+        int rc = bsx_ref_create_synthetic(&q, n_chr, chr_len, seed, device, &tmp);
+        if (rc) return rc;
+        std::string fa;
+        uint64_t total = 0;
+        for (uint32_t c = 0; c < n_chr; c++) total += chr_len[c] + 16;
+        fa.reserve(total);
+        std::vector<char> buf;
+        for (uint32_t c = 0; c < n_chr && rc == BSX_OK; c++) {
+            fa += ">" + tmp->names[c] + "\n";
+            buf.resize(chr_len[c]);
+            rc = bsx_synth_chr_text(tmp, c, 0, chr_len[c], buf.data());
+            fa.append(buf.data(), chr_len[c]);
+            fa += "\n";
+        }
+        bsx_ref_destroy(tmp);
+        if (rc) return rc;
+        rc = bsx_ref_create_from_fasta(p, fa.data(), fa.size(), device, out);
+        if (rc == BSX_OK) (*out)->synth_seed = seed;
+        return rc;
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device >= ndev) { g_bsx_err = "no HIP device"; return BSX_ERR_NODEVICE; }
     HIP_TRY(hipSetDevice(device));
@@ -284,8 +354,9 @@ extern "C" int bsx_synth_chr_text(const bsx_ref *r, uint32_t c, uint32_t from, u
 }
 
 int bsx_synth_reads_launch(const bsx_ref *r, uint32_t n, uint32_t read_len, int paired, uint64_t seed, uint32_t first_index, uint8_t *d_seq_a,
-                           uint8_t *d_seq_b, hipStream_t stream)
+                           uint8_t *d_seq_b, hipStream_t stream, int kind, uint8_t *d_qual_a, uint8_t *d_qual_b)
 {
+    if (kind == 2 && (!r->P.rrbs || !r->d_sites || paired)) { g_bsx_err = "RRBS reads need an RRBS reference and a single-end batch"; return BSX_ERR_ARG; }
     // usable fragment starts: positions of forward blocks where a fragment of the maximum span still fits
     const uint32_t span = paired ? 481 : read_len + 1;
     std::vector<uint32_t> gpos; std::vector<u64> prefix(1, 0);
@@ -305,7 +376,9 @@ int bsx_synth_reads_launch(const bsx_ref *r, uint32_t n, uint32_t read_len, int 
     g.refcat = r->d_refcat; g.blk_gpos = d_gpos; g.blk_prefix = d_prefix; g.n_blk = (uint32_t)gpos.size();
     g.bit_nt_packed = r->P.bit_nt[0] | (r->P.bit_nt[1] << 8) | (r->P.bit_nt[2] << 16) | ((uint32_t)r->P.bit_nt[3] << 24);
     g.seed = seed; g.read_len = read_len; g.paired = paired; g.first_unit = first_index;
-    hipLaunchKernelGGL(k_synth_reads, dim3(std::min<uint32_t>((n + 255) / 256, 256 * 16)), dim3(256), 0, stream, g, n, d_seq_a, d_seq_b);
+    g.kind = (uint32_t)kind; g.sites = r->d_sites; g.site_off = r->d_site_off; g.anchor = r->d_anchor; g.n_chr = r->n_chr;
+    g.digest_len = (uint32_t)strlen(r->P.digest_site); g.digest_pos = (uint32_t)r->P.digest_pos;
+    hipLaunchKernelGGL(k_synth_reads, dim3(std::min<uint32_t>((n + 255) / 256, 256 * 16)), dim3(256), 0, stream, g, n, d_seq_a, d_seq_b, d_qual_a, d_qual_b);
     hipError_t e = hipStreamSynchronize(stream);
     (void)hipFree(d_gpos); (void)hipFree(d_prefix);
     HIP_TRY(e);

@@ -160,6 +160,10 @@ int bsx_batch_upload_pe(bsx_batch *b, uint32_t n, const char *seqs_a, const uint
                         const char *seqs_b, const uint64_t *off_b, const char *quals_b, uint32_t first_index);
 /* synthetic bisulfite reads sampled ON the device from the resident reference (bench workload) */
 int bsx_batch_synth_reads(bsx_batch *b, uint32_t n, uint32_t read_len, uint64_t seed, uint32_t first_index);
+/* the same for the other bench workloads: kind 0 plain; 1 trimming workload — qualities with a 3' tail of 10-60 nt
+ * at Q2-Q15, 30 % of the fragments 30-149 nt long so that the reads run into the adapter AGATCGGAAGAGC...; 2 RRBS — single
+ * reads that start at the digestion sites of an RRBS reference, fragments read_len..220 nt */
+int bsx_batch_synth_reads_kind(bsx_batch *b, uint32_t n, uint32_t read_len, uint64_t seed, uint32_t first_index, int kind);
 /* Do_Batch (align.cpp:591-606 / pairs.cpp:192-218): asynchronous launch on the batch's HIP stream */
 int bsx_batch_run(bsx_batch *b);
 /* the same over units [first_unit, first_unit+n_units) of the uploaded batch (ReadInf.index = first_index + unit) */
@@ -175,6 +179,7 @@ int bsx_batch_counters(bsx_batch *b, uint64_t c[BSX_N_COUNTERS]);   /* accumulat
 int bsx_batch_reset_counters(bsx_batch *b);
 /* download the device-resident input reads (for the CPU baseline on device-synthesised input) */
 int bsx_batch_download_reads(bsx_batch *b, int mate, char *seqs, uint64_t *off);
+int bsx_batch_download_quals(bsx_batch *b, int mate, char *quals);   /* device-synthesised qualities (kind 1), same offsets */
 /* test hooks: mode 1 keeps every hit / pair list of every unit (needs max_units small; layout in DESIGN.md);
  * mode 2 records the shader-clock cycles each unit took (diagnostic runs only); 0 switches both off */
 int bsx_batch_set_debug(bsx_batch *b, int mode);

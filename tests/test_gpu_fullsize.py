@@ -137,3 +137,119 @@ def test_two_batches_in_flight(big):
     finally:
         for o in others:
             o.close()
+
+
+# ---- the other BASELINE configurations at the same scale --------------------------------------------------------------
+ADAPTER = "AGATCGGAAGAGCACACGTCTGAACTCCAGTCA"
+OTHER = {
+    # C2: 1x100 WGBS, -v 4; with -n 1 all four strands are searched from one read
+    "c2": dict(kw=dict(s=16, v=4, I=4, S=1, r=1), pe=False, L=100, kind=0, n=131072),
+    "c2_n1": dict(kw=dict(s=16, v=4, I=4, S=1, r=1, n=1), pe=False, L=100, kind=0, n=65536),
+    # C5: 2x144 with 3' adapters and low-quality tails, -A <adapter> -q 20 (variable read lengths after trimming)
+    "c5": dict(kw=dict(s=16, v=6, I=4, m=28, x=500, S=1, r=1, pairend=1, q=20, A=[ADAPTER]), pe=True, L=144, kind=1, n=65536),
+    # C4: RRBS -D C-CGG (seed 12, interval 1 forced), 1x75 reads at digestion sites; site tables + {tag, loc} index of the whole genome
+    "c4": dict(kw=dict(D="C-CGG", S=1, r=1), pe=False, L=75, kind=2, n=65536),
+}
+
+
+@pytest.fixture(scope="module", params=sorted(OTHER))
+def other(request):
+    cfg = OTHER[request.param]
+    ref = B.RefSeq(B.make_params(**cfg["kw"])).synthetic(HG38, seed=38).CreateIndex()
+    al = (B.PairAlign if cfg["pe"] else B.SingleAlign)(ref, cfg["n"])
+    al.synth_reads(cfg["n"], cfg["L"], seed=17, kind=cfg["kind"])
+    al.Do_Batch()
+    res = tuple(x.copy() for x in al.results())
+    cnt = al.counters().copy()
+    yield request.param, cfg, ref, al, res, cnt
+    al.close()
+    ref.close()
+
+
+def test_other_configs_closure_idempotence_partition(other):
+    name, cfg, ref, al, res, cnt = other
+    n = cfg["n"]
+    assert int(cnt[4]) == n
+    assert ref.n_words > 190_000_000 and ref.n_entries > (1_000_000 if name == "c4" else 1_400_000_000)
+    al.reset_counters()
+    al.Do_Batch()
+    res2 = al.results()
+    for a, b in zip(res, res2):
+        assert a.tobytes() == b.tobytes()
+    assert np.array_equal(al.counters()[:7], cnt[:7])
+    al.run_range(n // 2, n // 2, sync=True)
+    al.run_range(0, n // 2, sync=True)
+    for a, b in zip(res, al.results()):
+        assert a.tobytes() == b.tobytes()
+    if cfg["pe"]:
+        out = res[0]
+        placed = (out["unpaired_out"] == 0).mean()
+        assert placed > 0.9, placed            # trimmed pairs still pair up
+        assert len(np.unique(out["a"]["len"])) > 20   # trimming really produced a spread of read lengths
+    else:
+        hits = res[0]
+        assert (hits["n_best"] > 0).mean() > (0.85 if name != "c4" else 0.8)
+
+
+def test_other_configs_sample_equals_oracle(other, oracle):
+    """a sample of units incl. the ones with the most hits, re-aligned by the oracle — WGBS: against the reference + index
+    copied back from HBM; RRBS: against the oracle's OWN packing, site tables and index of the genome text"""
+    name, cfg, ref, al, res, cnt = other
+    kw, n, L = cfg["kw"], cfg["n"], cfg["L"]
+    if name == "c4":
+        parts = []
+        for c, nm in enumerate(ref.names()):
+            parts += [np.frombuffer(f">{nm}\n".encode(), np.uint8), ref.synth_bytes(c), np.frombuffer(b"\n", np.uint8)]
+        text = np.concatenate(parts).tobytes()
+        del parts
+        oref = oracle.OracleRef(oracle.make_params(**kw), fasta_text=text)
+        del text
+        assert sum(len(oref.sites(c)) for c in range(ref.n_chr)) == sum(len(ref.sites(c)) for c in range(ref.n_chr))
+        assert np.array_equal(oref.sites(3), ref.sites(3))
+        assert np.array_equal(oref.rrbs_entries(), ref.index()[2])
+    else:
+        f, c = ref.words()
+        a, s, r = ref.info()
+        off, nf, ent = ref.index()
+        oref = oracle.OracleRef.wrap(oracle.make_params(**kw), f, c, a, s, r, off, nf, ent)
+    b1, o1 = al.download_reads(0)
+    q1 = al.download_quals(0) if cfg["kind"] == 1 else None
+    if cfg["pe"]:
+        b2, o2 = al.download_reads(1)
+        q2 = al.download_quals(1) if cfg["kind"] == 1 else None
+        out, ca, cb, npairs = res
+        load = ca["n_hit"].sum(1).astype(np.int64) + cb["n_chit"].sum(1) + ca["n_chit"].sum(1) + cb["n_hit"].sum(1)
+    else:
+        hits, cc = res
+        load = cc["n_hit"].sum(1).astype(np.int64) + cc["n_chit"].sum(1)
+    sample = np.unique(np.concatenate([np.arange(1000), np.argsort(load)[-40:]]))
+    oa = oracle.OracleAligner(oref, 0)
+    nv = kw.get("v", 2) + 1
+
+    def txt(buf, off_, u):
+        return bytes(buf[int(off_[u]):int(off_[u + 1])]).decode()
+
+    for u in sample:
+        u = int(u)
+        if cfg["pe"]:
+            o = oa.pe(u, txt(b1, o1, u), txt(b2, o2, u), txt(q1, o1, u) if q1 is not None else None, txt(q2, o2, u) if q2 is not None else None)
+            g = out[u]
+            assert (o.a.filtered, o.b.filtered) == (g["a"]["flags"] & 1, g["b"]["flags"] & 1), u
+            assert (o.a.len, o.b.len) == (g["a"]["len"], g["b"]["len"]), u
+            assert o.paired == g["paired"] and list(o.n_pairs)[:2 * nv - 1] == list(npairs[u][:2 * nv - 1]), u
+            assert list(o.a.n_hit)[:nv] == list(ca[u]["n_hit"][:nv]) and list(o.b.n_chit)[:nv] == list(cb[u]["n_chit"][:nv]), u
+            if o.paired and o.tmp == 0:
+                pk = o.pick
+                assert (pk.a.chr, pk.a.loc, pk.b.chr, pk.b.loc, pk.insert, pk.na, pk.nb) == \
+                       (g["a_chr"], g["a_loc"], g["b_chr"], g["b_loc"], g["insert"], g["na"], g["nb"]), u
+        else:
+            o = oa.se(u, txt(b1, o1, u))
+            g = hits[u]
+            assert o.filtered == (g["flags"] & 1) and o.len == g["len"], u
+            if not o.filtered:
+                assert list(o.n_hit)[:nv] == list(cc[u]["n_hit"][:nv]) and list(o.n_chit)[:nv] == list(cc[u]["n_chit"][:nv]), u
+                assert o.n_best == g["n_best"], u
+                if o.n_best > 0:
+                    assert (o.chr, o.loc, o.best_class) == (g["chr"], g["loc"], g["best_class"]), u
+    oa.free()
+    oref.free()
