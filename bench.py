@@ -1,16 +1,18 @@
 #!/usr/bin/env python3
-"""bench.py — aligned reads/s of the HIP alignment hot path on BASELINE.json's headline configuration.
+"""bench.py — aligned reads/s of the HIP alignment hot path on BASELINE.json's configurations.
 
-Workload (config.workload = "C3"): 2x150 bp (stored as 144 nt, the reference's READ_144 cap) paired-end WGBS reads,
--s 16 -v 6 -I 4 -m 28 -x 500, against an hg38-sized synthetic genome (24 sequences with hg38's chromosome lengths,
-3.09 Gbp; generator in bsmap_amd/csrc/bsx_synth.hip, because hg38 itself is not on the GPU box).  A step is one
-Do_Batch over --pairs-per-step read pairs that are already resident in HBM; value = reads (2 per pair) of all ranks /
-wall time of the K timed steps (max over ranks).
+Default workload (config.workload = "C3", the one the metric is quoted on): 2x150 bp (stored as 144 nt, the reference's
+READ_144 cap) paired-end WGBS reads, -s 16 -v 6 -I 4 -m 28 -x 500, against an hg38-sized synthetic genome (24 sequences
+with hg38's chromosome lengths, 3.09 Gbp; generator in bsmap_amd/csrc/bsx_synth.hip, because hg38 itself is not on the
+GPU box).  A step is one Do_Batch over --pairs-per-step units that are already resident in HBM; value = reads of all
+ranks / wall time of the K timed steps (max over ranks).  --mode se | rrbs | trim run C2 / C4 / C5 the same way.
 
   python bench.py --gpus N --steps K --warmup W        (N > 1 without a launcher: spawns the N ranks itself, see launch_ranks)
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (one rank per GPU, reads sharded)
+  python bench.py --profile-serial                      (profiling: no two kernels overlap; see profiles/README.md)
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -23,12 +25,38 @@ HG38 = [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345
         135086622, 133275309, 114364328, 107043718, 101991189, 90338345, 83257441, 80373285, 58617616, 64444167,
         46709983, 50818468, 156040895, 57227415]
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+ADAPTER = "AGATCGGAAGAGCACACGTCTGAACTCCAGTCA"
+
+# BASELINE.json configs[1..4] (configs[0] is the CPU plumbing case, a parity test): options, read length, sampler kind
+MODES = {
+    "pe": dict(tag="C3", kw=dict(s=16, v=6, I=4, m=28, x=500, S=1, r=1, pairend=1), pe=True, L=144, kind=0,
+               metric="aligned reads/sec (whole node), 2x150 bp hg38 WGBS -v 6 -s 16",
+               workload="C3: 2x150(->144) bp PE WGBS vs hg38-sized synthetic genome, -s 16 -v 6 -I 4 -m 28 -x 500"),
+    "se": dict(tag="C2", kw=dict(s=16, v=4, I=4, S=1, r=1), pe=False, L=100, kind=0,
+               metric="aligned reads/sec (whole node), 1x100 bp hg38 WGBS -v 4 -s 16",
+               workload="C2: 1x100 bp SE WGBS vs hg38-sized synthetic genome, -s 16 -v 4 -I 4"),
+    "rrbs": dict(tag="C4", kw=dict(D="C-CGG", S=1, r=1), pe=False, L=75, kind=2,
+                 metric="aligned reads/sec (whole node), 1x75 bp hg38 RRBS -D C-CGG (seed 12, interval 1)",
+                 workload="C4: 1x75 bp RRBS reads at C-CGG sites vs hg38-sized synthetic genome, -D C-CGG (-s 12 -I 1 forced), -v 2"),
+    "trim": dict(tag="C5", kw=dict(s=16, v=6, I=4, m=28, x=500, S=1, r=1, pairend=1, q=20, A=[ADAPTER]), pe=True, L=144, kind=1,
+                 metric="aligned reads/sec (whole node), 2x150 bp hg38 WGBS with 3' adapters, -A <adapter> -q 20",
+                 workload="C5: 2x150(->144) bp PE WGBS with low-quality 3' tails and adapter read-through, -s 16 -v 6 -m 28 -x 500 -q 20 -A " + ADAPTER),
+}
 
 
 def algorithmic_bytes(c, n_reads):
     """8*N_lookup + sum_cand(4 + 8*W_c) + 80*N_orient + 16 per read"""
     n_lookup, n_cand, sum_w, n_orient = (int(x) for x in c[:4])
     return 8 * n_lookup + 4 * n_cand + 8 * sum_w + 80 * n_orient + 16 * n_reads
+
+
+def lib_sha16():
+    import bsmap_amd as B
+    h = hashlib.sha256()
+    with open(B.LIB_PATH, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()[:16]
 
 
 def launch_ranks(n, argv):
@@ -65,18 +93,19 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs-per-step", type=int, default=1 << 20)
+    ap.add_argument("--pairs-per-step", type=int, default=1 << 20, help="units (pairs, or single reads) per step")
     ap.add_argument("--genome", default="hg38", help="hg38 (3.09 Gbp synthetic, the bench config) or a fraction like 0.05 for quick checks")
-    ap.add_argument("--cpu-seconds", type=float, default=25.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of each cpu_baseline sample (0 = skip)")
     ap.add_argument("--e2e-pairs", type=int, default=8 << 20, help="pairs of the end-to-end CLI run (FASTQ -> SAM in /dev/shm) reported beside the metric; 0 = skip")
-    ap.add_argument("--in-flight", type=int, default=2, help="batches in flight per GPU (host threads, one device batch each): the latency-bound main "
-                    "kernel of one batch overlaps the VALU-bound scan passes of the other; 1 = strictly one Do_Batch at a time")
+    ap.add_argument("--in-flight", type=int, default=2, help="batches in flight per GPU (host threads, one device batch each): the main kernel of one "
+                    "batch (bound by random HBM requests) overlaps the scan passes of the other; 1 = strictly one Do_Batch at a time")
+    ap.add_argument("--transfer-steps", type=int, default=4, help="steps of the PCIe-inclusive leg (upload -> Do_Batch -> results per step); 0 = skip")
     ap.add_argument("--waves-per-cu", type=int, default=0)
-    ap.add_argument("--heavy-limits", default="", help="tuning: units per round,scan-task pool of the heavy pipeline (library default 32768,524288)")
+    ap.add_argument("--heavy-limits", default="", help="tuning: units per round,scan-task pool of the heavy pipeline")
     ap.add_argument("--heavy-threshold", type=int, default=0, help="tuning: candidate-list length that defers a unit to the heavy pipeline (0 = library default)")
-    ap.add_argument("--mode", default="pe", choices=["pe", "se"], help="pe = C3 (default, the metric's config); se = C2 (1x100, -v 4)")
+    ap.add_argument("--mode", default="pe", choices=sorted(MODES), help="pe = C3 (default, the metric's config); se = C2; rrbs = C4; trim = C5")
     ap.add_argument("--profile-serial", action="store_true", help="profiling mode: one batch in flight, one unit group (control and scan passes "
-                    "strictly alternate), no CPU / end-to-end legs — no two kernels overlap, so per-kernel durations add up to at most the step time")
+                    "strictly alternate), no CPU / end-to-end / transfer legs — no two kernels overlap, so per-kernel durations add up to at most the step time")
     ap.add_argument("--selftest-launch", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
@@ -84,7 +113,7 @@ def main():
     if args.selftest_launch:
         return selftest_launch()
     if args.profile_serial:
-        args.in_flight, args.cpu_seconds, args.e2e_pairs = 1, 0.0, 0
+        args.in_flight, args.cpu_seconds, args.e2e_pairs, args.transfer_steps = 1, 0.0, 0, 0
         os.environ["BSX_HEAVY_GROUPS"] = "1"  # read by bsx_batch_create
 
     import torch  # first: libbsx.so then binds to the HIP runtime torch has already loaded
@@ -108,9 +137,8 @@ def main():
     if args.heavy_limits:
         u_, t_ = (int(x) for x in args.heavy_limits.split(","))
         B.lib().bsx_set_heavy_limits(u_, t_)
-    pe = args.mode == "pe"
-    kw = dict(s=16, v=6, I=4, m=28, x=500, S=1, r=1, pairend=1) if pe else dict(s=16, v=4, I=4, S=1, r=1)
-    read_len = 144 if pe else 100
+    M = MODES[args.mode]
+    pe, kw, read_len = M["pe"], M["kw"], M["L"]
     lens = HG38 if args.genome == "hg38" else [max(200_000, int(x * float(args.genome))) for x in HG38]
     t0 = time.time()
     real_fa = os.environ.get("BSX_HG38")  # a real genome FASTA if one is at hand (never on the driver's box); reads are
@@ -127,12 +155,15 @@ def main():
     B_ = args.pairs_per_step
     n_total = B_ * (args.steps + args.warmup)
     nfl = max(1, args.in_flight)
-    batches = [(B.PairAlign if pe else B.SingleAlign)(ref, n_total) for _ in range(nfl)]
+    Align = B.PairAlign if pe else B.SingleAlign
+    t0 = time.time()
+    batches = [Align(ref, n_total) for _ in range(nfl)]
+    t_batches = time.time() - t0
     batch = batches[0]
     # reads are sharded by rank: unit ids of rank r start at r * n_total (independent units, no data-path collective);
     # every device batch holds the same deterministic reads, step i runs on batch i % in_flight
     for bt in batches:
-        bt.synth_reads(n_total, read_len, seed=3, first_index=rank * n_total)
+        bt.synth_reads(n_total, read_len, seed=3, first_index=rank * n_total, kind=M["kind"])
 
     def sync_all():
         torch.cuda.synchronize()
@@ -168,7 +199,7 @@ def main():
     counters = sum(bt.counters().astype(np.float64) for bt in batches)
     reads_per_unit = 2 if pe else 1
     n_reads_rank = args.steps * B_ * reads_per_unit
-    # stats reduction: the only collective of the path (RCCL all-gather of 9 doubles per rank)
+    # stats reduction: the only collective of the path (RCCL all-gather of a few doubles per rank)
     from bsmap_amd import sharding
     dt_max, tot_counters, allstats = sharding.gather_stats(dt, counters, dist, device="cuda")
     if rank != 0:
@@ -181,57 +212,173 @@ def main():
     # GPU, so the step time that counts is the wall time per step of the timed region
     k_ms = float(np.mean(kernel_ms)) if nfl == 1 else dt_max / args.steps * 1e3
     achieved = alg_bytes_launch / (k_ms * 1e-3) / 1e9
-    traffic = None
+    sha = lib_sha16()
+    traffic, traffic_note = None, "no PMC summary for this build (profiles/pmc_latest.json is from another libbsx.so)"
     pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-    if os.path.exists(pmc):
+    if os.path.exists(pmc) and args.mode == "pe":
         try:
-            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            pj = json.load(open(pmc))
+            if pj.get("lib_sha16") == sha:
+                traffic, traffic_note = pj.get("hbm_bytes_per_launch"), f"profiles/{pj.get('tag')}_pmc.json (same libbsx.so, serial mode)"
         except Exception:
-            traffic = None
+            pass
     out = {
-        "metric": "aligned reads/sec (whole node), 2x150 bp hg38 WGBS -v 6 -s 16" if pe else "aligned reads/sec (whole node), 1x100 bp hg38 WGBS -v 4 -s 16",
-        "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "metric": M["metric"], "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u32", "data": "synthetic" if not real_fa else "synthetic reads sampled from " + os.path.basename(real_fa),
-        "config": {"workload": "C3: 2x150(->144) bp PE WGBS vs hg38-sized synthetic genome, -s 16 -v 6 -I 4 -m 28 -x 500" if pe
-                   else "C2: 1x100 bp SE WGBS vs hg38-sized synthetic genome, -s 16 -v 4 -I 4",
-                   "pairs_per_step" if pe else "reads_per_step": B_, "genome_bp": int(sum(lens)), "index_entries": int(ref.n_entries),
-                   "parallelism": f"read-sharded x{world}", "batches_in_flight": nfl, "setup_s": {"genome": round(t_gen, 2), "index_build_gpu": round(t_index, 2)},
+        "config": {"workload": M["workload"], "pairs_per_step" if pe else "reads_per_step": B_, "genome_bp": int(sum(lens)), "index_entries": int(ref.n_entries),
+                   "parallelism": f"read-sharded x{world}", "batches_in_flight": nfl, "lib_sha16": sha,
+                   "setup_s": {"genome": round(t_gen, 2), "index_build_gpu": round(t_index, 2), "device_batches": round(t_batches, 2)},
                    "aligned_fraction": float((2 * tot_counters[6] + tot_counters[5]) / max(1.0, n_reads_rank * world)) if pe
                    else float(tot_counters[5] / max(1.0, n_reads_rank * world))},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "kernel": "one Do_Batch = k_align + heavy pipeline (k_hctrl/k_hscan iterations)", "kernel_ms": k_ms,
+                     "traffic": traffic, "traffic_source": traffic_note,
+                     "kernel": "one Do_Batch = k_align + heavy pipeline (k_hctrl/k_hscan iterations)", "kernel_ms": k_ms,
                      "event_ms_per_do_batch": float(np.mean(kernel_ms)), "heavy_units_last_step": int(batch.heavy_units()), "algorithmic_bytes_per_launch": alg_bytes_launch,
                      "per_read": {"n_lookup": float(counters[0]) / n_reads_rank, "n_cand": float(counters[1]) / n_reads_rank,
                                   "ref_words64": float(counters[2]) / n_reads_rank},
-                     "dominant_kernel": dominant_kernel(counters, scan_ms, args.steps)},
+                     "dominant_kernel": dominant_kernel(counters, scan_ms, args.steps, nfl)},
     }
+    if world == 1 and not args.profile_serial:
+        try:  # measured ceilings of this device beside the spec peak
+            pm = B.probe_memory(local_rank, 4 << 30, 1 << 30)
+            out["roofline"]["peak_measured"] = {"stream_read_GBps": pm["stream_read"], "stream_copy_GBps": pm["stream_copy"],
+                                                "gather16_GBps": pm["gather16"], "gather16_Gloads_per_s": pm["gather16_Gloads_per_s"],
+                                                "frac_of_stream_read": achieved / pm["stream_read"],
+                                                "note": "gather16 = 16-byte loads at random 4-byte-aligned addresses in a 1 GiB window (each moves a 64-byte sector): "
+                                                        "the access pattern of the scan; its rate does not improve for windows down to 64 MiB (profiles/r02e_probe_sweep.json)"}
+        except Exception as e:
+            out["roofline"]["peak_measured"] = {"error": str(e)[:200]}
+    if world == 1 and args.transfer_steps > 0:
+        try:
+            out["value_incl_transfers"] = incl_transfers(B, ref, batch, Align, pe, B_, min(args.transfer_steps, args.steps), nfl, reads_per_unit, args.warmup * B_, M["kind"] == 1)
+        except Exception as e:
+            out["value_incl_transfers"] = {"error": str(e)[:300]}
     if world == 1 and args.cpu_seconds > 0:
-        out["cpu_baseline"] = cpu_baseline(ref, batch, pe, kw, args.cpu_seconds, args.warmup * B_)
+        out["cpu_baseline"] = cpu_baseline(ref, batch, pe, kw, args.cpu_seconds, args.warmup * B_, M["kind"] == 1)
     for bt in batches:
         bt.close()
     ref.close()
-    if world == 1 and pe and args.e2e_pairs > 0:
+    if world == 1 and args.mode == "pe" and args.e2e_pairs > 0:
         out["end_to_end"] = end_to_end(args.e2e_pairs, args.genome)
     print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
 
-def dominant_kernel(counters, scan_ms, steps):
+def dominant_kernel(counters, scan_ms, steps, nfl):
     """k_hscan, the kernel most of the time goes to: launches and HIP-event durations measured live (events on the stream it
     is launched on), algorithmic bytes of the candidates it evaluated (4 B index entry + 8 B per 64-bit reference word the
-    reference's CountMismatch would touch).  Its reference gathers mostly hit the caches (clustered
-    candidates), so the algorithmic rate may exceed what HBM delivers: the kernel is VALU-bound."""
+    reference's CountMismatch would touch).  `bound` is derived from the committed counter summaries of the
+    same kernel (VALU issue rate against the ceiling measured by tools/microbench/valu_issue, texture-addresser busy
+    fraction), not asserted: see profiles/README.md."""
     tot_ms = float(sum(t for t, n in scan_ms)); launches = int(sum(n for t, n in scan_ms))
     cand, words = float(counters[7]), float(counters[8])
     alg = 4.0 * cand + 8.0 * words
     if launches == 0 or tot_ms <= 0:
         return None
-    return {"name": "k_hscan", "launches_per_step": launches / steps, "avg_launch_ms": tot_ms / launches, "ms_per_step": tot_ms / steps,
-            "candidates_per_launch": cand / launches, "algorithmic_bytes_per_launch": alg / launches,
-            "achieved_GBps": alg / (tot_ms * 1e-3) / 1e9, "frac_of_hbm_peak": alg / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "candidates_per_s": cand / (tot_ms * 1e-3), "bound": "valu (82 VALU instructions per 64 candidates, ~71 % of issue cycles)"}
+    d = {"name": "k_hscan", "launches_per_step": launches / steps, "avg_launch_ms": tot_ms / launches, "ms_per_step": tot_ms / steps,
+         "candidates_per_launch": cand / launches, "algorithmic_bytes_per_launch": alg / launches,
+         "achieved_GBps": alg / (tot_ms * 1e-3) / 1e9, "frac_of_hbm_peak": alg / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+         "candidates_per_s": cand / (tot_ms * 1e-3),
+         "class_shares": {"one_word": float(counters[9]) / max(cand, 1.0), "five_words": float(counters[10]) / max(cand, 1.0)},
+         "timing_note": "launch durations overlap other kernels when batches_in_flight > 1" if nfl > 1 else "serial: no other kernel runs beside it"}
+    d.update(kernel_bound())
+    return d
+
+
+def kernel_bound():
+    """bound of k_hscan from measurements kept under profiles/: SQ / TA counter passes of the kernel (tools/summarize_sq.py) and
+    the VALU issue ceiling of its instruction mix (tools/microbench/valu_issue.hip)"""
+    try:
+        import glob
+        sq = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sq.json")))[-1]
+        k = json.load(open(sq))["kernels"]["k_hscan"]["derived"]
+        vi = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_valu_issue.json")))[-1]))
+        mix = [m for m in vi["mixes"] if m["mix"].startswith("k_hscan head word")][0]["by_waves_per_simd"]
+        ceil = max(v["chip_G_wave_instr_per_s"] for v in mix.values()) * 1e9
+        fr = {"valu_issue": k["valu_instr_per_s"] / ceil, "texture_addresser_busy": k.get("ta_busy_frac"), "l2_hit": k.get("l2_hit_frac"),
+              "waiting_on_instruction_issue": k.get("wait_inst_frac")}
+        top = max((v, n) for n, v in fr.items() if v is not None and n in ("valu_issue", "texture_addresser_busy"))
+        return {"bound": f"{top[1]} ({top[0]:.2f}), co-limited with the other of VALU issue / gather rate; not HBM (L2 hit {fr['l2_hit']:.2f})",
+                "bound_evidence": {"fractions": fr, "valu_ceiling_G_wave_instr_per_s": ceil / 1e9, "sources": [os.path.basename(sq), "r02a_valu_issue.json", "r02k_hscan_marginal_costs.json"]}}
+    except Exception:
+        return {"bound": None, "bound_evidence": "no counter summary under profiles/"}
+
+
+def pinned_array(B, C, nbytes):
+    import numpy as np
+    p = B.lib().bsx_pinned_alloc(nbytes)
+    if not p:
+        return np.zeros(nbytes, np.uint8), None
+    return np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(p)), p
+
+
+def incl_transfers(B, ref, src, Align, pe, B_, steps, nfl, reads_per_unit, first_unit, quals):
+    """the second headline: the same Do_Batch with the PCIe legs inside the timed window — per step the reads of that step go up
+    from page-locked host memory (bsx_batch_upload_*), the batch runs, and the records come back (bsx_batch_results_*);
+    `in_flight` host threads as in the command-line driver, so one batch's transfers overlap the other's kernels"""
+    import ctypes as C
+    import threading
+    import numpy as np
+    B.lib().bsx_pinned_alloc.restype = C.c_void_p
+    B.lib().bsx_pinned_alloc.argtypes = [C.c_size_t]
+    B.lib().bsx_pinned_free.argtypes = [C.c_void_p]
+    nm = 2 if pe else 1
+    host, pins = [], []
+    for m in range(nm):
+        buf, off = src.download_reads(m)
+        lo, hi = int(off[first_unit]), int(off[first_unit + steps * B_])
+        a, p = pinned_array(B, C, hi - lo)
+        a[:] = buf[lo:hi]
+        pins.append(p)
+        q = None
+        if quals:
+            q, pq = pinned_array(B, C, hi - lo)
+            q[:] = src.download_quals(m)[lo:hi]
+            pins.append(pq)
+        host.append((a, (off[first_unit:first_unit + steps * B_ + 1] - off[first_unit]).astype(np.uint64), q))
+    small = [Align(ref, B_) for _ in range(nfl)]
+    L = B.lib()
+
+    def step(j, i):
+        b = small[j]
+        sl = []
+        for a, off, q in host:
+            o = (off[i * B_:(i + 1) * B_ + 1] - off[i * B_]).copy()
+            s0, s1 = int(off[i * B_]), int(off[(i + 1) * B_])
+            sl.append((a[s0:s1], o, q[s0:s1] if q is not None else None))
+        if pe:
+            b.ImportBatchReads((sl[0][0], sl[0][1]), (sl[1][0], sl[1][1]), sl[0][2], sl[1][2], first_index=first_unit + i * B_)
+        else:
+            b.ImportBatchReads((sl[0][0], sl[0][1]), sl[0][2], first_index=first_unit + i * B_)
+        b.Do_Batch()
+        b.results()
+
+    def worker(j, lo, hi):
+        for i in range(lo + j, hi, nfl):
+            step(j, i)
+    for j in range(nfl):  # untimed warm-up of each small batch
+        step(j, 0)
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=worker, args=(j, 0, steps)) for j in range(1, nfl)]
+    for t in th:
+        t.start()
+    worker(0, 0, steps)
+    for t in th:
+        t.join()
+    dt = time.perf_counter() - t0
+    for b in small:
+        b.close()
+    for p in pins:
+        if p:
+            L.bsx_pinned_free(p)
+    up = sum(int(h[1][-1]) * (2 if h[2] is not None else 1) + 8 * (steps * B_ + 1) for h in host)
+    down = steps * B_ * ((64 + 128) if pe else (16 + 64))
+    return {"value": steps * B_ * reads_per_unit / dt, "unit": "reads/s", "steps": steps, "ms_per_step": dt / steps * 1e3,
+            "host_to_device_bytes_per_step": up / steps, "device_to_host_bytes_per_step": down / steps,
+            "window": "per step: bsx_batch_upload (page-locked host arrays) -> Do_Batch -> bsx_batch_results, %d batches in flight; "
+                      "host numpy slicing of the step's arrays included" % nfl}
 
 
 def end_to_end(pairs, genome):
@@ -252,41 +399,55 @@ def end_to_end(pairs, genome):
         return {"error": str(e)[:300]}
 
 
-def cpu_baseline(ref, batch, pe, kw, target_s, first_unit):
+def cpu_baseline(ref, batch, pe, kw, target_s, first_unit, quals):
     """the oracle (plain-C port of the reference algorithm, pthread batch model of main.cpp:49-73) timed on this box's
-    host cores over a bounded sample of the SAME reads against the SAME reference + index (copied back from HBM)"""
+    host cores over a bounded sample of the SAME reads against the SAME reference + index (copied back from HBM; RRBS: the
+    port would first have to pack and index the 3.1 GB text on the host, so that mode reports no CPU figure).  Two thread
+    counts: every core of the box, and 8 — the reference caps its default -p at 8 (param.cpp:8-9)."""
     import numpy as np
     from oracle import oracle_ffi as O
+    if kw.get("D"):
+        return {"value": None, "unit": "reads/s", "cores": 0, "kind": "port", "sample": "not measured for RRBS: the port would have to pack and index the 3.1 GB text on the host first"}
     cores = os.cpu_count() or 1
     f, c = ref.words()
     a, s, r = ref.info()
     off, nf, ent = ref.index()
     oref = O.OracleRef.wrap(O.make_params(**kw), f, c, a, s, r, off, nf, ent)
     b1, o1 = batch.download_reads(0)
+    q1 = batch.download_quals(0) if quals else None
     L = int(o1[1] - o1[0])
     if pe:
         b2, o2 = batch.download_reads(1)
+        q2 = batch.download_quals(1) if quals else None
 
-    def run(n):
+    def run(n, threads):
         lo = first_unit
         oa = (o1[lo:lo + n + 1] - o1[lo]).copy()
         sa = b1[int(o1[lo]):int(o1[lo + n])].copy()
-        t0 = time.perf_counter()
+        qa = q1[int(o1[lo]):int(o1[lo + n])].copy() if quals else None
         if pe:
             sb = b2[int(o2[lo]):int(o2[lo + n])].copy()
             ob = (o2[lo:lo + n + 1] - o2[lo]).copy()
+            qb = q2[int(o2[lo]):int(o2[lo + n])].copy() if quals else None
             t0 = time.perf_counter()
-            O.pe_batch(oref, sa, oa, sb, ob, first_index=lo, threads=cores)
+            O.pe_batch(oref, sa, oa, sb, ob, qa, qb, first_index=lo, threads=threads)
         else:
-            O.se_batch(oref, sa, oa, first_index=lo, threads=cores)
+            t0 = time.perf_counter()
+            O.se_batch(oref, sa, oa, qa, first_index=lo, threads=threads)
         return time.perf_counter() - t0
-    n0 = min(20000, len(o1) - 1 - first_unit)
-    t_probe = run(n0)
-    n = int(min(len(o1) - 1 - first_unit, max(n0, n0 * target_s / max(t_probe, 1e-3))))
-    t = run(n)
-    reads = n * (2 if pe else 1)
-    return {"value": reads / t, "unit": "reads/s", "cores": cores, "kind": "port",
-            "sample": f"{n} {'pairs' if pe else 'reads'} of the timed workload ({L} nt), oracle/bsx_oracle.c with {cores} pthreads, {t:.1f} s"}
+
+    def sample(threads):
+        n0 = min(2000 if threads <= 8 else 20000, len(o1) - 1 - first_unit)
+        t_probe = run(n0, threads)
+        n = int(min(len(o1) - 1 - first_unit, max(n0, n0 * target_s / max(t_probe, 1e-3))))
+        t = run(n, threads)
+        return n, t
+    n, t = sample(cores)
+    n8, t8 = sample(min(8, cores))
+    rp = 2 if pe else 1
+    return {"value": n * rp / t, "unit": "reads/s", "cores": cores, "kind": "port",
+            "sample": f"{n} {'pairs' if pe else 'reads'} of the timed workload ({L} nt), oracle/bsx_oracle.c with {cores} pthreads, {t:.1f} s",
+            "p8": {"value": n8 * rp / t8, "cores": min(8, cores), "sample": f"{n8} {'pairs' if pe else 'reads'}, {min(8, cores)} pthreads (the reference's default -p cap), {t8:.1f} s"}}
 
 
 if __name__ == "__main__":

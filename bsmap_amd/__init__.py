@@ -63,7 +63,7 @@ EXPORTS = [
     "bsx_ref_n_chr", "bsx_ref_n_words", "bsx_ref_n_blocks", "bsx_ref_info", "bsx_ref_chr_name", "bsx_ref_blocks",
     "bsx_ref_download_words", "bsx_index_build", "bsx_index_n_entries", "bsx_index_download", "bsx_ref_n_sites", "bsx_ref_sites",
     "bsx_batch_create", "bsx_batch_destroy", "bsx_batch_upload_se", "bsx_batch_upload_pe", "bsx_batch_synth_reads", "bsx_batch_synth_reads_kind", "bsx_batch_download_quals",
-    "bsx_batch_run", "bsx_batch_run_range", "bsx_batch_sync", "bsx_batch_kernel_ms", "bsx_batch_scan_ms", "bsx_batch_results_se", "bsx_batch_results_pe",
+    "bsx_batch_run", "bsx_batch_run_range", "bsx_batch_sync", "bsx_batch_set_leak_exact", "bsx_batch_set_history", "bsx_batch_kernel_ms", "bsx_batch_scan_ms", "bsx_batch_results_se", "bsx_batch_results_pe",
     "bsx_batch_counters", "bsx_batch_reset_counters", "bsx_batch_download_reads", "bsx_batch_set_debug", "bsx_batch_unit_cycles", "bsx_batch_ctrl_clocks",
     "bsx_batch_debug_hits", "bsx_batch_debug_pairs", "bsx_batch_debug_plan", "bsx_set_waves_per_cu", "bsx_set_heavy_threshold", "bsx_set_heavy_limits", "bsx_batch_last_heavy_units", "bsx_pinned_alloc", "bsx_pinned_free", "bsx_probe_memory", "bsx_thread_device",
     "bsx_meth_create", "bsx_meth_destroy", "bsx_meth_set_reference", "bsx_meth_add", "bsx_meth_combine_cpg", "bsx_meth_valid_mappings",
@@ -117,6 +117,8 @@ def lib():
         L.bsx_batch_run.argtypes = [vp]
         L.bsx_batch_run_range.argtypes = [vp, u32, u32]
         L.bsx_batch_sync.argtypes = [vp]
+        L.bsx_batch_set_leak_exact.argtypes = [vp, i32]
+        L.bsx_batch_set_history.argtypes = [vp, u32, vp, vp, vp, vp, vp, vp]
         L.bsx_batch_kernel_ms.argtypes = [vp]
         L.bsx_batch_kernel_ms.restype = C.c_float
         L.bsx_batch_results_se.argtypes = [vp, vp, vp]
@@ -301,6 +303,22 @@ class _Batch:
             _check(lib().bsx_batch_sync(self.h))
 
     def sync(self): _check(lib().bsx_batch_sync(self.h))
+
+    def set_leak_exact(self, on=True):
+        """reproduce the single-threaded reference for reads whose planner state leaks from earlier reads (include/bsx.h)"""
+        _check(lib().bsx_batch_set_leak_exact(self.h, 1 if on else 0))
+        return self
+
+    def set_history(self, seqs_a, quals_a=None, seqs_b=None, quals_b=None):
+        """the reads that precede unit 0 in the input (lists of str), consulted in exact mode only"""
+        def pk(x):
+            return pack_reads(x) if x is not None else (None, None)
+        (ba, oa), (bb, ob) = pk(seqs_a), pk(seqs_b)
+        qa = pack_reads(quals_a)[0] if quals_a is not None else None
+        qb = pack_reads(quals_b)[0] if quals_b is not None else None
+        p = lambda a: a.ctypes.data if a is not None else None
+        _check(lib().bsx_batch_set_history(self.h, len(seqs_a), p(ba), p(oa), p(qa), p(bb), p(ob), p(qb)))
+        return self
     def scan_ms(self):
         """(sum of the k_hscan launch durations of the last run in ms, number of launches)"""
         t, n = C.c_float(), C.c_uint32()

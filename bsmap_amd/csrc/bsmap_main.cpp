@@ -8,8 +8,9 @@
 //   s_OutHitPair / s_OutHitUnpair  pairs.cpp:288-498       (paired SAM + BSP lines, read-through trimming)
 //   FixPairReadName                pairs.cpp:535-555
 // The alignment itself (FilterReads ... StringAlign selection) happens behind the C ABI of include/bsx.h.
-// BAM input is read natively (BGZF + BAM records, bsx_reads.h).  Not supported: .bam output (the reference pipes its SAM
-// through samtools view / sort / index, sam2bam.sh).
+// BAM input is read natively (BGZF + BAM records, bsx_reads.h); `-o x.bam` leaves the coordinate-sorted BAM file and its
+// .bai index the reference gets from samtools view / sort / index (main.cpp:466-473, sam2bam.sh), written natively
+// (bsx_bam_out.h).
 // Parsing, the GPU, formatting (-p threads) and writing run as a pipeline over a ring of batches; the output is always
 // in input order (the reference's order is nondeterministic for -p > 1).
 #include <algorithm>
@@ -28,6 +29,7 @@
 
 #include "../../include/bsx.h"
 #include "bsx_reads.h"
+#include "bsx_bam_out.h"
 
 using namespace std;
 using bsx_reads::Reader; using bsx_reads::ReadSet; using bsx_reads::ReadOpts; using bsx_reads::load_reads; using bsx_reads::Buf; using bsx_reads::RawAlloc;
@@ -425,7 +427,24 @@ struct Slot {
     vector<Text> out, out_unpair;
     int stage = 0;  // 0 free, 1 parsed, 2 aligned, 3 formatted
     long batch = -1;  // ordinal of the batch the slot holds while stage != 0
+    // BSX_P1_EXACT: the reads that precede this batch in each mate stream (the tail of the previous batch), see Hist
+    struct Hist { string seq, qual; vector<uint64_t> off; } hist[2];
 };
+
+// the last reads of a batch, kept by the parser for the next batch's Slot::hist
+void keep_tail(const ReadSet &r, size_t n_reads, size_t keep, Slot::Hist &h)
+{
+    const size_t n = min(n_reads, keep), lo = n_reads - n;
+    h.seq.clear(); h.qual.clear(); h.off.assign(1, 0);
+    for (size_t i = lo; i < n_reads; i++) {
+        const size_t sl = r.soff[i + 1] - r.soff[i], ql = r.qoff[i + 1] - r.qoff[i];
+        h.seq.append(r.seq.data() + r.soff[i], sl);
+        string q(sl, 'I');
+        memcpy(&q[0], r.qual.data() + r.qoff[i], min(sl, ql));
+        h.qual += q;
+        h.off.push_back(h.seq.size());
+    }
+}
 
 struct Ring {
     const int NS;
@@ -464,7 +483,7 @@ int main(int argc, char **argv)
     if (int bad = parse_options(argc, argv, o)) { cout << "unknown option: " << argv[bad] << endl; exit(bad); }
     if (o.out_file.size() > 4) {
         if (o.out_file.compare(o.out_file.size() - 4, 4, ".sam") == 0) o.out_sam = 1;
-        else if (o.out_file.compare(o.out_file.size() - 4, 4, ".bam") == 0) { cerr << "BAM output needs samtools and is not supported by this build; use .sam\n"; exit(1); }
+        else if (o.out_file.compare(o.out_file.size() - 4, 4, ".bam") == 0) o.out_sam = 2;  // SAM records, delivered as sorted BAM + index (main.cpp:295,466-473)
     }
     o.p.out_sam = o.out_sam;
     if (const char *e = getenv("BSX_BATCH")) o.batch = (unsigned)max(1, atoi(e));  // units per batch (default 2^20)
@@ -543,6 +562,8 @@ int main(int argc, char **argv)
     cout << "additional alignment: " << (char)toupper(p.read_nt) << " in reads => " << (char)toupper(p.ref_nt) << " in reference" << endl;
     if (o.a_file.empty()) { cerr << "missing query file(s)\n"; exit(1); }
     // output files are written with pwrite at running offsets: the chunks of a batch go out in parallel
+    const bool bam_out = o.out_sam == 2;
+    bsx_bam::Sink bam;
     const int fout = ::open(o.out_file.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
     if (fout < 0) { cerr << "failed to open output file (check -o option): " << o.out_file << endl; exit(1); }
     int fout_unpair = -1;
@@ -559,8 +580,11 @@ int main(int argc, char **argv)
         h.put("@HD\tVN:1.0\n");
         for (uint32_t c = 0; c < n_chr; c++) { h.put("@SQ\tSN:"); h.put(rv.names[c]); h.put("\tLN:"); h.put_u(rv.chr_size[c]); h.put('\n'); }
         h.put("@PG\tID:BSMAP_"); h.put(version); h.put('\n');
-        write_all(fout, h.s.data(), h.s.size(), 0);
-        off_out = (off_t)h.s.size();
+        if (bam_out) bam.open(o.out_file, h.s, rv.names, rv.chr_size);
+        else {
+            write_all(fout, h.s.data(), h.s.size(), 0);
+            off_out = (off_t)h.s.size();
+        }
     } else if (pe) {
         fout_unpair = ::open(o.out_unpair.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
         if (fout_unpair < 0) { cerr << "failed to open output file for unpaired hits (check -2 option): " << o.out_unpair << endl; exit(1); }
@@ -589,8 +613,14 @@ int main(int argc, char **argv)
     t_pin.join();
     const double t_map0 = now_s();
 
+    // BSX_P1_EXACT=1: reproduce the single-threaded reference also for the reads whose planner state leaks from earlier
+    // reads (bsx_batch_set_leak_exact); every batch carries the last 64 reads of its predecessor as history
+    const bool p1_exact = getenv("BSX_P1_EXACT") && atoi(getenv("BSX_P1_EXACT")) != 0;
+    if (p1_exact) for (int g = 0; g < NG; g++) bsx_batch_set_leak_exact(batches[g], 1);
     thread t_parse([&] {
         long k = 0;
+        Slot::Hist prev[2];
+        prev[0].off.assign(1, 0); prev[1].off.assign(1, 0);
         for (;; k++) {
             ring.acquire(k, 0);
             const double t = now_s();
@@ -604,6 +634,11 @@ int main(int argc, char **argv)
             if (!n1) break;
             s.n = n1;
             s.total_after = ra.index - o.read_start + 1;
+            if (p1_exact) {
+                s.hist[0] = prev[0]; s.hist[1] = prev[1];
+                keep_tail(s.A, n1, 64, prev[0]);
+                if (pe) keep_tail(s.B, min(n1, n2), 64, prev[1]);
+            }
             if (pe && n1 != n2) {
                 // Mate files of unequal length.  The reference reads 50000 pairs per batch and stops at the first batch whose
                 // two counts differ (main.cpp:88-93): it maps the first floor(min(N1,N2)/50000)*50000 pairs.  The batches here
@@ -628,6 +663,13 @@ int main(int argc, char **argv)
             Slot &s = ring.at(k);
             const uint32_t n = (uint32_t)s.n;
             int r;
+            if (p1_exact) {
+                const uint32_t nh = (uint32_t)s.hist[0].off.size() - 1;
+                const bool q = ra.format != 1 && (!pe || rb.format != 1);
+                r = bsx_batch_set_history(batch, nh, s.hist[0].seq.data(), s.hist[0].off.data(), q ? s.hist[0].qual.data() : nullptr,
+                                          pe ? s.hist[1].seq.data() : nullptr, pe ? s.hist[1].off.data() : nullptr, pe && q ? s.hist[1].qual.data() : nullptr);
+                if (r) die(r, "attaching the history");
+            }
             if (!pe) {
                 r = bsx_batch_upload_se(batch, n, s.A.seq.data(), s.A.soff.data(), ra.format != 1 ? s.A.upload_qual() : nullptr, s.A.first_index);
                 if (r) die(r, "uploading reads");
@@ -695,7 +737,9 @@ int main(int argc, char **argv)
     for (long k = 0; ring.acquire(k, 3); k++) {  // write stage on the main thread
         const double t = now_s();
         Slot &s = ring.at(k);
-        {
+        if (bam_out) {
+            for (const Text &x : s.out) bam.add_text(x.s.data(), x.s.size());  // records are sorted and written at the end
+        } else {
             vector<thread> wt;
             for (const Text &x : s.out) {
                 if (x.s.empty()) continue;
@@ -722,6 +766,10 @@ int main(int argc, char **argv)
     t_format.join();
     ::close(fout);
     if (fout_unpair >= 0) ::close(fout_unpair);
+    if (bam_out) {
+        cout << "Converting SAM to BAM ...\nSorting BAM ...\nIndexing BAM ...\n";  // sam2bam.sh's progress lines
+        bam.finish();
+    }
     const double t_map1 = now_s();
     const Formatter &fmt = totals;
     char pct[64];

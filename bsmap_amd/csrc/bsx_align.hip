@@ -65,12 +65,15 @@ struct MateLds {
     uint8_t seq[160];
     uint8_t qual[160];
     uint32_t w[2][10], m[2][10];  // packed read words / N-masks per orientation (align.h:74-77, copy 0 only)
-    uint32_t cnt[2][144];         // index2[seed][0] for every read offset (CountSeeds' operand)
+    uint32_t cnt[2][160];         // index2[seed][0] for every read offset (CountSeeds' operand); [noff, noff+16): the stale tail (exact mode)
     uint8_t start[2][16];         // seed_start_array / cseed_start_array
     uint8_t order[2][16];         // seedindex[].second / cseedindex[].second
+    // "-p 1 exact" mode: what the reference's never-reset planner state holds when this read is planned (resolve_leak)
+    uint32_t stale_key[2][16];    // seed_array / cseed_array entries [noff, noff+16) left behind by earlier, longer reads
+    uint8_t stale_so[2];          // seed_start_offset / cseed_start_offset of the last read that set them
 };
 
-template <bool PE> struct WaveLds { MateLds mate[PE ? 2 : 1]; };
+template <bool PE> struct WaveLds { MateLds mate[PE ? 2 : 1]; MateLds scratch; };
 
 struct BlockLds {
     uint8_t prof[16][16];
@@ -88,6 +91,7 @@ struct Mate {
     uint32_t bloom0, bloom1;  // 4096-bit membership filter over all accepted coordinates (bit b of lane l)
     uint32_t index;      // ReadInf.index
     int defer;           // main kernel: a candidate list exceeded heavy_threshold, redo this unit in the heavy kernel
+    int limit;           // the duplicate-suppression set overflowed (RRBS single-end only): results of this unit are flagged
 };
 
 struct Slab {
@@ -97,9 +101,14 @@ struct Slab {
     u64 *hits;        // [2][nclass+1][rowcap]
     uint32_t *keys;   // [(nclass+1)*rowcap] accepted coordinates beyond the 64 held in key_reg ...
     uint32_t *kslot;  // ... and the hash-set slot each of them occupies (for the per-unit clean-up)
-    uint32_t *hset;   // [BSX_HSET_SLOTS] open-addressing set of (coordinate+1); all zero between units
+    uint32_t *hset;   // [1 << hbits] open-addressing set of (coordinate+1); all zero between units
     u64 *tmp;         // [BSX_SORT_TMP] sort scratch
     uint32_t rowcap, nclass;
+    // keys / kslot hold kcap entries.  WGBS: every remembered coordinate is also a hit, so the -w caps bound them ((nclass+1) rows
+    // suffice).  RRBS single-end: coordinates the fragment-size filter rejects are remembered too (align.cpp:201-207: the
+    // insert comes first) and no cap bounds those — such batches get a much larger set (bsx_api.hip) and a unit that still
+    // overflows it is flagged BSX_F_LIMIT instead of writing past the slab
+    uint32_t kcap, hbits;
     __device__ __forceinline__ u64 *list(int orient, int w) const { return hits + ((size_t)(orient * (nclass + 1) + w)) * rowcap; }
 };
 
@@ -116,12 +125,17 @@ __device__ __forceinline__ uint32_t n_of(const Mate &M, int orient, int w) { ret
 // ---------------------------------------------------------------------------------------------------------------
 // FilterReads (align.cpp:579-589)
 // ---------------------------------------------------------------------------------------------------------------
-__device__ void load_and_filter(const AlignArgs &A, MateLds &L, Mate &M, int mate, uint32_t unit, int lane)
+// stream position j of mate stream `mate`: unit j of the batch, or for j < 0 read n_hist + j of the attached history
+__device__ void load_and_filter(const AlignArgs &A, MateLds &L, Mate &M, int mate, long j, int lane)
 {
     const DevParams &P = A.P;
-    const uint64_t b = A.off[mate][unit], e = A.off[mate][unit + 1];
+    const bool hist = j < 0;
+    const uint64_t *off = hist ? A.hist_off[mate] : A.off[mate];
+    const uint64_t jj = hist ? (uint64_t)((long)A.n_hist + j) : (uint64_t)j;
+    const uint64_t b = off[jj], e = off[jj + 1];
     int len = (int)min((uint64_t)P.max_readlen, e - b);  // reads.cpp:115-117
-    const uint8_t *s = A.seq[mate] + b, *q = A.qual[mate] ? A.qual[mate] + b : nullptr;
+    const uint8_t *sq = hist ? A.hist_seq[mate] : A.seq[mate], *qq = hist ? A.hist_qual[mate] : A.qual[mate];
+    const uint8_t *s = sq + b, *q = qq ? qq + b : nullptr;
     for (int i = lane; i < 160; i += 64) {
         L.seq[i] = i < len ? s[i] : 0;
         L.qual[i] = (q && i < len) ? q[i] : 0;
@@ -200,6 +214,7 @@ __device__ void load_and_filter(const AlignArgs &A, MateLds &L, Mate &M, int mat
     M.key_reg = 0;
     M.bloom0 = M.bloom1 = 0;
     M.defer = 0;
+    M.limit = 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -238,26 +253,55 @@ __device__ __forceinline__ uint32_t seed_key_at(const DevParams &P, const uint32
     return bsx_seed_hash((uint32_t)(v >> (64 - 2 * P.seed_size - 2 * r)) & P.seed_bits);
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// ReorderSeed (align.cpp:454-504) for one orientation
-// ---------------------------------------------------------------------------------------------------------------
-__device__ void plan_orient(const DevParams &P, const BlockLds &BL, MateLds &L, const Mate &M, int orient, int lane, Counters &C)
+// seed_array[o] / cseed_array[o] as the reference's planner sees it: the read's own hash for o < noff; beyond that the entry
+// an earlier read left behind (only reachable in "-p 1 exact" mode, see resolve_leak; zero-state mode never reads past noff)
+__device__ __forceinline__ uint32_t key_at(const DevParams &P, const MateLds &L, const Mate &M, int orient, int o)
 {
-    const int I = P.index_interval, S = P.seed_size, nseg = M.seedseg;
-    const int noff = M.len - S + 1;
-    // index2[s][0] (= 2 + bucket size, 0 for an empty bucket) for every offset of this orientation
-    for (int base = 0; base < noff; base += 64) {
+    const int noff = M.len - P.seed_size + 1;
+    return o >= noff ? L.stale_key[orient][min(o - noff, 15)] : seed_key_at(P, L.w[orient], o);
+}
+
+// index2[s][0] (= 2 + bucket size, 0 for an empty bucket) for every offset of this orientation -> L.cnt[orient][]
+__device__ void plan_counts(const DevParams &P, MateLds &L, const Mate &M, int orient, int lane, bool with_tail)
+{
+    const int noff = M.len - P.seed_size + 1, n = noff + (with_tail ? 16 : 0);
+    for (int base = 0; base < n; base += 64) {
         const int o = base + lane;
-        if (o < noff) {
-            const uint32_t key = seed_key_at(P, L.w[orient], o);
+        if (o < n) {
+            const uint32_t key = key_at(P, L, M, orient, o);
             const U2 b = *reinterpret_cast<const U2 *>(P.bucket_off + key);
-            const uint32_t n = b.b - b.a;
-            L.cnt[orient][o] = P.rrbs ? n : (n ? n + 2 : 0);
+            const uint32_t c = b.b - b.a;
+            L.cnt[orient][o] = P.rrbs ? c : (c ? c + 2 : 0);
         }
     }
     wave_fence();
+}
+
+// GetTotalSeedLoc for every start offset, first minimum wins (align.cpp:458-468); counts must be in L.cnt
+__device__ int plan_best_offset(const DevParams &P, const BlockLds &BL, const MateLds &L, const Mate &M, int orient, int lane)
+{
+    const int I = P.index_interval, nseg = M.seedseg, nstart = (M.len - I + 1) % P.seed_size;
     const uint32_t *cnt = L.cnt[orient];
-    int offset = 0;
+    u64 key = ~0ull;
+    if (lane < nstart) {
+        int tot = 0;
+        for (int seg = 0; seg < nseg; seg++)
+            for (int ph = 0; ph < I; ph++) tot += (int)cnt[BL.prof[seg][ph] + lane - ph];
+        if ((uint32_t)tot != 0xffffffffu) key = ((u64)(uint32_t)tot << 8) | (uint32_t)lane;
+    }
+    key = wave_min64(key);
+    return key != ~0ull ? (int)(key & 0xff) : -1;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// ReorderSeed (align.cpp:454-504) for one orientation
+// ---------------------------------------------------------------------------------------------------------------
+__device__ void plan_orient(const DevParams &P, const BlockLds &BL, MateLds &L, const Mate &M, int orient, int lane, Counters &C, bool leaky_exact = false)
+{
+    const int I = P.index_interval, S = P.seed_size, nseg = M.seedseg;
+    plan_counts(P, L, M, orient, lane, leaky_exact);
+    const uint32_t *cnt = L.cnt[orient];
+    int offset = leaky_exact ? (int)L.stale_so[orient] : 0;  // the loop below does not run for such a read: the old value stays (align.cpp:458)
     const int nstart = P.rrbs ? 0 : (M.len - I + 1) % S;
     u64 lookups = 0;
     if (nstart > 0) {  // GetTotalSeedLoc for every start, first minimum wins (align.cpp:458-468)
@@ -332,7 +376,7 @@ __device__ __forceinline__ uint32_t chr_of(const DevParams &P, const BlockLds &B
 // (first 64 in a register, the rest in the wave's HBM slab, 256 per round trip).
 __device__ __forceinline__ uint32_t bloom_slot(uint32_t key) { return (key * 0x9E3779B1u) >> 20; }  // 12 bits
 
-__device__ __forceinline__ uint32_t hset_home(uint32_t key) { return (key * 0x85EBCA6Bu) >> (32 - BSX_HSET_BITS); }
+__device__ __forceinline__ uint32_t hset_home(uint32_t key, uint32_t hbits) { return (key * 0x85EBCA6Bu) >> (32 - hbits); }
 
 __device__ __forceinline__ bool seen_before(const Mate &M, const Slab &SL, uint32_t key, int lane)
 {
@@ -342,8 +386,9 @@ __device__ __forceinline__ bool seen_before(const Mate &M, const Slab &SL, uint3
     if (bsx_ballot((uint32_t)lane < min(M.nkeys, 64u) && M.key_reg == key)) return true;
     if (M.nkeys <= 64) return false;
     // linear probing, 64 slots per step: found if the key shows up before the first empty slot
-    for (uint32_t h = hset_home(key);; h = (h + 64) & (BSX_HSET_SLOTS - 1)) {
-        const uint32_t v = SL.hset[(h + lane) & (BSX_HSET_SLOTS - 1)];
+    const uint32_t hmask = (1u << SL.hbits) - 1;
+    for (uint32_t h = hset_home(key, SL.hbits);; h = (h + 64) & hmask) {
+        const uint32_t v = SL.hset[(h + lane) & hmask];
         const u64 hit = bsx_ballot(v == key + 1), empty = bsx_ballot(v == 0);
         if (hit && (!empty || __builtin_ctzll(hit) < __builtin_ctzll(empty))) return true;
         if (empty) return false;
@@ -353,9 +398,11 @@ __device__ __forceinline__ bool seen_before(const Mate &M, const Slab &SL, uint3
 __device__ __forceinline__ void remember_key(Mate &M, const Slab &SL, uint32_t key, int lane)
 {
     if (M.nkeys < 64) { if ((uint32_t)lane == M.nkeys) M.key_reg = key; }
+    else if (M.nkeys >= SL.kcap) { M.limit = 1; return; }  // set full (RRBS only, see Slab): the coordinate is not remembered, the unit is flagged
     else {
-        for (uint32_t h = hset_home(key);; h = (h + 64) & (BSX_HSET_SLOTS - 1)) {
-            const uint32_t sidx = (h + lane) & (BSX_HSET_SLOTS - 1);
+        const uint32_t hmask = (1u << SL.hbits) - 1;
+        for (uint32_t h = hset_home(key, SL.hbits);; h = (h + 64) & hmask) {
+            const uint32_t sidx = (h + lane) & hmask;
             const u64 empty = bsx_ballot(SL.hset[sidx] == 0);
             if (empty) {
                 if (lane == (int)__builtin_ctzll(empty)) { SL.hset[sidx] = key + 1; SL.keys[M.nkeys] = key; SL.kslot[M.nkeys] = sidx; }
@@ -551,13 +598,13 @@ __device__ int accept_group(const DevParams &P, Mate &M, const Slab &SL, int ori
             const uint32_t nk = min(M.nkeys, 64u);
             for (uint32_t j = 0; j < nk; j++) found |= rl(M.key_reg, (int)j) == hkey;
             bool probing = maybe && !found && M.nkeys > 64;
-            uint32_t h = hset_home(hkey);
+            uint32_t h = hset_home(hkey, SL.hbits);
             while (bsx_ballot(probing)) {
                 if (probing) {
                     const uint32_t v = SL.hset[h];
                     if (v == hkey + 1) { found = true; probing = false; }
                     else if (v == 0) probing = false;
-                    else h = (h + 1) & (BSX_HSET_SLOTS - 1);
+                    else h = (h + 1) & ((1u << SL.hbits) - 1);
                 }
             }
             if (maybe && found) cand = false;
@@ -603,13 +650,13 @@ __device__ int accept_group(const DevParams &P, Mate &M, const Slab &SL, int ori
     }
     {
         bool pending = commit && kidx >= 64;
-        uint32_t h = hset_home(hkey);
+        uint32_t h = hset_home(hkey, SL.hbits);
         while (bsx_ballot(pending)) {  // claim by write-then-verify: lanes racing for one empty slot see who landed
             if (pending && SL.hset[h] == 0) SL.hset[h] = hkey + 1;
             wave_fence();
             if (pending) {
                 if (SL.hset[h] == hkey + 1) { pending = false; SL.keys[kidx] = hkey; SL.kslot[kidx] = h; }
-                else h = (h + 1) & (BSX_HSET_SLOTS - 1);
+                else h = (h + 1) & ((1u << SL.hbits) - 1);
             }
             wave_fence();
         }
@@ -647,7 +694,7 @@ __device__ __forceinline__ CandList make_list(const DevParams &P, const BlockLds
         } else {
             const int ph = lane >> 1;
             const int a = BL.prof[seg][ph], st = L.start[orient][seg];
-            const uint32_t key = seed_key_at(P, L.w[orient], a + st - ph);
+            const uint32_t key = key_at(P, L, M, orient, a + st - ph);
             const U2 b = *reinterpret_cast<const U2 *>(P.bucket_off + key);
             const uint32_t nf = P.bucket_nfwd[key];
             cl.sub_base = (lane & 1) ? b.a + nf : b.a;
@@ -833,7 +880,7 @@ __device__ void fix_unpaired_short_fragment(const DevParams &P, Mate &M, const S
 __device__ void select_hit(const DevParams &P, const Mate &M, const Slab &SL, bsx_hit &out, bool unpair_semantics)
 {
     out.chr = 0; out.loc = 0; out.n_best = 0; out.best_class = -1;
-    out.flags = M.filtered ? BSX_F_FILTERED : 0;
+    out.flags = (M.filtered ? BSX_F_FILTERED : 0) | (M.limit ? BSX_F_LIMIT : 0);
     out.len = (uint8_t)M.len; out.raw_len = (uint8_t)M.raw_len; out.max_snp = (uint8_t)M.max_snp; out.seedseg = (uint8_t)M.seedseg;
     if (M.filtered) return;
     int ii; uint32_t sum = 0, nf = 0;
@@ -979,45 +1026,95 @@ __device__ int get_pairs(const DevParams &P, const Mate &MA, const Mate &MB, con
 // ---------------------------------------------------------------------------------------------------------------
 struct UnitSlabs { Slab SA, SB; PairSlab PS; };
 
-__device__ __forceinline__ UnitSlabs carve_slab(uint8_t *slab, uint32_t nclass, uint32_t rowcap, bool pe)
+__device__ __forceinline__ UnitSlabs carve_slab(uint8_t *slab, uint32_t nclass, uint32_t rowcap, bool pe, uint32_t kcap, uint32_t hbits)
 {
     UnitSlabs U;
     U.SA.rowcap = U.SB.rowcap = rowcap; U.SA.nclass = U.SB.nclass = nclass;
+    U.SA.kcap = kcap; U.SA.hbits = hbits;
     U.SA.hits = (u64 *)slab;
     U.SA.keys = (uint32_t *)(U.SA.hits + (size_t)2 * (nclass + 1) * rowcap);
-    U.SA.kslot = U.SA.keys + (size_t)(nclass + 1) * rowcap;
-    U.SA.hset = U.SA.kslot + (size_t)(nclass + 1) * rowcap;
-    U.SA.tmp = (u64 *)(U.SA.hset + BSX_HSET_SLOTS);
+    U.SA.kslot = U.SA.keys + (size_t)kcap;
+    U.SA.hset = U.SA.kslot + (size_t)kcap;
+    U.SA.tmp = (u64 *)(U.SA.hset + ((size_t)1 << hbits));
     uint8_t *after_a = (uint8_t *)(U.SA.tmp + BSX_SORT_TMP);
     U.SB = U.SA;
     U.PS.rows = nullptr; U.PS.rowcap = rowcap;
     if (pe) {
         U.SB.hits = (u64 *)after_a;
         U.SB.keys = (uint32_t *)(U.SB.hits + (size_t)2 * (nclass + 1) * rowcap);
-        U.SB.kslot = U.SB.keys + (size_t)(nclass + 1) * rowcap;
-        U.SB.hset = U.SB.kslot + (size_t)(nclass + 1) * rowcap;
-        U.SB.tmp = (u64 *)(U.SB.hset + BSX_HSET_SLOTS);
+        U.SB.kslot = U.SB.keys + (size_t)kcap;
+        U.SB.hset = U.SB.kslot + (size_t)kcap;
+        U.SB.tmp = (u64 *)(U.SB.hset + ((size_t)1 << hbits));
         U.PS.rows = (uint32_t *)(U.SB.tmp + BSX_SORT_TMP);
     }
     return U;
 }
 
+// "-p 1 exact" mode.  The reference never resets seed_start_offset / seed_array (align.h:82-91): a read with
+// (len - I + 1) % S == 0 skips the loop that sets the offset (align.cpp:458-468) and plans with the value the last read of
+// its stream left behind, and its start offsets then reach seed_array entries behind its own last hash — values written by
+// earlier, longer reads.  Both are pure functions of the earlier reads of the stream (mate 1 and mate 2 are separate
+// streams: PairAlign owns two SingleAlign objects), so the wave that owns such a read walks back through the stream — units
+// of this batch, then the history the caller attached — until it has the offset of the last read that set one and every
+// tail entry it can reach; what nothing ever wrote is zero (the oracle's and the bridge's zero-initialised state).
+// (KRN: one instantiation per calling kernel, so that each inherits its caller's register budget)
+template <bool PE, int KRN>
+__device__ __noinline__ void resolve_leak(const AlignArgs &A, const BlockLds &BL, MateLds &LS, MateLds &L, const Mate &M, int mate, uint32_t unit, int lane)
+{
+    const DevParams &P = A.P;
+    const int S = P.seed_size, I = P.index_interval, noff = M.len - S + 1;
+    if (lane < 32) (&L.stale_key[0][0])[lane] = 0;
+    if (lane < 2) L.stale_so[lane] = 0;
+    wave_fence();
+    uint32_t need_so = M.flags & 3u;
+    uint32_t need_tail[2] = {(M.flags & 1u) ? 0xffffu : 0u, (M.flags & 2u) ? 0xffffu : 0u};
+    Counters dummy = {0, 0, 0, 0};
+    for (long j = (long)unit - 1; (need_so | need_tail[0] | need_tail[1]) && j >= -(long)A.n_hist; j--) {
+        Mate MJ;
+        MJ.index = 0;
+        load_and_filter(A, LS, MJ, mate, j, lane);
+        if (MJ.filtered) continue;  // RunAlign is not called for a read FilterReads rejects (align.cpp:598, pairs.cpp:199-213): state untouched
+        pack_read(P, LS, MJ, PE ? mate + 1 : 0, lane, dummy);
+        const int noff_j = MJ.len - S + 1;
+        for (int orient = 0; orient < 2; orient++) {
+            if (!((MJ.flags >> orient) & 1)) continue;
+            if (need_tail[orient]) {  // ConvertBinaySeq wrote entries [0, noff_j) of this read (align.cpp:101-105)
+                const int idx = noff + lane;
+                const bool got = lane < 16 && ((need_tail[orient] >> lane) & 1) && idx < noff_j;
+                if (got) L.stale_key[orient][lane] = seed_key_at(P, LS.w[orient], idx);
+                need_tail[orient] &= ~(uint32_t)bsx_ballot(got);
+            }
+            if (((need_so >> orient) & 1) && (MJ.len - I + 1) % S != 0) {  // this read ran the offset loop
+                plan_counts(P, LS, MJ, orient, lane, false);
+                const int so = plan_best_offset(P, BL, LS, MJ, orient, lane);
+                if (so >= 0) { if (lane == 0) L.stale_so[orient] = (uint8_t)so; need_so &= ~(1u << orient); }
+            }
+        }
+        wave_fence();
+    }
+    wave_fence();
+}
+
 // FilterReads + ConvertBinaySeq + ReorderSeed for the mate(s) of a unit
-template <bool PE>
-__device__ void unit_prepare(const AlignArgs &A, const BlockLds &BL, MateLds &LA, MateLds &LB, Mate &MA, Mate &MB, uint32_t unit, int lane, Counters &C)
+template <bool PE, int KRN>
+__device__ void unit_prepare(const AlignArgs &A, const BlockLds &BL, MateLds &LA, MateLds &LB, MateLds &LS, Mate &MA, Mate &MB, uint32_t unit, int lane, Counters &C)
 {
     const DevParams &P = A.P;
     MA.index = MB.index = A.first_index + unit;
-    load_and_filter(A, LA, MA, 0, unit, lane);
-    if (PE) load_and_filter(A, LB, MB, 1, unit, lane);
+    load_and_filter(A, LA, MA, 0, (long)unit, lane);
+    if (PE) load_and_filter(A, LB, MB, 1, (long)unit, lane);
     else MB = MA;
     if (!MA.filtered) {
         pack_read(P, LA, MA, PE ? 1 : 0, lane, C);
-        for (int o = 0; o < 2; o++) if ((MA.flags >> o) & 1) plan_orient(P, BL, LA, MA, o, lane, C);  // pairs.cpp:160 / align.cpp:444
+        const bool lk = A.leak_exact && !P.rrbs && (MA.len - P.index_interval + 1) % P.seed_size == 0;
+        if (lk) resolve_leak<PE, KRN>(A, BL, LS, LA, MA, 0, unit, lane);
+        for (int o = 0; o < 2; o++) if ((MA.flags >> o) & 1) plan_orient(P, BL, LA, MA, o, lane, C, lk);  // pairs.cpp:160 / align.cpp:444
     }
     if (PE && !MB.filtered) {
         pack_read(P, LB, MB, 2, lane, C);
-        for (int o = 0; o < 2; o++) if ((MB.flags >> o) & 1) plan_orient(P, BL, LB, MB, o, lane, C);
+        const bool lk = A.leak_exact && !P.rrbs && (MB.len - P.index_interval + 1) % P.seed_size == 0;
+        if (lk) resolve_leak<PE, KRN>(A, BL, LS, LB, MB, 1, unit, lane);
+        for (int o = 0; o < 2; o++) if ((MB.flags >> o) & 1) plan_orient(P, BL, LB, MB, o, lane, C, lk);
     }
 }
 
@@ -1087,15 +1184,15 @@ __device__ void unit_finish(const AlignArgs &A, const MateLds &LA, const MateLds
 
 // one unit in the main kernel; returns true if it was deferred to the heavy pipeline
 template <bool PE>
-__device__ bool process_unit(const AlignArgs &A, const BlockLds &BL, MateLds &LA, MateLds &LB, uint32_t unit, uint8_t *slab, int lane, Counters &C,
+__device__ bool process_unit(const AlignArgs &A, const BlockLds &BL, MateLds &LA, MateLds &LB, MateLds &LS, uint32_t unit, uint8_t *slab, int lane, Counters &C,
                              u64 &n_aligned, u64 &n_aligned_pairs)
 {
     const DevParams &P = A.P;
     const uint32_t hthr = A.heavy_threshold;
     const Counters C0 = C;
-    const UnitSlabs U = carve_slab(slab, (uint32_t)P.max_snp_num + 1, A.rowcap, PE);
+    const UnitSlabs U = carve_slab(slab, (uint32_t)P.max_snp_num + 1, A.rowcap, PE, A.kcap, A.hbits);
     Mate MA, MB;
-    unit_prepare<PE>(A, BL, LA, LB, MA, MB, unit, lane, C);
+    unit_prepare<PE, 0>(A, BL, LA, LB, LS, MA, MB, unit, lane, C);
     uint32_t pcnt_reg = 0;  // lane c holds _cur_n_hits[c]
     int paired = 0;
     bool defer = false;
@@ -1160,7 +1257,7 @@ __global__ __launch_bounds__(256, PE ? BSX_WAVES_PER_EU_PE : BSX_WAVES_PER_EU_SE
         if (unit >= A.n_units) break;
         const u64 t_begin = A.dbg_cycles ? __builtin_readcyclecounter() : 0;
         uint8_t *slab = A.scratch + (size_t)(A.debug ? unit : slot) * A.slab_bytes;
-        const bool deferred = process_unit<PE>(A, BL, LA, LB, unit, slab, lane, C, n_aligned, n_aligned_pairs);
+        const bool deferred = process_unit<PE>(A, BL, LA, LB, WL[wv].scratch, unit, slab, lane, C, n_aligned, n_aligned_pairs);
         if (deferred) { if (lane == 0) A.heavy_list[atomicAdd(A.heavy_count, 1u)] = unit; }
         else n_units_done++;
         if (A.dbg_cycles && lane == 0) A.dbg_cycles[unit] = (uint32_t)min((u64)0xffffffffull, (u64)__builtin_readcyclecounter() - t_begin);
@@ -1209,6 +1306,7 @@ struct HMate {
     uint32_t cnt_reg[64], key_reg[64], bloom0[64], bloom1[64];
     uint32_t w[2][10], m[2][10];
     uint8_t start[2][16], order[2][16];
+    uint32_t stale_key[2][16];  // "-p 1 exact" mode: make_list needs the tail entries again on later visits
 };
 struct HState {
     uint32_t want;  // tasks of a request the pool refused (0: none): the unit is only restored once that many are free
@@ -1248,7 +1346,7 @@ __device__ void save_mate(HMate &d, const Mate &M, const MateLds &L, int lane)
     }
     d.cnt_reg[lane] = M.cnt_reg; d.key_reg[lane] = M.key_reg; d.bloom0[lane] = M.bloom0; d.bloom1[lane] = M.bloom1;
     if (lane < 20) { (&d.w[0][0])[lane] = (&L.w[0][0])[lane]; (&d.m[0][0])[lane] = (&L.m[0][0])[lane]; }
-    if (lane < 32) { (&d.start[0][0])[lane] = (&L.start[0][0])[lane]; (&d.order[0][0])[lane] = (&L.order[0][0])[lane]; }
+    if (lane < 32) { (&d.start[0][0])[lane] = (&L.start[0][0])[lane]; (&d.order[0][0])[lane] = (&L.order[0][0])[lane]; (&d.stale_key[0][0])[lane] = (&L.stale_key[0][0])[lane]; }
 }
 
 __device__ void load_mate(const HMate &d, Mate &M, MateLds &L, int lane)
@@ -1256,10 +1354,10 @@ __device__ void load_mate(const HMate &d, Mate &M, MateLds &L, int lane)
     M.len = (int)rfl((uint32_t)d.len); M.raw_len = (int)rfl((uint32_t)d.raw_len); M.max_snp = (int)rfl((uint32_t)d.max_snp);
     M.seedseg = (int)rfl((uint32_t)d.seedseg); M.filtered = (int)rfl((uint32_t)d.filtered);
     M.flags = rfl(d.flags); M.snp_thres = rfl(d.snp_thres); M.nkeys = rfl(d.nkeys); M.index = rfl(d.index);
-    M.defer = 0;
+    M.defer = 0; M.limit = 0;
     M.cnt_reg = d.cnt_reg[lane]; M.key_reg = d.key_reg[lane]; M.bloom0 = d.bloom0[lane]; M.bloom1 = d.bloom1[lane];
     if (lane < 20) { (&L.w[0][0])[lane] = (&d.w[0][0])[lane]; (&L.m[0][0])[lane] = (&d.m[0][0])[lane]; }
-    if (lane < 32) { (&L.start[0][0])[lane] = (&d.start[0][0])[lane]; (&L.order[0][0])[lane] = (&d.order[0][0])[lane]; }
+    if (lane < 32) { (&L.start[0][0])[lane] = (&d.start[0][0])[lane]; (&L.order[0][0])[lane] = (&d.order[0][0])[lane]; (&L.stale_key[0][0])[lane] = (&d.stale_key[0][0])[lane]; }
     wave_fence();
 }
 
@@ -1542,7 +1640,7 @@ __global__ __launch_bounds__(256) void k_hctrl(AlignArgs A, HeavyArgs H)
             }
         }
         uint8_t *slab = A.debug ? A.scratch + (size_t)unit * A.slab_bytes : H.slabs + (size_t)hidx * A.slab_bytes;
-        const UnitSlabs U = carve_slab(slab, (uint32_t)A.P.max_snp_num + 1, A.rowcap, PE);
+        const UnitSlabs U = carve_slab(slab, (uint32_t)A.P.max_snp_num + 1, A.rowcap, PE, A.kcap, A.hbits);
         Mate MA, MB;
         Counters C = {0, 0, 0, 0};
         HCursor K;
@@ -1551,7 +1649,7 @@ __global__ __launch_bounds__(256) void k_hctrl(AlignArgs A, HeavyArgs H)
         uint32_t pcnt_reg = 0;
         const u64 cat_prep0 = A.dbg_cat ? __builtin_readcyclecounter() : 0;
         if (H.fresh) {
-            unit_prepare<PE>(A, BL, LA, LB, MA, MB, unit, lane, C);
+            unit_prepare<PE, 1>(A, BL, LA, LB, WL[wv].scratch, MA, MB, unit, lane, C);
             K.level = 0; K.sub = 0; K.orient = 0; K.have = 0; K.paired = 0; K.c = 0; K.W = HS_WIN0;
         } else {
             load_mate(S->mate[0], MA, LA, lane);

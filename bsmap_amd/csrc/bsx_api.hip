@@ -20,11 +20,12 @@ static int g_heavy_threshold = 32768;  // candidate-list length that sends a uni
 
 extern "C" int bsx_set_waves_per_cu(int w) { g_waves_per_cu = w; return BSX_OK; }
 extern "C" int bsx_set_heavy_threshold(int t) { g_heavy_threshold = t < 0 ? 0 : t; return BSX_OK; }
-static uint32_t g_hcap = 32768, g_task_cap = 524288;
+static bool g_user_limits = false;
+static uint32_t g_hcap = 24576, g_task_cap = 524288;  // a 2^20-pair batch defers ~9.4 K units (C3) to ~17.3 K (C5, trimmed reads)
 extern "C" int bsx_set_heavy_limits(uint32_t units_per_round, uint32_t task_pool)
 {
     if (units_per_round < 1 || task_pool < 2 || task_pool > (1u << 22)) return BSX_ERR_ARG;  // (a task record is 8 KB: 2^22 tasks = 34 GB)
-    g_hcap = units_per_round; g_task_cap = task_pool;
+    g_hcap = units_per_round; g_task_cap = task_pool; g_user_limits = true;
     return BSX_OK;
 }
 
@@ -200,7 +201,10 @@ void bsx_fill_devparams(const bsx_ref *r, DevParams &d)
 // ---------------------------------------------------------------------------------------------------------------
 struct bsx_batch {
     bsx_ref *ref = nullptr;
-    int paired = 0, debug = 0, has_qual = 0;
+    int paired = 0, debug = 0, has_qual = 0, leak_exact = 0;
+    uint32_t n_hist = 0;
+    uint8_t *d_hist_seq[2] = {nullptr, nullptr}, *d_hist_qual[2] = {nullptr, nullptr};
+    uint64_t *d_hist_off[2] = {nullptr, nullptr};
     uint32_t max_units = 0, n_units = 0, first_index = 0;
     hipStream_t stream = nullptr, stream_hi = nullptr;  // stream_hi: control passes of the heavy pipeline
     hipEvent_t ev_ctrl[2] = {nullptr, nullptr}, ev_scan[2] = {nullptr, nullptr}, ev_sync = nullptr;
@@ -235,10 +239,16 @@ struct bsx_batch {
     bool ran = false;
 };
 
+// duplicate-suppression set of one mate slab (Slab in bsx_align.hip).  WGBS and paired RRBS: every remembered coordinate is a
+// hit, the -w caps bound them.  Single-end RRBS also remembers the coordinates its fragment-size filter rejects
+// (align.cpp:201-207), which nothing caps: a poly-T read of the hg38-sized genome collects thousands — 2^18 keys, 2^19 slots.
+static uint32_t key_cap(const bsx_params &p, uint32_t rowcap) { return (p.rrbs && !p.pairend) ? (1u << 18) : (uint32_t)(p.max_snp_num + 2) * rowcap; }
+static uint32_t hset_bits(const bsx_params &p) { return (p.rrbs && !p.pairend) ? 19u : (uint32_t)BSX_HSET_BITS; }
+
 static uint64_t mate_bytes(const bsx_params &p, uint32_t rowcap)
 {
     const uint64_t rows = (uint64_t)p.max_snp_num + 2;  // nclass + 1 spare row (see Slab in bsx_align.hip)
-    return 2 * rows * rowcap * 8 + 2 * rows * rowcap * 4 + (uint64_t)BSX_HSET_SLOTS * 4 + (uint64_t)BSX_SORT_TMP * 8;
+    return 2 * rows * rowcap * 8 + 2 * (uint64_t)key_cap(p, rowcap) * 4 + ((uint64_t)4 << hset_bits(p)) + (uint64_t)BSX_SORT_TMP * 8;
 }
 
 static uint64_t slab_size(const bsx_params &p, int paired, uint32_t rowcap)
@@ -262,8 +272,9 @@ static int ensure_scratch(bsx_batch *b)
     b->grid_blocks = grid;
     b->n_cu = prop.multiProcessorCount;
     if (!b->d_heavy_list) {
-        b->hcap = std::min<uint32_t>(b->max_units, g_hcap);  // deferred units handled per round (more than this: several rounds)
-        b->task_cap = g_task_cap;
+        b->hcap = b->ref->P.rrbs ? 1u : std::min<uint32_t>(b->max_units, g_hcap);  // deferred units handled per round (more than this: several rounds); RRBS never defers
+        // the pools follow the batch size: a small batch does not reserve the 4 GB of task records a 2^20-unit one may use
+        b->task_cap = g_user_limits ? g_task_cap : std::min<uint32_t>(g_task_cap, std::max<uint32_t>(4096u, 64u * b->hcap));
         HIP_TRY(hipMalloc((void **)&b->d_heavy_list, ((size_t)b->max_units + 1) * 4));
         HIP_TRY(hipMalloc((void **)&b->d_heavy_count, 256));
         HIP_TRY(hipHostMalloc((void **)&b->h_pinned, 256, hipHostMallocDefault));
@@ -345,6 +356,7 @@ extern "C" void bsx_batch_destroy(bsx_batch *b)
     for (void *q : {(void *)b->d_hits, (void *)b->d_pairs, (void *)b->d_npairs, (void *)b->d_scratch, (void *)b->d_dbg, (void *)b->d_queue, (void *)b->d_counters, (void *)b->d_scan_stats, (void *)b->d_cycles, (void *)b->d_heavy_list, (void *)b->d_heavy_count,
                     (void *)b->d_hstate, (void *)b->d_hslabs, (void *)b->d_htasks, (void *)b->d_htout, (void *)b->d_hactive[0], (void *)b->d_hactive[1], (void *)b->d_hactive[2], (void *)b->d_hactive[3], (void *)b->d_hcnt, (void *)b->d_tsort[0], (void *)b->d_tsort[1], (void *)b->d_tsort[2], (void *)b->d_tsort[3], b->d_sort_tmp})
         if (q) (void)hipFree(q);
+    for (int m = 0; m < 2; m++) for (void *q : {(void *)b->d_hist_seq[m], (void *)b->d_hist_qual[m], (void *)b->d_hist_off[m]}) if (q) (void)hipFree(q);
     if (b->h_pinned) (void)hipHostFree(b->h_pinned);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
@@ -413,6 +425,38 @@ extern "C" int bsx_batch_upload_pe(bsx_batch *b, uint32_t n, const char *seqs_a,
     return BSX_OK;
 }
 
+extern "C" int bsx_batch_set_leak_exact(bsx_batch *b, int on)
+{
+    if (!b) return BSX_ERR_ARG;
+    b->leak_exact = on ? 1 : 0;
+    return BSX_OK;
+}
+
+extern "C" int bsx_batch_set_history(bsx_batch *b, uint32_t n, const char *seqs_a, const uint64_t *off_a, const char *quals_a, const char *seqs_b,
+                                     const uint64_t *off_b, const char *quals_b)
+{
+    if (!b || n > 65536) return BSX_ERR_ARG;
+    if (n && (!seqs_a || !off_a || (b->paired && (!seqs_b || !off_b)))) return BSX_ERR_ARG;
+    HIP_TRY(hipSetDevice(b->ref->device));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    const char *sq[2] = {seqs_a, seqs_b}, *ql[2] = {quals_a, quals_b};
+    const uint64_t *of[2] = {off_a, off_b};
+    for (int m = 0; m < (b->paired ? 2 : 1); m++) {
+        for (void *q : {(void *)b->d_hist_seq[m], (void *)b->d_hist_qual[m], (void *)b->d_hist_off[m]}) if (q) (void)hipFree(q);
+        b->d_hist_seq[m] = b->d_hist_qual[m] = nullptr; b->d_hist_off[m] = nullptr;
+        if (!n) continue;
+        if (of[m][0] != 0) { g_bsx_err = "off[0] must be 0"; return BSX_ERR_ARG; }
+        const uint64_t bytes = of[m][n];
+        HIP_TRY(hipMalloc((void **)&b->d_hist_seq[m], bytes + 256));
+        HIP_TRY(hipMalloc((void **)&b->d_hist_off[m], ((size_t)n + 1) * 8));
+        HIP_TRY(hipMemcpy(b->d_hist_seq[m], sq[m], bytes, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(b->d_hist_off[m], of[m], ((size_t)n + 1) * 8, hipMemcpyHostToDevice));
+        if (ql[m]) { HIP_TRY(hipMalloc((void **)&b->d_hist_qual[m], bytes + 256)); HIP_TRY(hipMemcpy(b->d_hist_qual[m], ql[m], bytes, hipMemcpyHostToDevice)); }
+    }
+    b->n_hist = n;
+    return BSX_OK;
+}
+
 extern "C" int bsx_batch_set_debug(bsx_batch *b, int keep)
 {
     if (!b) return BSX_ERR_ARG;
@@ -435,12 +479,14 @@ extern "C" int bsx_batch_run_range(bsx_batch *b, uint32_t first_unit, uint32_t n
     AlignArgs A;
     memset(&A, 0, sizeof(A));
     bsx_fill_devparams(b->ref, A.P);
-    A.n_units = first_unit + n_units; A.first_index = b->first_index; A.debug = b->debug; A.rowcap = b->rowcap;
+    A.n_units = first_unit + n_units; A.first_index = b->first_index; A.debug = b->debug; A.rowcap = b->rowcap; A.kcap = key_cap(b->ref->P, b->rowcap); A.hbits = hset_bits(b->ref->P);
     A.first_unit = first_unit;
     for (int m = 0; m < 2; m++) { A.seq[m] = b->d_seq[m]; A.off[m] = b->d_off[m]; A.qual[m] = b->has_qual ? b->d_qual[m] : nullptr; A.cc[m] = b->d_cc[m]; }
     A.hits_out = b->d_hits; A.pairs_out = b->d_pairs; A.npairs_out = b->d_npairs;
     A.scratch = b->d_scratch; A.slab_bytes = b->slab_bytes; A.queue = b->d_queue; A.counters = b->d_counters; A.scan_stats = b->d_scan_stats; A.dbg_plan = b->d_dbg; A.dbg_cycles = b->d_cycles; A.dbg_cat = b->d_cycles ? b->d_counters + 16 : nullptr;
     A.heavy_list = b->d_heavy_list; A.heavy_count = b->d_heavy_count;
+    A.leak_exact = b->leak_exact; A.n_hist = b->leak_exact ? b->n_hist : 0;
+    for (int m = 0; m < 2; m++) { A.hist_seq[m] = b->d_hist_seq[m]; A.hist_off[m] = b->d_hist_off[m]; A.hist_qual[m] = b->d_hist_qual[m]; }
     A.heavy_threshold = b->ref->P.rrbs ? 0u : (uint32_t)g_heavy_threshold;
     HIP_TRY(hipMemsetAsync(b->d_queue, 0, 4, b->stream));
     HIP_TRY(hipMemsetAsync(b->d_heavy_count, 0, 4, b->stream));

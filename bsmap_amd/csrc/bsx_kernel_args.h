@@ -8,6 +8,7 @@ struct AlignArgs {
     uint32_t first_unit;
     int32_t debug;             // 1: scratch slab per unit (lists kept for inspection) instead of per wave
     uint32_t rowcap;           // capacity of one hit / pair list row (= -w + 64, see DESIGN.md "cap overshoot")
+    uint32_t kcap, hbits;      // per-mate duplicate-suppression set of a slab: key capacity, log2 of its hash slots (Slab in bsx_align.hip)
     const uint8_t *seq[2];     // ASCII reads, mate 0 / 1
     const uint64_t *off[2];    // [n_units+1] byte offsets
     const uint8_t *qual[2];    // may be null
@@ -26,6 +27,13 @@ struct AlignArgs {
     uint32_t *dbg_cycles;      // [n_units] shader-clock cycles spent on each unit (diagnostic builds of a run only), may be null
     uint64_t *dbg_cat;         // [16] category clocks (sums, then the longest single span of each) of the heavy control kernel (diagnostic runs only), may be null
     uint8_t *dbg_plan;         // [n_units][128]: start[2][16], order[2][16] for mate a then mate b
+    // "-p 1 exact" mode (bsx_batch_set_leak_exact): reads whose planner state the reference inherits from earlier reads of the
+    // same stream (align.h:82-91, never reset) look those reads up — in this batch, then in the history the caller attached
+    int32_t leak_exact;
+    uint32_t n_hist;           // reads of history per mate stream (the reads that precede unit 0 in the input)
+    const uint8_t *hist_seq[2];
+    const uint64_t *hist_off[2];
+    const uint8_t *hist_qual[2];
 };
 
 // heavy pipeline (see bsx_align.hip): untyped view used by the host side

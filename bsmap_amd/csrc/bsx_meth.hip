@@ -449,13 +449,17 @@ void parse_chunk(const char *b, const char *e, int sam, const std::unordered_map
     }
 }
 
-// BAM: the BGZF blocks are inflated (in parallel) into one buffer, then the alignment records are walked; fields as
+// BAM, streamed: the BGZF blocks are inflated (in parallel) a bounded window at a time — a whole-genome BAM is hundreds of GB
+// inflated — and the alignment records of each window are handed to `flush` in file order (first-wins duplicate removal
+// depends on it); a record, or the header, that straddles the window edge is carried into the next window.  Fields as
 // `samtools view -X` would print them (what the reference reads): flag bits, RNAME from the header, POS, PNEXT, TLEN, SEQ, ZS:Z
-int parse_bam(const char *base, size_t len, const std::unordered_map<std::string, uint32_t> &cid, int unique, int pair, ParsedChunk &o)
+template <class Flush>
+int stream_bam(const char *base, size_t len, const std::unordered_map<std::string, uint32_t> &cid, int unique, int pair, size_t window, u64 &lines, int &bad_records,
+               Flush &&flush)
 {
-    struct Blk { size_t in_off, in_len, out_off, out_len; };
+    struct Blk { size_t in_off, in_len, out_len; };
     std::vector<Blk> blks;
-    size_t p = 0, total = 0;
+    size_t p = 0;
     const unsigned char *u = (const unsigned char *)base;
     while (p + 18 <= len) {
         if (u[p] != 0x1f || u[p + 1] != 0x8b || u[p + 2] != 8 || !(u[p + 3] & 4)) return 1;
@@ -469,80 +473,106 @@ int parse_bam(const char *base, size_t len, const std::unordered_map<std::string
         }
         if (bsize < 12 + xlen + 8 || p + bsize > len) return 1;
         const unsigned isize = u[p + bsize - 4] | (u[p + bsize - 3] << 8) | (u[p + bsize - 2] << 16) | ((unsigned)u[p + bsize - 1] << 24);
-        blks.push_back(Blk{p + 12 + xlen, bsize - 12 - xlen - 8, total, isize});
-        total += isize; p += bsize;
+        blks.push_back(Blk{p + 12 + xlen, bsize - 12 - xlen - 8, isize});
+        p += bsize;
     }
-    std::vector<unsigned char> buf(total + 8);
-    {
-        std::atomic<size_t> next(0);
-        std::atomic<int> bad(0);
-        auto work = [&] {
-            for (size_t i; (i = next.fetch_add(1)) < blks.size();) {
-                if (!blks[i].out_len) continue;
-                z_stream z;
-                memset(&z, 0, sizeof(z));
-                if (inflateInit2(&z, -15) != Z_OK) { bad = 1; continue; }
-                z.next_in = const_cast<unsigned char *>(u + blks[i].in_off); z.avail_in = (unsigned)blks[i].in_len;
-                z.next_out = buf.data() + blks[i].out_off; z.avail_out = (unsigned)blks[i].out_len;
-                if (inflate(&z, Z_FINISH) != Z_STREAM_END) bad = 1;
-                inflateEnd(&z);
-            }
-        };
-        const size_t nt = std::min<size_t>(std::max<size_t>(1, blks.size() / 16), std::max(1u, std::min(32u, std::thread::hardware_concurrency())));
-        std::vector<std::thread> th;
-        for (size_t t = 1; t < nt; t++) th.emplace_back(work);
-        work();
-        for (std::thread &x : th) x.join();
-        if (bad) return 1;
-    }
-    const unsigned char *b = buf.data(), *e = b + total;
-    auto rd32 = [&](const unsigned char *q) { int32_t v; memcpy(&v, q, 4); return v; };
-    if (total < 12 || memcmp(b, "BAM\1", 4) != 0) return 1;
-    const unsigned char *q = b + 8 + rd32(b + 4);
-    if (q + 4 > e) return 1;
-    const int32_t n_ref = rd32(q); q += 4;
-    std::vector<int64_t> ref_id;  // BAM reference index -> our chromosome id or -1
-    for (int32_t r = 0; r < n_ref; r++) {
-        if (q + 4 > e) return 1;
-        const int32_t ln = rd32(q); q += 4;
-        if (ln < 1 || q + ln + 4 > e) return 1;
-        auto it = cid.find(std::string((const char *)q, strnlen((const char *)q, (size_t)ln)));
-        ref_id.push_back(it == cid.end() ? -1 : (int64_t)it->second);
-        q += ln + 4;
-    }
+    auto rd32 = [](const unsigned char *q) { int32_t v; memcpy(&v, q, 4); return v; };
     static const char nt16[] = "=ACMGRSVTWYHKDBN";
-    while (q + 4 <= e) {
-        const int32_t bs = rd32(q); q += 4;
-        if (bs < 32 || q + bs > e) return 1;
-        const unsigned char *r = q;
-        q += bs;
-        o.lines++;
-        const int32_t tid = rd32(r), pos = rd32(r + 4), l_seq = rd32(r + 16), npos = rd32(r + 24), tlen = rd32(r + 28);
-        const unsigned l_name = r[8], n_cigar = r[12] | (r[13] << 8), flag = r[14] | (r[15] << 8);
-        if ((flag & 0x4) || (unique && (flag & 0x100)) || (pair && !(flag & 0x2))) continue;
-        if (tid < 0 || tid >= n_ref || ref_id[(size_t)tid] < 0) continue;
-        const unsigned char *sq = r + 32 + l_name + 4 * n_cigar, *ql = sq + ((size_t)l_seq + 1) / 2, *aux = ql + l_seq;
-        if (l_seq < 0 || aux > r + bs) return 1;
-        int st = -1;
-        while (aux + 3 <= r + bs) {  // optional fields: find ZS:Z
-            const unsigned char t0 = aux[0], t1 = aux[1], ty = aux[2];
-            aux += 3;
-            if (ty == 'Z' || ty == 'H') {
-                const size_t n = strnlen((const char *)aux, (size_t)(r + bs - aux));
-                if (t0 == 'Z' && t1 == 'S' && ty == 'Z' && n >= 2) { st = (aux[0] == '-' ? 1 : 0) | (aux[1] == '-' ? 2 : 0); break; }
-                aux += n + 1;
-            } else if (ty == 'A' || ty == 'c' || ty == 'C') aux += 1;
-            else if (ty == 's' || ty == 'S') aux += 2;
-            else if (ty == 'i' || ty == 'I' || ty == 'f') aux += 4;
-            else if (ty == 'B') { if (aux + 5 > r + bs) break; const unsigned char sub = aux[0]; const int32_t cnt = rd32(aux + 1); aux += 5 + (size_t)cnt * ((sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4); }
-            else break;
+    std::vector<unsigned char> buf;
+    std::vector<int64_t> ref_id;  // BAM reference index -> our chromosome id or -1
+    int32_t n_ref = 0;
+    bool header_done = false;
+    size_t carry = 0;
+    for (size_t bi = 0; bi < blks.size();) {
+        size_t bj = bi, out = 0;
+        while (bj < blks.size() && (bj == bi || out + blks[bj].out_len <= window)) { out += blks[bj].out_len; bj++; }
+        buf.resize(carry + out + 8);
+        {
+            std::vector<size_t> at(bj - bi + 1, carry);
+            for (size_t i = bi; i < bj; i++) at[i - bi + 1] = at[i - bi] + blks[i].out_len;
+            std::atomic<size_t> next(bi);
+            std::atomic<int> bad(0);
+            auto work = [&] {
+                for (size_t i; (i = next.fetch_add(1)) < bj;) {
+                    if (!blks[i].out_len) continue;
+                    z_stream z;
+                    memset(&z, 0, sizeof(z));
+                    if (inflateInit2(&z, -15) != Z_OK) { bad = 1; continue; }
+                    z.next_in = const_cast<unsigned char *>(u + blks[i].in_off); z.avail_in = (unsigned)blks[i].in_len;
+                    z.next_out = buf.data() + at[i - bi]; z.avail_out = (unsigned)blks[i].out_len;
+                    if (inflate(&z, Z_FINISH) != Z_STREAM_END) bad = 1;
+                    inflateEnd(&z);
+                }
+            };
+            const size_t nt = std::min<size_t>(std::max<size_t>(1, (bj - bi) / 16), std::max(1u, std::min(32u, std::thread::hardware_concurrency())));
+            std::vector<std::thread> th;
+            for (size_t t = 1; t < nt; t++) th.emplace_back(work);
+            work();
+            for (std::thread &x : th) x.join();
+            if (bad) return 1;
         }
-        if (st < 0) { o.bad = 2; continue; }
-        o.chr.push_back((uint32_t)ref_id[(size_t)tid]); o.pos.push_back(pos); o.strand.push_back((uint8_t)st); o.insert.push_back(tlen);
-        o.cut.push_back(tlen > 0 ? (int64_t)npos : -1);
-        for (int32_t i = 0; i < l_seq; i++) o.seq.push_back(nt16[(sq[i >> 1] >> ((~i & 1) << 2)) & 0xf]);
-        o.off.push_back(o.seq.size());
+        const unsigned char *b = buf.data(), *e = b + carry + out, *q = b;
+        bi = bj;
+        if (!header_done) {  // magic, text, reference names; all of it must be inside the buffer before it is read
+            bool complete = e - b >= 12 && e - b >= 12 + (ptrdiff_t)rd32(b + 4);
+            if (e - b >= 4 && memcmp(b, "BAM\1", 4) != 0) return 1;
+            if (complete) {
+                q = b + 8 + rd32(b + 4);
+                n_ref = rd32(q); q += 4;
+                ref_id.clear();
+                for (int32_t r = 0; r < n_ref && complete; r++) {
+                    if (q + 4 > e) { complete = false; break; }
+                    const int32_t ln = rd32(q);
+                    if (ln < 1) return 1;
+                    if (q + 4 + ln + 4 > e) { complete = false; break; }
+                    auto it = cid.find(std::string((const char *)q + 4, strnlen((const char *)q + 4, (size_t)ln)));
+                    ref_id.push_back(it == cid.end() ? -1 : (int64_t)it->second);
+                    q += 4 + ln + 4;
+                }
+            }
+            if (!complete) { carry += out; continue; }  // header longer than the window so far: read on
+            header_done = true;
+        }
+        ParsedChunk o;
+        while (q + 4 <= e) {
+            const int32_t bs = rd32(q);
+            if (bs < 32) return 1;
+            if (q + 4 + bs > e) break;  // the rest of this record is in the next window
+            const unsigned char *r = q + 4;
+            q += 4 + (size_t)bs;
+            o.lines++;
+            const int32_t tid = rd32(r), pos = rd32(r + 4), l_seq = rd32(r + 16), npos = rd32(r + 24), tlen = rd32(r + 28);
+            const unsigned l_name = r[8], n_cigar = r[12] | (r[13] << 8), flag = r[14] | (r[15] << 8);
+            if ((flag & 0x4) || (unique && (flag & 0x100)) || (pair && !(flag & 0x2))) continue;
+            if (tid < 0 || tid >= n_ref || ref_id[(size_t)tid] < 0) continue;
+            const unsigned char *sq = r + 32 + l_name + 4 * n_cigar, *ql = sq + ((size_t)l_seq + 1) / 2, *aux = ql + l_seq;
+            if (l_seq < 0 || aux > r + bs) return 1;
+            int st = -1;
+            while (aux + 3 <= r + bs) {  // optional fields: find ZS:Z
+                const unsigned char t0 = aux[0], t1 = aux[1], ty = aux[2];
+                aux += 3;
+                if (ty == 'Z' || ty == 'H') {
+                    const size_t n = strnlen((const char *)aux, (size_t)(r + bs - aux));
+                    if (t0 == 'Z' && t1 == 'S' && ty == 'Z' && n >= 2) { st = (aux[0] == '-' ? 1 : 0) | (aux[1] == '-' ? 2 : 0); break; }
+                    aux += n + 1;
+                } else if (ty == 'A' || ty == 'c' || ty == 'C') aux += 1;
+                else if (ty == 's' || ty == 'S') aux += 2;
+                else if (ty == 'i' || ty == 'I' || ty == 'f') aux += 4;
+                else if (ty == 'B') { if (aux + 5 > r + bs) break; const unsigned char sub = aux[0]; const int32_t cnt = rd32(aux + 1); aux += 5 + (size_t)cnt * ((sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4); }
+                else break;
+            }
+            if (st < 0) { bad_records = 2; continue; }
+            o.chr.push_back((uint32_t)ref_id[(size_t)tid]); o.pos.push_back(pos); o.strand.push_back((uint8_t)st); o.insert.push_back(tlen);
+            o.cut.push_back(tlen > 0 ? (int64_t)npos : -1);
+            for (int32_t i = 0; i < l_seq; i++) o.seq.push_back(nt16[(sq[i >> 1] >> ((~i & 1) << 2)) & 0xf]);
+            o.off.push_back(o.seq.size());
+        }
+        lines += o.lines;
+        if (!o.chr.empty()) { const int rc = flush(o); if (rc) return rc; }
+        carry = (size_t)(e - q);
+        if (carry) memmove(buf.data(), q, carry);
     }
+    if (!header_done || carry) return 1;  // no header, or a record cut off by the end of the file
     return 0;
 }
 
@@ -563,19 +593,23 @@ extern "C" int bsx_meth_add_file(bsx_meth *m, const char *path, int sam, const c
     if (base == MAP_FAILED) { g_bsx_err = std::string("cannot map ") + path; return BSX_ERR_IO; }
     std::unordered_map<std::string, uint32_t> cid;
     for (uint32_t c = 0; c < m->n_chr; c++) cid.emplace(chr_names ? std::string(chr_names[c]) : m->names[c], c);
-    if (sam == 2) {  // BAM
-        ParsedChunk all;
-        int rc2 = parse_bam(base, len, cid, unique, pair, all) ? BSX_ERR_IO : BSX_OK;
-        if (rc2) g_bsx_err = std::string("not a readable BAM file: ") + path;
-        if (rc2 == BSX_OK && all.bad == 2) { g_bsx_err = "alignment record without strand information"; rc2 = BSX_ERR_ARG; }
+    if (sam == 2) {  // BAM, a window of inflated blocks at a time (BSX_BAM_WINDOW bytes, default 256 MB)
+        u64 lines = 0;
+        int bad = 0, rc_add = BSX_OK;
+        const size_t window = getenv("BSX_BAM_WINDOW") ? (size_t)std::max(1ll, atoll(getenv("BSX_BAM_WINDOW"))) : ((size_t)256 << 20);
+        const int rcs = stream_bam(base, len, cid, unique, pair, window, lines, bad, [&](ParsedChunk &pc) {
+            if (pc.chr.size() > 0xffffffffull) { rc_add = BSX_ERR_LIMIT; return 1; }
+            pc.seq.push_back(0);
+            rc_add = bsx_meth_add(m, (uint32_t)pc.chr.size(), pc.chr.data(), pc.pos.data(), pc.strand.data(), pc.insert.data(), pc.cut.data(), pc.seq.data(),
+                                  (const uint64_t *)pc.off.data(), trim_fillin);
+            return rc_add != BSX_OK ? 1 : 0;
+        });
         munmap((void *)base, len);
-        if (n_lines) *n_lines = all.lines;
-        if (rc2 == BSX_OK && !all.chr.empty()) {
-            all.seq.push_back(0);
-            rc2 = bsx_meth_add(m, (uint32_t)all.chr.size(), all.chr.data(), all.pos.data(), all.strand.data(), all.insert.data(), all.cut.data(), all.seq.data(),
-                               (const uint64_t *)all.off.data(), trim_fillin);
-        }
-        return rc2;
+        if (n_lines) *n_lines = lines;
+        if (rc_add != BSX_OK) return rc_add;
+        if (rcs) { g_bsx_err = std::string("not a readable BAM file: ") + path; return BSX_ERR_IO; }
+        if (bad == 2) { g_bsx_err = "alignment record without strand information"; return BSX_ERR_ARG; }
+        return BSX_OK;
     }
     // pieces of ~256 MB (bounded host memory), each cut into per-thread chunks at line starts; alignments keep the file's order
     const size_t piece = 256u << 20;

@@ -118,6 +118,8 @@ typedef struct bsx_hit {
 } bsx_hit;
 #define BSX_F_FILTERED 1u  /* FilterReads() rejected the read (QC) */
 #define BSX_F_CHAIN 2u     /* chosen hit is on the read's reverse-complement orientation (chits) */
+#define BSX_F_LIMIT 4u     /* single-end RRBS only: the read matched more than 2^18 distinct places inside the threshold; the set that
+                              suppresses duplicate hits overflowed and the record may differ from the reference's */
 
 /* optional per-read class counts: _cur_n_hit[w] / _cur_n_chit[w] (align.h:85-86) */
 typedef struct bsx_class_counts { uint16_t n_hit[BSX_MAXSNPS + 1], n_chit[BSX_MAXSNPS + 1]; } bsx_class_counts;
@@ -169,6 +171,15 @@ int bsx_batch_run(bsx_batch *b);
 /* the same over units [first_unit, first_unit+n_units) of the uploaded batch (ReadInf.index = first_index + unit) */
 int bsx_batch_run_range(bsx_batch *b, uint32_t first_unit, uint32_t n_units);
 int bsx_batch_sync(bsx_batch *b);
+/* "-p 1 exact" mode (off by default).  The reference never resets SingleAlign::seed_start_offset / seed_array (align.h:82-91):
+ * a read with (len - I + 1) % S == 0 is planned with what earlier reads of its stream left there, so with -p 1 its result is a
+ * deterministic function of the reads before it (with -p > 1 it depends on thread scheduling).  By default every read starts
+ * from zeroed planner state; with this mode on, such reads look their predecessors up — units of the batch,
+ * then the history below — and reproduce the single-threaded reference exactly.  History = the reads that precede unit 0 in
+ * the input (the tail of the previous batch, up to 65536 reads; quals NULL iff the batch has none). */
+int bsx_batch_set_leak_exact(bsx_batch *b, int on);
+int bsx_batch_set_history(bsx_batch *b, uint32_t n, const char *seqs_a, const uint64_t *off_a, const char *quals_a, const char *seqs_b,
+                          const uint64_t *off_b, const char *quals_b);
 float bsx_batch_kernel_ms(bsx_batch *b);          /* HIP-event time of the last run's align kernel (after sync) */
 /* the scan kernel's launches of the last run: their number and the sum of their HIP-event durations on the stream they
  * were launched on (control kernels of the other unit group may run beside them on another stream) */
@@ -193,7 +204,7 @@ int bsx_set_waves_per_cu(int waves);
 /* tuning knob: candidate-list length (one SnpAlign call, one read orientation) from which a unit is handed to the
  * heavy pipeline (chip-wide scan tasks + resumable control passes); 0 = never.  Results do not depend on it. */
 int bsx_set_heavy_threshold(int n_candidates);
-/* pool sizes of the heavy pipeline for batches created afterwards (defaults 32768 units per round, 524288 scan tasks; at most 2^22);
+/* pool sizes of the heavy pipeline for batches created afterwards (defaults 24576 units per round and up to 524288 scan tasks, both scaled down for small batches; at most 2^22);
  * small values only make it take more rounds / passes — used by the tests to exercise those paths */
 int bsx_set_heavy_limits(uint32_t units_per_round, uint32_t task_pool);
 int bsx_batch_last_heavy_units(bsx_batch *b);   /* units the last run handed to the heavy pipeline */

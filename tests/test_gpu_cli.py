@@ -211,3 +211,88 @@ def test_cli_unequal_mate_files_cut_like_the_reference(tmp_path):
     r = _run_cli(meta, fasta, files, out, ["-p", "2"], {})  # default batch size: a multiple of 50000, so the cut is the reference's
     assert "mate files differ in length" in r.stderr
     assert [l for l in open(out).read().split("\n") if l and not l.startswith("@")] == []
+
+
+def _undefined_head(meta):
+    """leaky reads that precede the first read of their stream that sets the planner state: the real binary plans them from
+    uninitialised stack memory (SingleAlign is a local of the thread function, main.cpp:51), nothing defines their result"""
+    kw = meta["kw"]
+    if "D" in kw:
+        return set()
+    S, I = kw.get("s", 16), kw.get("I", 4)
+    bad = set()
+    streams = ("",) if meta["kind"] == "se" else ("a", "b")
+    for m in streams:
+        for r, e in zip(meta["reads"], meta["expected"]):
+            ee = e[m] if m else e
+            if ee["filtered"]:
+                continue
+            if (ee["len"] - I + 1) % S == 0:
+                bad.add(r["name"])
+            else:
+                break
+    return bad
+
+
+@pytest.mark.parametrize("name", [n for n in sorted(CLI) if _leaky_names(G.load(n)[0])])
+@pytest.mark.parametrize("tag", ["sam_Ru", "bsp_u"])
+def test_cli_exact_mode_matches_reference_binary_for_every_read(name, tag, tmp_path):
+    """BSX_P1_EXACT=1: the files of the real `bsmap -p 1` compared WITHOUT thinning out the reads whose planner state leaks
+    from earlier reads; many small batches, so most predecessors come from the history carried across batches"""
+    meta, arr, fasta = G.load(name)
+    run = CLI[name][tag]
+    pe = meta["kind"] == "pe"
+    files = _write_fastq(meta, tmp_path, "ex")
+    out, out2 = str(tmp_path / ("o" + run["ext"])), str(tmp_path / ("o2" + run["ext"]))
+    opts = [o for i, o in enumerate(run["options"]) if not (o == "-D" or (i and run["options"][i - 1] == "-D"))]
+    cmd = [BIN] + (["-D", meta["kw"]["D"]] if "D" in meta["kw"] else []) + ["-a", files[0]] + (["-b", files[1]] if pe else []) + ["-d", fasta, "-o", out] + \
+        (["-2", out2] if pe and run["ext"] == ".bsp" else []) + opts
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, BSX_P1_EXACT="1", BSX_BATCH="37"))
+    assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-1500:]
+    skip = _undefined_head(meta)
+
+    def keep(ln):
+        nm = ln.split("\t")[0]
+        nm = nm[:-2] if nm.endswith(("/1", "/2")) else nm
+        return nm not in skip
+
+    n_leaky_compared = 0
+    leaky = _leaky_names(meta)
+    for got_path, exp_text in ((out, run["out"]), (out2, run["out2"])):
+        if exp_text is None:
+            continue
+        got, exp = [l for l in _body(open(got_path).read()) if keep(l)], [l for l in _body(exp_text) if keep(l)]
+        if run["ext"] == ".bsp":
+            def norm(l):
+                f = l.split("\t")
+                return "\t".join([f[0], "QC"]) if len(f) >= 4 and f[3] == "QC" else l
+            got, exp = [norm(l) for l in got], [norm(l) for l in exp]
+        assert len(got) == len(exp), (len(got), len(exp))
+        for g, e in zip(got, exp):
+            assert g == e
+            nm = g.split("\t")[0]
+            n_leaky_compared += (nm[:-2] if nm.endswith(("/1", "/2")) else nm) in leaky
+    assert n_leaky_compared > 0
+
+
+BAMOUT = json.load(gzip.open(os.path.join(G.GOLDEN, "cli_bamout.json.gz"), "rt"))
+
+
+@pytest.mark.parametrize("key", [k for k in sorted(BAMOUT) if k.endswith("/sam_Ru")])
+def test_cli_bam_output_equals_samtools_pipeline(key, tmp_path):
+    """-o x.bam: the driver leaves the sorted BAM + .bai that the reference gets from `samtools view -bS | sort | index`
+    (main.cpp:466-473, sam2bam.sh) — compared record by record, and bin by bin, with the file the vendored samtools made from
+    the REAL binary's SAM; exact mode on, so no read is left out of the comparison"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_bam_output_cpu import compare_with_gold
+    name = key.split("/")[0]
+    meta, arr, fasta = G.load(name)
+    gold = BAMOUT[key]
+    files = _write_fastq(meta, tmp_path, "bo")
+    out = str(tmp_path / "x.bam")
+    opts = [o for i, o in enumerate(gold["options"]) if not (o == "-D" or (i and gold["options"][i - 1] == "-D"))]
+    res = _run_cli(meta, fasta, files, out, opts + ["-p", "3"], {"BSX_P1_EXACT": "1", "BSX_BATCH": "61", "BSX_BAM_SORT_MEM": "50000"})
+    assert "Total number of aligned reads" in res.stdout
+    n = compare_with_gold(out, gold, skip_names=_undefined_head(meta))
+    assert n > 300 and os.path.exists(out + ".bai")

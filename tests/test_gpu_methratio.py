@@ -86,3 +86,33 @@ def test_methratio_low_level_calls_agree_with_the_file_path(files):
     L.bsx_meth_destroy(h)
     exp = [(f[0], int(f[1]), int(f[5]), int(f[6])) for f in (l.split("\t") for l in open(out).read().split("\n")[1:] if l)]
     assert sorted(got) == sorted(exp) and len(got) > 1000
+
+
+@pytest.mark.parametrize("window", ["1", "70000", "1000000"])
+def test_methratio_bam_is_streamed_in_bounded_windows(window, files, capsys, monkeypatch):
+    """the BAM path inflates a bounded window of BGZF blocks at a time (a whole-genome BAM does not fit host memory): with
+    windows of one block, a few blocks, everything — header and records straddling the window edges — the table stays the
+    reference's (duplicate removal across windows keeps the file order)"""
+    from bsmap_amd import methratio
+    fa, paths, d = files
+    import bam_util
+    case = [c for c in sorted(GOLD["cases"]) if any(p.endswith(".bam") for p in paths[c])][0]
+    # the same file in BGZF blocks of 997 bytes: every window edge then cuts through the header or a record
+    small = []
+    for p_ in paths[case]:
+        data, _ = bam_util.read_bgzf(p_)
+        q = str(d / ("small_" + os.path.basename(p_)))
+        with open(q, "wb") as f:
+            for i in range(0, len(data), 997):
+                f.write(bam_util._bgzf_block(data[i:i + 997]))
+            f.write(bam_util._bgzf_block(b""))
+        small.append(q)
+    monkeypatch.setenv("BSX_BAM_WINDOW", window)
+    for i, run in enumerate(GOLD["cases"][case]["runs"][:6]):
+        exp = run
+        if "same_as" in run:
+            exp = [r for r in GOLD["cases"][run["same_as"]]["runs"] if r["options"] == run["options"]][0]
+        out = str(d / f"win_{window}_{i}.txt")
+        methratio.main(["-q", "-o", out, "-d", fa] + list(run["options"]) + small)
+        assert open(out).read() == exp["table"]
+        capsys.readouterr()

@@ -62,7 +62,12 @@ def main():
     write_step = sum(v["sum"] for k, v in write.items() if k[:100] in summ) * 1024 / wsteps
     for k, e in summ.items():
         e["launches_per_step"] = e["launches"] / fsteps
-    out = {"tag": tag, "steps_in_fetch_pass": fsteps, "steps_in_write_pass": wsteps, "kernels": summ,
+    import hashlib
+    try:
+        sha = hashlib.sha256(open(os.path.join(ROOT, "bsmap_amd", "libbsx.so"), "rb").read()).hexdigest()[:16]
+    except OSError:
+        sha = None
+    out = {"tag": tag, "lib_sha16": sha, "steps_in_fetch_pass": fsteps, "steps_in_write_pass": wsteps, "kernels": summ,
            "fetch_bytes_per_step_raw": fetch_step, "fetch_bytes_per_step_x2_gfx950": 2 * fetch_step, "write_bytes_per_step": write_step,
            "hbm_bytes_per_launch": 2 * fetch_step + write_step,
            "note": "per bench step (one Do_Batch = k_align + heavy-pipeline iterations); read side = 2 x FETCH_SIZE "
