@@ -73,7 +73,7 @@ struct MateLds {
     uint8_t stale_so[2];          // seed_start_offset / cseed_start_offset of the last read that set them
 };
 
-template <bool PE> struct WaveLds { MateLds mate[PE ? 2 : 1]; MateLds scratch; };
+template <bool PE> struct WaveLds { MateLds mate[PE ? 2 : 1]; };
 
 struct BlockLds {
     uint8_t prof[16][16];
@@ -83,7 +83,7 @@ struct BlockLds {
 // wave-uniform per-mate state; cnt_reg / key_reg are lane-distributed tables
 struct Mate {
     int len, raw_len, max_snp, seedseg, filtered;
-    uint32_t flags;      // bit0 flag_chain, bit1 cflag_chain
+    uint32_t flags;      // bit0 flag_chain, bit1 cflag_chain, bit2 duplicate-suppression set overflowed (RRBS single-end only)
     uint32_t snp_thres;
     uint32_t nkeys;
     uint32_t cnt_reg;    // lane (orient*16+w) holds _cur_n_hit / _cur_n_chit
@@ -91,7 +91,6 @@ struct Mate {
     uint32_t bloom0, bloom1;  // 4096-bit membership filter over all accepted coordinates (bit b of lane l)
     uint32_t index;      // ReadInf.index
     int defer;           // main kernel: a candidate list exceeded heavy_threshold, redo this unit in the heavy kernel
-    int limit;           // the duplicate-suppression set overflowed (RRBS single-end only): results of this unit are flagged
 };
 
 struct Slab {
@@ -214,7 +213,7 @@ __device__ void load_and_filter(const AlignArgs &A, MateLds &L, Mate &M, int mat
     M.key_reg = 0;
     M.bloom0 = M.bloom1 = 0;
     M.defer = 0;
-    M.limit = 0;
+    M.flags = 0;  // (set by pack_read; a filtered read never gets there and bit 2 is reported)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -255,20 +254,24 @@ __device__ __forceinline__ uint32_t seed_key_at(const DevParams &P, const uint32
 
 // seed_array[o] / cseed_array[o] as the reference's planner sees it: the read's own hash for o < noff; beyond that the entry
 // an earlier read left behind (only reachable in "-p 1 exact" mode, see resolve_leak; zero-state mode never reads past noff)
+// (EXACT: the main kernel exists in two instantiations; with the mode off it carries none of this)
+template <bool EXACT>
 __device__ __forceinline__ uint32_t key_at(const DevParams &P, const MateLds &L, const Mate &M, int orient, int o)
 {
+    if (!EXACT) return seed_key_at(P, L.w[orient], o);
     const int noff = M.len - P.seed_size + 1;
     return o >= noff ? L.stale_key[orient][min(o - noff, 15)] : seed_key_at(P, L.w[orient], o);
 }
 
 // index2[s][0] (= 2 + bucket size, 0 for an empty bucket) for every offset of this orientation -> L.cnt[orient][]
+template <bool EXACT>
 __device__ void plan_counts(const DevParams &P, MateLds &L, const Mate &M, int orient, int lane, bool with_tail)
 {
     const int noff = M.len - P.seed_size + 1, n = noff + (with_tail ? 16 : 0);
     for (int base = 0; base < n; base += 64) {
         const int o = base + lane;
         if (o < n) {
-            const uint32_t key = key_at(P, L, M, orient, o);
+            const uint32_t key = key_at<EXACT>(P, L, M, orient, o);
             const U2 b = *reinterpret_cast<const U2 *>(P.bucket_off + key);
             const uint32_t c = b.b - b.a;
             L.cnt[orient][o] = P.rrbs ? c : (c ? c + 2 : 0);
@@ -296,10 +299,12 @@ __device__ int plan_best_offset(const DevParams &P, const BlockLds &BL, const Ma
 // ---------------------------------------------------------------------------------------------------------------
 // ReorderSeed (align.cpp:454-504) for one orientation
 // ---------------------------------------------------------------------------------------------------------------
-__device__ void plan_orient(const DevParams &P, const BlockLds &BL, MateLds &L, const Mate &M, int orient, int lane, Counters &C, bool leaky_exact = false)
+template <bool EXACT>
+__device__ void plan_orient(const DevParams &P, const BlockLds &BL, MateLds &L, const Mate &M, int orient, int lane, Counters &C, bool leaky_arg = false)
 {
+    const bool leaky_exact = EXACT && leaky_arg;
     const int I = P.index_interval, S = P.seed_size, nseg = M.seedseg;
-    plan_counts(P, L, M, orient, lane, leaky_exact);
+    plan_counts<EXACT>(P, L, M, orient, lane, leaky_exact);
     const uint32_t *cnt = L.cnt[orient];
     int offset = leaky_exact ? (int)L.stale_so[orient] : 0;  // the loop below does not run for such a read: the old value stays (align.cpp:458)
     const int nstart = P.rrbs ? 0 : (M.len - I + 1) % S;
@@ -398,7 +403,7 @@ __device__ __forceinline__ bool seen_before(const Mate &M, const Slab &SL, uint3
 __device__ __forceinline__ void remember_key(Mate &M, const Slab &SL, uint32_t key, int lane)
 {
     if (M.nkeys < 64) { if ((uint32_t)lane == M.nkeys) M.key_reg = key; }
-    else if (M.nkeys >= SL.kcap) { M.limit = 1; return; }  // set full (RRBS only, see Slab): the coordinate is not remembered, the unit is flagged
+    else if (M.nkeys >= SL.kcap) { M.flags |= 4u; return; }  // set full (RRBS only, see Slab): the coordinate is not remembered, the unit is flagged (bit 2 of flags)
     else {
         const uint32_t hmask = (1u << SL.hbits) - 1;
         for (uint32_t h = hset_home(key, SL.hbits);; h = (h + 64) & hmask) {
@@ -679,6 +684,7 @@ struct CandList {
     int nsub;
 };
 
+template <bool EXACT>
 __device__ __forceinline__ CandList make_list(const DevParams &P, const BlockLds &BL, const MateLds &L, const Mate &M, int orient, int seg, int lane)
 {
     CandList cl;
@@ -694,7 +700,7 @@ __device__ __forceinline__ CandList make_list(const DevParams &P, const BlockLds
         } else {
             const int ph = lane >> 1;
             const int a = BL.prof[seg][ph], st = L.start[orient][seg];
-            const uint32_t key = key_at(P, L, M, orient, a + st - ph);
+            const uint32_t key = key_at<EXACT>(P, L, M, orient, a + st - ph);
             const U2 b = *reinterpret_cast<const U2 *>(P.bucket_off + key);
             const uint32_t nf = P.bucket_nfwd[key];
             cl.sub_base = (lane & 1) ? b.a + nf : b.a;
@@ -823,13 +829,14 @@ __device__ int wave_scan_range(const DevParams &P, const BlockLds &BL, const Mat
 
 // SnpAlign (align.cpp:168-347) in the main kernel.  A WGBS list of heavy_threshold candidates or more sets M.defer and
 // returns: the unit is redone from scratch by the heavy pipeline, which scans such lists with the whole chip.
+template <bool EXACT>
 __device__ void snp_align(const DevParams &P, const BlockLds &BL, const MateLds &L, Mate &M, const Slab &SL, int mode, int lane,
                           Counters &C, uint32_t heavy_threshold)
 {
     for (int orient = 0; orient < 2; orient++) {
         if (!((M.flags >> orient) & 1)) continue;
         const int seg = L.order[orient][mode];  // modeindex
-        const CandList cl = make_list(P, BL, L, M, orient, seg, lane);
+        const CandList cl = make_list<EXACT>(P, BL, L, M, orient, seg, lane);
         if (!P.rrbs && heavy_threshold && cl.total >= heavy_threshold) { M.defer = 1; return; }
         if (wave_scan_range<false, 1>(P, BL, L, M, SL, cl, orient, seg, mode, 0, cl.total, 0, lane, C) == 2) { wave_fence(); return; }
     }
@@ -837,11 +844,12 @@ __device__ void snp_align(const DevParams &P, const BlockLds &BL, const MateLds 
 }
 
 // SingleAlign::RunAlign (align.cpp:435-452) after packing/planning
+template <bool EXACT>
 __device__ void run_align_single(const DevParams &P, const BlockLds &BL, const MateLds &L, Mate &M, const Slab &SL, int lane, Counters &C,
                                  uint32_t heavy_threshold)
 {
     for (int i = 0; i < M.seedseg; i++) {
-        snp_align(P, BL, L, M, SL, i, lane, C, heavy_threshold);
+        snp_align<EXACT>(P, BL, L, M, SL, i, lane, C, heavy_threshold);
         if (M.defer) return;
         if (!P.rrbs) {
             const u64 nz = bsx_ballot(M.cnt_reg != 0 && (lane & 15) <= i && lane < 32);
@@ -880,7 +888,7 @@ __device__ void fix_unpaired_short_fragment(const DevParams &P, Mate &M, const S
 __device__ void select_hit(const DevParams &P, const Mate &M, const Slab &SL, bsx_hit &out, bool unpair_semantics)
 {
     out.chr = 0; out.loc = 0; out.n_best = 0; out.best_class = -1;
-    out.flags = (M.filtered ? BSX_F_FILTERED : 0) | (M.limit ? BSX_F_LIMIT : 0);
+    out.flags = (M.filtered ? BSX_F_FILTERED : 0) | ((M.flags & 4u) ? BSX_F_LIMIT : 0);
     out.len = (uint8_t)M.len; out.raw_len = (uint8_t)M.raw_len; out.max_snp = (uint8_t)M.max_snp; out.seedseg = (uint8_t)M.seedseg;
     if (M.filtered) return;
     int ii; uint32_t sum = 0, nf = 0;
@@ -1057,9 +1065,8 @@ __device__ __forceinline__ UnitSlabs carve_slab(uint8_t *slab, uint32_t nclass, 
 // streams: PairAlign owns two SingleAlign objects), so the wave that owns such a read walks back through the stream — units
 // of this batch, then the history the caller attached — until it has the offset of the last read that set one and every
 // tail entry it can reach; what nothing ever wrote is zero (the oracle's and the bridge's zero-initialised state).
-// (KRN: one instantiation per calling kernel, so that each inherits its caller's register budget)
-template <bool PE, int KRN>
-__device__ __noinline__ void resolve_leak(const AlignArgs &A, const BlockLds &BL, MateLds &LS, MateLds &L, const Mate &M, int mate, uint32_t unit, int lane)
+template <bool PE>
+__device__ void resolve_leak(const AlignArgs &A, const BlockLds &BL, MateLds &LS, MateLds &L, const Mate &M, int mate, uint32_t unit, int lane)
 {
     const DevParams &P = A.P;
     const int S = P.seed_size, I = P.index_interval, noff = M.len - S + 1;
@@ -1085,7 +1092,7 @@ __device__ __noinline__ void resolve_leak(const AlignArgs &A, const BlockLds &BL
                 need_tail[orient] &= ~(uint32_t)bsx_ballot(got);
             }
             if (((need_so >> orient) & 1) && (MJ.len - I + 1) % S != 0) {  // this read ran the offset loop
-                plan_counts(P, LS, MJ, orient, lane, false);
+                plan_counts<false>(P, LS, MJ, orient, lane, false);
                 const int so = plan_best_offset(P, BL, LS, MJ, orient, lane);
                 if (so >= 0) { if (lane == 0) L.stale_so[orient] = (uint8_t)so; need_so &= ~(1u << orient); }
             }
@@ -1096,8 +1103,18 @@ __device__ __noinline__ void resolve_leak(const AlignArgs &A, const BlockLds &BL
 }
 
 // FilterReads + ConvertBinaySeq + ReorderSeed for the mate(s) of a unit
-template <bool PE, int KRN>
-__device__ void unit_prepare(const AlignArgs &A, const BlockLds &BL, MateLds &LA, MateLds &LB, MateLds &LS, Mate &MA, Mate &MB, uint32_t unit, int lane, Counters &C)
+// what k_leak left for a unit's mate (exact mode): the stale tail entries and start offsets
+struct LeakRec { uint32_t key[2][16]; uint8_t so[2]; uint8_t pad[6]; };
+__device__ __forceinline__ void load_leak_rec(const AlignArgs &A, MateLds &L, uint32_t unit, int mate, int lane)
+{
+    const LeakRec *r = (const LeakRec *)A.leak_rec + ((size_t)unit * 2 + mate);
+    if (lane < 32) (&L.stale_key[0][0])[lane] = (&r->key[0][0])[lane];
+    if (lane < 2) L.stale_so[lane] = r->so[lane];
+    wave_fence();
+}
+
+template <bool PE, bool EXACT>
+__device__ void unit_prepare(const AlignArgs &A, const BlockLds &BL, MateLds &LA, MateLds &LB, Mate &MA, Mate &MB, uint32_t unit, int lane, Counters &C)
 {
     const DevParams &P = A.P;
     MA.index = MB.index = A.first_index + unit;
@@ -1106,15 +1123,15 @@ __device__ void unit_prepare(const AlignArgs &A, const BlockLds &BL, MateLds &LA
     else MB = MA;
     if (!MA.filtered) {
         pack_read(P, LA, MA, PE ? 1 : 0, lane, C);
-        const bool lk = A.leak_exact && !P.rrbs && (MA.len - P.index_interval + 1) % P.seed_size == 0;
-        if (lk) resolve_leak<PE, KRN>(A, BL, LS, LA, MA, 0, unit, lane);
-        for (int o = 0; o < 2; o++) if ((MA.flags >> o) & 1) plan_orient(P, BL, LA, MA, o, lane, C, lk);  // pairs.cpp:160 / align.cpp:444
+        const bool lk = EXACT && A.leak_exact && !P.rrbs && (MA.len - P.index_interval + 1) % P.seed_size == 0;
+        if (lk) load_leak_rec(A, LA, unit, 0, lane);
+        for (int o = 0; o < 2; o++) if ((MA.flags >> o) & 1) plan_orient<EXACT>(P, BL, LA, MA, o, lane, C, lk);  // pairs.cpp:160 / align.cpp:444
     }
     if (PE && !MB.filtered) {
         pack_read(P, LB, MB, 2, lane, C);
-        const bool lk = A.leak_exact && !P.rrbs && (MB.len - P.index_interval + 1) % P.seed_size == 0;
-        if (lk) resolve_leak<PE, KRN>(A, BL, LS, LB, MB, 1, unit, lane);
-        for (int o = 0; o < 2; o++) if ((MB.flags >> o) & 1) plan_orient(P, BL, LB, MB, o, lane, C, lk);
+        const bool lk = EXACT && A.leak_exact && !P.rrbs && (MB.len - P.index_interval + 1) % P.seed_size == 0;
+        if (lk) load_leak_rec(A, LB, unit, 1, lane);
+        for (int o = 0; o < 2; o++) if ((MB.flags >> o) & 1) plan_orient<EXACT>(P, BL, LB, MB, o, lane, C, lk);
     }
 }
 
@@ -1183,8 +1200,8 @@ __device__ void unit_finish(const AlignArgs &A, const MateLds &LA, const MateLds
 }
 
 // one unit in the main kernel; returns true if it was deferred to the heavy pipeline
-template <bool PE>
-__device__ bool process_unit(const AlignArgs &A, const BlockLds &BL, MateLds &LA, MateLds &LB, MateLds &LS, uint32_t unit, uint8_t *slab, int lane, Counters &C,
+template <bool PE, bool EXACT>
+__device__ bool process_unit(const AlignArgs &A, const BlockLds &BL, MateLds &LA, MateLds &LB, uint32_t unit, uint8_t *slab, int lane, Counters &C,
                              u64 &n_aligned, u64 &n_aligned_pairs)
 {
     const DevParams &P = A.P;
@@ -1192,21 +1209,21 @@ __device__ bool process_unit(const AlignArgs &A, const BlockLds &BL, MateLds &LA
     const Counters C0 = C;
     const UnitSlabs U = carve_slab(slab, (uint32_t)P.max_snp_num + 1, A.rowcap, PE, A.kcap, A.hbits);
     Mate MA, MB;
-    unit_prepare<PE, 0>(A, BL, LA, LB, LS, MA, MB, unit, lane, C);
+    unit_prepare<PE, EXACT>(A, BL, LA, LB, MA, MB, unit, lane, C);
     uint32_t pcnt_reg = 0;  // lane c holds _cur_n_hits[c]
     int paired = 0;
     bool defer = false;
     if (PE && !MA.filtered && !MB.filtered) {
         const int maxi = max(MA.max_snp, MB.max_snp);  // PairAlign::RunAlign (pairs.cpp:163-172)
         for (int i = 0; i <= maxi && !paired && !defer; i++) {
-            if (i < MA.seedseg) snp_align(P, BL, LA, MA, U.SA, i, lane, C, hthr);
-            if (!MA.defer && i < MB.seedseg) snp_align(P, BL, LB, MB, U.SB, i, lane, C, hthr);
+            if (i < MA.seedseg) snp_align<EXACT>(P, BL, LA, MA, U.SA, i, lane, C, hthr);
+            if (!MA.defer && i < MB.seedseg) snp_align<EXACT>(P, BL, LB, MB, U.SB, i, lane, C, hthr);
             if (MA.defer || MB.defer) { defer = true; break; }
             if (pair_level_post(P, MA, MB, U, pcnt_reg, i, lane) > 0) paired = i + 1;
         }
     } else {
-        if (!MA.filtered) { run_align_single(P, BL, LA, MA, U.SA, lane, C, hthr); defer = MA.defer; }
-        if (PE && !defer && !MB.filtered) { run_align_single(P, BL, LB, MB, U.SB, lane, C, hthr); defer = MB.defer; }
+        if (!MA.filtered) { run_align_single<EXACT>(P, BL, LA, MA, U.SA, lane, C, hthr); defer = MA.defer; }
+        if (PE && !defer && !MB.filtered) { run_align_single<EXACT>(P, BL, LB, MB, U.SB, lane, C, hthr); defer = MB.defer; }
     }
     if (defer) { forget_keys(MA, U.SA, lane); if (PE) forget_keys(MB, U.SB, lane); C = C0; return true; }
     unit_finish<PE>(A, LA, LB, MA, MB, U, pcnt_reg, paired, unit, lane, n_aligned, n_aligned_pairs);
@@ -1230,6 +1247,35 @@ __device__ void flush_counters(const AlignArgs &A, const Counters &C, u64 n_unit
     atomicAdd((u64 *)&A.counters[6], n_aligned_pairs);
 }
 
+// "-p 1 exact" mode, pre-pass: one wave per unit finds, for every mate whose planner state leaks, what the reference's state
+// holds at that point of the stream (resolve_leak) and leaves it in A.leak_rec for the align kernels — kept out of the main
+// kernel, whose per-unit function must stay a leaf (a call inside it cost 18 ms per 2^20 pairs even when never taken)
+template <bool PE>
+__global__ __launch_bounds__(256) void k_leak(AlignArgs A)
+{
+    __shared__ BlockLds BL;
+    __shared__ MateLds LM[4], LSC[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    init_block_lds(A.P, BL, threadIdx.x, 256);
+    __syncthreads();
+    const DevParams &P = A.P;
+    Counters dummy = {0, 0, 0, 0};
+    for (uint32_t unit = A.first_unit + blockIdx.x * 4 + wv; unit < A.n_units; unit += gridDim.x * 4) {
+        for (int mate = 0; mate < (PE ? 2 : 1); mate++) {
+            Mate M;
+            M.index = 0;
+            load_and_filter(A, LM[wv], M, mate, (long)unit, lane);
+            if (M.filtered || (M.len - P.index_interval + 1) % P.seed_size != 0) continue;
+            pack_read(P, LM[wv], M, PE ? mate + 1 : 0, lane, dummy);
+            resolve_leak<PE>(A, BL, LSC[wv], LM[wv], M, mate, unit, lane);
+            LeakRec *r = (LeakRec *)A.leak_rec + ((size_t)unit * 2 + mate);
+            if (lane < 32) (&r->key[0][0])[lane] = (&LM[wv].stale_key[0][0])[lane];
+            if (lane < 2) r->so[lane] = LM[wv].stale_so[lane];
+        }
+        wave_fence();
+    }
+}
+
 #ifndef BSX_WAVES_PER_EU_SE
 #define BSX_WAVES_PER_EU_SE 6
 #endif
@@ -1237,7 +1283,7 @@ __device__ void flush_counters(const AlignArgs &A, const Counters &C, u64 n_unit
 #define BSX_WAVES_PER_EU_PE 4
 #endif
 // main kernel: persistent waves, one unit per wave at a time
-template <bool PE>
+template <bool PE, bool EXACT>
 __global__ __launch_bounds__(256, PE ? BSX_WAVES_PER_EU_PE : BSX_WAVES_PER_EU_SE) void k_align(AlignArgs A)
 {
     __shared__ BlockLds BL;
@@ -1257,7 +1303,7 @@ __global__ __launch_bounds__(256, PE ? BSX_WAVES_PER_EU_PE : BSX_WAVES_PER_EU_SE
         if (unit >= A.n_units) break;
         const u64 t_begin = A.dbg_cycles ? __builtin_readcyclecounter() : 0;
         uint8_t *slab = A.scratch + (size_t)(A.debug ? unit : slot) * A.slab_bytes;
-        const bool deferred = process_unit<PE>(A, BL, LA, LB, WL[wv].scratch, unit, slab, lane, C, n_aligned, n_aligned_pairs);
+        const bool deferred = process_unit<PE, EXACT>(A, BL, LA, LB, unit, slab, lane, C, n_aligned, n_aligned_pairs);
         if (deferred) { if (lane == 0) A.heavy_list[atomicAdd(A.heavy_count, 1u)] = unit; }
         else n_units_done++;
         if (A.dbg_cycles && lane == 0) A.dbg_cycles[unit] = (uint32_t)min((u64)0xffffffffull, (u64)__builtin_readcyclecounter() - t_begin);
@@ -1354,7 +1400,7 @@ __device__ void load_mate(const HMate &d, Mate &M, MateLds &L, int lane)
     M.len = (int)rfl((uint32_t)d.len); M.raw_len = (int)rfl((uint32_t)d.raw_len); M.max_snp = (int)rfl((uint32_t)d.max_snp);
     M.seedseg = (int)rfl((uint32_t)d.seedseg); M.filtered = (int)rfl((uint32_t)d.filtered);
     M.flags = rfl(d.flags); M.snp_thres = rfl(d.snp_thres); M.nkeys = rfl(d.nkeys); M.index = rfl(d.index);
-    M.defer = 0; M.limit = 0;
+    M.defer = 0;
     M.cnt_reg = d.cnt_reg[lane]; M.key_reg = d.key_reg[lane]; M.bloom0 = d.bloom0[lane]; M.bloom1 = d.bloom1[lane];
     if (lane < 20) { (&L.w[0][0])[lane] = (&d.w[0][0])[lane]; (&L.m[0][0])[lane] = (&d.m[0][0])[lane]; }
     if (lane < 32) { (&L.start[0][0])[lane] = (&d.start[0][0])[lane]; (&L.order[0][0])[lane] = (&d.order[0][0])[lane]; (&L.stale_key[0][0])[lane] = (&d.stale_key[0][0])[lane]; }
@@ -1391,7 +1437,7 @@ __device__ int snp_align_heavy(const AlignArgs &A, const HeavyArgs &H, HState *S
         const int orient = K.orient;
         if (!((M.flags >> orient) & 1)) continue;
         const int seg = L.order[orient][mode];
-        const CandList cl = make_list(P, BL, L, M, orient, seg, lane);
+        const CandList cl = make_list<true>(P, BL, L, M, orient, seg, lane);
         if (cl.total < min(A.heavy_threshold, (uint32_t)HS_TASK_MIN)) {  // short list: the owning wave scans it itself
             CAT_BEGIN(A);
             const int r_ = wave_scan_range<false, 4>(P, BL, L, M, SL, cl, orient, seg, mode, 0, cl.total, 0, lane, C);
@@ -1649,7 +1695,7 @@ __global__ __launch_bounds__(256) void k_hctrl(AlignArgs A, HeavyArgs H)
         uint32_t pcnt_reg = 0;
         const u64 cat_prep0 = A.dbg_cat ? __builtin_readcyclecounter() : 0;
         if (H.fresh) {
-            unit_prepare<PE, 1>(A, BL, LA, LB, WL[wv].scratch, MA, MB, unit, lane, C);
+            unit_prepare<PE, true>(A, BL, LA, LB, MA, MB, unit, lane, C);
             K.level = 0; K.sub = 0; K.orient = 0; K.have = 0; K.paired = 0; K.c = 0; K.W = HS_WIN0;
         } else {
             load_mate(S->mate[0], MA, LA, lane);
@@ -1934,10 +1980,20 @@ __global__ __launch_bounds__(64 * BSX_HSCAN_WPB, BSX_HSCAN_WAVES) void k_hscan(A
 
 }  // namespace
 
+void bsx_launch_leak(const AlignArgs &A, int paired, int grid_blocks, hipStream_t stream)
+{
+    if (paired) hipLaunchKernelGGL(k_leak<true>, dim3(grid_blocks), dim3(256), 0, stream, A);
+    else hipLaunchKernelGGL(k_leak<false>, dim3(grid_blocks), dim3(256), 0, stream, A);
+}
+size_t bsx_leakrec_bytes(void) { return sizeof(LeakRec); }
+
 void bsx_launch_align(const AlignArgs &A, int paired, int grid_blocks, hipStream_t stream)
 {
-    if (paired) hipLaunchKernelGGL(k_align<true>, dim3(grid_blocks), dim3(256), 0, stream, A);
-    else hipLaunchKernelGGL(k_align<false>, dim3(grid_blocks), dim3(256), 0, stream, A);
+    if (A.leak_exact) {
+        if (paired) hipLaunchKernelGGL((k_align<true, true>), dim3(grid_blocks), dim3(256), 0, stream, A);
+        else hipLaunchKernelGGL((k_align<false, true>), dim3(grid_blocks), dim3(256), 0, stream, A);
+    } else if (paired) hipLaunchKernelGGL((k_align<true, false>), dim3(grid_blocks), dim3(256), 0, stream, A);
+    else hipLaunchKernelGGL((k_align<false, false>), dim3(grid_blocks), dim3(256), 0, stream, A);
 }
 
 void bsx_launch_hctrl(const AlignArgs &A, const HeavyArgsRaw &R, int paired, int grid_blocks, hipStream_t stream)
@@ -1974,8 +2030,8 @@ size_t bsx_htaskout_bytes(void) { return sizeof(HTaskOut); }
 int bsx_align_occupancy(int paired)
 {
     int nb = 0;
-    hipError_t e = paired ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_align<true>, 256, 0)
-                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_align<false>, 256, 0);
+    hipError_t e = paired ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_align<true, false>, 256, 0)
+                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_align<false, false>, 256, 0);
     if (e != hipSuccess || nb < 1) nb = 2;
     return nb;
 }

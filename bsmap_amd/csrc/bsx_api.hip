@@ -205,6 +205,7 @@ struct bsx_batch {
     uint32_t n_hist = 0;
     uint8_t *d_hist_seq[2] = {nullptr, nullptr}, *d_hist_qual[2] = {nullptr, nullptr};
     uint64_t *d_hist_off[2] = {nullptr, nullptr};
+    uint8_t *d_leak_rec = nullptr;
     uint32_t max_units = 0, n_units = 0, first_index = 0;
     hipStream_t stream = nullptr, stream_hi = nullptr;  // stream_hi: control passes of the heavy pipeline
     hipEvent_t ev_ctrl[2] = {nullptr, nullptr}, ev_scan[2] = {nullptr, nullptr}, ev_sync = nullptr;
@@ -357,6 +358,7 @@ extern "C" void bsx_batch_destroy(bsx_batch *b)
                     (void *)b->d_hstate, (void *)b->d_hslabs, (void *)b->d_htasks, (void *)b->d_htout, (void *)b->d_hactive[0], (void *)b->d_hactive[1], (void *)b->d_hactive[2], (void *)b->d_hactive[3], (void *)b->d_hcnt, (void *)b->d_tsort[0], (void *)b->d_tsort[1], (void *)b->d_tsort[2], (void *)b->d_tsort[3], b->d_sort_tmp})
         if (q) (void)hipFree(q);
     for (int m = 0; m < 2; m++) for (void *q : {(void *)b->d_hist_seq[m], (void *)b->d_hist_qual[m], (void *)b->d_hist_off[m]}) if (q) (void)hipFree(q);
+    if (b->d_leak_rec) (void)hipFree(b->d_leak_rec);
     if (b->h_pinned) (void)hipHostFree(b->h_pinned);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
@@ -492,6 +494,12 @@ extern "C" int bsx_batch_run_range(bsx_batch *b, uint32_t first_unit, uint32_t n
     HIP_TRY(hipMemsetAsync(b->d_heavy_count, 0, 4, b->stream));
     if (b->debug) HIP_TRY(hipMemsetAsync(b->d_scratch, 0, (size_t)b->max_units * b->slab_bytes, b->stream));
     HIP_TRY(hipEventRecord(b->ev0, b->stream));
+    if (b->leak_exact && !b->ref->P.rrbs) {  // pre-pass of the exact mode: planner state that leaks from earlier reads
+        if (!b->d_leak_rec) HIP_TRY(hipMalloc((void **)&b->d_leak_rec, (size_t)b->max_units * 2 * bsx_leakrec_bytes()));
+        A.leak_rec = b->d_leak_rec;
+        bsx_launch_leak(A, b->paired, (int)std::min<uint32_t>((n_units + 3) / 4, (uint32_t)b->n_cu * 8), b->stream);
+        HIP_TRY(hipGetLastError());
+    }
     bsx_launch_align(A, b->paired, b->grid_blocks, b->stream);
     HIP_TRY(hipGetLastError());
     b->last_heavy = 0; b->last_heavy_iters = 0; b->scan_ev_used = 0;

@@ -30,6 +30,7 @@ struct AlignArgs {
     // "-p 1 exact" mode (bsx_batch_set_leak_exact): reads whose planner state the reference inherits from earlier reads of the
     // same stream (align.h:82-91, never reset) look those reads up — in this batch, then in the history the caller attached
     int32_t leak_exact;
+    const uint8_t *leak_rec;   // [n_units][2] LeakRec written by k_leak (exact mode only)
     uint32_t n_hist;           // reads of history per mate stream (the reads that precede unit 0 in the input)
     const uint8_t *hist_seq[2];
     const uint64_t *hist_off[2];
@@ -51,6 +52,8 @@ struct HeavyArgsRaw {
 };
 
 void bsx_launch_align(const AlignArgs &A, int paired, int grid_blocks, hipStream_t stream);
+void bsx_launch_leak(const AlignArgs &A, int paired, int grid_blocks, hipStream_t stream);
+size_t bsx_leakrec_bytes(void);
 void bsx_launch_hctrl(const AlignArgs &A, const HeavyArgsRaw &H, int paired, int grid_blocks, hipStream_t stream);
 void bsx_launch_hscan(const AlignArgs &A, const HeavyArgsRaw &H, uint32_t n_tasks, hipStream_t stream);
 void bsx_launch_task_keys(const HeavyArgsRaw &H, uint32_t n_tasks, uint32_t *keys, uint32_t *ids, hipStream_t stream);
