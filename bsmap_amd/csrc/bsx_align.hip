@@ -827,6 +827,9 @@ __device__ int wave_scan_range(const DevParams &P, const BlockLds &BL, const Mat
     return status;
 }
 
+#ifndef BSX_MAIN_NB
+#define BSX_MAIN_NB 1  /* chunks of 64 candidates per step of the main kernel's scan */
+#endif
 // SnpAlign (align.cpp:168-347) in the main kernel.  A WGBS list of heavy_threshold candidates or more sets M.defer and
 // returns: the unit is redone from scratch by the heavy pipeline, which scans such lists with the whole chip.
 template <bool EXACT>
@@ -838,7 +841,7 @@ __device__ void snp_align(const DevParams &P, const BlockLds &BL, const MateLds 
         const int seg = L.order[orient][mode];  // modeindex
         const CandList cl = make_list<EXACT>(P, BL, L, M, orient, seg, lane);
         if (!P.rrbs && heavy_threshold && cl.total >= heavy_threshold) { M.defer = 1; return; }
-        if (wave_scan_range<false, 1>(P, BL, L, M, SL, cl, orient, seg, mode, 0, cl.total, 0, lane, C) == 2) { wave_fence(); return; }
+        if (wave_scan_range<false, BSX_MAIN_NB>(P, BL, L, M, SL, cl, orient, seg, mode, 0, cl.total, 0, lane, C) == 2) { wave_fence(); return; }
     }
     wave_fence();
 }
@@ -1200,8 +1203,10 @@ __device__ void unit_finish(const AlignArgs &A, const MateLds &LA, const MateLds
 }
 
 // one unit in the main kernel; returns true if it was deferred to the heavy pipeline
+// (always inlined into the kernel: as a called function its callee-saved registers cost 21 KB of scratch writes per pair,
+//  a fifth of the kernel's memory requests — 59.6 ms against 48.6 ms per 2^20 pairs)
 template <bool PE, bool EXACT>
-__device__ bool process_unit(const AlignArgs &A, const BlockLds &BL, MateLds &LA, MateLds &LB, uint32_t unit, uint8_t *slab, int lane, Counters &C,
+__device__ __forceinline__ bool process_unit(const AlignArgs &A, const BlockLds &BL, MateLds &LA, MateLds &LB, uint32_t unit, uint8_t *slab, int lane, Counters &C,
                              u64 &n_aligned, u64 &n_aligned_pairs)
 {
     const DevParams &P = A.P;
@@ -1654,8 +1659,11 @@ __device__ bool heavy_advance(const AlignArgs &A, const HeavyArgs &H, HState *S,
     }
 }
 
+#ifndef BSX_HCTRL_WAVES
+#define BSX_HCTRL_WAVES 1  /* waves per SIMD the control kernel's register budget allows (1 = 512 registers) */
+#endif
 template <bool PE>
-__global__ __launch_bounds__(256) void k_hctrl(AlignArgs A, HeavyArgs H)
+__global__ __launch_bounds__(256, BSX_HCTRL_WAVES) void k_hctrl(AlignArgs A, HeavyArgs H)
 {
     __shared__ BlockLds BL;
     __shared__ WaveLds<PE> WL[4];
