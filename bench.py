@@ -99,7 +99,7 @@ def main():
     ap.add_argument("--e2e-pairs", type=int, default=8 << 20, help="pairs of the end-to-end CLI run (FASTQ -> SAM in /dev/shm) reported beside the metric; 0 = skip")
     ap.add_argument("--in-flight", type=int, default=2, help="batches in flight per GPU (host threads, one device batch each): the main kernel of one "
                     "batch (bound by random HBM requests) overlaps the scan passes of the other; 1 = strictly one Do_Batch at a time")
-    ap.add_argument("--transfer-steps", type=int, default=4, help="steps of the PCIe-inclusive leg (upload -> Do_Batch -> results per step); 0 = skip")
+    ap.add_argument("--transfer-steps", type=int, default=6, help="steps of the PCIe-inclusive leg (upload -> Do_Batch -> results per step); 0 = skip")
     ap.add_argument("--waves-per-cu", type=int, default=0)
     ap.add_argument("--heavy-limits", default="", help="tuning: units per round,scan-task pool of the heavy pipeline")
     ap.add_argument("--heavy-threshold", type=int, default=0, help="tuning: candidate-list length that defers a unit to the heavy pipeline (0 = library default)")
@@ -197,6 +197,24 @@ def main():
     sync_all()
     dt = time.perf_counter() - t0
     counters = sum(bt.counters().astype(np.float64) for bt in batches)
+    # per-kernel evidence comes from a serial replay (one batch, control and scan passes strictly alternating): with batches in
+    # flight the launches of different batches overlap and their durations say nothing about one kernel
+    serial = None
+    if nfl > 1 and world == 1 and args.steps >= 2:
+        os.environ["BSX_HEAVY_GROUPS"] = "1"
+        sb = Align(ref, n_total)   # (the group count is read when a batch is created and applies from then on)
+        sb.synth_reads(n_total, read_len, seed=3, first_index=rank * n_total, kind=M["kind"])
+        sb.run_range(0, B_, sync=True)
+        sb.reset_counters()
+        s_ms, s_scan = [], []
+        t1 = time.perf_counter()
+        for i in range(args.warmup, args.warmup + 2):
+            sb.run_range(i * B_, B_, sync=True)
+            s_ms.append(sb.kernel_ms()); s_scan.append(sb.scan_ms())
+        serial = {"ms_per_step": (time.perf_counter() - t1) / 2 * 1e3, "event_ms_per_do_batch": float(np.mean(s_ms)), "scan_ms": s_scan,
+                  "counters": sb.counters().astype(np.float64)}
+        sb.close()
+        os.environ.pop("BSX_HEAVY_GROUPS", None)
     reads_per_unit = 2 if pe else 1
     n_reads_rank = args.steps * B_ * reads_per_unit
     # stats reduction: the only collective of the path (RCCL all-gather of a few doubles per rank)
@@ -237,8 +255,11 @@ def main():
                      "event_ms_per_do_batch": float(np.mean(kernel_ms)), "heavy_units_last_step": int(batch.heavy_units()), "algorithmic_bytes_per_launch": alg_bytes_launch,
                      "per_read": {"n_lookup": float(counters[0]) / n_reads_rank, "n_cand": float(counters[1]) / n_reads_rank,
                                   "ref_words64": float(counters[2]) / n_reads_rank},
-                     "dominant_kernel": dominant_kernel(counters, scan_ms, args.steps, nfl)},
+                     "dominant_kernel": dominant_kernel(serial["counters"], serial["scan_ms"], 2, 1) if serial else dominant_kernel(counters, scan_ms, args.steps, nfl)},
     }
+    if serial:
+        out["roofline"]["serial_replay"] = {"ms_per_step": serial["ms_per_step"], "event_ms_per_do_batch": serial["event_ms_per_do_batch"],
+                                            "note": "two steps with one batch in flight and one unit group after the timed region: the source of dominant_kernel"}
     if world == 1 and not args.profile_serial:
         try:  # measured ceilings of this device beside the spec peak
             pm = B.probe_memory(local_rank, 4 << 30, 1 << 30)
@@ -338,8 +359,17 @@ def incl_transfers(B, ref, src, Align, pe, B_, steps, nfl, reads_per_unit, first
             q[:] = src.download_quals(m)[lo:hi]
             pins.append(pq)
         host.append((a, (off[first_unit:first_unit + steps * B_ + 1] - off[first_unit]).astype(np.uint64), q))
-    small = [Align(ref, B_) for _ in range(nfl)]
+    nt = nfl + 1  # one more batch than the resident-input run keeps in flight: a batch that is moving data does not compute
+    small = [Align(ref, B_) for _ in range(nt)]
     L = B.lib()
+    sinks = []    # page-locked result arrays per batch
+    for _ in range(nt):
+        arrs = []
+        for dt in ((B.PAIR_DTYPE, B.CC_DTYPE, B.CC_DTYPE) if pe else (B.HIT_DTYPE, B.CC_DTYPE)):
+            raw, p_ = pinned_array(B, C, B_ * dt.itemsize)
+            pins.append(p_)
+            arrs.append(raw.view(dt))
+        sinks.append(tuple(arrs))
 
     def step(j, i):
         b = small[j]
@@ -353,15 +383,15 @@ def incl_transfers(B, ref, src, Align, pe, B_, steps, nfl, reads_per_unit, first
         else:
             b.ImportBatchReads((sl[0][0], sl[0][1]), sl[0][2], first_index=first_unit + i * B_)
         b.Do_Batch()
-        b.results()
+        b.results(into=sinks[j])
 
     def worker(j, lo, hi):
-        for i in range(lo + j, hi, nfl):
+        for i in range(lo + j, hi, nt):
             step(j, i)
-    for j in range(nfl):  # untimed warm-up of each small batch
+    for j in range(nt):  # untimed warm-up of each small batch
         step(j, 0)
     t0 = time.perf_counter()
-    th = [threading.Thread(target=worker, args=(j, 0, steps)) for j in range(1, nfl)]
+    th = [threading.Thread(target=worker, args=(j, 0, steps)) for j in range(1, nt)]
     for t in th:
         t.start()
     worker(0, 0, steps)
@@ -377,8 +407,8 @@ def incl_transfers(B, ref, src, Align, pe, B_, steps, nfl, reads_per_unit, first
     down = steps * B_ * ((64 + 128) if pe else (16 + 64))
     return {"value": steps * B_ * reads_per_unit / dt, "unit": "reads/s", "steps": steps, "ms_per_step": dt / steps * 1e3,
             "host_to_device_bytes_per_step": up / steps, "device_to_host_bytes_per_step": down / steps,
-            "window": "per step: bsx_batch_upload (page-locked host arrays) -> Do_Batch -> bsx_batch_results, %d batches in flight; "
-                      "host numpy slicing of the step's arrays included" % nfl}
+            "window": "per step: bsx_batch_upload (page-locked host arrays) -> Do_Batch -> bsx_batch_results (page-locked), %d batches in flight; "
+                      "host numpy slicing of the step's arrays included" % nt}
 
 
 def end_to_end(pairs, genome):

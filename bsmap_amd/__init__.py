@@ -396,10 +396,14 @@ class SingleAlign(_Batch):
         _check(lib().bsx_batch_upload_se(self.h, self.n, buf.ctypes.data, off.ctypes.data, qb.ctypes.data if qb is not None else None, first_index))
         return self
 
-    def results(self, counts=True):
-        out = np.zeros(self.n, HIT_DTYPE)
-        cc = np.zeros(self.n, CC_DTYPE) if counts else None
-        _check(lib().bsx_batch_results_se(self.h, out.ctypes.data, cc.ctypes.data if counts else None))
+    def results(self, counts=True, into=None):
+        """into = (hits, counts) preallocated arrays (e.g. views of page-locked memory) to receive the records"""
+        if into is not None:
+            out, cc = into
+        else:
+            out = np.zeros(self.n, HIT_DTYPE)
+            cc = np.zeros(self.n, CC_DTYPE) if counts else None
+        _check(lib().bsx_batch_results_se(self.h, out.ctypes.data, cc.ctypes.data if cc is not None else None))
         return out, cc
 
 
@@ -420,7 +424,13 @@ class PairAlign(_Batch):
                                          bb.ctypes.data, ob.ctypes.data, qb.ctypes.data if qb is not None else None, first_index))
         return self
 
-    def results(self):
+    def results(self, into=None):
+        """into = (pairs, counts_a, counts_b) preallocated arrays (e.g. views of page-locked memory): the records the formatters
+        need, without the per-class pair counts (what the command-line driver fetches)"""
+        if into is not None:
+            out, ca, cb = into
+            _check(lib().bsx_batch_results_pe(self.h, out.ctypes.data, ca.ctypes.data, cb.ctypes.data, None))
+            return out, ca, cb, None
         out = np.zeros(self.n, PAIR_DTYPE)
         ca, cb = np.zeros(self.n, CC_DTYPE), np.zeros(self.n, CC_DTYPE)
         npairs = np.zeros((self.n, 31), np.uint16)

@@ -12,6 +12,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUTDIR = os.environ.get("BSX_PROFILES_DIR") or os.path.join(ROOT, "profiles")  # (on the GPU box: a directory under gpurun_out/)
 
 
 def per_kernel(dirname, counter):
@@ -30,7 +31,7 @@ def per_kernel(dirname, counter):
 
 def main():
     tag, stats_dir, fetch_dir, write_dir = sys.argv[1:5]
-    os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+    os.makedirs(OUTDIR, exist_ok=True)
     for f in glob.glob(os.path.join(stats_dir, "**", "*_kernel_stats.csv"), recursive=True):
         rows = list(csv.reader(open(f)))
         with open(os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv"), "w") as o:

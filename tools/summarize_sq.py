@@ -21,6 +21,7 @@ import sqlite3
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUTDIR = os.environ.get("BSX_PROFILES_DIR") or os.path.join(ROOT, "profiles")  # (on the GPU box: a directory under gpurun_out/)
 KERNELS = ("k_align", "k_hscan", "k_hctrl", "k_plan", "k_scan")
 N_CU, N_SIMD = 256, 1024
 
@@ -99,7 +100,7 @@ def main():
             d["l2_hit_frac"] = g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum"))
         e["derived"] = d
         out["kernels"][k] = e
-    os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+    os.makedirs(OUTDIR, exist_ok=True)
     json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_sq.json"), "w"), indent=1)
     print(json.dumps({k: v["derived"] for k, v in out["kernels"].items()}, indent=1))
 
