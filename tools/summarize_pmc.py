@@ -34,7 +34,7 @@ def main():
     os.makedirs(OUTDIR, exist_ok=True)
     for f in glob.glob(os.path.join(stats_dir, "**", "*_kernel_stats.csv"), recursive=True):
         rows = list(csv.reader(open(f)))
-        with open(os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv"), "w") as o:
+        with open(os.path.join(OUTDIR, f"{tag}_kernel_stats.csv"), "w") as o:
             w = csv.writer(o)
             for r in rows:
                 r[0] = r[0][:120]
@@ -73,8 +73,8 @@ def main():
            "hbm_bytes_per_launch": 2 * fetch_step + write_step,
            "note": "per bench step (one Do_Batch = k_align + heavy-pipeline iterations); read side = 2 x FETCH_SIZE "
                    "(gfx950 correction of MI355X_MICROARCH.md, uncalibrated for narrow random loads), write side = WRITE_SIZE"}
-    json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_pmc.json"), "w"), indent=1)
-    json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_latest.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(OUTDIR, f"{tag}_pmc.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(OUTDIR, "pmc_latest.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
 
 

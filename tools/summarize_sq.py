@@ -101,7 +101,7 @@ def main():
         e["derived"] = d
         out["kernels"][k] = e
     os.makedirs(OUTDIR, exist_ok=True)
-    json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_sq.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(OUTDIR, f"{tag}_sq.json"), "w"), indent=1)
     print(json.dumps({k: v["derived"] for k, v in out["kernels"].items()}, indent=1))
 
 
