@@ -654,7 +654,8 @@ __device__ int accept_group(const DevParams &P, Mate &M, const Slab &SL, int ori
         }
     }
     {
-        bool pending = commit && kidx >= 64;
+        if (bsx_ballot(commit && kidx >= SL.kcap)) M.flags |= 4u;  // set full: the unit is flagged and redone (see k_hctrl); nothing is written past the arrays
+        bool pending = commit && kidx >= 64 && kidx < SL.kcap;
         uint32_t h = hset_home(hkey, SL.hbits);
         while (bsx_ballot(pending)) {  // claim by write-then-verify: lanes racing for one empty slot see who landed
             if (pending && SL.hset[h] == 0) SL.hset[h] = hkey + 1;
@@ -666,7 +667,7 @@ __device__ int accept_group(const DevParams &P, Mate &M, const Slab &SL, int ori
             wave_fence();
         }
     }
-    M.nkeys += (uint32_t)__builtin_popcountll(km);
+    M.nkeys = min(M.nkeys + (uint32_t)__builtin_popcountll(km), max(SL.kcap, 64u));
     wave_fence();
     if (!em) return 0;
     ev_lane = E;
@@ -840,7 +841,7 @@ __device__ void snp_align(const DevParams &P, const BlockLds &BL, const MateLds 
         if (!((M.flags >> orient) & 1)) continue;
         const int seg = L.order[orient][mode];  // modeindex
         const CandList cl = make_list<EXACT>(P, BL, L, M, orient, seg, lane);
-        if (!P.rrbs && heavy_threshold && cl.total >= heavy_threshold) { M.defer = 1; return; }
+        if (heavy_threshold && cl.total >= heavy_threshold) { M.defer = 1; return; }
         if (wave_scan_range<false, BSX_MAIN_NB>(P, BL, L, M, SL, cl, orient, seg, mode, 0, cl.total, 0, lane, C) == 2) { wave_fence(); return; }
     }
     wave_fence();
@@ -1306,6 +1307,7 @@ __global__ __launch_bounds__(256, PE ? BSX_WAVES_PER_EU_PE : BSX_WAVES_PER_EU_SE
         if (lane == 0) unit = atomicAdd(A.queue, 1u);
         unit = rfl(unit) + A.first_unit;
         if (unit >= A.n_units) break;
+        if (A.unit_list) unit = rfl(A.unit_list[unit]);  // redo run: the units named by the list
         const u64 t_begin = A.dbg_cycles ? __builtin_readcyclecounter() : 0;
         uint8_t *slab = A.scratch + (size_t)(A.debug ? unit : slot) * A.slab_bytes;
         const bool deferred = process_unit<PE, EXACT>(A, BL, LA, LB, unit, slab, lane, C, n_aligned, n_aligned_pairs);
@@ -1350,7 +1352,8 @@ __global__ __launch_bounds__(256, PE ? BSX_WAVES_PER_EU_PE : BSX_WAVES_PER_EU_SE
 
 struct SurvRec { uint32_t w_ord, hchr, hloc, hkey; };  // w in bits 0-7, ordinal inside the task in bits 8+
 
-struct ListReq { uint32_t nsub, total, nwords, len, thres, pad[3]; uint32_t sub_pre[32], sub_n[32], sub_base[32], sub_h[32]; uint32_t rw[12], rm[12]; };
+struct ListReq { uint32_t nsub, total, nwords, len, thres, rrbs, tag_xor, tag_want;  // rrbs: the list is one bucket of {tag, loc} pairs; entries with ((tag ^ tag_xor) >> 16) == tag_want are its candidates
+                 uint32_t sub_pre[32], sub_n[32], sub_base[32], sub_h[32]; uint32_t rw[12], rm[12]; };
 struct HMate {
     int32_t len, raw_len, max_snp, seedseg, filtered;
     uint32_t flags, snp_thres, nkeys, index, pad[7];
@@ -1495,7 +1498,7 @@ __device__ int snp_align_heavy(const AlignArgs &A, const HeavyArgs &H, HState *S
                                     if ((uint32_t)lane < total) r = H.tout[t0 + tg + my_t].surv[my_i];
                                     u64 m = total >= 64 ? ~0ull : ((1ull << total) - 1);
                                     m &= surv_coords(P, BL, r, M.len, lane, m);
-                                    if (total > BSX_GROUP_MIN) e = accept_group(P, M, SL, orient, mode, m, r.w_ord & 0xff, r.hchr, r.hloc, r.hkey, lane, ls);
+                                    if (total > BSX_GROUP_MIN && !P.rrbs) e = accept_group(P, M, SL, orient, mode, m, r.w_ord & 0xff, r.hchr, r.hloc, r.hkey, lane, ls);
                                     else
                                         while (m) {
                                             const int l1 = (int)__builtin_ctzll(m);
@@ -1553,7 +1556,7 @@ __device__ int snp_align_heavy(const AlignArgs &A, const HeavyArgs &H, HState *S
                             if (i < nv) r = o->surv[i];
                             u64 m = bsx_ballot(i < nv);
                             m &= surv_coords(P, BL, r, M.len, lane, m);
-                            if (__builtin_popcountll(m) > BSX_GROUP_MIN) {
+                            if (__builtin_popcountll(m) > BSX_GROUP_MIN && !P.rrbs) {
                                 int ls;
                                 const int e = accept_group(P, M, SL, orient, mode, m, r.w_ord & 0xff, r.hchr, r.hloc, r.hkey, lane, ls);
                                 if (e) { event = e; X = tc0 + (rl(r.w_ord, ls) >> 8); }
@@ -1603,6 +1606,8 @@ __device__ int snp_align_heavy(const AlignArgs &A, const HeavyArgs &H, HState *S
                     if (lane < 9) { R.rw[lane] = L.w[orient][lane]; R.rm[lane] = L.m[orient][lane]; }
                     if (lane == 0) {
                         R.nsub = (uint32_t)cl.nsub; R.total = cl.total; R.nwords = (uint32_t)((M.len + 15) >> 4); R.len = (uint32_t)M.len; R.thres = M.snp_thres;
+                        R.rrbs = P.rrbs ? 1u : 0u;  // tag filter of align.cpp:187,229: forward reads want their segment, rc reads cmodeindex with the direction bit flipped
+                        R.tag_xor = orient ? 0x1000000u : 0u; R.tag_want = orient ? (uint32_t)(M.len / P.seed_size - 1 - seg) : (uint32_t)seg;
                         S->t0 = t0; S->n_tasks = nt; S->win_c0 = K.c; S->win_n = wn;
                     }
                     K.have = 1;
@@ -1652,7 +1657,7 @@ __device__ bool heavy_advance(const AlignArgs &A, const HeavyArgs &H, HState *S,
         Mate &M = second ? MB : MA;
         if (M.filtered || K.level >= M.seedseg) { K.sub++; K.level = 0; K.orient = 0; K.c = 0; K.W = HS_WIN0; K.have = 0; continue; }
         if (snp_align_heavy(A, H, S, hidx, BL, second ? LB : LA, M, second ? U.SB : U.SA, K.level, K, lane, C) == 2) return false;
-        const u64 nz = bsx_ballot(M.cnt_reg != 0 && (lane & 15) <= K.level && lane < 32);
+        const u64 nz = P.rrbs ? 0ull : bsx_ballot(M.cnt_reg != 0 && (lane & 15) <= K.level && lane < 32);  // RRBS runs all rounds (align.cpp:448)
         if (nz) { K.sub++; K.level = 0; }
         else K.level++;
         K.orient = 0; K.c = 0; K.W = HS_WIN0; K.have = 0;
@@ -1693,8 +1698,11 @@ __global__ __launch_bounds__(256, BSX_HCTRL_WAVES) void k_hctrl(AlignArgs A, Hea
                 continue;
             }
         }
-        uint8_t *slab = A.debug ? A.scratch + (size_t)unit * A.slab_bytes : H.slabs + (size_t)hidx * A.slab_bytes;
-        const UnitSlabs U = carve_slab(slab, (uint32_t)A.P.max_snp_num + 1, A.rowcap, PE, A.kcap, A.hbits);
+        // (the slabs of deferred units carry the ordinary, small duplicate set even where the main kernel's are large — single-end
+        //  RRBS —: there are too many deferred units for 4 MB each; a unit that overflows it is redone by the main kernel, below)
+        uint8_t *slab = A.debug ? A.scratch + (size_t)unit * A.slab_bytes : H.slabs + (size_t)hidx * A.hslab_bytes;
+        const UnitSlabs U = A.debug ? carve_slab(slab, (uint32_t)A.P.max_snp_num + 1, A.rowcap, PE, A.kcap, A.hbits)
+                                    : carve_slab(slab, (uint32_t)A.P.max_snp_num + 1, A.rowcap, PE, A.hkcap, A.hhbits);
         Mate MA, MB;
         Counters C = {0, 0, 0, 0};
         HCursor K;
@@ -1725,7 +1733,12 @@ __global__ __launch_bounds__(256, BSX_HCTRL_WAVES) void k_hctrl(AlignArgs A, Hea
                 for (int k_ = 0; k_ < 6; k_++) A.dbg_cat[16 + k_] = (K.vc[k_] << 16) | min(K.vn[k_], 0xffffu);
         }
         const u64 cat_fin0 = A.dbg_cat ? __builtin_readcyclecounter() : 0;
-        if (done) {
+        if (done && ((MA.flags | (PE ? MB.flags : 0u)) & 4u)) {
+            // the small duplicate set of this unit's heavy slab overflowed (single-end RRBS: coordinates its fragment filter rejects
+            // are remembered too): its records are not written; the main kernel redoes it alone with its large set, undeferred
+            forget_keys(MA, U.SA, lane); if (PE) forget_keys(MB, U.SB, lane);
+            if (lane == 0) A.redo_list[atomicAdd(A.redo_count, 1u)] = unit;
+        } else if (done) {
             unit_finish<PE>(A, LA, LB, MA, MB, U, pcnt_reg, K.paired, unit, lane, n_aligned, n_aligned_pairs);
             Cflush.n_lookup += C.n_lookup; Cflush.n_cand += C.n_cand; Cflush.sum_w += C.sum_w; Cflush.n_orient += C.n_orient;
             n_units_done++;
@@ -1766,7 +1779,7 @@ __global__ __launch_bounds__(256, BSX_HCTRL_WAVES) void k_hctrl(AlignArgs A, Hea
 // ballots: with w0ref <= p48 <= w01ref, a task of n candidates touches  2 n - #(w0ref > thres) + 3 #(w01ref <= thres)
 // words; both counts are accumulated per lane and reduced once per task.
 #define HS_QCAP 256u  /* FIFO slots per wave (16 bytes each): at most 63 left over + 2 chunks of 64 pushed between drains */
-struct ScanAcc { uint32_t c1, f5; };  // per lane: candidates with w0ref > thres / candidates evaluated in full with w01ref <= thres
+struct ScanAcc { uint32_t c1, f5, nv; };  // per lane: candidates with w0ref > thres / evaluated in full with w01ref <= thres / (RRBS) candidates at all
 struct ScanCtx {
     const uint32_t *refall;  // forward copy; the rc copy follows it in the same allocation
     uint4 *Q;                // this wave's FIFO
@@ -1841,6 +1854,72 @@ __device__ __forceinline__ void hscan_drain(ScanCtx &X, uint32_t n, const uint32
     }
 }
 
+// stage 1 for one chunk: 64 candidates, lane l holds one (pm1 = its position - 1, boff = byte offset of its first reference
+// word, r0 = those four words); candidates still within the threshold after 48 nt go into the FIFO.  MASKED: some lanes hold
+// no candidate (`valid`).
+template <bool MASKED>
+__device__ __forceinline__ void hscan_eval(ScanCtx &X, const U4 r0, uint32_t pm1, uint32_t boff, bool valid, uint32_t tag, int u, const uint32_t (&rw)[9],
+                                           const uint32_t (&rm)[9])
+{
+    const int lane = X.lane;
+    const uint32_t sh = mad30(pm1, 30);
+    const uint32_t him = (uint32_t)((int32_t)0x80000000 >> (mad30(pm1, 29) & 31u));
+    const uint32_t f0 = __builtin_amdgcn_alignbit(r0.a, r0.b, sh), f1 = __builtin_amdgcn_alignbit(r0.b, r0.c, sh), f2 = __builtin_amdgcn_alignbit(r0.c, r0.d, sh);
+    const uint32_t m1 = bsx_mismatch_hi(rw[1], bsx_tmask(rw[1], rm[1]), f1);
+    const uint32_t c0 = __popc(bsx_mismatch_hi(rw[0], bsx_tmask(rw[0], rm[0]), f0));
+    const uint32_t w0ref = __popc(m1 & him) + c0;
+    uint32_t p48 = __popc(bsx_mismatch_hi(rw[2], bsx_tmask(rw[2], rm[2]), f2)) + (__popc(m1) + c0);
+#if defined(BSX_DUP) && BSX_DUP == 4  /* timing diagnostic: the first stage's arithmetic twice */
+    {
+        uint32_t a_ = r0.a, b_ = r0.b, c_ = r0.c, d_ = r0.d; asm volatile("" : "+v"(a_), "+v"(b_), "+v"(c_), "+v"(d_));
+        const uint32_t g0 = __builtin_amdgcn_alignbit(a_, b_, sh), g1 = __builtin_amdgcn_alignbit(b_, c_, sh), g2 = __builtin_amdgcn_alignbit(c_, d_, sh);
+        const uint32_t n1_ = bsx_mismatch_hi(rw[1], bsx_tmask(rw[1], rm[1]), g1);
+        const uint32_t q48 = __popc(bsx_mismatch_hi(rw[2], bsx_tmask(rw[2], rm[2]), g2)) + (__popc(n1_) + __popc(bsx_mismatch_hi(rw[0], bsx_tmask(rw[0], rm[0]), g0))) + __popc(n1_ & him);
+        p48 |= (q48 - w0ref) ^ p48;
+    }
+#endif
+    const bool need = (!MASKED || valid) && p48 <= X.thres0;
+    X.acc.c1 += ((!MASKED || valid) && w0ref > X.thres0) ? 1u : 0u;
+    const u64 nm = bsx_ballot(need);
+    if (nm) {
+        if (need) {
+            const uint32_t pos = X.qh + X.qn + (uint32_t)__builtin_popcountll(nm & lanemask_lt(lane));
+            X.Q[pos & (HS_QCAP - 1)] = make_uint4(boff, p48 | tag, r0.d, pm1);
+        }
+        X.qn += (uint32_t)__builtin_popcountll(nm);
+    }
+    if (u & 1) {  // (FIFO writes and reads of a wave are ordered: same wave, same LDS)
+        while (X.qn >= 64 && !X.overflow) hscan_drain(X, 64, rw, rm);
+    }
+}
+
+// stage 1 for 256 consecutive entries of an RRBS bucket ({tag, loc} pairs, align.cpp:175-252): only entries of the read's
+// segment / direction are candidates (tag filter), the strand copy comes with the entry, the position is chromosome-local
+__device__ __forceinline__ void hscan_step_rrbs(ScanCtx &X, const U2 *__restrict__ q, uint32_t n_here, uint32_t ord0, uint32_t h, uint32_t tag_xor, uint32_t tag_want,
+                                                uint32_t cref_off, const uint32_t *anchor, const uint32_t (&rw)[9], const uint32_t (&rm)[9])
+{
+    const int lane = X.lane;
+    U2 e[4];
+    uint32_t pm1[4], boff[4], tag[4];
+    bool valid[4];
+    U4 r0[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { e[u].a = e[u].b = 0; if ((uint32_t)(u * 64 + lane) < n_here) e[u] = q[u * 64]; }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const uint32_t rchr = e[u].a & 0xffffu;
+        valid[u] = (uint32_t)(u * 64 + lane) < n_here && ((e[u].a ^ tag_xor) >> 16) == tag_want && e[u].b >= h;  // mode or strand not match / underflow the start of refseq
+        pm1[u] = valid[u] ? anchor[rchr >> 1] + (e[u].b - h) - 1u : 15u;
+        boff[u] = ((pm1[u] >> 2) & 0x3ffffffcu) + ((rchr & 1u) ? cref_off : 0u);
+        tag[u] = (ord0 + (uint32_t)(u * 64 + lane)) << 8 | (rchr & 1u) << 31;
+        X.acc.nv += valid[u] ? 1u : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) r0[u] = *reinterpret_cast<const U4 *>(reinterpret_cast<const uint8_t *>(X.refall) + (valid[u] ? boff[u] : 0u));
+#pragma unroll
+    for (int u = 0; u < 4; u++) hscan_eval<true>(X, r0[u], pm1[u], boff[u], valid[u], tag[u], u, rw, rm);
+}
+
 // stage 1 for 256 consecutive candidates of one sub-range (four chunks of 64; lane l of chunk u holds candidate
 // cb + 64u + l).  FULL: all 256 exist (every step of a sub-range but its last).
 template <bool FULL>
@@ -1880,50 +1959,24 @@ __device__ __forceinline__ void hscan_step(ScanCtx &X, const uint32_t *__restric
     }
 #endif
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-        const uint32_t sh = mad30(pm1[u], 30);
-        const uint32_t him = (uint32_t)((int32_t)0x80000000 >> (mad30(pm1[u], 29) & 31u));
-        const uint32_t f0 = __builtin_amdgcn_alignbit(r0[u].a, r0[u].b, sh), f1 = __builtin_amdgcn_alignbit(r0[u].b, r0[u].c, sh),
-                       f2 = __builtin_amdgcn_alignbit(r0[u].c, r0[u].d, sh);
-        const uint32_t m1 = bsx_mismatch_hi(rw[1], bsx_tmask(rw[1], rm[1]), f1);
-        const uint32_t c0 = __popc(bsx_mismatch_hi(rw[0], bsx_tmask(rw[0], rm[0]), f0));
-        const uint32_t w0ref = __popc(m1 & him) + c0;
-        uint32_t p48 = __popc(bsx_mismatch_hi(rw[2], bsx_tmask(rw[2], rm[2]), f2)) + (__popc(m1) + c0);
-#if defined(BSX_DUP) && BSX_DUP == 4  /* timing diagnostic: the first stage's arithmetic twice */
-        {
-            uint32_t a_ = r0[u].a, b_ = r0[u].b, c_ = r0[u].c, d_ = r0[u].d; asm volatile("" : "+v"(a_), "+v"(b_), "+v"(c_), "+v"(d_));
-            const uint32_t g0 = __builtin_amdgcn_alignbit(a_, b_, sh), g1 = __builtin_amdgcn_alignbit(b_, c_, sh), g2 = __builtin_amdgcn_alignbit(c_, d_, sh);
-            const uint32_t n1_ = bsx_mismatch_hi(rw[1], bsx_tmask(rw[1], rm[1]), g1);
-            const uint32_t q48 = __popc(bsx_mismatch_hi(rw[2], bsx_tmask(rw[2], rm[2]), g2)) + (__popc(n1_) + __popc(bsx_mismatch_hi(rw[0], bsx_tmask(rw[0], rm[0]), g0))) + __popc(n1_ & him);
-            p48 |= (q48 - w0ref) ^ p48;
-        }
-#endif
-        const bool need = (FULL || valid[u]) && p48 <= X.thres0;
-        X.acc.c1 += ((FULL || valid[u]) && w0ref > X.thres0) ? 1u : 0u;
-        const u64 nm = bsx_ballot(need);
-        if (nm) {
-            if (need) {
-                const uint32_t pos = X.qh + X.qn + (uint32_t)__builtin_popcountll(nm & lanemask_lt(lane));
-                X.Q[pos & (HS_QCAP - 1)] = make_uint4(boff[u], p48 | (tag + ((uint32_t)u << 14)), r0[u].d, pm1[u]);
-            }
-            X.qn += (uint32_t)__builtin_popcountll(nm);
-        }
-        if (u & 1) {  // (FIFO writes and reads of a wave are ordered: same wave, same LDS)
-            while (X.qn >= 64 && !X.overflow) hscan_drain(X, 64, rw, rm);
-        }
-    }
+    for (int u = 0; u < 4; u++) hscan_eval<!FULL>(X, r0[u], pm1[u], boff[u], valid[u], tag + ((uint32_t)u << 14), u, rw, rm);
 }
 
 __global__ __launch_bounds__(64 * BSX_HSCAN_WPB, BSX_HSCAN_WAVES) void k_hscan(AlignArgs A, HeavyArgs H)
 {
     __shared__ uint32_t TAB[BSX_HSCAN_WPB][4][32];
     __shared__ uint4 QBUF[BSX_HSCAN_WPB][HS_QCAP];
+    __shared__ uint32_t ANCH[BSX_LDS_CHR + 1];  // RRBS: chromosome anchors (entries carry chromosome-local positions)
 #ifdef BSX_HSCAN_PAD  /* occupancy experiments: extra LDS per block limits the resident waves */
     __shared__ uint32_t PAD[BSX_HSCAN_PAD / 4];
     if (threadIdx.x == 0 && A.n_units == 0xffffffffu) PAD[0] = 1;
 #endif
     const DevParams &P = A.P;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (P.rrbs) {
+        if (P.n_chr <= BSX_LDS_CHR) for (uint32_t i = threadIdx.x; i <= P.n_chr; i += 64 * BSX_HSCAN_WPB) ANCH[i] = P.anchor[i];
+        __syncthreads();
+    }
     // one task per wave, no queue: the blocks of a pass retire one by one, so the control kernel of the other unit
     // group (high-priority stream) finds free slots while this kernel is still running
     const uint32_t n_tasks = min(*H.n_tasks, H.task_cap);
@@ -1948,16 +2001,24 @@ __global__ __launch_bounds__(64 * BSX_HSCAN_WPB, BSX_HSCAN_WAVES) void k_hscan(A
     wave_fence();
     ScanCtx X;
     X.refall = P.refcat; X.Q = QBUF[wv]; X.qh = 0; X.qn = 0; X.thres0 = rfl(R.thres); X.nsurv = 0; X.nwords = (int)rfl(R.nwords); X.lane = lane;
-    X.overflow = false; X.o = o; X.acc.c1 = 0; X.acc.f5 = 0;
+    X.overflow = false; X.o = o; X.acc.c1 = 0; X.acc.f5 = 0; X.acc.nv = 0;
 #ifdef BSX_SPAN_STATS
     X.span[0] = X.span[1] = X.span[2] = X.span[3] = 0;
 #endif
     const uint32_t cref_off = (uint32_t)((const uint8_t *)P.crefcat - (const uint8_t *)P.refcat);  // both copies live in one allocation (bsx_api.hip)
     const uint32_t c_end = tc0 + tn;
+    const bool rrbs = rfl(R.rrbs) != 0;
+    if (rrbs) {  // one bucket of {tag, loc} pairs; four chunks of 64 entries per step, the tag filter decides which are candidates
+        const U2 *ent2 = reinterpret_cast<const U2 *>(P.entries) + rfl(TAB[wv][2][0]);
+        const uint32_t h = rfl(TAB[wv][3][0]), tx = rfl(R.tag_xor), tw = rfl(R.tag_want);
+        const uint32_t *anchor = P.n_chr <= BSX_LDS_CHR ? ANCH : P.anchor;
+        for (uint32_t cb = tc0; cb < c_end && !X.overflow; cb += 256)
+            hscan_step_rrbs(X, ent2 + cb + lane, min(256u, c_end - cb), cb - tc0, h, tx, tw, cref_off, anchor, rw, rm);
+    }
     // the task's candidates sub-range by sub-range (list order): inside one sub-range entry address, h and strand are
     // wave-uniform; four chunks are in flight per step — entries first, then all four 16-byte reference loads.
     // Neighbouring lanes hold neighbouring entries, so in a repeat bucket one reference gather touches few lines.
-    for (uint32_t sidx = 0; sidx < nsub && !X.overflow; sidx++) {
+    for (uint32_t sidx = 0; sidx < nsub && !X.overflow && !rrbs; sidx++) {
         const uint32_t ps = rfl(TAB[wv][0][sidx]), ns = rfl(TAB[wv][1][sidx]);
         const uint32_t lo = max(tc0, ps), hi = min(c_end, ps + ns);
         if (lo >= hi) continue;
@@ -1970,14 +2031,15 @@ __global__ __launch_bounds__(64 * BSX_HSCAN_WPB, BSX_HSCAN_WAVES) void k_hscan(A
     }
     while (X.qn && !X.overflow) hscan_drain(X, min(X.qn, 64u), rw, rm);
     const uint32_t n1 = wave_sum(X.acc.c1), n5 = wave_sum(X.acc.f5);
-    const uint32_t words = 2u * tn - n1 + 3u * n5;  // 1, 2 or 5 words per candidate (see above)
+    const uint32_t n_cand = rrbs ? wave_sum(X.acc.nv) : tn;  // RRBS: only the entries that passed the tag filter are candidates
+    const uint32_t words = 2u * n_cand - n1 + 3u * n5;  // 1, 2 or 5 words per candidate (see above)
     if (lane == 0) {
-        o->count = X.overflow ? 0 : X.nsurv; o->overflow = X.overflow ? 1 : 0; o->acc[0] = tn; o->acc[1] = words; o->acc[2] = 0; o->acc[3] = 0;
+        o->count = X.overflow ? 0 : X.nsurv; o->overflow = X.overflow ? 1 : 0; o->acc[0] = n_cand; o->acc[1] = words; o->acc[2] = 0; o->acc[3] = 0;
         if (!X.overflow) {  // work of the scan kernel (incl. speculation); an overflowed task is redone by the control kernel.
             // Millions of tasks per batch: one counter word takes ~88 atomics per microsecond, so these statistics are
             // sharded over 64 cache lines (summed by bsx_batch_counters) instead of being added to four hot words
             u64 *sh = (u64 *)A.scan_stats + (size_t)(blockIdx.x & 63u) * 8;
-            atomicAdd((u64 *)&sh[0], (u64)tn); atomicAdd((u64 *)&sh[1], (u64)words);
+            atomicAdd((u64 *)&sh[0], (u64)n_cand); atomicAdd((u64 *)&sh[1], (u64)words);
             atomicAdd((u64 *)&sh[2], (u64)n1); atomicAdd((u64 *)&sh[3], (u64)n5);
 #ifdef BSX_SPAN_STATS
             for (int k_ = 0; k_ < 4; k_++) atomicAdd((u64 *)&sh[4 + k_], (u64)X.span[k_]);

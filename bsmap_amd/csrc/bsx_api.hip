@@ -230,11 +230,12 @@ struct bsx_batch {
     uint32_t hcap = 0, task_cap = 0;
     uint32_t *h_pinned = nullptr;  // pinned host words for the per-pass count read-backs
     int n_cu = 0;
-    uint32_t last_heavy = 0, last_heavy_iters = 0;
+    uint32_t last_heavy = 0, last_heavy_iters = 0, last_redo = 0;
     size_t scratch_bytes = 0;
     uint32_t *d_queue = nullptr;
     uint64_t *d_counters = nullptr, *d_scan_stats = nullptr;
-    uint64_t slab_bytes = 0;
+    uint64_t slab_bytes = 0, hslab_bytes = 0;
+    uint32_t *d_redo = nullptr;  // [max_units + 1]: count, then unit ids
     uint32_t rowcap = 0;
     int grid_blocks = 0;
     bool ran = false;
@@ -246,15 +247,19 @@ struct bsx_batch {
 static uint32_t key_cap(const bsx_params &p, uint32_t rowcap) { return (p.rrbs && !p.pairend) ? (1u << 18) : (uint32_t)(p.max_snp_num + 2) * rowcap; }
 static uint32_t hset_bits(const bsx_params &p) { return (p.rrbs && !p.pairend) ? 19u : (uint32_t)BSX_HSET_BITS; }
 
-static uint64_t mate_bytes(const bsx_params &p, uint32_t rowcap)
+// the small set of the heavy pipeline's slabs (BSX_HEAVY_KCAP: test hook that makes it overflow)
+static uint32_t heavy_key_cap(const bsx_params &p, uint32_t rowcap) { return getenv("BSX_HEAVY_KCAP") ? (uint32_t)std::max(64, atoi(getenv("BSX_HEAVY_KCAP"))) : (uint32_t)(p.max_snp_num + 2) * rowcap; }
+
+static uint64_t mate_bytes(const bsx_params &p, uint32_t rowcap, bool heavy = false)
 {
     const uint64_t rows = (uint64_t)p.max_snp_num + 2;  // nclass + 1 spare row (see Slab in bsx_align.hip)
-    return 2 * rows * rowcap * 8 + 2 * (uint64_t)key_cap(p, rowcap) * 4 + ((uint64_t)4 << hset_bits(p)) + (uint64_t)BSX_SORT_TMP * 8;
+    const uint64_t kc = heavy ? heavy_key_cap(p, rowcap) : key_cap(p, rowcap), hb = heavy ? (uint64_t)BSX_HSET_BITS : hset_bits(p);
+    return 2 * rows * rowcap * 8 + 2 * kc * 4 + ((uint64_t)4 << hb) + (uint64_t)BSX_SORT_TMP * 8;
 }
 
-static uint64_t slab_size(const bsx_params &p, int paired, uint32_t rowcap)
+static uint64_t slab_size(const bsx_params &p, int paired, uint32_t rowcap, bool heavy = false)
 {
-    const uint64_t mate = mate_bytes(p, rowcap);
+    const uint64_t mate = mate_bytes(p, rowcap, heavy);
     uint64_t s = mate;
     if (paired) s = 2 * mate + (2 * (uint64_t)p.max_snp_num + 2) * rowcap * 24;
     return (s + 255) & ~255ull;
@@ -273,7 +278,10 @@ static int ensure_scratch(bsx_batch *b)
     b->grid_blocks = grid;
     b->n_cu = prop.multiProcessorCount;
     if (!b->d_heavy_list) {
-        b->hcap = b->ref->P.rrbs ? 1u : std::min<uint32_t>(b->max_units, g_hcap);  // deferred units handled per round (more than this: several rounds); RRBS never defers
+        // deferred units handled per round (more than this: several rounds): what 26 GB of slabs hold — 24 576 units of the 1.07 MB
+        // paired -v 6 slab, 111 K of the 234 KB single-end -v 2 one (RRBS defers a third of its reads: Alu-like fragments)
+        b->hcap = g_user_limits ? g_hcap : (uint32_t)std::min<uint64_t>(262144, std::max<uint64_t>(g_hcap, (26ull << 30) / b->hslab_bytes));
+        b->hcap = std::min<uint32_t>(b->max_units, b->hcap);
         // the pools follow the batch size: a small batch does not reserve the 4 GB of task records a 2^20-unit one may use
         b->task_cap = g_user_limits ? g_task_cap : std::min<uint32_t>(g_task_cap, std::max<uint32_t>(4096u, 64u * b->hcap));
         HIP_TRY(hipMalloc((void **)&b->d_heavy_list, ((size_t)b->max_units + 1) * 4));
@@ -281,8 +289,9 @@ static int ensure_scratch(bsx_batch *b)
         HIP_TRY(hipHostMalloc((void **)&b->h_pinned, 256, hipHostMallocDefault));
         HIP_TRY(hipMalloc((void **)&b->d_hstate, (size_t)b->hcap * bsx_hstate_bytes()));
         if (getenv("BSX_POISON")) HIP_TRY(hipMemsetAsync(b->d_hstate, 0xA5, (size_t)b->hcap * bsx_hstate_bytes(), b->stream));  // test hook: recycled memory is not zero
-        HIP_TRY(hipMalloc((void **)&b->d_hslabs, (size_t)b->hcap * b->slab_bytes));
-        HIP_TRY(hipMemsetAsync(b->d_hslabs, 0, (size_t)b->hcap * b->slab_bytes, b->stream));
+        HIP_TRY(hipMalloc((void **)&b->d_hslabs, (size_t)b->hcap * b->hslab_bytes));
+        HIP_TRY(hipMemsetAsync(b->d_hslabs, 0, (size_t)b->hcap * b->hslab_bytes, b->stream));
+        HIP_TRY(hipMalloc((void **)&b->d_redo, ((size_t)b->max_units + 1) * 4));
         HIP_TRY(hipMalloc((void **)&b->d_htasks, (size_t)b->task_cap * bsx_htask_bytes()));
         HIP_TRY(hipMalloc((void **)&b->d_htout, (size_t)b->task_cap * bsx_htaskout_bytes()));
         if (getenv("BSX_POISON")) {
@@ -314,6 +323,7 @@ extern "C" int bsx_batch_create(bsx_ref *r, uint32_t max_units, int paired, bsx_
     b->ref = r; b->paired = paired ? 1 : 0; b->max_units = max_units;
     b->rowcap = BSX_ROWCAP;
     b->slab_bytes = slab_size(r->P, b->paired, b->rowcap);
+    b->hslab_bytes = slab_size(r->P, b->paired, b->rowcap, true);
     int rc = BSX_OK;
     auto fail = [&](int code) { bsx_batch_destroy(b); return code; };
     if (const char *e = getenv("BSX_HEAVY_GROUPS")) g_heavy_groups = atoi(e) == 1 ? 1 : 2;  // diagnostic: 1 = alternate control and scan passes strictly
@@ -355,7 +365,7 @@ extern "C" void bsx_batch_destroy(bsx_batch *b)
         for (void *q : {(void *)b->d_seq[m], (void *)b->d_qual[m], (void *)b->d_off[m], (void *)b->d_cc[m]})
             if (q) (void)hipFree(q);
     for (void *q : {(void *)b->d_hits, (void *)b->d_pairs, (void *)b->d_npairs, (void *)b->d_scratch, (void *)b->d_dbg, (void *)b->d_queue, (void *)b->d_counters, (void *)b->d_scan_stats, (void *)b->d_cycles, (void *)b->d_heavy_list, (void *)b->d_heavy_count,
-                    (void *)b->d_hstate, (void *)b->d_hslabs, (void *)b->d_htasks, (void *)b->d_htout, (void *)b->d_hactive[0], (void *)b->d_hactive[1], (void *)b->d_hactive[2], (void *)b->d_hactive[3], (void *)b->d_hcnt, (void *)b->d_tsort[0], (void *)b->d_tsort[1], (void *)b->d_tsort[2], (void *)b->d_tsort[3], b->d_sort_tmp})
+                    (void *)b->d_hstate, (void *)b->d_hslabs, (void *)b->d_htasks, (void *)b->d_htout, (void *)b->d_hactive[0], (void *)b->d_hactive[1], (void *)b->d_hactive[2], (void *)b->d_hactive[3], (void *)b->d_hcnt, (void *)b->d_tsort[0], (void *)b->d_tsort[1], (void *)b->d_tsort[2], (void *)b->d_tsort[3], b->d_sort_tmp, (void *)b->d_redo})
         if (q) (void)hipFree(q);
     for (int m = 0; m < 2; m++) for (void *q : {(void *)b->d_hist_seq[m], (void *)b->d_hist_qual[m], (void *)b->d_hist_off[m]}) if (q) (void)hipFree(q);
     if (b->d_leak_rec) (void)hipFree(b->d_leak_rec);
@@ -482,6 +492,8 @@ extern "C" int bsx_batch_run_range(bsx_batch *b, uint32_t first_unit, uint32_t n
     memset(&A, 0, sizeof(A));
     bsx_fill_devparams(b->ref, A.P);
     A.n_units = first_unit + n_units; A.first_index = b->first_index; A.debug = b->debug; A.rowcap = b->rowcap; A.kcap = key_cap(b->ref->P, b->rowcap); A.hbits = hset_bits(b->ref->P);
+    A.hkcap = heavy_key_cap(b->ref->P, b->rowcap); A.hhbits = BSX_HSET_BITS; A.hslab_bytes = b->hslab_bytes;
+    A.redo_count = b->d_redo; A.redo_list = b->d_redo + 1; A.unit_list = nullptr;
     A.first_unit = first_unit;
     for (int m = 0; m < 2; m++) { A.seq[m] = b->d_seq[m]; A.off[m] = b->d_off[m]; A.qual[m] = b->has_qual ? b->d_qual[m] : nullptr; A.cc[m] = b->d_cc[m]; }
     A.hits_out = b->d_hits; A.pairs_out = b->d_pairs; A.npairs_out = b->d_npairs;
@@ -489,9 +501,10 @@ extern "C" int bsx_batch_run_range(bsx_batch *b, uint32_t first_unit, uint32_t n
     A.heavy_list = b->d_heavy_list; A.heavy_count = b->d_heavy_count;
     A.leak_exact = b->leak_exact; A.n_hist = b->leak_exact ? b->n_hist : 0;
     for (int m = 0; m < 2; m++) { A.hist_seq[m] = b->d_hist_seq[m]; A.hist_off[m] = b->d_hist_off[m]; A.hist_qual[m] = b->d_hist_qual[m]; }
-    A.heavy_threshold = b->ref->P.rrbs ? 0u : (uint32_t)g_heavy_threshold;
+    A.heavy_threshold = (uint32_t)g_heavy_threshold;
     HIP_TRY(hipMemsetAsync(b->d_queue, 0, 4, b->stream));
     HIP_TRY(hipMemsetAsync(b->d_heavy_count, 0, 4, b->stream));
+    HIP_TRY(hipMemsetAsync(b->d_redo, 0, 4, b->stream));
     if (b->debug) HIP_TRY(hipMemsetAsync(b->d_scratch, 0, (size_t)b->max_units * b->slab_bytes, b->stream));
     HIP_TRY(hipEventRecord(b->ev0, b->stream));
     if (b->leak_exact && !b->ref->P.rrbs) {  // pre-pass of the exact mode: planner state that leaks from earlier reads
@@ -502,7 +515,7 @@ extern "C" int bsx_batch_run_range(bsx_batch *b, uint32_t first_unit, uint32_t n
     }
     bsx_launch_align(A, b->paired, b->grid_blocks, b->stream);
     HIP_TRY(hipGetLastError());
-    b->last_heavy = 0; b->last_heavy_iters = 0; b->scan_ev_used = 0;
+    b->last_heavy = 0; b->last_heavy_iters = 0; b->last_redo = 0; b->scan_ev_used = 0;
     if (A.heavy_threshold) {
         // heavy pipeline: iterate k_hctrl / k_hscan until every deferred unit is finished (host-driven, so this call
         // returns only after the deferred units are done; units that were not deferred are already complete)
@@ -600,6 +613,21 @@ extern "C" int bsx_batch_run_range(bsx_batch *b, uint32_t first_unit, uint32_t n
             }
             HIP_TRY(hipEventRecord(b->ev_sync, b->stream_hi));            // the main stream continues behind the last control pass
             HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_sync, 0));
+        }
+    }
+    if (A.heavy_threshold && b->last_heavy) {
+        // deferred units whose small duplicate set overflowed (single-end RRBS only, see k_hctrl): the main kernel redoes them,
+        // undeferred, with its large per-wave set
+        HIP_TRY(hipMemcpyAsync(b->h_pinned, b->d_redo, 4, hipMemcpyDeviceToHost, b->stream));
+        HIP_TRY(hipStreamSynchronize(b->stream));
+        const uint32_t n_redo = b->h_pinned[0];
+        b->last_redo = n_redo;
+        if (n_redo) {
+            AlignArgs R = A;
+            R.unit_list = b->d_redo + 1; R.first_unit = 0; R.n_units = n_redo; R.heavy_threshold = 0;
+            HIP_TRY(hipMemsetAsync(b->d_queue, 0, 4, b->stream));
+            bsx_launch_align(R, b->paired, std::min<int>(b->grid_blocks, (int)((n_redo + 3) / 4)), b->stream);
+            HIP_TRY(hipGetLastError());
         }
     }
     HIP_TRY(hipEventRecord(b->ev1, b->stream));
@@ -742,6 +770,14 @@ extern "C" int bsx_batch_last_heavy_units(bsx_batch *b)
     HIP_TRY(hipSetDevice(b->ref->device));
     HIP_TRY(hipStreamSynchronize(b->stream));
     return (int)b->last_heavy;
+}
+
+extern "C" int bsx_batch_last_redo_units(bsx_batch *b)
+{
+    if (!b || !b->ran) return BSX_ERR_STATE;
+    HIP_TRY(hipSetDevice(b->ref->device));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return (int)b->last_redo;
 }
 
 extern "C" int bsx_batch_ctrl_clocks(bsx_batch *b, uint64_t out[24])

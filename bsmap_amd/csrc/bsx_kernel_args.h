@@ -9,6 +9,10 @@ struct AlignArgs {
     int32_t debug;             // 1: scratch slab per unit (lists kept for inspection) instead of per wave
     uint32_t rowcap;           // capacity of one hit / pair list row (= -w + 64, see DESIGN.md "cap overshoot")
     uint32_t kcap, hbits;      // per-mate duplicate-suppression set of a slab: key capacity, log2 of its hash slots (Slab in bsx_align.hip)
+    uint32_t hkcap, hhbits;    // the same for the slabs of deferred units (heavy pipeline)
+    uint64_t hslab_bytes;
+    uint32_t *redo_list, *redo_count;  // deferred units whose small set overflowed: redone by the main kernel (unit_list)
+    const uint32_t *unit_list; // main kernel: process units unit_list[first_unit .. n_units) instead of the range itself
     const uint8_t *seq[2];     // ASCII reads, mate 0 / 1
     const uint64_t *off[2];    // [n_units+1] byte offsets
     const uint8_t *qual[2];    // may be null

@@ -208,6 +208,7 @@ int bsx_set_heavy_threshold(int n_candidates);
  * small values only make it take more rounds / passes — used by the tests to exercise those paths */
 int bsx_set_heavy_limits(uint32_t units_per_round, uint32_t task_pool);
 int bsx_batch_last_heavy_units(bsx_batch *b);   /* units the last run handed to the heavy pipeline */
+int bsx_batch_last_redo_units(bsx_batch *b);    /* of those, units the main kernel had to redo (their duplicate set outgrew the heavy slab; single-end RRBS) */
 
 /* ---- measurement aid ("report both peak and a measured ceiling") -----------------------------------
  * Memory rates of `device` in GB/s (1e9 bytes): streaming read of `bytes`, streaming copy (read + write counted), and

@@ -310,6 +310,7 @@ def test_rrbs_random_options_vs_oracle(seed, oracle, tmp_path_factory):
         assert [int(x) for x in sa.counters()[:4]] == ocnt
         if kw["D"] == "C-CGG" and kw["v"] >= 2 and kw["L"] >= 75:
             assert has.sum() > 300, has.sum()  # the reads really are site-anchored fragments
+        test_rrbs_random_options_vs_oracle.last_heavy = sa.heavy_units()
         sa.close()
     else:
         # mates: the read and the reverse complement of the fragment's other end are not generated here; pair each read with
@@ -332,9 +333,24 @@ def test_rrbs_random_options_vs_oracle(seed, oracle, tmp_path_factory):
             for f in ("chr", "loc", "best_class"):
                 assert np.array_equal(ores[m_][f][sel], out[m_][f][sel]), (m_, f)
         assert [int(x) for x in pa.counters()[:4]] == ocnt
+        test_rrbs_random_options_vs_oracle.last_heavy = pa.heavy_units()
         pa.close()
     gref.close()
     oref.free()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 5, 6, 9, 12, 14, 17, 21])
+def test_rrbs_through_the_heavy_pipeline(seed, oracle, tmp_path_factory):
+    """the same RRBS draws with the heavy-unit threshold forced down to 8 candidates: buckets of {tag, loc} pairs go through the
+    scan kernel (segment / direction filter on the device, chromosome-local positions, per-entry strand), survivors through the
+    one-at-a-time replay with the fragment-size filter, every round runs (RRBS has no early stop) — hits, picks, pairs and the
+    work counters must not change"""
+    B.lib().bsx_set_heavy_threshold(8)
+    try:
+        test_rrbs_random_options_vs_oracle(seed, oracle, tmp_path_factory)
+        assert test_rrbs_random_options_vs_oracle.last_heavy > 50
+    finally:
+        B.lib().bsx_set_heavy_threshold(32768)
 
 
 def test_empty_and_degenerate_inputs(edge_genome, oracle):
@@ -424,6 +440,7 @@ def test_heavy_pipeline_large_buckets(pe, heavy_genome, oracle, extra=None):
         sa.ImportBatchReads((sb, so)).Do_Batch()
         hits, cc = sa.results()
         assert sa.heavy_units() > 500
+        test_heavy_pipeline_large_buckets.last_redo = sa.redo_units()
         assert np.array_equal(ores["n_hit"][:, :7], cc["n_hit"][:, :7]) and np.array_equal(ores["n_chit"][:, :7], cc["n_chit"][:, :7])
         has = ores["n_best"] > 0
         for f in ("chr", "loc", "best_class"):
@@ -439,6 +456,7 @@ def test_heavy_pipeline_large_buckets(pe, heavy_genome, oracle, extra=None):
         pa.ImportBatchReads((s1, o1), (s2, o2)).Do_Batch()
         out, ca, cb, npairs = pa.results()
         assert pa.heavy_units() > 500
+        test_heavy_pipeline_large_buckets.last_redo = pa.redo_units()
         assert np.array_equal(ores["paired"], out["paired"]) and np.array_equal(ores["n_pairs"][:, :13], npairs[:, :13])
         for m, cnts in (("a", ca), ("b", cb)):
             assert np.array_equal(ores[m]["n_hit"][:, :7], cnts["n_hit"][:, :7]) and np.array_equal(ores[m]["n_chit"][:, :7], cnts["n_chit"][:, :7]), m
@@ -449,6 +467,16 @@ def test_heavy_pipeline_large_buckets(pe, heavy_genome, oracle, extra=None):
         pa.close()
     gref.close()
     oref.free()
+
+
+@pytest.mark.parametrize("pe", [False, True], ids=["se", "pe"])
+def test_heavy_units_redone_when_their_duplicate_set_overflows(pe, heavy_genome, oracle, monkeypatch):
+    """the slabs of deferred units carry a small duplicate-suppression set; a unit that outgrows it (single-end RRBS in practice,
+    forced here with a 64-key set) is handed back to the main kernel, which redoes it undeferred — records and work counters as
+    if nothing had happened"""
+    monkeypatch.setenv("BSX_HEAVY_KCAP", "64")
+    test_heavy_pipeline_large_buckets(pe, heavy_genome, oracle)
+    assert test_heavy_pipeline_large_buckets.last_redo > 20
 
 
 @pytest.mark.parametrize("extra", [dict(w=20), dict(w=3, r=0), dict(w=150, n=1), dict(r=0, v=3)], ids=["w20", "w3_r0", "w150_n1", "r0_v3"])
