@@ -83,6 +83,7 @@ struct BlockLds {
 // wave-uniform per-mate state; cnt_reg / key_reg are lane-distributed tables
 struct Mate {
     int len, raw_len, max_snp, seedseg, filtered;
+    int nfull;           // len / seed_size (RRBS: cmodeindex = nfull - 1 - segment, align.cpp:221)
     uint32_t flags;      // bit0 flag_chain, bit1 cflag_chain, bit2 duplicate-suppression set overflowed (RRBS single-end only)
     uint32_t snp_thres;
     uint32_t nkeys;
@@ -207,6 +208,7 @@ __device__ void load_and_filter(const AlignArgs &A, MateLds &L, Mate &M, int mat
     M.max_snp = M.filtered ? 0 : (int)(((uint64_t)(P.max_snp_num + 1) * (uint64_t)(len - 1)) / (uint64_t)M.raw_len);
     const int x = (len - P.index_interval + 1) / P.seed_size, y = M.max_snp + 1;  // align.cpp:440
     M.seedseg = M.filtered ? 0 : min(x, y);
+    M.nfull = len / P.seed_size;
     M.snp_thres = (uint32_t)M.max_snp;
     M.nkeys = 0;
     M.cnt_reg = 0;
@@ -696,8 +698,12 @@ __device__ __forceinline__ CandList make_list(const DevParams &P, const BlockLds
             const int a = BL.prof[seg][0];
             const int coff = orient ? (M.len % P.seed_size) : 0;  // cseed_offset (align.cpp:443)
             const uint32_t key = seed_key_at(P, L.w[orient], a + coff + L.start[orient][seg]);
-            const U2 b = *reinterpret_cast<const U2 *>(P.bucket_off + key);
-            cl.sub_base = b.a; cl.sub_n = b.b - b.a; cl.sub_h = (uint32_t)(a + coff);
+            // the entries of this read's (segment, direction) are a contiguous part of the bucket (bsx_index_build_rrbs);
+            // a group outside 0..15 has no entry (the reference's tag filter rejects the whole bucket)
+            const uint32_t g_ = orient ? (uint32_t)(M.nfull - 1 - seg) : (uint32_t)seg;  // cmodeindex (align.cpp:221) / modeindex
+            const U2 b = *reinterpret_cast<const U2 *>(P.rrbs_goff + (size_t)key * 32 + (orient << 4) + (g_ & 15));
+            cl.sub_base = b.a; cl.sub_n = g_ > 15u ? 0u : b.b - b.a;
+            cl.sub_h = (uint32_t)(a + coff);
         } else {
             const int ph = lane >> 1;
             const int a = BL.prof[seg][ph], st = L.start[orient][seg];
@@ -730,7 +736,7 @@ __device__ int wave_scan_range(const DevParams &P, const BlockLds &BL, const Mat
     uint32_t rw[9], rm[9];  // read words + masks in scalar registers
 #pragma unroll
     for (int t = 0; t < 9; t++) { rw[t] = rfl(L.w[orient][t]); rm[t] = rfl(L.m[orient][t]); }
-    const int cmode = M.len / P.seed_size - 1 - seg;  // cmodeindex (align.cpp:221)
+    const int cmode = M.nfull - 1 - seg;  // cmodeindex (align.cpp:221)
     int status = 0;
     // BSX_SCAN_NB chunks of 64 candidates per step: all their index entries are requested together, then all their
     // first reference words, and only then are the chunks evaluated one after the other in list order (two memory
@@ -1356,7 +1362,7 @@ struct ListReq { uint32_t nsub, total, nwords, len, thres, rrbs, tag_xor, tag_wa
                  uint32_t sub_pre[32], sub_n[32], sub_base[32], sub_h[32]; uint32_t rw[12], rm[12]; };
 struct HMate {
     int32_t len, raw_len, max_snp, seedseg, filtered;
-    uint32_t flags, snp_thres, nkeys, index, pad[7];
+    uint32_t flags, snp_thres, nkeys, index, nfull, pad[6];
     uint32_t cnt_reg[64], key_reg[64], bloom0[64], bloom1[64];
     uint32_t w[2][10], m[2][10];
     uint8_t start[2][16], order[2][16];
@@ -1396,7 +1402,7 @@ __device__ void save_mate(HMate &d, const Mate &M, const MateLds &L, int lane)
 {
     if (lane == 0) {
         d.len = M.len; d.raw_len = M.raw_len; d.max_snp = M.max_snp; d.seedseg = M.seedseg; d.filtered = M.filtered;
-        d.flags = M.flags; d.snp_thres = M.snp_thres; d.nkeys = M.nkeys; d.index = M.index;
+        d.flags = M.flags; d.snp_thres = M.snp_thres; d.nkeys = M.nkeys; d.index = M.index; d.nfull = (uint32_t)M.nfull;
     }
     d.cnt_reg[lane] = M.cnt_reg; d.key_reg[lane] = M.key_reg; d.bloom0[lane] = M.bloom0; d.bloom1[lane] = M.bloom1;
     if (lane < 20) { (&d.w[0][0])[lane] = (&L.w[0][0])[lane]; (&d.m[0][0])[lane] = (&L.m[0][0])[lane]; }
@@ -1407,7 +1413,7 @@ __device__ void load_mate(const HMate &d, Mate &M, MateLds &L, int lane)
 {
     M.len = (int)rfl((uint32_t)d.len); M.raw_len = (int)rfl((uint32_t)d.raw_len); M.max_snp = (int)rfl((uint32_t)d.max_snp);
     M.seedseg = (int)rfl((uint32_t)d.seedseg); M.filtered = (int)rfl((uint32_t)d.filtered);
-    M.flags = rfl(d.flags); M.snp_thres = rfl(d.snp_thres); M.nkeys = rfl(d.nkeys); M.index = rfl(d.index);
+    M.flags = rfl(d.flags); M.snp_thres = rfl(d.snp_thres); M.nkeys = rfl(d.nkeys); M.index = rfl(d.index); M.nfull = (int)rfl(d.nfull);
     M.defer = 0;
     M.cnt_reg = d.cnt_reg[lane]; M.key_reg = d.key_reg[lane]; M.bloom0 = d.bloom0[lane]; M.bloom1 = d.bloom1[lane];
     if (lane < 20) { (&L.w[0][0])[lane] = (&d.w[0][0])[lane]; (&L.m[0][0])[lane] = (&d.m[0][0])[lane]; }
@@ -1607,7 +1613,7 @@ __device__ int snp_align_heavy(const AlignArgs &A, const HeavyArgs &H, HState *S
                     if (lane == 0) {
                         R.nsub = (uint32_t)cl.nsub; R.total = cl.total; R.nwords = (uint32_t)((M.len + 15) >> 4); R.len = (uint32_t)M.len; R.thres = M.snp_thres;
                         R.rrbs = P.rrbs ? 1u : 0u;  // tag filter of align.cpp:187,229: forward reads want their segment, rc reads cmodeindex with the direction bit flipped
-                        R.tag_xor = orient ? 0x1000000u : 0u; R.tag_want = orient ? (uint32_t)(M.len / P.seed_size - 1 - seg) : (uint32_t)seg;
+                        R.tag_xor = orient ? 0x1000000u : 0u; R.tag_want = orient ? (uint32_t)(M.nfull - 1 - seg) : (uint32_t)seg;
                         S->t0 = t0; S->n_tasks = nt; S->win_c0 = K.c; S->win_n = wn;
                     }
                     K.have = 1;

@@ -114,7 +114,7 @@ extern "C" void bsx_ref_destroy(bsx_ref *r)
     if (!r) return;
     (void)hipSetDevice(r->device);
     for (void *q : {(void *)r->d_refcat, (void *)r->d_anchor, (void *)r->d_chr_size, (void *)r->d_rc_offset,
-                    (void *)r->d_bucket_off, (void *)r->d_bucket_nfwd, (void *)r->d_entries, (void *)r->d_sites, (void *)r->d_site_off})
+                    (void *)r->d_bucket_off, (void *)r->d_bucket_nfwd, (void *)r->d_entries, (void *)r->d_sites, (void *)r->d_site_off, (void *)r->d_rrbs_goff})
         if (q) (void)hipFree(q);
     delete r;
 }
@@ -161,7 +161,10 @@ extern "C" int bsx_index_download(const bsx_ref *r, uint32_t *bucket_off, uint32
     const size_t K = r->P.total_kmers;
     if (bucket_off) HIP_TRY(hipMemcpy(bucket_off, r->d_bucket_off, (K + 1) * 4, hipMemcpyDeviceToHost));
     if (bucket_nfwd) HIP_TRY(hipMemcpy(bucket_nfwd, r->d_bucket_nfwd, K * 4, hipMemcpyDeviceToHost));
-    if (entries && r->n_entries) HIP_TRY(hipMemcpy(entries, r->d_entries, r->n_entries * (r->P.rrbs ? 8 : 4), hipMemcpyDeviceToHost));
+    if (entries && r->n_entries) {
+        if (r->P.rrbs && !r->rrbs_entries_host.empty()) memcpy(entries, r->rrbs_entries_host.data(), r->n_entries * 8);  // the reference's order (the device copy is grouped)
+        else HIP_TRY(hipMemcpy(entries, r->d_entries, r->n_entries * (r->P.rrbs ? 8 : 4), hipMemcpyDeviceToHost));
+    }
     return BSX_OK;
 }
 extern "C" uint32_t bsx_ref_n_sites(const bsx_ref *r, uint32_t c) { return (r && c < r->sites.size()) ? (uint32_t)r->sites[c].size() : 0; }
@@ -193,7 +196,7 @@ void bsx_fill_devparams(const bsx_ref *r, DevParams &d)
     d.n_chr = r->n_chr;
     d.refcat = r->d_refcat; d.crefcat = r->d_crefcat; d.anchor = r->d_anchor; d.chr_size = r->d_chr_size; d.rc_offset = r->d_rc_offset;
     d.bucket_off = r->d_bucket_off; d.bucket_nfwd = r->d_bucket_nfwd; d.entries = r->d_entries;
-    d.sites = r->d_sites; d.site_off = r->d_site_off;
+    d.sites = r->d_sites; d.site_off = r->d_site_off; d.rrbs_goff = r->d_rrbs_goff;
 }
 
 // ---------------------------------------------------------------------------------------------------------------

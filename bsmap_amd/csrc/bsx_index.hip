@@ -171,6 +171,29 @@ int bsx_index_build_rrbs(bsx_ref *r, const std::vector<uint32_t> &refcat, const 
             ent.assign(2 * (size_t)off[K] + 64, 0);
         }
     }
+    // The kernels walk the entries of a bucket that carry the read's segment and direction (align.cpp:187,229).  The reference
+    // filters the whole bucket; here every bucket is stably partitioned by (segment, direction) — the visiting order among
+    // the entries of one group is unchanged, and that is all the reference's loop observes — with an offset table per
+    // (bucket, group), so a read's candidates are one contiguous range (24 x fewer entries streamed at hg38 size).
+    // bsx_index_download still returns the reference's own order (kept on the host).
+    bool grouped = P.max_seedseg_num <= 16;
+    std::vector<uint32_t> goff, gent;
+    if (grouped) {
+        goff.assign((size_t)K * 32 + 1, 0);
+        gent.assign(ent.size(), 0);
+        for (uint32_t k = 0; k < K; k++) {
+            uint32_t cnt[32] = {0};
+            for (uint32_t q = off[k]; q < off[k + 1]; q++) { const uint32_t t = ent[2 * (size_t)q]; cnt[((t >> 16) & 15u) + 16u * (t >> 24)]++; }
+            uint32_t at = off[k], pos[32];
+            for (int g = 0; g < 32; g++) { goff[(size_t)k * 32 + g] = at; pos[g] = at; at += cnt[g]; }
+            for (uint32_t q = off[k]; q < off[k + 1]; q++) {
+                const uint32_t t = ent[2 * (size_t)q], w = pos[((t >> 16) & 15u) + 16u * (t >> 24)]++;
+                gent[2 * (size_t)w] = t; gent[2 * (size_t)w + 1] = ent[2 * (size_t)q + 1];
+            }
+        }
+        goff[(size_t)K * 32] = off[K];
+        r->rrbs_entries_host.assign(ent.begin(), ent.begin() + 2 * (size_t)off[K]);
+    }
     std::vector<uint32_t> site_off(r->n_chr + 1, 0), sites_flat;
     for (uint32_t c = 0; c < r->n_chr; c++) { site_off[c + 1] = site_off[c] + (uint32_t)r->sites[c].size(); sites_flat.insert(sites_flat.end(), r->sites[c].begin(), r->sites[c].end()); }
     sites_flat.push_back(0);  // one-past-the-end read of the reference (dbseq.cpp:562) lands on a defined 0
@@ -179,7 +202,13 @@ int bsx_index_build_rrbs(bsx_ref *r, const std::vector<uint32_t> &refcat, const 
         return BSX_ERR_NOMEM;
     HIP_TRY(hipMemcpy(d_off.p, off.data(), ((size_t)K + 1) * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(d_nfwd.p, 0, (size_t)K * 4));
-    HIP_TRY(hipMemcpy(d_ent.p, ent.data(), ent.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_ent.p, grouped ? gent.data() : ent.data(), ent.size() * 4, hipMemcpyHostToDevice));
+    if (grouped) {
+        DevBuf<uint32_t> d_goff;
+        if (d_goff.alloc(goff.size())) return BSX_ERR_NOMEM;
+        HIP_TRY(hipMemcpy(d_goff.p, goff.data(), goff.size() * 4, hipMemcpyHostToDevice));
+        r->d_rrbs_goff = d_goff.release();
+    }
     HIP_TRY(hipMemcpy(d_sites.p, sites_flat.data(), sites_flat.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_soff.p, site_off.data(), site_off.size() * 4, hipMemcpyHostToDevice));
     r->d_bucket_off = d_off.release(); r->d_bucket_nfwd = d_nfwd.release(); r->d_entries = d_ent.release();

@@ -34,6 +34,8 @@ struct DevParams {
     const uint32_t *bucket_off, *bucket_nfwd, *entries;
     // RRBS site table
     const uint32_t *sites, *site_off;
+    // RRBS: entries of a bucket grouped by (segment + 16 * direction); rrbs_goff[key * 32 + group] = first entry (null: ungrouped)
+    const uint32_t *rrbs_goff;
 };
 
 struct Block { uint32_t id, begin, end; };
@@ -53,7 +55,8 @@ struct bsx_ref {
     // device
     uint32_t *d_refcat = nullptr, *d_crefcat = nullptr, *d_anchor = nullptr, *d_chr_size = nullptr, *d_rc_offset = nullptr;
     uint32_t *d_bucket_off = nullptr, *d_bucket_nfwd = nullptr, *d_entries = nullptr;
-    uint32_t *d_sites = nullptr, *d_site_off = nullptr;
+    uint32_t *d_sites = nullptr, *d_site_off = nullptr, *d_rrbs_goff = nullptr;
+    std::vector<uint32_t> rrbs_entries_host;  // RRBS entries in the reference's order (the device copy is grouped, see bsx_index_build_rrbs)
     uint64_t n_entries = 0;
     bool has_index = false;
     uint64_t synth_seed = 0;
