@@ -96,7 +96,7 @@ def main():
     ap.add_argument("--pairs-per-step", type=int, default=1 << 20, help="units (pairs, or single reads) per step")
     ap.add_argument("--genome", default="hg38", help="hg38 (3.09 Gbp synthetic, the bench config) or a fraction like 0.05 for quick checks")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of each cpu_baseline sample (0 = skip)")
-    ap.add_argument("--e2e-pairs", type=int, default=8 << 20, help="pairs of the end-to-end CLI run (FASTQ -> SAM in /dev/shm) reported beside the metric; 0 = skip")
+    ap.add_argument("--e2e-pairs", type=int, default=16 << 20, help="pairs of the end-to-end CLI run (FASTQ -> SAM in /dev/shm) reported beside the metric; 0 = skip")
     ap.add_argument("--in-flight", type=int, default=2, help="batches in flight per GPU (host threads, one device batch each): the main kernel of one "
                     "batch (bound by random HBM requests) overlaps the scan passes of the other; 1 = strictly one Do_Batch at a time")
     ap.add_argument("--transfer-steps", type=int, default=6, help="steps of the PCIe-inclusive leg (upload -> Do_Batch -> results per step); 0 = skip")
@@ -429,16 +429,36 @@ def end_to_end(pairs, genome):
         return {"error": str(e)[:300]}
 
 
+def usable_cpus():
+    """CPUs this process can use: the affinity mask cut down to the cgroup CPU quota (a box that shows 256 hardware threads
+    may allow 16 CPUs' worth of time; more threads than that only get throttled).  Same rule as csrc/bsx_cpus.h."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = period = None
+    try:
+        q, p_ = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota, period = int(q), int(p_)
+    except (OSError, ValueError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        except (OSError, ValueError):
+            pass
+    if quota and period and quota > 0:
+        n = min(n, max(1, -(-quota // period)))
+    return max(1, n)
+
+
 def cpu_baseline(ref, batch, pe, kw, target_s, first_unit, quals):
     """the oracle (plain-C port of the reference algorithm, pthread batch model of main.cpp:49-73) timed on this box's
     host cores over a bounded sample of the SAME reads against the SAME reference + index (copied back from HBM; RRBS: the
     port would first have to pack and index the 3.1 GB text on the host, so that mode reports no CPU figure).  Two thread
-    counts: every core of the box, and 8 — the reference caps its default -p at 8 (param.cpp:8-9)."""
+    counts: every CPU the process may use (usable_cpus()), and 8 — the reference caps its default -p at 8 (param.cpp:8-9)."""
     import numpy as np
     from oracle import oracle_ffi as O
     if kw.get("D"):
         return {"value": None, "unit": "reads/s", "cores": 0, "kind": "port", "sample": "not measured for RRBS: the port would have to pack and index the 3.1 GB text on the host first"}
-    cores = os.cpu_count() or 1
+    cores, hw = usable_cpus(), os.cpu_count() or 1
     f, c = ref.words()
     a, s, r = ref.info()
     off, nf, ent = ref.index()
@@ -475,8 +495,9 @@ def cpu_baseline(ref, batch, pe, kw, target_s, first_unit, quals):
     n, t = sample(cores)
     n8, t8 = sample(min(8, cores))
     rp = 2 if pe else 1
-    return {"value": n * rp / t, "unit": "reads/s", "cores": cores, "kind": "port",
-            "sample": f"{n} {'pairs' if pe else 'reads'} of the timed workload ({L} nt), oracle/bsx_oracle.c with {cores} pthreads, {t:.1f} s",
+    return {"value": n * rp / t, "unit": "reads/s", "cores": cores, "kind": "port", "hardware_threads": hw,
+            "sample": f"{n} {'pairs' if pe else 'reads'} of the timed workload ({L} nt), oracle/bsx_oracle.c with {cores} pthreads"
+                      f" (the CPUs this process may use: affinity mask and cgroup quota; the box shows {hw} hardware threads), {t:.1f} s",
             "p8": {"value": n8 * rp / t8, "cores": min(8, cores), "sample": f"{n8} {'pairs' if pe else 'reads'}, {min(8, cores)} pthreads (the reference's default -p cap), {t8:.1f} s"}}
 
 

@@ -28,6 +28,7 @@
 #include <vector>
 
 #include "../../include/bsx.h"
+#include "bsx_cpus.h"
 #include "bsx_reads.h"
 #include "bsx_bam_out.h"
 
@@ -606,10 +607,13 @@ int main(int argc, char **argv)
         for (int d = 0; d < ND; d++) dl += (d ? "," : "") + to_string(o.devices[d]);
         if (pe) cout << "Pair-end alignment(GPU " << dl << ")\n"; else cout << "Single read alignment(GPU " << dl << ")\n";
     }
-    const int workers = o.num_procs > 0 ? o.num_procs : (int)min(64u, max(1u, thread::hardware_concurrency()));
+    // format workers: the CPUs this process may use (affinity mask and cgroup quota, not the hardware thread count) less the
+    // parse, GPU-driver and write threads; oversubscribing a quota throttles every thread, the ones feeding the GPU included
+    const unsigned ncpu = bsx_usable_cpus();
+    const int workers = o.num_procs > 0 ? o.num_procs : (int)min(64u, max(1u, ncpu > 8 ? ncpu - 4 : ncpu));
     Formatter totals(o, rv);
     unsigned total = 0;
-    double busy[4] = {0, 0, 0, 0};
+    double busy[4] = {0, 0, 0, 0}, gpu_part[3] = {0, 0, 0};  // gpu_part: upload, align, read-back
     t_pin.join();
     const double t_map0 = now_s();
 
@@ -660,6 +664,7 @@ int main(int argc, char **argv)
         bsx_batch *batch = batches[g];
         for (long k = g; ring.acquire(k, 1); k += NG) {
             const double t = now_s();
+            double t1 = t, t2 = t;
             Slot &s = ring.at(k);
             const uint32_t n = (uint32_t)s.n;
             int r;
@@ -673,7 +678,9 @@ int main(int argc, char **argv)
             if (!pe) {
                 r = bsx_batch_upload_se(batch, n, s.A.seq.data(), s.A.soff.data(), ra.format != 1 ? s.A.upload_qual() : nullptr, s.A.first_index);
                 if (r) die(r, "uploading reads");
+                t1 = now_s();
                 if ((r = bsx_batch_run(batch)) || (r = bsx_batch_sync(batch))) die(r, "aligning");
+                t2 = now_s();
                 s.hits.resize(n); s.cca.resize(n);
                 if ((r = bsx_batch_results_se(batch, s.hits.data(), s.cca.data()))) die(r, "reading results");
             } else {
@@ -681,11 +688,13 @@ int main(int argc, char **argv)
                 r = bsx_batch_upload_pe(batch, n, s.A.seq.data(), s.A.soff.data(), q ? s.A.upload_qual() : nullptr, s.B.seq.data(), s.B.soff.data(),
                                         q ? s.B.upload_qual() : nullptr, s.A.first_index);
                 if (r) die(r, "uploading reads");
+                t1 = now_s();
                 if ((r = bsx_batch_run(batch)) || (r = bsx_batch_sync(batch))) die(r, "aligning");
+                t2 = now_s();
                 s.pairs.resize(n); s.cca.resize(n); s.ccb.resize(n);
                 if ((r = bsx_batch_results_pe(batch, s.pairs.data(), s.cca.data(), s.ccb.data(), nullptr))) die(r, "reading results");
             }
-            { lock_guard<mutex> lk(mu_busy); busy[1] += now_s() - t; }
+            { const double t3 = now_s(); lock_guard<mutex> lk(mu_busy); busy[1] += t3 - t; gpu_part[0] += t1 - t; gpu_part[1] += t2 - t1; gpu_part[2] += t3 - t2; }
             ring.release(k, 2);
         }
     };
@@ -696,7 +705,9 @@ int main(int argc, char **argv)
             const double t = now_s();
             Slot &s = ring.at(k);
             const int W = (int)min<size_t>((size_t)workers, max<size_t>(1, s.n / 1024));
-            s.out.assign(W, Text()); s.out_unpair.assign(W, Text());
+            // the slot's text buffers keep their capacity from batch to batch (a fresh 0.7 GB per batch would be page-faulted in again)
+            if ((int)s.out.size() != W) { s.out.assign(W, Text()); s.out_unpair.assign(W, Text()); }
+            else for (int w = 0; w < W; w++) { s.out[w].s.clear(); s.out_unpair[w].s.clear(); }
             vector<Formatter> fm(W, Formatter(o, rv));
             auto work = [&](int w) {
                 const size_t lo = s.n * w / W, hi = s.n * (w + 1) / W;
@@ -791,8 +802,8 @@ int main(int argc, char **argv)
     cout << "Total time consumed:  " << t_end - t_begin << " secs\n";
     if (getenv("BSX_TIMING"))  // machine-readable phase times (extension; stderr so that stdout keeps the reference's lines)
         fprintf(stderr, "{\"load_reference_s\": %.3f, \"index_build_s\": %.3f, \"mapping_s\": %.3f, \"units\": %u, \"reads\": %u, \"workers\": %d, "
-                        "\"stage_busy_s\": {\"parse\": %.3f, \"gpu\": %.3f, \"format\": %.3f, \"write\": %.3f}}\n",
-                t_loaded - t0, t_indexed - t_loaded, t_map1 - t_map0, total, pe ? 2 * total : total, workers, busy[0], busy[1], busy[2], busy[3]);
+                        "\"stage_busy_s\": {\"parse\": %.3f, \"gpu\": %.3f, \"format\": %.3f, \"write\": %.3f, \"gpu_upload\": %.3f, \"gpu_align\": %.3f, \"gpu_readback\": %.3f}}\n",
+                t_loaded - t0, t_indexed - t_loaded, t_map1 - t_map0, total, pe ? 2 * total : total, workers, busy[0], busy[1], busy[2], busy[3], gpu_part[0], gpu_part[1], gpu_part[2]);
     for (int g = 0; g < NG; g++) bsx_batch_destroy(batches[g]);
     for (bsx_ref *r : refs) bsx_ref_destroy(r);
     return 0;

@@ -14,6 +14,7 @@
 #include <sstream>
 #include <thread>
 
+#include "bsx_cpus.h"
 #include "bsx_internal.h"
 
 thread_local std::string g_bsx_err;
@@ -270,7 +271,7 @@ int bsx_pack_fasta(const bsx_params &P, const char *text, uint64_t n, bsx_ref &r
         std::atomic<size_t> next(0);
         auto work = [&] { for (size_t i; (i = next.fetch_add(1)) < recs.size();) pack_record(P, text, recs[i], (uint32_t)i, code_f, code_r, cls, pk[i]); };
         // large records first would balance better, but FASTA files list the long chromosomes first anyway
-        const size_t nt = std::min<size_t>(recs.size(), n < (8u << 20) ? 1 : std::max(1u, std::min(32u, std::thread::hardware_concurrency())));
+        const size_t nt = std::min<size_t>(recs.size(), n < (8u << 20) ? 1 : std::max(1u, std::min(32u, bsx_usable_cpus())));
         std::vector<std::thread> th;
         for (size_t t = 1; t < nt; t++) th.emplace_back(work);
         work();

@@ -30,6 +30,7 @@
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
 
+#include "bsx_cpus.h"
 #include "bsx_internal.h"
 
 namespace {
@@ -504,7 +505,7 @@ int stream_bam(const char *base, size_t len, const std::unordered_map<std::strin
                     inflateEnd(&z);
                 }
             };
-            const size_t nt = std::min<size_t>(std::max<size_t>(1, (bj - bi) / 16), std::max(1u, std::min(32u, std::thread::hardware_concurrency())));
+            const size_t nt = std::min<size_t>(std::max<size_t>(1, (bj - bi) / 16), std::max(1u, std::min(32u, bsx_usable_cpus())));
             std::vector<std::thread> th;
             for (size_t t = 1; t < nt; t++) th.emplace_back(work);
             work();
@@ -617,7 +618,7 @@ extern "C" int bsx_meth_add_file(bsx_meth *m, const char *path, int sam, const c
     for (size_t p0 = 0; p0 < len && rc == BSX_OK;) {
         size_t p1 = std::min(len, p0 + piece);
         if (p1 < len) { const char *nl = (const char *)memchr(base + p1, '\n', len - p1); p1 = nl ? (size_t)(nl - base) + 1 : len; }
-        const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min(32u, std::max(1u, std::thread::hardware_concurrency())), (p1 - p0) / (1u << 20) + 1));
+        const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min(32u, std::max(1u, bsx_usable_cpus())), (p1 - p0) / (1u << 20) + 1));
         std::vector<size_t> cut(nt + 1, p1);
         cut[0] = p0;
         for (unsigned t = 1; t < nt; t++) {
@@ -684,7 +685,7 @@ extern "C" int bsx_meth_write_table(bsx_meth *m, const char *path, uint32_t n_or
         if (hipMemcpy(ctx.data(), m->d_ctx, (size_t)rows * 8, hipMemcpyDeviceToHost) != hipSuccess) { rc = BSX_ERR_DEVICE; break; }
         const char *name = chr_names ? chr_names[c] : m->names[c].c_str();
         // rows are formatted by a pool of threads, each a contiguous range, and written in order
-        const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min(32u, std::max(1u, std::thread::hardware_concurrency())), rows / 65536 + 1));
+        const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min(32u, std::max(1u, bsx_usable_cpus())), rows / 65536 + 1));
         std::vector<std::string> parts(nt);
         auto fmt = [&](unsigned t) {
             std::string &o = parts[t];
@@ -783,7 +784,7 @@ extern "C" int bsx_meth_create_from_fasta(const char *path, const char *chroms_c
                 }
             }
         };
-        const size_t nt = std::min<size_t>(recs.size(), std::max(1u, std::min(32u, std::thread::hardware_concurrency())));
+        const size_t nt = std::min<size_t>(recs.size(), std::max(1u, std::min(32u, bsx_usable_cpus())));
         std::vector<std::thread> th;
         for (size_t t = 1; t < nt; t++) th.emplace_back(work);
         work();
