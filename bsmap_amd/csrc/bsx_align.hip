@@ -33,6 +33,41 @@ typedef unsigned long long u64;
 struct __attribute__((packed, aligned(4))) U4 { uint32_t a, b, c, d; };
 struct __attribute__((packed, aligned(4))) U2 { uint32_t a, b; };
 
+// Loads of the main kernel (k_align) and the control kernel: random one-touch gathers over the 172 MB bucket table, the
+// 5.9 GB of entries and the 1.5 GB reference.  -DBSX_MAIN_NT=1 marks them non-temporal so that they do not push the scan
+// kernel's shared lines out of L2 while the two run side by side (two batches in flight).
+#ifndef BSX_MAIN_NT
+#define BSX_MAIN_NT 0
+#endif
+typedef uint32_t v4u_a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef uint32_t v2u_a4 __attribute__((ext_vector_type(2), aligned(4)));
+__device__ __forceinline__ U4 ldm4(const uint32_t *p)
+{
+#if BSX_MAIN_NT
+    const v4u_a4 v = __builtin_nontemporal_load(reinterpret_cast<const v4u_a4 *>(p));
+    return U4{v.x, v.y, v.z, v.w};
+#else
+    return *reinterpret_cast<const U4 *>(p);
+#endif
+}
+__device__ __forceinline__ U2 ldm2(const uint32_t *p)
+{
+#if BSX_MAIN_NT
+    const v2u_a4 v = __builtin_nontemporal_load(reinterpret_cast<const v2u_a4 *>(p));
+    return U2{v.x, v.y};
+#else
+    return *reinterpret_cast<const U2 *>(p);
+#endif
+}
+__device__ __forceinline__ uint32_t ldm1(const uint32_t *p)
+{
+#if BSX_MAIN_NT
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+
 // wave64 ballot straight from the condition bit (HIP's __ballot(int) goes through a 0/1 VGPR and a compare)
 __device__ __forceinline__ unsigned long long bsx_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 // x * 30 + c on the low 24 bits of x in one full-rate instruction (a plain 32-bit multiply is quarter rate); only the
@@ -274,7 +309,7 @@ __device__ void plan_counts(const DevParams &P, MateLds &L, const Mate &M, int o
         const int o = base + lane;
         if (o < n) {
             const uint32_t key = key_at<EXACT>(P, L, M, orient, o);
-            const U2 b = *reinterpret_cast<const U2 *>(P.bucket_off + key);
+            const U2 b = ldm2(P.bucket_off + key);
             const uint32_t c = b.b - b.a;
             L.cnt[orient][o] = P.rrbs ? c : (c ? c + 2 : 0);
         }
@@ -483,9 +518,9 @@ __device__ __forceinline__ CandEval eval_loaded(const uint32_t *rp, const U4 r0,
     if (r.p48 <= thres0) {
         uint32_t wd[7];
         wd[0] = r0.d;
-        if (nwords > 3) { const U4 r1 = *reinterpret_cast<const U4 *>(rp + 4); wd[1] = r1.a; wd[2] = r1.b; wd[3] = r1.c; wd[4] = r1.d; }
+        if (nwords > 3) { const U4 r1 = ldm4(rp + 4); wd[1] = r1.a; wd[2] = r1.b; wd[3] = r1.c; wd[4] = r1.d; }
         else { wd[1] = wd[2] = wd[3] = wd[4] = 0; }
-        if (nwords > 7) { const U2 r2 = *reinterpret_cast<const U2 *>(rp + 8); wd[5] = r2.a; wd[6] = r2.b; }
+        if (nwords > 7) { const U2 r2 = ldm2(rp + 8); wd[5] = r2.a; wd[6] = r2.b; }
         else { wd[5] = wd[6] = 0; }
         uint32_t tot = r.p48;
         r.w01ref = r.p48;
@@ -505,7 +540,7 @@ __device__ __forceinline__ CandEval eval_candidate(const DevParams &P, const uin
                                                    uint32_t p, uint32_t strand, uint32_t thres0)
 {
     const uint32_t *rp = (strand ? P.crefcat : P.refcat) + ((p - 1) >> 4);
-    const U4 r0 = *reinterpret_cast<const U4 *>(rp);
+    const U4 r0 = ldm4(rp);
     return eval_loaded(rp, r0, rw, rm, nwords, p, thres0);
 }
 
@@ -708,8 +743,8 @@ __device__ __forceinline__ CandList make_list(const DevParams &P, const BlockLds
             const int ph = lane >> 1;
             const int a = BL.prof[seg][ph], st = L.start[orient][seg];
             const uint32_t key = key_at<EXACT>(P, L, M, orient, a + st - ph);
-            const U2 b = *reinterpret_cast<const U2 *>(P.bucket_off + key);
-            const uint32_t nf = P.bucket_nfwd[key];
+            const U2 b = ldm2(P.bucket_off + key);
+            const uint32_t nf = ldm1(P.bucket_nfwd + key);
             cl.sub_base = (lane & 1) ? b.a + nf : b.a;
             cl.sub_n = (lane & 1) ? (b.b - b.a - nf) : nf;
             cl.sub_h = (uint32_t)(-a + ph - st);  // h (align.cpp:263)
@@ -768,14 +803,14 @@ __device__ int wave_scan_range(const DevParams &P, const BlockLds &BL, const Mat
                 const uint32_t ps = rl(cl.sub_pre, s), ns = rl(cl.sub_n, s);
                 if (idx >= ps && idx < ps + ns) { e_idx = rl(cl.sub_base, s) + (idx - ps); h = rl(cl.sub_h, s); strand = s & 1; }
             }
-            const uint32_t e = P.entries[e_idx];
+            const uint32_t e = ldm1(P.entries + e_idx);
             if (valid) p = e + h;
         }
         p_[u] = p; aux_[u] = P.rrbs ? rchr : strand; valid_[u] = valid;
       }
 #pragma unroll
       for (int u = 0; u < BSX_SCAN_NB; u++)
-        r0_[u] = *reinterpret_cast<const U4 *>(((P.rrbs ? (aux_[u] & 1) : aux_[u]) ? P.crefcat : P.refcat) + ((p_[u] - 1) >> 4));
+        r0_[u] = ldm4(((P.rrbs ? (aux_[u] & 1) : aux_[u]) ? P.crefcat : P.refcat) + ((p_[u] - 1) >> 4));
 #pragma unroll
       for (int u = 0; u < BSX_SCAN_NB; u++) {
         const uint32_t c0 = cs + 64 * u;

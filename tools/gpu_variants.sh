@@ -1,4 +1,4 @@
-# GPU box: serial-mode bench line for the default library and for each named variant.  usage: bash tools/gpu_variants.sh <tag> [variant ...]
+# GPU box: serial-mode and default-mode (two batches in flight) bench lines for the default library and for each named variant.  usage: bash tools/gpu_variants.sh <tag> [variant ...]
 TAG=$1; shift
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O; cd $R
 for v in default "$@"; do
@@ -12,4 +12,6 @@ try:
 except Exception as e:
     print("$v: no line:", e)
 PY
+  timeout 600 python3 bench.py --steps 6 --warmup 2 --cpu-seconds 0 --e2e-pairs 0 --transfer-steps 0 > $O/${TAG}_${v}_default.json 2>> $O/${TAG}_$v.err
+  python3 -c "import json;d=json.load(open('$O/${TAG}_${v}_default.json'));print('$v: default ms/step %.1f  reads/s %.0f' % (d['ms_per_step'], d['value']))"
 done
