@@ -315,14 +315,15 @@ def kernel_bound():
         import glob
         sq = [f for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sq.json"))) if "k_hscan" in json.load(open(f)).get("kernels", {})][-1]
         k = json.load(open(sq))["kernels"]["k_hscan"]["derived"]
-        vi = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_valu_issue.json")))[-1]))
+        vif = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_valu_issue.json")))[-1]
+        vi = json.load(open(vif))
         mix = [m for m in vi["mixes"] if m["mix"].startswith("k_hscan head word")][0]["by_waves_per_simd"]
         ceil = max(v["chip_G_wave_instr_per_s"] for v in mix.values()) * 1e9
         fr = {"valu_issue": k["valu_instr_per_s"] / ceil, "texture_addresser_busy": k.get("ta_busy_frac"), "l2_hit": k.get("l2_hit_frac"),
               "waiting_on_instruction_issue": k.get("wait_inst_frac")}
         top = max((v, n) for n, v in fr.items() if v is not None and n in ("valu_issue", "texture_addresser_busy"))
         return {"bound": f"{top[1]} ({top[0]:.2f}), co-limited with the other of VALU issue / gather rate; not HBM (L2 hit {fr['l2_hit']:.2f})",
-                "bound_evidence": {"fractions": fr, "valu_ceiling_G_wave_instr_per_s": ceil / 1e9, "sources": [os.path.basename(sq), "r02z_valu_issue.json", "r02k_hscan_marginal_costs.json"]}}
+                "bound_evidence": {"fractions": fr, "valu_ceiling_G_wave_instr_per_s": ceil / 1e9, "sources": [os.path.basename(sq), os.path.basename(vif), "r02k_hscan_marginal_costs.json"]}}
     except Exception:
         return {"bound": None, "bound_evidence": "no counter summary under profiles/"}
 
