@@ -224,3 +224,20 @@ def write_fastq(path, reads, seq_key="seq", qual_key="qual"):
     with open(path, "w") as f:
         for r in reads:
             f.write(f"@{r['name']}\n{r[seq_key]}\n+\n{r[qual_key]}\n")
+
+
+def c1_full_inputs(tmp):
+    """BASELINE.json's configs[0] at its stated size: 1 Mb genome FASTA + 10 000 single-end 36 bp reads (200 of them of
+    varying length, so that the planner-state leak of DESIGN.md §4 occurs); returns (fasta path, fastq path, sha256 of both
+    texts).  tests/golden/c1_full.json.gz holds the real binary's SAM for exactly these files."""
+    import hashlib
+    import os
+    g = make_genome(seed=1, chr_lens=(1_000_000,), gc=0.51)
+    fa = os.path.join(tmp, "c1_genome.fa")
+    write_fasta(fa, g)
+    reads = make_se_reads(g, 9_800, 36, seed=101, sub_rate=0.01, strands=("++", "-+"))
+    reads += make_se_reads(g, 200, 36, seed=102, sub_rate=0.04, strands=("++", "-+"), var_len=True)
+    fq = os.path.join(tmp, "c1_reads.fq")
+    write_fastq(fq, reads)
+    h = hashlib.sha256(open(fa, "rb").read() + open(fq, "rb").read()).hexdigest()
+    return fa, fq, h

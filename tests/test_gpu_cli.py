@@ -296,3 +296,26 @@ def test_cli_bam_output_equals_samtools_pipeline(key, tmp_path):
     assert "Total number of aligned reads" in res.stdout
     n = compare_with_gold(out, gold, skip_names=_undefined_head(meta))
     assert n > 300 and os.path.exists(out + ".bai")
+
+
+def test_c1_at_baseline_size_matches_reference_binary(tmp_path):
+    """BASELINE.json configs[0] at its stated size (10 000 x 36 bp single-end on 1 Mb, -s 12 -v 2): the SAM file is
+    byte-identical to the real `bsmap -p 1` (tests/golden/c1_full.json.gz, made by make_golden_c1_full.py) for EVERY read —
+    BSX_P1_EXACT=1 reproduces the reads whose planner state leaks from their predecessors too."""
+    import bsx_testdata as td
+    gold = json.load(gzip.open(os.path.join(G.GOLDEN, "c1_full.json.gz"), "rt"))
+    fa, fq, h = td.c1_full_inputs(str(tmp_path))
+    assert h == gold["inputs_sha256"], "the seeded generators no longer produce the files the fixture was made from"
+    out = str(tmp_path / "o.sam")
+    res = subprocess.run([BIN, "-a", fq, "-d", fa, "-o", out] + gold["options"], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, BSX_P1_EXACT="1"))
+    assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-1500:]
+    got, exp = _body(open(out).read()), _body(gold["sam"])
+    assert len(exp) > 9000
+    assert got == exp
+    # without the exact mode only leaky reads may differ, and few of them do
+    res = subprocess.run([BIN, "-a", fq, "-d", fa, "-o", out] + gold["options"], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0
+    got = _body(open(out).read())
+    diff = sum(a != b for a, b in zip(got, exp)) + abs(len(got) - len(exp))
+    assert diff <= 40, diff
