@@ -252,7 +252,7 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_note,
                      "kernel": "one Do_Batch = k_align + heavy pipeline (k_hctrl/k_hscan iterations)", "kernel_ms": k_ms,
-                     "event_ms_per_do_batch": float(np.mean(kernel_ms)), "heavy_units_last_step": int(batch.heavy_units()), "algorithmic_bytes_per_launch": alg_bytes_launch,
+                     "event_ms_per_do_batch": float(np.mean(kernel_ms)), "heavy_units_last_step": int(batch.heavy_units()), "redo_units_last_step": int(batch.redo_units()), "algorithmic_bytes_per_launch": alg_bytes_launch,
                      "per_read": {"n_lookup": float(counters[0]) / n_reads_rank, "n_cand": float(counters[1]) / n_reads_rank,
                                   "ref_words64": float(counters[2]) / n_reads_rank},
                      "dominant_kernel": dominant_kernel(serial["counters"], serial["scan_ms"], 2, 1) if serial else dominant_kernel(counters, scan_ms, args.steps, nfl)},

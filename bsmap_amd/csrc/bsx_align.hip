@@ -658,22 +658,29 @@ __device__ int accept_group(const DevParams &P, Mate &M, const Slab &SL, int ori
         if (lane > j && rl(hkey, j) == hkey) cand = false;
     }
     if (!bsx_ballot(cand)) return 0;
+    // RRBS single-end, forward chain: a new coordinate is remembered first and then dropped if its restriction fragment is
+    // out of range (align.cpp:201-207) — `cand` lanes enter the hitset, only `app` lanes are appended and can cause events
+    bool app = cand;
+    if (P.rrbs && !P.pairend && orient == 0 && cand) {
+        const int sl = ccgg_seglen(P, hchr, hloc, M.len);
+        app = !(sl > P.max_insert || sl < P.min_insert);
+    }
     // position inside the class list and the first event
     uint32_t rank = 0, mine = 0, other = 0;
     const uint32_t cmax = min(M.snp_thres, (uint32_t)BSX_MAXSNPS);
     for (uint32_t c = 0; c <= cmax; c++) {
-        const u64 mc = bsx_ballot(cand && ws == c);
+        const u64 mc = bsx_ballot(app && ws == c);
         if (!mc) continue;
         const uint32_t a = n_of(M, orient, (int)c), b = n_of(M, 1 - orient, (int)c);
-        if (cand && ws == c) { rank = (uint32_t)__builtin_popcountll(mc & (lanemask_lt(lane) | (1ull << lane))); mine = a; other = b; }
+        if (app && ws == c) { rank = (uint32_t)__builtin_popcountll(mc & (lanemask_lt(lane) | (1ull << lane))); mine = a; other = b; }
     }
     const uint32_t both = mine + other + rank;
-    const bool ev2 = cand && (((int)ws == mode && !P.pairend && P.report_repeat_hits == 0 && both > 1) || (both >= (uint32_t)P.max_num_hits && ws == 0));
-    const bool ev1 = cand && !ev2 && both >= (uint32_t)P.max_num_hits;
+    const bool ev2 = app && (((int)ws == mode && !P.pairend && P.report_repeat_hits == 0 && both > 1) || (both >= (uint32_t)P.max_num_hits && ws == 0));
+    const bool ev1 = app && !ev2 && both >= (uint32_t)P.max_num_hits;
     const u64 em2 = bsx_ballot(ev2), em = em2 | bsx_ballot(ev1);
     const int E = em ? (int)__builtin_ctzll(em) : 64;
-    const bool commit = cand && lane <= E;
-    const u64 km = bsx_ballot(commit);
+    const bool commit = app && lane <= E, commit_key = cand && lane <= E;
+    const u64 km = bsx_ballot(commit_key);
     if (commit) SL.list(orient, (int)ws)[mine + rank - 1] = ((u64)hchr << 32) | hloc;  // hits[w][n++] = hit
     for (uint32_t c = 0; c <= cmax; c++) {
         const u64 mc = bsx_ballot(commit && ws == c);
@@ -691,8 +698,8 @@ __device__ int accept_group(const DevParams &P, Mate &M, const Slab &SL, int ori
         }
     }
     {
-        if (bsx_ballot(commit && kidx >= SL.kcap)) M.flags |= 4u;  // set full: the unit is flagged and redone (see k_hctrl); nothing is written past the arrays
-        bool pending = commit && kidx >= 64 && kidx < SL.kcap;
+        if (bsx_ballot(commit_key && kidx >= SL.kcap)) M.flags |= 4u;  // set full: the unit is flagged and redone (see k_hctrl); nothing is written past the arrays
+        bool pending = commit_key && kidx >= 64 && kidx < SL.kcap;
         uint32_t h = hset_home(hkey, SL.hbits);
         while (bsx_ballot(pending)) {  // claim by write-then-verify: lanes racing for one empty slot see who landed
             if (pending && SL.hset[h] == 0) SL.hset[h] = hkey + 1;
@@ -837,7 +844,7 @@ __device__ int wave_scan_range(const DevParams &P, const BlockLds &BL, const Mat
                 } else pass = hit_coords(P, BL, p, strand, M.len, hchr, hloc, hkey);
             }
             u64 surv_m = bsx_ballot(pass);  // ordered replay of the survivors
-            if (BSX_SCAN_NB > 1 && !P.rrbs && __builtin_popcountll(surv_m) > BSX_GROUP_MIN) {  // heavy pipeline: 64 at a time, resuming behind every threshold change
+            if (BSX_SCAN_NB > 1 && __builtin_popcountll(surv_m) > BSX_GROUP_MIN) {  // heavy pipeline: 64 at a time, resuming behind every threshold change
                 while (surv_m) {
                     int ls;
                     const int e = accept_group(P, M, SL, orient, mode, surv_m, w, hchr, hloc, hkey, lane, ls);
@@ -1539,7 +1546,7 @@ __device__ int snp_align_heavy(const AlignArgs &A, const HeavyArgs &H, HState *S
                                     if ((uint32_t)lane < total) r = H.tout[t0 + tg + my_t].surv[my_i];
                                     u64 m = total >= 64 ? ~0ull : ((1ull << total) - 1);
                                     m &= surv_coords(P, BL, r, M.len, lane, m);
-                                    if (total > BSX_GROUP_MIN && !P.rrbs) e = accept_group(P, M, SL, orient, mode, m, r.w_ord & 0xff, r.hchr, r.hloc, r.hkey, lane, ls);
+                                    if (total > BSX_GROUP_MIN) e = accept_group(P, M, SL, orient, mode, m, r.w_ord & 0xff, r.hchr, r.hloc, r.hkey, lane, ls);
                                     else
                                         while (m) {
                                             const int l1 = (int)__builtin_ctzll(m);
@@ -1597,7 +1604,7 @@ __device__ int snp_align_heavy(const AlignArgs &A, const HeavyArgs &H, HState *S
                             if (i < nv) r = o->surv[i];
                             u64 m = bsx_ballot(i < nv);
                             m &= surv_coords(P, BL, r, M.len, lane, m);
-                            if (__builtin_popcountll(m) > BSX_GROUP_MIN && !P.rrbs) {
+                            if (__builtin_popcountll(m) > BSX_GROUP_MIN) {
                                 int ls;
                                 const int e = accept_group(P, M, SL, orient, mode, m, r.w_ord & 0xff, r.hchr, r.hloc, r.hkey, lane, ls);
                                 if (e) { event = e; X = tc0 + (rl(r.w_ord, ls) >> 8); }

@@ -16,10 +16,13 @@
 
 static int g_waves_per_cu = 0;
 static int g_heavy_groups = 2;      // unit groups of the heavy pipeline that run out of phase (1 = strictly alternating passes)
-static int g_heavy_threshold = 32768;  // candidate-list length that sends a unit to the heavy pipeline
+static int g_heavy_threshold = 0;  // candidate-list length that sends a unit to the heavy pipeline; 0 = by mode (heavy_threshold_for)
 
 extern "C" int bsx_set_waves_per_cu(int w) { g_waves_per_cu = w; return BSX_OK; }
 extern "C" int bsx_set_heavy_threshold(int t) { g_heavy_threshold = t < 0 ? 0 : t; return BSX_OK; }
+// measured on the BASELINE configs: WGBS is flat from 8 192 to 65 536; RRBS reads of the mid-size repeat families
+// cost the main kernel a millisecond each (one wave, 4 MB slab) and go through the scan kernel instead
+static uint32_t heavy_threshold_for(const bsx_params &p) { return g_heavy_threshold > 0 ? (uint32_t)g_heavy_threshold : (p.rrbs ? 4096u : 32768u); }
 static bool g_user_limits = false;
 static uint32_t g_hcap = 24576, g_task_cap = 524288;  // a 2^20-pair batch defers ~9.4 K units (C3) to ~17.3 K (C5, trimmed reads)
 extern "C" int bsx_set_heavy_limits(uint32_t units_per_round, uint32_t task_pool)
@@ -504,7 +507,7 @@ extern "C" int bsx_batch_run_range(bsx_batch *b, uint32_t first_unit, uint32_t n
     A.heavy_list = b->d_heavy_list; A.heavy_count = b->d_heavy_count;
     A.leak_exact = b->leak_exact; A.n_hist = b->leak_exact ? b->n_hist : 0;
     for (int m = 0; m < 2; m++) { A.hist_seq[m] = b->d_hist_seq[m]; A.hist_off[m] = b->d_hist_off[m]; A.hist_qual[m] = b->d_hist_qual[m]; }
-    A.heavy_threshold = (uint32_t)g_heavy_threshold;
+    A.heavy_threshold = heavy_threshold_for(b->ref->P);
     HIP_TRY(hipMemsetAsync(b->d_queue, 0, 4, b->stream));
     HIP_TRY(hipMemsetAsync(b->d_heavy_count, 0, 4, b->stream));
     HIP_TRY(hipMemsetAsync(b->d_redo, 0, 4, b->stream));

@@ -202,7 +202,8 @@ int bsx_batch_debug_plan(bsx_batch *b, uint32_t unit, int mate, int32_t *start_a
 /* tuning knob: resident waves per CU for the persistent align kernel (default chosen from register use) */
 int bsx_set_waves_per_cu(int waves);
 /* tuning knob: candidate-list length (one SnpAlign call, one read orientation) from which a unit is handed to the
- * heavy pipeline (chip-wide scan tasks + resumable control passes); 0 = never.  Results do not depend on it. */
+ * heavy pipeline (chip-wide scan tasks + resumable control passes); 0 = the library's choice by mode (32768 WGBS, 4096 RRBS),
+ * a value no list reaches = never.  Results do not depend on it. */
 int bsx_set_heavy_threshold(int n_candidates);
 /* pool sizes of the heavy pipeline for batches created afterwards (defaults 24576 units per round and up to 524288 scan tasks, both scaled down for small batches; at most 2^22);
  * small values only make it take more rounds / passes — used by the tests to exercise those paths */

@@ -65,7 +65,7 @@ def test_heavy_path_invariance(big):
         assert pa.heavy_units() == 0
         o2, a2, b2, n2 = pa.results()
     finally:
-        B.lib().bsx_set_heavy_threshold(32768)
+        B.lib().bsx_set_heavy_threshold(0)
     assert o2[:2048].tobytes() == out[:2048].tobytes() and a2[:2048].tobytes() == ca[:2048].tobytes() and n2[:2048].tobytes() == npairs[:2048].tobytes()
 
 

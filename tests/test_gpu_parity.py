@@ -350,7 +350,7 @@ def test_rrbs_through_the_heavy_pipeline(seed, oracle, tmp_path_factory):
         test_rrbs_random_options_vs_oracle(seed, oracle, tmp_path_factory)
         assert test_rrbs_random_options_vs_oracle.last_heavy > 5
     finally:
-        B.lib().bsx_set_heavy_threshold(32768)
+        B.lib().bsx_set_heavy_threshold(0)
 
 
 def test_empty_and_degenerate_inputs(edge_genome, oracle):
@@ -388,7 +388,7 @@ def test_heavy_pipeline_forced_on_edge_cases(name, kw, spec, edge_genome, oracle
     try:
         test_edge_cases_vs_oracle(name, kw, spec, edge_genome, oracle)
     finally:
-        B.lib().bsx_set_heavy_threshold(32768)
+        B.lib().bsx_set_heavy_threshold(0)
 
 
 def test_heavy_pipeline_is_used(edge_genome, oracle):
@@ -404,7 +404,7 @@ def test_heavy_pipeline_is_used(edge_genome, oracle):
         h1, c1 = sa.results()
         n_heavy = sa.heavy_units()
     finally:
-        B.lib().bsx_set_heavy_threshold(32768)
+        B.lib().bsx_set_heavy_threshold(0)
     sa.Do_Batch()
     h2, c2 = sa.results()
     assert n_heavy > 20 and sa.heavy_units() == 0
