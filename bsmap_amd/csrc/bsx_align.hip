@@ -2096,6 +2096,172 @@ __global__ __launch_bounds__(64 * BSX_HSCAN_WPB, BSX_HSCAN_WAVES) void k_hscan(A
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// k_hscan_shared — RRBS: one pass of the reference over a window of candidates for up to HS_SHARE reads at once.
+// RRBS reads start at restriction sites, so the reads that fall into one repeat family walk the same bucket with the same
+// read offset h (align.cpp:175-252: one seed per segment, all starts 0): after the task sort, runs of tasks that cover
+// exactly the same window — same first entry, same length, same h and tag filter — sit next to each other (tens of
+// thousands of reads per window on the hg38-sized genome).  A wave takes HS_SHARE consecutive tasks of the scan order, splits
+// them into such runs, and per run loads each candidate's entry and reference words ONCE (funnel-shifted into the read
+// frame once, too) and evaluates every read of the run against them: the per-candidate gather — the limit of the one-read
+// kernel on RRBS (texture addresser busy 0.94) — is shared, only the XOR/popcount work is per read.
+// Results per task are exactly those of k_hscan: survivors in list order, candidate count and word count (align.h:189-197).
+// ---------------------------------------------------------------------------------------------------------------
+#define HS_SHARE 16u  /* tasks per wave */
+struct SharedChunk { uint32_t wd[10]; uint32_t pm1, strand; bool valid; };
+
+__device__ __forceinline__ SharedChunk shared_load(const U2 *__restrict__ ent2, uint32_t idx, bool in_range, uint32_t h, uint32_t tag_xor, uint32_t tag_want,
+                                                   const uint32_t *anchor, const uint32_t *refall, uint32_t cref_off, int nwords)
+{
+    SharedChunk c;
+    U2 e; e.a = e.b = 0;
+    if (in_range) e = ent2[idx];
+    const uint32_t rchr = e.a & 0xffffu;
+    c.valid = in_range && ((e.a ^ tag_xor) >> 16) == tag_want && e.b >= h;  // mode or strand not match / underflow the start of refseq
+    c.pm1 = c.valid ? anchor[rchr >> 1] + (e.b - h) - 1u : 15u;
+    c.strand = rchr & 1u;
+    const uint32_t boff = c.valid ? ((c.pm1 >> 2) & 0x3ffffffcu) + (c.strand ? cref_off : 0u) : 0u;
+    const uint32_t *rp = reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(refall) + boff);
+    const U4 r0 = *reinterpret_cast<const U4 *>(rp);
+    U4 r1; U2 r2;
+    r1.a = r1.b = r1.c = r1.d = 0; r2.a = r2.b = 0;
+    if (c.valid && nwords > 3) r1 = *reinterpret_cast<const U4 *>(rp + 4);
+    if (c.valid && nwords > 7) r2 = *reinterpret_cast<const U2 *>(rp + 8);
+    c.wd[0] = r0.a; c.wd[1] = r0.b; c.wd[2] = r0.c; c.wd[3] = r0.d; c.wd[4] = r1.a; c.wd[5] = r1.b; c.wd[6] = r1.c; c.wd[7] = r1.d; c.wd[8] = r2.a; c.wd[9] = r2.b;
+    return c;
+}
+
+__global__ __launch_bounds__(256, 4) void k_hscan_shared(AlignArgs A, HeavyArgs H)
+{
+    __shared__ uint32_t UW[4][HS_SHARE][20];   // per read of the run: 9 read words, 9 T-masks, threshold, task id
+    __shared__ uint32_t UC[4][HS_SHARE][4];    // per read: survivors so far, candidates beyond the first word, five-word candidates, (unused)
+    __shared__ uint32_t ANCH[BSX_LDS_CHR + 1];
+    const DevParams &P = A.P;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (P.n_chr <= BSX_LDS_CHR) for (uint32_t i = threadIdx.x; i <= P.n_chr; i += 256) ANCH[i] = P.anchor[i];
+    __syncthreads();
+    const uint32_t *anchor = P.n_chr <= BSX_LDS_CHR ? ANCH : P.anchor;
+    const uint32_t n_tasks = min(*H.n_tasks, H.task_cap);
+    const uint32_t s0 = (blockIdx.x * 4u + (uint32_t)wv) * HS_SHARE;
+    if (s0 >= n_tasks) return;
+    const uint32_t nj = min(HS_SHARE, n_tasks - s0);
+    const uint32_t cref_off = (uint32_t)((const uint8_t *)P.crefcat - (const uint8_t *)P.refcat);
+    // lane j < nj: task j of this wave, in scan order, and the signature of its window
+    uint32_t tid = 0, th = 0, tc0 = 0, tn = 0, tkey = 0, sh_ = 0, stx = 0, stw = 0, snw = 0;
+    if ((uint32_t)lane < nj) {
+        tid = H.order ? H.order[s0 + lane] : s0 + (uint32_t)lane;
+        const HTask tk = H.tasks[tid];
+        th = tk.h; tc0 = tk.c0; tn = tk.n; tkey = tk.key;
+        if (tn) {
+            const ListReq &R = H.state[th].req;
+            tkey = R.sub_base[0] + (tc0 - R.sub_pre[0]);  // first entry of the window
+            sh_ = R.sub_h[0]; stx = R.tag_xor; stw = R.tag_want; snw = R.nwords;
+        } else {  // slot neutralised by a refused request: its unit has not published a list
+            HTaskOut *o = &H.tout[tid];
+            o->count = 0; o->overflow = 0; o->acc[0] = o->acc[1] = o->acc[2] = o->acc[3] = 0;
+        }
+    }
+    u64 st_cand = 0, st_words = 0, st_n1 = 0, st_n5 = 0;  // statistics of the scan kernel (lane 0)
+    for (uint32_t i0 = 0; i0 < nj;) {
+        if (rl(tn, (int)i0) == 0) { i0++; continue; }
+        // the run of tasks from i0 that cover exactly the same window
+        const bool same = (uint32_t)lane >= i0 && (uint32_t)lane < nj && tn == rl(tn, (int)i0) && tkey == rl(tkey, (int)i0) && sh_ == rl(sh_, (int)i0) &&
+                          stx == rl(stx, (int)i0) && stw == rl(stw, (int)i0) && snw == rl(snw, (int)i0);
+        const u64 sm = bsx_ballot(same) >> i0;
+        const uint32_t K = (uint32_t)__builtin_ctzll(~sm);  // (bit 0 is set: the task equals itself)
+        const uint32_t key = rl(tkey, (int)i0), n = rl(tn, (int)i0), h = rl(sh_, (int)i0), tx = rl(stx, (int)i0), tw = rl(stw, (int)i0);
+        const int nwords = (int)rl(snw, (int)i0);
+        wave_fence();
+        for (uint32_t xb = 0; xb < K * 20u; xb += 64) {
+            const uint32_t x = xb + (uint32_t)lane, k = min(x / 20u, K - 1u), f = x - k * 20u;
+            const uint32_t hk = (uint32_t)__shfl((int)th, (int)(i0 + k)), tk = (uint32_t)__shfl((int)tid, (int)(i0 + k));  // (all lanes take part)
+            if (x < K * 20u) {
+                const ListReq &R = H.state[hk].req;
+                uint32_t v;
+                if (f < 9) v = R.rw[f];
+                else if (f < 18) v = bsx_tmask(R.rw[f - 9], R.rm[f - 9]);
+                else if (f == 18) v = R.thres;
+                else v = tk;
+                UW[wv][k][f] = v;
+            }
+        }
+        if ((uint32_t)lane < K * 4u) UC[wv][lane >> 2][lane & 3] = 0;
+        wave_fence();
+        const U2 *ent2 = reinterpret_cast<const U2 *>(P.entries) + key;
+        SharedChunk cur = shared_load(ent2, (uint32_t)lane, (uint32_t)lane < n, h, tx, tw, anchor, P.refcat, cref_off, nwords);
+        uint32_t nv = 0;
+        for (uint32_t cb = 0; cb < n; cb += 64) {
+            SharedChunk nxt;
+            const bool more = cb + 64 < n;
+            if (more) nxt = shared_load(ent2, cb + 64 + (uint32_t)lane, cb + 64 + (uint32_t)lane < n, h, tx, tw, anchor, P.refcat, cref_off, nwords);
+            // the candidate's reference words in the read frame — the same for every read of the run
+            const uint32_t shf = mad30(cur.pm1, 30);
+            const uint32_t him = (uint32_t)((int32_t)0x80000000 >> (mad30(cur.pm1, 29) & 31u));
+            uint32_t f[9];
+#pragma unroll
+            for (int t = 0; t < 9; t++) f[t] = __builtin_amdgcn_alignbit(cur.wd[t], cur.wd[t + 1], shf);
+            nv += cur.valid ? 1u : 0u;
+            const uint32_t ord = (cb + (uint32_t)lane) << 8;
+            for (uint32_t k = 0; k < K; k++) {
+                const uint32_t *uw = UW[wv][k];
+                const uint32_t thr = uw[18];
+                const uint32_t m1 = bsx_mismatch_hi(uw[1], uw[10], f[1]);
+                const uint32_t c0 = __popc(bsx_mismatch_hi(uw[0], uw[9], f[0]));
+                const uint32_t w0ref = __popc(m1 & him) + c0;
+                uint32_t tot = __popc(bsx_mismatch_hi(uw[2], uw[11], f[2])) + (__popc(m1) + c0);
+                uint32_t w01ref = tot;
+                if (nwords > 3) {
+                    const uint32_t m3 = bsx_mismatch_hi(uw[3], uw[12], f[3]);
+                    tot += __popc(m3); w01ref += __popc(m3 & him);
+                    tot += __popc(bsx_mismatch_hi(uw[4], uw[13], f[4]));
+                    if (nwords > 5) {
+                        tot += __popc(bsx_mismatch_hi(uw[5], uw[14], f[5]));
+                        tot += __popc(bsx_mismatch_hi(uw[6], uw[15], f[6]));
+                        if (nwords > 7) {
+                            tot += __popc(bsx_mismatch_hi(uw[7], uw[16], f[7]));
+                            tot += __popc(bsx_mismatch_hi(uw[8], uw[17], f[8]));
+                        }
+                    }
+                }
+                const u64 b1 = bsx_ballot(cur.valid && w0ref > thr), b5 = bsx_ballot(cur.valid && w01ref <= thr), bp = bsx_ballot(cur.valid && tot <= thr);
+                if (lane == 0) { UC[wv][k][1] += (uint32_t)__builtin_popcountll(b1); UC[wv][k][2] += (uint32_t)__builtin_popcountll(b5); }
+                if (bp) {
+                    const uint32_t base = UC[wv][k][0];
+                    const uint32_t pos = base + (uint32_t)__builtin_popcountll(bp & lanemask_lt(lane));
+                    if (((bp >> lane) & 1) && pos < HS_SCAP) {
+                        SurvRec r; r.w_ord = tot | ord; r.hchr = cur.strand; r.hloc = cur.pm1 + 1; r.hkey = 0;
+                        H.tout[uw[19]].surv[pos] = r;
+                    }
+                    wave_fence();
+                    if (lane == 0) UC[wv][k][0] = base + (uint32_t)__builtin_popcountll(bp);
+                    wave_fence();
+                }
+            }
+            if (more) cur = nxt;
+        }
+        wave_fence();
+        const uint32_t n_cand = wave_sum(nv);
+        if ((uint32_t)lane < K) {
+            const uint32_t ns = UC[wv][lane][0], n1 = UC[wv][lane][1], n5 = UC[wv][lane][2];
+            const bool ov = ns > HS_SCAP;
+            HTaskOut *o = &H.tout[UW[wv][lane][19]];
+            o->count = ov ? 0 : ns; o->overflow = ov ? 1 : 0; o->acc[0] = n_cand; o->acc[1] = 2u * n_cand - n1 + 3u * n5; o->acc[2] = 0; o->acc[3] = 0;
+        }
+        {   // work of the scan kernel (incl. speculation); an overflowed task is redone by the control kernel
+            const bool cnt = (uint32_t)lane < K && UC[wv][lane < (int)HS_SHARE ? lane : 0][0] <= HS_SCAP;
+            const uint32_t n1 = cnt ? UC[wv][lane][1] : 0, n5 = cnt ? UC[wv][lane][2] : 0;
+            const uint32_t kk = (uint32_t)__builtin_popcountll(bsx_ballot(cnt));
+            const uint32_t s1 = wave_sum(n1), s5 = wave_sum(n5);
+            st_cand += (u64)kk * n_cand; st_n1 += s1; st_n5 += s5; st_words += 2ull * kk * n_cand - s1 + 3ull * s5;
+        }
+        wave_fence();
+        i0 += K;
+    }
+    if (lane == 0) {
+        u64 *sh = (u64 *)A.scan_stats + (size_t)(blockIdx.x & 63u) * 8;
+        atomicAdd((u64 *)&sh[0], st_cand); atomicAdd((u64 *)&sh[1], st_words); atomicAdd((u64 *)&sh[2], st_n1); atomicAdd((u64 *)&sh[3], st_n5);
+    }
+}
 }  // namespace
 
 void bsx_launch_leak(const AlignArgs &A, int paired, int grid_blocks, hipStream_t stream)
@@ -2119,6 +2285,13 @@ void bsx_launch_hctrl(const AlignArgs &A, const HeavyArgsRaw &R, int paired, int
     const HeavyArgs H = typed(R);
     if (paired) hipLaunchKernelGGL(k_hctrl<true>, dim3(grid_blocks), dim3(256), 0, stream, A, H);
     else hipLaunchKernelGGL(k_hctrl<false>, dim3(grid_blocks), dim3(256), 0, stream, A, H);
+}
+
+void bsx_launch_hscan_shared(const AlignArgs &A, const HeavyArgsRaw &R, uint32_t n_tasks, hipStream_t stream)
+{
+    const HeavyArgs H = typed(R);
+    const uint32_t jobs = (n_tasks + HS_SHARE - 1) / HS_SHARE;
+    hipLaunchKernelGGL(k_hscan_shared, dim3((jobs + 3) / 4), dim3(256), 0, stream, A, H);
 }
 
 void bsx_launch_hscan(const AlignArgs &A, const HeavyArgsRaw &R, uint32_t n_tasks, hipStream_t stream)

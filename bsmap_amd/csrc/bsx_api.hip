@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <cmath>
 #include <vector>
 
 #include "bsx_internal.h"
@@ -539,6 +540,9 @@ extern "C" int bsx_batch_run_range(bsx_batch *b, uint32_t first_unit, uint32_t n
         const bool trace = getenv("BSX_TRACE_HEAVY") != nullptr;
         const bool sort_tasks = !getenv("BSX_SORT_TASKS") || atoi(getenv("BSX_SORT_TASKS")) != 0;
         const bool xcd_map = !getenv("BSX_XCD_MAP") || atoi(getenv("BSX_XCD_MAP")) != 0;
+        const bool share_stats = getenv("BSX_SHARE_STATS") != nullptr;
+        const bool shared_scan = b->ref->P.rrbs && (!getenv("BSX_SHARED_SCAN") || atoi(getenv("BSX_SHARED_SCAN")) != 0);
+        uint64_t share_same = 0, share_total = 0, share_hist[16] = {0};
         const int n_groups = g_heavy_groups;
         struct Group { uint32_t n_act = 0, iter = 0; int cur = 0; bool done = true, scan_pending = false; HeavyArgsRaw H; uint32_t *blk[2]; };
         for (uint32_t base = 0; base < n_heavy; base += b->hcap) {
@@ -603,9 +607,24 @@ extern "C" int bsx_batch_run_range(bsx_batch *b, uint32_t first_unit, uint32_t n
                             int rcs = bsx_sort_pairs_u32(&b->d_sort_tmp, &b->sort_tmp_bytes, b->d_tsort[0], b->d_tsort[1], b->d_tsort[2], b->d_tsort[3], n_tasks, b->stream);
                             if (rcs) return rcs;
                             q.H.order = b->d_tsort[3];
+                            if (share_stats) {  // diagnostic: how many scan tasks of a pass cover exactly the window of their neighbour in scan order?
+                                std::vector<uint32_t> ord(n_tasks);
+                                std::vector<uint32_t> tk((size_t)n_tasks * 4);
+                                HIP_TRY(hipStreamSynchronize(b->stream));
+                                HIP_TRY(hipMemcpy(ord.data(), b->d_tsort[3], (size_t)n_tasks * 4, hipMemcpyDeviceToHost));
+                                HIP_TRY(hipMemcpy(tk.data(), q.H.tasks, (size_t)n_tasks * 16, hipMemcpyDeviceToHost));
+                                uint64_t same = 0, run = 1;
+                                for (uint32_t i = 1; i <= n_tasks; i++) {
+                                    const bool eq = i < n_tasks && tk[4 * (size_t)ord[i] + 3] == tk[4 * (size_t)ord[i - 1] + 3] && tk[4 * (size_t)ord[i] + 2] == tk[4 * (size_t)ord[i - 1] + 2];
+                                    if (eq) { same++; run++; }
+                                    else { share_hist[std::min<uint64_t>(15, (uint64_t)std::log2((double)run))]++; run = 1; }
+                                }
+                                share_same += same; share_total += n_tasks;
+                            }
                         }
                         HIP_TRY(hipEventRecord(b->scan_ev[b->scan_ev_used], b->stream));
-                        bsx_launch_hscan(A, q.H, n_tasks, b->stream);
+                        if (shared_scan && q.H.order) bsx_launch_hscan_shared(A, q.H, n_tasks, b->stream);  // RRBS: runs of tasks over one window, scanned together
+                        else bsx_launch_hscan(A, q.H, n_tasks, b->stream);
                         HIP_TRY(hipGetLastError());
                         HIP_TRY(hipEventRecord(b->scan_ev[b->scan_ev_used + 1], b->stream));
                         b->scan_ev_used += 2;
@@ -619,6 +638,11 @@ extern "C" int bsx_batch_run_range(bsx_batch *b, uint32_t first_unit, uint32_t n
             }
             HIP_TRY(hipEventRecord(b->ev_sync, b->stream_hi));            // the main stream continues behind the last control pass
             HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_sync, 0));
+        }
+        if (share_stats) {
+            fprintf(stderr, "share_stats: %llu of %llu scan tasks repeat their neighbour's window; runs by log2(length):", (unsigned long long)share_same, (unsigned long long)share_total);
+            for (int i = 0; i < 16; i++) fprintf(stderr, " %llu", (unsigned long long)share_hist[i]);
+            fprintf(stderr, "\n");
         }
     }
     if (A.heavy_threshold && b->last_heavy) {
