@@ -475,6 +475,16 @@ __device__ int ccgg_seglen(const DevParams &P, uint32_t chr, uint32_t pos, int r
     const uint32_t *sites = P.sites + P.site_off[c];
     const int size = (int)(P.site_off[c + 1] - P.site_off[c]);
     int left = 0, right = size - 1;
+    if (P.site_bin && size >= 2) {
+        // The reference's loop (below) ends with left = the last site <= pos, kept inside [0, size-2], and right = left + 1 (an
+        // exact hit can only be a probe strictly between the ends, which gives the same).  The same pair from the 4 kb bin table:
+        // a handful of sites to search instead of the whole chromosome's list (17 dependent loads on the hg38-sized genome).
+        const uint32_t *tab = P.site_bin + P.site_bin_off[c];
+        const uint32_t nb = P.site_bin_off[c + 1] - P.site_bin_off[c], b = min(pos >> BSX_SITE_BIN_SHIFT, nb - 2);
+        int lo = (int)tab[b], hi = (pos >> BSX_SITE_BIN_SHIFT) > nb - 2 ? size : (int)tab[b + 1];  // sites before lo are < the bin, sites from hi on are beyond it
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (sites[mid] <= pos) lo = mid + 1; else hi = mid; }  // lo = number of sites <= pos
+        left = max(0, min(size - 2, lo - 1)); right = left + 1;
+    } else
     while (left < right - 1) {
         const int mid = (left + right) / 2;
         const uint32_t mv = sites[mid];
@@ -1712,11 +1722,14 @@ __device__ bool heavy_advance(const AlignArgs &A, const HeavyArgs &H, HState *S,
     }
 }
 
+#ifndef BSX_HCTRL_WAVES_SE
+#define BSX_HCTRL_WAVES_SE 1  /* the same for single-end batches */
+#endif
 #ifndef BSX_HCTRL_WAVES
 #define BSX_HCTRL_WAVES 1  /* waves per SIMD the control kernel's register budget allows (1 = 512 registers) */
 #endif
 template <bool PE>
-__global__ __launch_bounds__(256, BSX_HCTRL_WAVES) void k_hctrl(AlignArgs A, HeavyArgs H)
+__global__ __launch_bounds__(256, PE ? BSX_HCTRL_WAVES : BSX_HCTRL_WAVES_SE) void k_hctrl(AlignArgs A, HeavyArgs H)
 {
     __shared__ BlockLds BL;
     __shared__ WaveLds<PE> WL[4];

@@ -213,6 +213,26 @@ int bsx_index_build_rrbs(bsx_ref *r, const std::vector<uint32_t> &refcat, const 
     HIP_TRY(hipMemcpy(d_soff.p, site_off.data(), site_off.size() * 4, hipMemcpyHostToDevice));
     r->d_bucket_off = d_off.release(); r->d_bucket_nfwd = d_nfwd.release(); r->d_entries = d_ent.release();
     r->d_sites = d_sites.release(); r->d_site_off = d_soff.release();
+    {   // where a position's 4 kb bin starts in its chromosome's site list: the fragment-size filter's search (ccgg_seglen) starts there
+        std::vector<uint32_t> bin_off(r->n_chr + 1, 0), bins;
+        for (uint32_t c = 0; c < r->n_chr; c++) {
+            const std::vector<uint32_t> &sv = r->sites[c];
+            const uint32_t top = std::max(r->chr_size[c], sv.empty() ? 0u : sv.back());
+            const uint32_t nb = (top >> BSX_SITE_BIN_SHIFT) + 2;  // bins 0 .. top's bin, plus the end of the last one
+            bin_off[c + 1] = bin_off[c] + nb;
+            size_t i = 0;
+            for (uint32_t b = 0; b < nb; b++) {
+                const uint64_t lo = (uint64_t)b << BSX_SITE_BIN_SHIFT;
+                while (i < sv.size() && sv[i] < lo) i++;
+                bins.push_back((uint32_t)i);
+            }
+        }
+        DevBuf<uint32_t> d_bin, d_boff;
+        if (d_bin.alloc(bins.size()) || d_boff.alloc(bin_off.size())) return BSX_ERR_NOMEM;
+        HIP_TRY(hipMemcpy(d_bin.p, bins.data(), bins.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_boff.p, bin_off.data(), bin_off.size() * 4, hipMemcpyHostToDevice));
+        r->d_site_bin = d_bin.release(); r->d_site_bin_off = d_boff.release();
+    }
     r->n_entries = off[K];
     r->has_index = true;
     return BSX_OK;

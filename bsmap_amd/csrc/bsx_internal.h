@@ -36,7 +36,10 @@ struct DevParams {
     const uint32_t *sites, *site_off;
     // RRBS: entries of a bucket grouped by (segment + 16 * direction); rrbs_goff[key * 32 + group] = first entry (null: ungrouped)
     const uint32_t *rrbs_goff;
+    // RRBS: site_bin[site_bin_off[c] + (pos >> BSX_SITE_BIN_SHIFT)] = number of sites of chromosome c below that 4 kb bin (null: plain binary search)
+    const uint32_t *site_bin, *site_bin_off;
 };
+#define BSX_SITE_BIN_SHIFT 12
 
 struct Block { uint32_t id, begin, end; };
 
@@ -55,7 +58,7 @@ struct bsx_ref {
     // device
     uint32_t *d_refcat = nullptr, *d_crefcat = nullptr, *d_anchor = nullptr, *d_chr_size = nullptr, *d_rc_offset = nullptr;
     uint32_t *d_bucket_off = nullptr, *d_bucket_nfwd = nullptr, *d_entries = nullptr;
-    uint32_t *d_sites = nullptr, *d_site_off = nullptr, *d_rrbs_goff = nullptr;
+    uint32_t *d_sites = nullptr, *d_site_off = nullptr, *d_rrbs_goff = nullptr, *d_site_bin = nullptr, *d_site_bin_off = nullptr;
     std::vector<uint32_t> rrbs_entries_host;  // RRBS entries in the reference's order (the device copy is grouped, see bsx_index_build_rrbs)
     uint64_t n_entries = 0;
     bool has_index = false;
