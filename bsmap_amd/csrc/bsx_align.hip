@@ -75,6 +75,7 @@ __device__ __forceinline__ unsigned long long bsx_ballot(bool p) { return __buil
 #define mad30(x, c) ({ uint32_t d_; asm("v_mad_u32_u24 %0, %1, 30, " #c : "=v"(d_) : "v"(x)); d_; })  /* x * 30 + c (low 24 bits of x) */
 __device__ __forceinline__ uint32_t rfl(uint32_t x) { return __builtin_amdgcn_readfirstlane(x); }
 __device__ __forceinline__ uint32_t rl(uint32_t x, int l) { return __builtin_amdgcn_readlane(x, l); }
+__device__ __forceinline__ uint32_t rl_u(uint32_t x, uint32_t l) { return __builtin_amdgcn_readlane(x, (int)__builtin_amdgcn_readfirstlane(l)); }  // wave-uniform lane number held in a register
 __device__ __forceinline__ u64 rl64(u64 x, int l) { return ((u64)rl((uint32_t)(x >> 32), l) << 32) | rl((uint32_t)x, l); }
 __device__ __forceinline__ u64 lanemask_lt(int lane) { return lane ? (~0ull >> (64 - lane)) : 0ull; }
 __device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
@@ -2146,8 +2147,7 @@ __device__ __forceinline__ SharedChunk shared_load(const U2 *__restrict__ ent2, 
 
 __global__ __launch_bounds__(256, 4) void k_hscan_shared(AlignArgs A, HeavyArgs H)
 {
-    __shared__ uint32_t UW[4][HS_SHARE][20];   // per read of the run: 9 read words, 9 T-masks, threshold, task id
-    __shared__ uint32_t UC[4][HS_SHARE][4];    // per read: survivors so far, candidates beyond the first word, five-word candidates, (unused)
+    __shared__ __attribute__((aligned(16))) uint32_t UW[4][HS_SHARE][20];   // per read of the run: 9 read words, 9 T-masks, threshold, task id
     __shared__ uint32_t ANCH[BSX_LDS_CHR + 1];
     const DevParams &P = A.P;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -2198,7 +2198,7 @@ __global__ __launch_bounds__(256, 4) void k_hscan_shared(AlignArgs A, HeavyArgs 
                 UW[wv][k][f] = v;
             }
         }
-        if ((uint32_t)lane < K * 4u) UC[wv][lane >> 2][lane & 3] = 0;
+        uint32_t c15 = 0, nsv = 0;  // lane k: counters of read k (see the loop)
         wave_fence();
         const U2 *ent2 = reinterpret_cast<const U2 *>(P.entries) + key;
         SharedChunk cur = shared_load(ent2, (uint32_t)lane, (uint32_t)lane < n, h, tx, tw, anchor, P.refcat, cref_off, nwords);
@@ -2215,56 +2215,59 @@ __global__ __launch_bounds__(256, 4) void k_hscan_shared(AlignArgs A, HeavyArgs 
             for (int t = 0; t < 9; t++) f[t] = __builtin_amdgcn_alignbit(cur.wd[t], cur.wd[t + 1], shf);
             nv += cur.valid ? 1u : 0u;
             const uint32_t ord = (cb + (uint32_t)lane) << 8;
-            for (uint32_t k = 0; k < K; k++) {
-                const uint32_t *uw = UW[wv][k];
-                const uint32_t thr = uw[18];
-                const uint32_t m1 = bsx_mismatch_hi(uw[1], uw[10], f[1]);
-                const uint32_t c0 = __popc(bsx_mismatch_hi(uw[0], uw[9], f[0]));
+            const u64 vm = bsx_ballot(cur.valid);
+            const uint4 *up = reinterpret_cast<const uint4 *>(UW[wv][0]);
+            for (uint32_t k = 0; k < K; k++, up += 5) {
+                const uint4 a0 = up[0], a1 = up[1], a2 = up[2], a3 = up[3], a4 = up[4];  // read words 0-3 | 4-7 | 8, masks 0-2 | masks 3-6 | masks 7-8, threshold, task id
+                const uint32_t thr = a4.z;
+                const uint32_t m1 = bsx_mismatch_hi(a0.y, a2.z, f[1]);
+                const uint32_t c0 = __popc(bsx_mismatch_hi(a0.x, a2.y, f[0]));
                 const uint32_t w0ref = __popc(m1 & him) + c0;
-                uint32_t tot = __popc(bsx_mismatch_hi(uw[2], uw[11], f[2])) + (__popc(m1) + c0);
+                uint32_t tot = __popc(bsx_mismatch_hi(a0.z, a2.w, f[2])) + (__popc(m1) + c0);
                 uint32_t w01ref = tot;
                 if (nwords > 3) {
-                    const uint32_t m3 = bsx_mismatch_hi(uw[3], uw[12], f[3]);
+                    const uint32_t m3 = bsx_mismatch_hi(a0.w, a3.x, f[3]);
                     tot += __popc(m3); w01ref += __popc(m3 & him);
-                    tot += __popc(bsx_mismatch_hi(uw[4], uw[13], f[4]));
+                    tot += __popc(bsx_mismatch_hi(a1.x, a3.y, f[4]));
                     if (nwords > 5) {
-                        tot += __popc(bsx_mismatch_hi(uw[5], uw[14], f[5]));
-                        tot += __popc(bsx_mismatch_hi(uw[6], uw[15], f[6]));
+                        tot += __popc(bsx_mismatch_hi(a1.y, a3.z, f[5]));
+                        tot += __popc(bsx_mismatch_hi(a1.z, a3.w, f[6]));
                         if (nwords > 7) {
-                            tot += __popc(bsx_mismatch_hi(uw[7], uw[16], f[7]));
-                            tot += __popc(bsx_mismatch_hi(uw[8], uw[17], f[8]));
+                            tot += __popc(bsx_mismatch_hi(a1.w, a4.x, f[7]));
+                            tot += __popc(bsx_mismatch_hi(a2.x, a4.y, f[8]));
                         }
                     }
                 }
-                const u64 b1 = bsx_ballot(cur.valid && w0ref > thr), b5 = bsx_ballot(cur.valid && w01ref <= thr), bp = bsx_ballot(cur.valid && tot <= thr);
-                if (lane == 0) { UC[wv][k][1] += (uint32_t)__builtin_popcountll(b1); UC[wv][k][2] += (uint32_t)__builtin_popcountll(b5); }
+                const u64 b1 = bsx_ballot(w0ref > thr) & vm, b5 = bsx_ballot(w01ref <= thr) & vm, bp = bsx_ballot(tot <= thr) & vm;
+                // lane k keeps read k's counters: candidates beyond the first word | five-word candidates << 16, survivors
+                const uint32_t add15 = (uint32_t)__builtin_popcountll(b1) | ((uint32_t)__builtin_popcountll(b5) << 16);
+                if ((uint32_t)lane == k) c15 += add15;
                 if (bp) {
-                    const uint32_t base = UC[wv][k][0];
+                    const uint32_t base = rl_u(nsv, k);
                     const uint32_t pos = base + (uint32_t)__builtin_popcountll(bp & lanemask_lt(lane));
                     if (((bp >> lane) & 1) && pos < HS_SCAP) {
                         SurvRec r; r.w_ord = tot | ord; r.hchr = cur.strand; r.hloc = cur.pm1 + 1; r.hkey = 0;
-                        H.tout[uw[19]].surv[pos] = r;
+                        H.tout[a4.w].surv[pos] = r;
                     }
-                    wave_fence();
-                    if (lane == 0) UC[wv][k][0] = base + (uint32_t)__builtin_popcountll(bp);
-                    wave_fence();
+                    if ((uint32_t)lane == k) nsv += (uint32_t)__builtin_popcountll(bp);
                 }
             }
             if (more) cur = nxt;
         }
         wave_fence();
         const uint32_t n_cand = wave_sum(nv);
-        if ((uint32_t)lane < K) {
-            const uint32_t ns = UC[wv][lane][0], n1 = UC[wv][lane][1], n5 = UC[wv][lane][2];
+        {
+            const bool mine = (uint32_t)lane < K;
+            const uint32_t ns = nsv, n1 = c15 & 0xffffu, n5 = c15 >> 16;
             const bool ov = ns > HS_SCAP;
-            HTaskOut *o = &H.tout[UW[wv][lane][19]];
-            o->count = ov ? 0 : ns; o->overflow = ov ? 1 : 0; o->acc[0] = n_cand; o->acc[1] = 2u * n_cand - n1 + 3u * n5; o->acc[2] = 0; o->acc[3] = 0;
-        }
-        {   // work of the scan kernel (incl. speculation); an overflowed task is redone by the control kernel
-            const bool cnt = (uint32_t)lane < K && UC[wv][lane < (int)HS_SHARE ? lane : 0][0] <= HS_SCAP;
-            const uint32_t n1 = cnt ? UC[wv][lane][1] : 0, n5 = cnt ? UC[wv][lane][2] : 0;
+            if (mine) {
+                HTaskOut *o = &H.tout[UW[wv][lane][19]];
+                o->count = ov ? 0 : ns; o->overflow = ov ? 1 : 0; o->acc[0] = n_cand; o->acc[1] = 2u * n_cand - n1 + 3u * n5; o->acc[2] = 0; o->acc[3] = 0;
+            }
+            // work of the scan kernel (incl. speculation); an overflowed task is redone by the control kernel
+            const bool cnt = mine && !ov;
             const uint32_t kk = (uint32_t)__builtin_popcountll(bsx_ballot(cnt));
-            const uint32_t s1 = wave_sum(n1), s5 = wave_sum(n5);
+            const uint32_t s1 = wave_sum(cnt ? n1 : 0), s5 = wave_sum(cnt ? n5 : 0);
             st_cand += (u64)kk * n_cand; st_n1 += s1; st_n5 += s5; st_words += 2ull * kk * n_cand - s1 + 3ull * s5;
         }
         wave_fence();
