@@ -2325,6 +2325,27 @@ __global__ void k_task_keys(const HTask *tasks, const uint32_t *n_tasks_ptr, uin
     if (i < n) { keys[i] = tasks[i].key; ids[i] = i; }
 }
 }  // namespace
+namespace {
+// diagnostic (BSX_SHARE_STATS): the read offset h of the sub-range each task starts in
+__global__ void k_task_sig(const HTask *tasks, const HState *state, uint32_t n, uint32_t *sig)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const HTask tk = tasks[i];
+    uint32_t v = 0xffffffffu;
+    if (tk.n) {
+        const ListReq &R = state[tk.h].req;
+        for (uint32_t s_ = 0; s_ < min(R.nsub, 32u); s_++)
+            if (tk.c0 >= R.sub_pre[s_] && tk.c0 < R.sub_pre[s_] + R.sub_n[s_]) v = R.sub_h[s_] ^ (tk.c0 + tk.n > R.sub_pre[s_] + R.sub_n[s_] ? 0x80000000u : 0u);
+    }
+    sig[i] = v;
+}
+}  // namespace
+void bsx_launch_task_sig(const HeavyArgsRaw &R, uint32_t n_tasks, uint32_t *sig, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_task_sig, dim3((n_tasks + 255) / 256), dim3(256), 0, stream, (const HTask *)R.tasks, (const HState *)R.state, n_tasks, sig);
+}
+
 void bsx_launch_task_keys(const HeavyArgsRaw &R, uint32_t n_tasks, uint32_t *keys, uint32_t *ids, hipStream_t stream)
 {
     hipLaunchKernelGGL(k_task_keys, dim3((n_tasks + 255) / 256), dim3(256), 0, stream, (const HTask *)R.tasks, R.n_tasks, R.task_cap, keys, ids);

@@ -542,7 +542,7 @@ extern "C" int bsx_batch_run_range(bsx_batch *b, uint32_t first_unit, uint32_t n
         const bool xcd_map = !getenv("BSX_XCD_MAP") || atoi(getenv("BSX_XCD_MAP")) != 0;
         const bool share_stats = getenv("BSX_SHARE_STATS") != nullptr;
         const bool shared_scan = b->ref->P.rrbs && (!getenv("BSX_SHARED_SCAN") || atoi(getenv("BSX_SHARED_SCAN")) != 0);
-        uint64_t share_same = 0, share_total = 0, share_hist[16] = {0};
+        uint64_t share_same = 0, share_same_h = 0, share_total = 0, share_hist[16] = {0};
         const int n_groups = g_heavy_groups;
         struct Group { uint32_t n_act = 0, iter = 0; int cur = 0; bool done = true, scan_pending = false; HeavyArgsRaw H; uint32_t *blk[2]; };
         for (uint32_t base = 0; base < n_heavy; base += b->hcap) {
@@ -613,9 +613,14 @@ extern "C" int bsx_batch_run_range(bsx_batch *b, uint32_t first_unit, uint32_t n
                                 HIP_TRY(hipStreamSynchronize(b->stream));
                                 HIP_TRY(hipMemcpy(ord.data(), b->d_tsort[3], (size_t)n_tasks * 4, hipMemcpyDeviceToHost));
                                 HIP_TRY(hipMemcpy(tk.data(), q.H.tasks, (size_t)n_tasks * 16, hipMemcpyDeviceToHost));
+                                std::vector<uint32_t> sig(n_tasks);
+                                bsx_launch_task_sig(q.H, n_tasks, b->d_tsort[0], b->stream);  // (the unsorted keys are no longer needed)
+                                HIP_TRY(hipStreamSynchronize(b->stream));
+                                HIP_TRY(hipMemcpy(sig.data(), b->d_tsort[0], (size_t)n_tasks * 4, hipMemcpyDeviceToHost));
                                 uint64_t same = 0, run = 1;
                                 for (uint32_t i = 1; i <= n_tasks; i++) {
                                     const bool eq = i < n_tasks && tk[4 * (size_t)ord[i] + 3] == tk[4 * (size_t)ord[i - 1] + 3] && tk[4 * (size_t)ord[i] + 2] == tk[4 * (size_t)ord[i - 1] + 2];
+                                    if (eq && sig[ord[i]] == sig[ord[i - 1]] && !(sig[ord[i]] >> 31)) share_same_h++;
                                     if (eq) { same++; run++; }
                                     else { share_hist[std::min<uint64_t>(15, (uint64_t)std::log2((double)run))]++; run = 1; }
                                 }
@@ -640,7 +645,7 @@ extern "C" int bsx_batch_run_range(bsx_batch *b, uint32_t first_unit, uint32_t n
             HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_sync, 0));
         }
         if (share_stats) {
-            fprintf(stderr, "share_stats: %llu of %llu scan tasks repeat their neighbour's window; runs by log2(length):", (unsigned long long)share_same, (unsigned long long)share_total);
+            fprintf(stderr, "share_stats: %llu of %llu scan tasks repeat their neighbour's window (%llu with the same read offset, inside one sub-range); runs by log2(length):", (unsigned long long)share_same, (unsigned long long)share_total, (unsigned long long)share_same_h);
             for (int i = 0; i < 16; i++) fprintf(stderr, " %llu", (unsigned long long)share_hist[i]);
             fprintf(stderr, "\n");
         }

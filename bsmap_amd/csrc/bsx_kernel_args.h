@@ -60,6 +60,7 @@ void bsx_launch_leak(const AlignArgs &A, int paired, int grid_blocks, hipStream_
 size_t bsx_leakrec_bytes(void);
 void bsx_launch_hctrl(const AlignArgs &A, const HeavyArgsRaw &H, int paired, int grid_blocks, hipStream_t stream);
 void bsx_launch_hscan(const AlignArgs &A, const HeavyArgsRaw &H, uint32_t n_tasks, hipStream_t stream);
+void bsx_launch_task_sig(const HeavyArgsRaw &H, uint32_t n_tasks, uint32_t *sig, hipStream_t stream);  // diagnostic
 void bsx_launch_hscan_shared(const AlignArgs &A, const HeavyArgsRaw &H, uint32_t n_tasks, hipStream_t stream);  // RRBS: up to 16 tasks of one window per wave
 void bsx_launch_task_keys(const HeavyArgsRaw &H, uint32_t n_tasks, uint32_t *keys, uint32_t *ids, hipStream_t stream);
 // bsx_index.hip: stable radix sort of (key, id) pairs (rocPRIM); temp grows on demand
