@@ -470,13 +470,17 @@ __device__ __forceinline__ void forget_keys(const Mate &M, const Slab &SL, int l
 // SnpAlign (align.cpp:168-347) — returns when the reference's SnpAlign would return
 // ---------------------------------------------------------------------------------------------------------------
 // RefSeq::CCGG_seglen (dbseq.cpp:541-567), fragment length only
+// BINS: start the search from the 4 kb bin table.  Only the control kernel of the heavy pipeline does (where it replays hundreds of
+// survivors per read); the main kernel keeps the plain search — its register allocation sits at the 128-VGPR limit and the
+// extra code there costs the WGBS instantiation 1 KB of spill per lane.
+template <bool BINS>
 __device__ int ccgg_seglen(const DevParams &P, uint32_t chr, uint32_t pos, int readlen)
 {
     const uint32_t c = chr >> 1;
     const uint32_t *sites = P.sites + P.site_off[c];
     const int size = (int)(P.site_off[c + 1] - P.site_off[c]);
     int left = 0, right = size - 1;
-    if (P.site_bin && size >= 2) {
+    if (BINS && P.site_bin && size >= 2) {
         // The reference's loop (below) ends with left = the last site <= pos, kept inside [0, size-2], and right = left + 1 (an
         // exact hit can only be a probe strictly between the ends, which gives the same).  The same pair from the 4 kb bin table:
         // a handful of sites to search instead of the whole chromosome's list (17 dependent loads on the hg38-sized genome).
@@ -606,6 +610,7 @@ __device__ __forceinline__ bool hit_coords(const DevParams &P, const BlockLds &B
 // One accepted-candidate step of the reference's inner loops (align.cpp:274-278 and the RRBS twin :201-212):
 // hitset.insert, optional fragment filter, append, -r 0 early return, -w cap.  Returns 0 nothing happened /
 // 1 threshold lowered / 2 SnpAlign returns.
+template <bool BINS>
 __device__ __forceinline__ int accept_survivor(const DevParams &P, Mate &M, const Slab &SL, int orient, int mode, uint32_t ws, uint32_t hchr,
                                                uint32_t hloc, uint32_t hkey, int lane)
 {
@@ -613,7 +618,7 @@ __device__ __forceinline__ int accept_survivor(const DevParams &P, Mate &M, cons
     if (seen_before(M, SL, hkey, lane)) return 0;
     remember_key(M, SL, hkey, lane);  // hitset.insert
     if (P.rrbs && !P.pairend && orient == 0) {  // fragment size filter, forward chain only (align.cpp:202-207)
-        const int sl = ccgg_seglen(P, hchr, hloc, M.len);
+        const int sl = ccgg_seglen<BINS>(P, hchr, hloc, M.len);
         if (sl > P.max_insert || sl < P.min_insert) return 0;
     }
     const uint32_t n = n_of(M, orient, (int)ws);
@@ -673,7 +678,7 @@ __device__ int accept_group(const DevParams &P, Mate &M, const Slab &SL, int ori
     // out of range (align.cpp:201-207) — `cand` lanes enter the hitset, only `app` lanes are appended and can cause events
     bool app = cand;
     if (P.rrbs && !P.pairend && orient == 0 && cand) {
-        const int sl = ccgg_seglen(P, hchr, hloc, M.len);
+        const int sl = ccgg_seglen<true>(P, hchr, hloc, M.len);
         app = !(sl > P.max_insert || sl < P.min_insert);
     }
     // position inside the class list and the first event
@@ -780,7 +785,8 @@ __device__ __forceinline__ CandList make_list(const DevParams &P, const BlockLds
 //   COUNT_ONLY: no replay; only the work counters are advanced, with the threshold frozen at thres_fixed (used to
 //   re-count the part of a pre-scanned task that precedes an event).
 // Returns 0 = range finished, 1 = range finished and the threshold was lowered on the way, 2 = SnpAlign returns.
-template <bool COUNT_ONLY, int BSX_SCAN_NB>
+// PE: instantiated for a paired batch (only picks the form of the single-end RRBS fragment filter's site search, see ccgg_seglen)
+template <bool COUNT_ONLY, int BSX_SCAN_NB, bool PE = true>
 __device__ int wave_scan_range(const DevParams &P, const BlockLds &BL, const MateLds &L, Mate &M, const Slab &SL, const CandList &cl, int orient,
                                int seg, int mode, uint32_t c_begin, uint32_t c_end, uint32_t thres_fixed, int lane, Counters &C)
 {
@@ -868,7 +874,7 @@ __device__ int wave_scan_range(const DevParams &P, const BlockLds &BL, const Mat
             while (surv_m) {
                 const int ls = (int)__builtin_ctzll(surv_m);
                 surv_m &= surv_m - 1;
-                const int e = accept_survivor(P, M, SL, orient, mode, rl(w, ls), rl(hchr, ls), rl(hloc, ls), rl(hkey, ls), lane);
+                const int e = accept_survivor<(BSX_SCAN_NB > 1) || !PE>(P, M, SL, orient, mode, rl(w, ls), rl(hchr, ls), rl(hloc, ls), rl(hkey, ls), lane);
                 if (e == 1) { status = 1; if (lane > ls) thr_eff = M.snp_thres; }
                 else if (e == 2) { if (lane > ls) alive = false; stop = true; break; }
             }
@@ -892,7 +898,7 @@ __device__ int wave_scan_range(const DevParams &P, const BlockLds &BL, const Mat
 #endif
 // SnpAlign (align.cpp:168-347) in the main kernel.  A WGBS list of heavy_threshold candidates or more sets M.defer and
 // returns: the unit is redone from scratch by the heavy pipeline, which scans such lists with the whole chip.
-template <bool EXACT>
+template <bool EXACT, bool PE>
 __device__ void snp_align(const DevParams &P, const BlockLds &BL, const MateLds &L, Mate &M, const Slab &SL, int mode, int lane,
                           Counters &C, uint32_t heavy_threshold)
 {
@@ -901,18 +907,18 @@ __device__ void snp_align(const DevParams &P, const BlockLds &BL, const MateLds 
         const int seg = L.order[orient][mode];  // modeindex
         const CandList cl = make_list<EXACT>(P, BL, L, M, orient, seg, lane);
         if (heavy_threshold && cl.total >= heavy_threshold) { M.defer = 1; return; }
-        if (wave_scan_range<false, BSX_MAIN_NB>(P, BL, L, M, SL, cl, orient, seg, mode, 0, cl.total, 0, lane, C) == 2) { wave_fence(); return; }
+        if (wave_scan_range<false, BSX_MAIN_NB, PE>(P, BL, L, M, SL, cl, orient, seg, mode, 0, cl.total, 0, lane, C) == 2) { wave_fence(); return; }
     }
     wave_fence();
 }
 
 // SingleAlign::RunAlign (align.cpp:435-452) after packing/planning
-template <bool EXACT>
+template <bool EXACT, bool PE>
 __device__ void run_align_single(const DevParams &P, const BlockLds &BL, const MateLds &L, Mate &M, const Slab &SL, int lane, Counters &C,
                                  uint32_t heavy_threshold)
 {
     for (int i = 0; i < M.seedseg; i++) {
-        snp_align<EXACT>(P, BL, L, M, SL, i, lane, C, heavy_threshold);
+        snp_align<EXACT, PE>(P, BL, L, M, SL, i, lane, C, heavy_threshold);
         if (M.defer) return;
         if (!P.rrbs) {
             const u64 nz = bsx_ballot(M.cnt_reg != 0 && (lane & 15) <= i && lane < 32);
@@ -935,7 +941,7 @@ __device__ void fix_unpaired_short_fragment(const DevParams &P, Mate &M, const S
                 const uint32_t i = base + lane;
                 const u64 h = i < n ? lst[i] : 0;
                 bool keep = false;
-                if (i < n) { const int sl = ccgg_seglen(P, (uint32_t)(h >> 32), (uint32_t)h, M.len); keep = !(sl < P.min_insert || sl > P.max_insert); }
+                if (i < n) { const int sl = ccgg_seglen<false>(P, (uint32_t)(h >> 32), (uint32_t)h, M.len); keep = !(sl < P.min_insert || sl > P.max_insert); }
                 const u64 m = bsx_ballot(keep);
                 if (keep) lst[kept + (uint32_t)__builtin_popcountll(m & lanemask_lt(lane))] = h;
                 kept += (uint32_t)__builtin_popcountll(m);
@@ -1281,14 +1287,14 @@ __device__ __forceinline__ bool process_unit(const AlignArgs &A, const BlockLds 
     if (PE && !MA.filtered && !MB.filtered) {
         const int maxi = max(MA.max_snp, MB.max_snp);  // PairAlign::RunAlign (pairs.cpp:163-172)
         for (int i = 0; i <= maxi && !paired && !defer; i++) {
-            if (i < MA.seedseg) snp_align<EXACT>(P, BL, LA, MA, U.SA, i, lane, C, hthr);
-            if (!MA.defer && i < MB.seedseg) snp_align<EXACT>(P, BL, LB, MB, U.SB, i, lane, C, hthr);
+            if (i < MA.seedseg) snp_align<EXACT, PE>(P, BL, LA, MA, U.SA, i, lane, C, hthr);
+            if (!MA.defer && i < MB.seedseg) snp_align<EXACT, PE>(P, BL, LB, MB, U.SB, i, lane, C, hthr);
             if (MA.defer || MB.defer) { defer = true; break; }
             if (pair_level_post(P, MA, MB, U, pcnt_reg, i, lane) > 0) paired = i + 1;
         }
     } else {
-        if (!MA.filtered) { run_align_single<EXACT>(P, BL, LA, MA, U.SA, lane, C, hthr); defer = MA.defer; }
-        if (PE && !defer && !MB.filtered) { run_align_single<EXACT>(P, BL, LB, MB, U.SB, lane, C, hthr); defer = MB.defer; }
+        if (!MA.filtered) { run_align_single<EXACT, PE>(P, BL, LA, MA, U.SA, lane, C, hthr); defer = MA.defer; }
+        if (PE && !defer && !MB.filtered) { run_align_single<EXACT, PE>(P, BL, LB, MB, U.SB, lane, C, hthr); defer = MB.defer; }
     }
     if (defer) { forget_keys(MA, U.SA, lane); if (PE) forget_keys(MB, U.SB, lane); C = C0; return true; }
     unit_finish<PE>(A, LA, LB, MA, MB, U, pcnt_reg, paired, unit, lane, n_aligned, n_aligned_pairs);
@@ -1562,7 +1568,7 @@ __device__ int snp_align_heavy(const AlignArgs &A, const HeavyArgs &H, HState *S
                                         while (m) {
                                             const int l1 = (int)__builtin_ctzll(m);
                                             m &= m - 1;
-                                            e = accept_survivor(P, M, SL, orient, mode, rl(r.w_ord, l1) & 0xff, rl(r.hchr, l1), rl(r.hloc, l1), rl(r.hkey, l1), lane);
+                                            e = accept_survivor<true>(P, M, SL, orient, mode, rl(r.w_ord, l1) & 0xff, rl(r.hchr, l1), rl(r.hloc, l1), rl(r.hkey, l1), lane);
                                             if (e) { ls = l1; break; }
                                         }
                                     CAT_END(A, 2);
@@ -1625,7 +1631,7 @@ __device__ int snp_align_heavy(const AlignArgs &A, const HeavyArgs &H, HState *S
                                 const int ls = (int)__builtin_ctzll(m);
                                 m &= m - 1;
                                 const uint32_t wo = rl(r.w_ord, ls);
-                                const int e = accept_survivor(P, M, SL, orient, mode, wo & 0xff, rl(r.hchr, ls), rl(r.hloc, ls), rl(r.hkey, ls), lane);
+                                const int e = accept_survivor<true>(P, M, SL, orient, mode, wo & 0xff, rl(r.hchr, ls), rl(r.hloc, ls), rl(r.hkey, ls), lane);
                                 if (e) { event = e; X = tc0 + (wo >> 8); break; }
                             }
                         }

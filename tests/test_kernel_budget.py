@@ -1,0 +1,43 @@
+"""Register / spill budget of the hot kernels (CPU-side: hipcc cross-compiles gfx950 and reports the resource usage).
+The main kernel's per-unit code is inlined into one 128-VGPR function; twice in round 2 an innocent-looking edit in a rarely
+taken branch (an integer division, a second binary search) pushed it from 256 B to 1.3 KB of spill per lane — 49 -> 67 ms per
+2^20 pairs — and only a profile showed it.  This test fails the build instead."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "bsmap_amd", "csrc", "bsx_align.hip")
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+# kernel (mangled-name fragment) -> (max VGPRs, max scratch bytes per lane)
+BUDGET = {
+    "7k_alignILb1ELb0EE": (128, 320),   # paired-end WGBS main kernel (the headline config)
+    "7k_alignILb0ELb0EE": (96, 320),    # single-end
+    "7k_hscanE": (64, 0),               # scan kernel of the heavy pipeline
+    "14k_hscan_shared": (96, 0),        # RRBS scan kernel
+}
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
+def test_hot_kernels_stay_within_their_register_budget(tmp_path):
+    res = subprocess.run([HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage",
+                          "-c", SRC, "-o", str(tmp_path / "a.o")], capture_output=True, text=True, timeout=1200, cwd=os.path.dirname(SRC))
+    assert res.returncode == 0, res.stderr[-2000:]
+    usage, name = {}, None
+    for line in res.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+            usage[name] = {}
+            continue
+        m = re.search(r"remark:\s+(VGPRs|ScratchSize \[bytes/lane\]): (\d+)", line)
+        if m and name:
+            usage[name][m.group(1).split()[0]] = int(m.group(2))
+    for frag, (vg, sc) in BUDGET.items():
+        hits = [u for n, u in usage.items() if frag in n]
+        assert len(hits) == 1, (frag, list(usage))
+        assert hits[0]["VGPRs"] <= vg and hits[0]["ScratchSize"] <= sc, (frag, hits[0], "budget", vg, sc)
