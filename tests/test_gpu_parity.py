@@ -342,9 +342,9 @@ def test_rrbs_random_options_vs_oracle(seed, oracle, tmp_path_factory):
 @pytest.mark.parametrize("seed", [1, 2, 3, 5, 6, 9, 12, 14, 17, 21])
 def test_rrbs_through_the_heavy_pipeline(seed, oracle, tmp_path_factory):
     """the same RRBS draws with the heavy-unit threshold forced down to 2 candidates: buckets of {tag, loc} pairs go through the
-    scan kernel (segment / direction filter on the device, chromosome-local positions, per-entry strand), survivors through the
-    one-at-a-time replay with the fragment-size filter, every round runs (RRBS has no early stop) — hits, picks, pairs and the
-    work counters must not change"""
+    scan kernels (k_hscan_shared for runs of tasks over one window, segment / direction filter on the device, chromosome-local
+    positions, per-entry strand), survivors through the 64-at-a-time replay with the per-lane fragment-size filter, every round
+    runs (RRBS has no early stop) — hits, picks, pairs and the work counters must not change"""
     B.lib().bsx_set_heavy_threshold(2)
     try:
         test_rrbs_random_options_vs_oracle(seed, oracle, tmp_path_factory)
