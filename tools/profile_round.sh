@@ -10,10 +10,6 @@ R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O
 export BSX_PROFILES_DIR=$O
 S=/tmp/bsx_prof_$$; mkdir -p $S
 cd $R
-timeout 1200 python3 bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err; echo "default rc=$?"
-for m in se rrbs trim; do
-  timeout 900 python3 bench.py --mode $m --e2e-pairs 0 > $O/${TAG}_bench_$m.json 2> $O/${TAG}_bench_$m.err; echo "$m rc=$?"
-done
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $S/stats -o s --output-format csv -- python3 $R/bench.py --profile-serial --steps 3 --warmup 1 > $O/${TAG}_bench_serial.json 2> $S/stats.log; echo "stats rc=$?"
 rocprofv3 --kernel-trace --stats -d $S/stats_default -o s --output-format csv -- python3 $R/bench.py --cpu-seconds 0 --e2e-pairs 0 --transfer-steps 0 --steps 4 --warmup 2 > $O/${TAG}_bench_under_rocprof.json 2> $S/stats_default.log; echo "stats default rc=$?"
@@ -24,5 +20,11 @@ for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_
 done
 python3 $R/tools/summarize_pmc.py $TAG $S/stats $S/pmc_FETCH_SIZE $S/pmc_WRITE_SIZE > /dev/null; echo "summarize_pmc rc=$?"
 python3 $R/tools/summarize_sq.py $TAG $S/pmc_SQ_WAVES $S/pmc_SQ_WAIT_INST_ANY $S/pmc_TA_TA_BUSY_sum > /dev/null; echo "summarize_sq rc=$?"
+cp $O/pmc_latest.json $R/profiles/pmc_latest.json  # (on the box) so that the bench lines below carry this build's traffic
+cd $R
+timeout 1200 python3 bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err; echo "default rc=$?"
+for m in se rrbs trim; do
+  timeout 900 python3 bench.py --mode $m --e2e-pairs 0 > $O/${TAG}_bench_$m.json 2> $O/${TAG}_bench_$m.err; echo "$m rc=$?"
+done
 $R/tools/microbench/valu_issue > $O/${TAG}_valu_issue.json 2>/dev/null; echo "valu rc=$?"
 rm -rf $S; ls -la $O | head -30
