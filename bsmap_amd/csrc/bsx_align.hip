@@ -97,6 +97,19 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
     return v;
 }
 
+// The wave-uniform part of a read's state lives in LDS (one MateU per mate and wave, allocated by the kernels): as members of a
+// private struct these fields ended up in scratch memory — the 128-VGPR budget of the main kernel has no room for them — and
+// every access was a scratch round trip inside a latency-bound chain.  All lanes of the wave write the same value.
+struct MateU {
+    int len, raw_len, max_snp, seedseg, filtered;
+    int nfull;           // len / seed_size (RRBS: cmodeindex = nfull - 1 - segment, align.cpp:221)
+    uint32_t flags;      // bit0 flag_chain, bit1 cflag_chain, bit2 duplicate-suppression set overflowed (RRBS single-end only)
+    uint32_t snp_thres;
+    uint32_t nkeys;
+    uint32_t index;      // ReadInf.index
+    int defer;           // main kernel: a candidate list exceeded heavy_threshold, redo this unit in the heavy kernel
+    uint32_t pad;
+};
 struct MateLds {
     uint8_t seq[160];
     uint8_t qual[160];
@@ -107,6 +120,7 @@ struct MateLds {
     // "-p 1 exact" mode: what the reference's never-reset planner state holds when this read is planned (resolve_leak)
     uint32_t stale_key[2][16];    // seed_array / cseed_array entries [noff, noff+16) left behind by earlier, longer reads
     uint8_t stale_so[2];          // seed_start_offset / cseed_start_offset of the last read that set them
+    MateU u, u2;                  // the read's wave-uniform state (Mate::u points here); u2: the absent second mate of a single-end unit
 };
 
 template <bool PE> struct WaveLds { MateLds mate[PE ? 2 : 1]; };
@@ -117,18 +131,14 @@ struct BlockLds {
 };
 
 // wave-uniform per-mate state; cnt_reg / key_reg are lane-distributed tables
+typedef __attribute__((address_space(3))) MateU LdsMateU;
 struct Mate {
-    int len, raw_len, max_snp, seedseg, filtered;
-    int nfull;           // len / seed_size (RRBS: cmodeindex = nfull - 1 - segment, align.cpp:221)
-    uint32_t flags;      // bit0 flag_chain, bit1 cflag_chain, bit2 duplicate-suppression set overflowed (RRBS single-end only)
-    uint32_t snp_thres;
-    uint32_t nkeys;
+    LdsMateU *u;
     uint32_t cnt_reg;    // lane (orient*16+w) holds _cur_n_hit / _cur_n_chit
     uint32_t key_reg;    // lane i holds the i-th accepted forward coordinate (hitset, first 64)
     uint32_t bloom0, bloom1;  // 4096-bit membership filter over all accepted coordinates (bit b of lane l)
-    uint32_t index;      // ReadInf.index
-    int defer;           // main kernel: a candidate list exceeded heavy_threshold, redo this unit in the heavy kernel
 };
+__device__ __forceinline__ LdsMateU *lds_mate(MateU *p) { return (LdsMateU *)p; }
 
 struct Slab {
     // Rows are laid out exactly like the reference's `new HitArray[MAXSNPS+1]` (align.cpp:21-22): row w starts at
@@ -177,8 +187,8 @@ __device__ void load_and_filter(const AlignArgs &A, MateLds &L, Mate &M, int mat
         L.qual[i] = (q && i < len) ? q[i] : 0;
     }
     wave_fence();
-    M.raw_len = len;
-    M.filtered = 0;
+    M.u->raw_len = len;
+    M.u->filtered = 0;
     // TrimAdapter, WGBS branch (align.cpp:410-423): first adapter, then first position, whose <=15-nt prefix matches
     // the read tail with k >= 5*mismatches and k > 3
     if (P.n_adapter > 0 && len >= 5) {
@@ -229,29 +239,29 @@ __device__ void load_and_filter(const AlignArgs &A, MateLds &L, Mate &M, int mat
             if (mask) best = base + 64 - (int)__builtin_clzll(mask);
         }
         if (best >= P.seed_size) len = min(len, best);
-        else M.filtered = 1;
+        else M.u->filtered = 1;
     }
-    if (len < P.seed_size) M.filtered = 1;  // min_read_size
+    if (len < P.seed_size) M.u->filtered = 1;  // min_read_size
     {
         uint32_t ns = 0;  // CountNs (align.cpp:48-55)
         for (int base = 0; base < len; base += 64) {
             const int i = base + lane;
             ns += (uint32_t)__builtin_popcountll(bsx_ballot(i < len && nt_idx(L.seq[i]) < 0));
         }
-        if ((int)ns > P.max_ns) M.filtered = 1;
+        if ((int)ns > P.max_ns) M.u->filtered = 1;
     }
-    M.len = len;
-    M.max_snp = M.filtered ? 0 : (int)(((uint64_t)(P.max_snp_num + 1) * (uint64_t)(len - 1)) / (uint64_t)M.raw_len);
-    const int x = (len - P.index_interval + 1) / P.seed_size, y = M.max_snp + 1;  // align.cpp:440
-    M.seedseg = M.filtered ? 0 : min(x, y);
-    M.nfull = len / P.seed_size;
-    M.snp_thres = (uint32_t)M.max_snp;
-    M.nkeys = 0;
+    M.u->len = len;
+    M.u->max_snp = M.u->filtered ? 0 : (int)(((uint64_t)(P.max_snp_num + 1) * (uint64_t)(len - 1)) / (uint64_t)M.u->raw_len);
+    const int x = (len - P.index_interval + 1) / P.seed_size, y = M.u->max_snp + 1;  // align.cpp:440
+    M.u->seedseg = M.u->filtered ? 0 : min(x, y);
+    M.u->nfull = len / P.seed_size;
+    M.u->snp_thres = (uint32_t)M.u->max_snp;
+    M.u->nkeys = 0;
     M.cnt_reg = 0;
     M.key_reg = 0;
     M.bloom0 = M.bloom1 = 0;
-    M.defer = 0;
-    M.flags = 0;  // (set by pack_read; a filtered read never gets there and bit 2 is reported)
+    M.u->defer = 0;
+    M.u->flags = 0;  // (set by pack_read; a filtered read never gets there and bit 2 is reported)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -260,15 +270,15 @@ __device__ void load_and_filter(const AlignArgs &A, MateLds &L, Mate &M, int mat
 // ---------------------------------------------------------------------------------------------------------------
 __device__ void pack_read(const DevParams &P, MateLds &L, Mate &M, int readset, int lane, Counters &C)
 {
-    M.flags = ((P.chains || readset < 2) ? 1u : 0u) | ((P.chains || readset == 2) ? 2u : 0u);  // align.cpp:93-94
+    M.u->flags = ((P.chains || readset < 2) ? 1u : 0u) | ((P.chains || readset == 2) ? 2u : 0u);  // align.cpp:93-94
     const int orient = lane >> 4, t = lane & 15;
     if (orient < 2 && t < 10) {
         uint32_t w = 0, m = 0;
         for (int j = 0; j < 16; j++) {
             const int pos = t * 16 + j;
             uint32_t code = 0, reg = 0;
-            if (pos < M.len) {
-                const int k = nt_idx(L.seq[orient ? M.len - 1 - pos : pos]);
+            if (pos < M.u->len) {
+                const int k = nt_idx(L.seq[orient ? M.u->len - 1 - pos : pos]);
                 const int sel = orient ? (k < 0 ? 3 : 3 - k) : (k < 0 ? 0 : k);  // rev_alphabet / alphabet
                 code = (P.bit_nt_packed >> (8 * sel)) & 3u;
                 reg = k < 0 ? 0u : 3u;                                              // reg_alphabet
@@ -280,7 +290,7 @@ __device__ void pack_read(const DevParams &P, MateLds &L, Mate &M, int readset, 
         L.m[orient][t] = m;
     }
     wave_fence();
-    C.n_orient += (M.flags & 1) + ((M.flags >> 1) & 1);
+    C.n_orient += (M.u->flags & 1) + ((M.u->flags >> 1) & 1);
 }
 
 __device__ __forceinline__ uint32_t seed_key_at(const DevParams &P, const uint32_t *w, int o)
@@ -297,7 +307,7 @@ template <bool EXACT>
 __device__ __forceinline__ uint32_t key_at(const DevParams &P, const MateLds &L, const Mate &M, int orient, int o)
 {
     if (!EXACT) return seed_key_at(P, L.w[orient], o);
-    const int noff = M.len - P.seed_size + 1;
+    const int noff = M.u->len - P.seed_size + 1;
     return o >= noff ? L.stale_key[orient][min(o - noff, 15)] : seed_key_at(P, L.w[orient], o);
 }
 
@@ -305,7 +315,7 @@ __device__ __forceinline__ uint32_t key_at(const DevParams &P, const MateLds &L,
 template <bool EXACT>
 __device__ void plan_counts(const DevParams &P, MateLds &L, const Mate &M, int orient, int lane, bool with_tail)
 {
-    const int noff = M.len - P.seed_size + 1, n = noff + (with_tail ? 16 : 0);
+    const int noff = M.u->len - P.seed_size + 1, n = noff + (with_tail ? 16 : 0);
     for (int base = 0; base < n; base += 64) {
         const int o = base + lane;
         if (o < n) {
@@ -321,7 +331,7 @@ __device__ void plan_counts(const DevParams &P, MateLds &L, const Mate &M, int o
 // GetTotalSeedLoc for every start offset, first minimum wins (align.cpp:458-468); counts must be in L.cnt
 __device__ int plan_best_offset(const DevParams &P, const BlockLds &BL, const MateLds &L, const Mate &M, int orient, int lane)
 {
-    const int I = P.index_interval, nseg = M.seedseg, nstart = (M.len - I + 1) % P.seed_size;
+    const int I = P.index_interval, nseg = M.u->seedseg, nstart = (M.u->len - I + 1) % P.seed_size;
     const uint32_t *cnt = L.cnt[orient];
     u64 key = ~0ull;
     if (lane < nstart) {
@@ -341,11 +351,11 @@ template <bool EXACT>
 __device__ void plan_orient(const DevParams &P, const BlockLds &BL, MateLds &L, const Mate &M, int orient, int lane, Counters &C, bool leaky_arg = false)
 {
     const bool leaky_exact = EXACT && leaky_arg;
-    const int I = P.index_interval, S = P.seed_size, nseg = M.seedseg;
+    const int I = P.index_interval, S = P.seed_size, nseg = M.u->seedseg;
     plan_counts<EXACT>(P, L, M, orient, lane, leaky_exact);
     const uint32_t *cnt = L.cnt[orient];
     int offset = leaky_exact ? (int)L.stale_so[orient] : 0;  // the loop below does not run for such a read: the old value stays (align.cpp:458)
-    const int nstart = P.rrbs ? 0 : (M.len - I + 1) % S;
+    const int nstart = P.rrbs ? 0 : (M.u->len - I + 1) % S;
     u64 lookups = 0;
     if (nstart > 0) {  // GetTotalSeedLoc for every start, first minimum wins (align.cpp:458-468)
         u64 key = ~0ull;
@@ -385,7 +395,7 @@ __device__ void plan_orient(const DevParams &P, const BlockLds &BL, MateLds &L, 
     {
         int s = 0;
         if (lane < nseg) {
-            if (P.rrbs) s = (int)cnt[BL.prof[lane][0] + (orient ? (M.len % S) : 0) + L.start[orient][lane]];  // GenerateCSeeds adds cseed_offset
+            if (P.rrbs) s = (int)cnt[BL.prof[lane][0] + (orient ? (M.u->len % S) : 0) + L.start[orient][lane]];  // GenerateCSeeds adds cseed_offset
             else
                 for (int ph = 0; ph < I; ph++) s += (int)cnt[BL.prof[lane][ph] + L.start[orient][lane] - ph];
         }
@@ -426,8 +436,8 @@ __device__ __forceinline__ bool seen_before(const Mate &M, const Slab &SL, uint3
     const uint32_t slot = bloom_slot(key);
     const uint32_t word = (slot & 2048) ? rl(M.bloom1, (slot >> 5) & 63) : rl(M.bloom0, (slot >> 5) & 63);
     if (!((word >> (slot & 31)) & 1)) return false;
-    if (bsx_ballot((uint32_t)lane < min(M.nkeys, 64u) && M.key_reg == key)) return true;
-    if (M.nkeys <= 64) return false;
+    if (bsx_ballot((uint32_t)lane < min(M.u->nkeys, 64u) && M.key_reg == key)) return true;
+    if (M.u->nkeys <= 64) return false;
     // linear probing, 64 slots per step: found if the key shows up before the first empty slot
     const uint32_t hmask = (1u << SL.hbits) - 1;
     for (uint32_t h = hset_home(key, SL.hbits);; h = (h + 64) & hmask) {
@@ -440,29 +450,33 @@ __device__ __forceinline__ bool seen_before(const Mate &M, const Slab &SL, uint3
 
 __device__ __forceinline__ void remember_key(Mate &M, const Slab &SL, uint32_t key, int lane)
 {
-    if (M.nkeys < 64) { if ((uint32_t)lane == M.nkeys) M.key_reg = key; }
-    else if (M.nkeys >= SL.kcap) { M.flags |= 4u; return; }  // set full (RRBS only, see Slab): the coordinate is not remembered, the unit is flagged (bit 2 of flags)
+    if (M.u->nkeys < 64) { if ((uint32_t)lane == M.u->nkeys) M.key_reg = key; }
+    else if (M.u->nkeys >= SL.kcap) { M.u->flags |= 4u; return; }  // set full (RRBS only, see Slab): the coordinate is not remembered, the unit is flagged (bit 2 of flags)
     else {
         const uint32_t hmask = (1u << SL.hbits) - 1;
         for (uint32_t h = hset_home(key, SL.hbits);; h = (h + 64) & hmask) {
             const uint32_t sidx = (h + lane) & hmask;
             const u64 empty = bsx_ballot(SL.hset[sidx] == 0);
             if (empty) {
-                if (lane == (int)__builtin_ctzll(empty)) { SL.hset[sidx] = key + 1; SL.keys[M.nkeys] = key; SL.kslot[M.nkeys] = sidx; }
+                if (lane == (int)__builtin_ctzll(empty)) { SL.hset[sidx] = key + 1; SL.keys[M.u->nkeys] = key; SL.kslot[M.u->nkeys] = sidx; }
                 break;
             }
         }
         wave_fence();
     }
-    M.nkeys++;
+    M.u->nkeys++;
     const uint32_t slot = bloom_slot(key);
-    if ((uint32_t)lane == ((slot >> 5) & 63)) { if (slot & 2048) M.bloom1 |= 1u << (slot & 31); else M.bloom0 |= 1u << (slot & 31); }
+    // (both words are written unconditionally: an "if / else" over two fields becomes a store through a selected address, and
+    //  one such store keeps the whole Mate in private memory — every M.field access a scratch round trip — instead of registers)
+    const uint32_t bit = (uint32_t)lane == ((slot >> 5) & 63) ? 1u << (slot & 31) : 0u;
+    M.bloom0 |= (slot & 2048) ? 0u : bit;
+    M.bloom1 |= (slot & 2048) ? bit : 0u;
 }
 
 // leave the hash set empty for the next unit that uses this slab
 __device__ __forceinline__ void forget_keys(const Mate &M, const Slab &SL, int lane)
 {
-    for (uint32_t i = 64 + lane; i < M.nkeys; i += 64) SL.hset[SL.kslot[i]] = 0;
+    for (uint32_t i = 64 + lane; i < M.u->nkeys; i += 64) SL.hset[SL.kslot[i]] = 0;
     wave_fence();
 }
 
@@ -614,11 +628,11 @@ template <bool BINS>
 __device__ __forceinline__ int accept_survivor(const DevParams &P, Mate &M, const Slab &SL, int orient, int mode, uint32_t ws, uint32_t hchr,
                                                uint32_t hloc, uint32_t hkey, int lane)
 {
-    if (ws > M.snp_thres) return 0;
+    if (ws > M.u->snp_thres) return 0;
     if (seen_before(M, SL, hkey, lane)) return 0;
     remember_key(M, SL, hkey, lane);  // hitset.insert
     if (P.rrbs && !P.pairend && orient == 0) {  // fragment size filter, forward chain only (align.cpp:202-207)
-        const int sl = ccgg_seglen<BINS>(P, hchr, hloc, M.len);
+        const int sl = ccgg_seglen<BINS>(P, hchr, hloc, M.u->len);
         if (sl > P.max_insert || sl < P.min_insert) return 0;
     }
     const uint32_t n = n_of(M, orient, (int)ws);
@@ -628,7 +642,7 @@ __device__ __forceinline__ int accept_survivor(const DevParams &P, Mate &M, cons
     if ((int)ws == mode && !P.pairend && P.report_repeat_hits == 0 && both > 1) return 2;
     if (both >= (uint32_t)P.max_num_hits) {
         if (ws == 0) return 2;
-        M.snp_thres = ws - 1;
+        M.u->snp_thres = ws - 1;
         return 1;
     }
     return 0;
@@ -644,7 +658,7 @@ __device__ int accept_group(const DevParams &P, Mate &M, const Slab &SL, int ori
                             uint32_t hkey, int lane, int &ev_lane)
 {
     ev_lane = -1;
-    bool cand = ((act >> lane) & 1) && ws <= M.snp_thres;
+    bool cand = ((act >> lane) & 1) && ws <= M.u->snp_thres;
     // already in the hitset?  filter bits live in other lanes' registers: fetch the word, then the exact tests
     {
         const uint32_t slot = bloom_slot(hkey);
@@ -653,9 +667,9 @@ __device__ int accept_group(const DevParams &P, Mate &M, const Slab &SL, int ori
         const bool maybe = cand && ((((slot & 2048) ? w1 : w0) >> (slot & 31)) & 1);
         if (bsx_ballot(maybe)) {
             bool found = false;
-            const uint32_t nk = min(M.nkeys, 64u);
+            const uint32_t nk = min(M.u->nkeys, 64u);
             for (uint32_t j = 0; j < nk; j++) found |= rl(M.key_reg, (int)j) == hkey;
-            bool probing = maybe && !found && M.nkeys > 64;
+            bool probing = maybe && !found && M.u->nkeys > 64;
             uint32_t h = hset_home(hkey, SL.hbits);
             while (bsx_ballot(probing)) {
                 if (probing) {
@@ -678,12 +692,12 @@ __device__ int accept_group(const DevParams &P, Mate &M, const Slab &SL, int ori
     // out of range (align.cpp:201-207) — `cand` lanes enter the hitset, only `app` lanes are appended and can cause events
     bool app = cand;
     if (P.rrbs && !P.pairend && orient == 0 && cand) {
-        const int sl = ccgg_seglen<true>(P, hchr, hloc, M.len);
+        const int sl = ccgg_seglen<true>(P, hchr, hloc, M.u->len);
         app = !(sl > P.max_insert || sl < P.min_insert);
     }
     // position inside the class list and the first event
     uint32_t rank = 0, mine = 0, other = 0;
-    const uint32_t cmax = min(M.snp_thres, (uint32_t)BSX_MAXSNPS);
+    const uint32_t cmax = min(M.u->snp_thres, (uint32_t)BSX_MAXSNPS);
     for (uint32_t c = 0; c <= cmax; c++) {
         const u64 mc = bsx_ballot(app && ws == c);
         if (!mc) continue;
@@ -703,18 +717,20 @@ __device__ int accept_group(const DevParams &P, Mate &M, const Slab &SL, int ori
         if (mc && lane == orient * 16 + (int)c) M.cnt_reg += (uint32_t)__builtin_popcountll(mc);
     }
     // hitset.insert: registers for the first 64 coordinates, the slab's hash set beyond, filter bits for all
-    const uint32_t kidx = M.nkeys + (uint32_t)__builtin_popcountll(km & lanemask_lt(lane));
+    const uint32_t kidx = M.u->nkeys + (uint32_t)__builtin_popcountll(km & lanemask_lt(lane));
     {
-        uint32_t k = M.nkeys;
+        uint32_t k = M.u->nkeys;
         for (u64 t = km; t; t &= t - 1, k++) {
             const int j = (int)__builtin_ctzll(t);
             const uint32_t kv = rl(hkey, j), slot = bloom_slot(kv);
             if (k < 64 && (uint32_t)lane == k) M.key_reg = kv;
-            if ((uint32_t)lane == ((slot >> 5) & 63)) { if (slot & 2048) M.bloom1 |= 1u << (slot & 31); else M.bloom0 |= 1u << (slot & 31); }
+            const uint32_t bit = (uint32_t)lane == ((slot >> 5) & 63) ? 1u << (slot & 31) : 0u;
+            M.bloom0 |= (slot & 2048) ? 0u : bit;  // (no store through a selected address: see remember_key)
+            M.bloom1 |= (slot & 2048) ? bit : 0u;
         }
     }
     {
-        if (bsx_ballot(commit_key && kidx >= SL.kcap)) M.flags |= 4u;  // set full: the unit is flagged and redone (see k_hctrl); nothing is written past the arrays
+        if (bsx_ballot(commit_key && kidx >= SL.kcap)) M.u->flags |= 4u;  // set full: the unit is flagged and redone (see k_hctrl); nothing is written past the arrays
         bool pending = commit_key && kidx >= 64 && kidx < SL.kcap;
         uint32_t h = hset_home(hkey, SL.hbits);
         while (bsx_ballot(pending)) {  // claim by write-then-verify: lanes racing for one empty slot see who landed
@@ -727,12 +743,12 @@ __device__ int accept_group(const DevParams &P, Mate &M, const Slab &SL, int ori
             wave_fence();
         }
     }
-    M.nkeys = min(M.nkeys + (uint32_t)__builtin_popcountll(km), max(SL.kcap, 64u));
+    M.u->nkeys = min(M.u->nkeys + (uint32_t)__builtin_popcountll(km), max(SL.kcap, 64u));
     wave_fence();
     if (!em) return 0;
     ev_lane = E;
     if ((em2 >> E) & 1) return 2;
-    M.snp_thres = rl(ws, E) - 1;
+    M.u->snp_thres = rl(ws, E) - 1;
     return 1;
 }
 
@@ -754,11 +770,11 @@ __device__ __forceinline__ CandList make_list(const DevParams &P, const BlockLds
     if (lane < cl.nsub) {
         if (P.rrbs) {
             const int a = BL.prof[seg][0];
-            const int coff = orient ? (M.len % P.seed_size) : 0;  // cseed_offset (align.cpp:443)
+            const int coff = orient ? (M.u->len % P.seed_size) : 0;  // cseed_offset (align.cpp:443)
             const uint32_t key = seed_key_at(P, L.w[orient], a + coff + L.start[orient][seg]);
             // the entries of this read's (segment, direction) are a contiguous part of the bucket (bsx_index_build_rrbs);
             // a group outside 0..15 has no entry (the reference's tag filter rejects the whole bucket)
-            const uint32_t g_ = orient ? (uint32_t)(M.nfull - 1 - seg) : (uint32_t)seg;  // cmodeindex (align.cpp:221) / modeindex
+            const uint32_t g_ = orient ? (uint32_t)(M.u->nfull - 1 - seg) : (uint32_t)seg;  // cmodeindex (align.cpp:221) / modeindex
             const U2 b = *reinterpret_cast<const U2 *>(P.rrbs_goff + (size_t)key * 32 + (orient << 4) + (g_ & 15));
             cl.sub_base = b.a; cl.sub_n = g_ > 15u ? 0u : b.b - b.a;
             cl.sub_h = (uint32_t)(a + coff);
@@ -790,12 +806,12 @@ template <bool COUNT_ONLY, int BSX_SCAN_NB, bool PE = true>
 __device__ int wave_scan_range(const DevParams &P, const BlockLds &BL, const MateLds &L, Mate &M, const Slab &SL, const CandList &cl, int orient,
                                int seg, int mode, uint32_t c_begin, uint32_t c_end, uint32_t thres_fixed, int lane, Counters &C)
 {
-    const int nwords = (M.len + 15) >> 4;
+    const int nwords = (M.u->len + 15) >> 4;
     const bool lds_chr = P.n_chr <= BSX_LDS_CHR;
     uint32_t rw[9], rm[9];  // read words + masks in scalar registers
 #pragma unroll
     for (int t = 0; t < 9; t++) { rw[t] = rfl(L.w[orient][t]); rm[t] = rfl(L.m[orient][t]); }
-    const int cmode = M.nfull - 1 - seg;  // cmodeindex (align.cpp:221)
+    const int cmode = M.u->nfull - 1 - seg;  // cmodeindex (align.cpp:221)
     int status = 0;
     // BSX_SCAN_NB chunks of 64 candidates per step: all their index entries are requested together, then all their
     // first reference words, and only then are the chunks evaluated one after the other in list order (two memory
@@ -842,7 +858,7 @@ __device__ int wave_scan_range(const DevParams &P, const BlockLds &BL, const Mat
         const bool valid = valid_[u];
         const uint32_t p = p_[u], rchr = aux_[u], strand = P.rrbs ? (aux_[u] & 1) : aux_[u];
         CandEval ev = {0xffff, 0, 0, 0};
-        const uint32_t thres0 = COUNT_ONLY ? thres_fixed : M.snp_thres;
+        const uint32_t thres0 = COUNT_ONLY ? thres_fixed : M.u->snp_thres;
         if (valid) ev = eval_loaded((strand ? P.crefcat : P.refcat) + ((p - 1) >> 4), r0_[u], rw, rm, nwords, p, thres0);
         uint32_t thr_eff = thres0;
         bool alive = valid, stop = false;
@@ -855,10 +871,10 @@ __device__ int wave_scan_range(const DevParams &P, const BlockLds &BL, const Mat
                     const uint32_t c = rchr >> 1;
                     const uint32_t an = lds_chr ? BL.anchor[c] : P.anchor[c], sz = lds_chr ? BL.chr_size[c] : P.chr_size[c];
                     uint32_t loc = p - an;
-                    if (strand) loc = (lds_chr ? BL.rc_offset[c] : P.rc_offset[c]) - (uint32_t)M.len - loc;
+                    if (strand) loc = (lds_chr ? BL.rc_offset[c] : P.rc_offset[c]) - (uint32_t)M.u->len - loc;
                     hchr = 2 * c + strand; hloc = loc; hkey = an + loc;
-                    if ((u64)loc + (u64)M.len > (u64)sz) pass = false;
-                } else pass = hit_coords(P, BL, p, strand, M.len, hchr, hloc, hkey);
+                    if ((u64)loc + (u64)M.u->len > (u64)sz) pass = false;
+                } else pass = hit_coords(P, BL, p, strand, M.u->len, hchr, hloc, hkey);
             }
             u64 surv_m = bsx_ballot(pass);  // ordered replay of the survivors
             if (BSX_SCAN_NB > 1 && __builtin_popcountll(surv_m) > BSX_GROUP_MIN) {  // heavy pipeline: 64 at a time, resuming behind every threshold change
@@ -866,7 +882,7 @@ __device__ int wave_scan_range(const DevParams &P, const BlockLds &BL, const Mat
                     int ls;
                     const int e = accept_group(P, M, SL, orient, mode, surv_m, w, hchr, hloc, hkey, lane, ls);
                     if (e == 0) break;
-                    if (e == 1) { status = 1; if (lane > ls) thr_eff = M.snp_thres; surv_m &= ~(lanemask_lt(ls) | (1ull << ls)); }
+                    if (e == 1) { status = 1; if (lane > ls) thr_eff = M.u->snp_thres; surv_m &= ~(lanemask_lt(ls) | (1ull << ls)); }
                     else { if (lane > ls) alive = false; stop = true; break; }
                 }
                 surv_m = 0;
@@ -875,7 +891,7 @@ __device__ int wave_scan_range(const DevParams &P, const BlockLds &BL, const Mat
                 const int ls = (int)__builtin_ctzll(surv_m);
                 surv_m &= surv_m - 1;
                 const int e = accept_survivor<(BSX_SCAN_NB > 1) || !PE>(P, M, SL, orient, mode, rl(w, ls), rl(hchr, ls), rl(hloc, ls), rl(hkey, ls), lane);
-                if (e == 1) { status = 1; if (lane > ls) thr_eff = M.snp_thres; }
+                if (e == 1) { status = 1; if (lane > ls) thr_eff = M.u->snp_thres; }
                 else if (e == 2) { if (lane > ls) alive = false; stop = true; break; }
             }
         }
@@ -896,17 +912,17 @@ __device__ int wave_scan_range(const DevParams &P, const BlockLds &BL, const Mat
 #ifndef BSX_MAIN_NB
 #define BSX_MAIN_NB 1  /* chunks of 64 candidates per step of the main kernel's scan */
 #endif
-// SnpAlign (align.cpp:168-347) in the main kernel.  A WGBS list of heavy_threshold candidates or more sets M.defer and
+// SnpAlign (align.cpp:168-347) in the main kernel.  A WGBS list of heavy_threshold candidates or more sets M.u->defer and
 // returns: the unit is redone from scratch by the heavy pipeline, which scans such lists with the whole chip.
 template <bool EXACT, bool PE>
 __device__ void snp_align(const DevParams &P, const BlockLds &BL, const MateLds &L, Mate &M, const Slab &SL, int mode, int lane,
                           Counters &C, uint32_t heavy_threshold)
 {
     for (int orient = 0; orient < 2; orient++) {
-        if (!((M.flags >> orient) & 1)) continue;
+        if (!((M.u->flags >> orient) & 1)) continue;
         const int seg = L.order[orient][mode];  // modeindex
         const CandList cl = make_list<EXACT>(P, BL, L, M, orient, seg, lane);
-        if (heavy_threshold && cl.total >= heavy_threshold) { M.defer = 1; return; }
+        if (heavy_threshold && cl.total >= heavy_threshold) { M.u->defer = 1; return; }
         if (wave_scan_range<false, BSX_MAIN_NB, PE>(P, BL, L, M, SL, cl, orient, seg, mode, 0, cl.total, 0, lane, C) == 2) { wave_fence(); return; }
     }
     wave_fence();
@@ -917,9 +933,9 @@ template <bool EXACT, bool PE>
 __device__ void run_align_single(const DevParams &P, const BlockLds &BL, const MateLds &L, Mate &M, const Slab &SL, int lane, Counters &C,
                                  uint32_t heavy_threshold)
 {
-    for (int i = 0; i < M.seedseg; i++) {
+    for (int i = 0; i < M.u->seedseg; i++) {
         snp_align<EXACT, PE>(P, BL, L, M, SL, i, lane, C, heavy_threshold);
-        if (M.defer) return;
+        if (M.u->defer) return;
         if (!P.rrbs) {
             const u64 nz = bsx_ballot(M.cnt_reg != 0 && (lane & 15) <= i && lane < 32);
             if (nz) return;
@@ -931,8 +947,8 @@ __device__ void run_align_single(const DevParams &P, const BlockLds &BL, const M
 // the hits whose restriction fragment is out of range; stops at the first class that still has a hit
 __device__ void fix_unpaired_short_fragment(const DevParams &P, Mate &M, const Slab &SL, int lane)
 {
-    if (M.filtered || M.len >= P.min_insert) return;
-    for (int ii = 0; ii <= M.max_snp; ii++) {
+    if (M.u->filtered || M.u->len >= P.min_insert) return;
+    for (int ii = 0; ii <= M.u->max_snp; ii++) {
         for (int orient = 0; orient < 2; orient++) {
             const uint32_t n = n_of(M, orient, ii);
             u64 *lst = SL.list(orient, ii);
@@ -941,7 +957,7 @@ __device__ void fix_unpaired_short_fragment(const DevParams &P, Mate &M, const S
                 const uint32_t i = base + lane;
                 const u64 h = i < n ? lst[i] : 0;
                 bool keep = false;
-                if (i < n) { const int sl = ccgg_seglen<false>(P, (uint32_t)(h >> 32), (uint32_t)h, M.len); keep = !(sl < P.min_insert || sl > P.max_insert); }
+                if (i < n) { const int sl = ccgg_seglen<false>(P, (uint32_t)(h >> 32), (uint32_t)h, M.u->len); keep = !(sl < P.min_insert || sl > P.max_insert); }
                 const u64 m = bsx_ballot(keep);
                 if (keep) lst[kept + (uint32_t)__builtin_popcountll(m & lanemask_lt(lane))] = h;
                 kept += (uint32_t)__builtin_popcountll(m);
@@ -957,18 +973,18 @@ __device__ void fix_unpaired_short_fragment(const DevParams &P, Mate &M, const S
 __device__ void select_hit(const DevParams &P, const Mate &M, const Slab &SL, bsx_hit &out, bool unpair_semantics)
 {
     out.chr = 0; out.loc = 0; out.n_best = 0; out.best_class = -1;
-    out.flags = (M.filtered ? BSX_F_FILTERED : 0) | ((M.flags & 4u) ? BSX_F_LIMIT : 0);
-    out.len = (uint8_t)M.len; out.raw_len = (uint8_t)M.raw_len; out.max_snp = (uint8_t)M.max_snp; out.seedseg = (uint8_t)M.seedseg;
-    if (M.filtered) return;
+    out.flags = (M.u->filtered ? BSX_F_FILTERED : 0) | ((M.u->flags & 4u) ? BSX_F_LIMIT : 0);
+    out.len = (uint8_t)M.u->len; out.raw_len = (uint8_t)M.u->raw_len; out.max_snp = (uint8_t)M.u->max_snp; out.seedseg = (uint8_t)M.u->seedseg;
+    if (M.u->filtered) return;
     int ii; uint32_t sum = 0, nf = 0;
-    for (ii = 0; ii <= M.max_snp; ii++) {
+    for (ii = 0; ii <= M.u->max_snp; ii++) {
         nf = n_of(M, 0, ii);
         if ((sum = nf + n_of(M, 1, ii)) > 0) break;
     }
     if (sum == 0) return;
     out.n_best = (uint16_t)sum; out.best_class = (int8_t)ii;
     uint32_t j = 0;
-    if (!unpair_semantics || sum > 1) j = bsx_myrand(M.index, P.randseed) % sum;
+    if (!unpair_semantics || sum > 1) j = bsx_myrand(M.u->index, P.randseed) % sum;
     u64 h;
     if (j < nf) h = SL.list(0, ii)[j];
     else { h = SL.list(1, ii)[j - nf]; out.flags |= BSX_F_CHAIN; }
@@ -1039,7 +1055,7 @@ __device__ __forceinline__ uint32_t first_chr_ge(const u64 *lst, uint32_t from, 
 __device__ int get_pairs(const DevParams &P, const Mate &MA, const Mate &MB, const Slab &SA, const Slab &SB, const PairSlab &PS,
                          uint32_t &pcnt_reg, int na, int nb, int lane)
 {
-    if (na > MA.max_snp || nb > MB.max_snp) return 0;
+    if (na > MA.u->max_snp || nb > MB.u->max_snp) return 0;
     const int cls = na + nb;
     uint32_t cnt = rl(pcnt_reg, cls);
     uint32_t *row = PS.row(cls);
@@ -1072,8 +1088,8 @@ __device__ int get_pairs(const DevParams &P, const Mate &MA, const Mate &MB, con
                 const uint32_t bloc = (uint32_t)hb;
                 uint32_t seg_start, seg_end;
                 const bool odd = (chra & 1) != 0;
-                if (pass == 0 ? odd : !odd) { seg_start = bloc; seg_end = aloc + (uint32_t)MA.len; }   // pairs.cpp:72,99
-                else { seg_start = aloc; seg_end = bloc + (uint32_t)MB.len; }                          // pairs.cpp:73,100
+                if (pass == 0 ? odd : !odd) { seg_start = bloc; seg_end = aloc + (uint32_t)MA.u->len; }   // pairs.cpp:72,99
+                else { seg_start = aloc; seg_end = bloc + (uint32_t)MB.u->len; }                          // pairs.cpp:73,100
                 const int insert = (int)(seg_end - seg_start);
                 const bool ok = valid && insert >= P.min_insert && insert <= P.max_insert;
                 u64 m = bsx_ballot(ok);
@@ -1138,29 +1154,30 @@ template <bool PE>
 __device__ void resolve_leak(const AlignArgs &A, const BlockLds &BL, MateLds &LS, MateLds &L, const Mate &M, int mate, uint32_t unit, int lane)
 {
     const DevParams &P = A.P;
-    const int S = P.seed_size, I = P.index_interval, noff = M.len - S + 1;
+    const int S = P.seed_size, I = P.index_interval, noff = M.u->len - S + 1;
     if (lane < 32) (&L.stale_key[0][0])[lane] = 0;
     if (lane < 2) L.stale_so[lane] = 0;
     wave_fence();
-    uint32_t need_so = M.flags & 3u;
-    uint32_t need_tail[2] = {(M.flags & 1u) ? 0xffffu : 0u, (M.flags & 2u) ? 0xffffu : 0u};
+    uint32_t need_so = M.u->flags & 3u;
+    uint32_t need_tail[2] = {(M.u->flags & 1u) ? 0xffffu : 0u, (M.u->flags & 2u) ? 0xffffu : 0u};
     Counters dummy = {0, 0, 0, 0};
     for (long j = (long)unit - 1; (need_so | need_tail[0] | need_tail[1]) && j >= -(long)A.n_hist; j--) {
         Mate MJ;
-        MJ.index = 0;
+        MJ.u = lds_mate(&LS.u);
+        MJ.u->index = 0;
         load_and_filter(A, LS, MJ, mate, j, lane);
-        if (MJ.filtered) continue;  // RunAlign is not called for a read FilterReads rejects (align.cpp:598, pairs.cpp:199-213): state untouched
+        if (MJ.u->filtered) continue;  // RunAlign is not called for a read FilterReads rejects (align.cpp:598, pairs.cpp:199-213): state untouched
         pack_read(P, LS, MJ, PE ? mate + 1 : 0, lane, dummy);
-        const int noff_j = MJ.len - S + 1;
+        const int noff_j = MJ.u->len - S + 1;
         for (int orient = 0; orient < 2; orient++) {
-            if (!((MJ.flags >> orient) & 1)) continue;
+            if (!((MJ.u->flags >> orient) & 1)) continue;
             if (need_tail[orient]) {  // ConvertBinaySeq wrote entries [0, noff_j) of this read (align.cpp:101-105)
                 const int idx = noff + lane;
                 const bool got = lane < 16 && ((need_tail[orient] >> lane) & 1) && idx < noff_j;
                 if (got) L.stale_key[orient][lane] = seed_key_at(P, LS.w[orient], idx);
                 need_tail[orient] &= ~(uint32_t)bsx_ballot(got);
             }
-            if (((need_so >> orient) & 1) && (MJ.len - I + 1) % S != 0) {  // this read ran the offset loop
+            if (((need_so >> orient) & 1) && (MJ.u->len - I + 1) % S != 0) {  // this read ran the offset loop
                 plan_counts<false>(P, LS, MJ, orient, lane, false);
                 const int so = plan_best_offset(P, BL, LS, MJ, orient, lane);
                 if (so >= 0) { if (lane == 0) L.stale_so[orient] = (uint8_t)so; need_so &= ~(1u << orient); }
@@ -1186,29 +1203,29 @@ template <bool PE, bool EXACT>
 __device__ void unit_prepare(const AlignArgs &A, const BlockLds &BL, MateLds &LA, MateLds &LB, Mate &MA, Mate &MB, uint32_t unit, int lane, Counters &C)
 {
     const DevParams &P = A.P;
-    MA.index = MB.index = A.first_index + unit;
+    MA.u->index = MB.u->index = A.first_index + unit;
     load_and_filter(A, LA, MA, 0, (long)unit, lane);
     if (PE) load_and_filter(A, LB, MB, 1, (long)unit, lane);
     else MB = MA;
-    if (!MA.filtered) {
+    if (!MA.u->filtered) {
         pack_read(P, LA, MA, PE ? 1 : 0, lane, C);
-        const bool lk = EXACT && A.leak_exact && !P.rrbs && (MA.len - P.index_interval + 1) % P.seed_size == 0;
+        const bool lk = EXACT && A.leak_exact && !P.rrbs && (MA.u->len - P.index_interval + 1) % P.seed_size == 0;
         if (lk) load_leak_rec(A, LA, unit, 0, lane);
-        for (int o = 0; o < 2; o++) if ((MA.flags >> o) & 1) plan_orient<EXACT>(P, BL, LA, MA, o, lane, C, lk);  // pairs.cpp:160 / align.cpp:444
+        for (int o = 0; o < 2; o++) if ((MA.u->flags >> o) & 1) plan_orient<EXACT>(P, BL, LA, MA, o, lane, C, lk);  // pairs.cpp:160 / align.cpp:444
     }
-    if (PE && !MB.filtered) {
+    if (PE && !MB.u->filtered) {
         pack_read(P, LB, MB, 2, lane, C);
-        const bool lk = EXACT && A.leak_exact && !P.rrbs && (MB.len - P.index_interval + 1) % P.seed_size == 0;
+        const bool lk = EXACT && A.leak_exact && !P.rrbs && (MB.u->len - P.index_interval + 1) % P.seed_size == 0;
         if (lk) load_leak_rec(A, LB, unit, 1, lane);
-        for (int o = 0; o < 2; o++) if ((MB.flags >> o) & 1) plan_orient<EXACT>(P, BL, LB, MB, o, lane, C, lk);
+        for (int o = 0; o < 2; o++) if ((MB.u->flags >> o) & 1) plan_orient<EXACT>(P, BL, LB, MB, o, lane, C, lk);
     }
 }
 
 // one level of PairAlign::RunAlign after both SnpAlign calls (pairs.cpp:167-171): sort class `level`, join
 __device__ int pair_level_post(const DevParams &P, const Mate &MA, const Mate &MB, const UnitSlabs &U, uint32_t &pcnt_reg, int i, int lane, u64 *lds_sort = nullptr)
 {
-    if (i <= MA.max_snp) { sort_list(U.SA.list(0, i), n_of(MA, 0, i), U.SA.tmp, lane, lds_sort); sort_list(U.SA.list(1, i), n_of(MA, 1, i), U.SA.tmp, lane, lds_sort); }
-    if (i <= MB.max_snp) { sort_list(U.SB.list(0, i), n_of(MB, 0, i), U.SB.tmp, lane, lds_sort); sort_list(U.SB.list(1, i), n_of(MB, 1, i), U.SB.tmp, lane, lds_sort); }
+    if (i <= MA.u->max_snp) { sort_list(U.SA.list(0, i), n_of(MA, 0, i), U.SA.tmp, lane, lds_sort); sort_list(U.SA.list(1, i), n_of(MA, 1, i), U.SA.tmp, lane, lds_sort); }
+    if (i <= MB.u->max_snp) { sort_list(U.SB.list(0, i), n_of(MB, 0, i), U.SB.tmp, lane, lds_sort); sort_list(U.SB.list(1, i), n_of(MB, 1, i), U.SB.tmp, lane, lds_sort); }
     int n = get_pairs(P, MA, MB, U.SA, U.SB, U.PS, pcnt_reg, i, i, lane);
     for (int j = 0; j < i; j++) n += get_pairs(P, MA, MB, U.SA, U.SB, U.PS, pcnt_reg, i, j, lane) + get_pairs(P, MA, MB, U.SA, U.SB, U.PS, pcnt_reg, j, i, lane);
     return n;
@@ -1240,7 +1257,7 @@ __device__ void unit_finish(const AlignArgs &A, const MateLds &LA, const MateLds
             out.pair_class = (int8_t)c; out.n_pairs = (uint16_t)n;
             int j = -1;
             if (n == 1) j = 0;
-            else if (P.report_repeat_hits == 1) j = (int)(bsx_myrand(MA.index, P.randseed) % n);
+            else if (P.report_repeat_hits == 1) j = (int)(bsx_myrand(MA.u->index, P.randseed) % n);
             if (j >= 0) {
                 const uint32_t *o = U.PS.row(c) + (size_t)j * 6;
                 out.chain = (uint8_t)(o[0] & 0xffff); out.na = (uint8_t)((o[0] >> 16) & 0xff); out.nb = (uint8_t)(o[0] >> 24);
@@ -1280,21 +1297,22 @@ __device__ __forceinline__ bool process_unit(const AlignArgs &A, const BlockLds 
     const Counters C0 = C;
     const UnitSlabs U = carve_slab(slab, (uint32_t)P.max_snp_num + 1, A.rowcap, PE, A.kcap, A.hbits);
     Mate MA, MB;
+    MA.u = lds_mate(&LA.u); MB.u = PE ? lds_mate(&LB.u) : lds_mate(&LA.u2);
     unit_prepare<PE, EXACT>(A, BL, LA, LB, MA, MB, unit, lane, C);
     uint32_t pcnt_reg = 0;  // lane c holds _cur_n_hits[c]
     int paired = 0;
     bool defer = false;
-    if (PE && !MA.filtered && !MB.filtered) {
-        const int maxi = max(MA.max_snp, MB.max_snp);  // PairAlign::RunAlign (pairs.cpp:163-172)
+    if (PE && !MA.u->filtered && !MB.u->filtered) {
+        const int maxi = max(MA.u->max_snp, MB.u->max_snp);  // PairAlign::RunAlign (pairs.cpp:163-172)
         for (int i = 0; i <= maxi && !paired && !defer; i++) {
-            if (i < MA.seedseg) snp_align<EXACT, PE>(P, BL, LA, MA, U.SA, i, lane, C, hthr);
-            if (!MA.defer && i < MB.seedseg) snp_align<EXACT, PE>(P, BL, LB, MB, U.SB, i, lane, C, hthr);
-            if (MA.defer || MB.defer) { defer = true; break; }
+            if (i < MA.u->seedseg) snp_align<EXACT, PE>(P, BL, LA, MA, U.SA, i, lane, C, hthr);
+            if (!MA.u->defer && i < MB.u->seedseg) snp_align<EXACT, PE>(P, BL, LB, MB, U.SB, i, lane, C, hthr);
+            if (MA.u->defer || MB.u->defer) { defer = true; break; }
             if (pair_level_post(P, MA, MB, U, pcnt_reg, i, lane) > 0) paired = i + 1;
         }
     } else {
-        if (!MA.filtered) { run_align_single<EXACT, PE>(P, BL, LA, MA, U.SA, lane, C, hthr); defer = MA.defer; }
-        if (PE && !defer && !MB.filtered) { run_align_single<EXACT, PE>(P, BL, LB, MB, U.SB, lane, C, hthr); defer = MB.defer; }
+        if (!MA.u->filtered) { run_align_single<EXACT, PE>(P, BL, LA, MA, U.SA, lane, C, hthr); defer = MA.u->defer; }
+        if (PE && !defer && !MB.u->filtered) { run_align_single<EXACT, PE>(P, BL, LB, MB, U.SB, lane, C, hthr); defer = MB.u->defer; }
     }
     if (defer) { forget_keys(MA, U.SA, lane); if (PE) forget_keys(MB, U.SB, lane); C = C0; return true; }
     unit_finish<PE>(A, LA, LB, MA, MB, U, pcnt_reg, paired, unit, lane, n_aligned, n_aligned_pairs);
@@ -1334,9 +1352,10 @@ __global__ __launch_bounds__(256) void k_leak(AlignArgs A)
     for (uint32_t unit = A.first_unit + blockIdx.x * 4 + wv; unit < A.n_units; unit += gridDim.x * 4) {
         for (int mate = 0; mate < (PE ? 2 : 1); mate++) {
             Mate M;
-            M.index = 0;
+            M.u = lds_mate(&LM[wv].u);
+            M.u->index = 0;
             load_and_filter(A, LM[wv], M, mate, (long)unit, lane);
-            if (M.filtered || (M.len - P.index_interval + 1) % P.seed_size != 0) continue;
+            if (M.u->filtered || (M.u->len - P.index_interval + 1) % P.seed_size != 0) continue;
             pack_read(P, LM[wv], M, PE ? mate + 1 : 0, lane, dummy);
             resolve_leak<PE>(A, BL, LSC[wv], LM[wv], M, mate, unit, lane);
             LeakRec *r = (LeakRec *)A.leak_rec + ((size_t)unit * 2 + mate);
@@ -1460,8 +1479,8 @@ __host__ HeavyArgs typed(const HeavyArgsRaw &r)
 __device__ void save_mate(HMate &d, const Mate &M, const MateLds &L, int lane)
 {
     if (lane == 0) {
-        d.len = M.len; d.raw_len = M.raw_len; d.max_snp = M.max_snp; d.seedseg = M.seedseg; d.filtered = M.filtered;
-        d.flags = M.flags; d.snp_thres = M.snp_thres; d.nkeys = M.nkeys; d.index = M.index; d.nfull = (uint32_t)M.nfull;
+        d.len = M.u->len; d.raw_len = M.u->raw_len; d.max_snp = M.u->max_snp; d.seedseg = M.u->seedseg; d.filtered = M.u->filtered;
+        d.flags = M.u->flags; d.snp_thres = M.u->snp_thres; d.nkeys = M.u->nkeys; d.index = M.u->index; d.nfull = (uint32_t)M.u->nfull;
     }
     d.cnt_reg[lane] = M.cnt_reg; d.key_reg[lane] = M.key_reg; d.bloom0[lane] = M.bloom0; d.bloom1[lane] = M.bloom1;
     if (lane < 20) { (&d.w[0][0])[lane] = (&L.w[0][0])[lane]; (&d.m[0][0])[lane] = (&L.m[0][0])[lane]; }
@@ -1470,10 +1489,10 @@ __device__ void save_mate(HMate &d, const Mate &M, const MateLds &L, int lane)
 
 __device__ void load_mate(const HMate &d, Mate &M, MateLds &L, int lane)
 {
-    M.len = (int)rfl((uint32_t)d.len); M.raw_len = (int)rfl((uint32_t)d.raw_len); M.max_snp = (int)rfl((uint32_t)d.max_snp);
-    M.seedseg = (int)rfl((uint32_t)d.seedseg); M.filtered = (int)rfl((uint32_t)d.filtered);
-    M.flags = rfl(d.flags); M.snp_thres = rfl(d.snp_thres); M.nkeys = rfl(d.nkeys); M.index = rfl(d.index); M.nfull = (int)rfl(d.nfull);
-    M.defer = 0;
+    M.u->len = (int)rfl((uint32_t)d.len); M.u->raw_len = (int)rfl((uint32_t)d.raw_len); M.u->max_snp = (int)rfl((uint32_t)d.max_snp);
+    M.u->seedseg = (int)rfl((uint32_t)d.seedseg); M.u->filtered = (int)rfl((uint32_t)d.filtered);
+    M.u->flags = rfl(d.flags); M.u->snp_thres = rfl(d.snp_thres); M.u->nkeys = rfl(d.nkeys); M.u->index = rfl(d.index); M.u->nfull = (int)rfl(d.nfull);
+    M.u->defer = 0;
     M.cnt_reg = d.cnt_reg[lane]; M.key_reg = d.key_reg[lane]; M.bloom0 = d.bloom0[lane]; M.bloom1 = d.bloom1[lane];
     if (lane < 20) { (&L.w[0][0])[lane] = (&d.w[0][0])[lane]; (&L.m[0][0])[lane] = (&d.m[0][0])[lane]; }
     if (lane < 32) { (&L.start[0][0])[lane] = (&d.start[0][0])[lane]; (&L.order[0][0])[lane] = (&d.order[0][0])[lane]; (&L.stale_key[0][0])[lane] = (&d.stale_key[0][0])[lane]; }
@@ -1508,7 +1527,7 @@ __device__ int snp_align_heavy(const AlignArgs &A, const HeavyArgs &H, HState *S
     const DevParams &P = A.P;
     for (; K.orient < 2; K.orient++, K.c = 0, K.W = HS_WIN0) {
         const int orient = K.orient;
-        if (!((M.flags >> orient) & 1)) continue;
+        if (!((M.u->flags >> orient) & 1)) continue;
         const int seg = L.order[orient][mode];
         const CandList cl = make_list<true>(P, BL, L, M, orient, seg, lane);
         if (cl.total < min(A.heavy_threshold, (uint32_t)HS_TASK_MIN)) {  // short list: the owning wave scans it itself
@@ -1562,7 +1581,7 @@ __device__ int snp_align_heavy(const AlignArgs &A, const HeavyArgs &H, HState *S
                                     }
                                     if ((uint32_t)lane < total) r = H.tout[t0 + tg + my_t].surv[my_i];
                                     u64 m = total >= 64 ? ~0ull : ((1ull << total) - 1);
-                                    m &= surv_coords(P, BL, r, M.len, lane, m);
+                                    m &= surv_coords(P, BL, r, M.u->len, lane, m);
                                     if (total > BSX_GROUP_MIN) e = accept_group(P, M, SL, orient, mode, m, r.w_ord & 0xff, r.hchr, r.hloc, r.hkey, lane, ls);
                                     else
                                         while (m) {
@@ -1620,7 +1639,7 @@ __device__ int snp_align_heavy(const AlignArgs &A, const HeavyArgs &H, HState *S
                             SurvRec r = {0, 0, 0, 0};
                             if (i < nv) r = o->surv[i];
                             u64 m = bsx_ballot(i < nv);
-                            m &= surv_coords(P, BL, r, M.len, lane, m);
+                            m &= surv_coords(P, BL, r, M.u->len, lane, m);
                             if (__builtin_popcountll(m) > BSX_GROUP_MIN) {
                                 int ls;
                                 const int e = accept_group(P, M, SL, orient, mode, m, r.w_ord & 0xff, r.hchr, r.hloc, r.hkey, lane, ls);
@@ -1670,9 +1689,9 @@ __device__ int snp_align_heavy(const AlignArgs &A, const HeavyArgs &H, HState *S
                     if (lane < 32) { R.sub_pre[lane] = cl.sub_pre; R.sub_n[lane] = cl.sub_n; R.sub_base[lane] = cl.sub_base; R.sub_h[lane] = cl.sub_h; }
                     if (lane < 9) { R.rw[lane] = L.w[orient][lane]; R.rm[lane] = L.m[orient][lane]; }
                     if (lane == 0) {
-                        R.nsub = (uint32_t)cl.nsub; R.total = cl.total; R.nwords = (uint32_t)((M.len + 15) >> 4); R.len = (uint32_t)M.len; R.thres = M.snp_thres;
+                        R.nsub = (uint32_t)cl.nsub; R.total = cl.total; R.nwords = (uint32_t)((M.u->len + 15) >> 4); R.len = (uint32_t)M.u->len; R.thres = M.u->snp_thres;
                         R.rrbs = P.rrbs ? 1u : 0u;  // tag filter of align.cpp:187,229: forward reads want their segment, rc reads cmodeindex with the direction bit flipped
-                        R.tag_xor = orient ? 0x1000000u : 0u; R.tag_want = orient ? (uint32_t)(M.nfull - 1 - seg) : (uint32_t)seg;
+                        R.tag_xor = orient ? 0x1000000u : 0u; R.tag_want = orient ? (uint32_t)(M.u->nfull - 1 - seg) : (uint32_t)seg;
                         S->t0 = t0; S->n_tasks = nt; S->win_c0 = K.c; S->win_n = wn;
                     }
                     K.have = 1;
@@ -1696,16 +1715,16 @@ __device__ bool heavy_advance(const AlignArgs &A, const HeavyArgs &H, HState *S,
                               Mate &MB, const UnitSlabs &U, uint32_t &pcnt_reg, HCursor &K, int lane, Counters &C, u64 *lds_sort)
 {
     const DevParams &P = A.P;
-    if (PE && !MA.filtered && !MB.filtered) {
-        const int maxi = max(MA.max_snp, MB.max_snp);  // PairAlign::RunAlign (pairs.cpp:163-172)
+    if (PE && !MA.u->filtered && !MB.u->filtered) {
+        const int maxi = max(MA.u->max_snp, MB.u->max_snp);  // PairAlign::RunAlign (pairs.cpp:163-172)
         for (;;) {
             if (K.level > maxi) return true;
             if (K.sub == 0) {
-                if (K.level < MA.seedseg && snp_align_heavy(A, H, S, hidx, BL, LA, MA, U.SA, K.level, K, lane, C) == 2) return false;
+                if (K.level < MA.u->seedseg && snp_align_heavy(A, H, S, hidx, BL, LA, MA, U.SA, K.level, K, lane, C) == 2) return false;
                 K.sub = 1; K.orient = 0; K.c = 0; K.W = HS_WIN0; K.have = 0;
             }
             if (K.sub == 1) {
-                if (K.level < MB.seedseg && snp_align_heavy(A, H, S, hidx, BL, LB, MB, U.SB, K.level, K, lane, C) == 2) return false;
+                if (K.level < MB.u->seedseg && snp_align_heavy(A, H, S, hidx, BL, LB, MB, U.SB, K.level, K, lane, C) == 2) return false;
                 K.sub = 2;
             }
             CAT_BEGIN(A);
@@ -1720,7 +1739,7 @@ __device__ bool heavy_advance(const AlignArgs &A, const HeavyArgs &H, HState *S,
         if (K.sub > (PE ? 1 : 0)) return true;
         const bool second = K.sub == 1;
         Mate &M = second ? MB : MA;
-        if (M.filtered || K.level >= M.seedseg) { K.sub++; K.level = 0; K.orient = 0; K.c = 0; K.W = HS_WIN0; K.have = 0; continue; }
+        if (M.u->filtered || K.level >= M.u->seedseg) { K.sub++; K.level = 0; K.orient = 0; K.c = 0; K.W = HS_WIN0; K.have = 0; continue; }
         if (snp_align_heavy(A, H, S, hidx, BL, second ? LB : LA, M, second ? U.SB : U.SA, K.level, K, lane, C) == 2) return false;
         const u64 nz = P.rrbs ? 0ull : bsx_ballot(M.cnt_reg != 0 && (lane & 15) <= K.level && lane < 32);  // RRBS runs all rounds (align.cpp:448)
         if (nz) { K.sub++; K.level = 0; }
@@ -1772,6 +1791,7 @@ __global__ __launch_bounds__(256, PE ? BSX_HCTRL_WAVES : BSX_HCTRL_WAVES_SE) voi
         const UnitSlabs U = A.debug ? carve_slab(slab, (uint32_t)A.P.max_snp_num + 1, A.rowcap, PE, A.kcap, A.hbits)
                                     : carve_slab(slab, (uint32_t)A.P.max_snp_num + 1, A.rowcap, PE, A.hkcap, A.hhbits);
         Mate MA, MB;
+        MA.u = lds_mate(&LA.u); MB.u = PE ? lds_mate(&LB.u) : lds_mate(&LA.u2);
         Counters C = {0, 0, 0, 0};
         HCursor K;
         K.n_active = n_active_in; K.want = 0;
@@ -1801,7 +1821,7 @@ __global__ __launch_bounds__(256, PE ? BSX_HCTRL_WAVES : BSX_HCTRL_WAVES_SE) voi
                 for (int k_ = 0; k_ < 6; k_++) A.dbg_cat[16 + k_] = (K.vc[k_] << 16) | min(K.vn[k_], 0xffffu);
         }
         const u64 cat_fin0 = A.dbg_cat ? __builtin_readcyclecounter() : 0;
-        if (done && ((MA.flags | (PE ? MB.flags : 0u)) & 4u)) {
+        if (done && ((MA.u->flags | (PE ? MB.u->flags : 0u)) & 4u)) {
             // the small duplicate set of this unit's heavy slab overflowed (single-end RRBS: coordinates its fragment filter rejects
             // are remembered too): its records are not written; the main kernel redoes it alone with its large set, undeferred
             forget_keys(MA, U.SA, lane); if (PE) forget_keys(MB, U.SB, lane);
