@@ -1521,7 +1521,7 @@ __device__ __forceinline__ u64 surv_coords(const DevParams &P, const BlockLds &B
 
 // resumable SnpAlign for a deferred unit: 0 = call complete, 1 = the reference's SnpAlign returned early, 2 = a window
 // of the current list was published and the unit must wait for k_hscan
-__device__ int snp_align_heavy(const AlignArgs &A, const HeavyArgs &H, HState *S, uint32_t hidx, const BlockLds &BL, const MateLds &L, Mate &M,
+__device__ __forceinline__ int snp_align_heavy(const AlignArgs &A, const HeavyArgs &H, HState *S, uint32_t hidx, const BlockLds &BL, const MateLds &L, Mate &M,
                                const Slab &SL, int mode, HCursor &K, int lane, Counters &C)
 {
     const DevParams &P = A.P;
@@ -1711,7 +1711,7 @@ __device__ int snp_align_heavy(const AlignArgs &A, const HeavyArgs &H, HState *S
 
 // advance a deferred unit as far as possible; true when it is finished
 template <bool PE>
-__device__ bool heavy_advance(const AlignArgs &A, const HeavyArgs &H, HState *S, uint32_t hidx, const BlockLds &BL, MateLds &LA, MateLds &LB, Mate &MA,
+__device__ __forceinline__ bool heavy_advance(const AlignArgs &A, const HeavyArgs &H, HState *S, uint32_t hidx, const BlockLds &BL, MateLds &LA, MateLds &LB, Mate &MA,
                               Mate &MB, const UnitSlabs &U, uint32_t &pcnt_reg, HCursor &K, int lane, Counters &C, u64 *lds_sort)
 {
     const DevParams &P = A.P;
