@@ -1755,12 +1755,26 @@ __device__ __forceinline__ bool heavy_advance(const AlignArgs &A, const HeavyArg
 #define BSX_HCTRL_WAVES 1  /* waves per SIMD the control kernel's register budget allows (1 = 512 registers) */
 #endif
 template <bool PE>
-__global__ __launch_bounds__(256, PE ? BSX_HCTRL_WAVES : BSX_HCTRL_WAVES_SE) void k_hctrl(AlignArgs A, HeavyArgs H)
+__global__ __launch_bounds__(256, PE ? BSX_HCTRL_WAVES : BSX_HCTRL_WAVES_SE) void k_hctrl(AlignArgs A_, HeavyArgs H_)
 {
     __shared__ BlockLds BL;
     __shared__ WaveLds<PE> WL[4];
     __shared__ u64 SORTBUF[4][BSX_LDS_SORT];
+    // The helpers called from here (scan, replay, prepare / finish, state save / restore) are real calls that take the arguments,
+    // the cursor, the counters and the slab pointers by reference: as private objects they would live in scratch memory — 256 bytes
+    // and four cache lines per scalar access, in a kernel that is one chain of dependent accesses.  All of them are wave-uniform:
+    // one copy per block (arguments) or per wave in LDS instead.
+    __shared__ AlignArgs As;
+    __shared__ HeavyArgs Hs;
+    __shared__ HCursor KS[4];
+    __shared__ Counters CS[4];
+    __shared__ UnitSlabs US[4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (uint32_t i = threadIdx.x; i < sizeof(AlignArgs) / 4; i += 256) ((uint32_t *)&As)[i] = ((const uint32_t *)&A_)[i];
+    for (uint32_t i = threadIdx.x; i < sizeof(HeavyArgs) / 4; i += 256) ((uint32_t *)&Hs)[i] = ((const uint32_t *)&H_)[i];
+    __syncthreads();
+    const AlignArgs &A = As;
+    const HeavyArgs &H = Hs;
     init_block_lds(A.P, BL, threadIdx.x, 256);
     __syncthreads();
     MateLds &LA = WL[wv].mate[0];
@@ -1788,12 +1802,14 @@ __global__ __launch_bounds__(256, PE ? BSX_HCTRL_WAVES : BSX_HCTRL_WAVES_SE) voi
         // (the slabs of deferred units carry the ordinary, small duplicate set even where the main kernel's are large — single-end
         //  RRBS —: there are too many deferred units for 4 MB each; a unit that overflows it is redone by the main kernel, below)
         uint8_t *slab = A.debug ? A.scratch + (size_t)unit * A.slab_bytes : H.slabs + (size_t)hidx * A.hslab_bytes;
-        const UnitSlabs U = A.debug ? carve_slab(slab, (uint32_t)A.P.max_snp_num + 1, A.rowcap, PE, A.kcap, A.hbits)
-                                    : carve_slab(slab, (uint32_t)A.P.max_snp_num + 1, A.rowcap, PE, A.hkcap, A.hhbits);
+        UnitSlabs &U = US[wv];
+        U = A.debug ? carve_slab(slab, (uint32_t)A.P.max_snp_num + 1, A.rowcap, PE, A.kcap, A.hbits)
+                    : carve_slab(slab, (uint32_t)A.P.max_snp_num + 1, A.rowcap, PE, A.hkcap, A.hhbits);
         Mate MA, MB;
         MA.u = lds_mate(&LA.u); MB.u = PE ? lds_mate(&LB.u) : lds_mate(&LA.u2);
-        Counters C = {0, 0, 0, 0};
-        HCursor K;
+        Counters &C = CS[wv];
+        C.n_lookup = 0; C.n_cand = 0; C.sum_w = 0; C.n_orient = 0;
+        HCursor &K = KS[wv];
         K.n_active = n_active_in; K.want = 0;
         for (int k_ = 0; k_ < 6; k_++) { K.vc[k_] = 0; K.vn[k_] = 0; }
         uint32_t pcnt_reg = 0;
