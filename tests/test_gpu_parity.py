@@ -598,3 +598,51 @@ def test_heavy_pipeline_small_pools(heavy_genome, oracle):
         test_heavy_pipeline_large_buckets(False, heavy_genome, oracle)
     finally:
         B.lib().bsx_set_heavy_limits(32768, 524288)
+
+
+def test_rrbs_shared_scan_runs_and_survivor_overflow(oracle, tmp_path):
+    """k_hscan_shared: hundreds of RRBS reads that walk the same window of one bucket (two tandem families whose every copy carries
+    the digestion site: 1500 and 300 near-identical copies), evaluated 16 per wave.  The 1500-copy family yields more survivors
+    per scan task than the record holds (512): those tasks come back flagged and the control kernel redoes them with its own
+    scan — counts, picks and the work counters must still equal the oracle's."""
+    rng = np.random.default_rng(77)
+
+    def family(n_copies, unit_len, div):
+        unit = td.random_seq(rng, unit_len, 0.5).copy()
+        out = []
+        for _ in range(n_copies):
+            cp = unit.copy()
+            mut = rng.random(unit_len) < div
+            cp[mut] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, int(mut.sum()))]
+            out.append(b"CCGG" + cp.tobytes())
+        return b"".join(out)
+    flank = lambda n: td.random_seq(rng, n, 0.5).tobytes()
+    chr1 = flank(30_000) + family(1500, 100, 0.004) + b"CCGG" + flank(20_000) + family(300, 120, 0.01) + b"CCGG" + flank(30_000)
+    g = [("chr1", chr1.decode()), ("chr2", td.make_genome(seed=3, chr_lens=(60_000,), cpg_sites=150)[0][1])]
+    fa = str(tmp_path / "g.fa")
+    td.write_fasta(fa, g)
+    kw = dict(D="C-CGG", v=2, S=7, r=1, w=1000, m=40, x=220)
+    oref = oracle.OracleRef(oracle.make_params(**kw), fasta_path=fa)
+    gref = B.RefSeq(B.make_params(**kw)).Run_ConvertBinseq(fasta_path=fa).CreateIndex()
+    reads = [r for r in td.make_rrbs_reads(g, 1200, 75, seed=5, sub_rate=0.004)]
+    sb, so = oracle.pack_reads([r["seq"] for r in reads])
+    ores, ocnt = oracle.se_batch(oref, sb, so, threads=8)
+    assert int(ores["n_hit"].sum(axis=1).max()) >= 1000  # the -w cap is reached: far more than 512 survivors in one task
+    B.lib().bsx_set_heavy_threshold(200)
+    try:
+        sa = B.SingleAlign(gref, len(reads))
+        sa.ImportBatchReads((sb, so)).Do_Batch()
+        hits, cc = sa.results()
+        assert sa.heavy_units() > 400
+        nclass = kw["v"] + 1
+        ok = ores["filtered"] == 0
+        assert np.array_equal(ores["n_hit"][ok][:, :nclass], cc["n_hit"][ok][:, :nclass]) and np.array_equal(ores["n_chit"][ok][:, :nclass], cc["n_chit"][ok][:, :nclass])
+        has = ok & (ores["n_best"] > 0)
+        for f in ("chr", "loc", "best_class"):
+            assert np.array_equal(ores[f][has], hits[f][has]), f
+        assert [int(x) for x in sa.counters()[:4]] == ocnt
+        sa.close()
+    finally:
+        B.lib().bsx_set_heavy_threshold(0)
+    gref.close()
+    oref.free()
