@@ -8,8 +8,10 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
 HG38 = [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636, 138394717, 133797422, 135086622, 133275309, 114364328, 107043718, 101991189, 90338345, 83257441, 80373285, 58617616, 64444167, 46709983, 50818468, 156040895, 57227415]
 lens = [max(200000, int(x * frac)) for x in HG38]
 kw = dict(s=16, v=6, I=4, m=28, x=500, S=1, r=1, pairend=1)
+TRIM = os.environ.get("MODE") == "trim"  # C5: -q 20 -A, reads with low-quality tails and adapter read-through
+if TRIM: kw.update(q=20, A=["AGATCGGAAGAGC"])
 ref = B.RefSeq(B.make_params(**kw)).synthetic(lens, seed=38).CreateIndex()
-pa = B.PairAlign(ref, n); pa.synth_reads(n, 144, seed=3)
+pa = B.PairAlign(ref, n); pa.synth_reads(n, 144, seed=3, kind=1 if TRIM else 0)
 pa.Do_Batch(); pa.Do_Batch(); print("kernel ms", pa.kernel_ms())
 pa.set_debug(2); pa.Do_Batch(); print("kernel ms (cycles on)", pa.kernel_ms())
 c = pa.unit_cycles().astype(np.float64)
