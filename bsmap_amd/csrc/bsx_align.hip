@@ -1787,7 +1787,9 @@ __global__ __launch_bounds__(256, PE ? BSX_HCTRL_WAVES : BSX_HCTRL_WAVES_SE) voi
         if (lane == 0) i = atomicAdd(H.queue, 1u);
         i = rfl(i);
         if (i >= n_active_in) break;
-        const uint32_t hidx = H.fresh ? H.hidx_base + i : rfl(H.active_in[i]);
+        // (later passes take the list back to front: a unit whose visit ended last in the previous pass — a long visit — was appended
+        //  last; starting those first keeps the pass from waiting for one long visit that began when all the others were done)
+        const uint32_t hidx = H.fresh ? H.hidx_base + i : rfl(H.active_in[n_active_in - 1u - i]);
         const uint32_t unit = rfl(A.heavy_list[H.list_base + hidx]);
         HState *S = &H.state[hidx];
         if (!H.fresh) {
