@@ -1288,14 +1288,20 @@ __device__ void unit_finish(const AlignArgs &A, const MateLds &LA, const MateLds
 // one unit in the main kernel; returns true if it was deferred to the heavy pipeline
 // (always inlined into the kernel: as a called function its callee-saved registers cost 21 KB of scratch writes per pair,
 //  a fifth of the kernel's memory requests — 59.6 ms against 48.6 ms per 2^20 pairs)
+// UnitLds: the wave-uniform per-unit state that is not in MateU — slab pointers and the work counters with their value at the
+// unit's start (restored when the unit is deferred); in LDS for the same reason (the main kernel is short of scalar registers)
+struct UnitLds { UnitSlabs U; Counters C, C0; };
 template <bool PE, bool EXACT>
-__device__ __forceinline__ bool process_unit(const AlignArgs &A, const BlockLds &BL, MateLds &LA, MateLds &LB, uint32_t unit, uint8_t *slab, int lane, Counters &C,
+__device__ __forceinline__ bool process_unit(const AlignArgs &A, const BlockLds &BL, MateLds &LA, MateLds &LB, uint32_t unit, uint8_t *slab, int lane, UnitLds &UL,
                              u64 &n_aligned, u64 &n_aligned_pairs)
 {
     const DevParams &P = A.P;
     const uint32_t hthr = A.heavy_threshold;
-    const Counters C0 = C;
-    const UnitSlabs U = carve_slab(slab, (uint32_t)P.max_snp_num + 1, A.rowcap, PE, A.kcap, A.hbits);
+    Counters &C = UL.C;
+    UL.C0 = C;
+    const Counters &C0 = UL.C0;
+    UnitSlabs &U = UL.U;
+    U = carve_slab(slab, (uint32_t)P.max_snp_num + 1, A.rowcap, PE, A.kcap, A.hbits);
     Mate MA, MB;
     MA.u = lds_mate(&LA.u); MB.u = PE ? lds_mate(&LB.u) : lds_mate(&LA.u2);
     unit_prepare<PE, EXACT>(A, BL, LA, LB, MA, MB, unit, lane, C);
@@ -1384,7 +1390,10 @@ __global__ __launch_bounds__(256, PE ? BSX_WAVES_PER_EU_PE : BSX_WAVES_PER_EU_SE
     const uint32_t slot = blockIdx.x * 4 + wv;
     MateLds &LA = WL[wv].mate[0];
     MateLds &LB = WL[wv].mate[PE ? 1 : 0];
-    Counters C = {0, 0, 0, 0};
+    __shared__ UnitLds ULS[4];
+    UnitLds &UL = ULS[wv];
+    Counters &C = UL.C;
+    C.n_lookup = 0; C.n_cand = 0; C.sum_w = 0; C.n_orient = 0;
     u64 n_units_done = 0, n_aligned = 0, n_aligned_pairs = 0;
     for (;;) {
         uint32_t unit = 0;
@@ -1394,7 +1403,7 @@ __global__ __launch_bounds__(256, PE ? BSX_WAVES_PER_EU_PE : BSX_WAVES_PER_EU_SE
         if (A.unit_list) unit = rfl(A.unit_list[unit]);  // redo run: the units named by the list
         const u64 t_begin = A.dbg_cycles ? __builtin_readcyclecounter() : 0;
         uint8_t *slab = A.scratch + (size_t)(A.debug ? unit : slot) * A.slab_bytes;
-        const bool deferred = process_unit<PE, EXACT>(A, BL, LA, LB, unit, slab, lane, C, n_aligned, n_aligned_pairs);
+        const bool deferred = process_unit<PE, EXACT>(A, BL, LA, LB, unit, slab, lane, UL, n_aligned, n_aligned_pairs);
         if (deferred) { if (lane == 0) A.heavy_list[atomicAdd(A.heavy_count, 1u)] = unit; }
         else n_units_done++;
         if (A.dbg_cycles && lane == 0) A.dbg_cycles[unit] = (uint32_t)min((u64)0xffffffffull, (u64)__builtin_readcyclecounter() - t_begin);
