@@ -1877,7 +1877,7 @@ __global__ __launch_bounds__(256, PE ? BSX_HCTRL_WAVES : BSX_HCTRL_WAVES_SE) voi
 #define BSX_HSCAN_WAVES 6  /* waves per SIMD the register budget is set for */
 #endif
 #ifndef BSX_HSCAN_WPB
-#define BSX_HSCAN_WPB 4  /* waves (= tasks) per block */
+#define BSX_HSCAN_WPB 2  /* waves (= tasks) per block: 2 measured best (1: 104.5, 2: 101.3, 4: 102.9, 8: 106.2, 16: 116.6 ms per step) */
 #endif
 
 // k_hscan evaluates a candidate in two stages.  Stage 1 (every candidate): the first 48 nt from one 16-byte reference
