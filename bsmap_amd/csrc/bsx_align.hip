@@ -1334,10 +1334,14 @@ __device__ void init_block_lds(const DevParams &P, BlockLds &BL, int tid, int nt
     }
 }
 
-__device__ void flush_counters(const AlignArgs &A, const Counters &C, u64 n_units_done, u64 n_aligned, u64 n_aligned_pairs)
+__device__ void flush_counters(const AlignArgs &A, const Counters &C, u64 n_units_done, u64 n_aligned, u64 n_aligned_pairs, bool main_kernel = false)
 {
     atomicAdd((u64 *)&A.counters[0], C.n_lookup); atomicAdd((u64 *)&A.counters[1], C.n_cand);
     atomicAdd((u64 *)&A.counters[2], C.sum_w); atomicAdd((u64 *)&A.counters[3], C.n_orient);
+    if (main_kernel) {  // the main kernel's own share (counters 11-14)
+        atomicAdd((u64 *)&A.counters[11], C.n_lookup); atomicAdd((u64 *)&A.counters[12], C.n_cand);
+        atomicAdd((u64 *)&A.counters[13], C.sum_w); atomicAdd((u64 *)&A.counters[14], C.n_orient);
+    }
     atomicAdd((u64 *)&A.counters[4], n_units_done); atomicAdd((u64 *)&A.counters[5], n_aligned);
     atomicAdd((u64 *)&A.counters[6], n_aligned_pairs);
 }
@@ -1409,7 +1413,7 @@ __global__ __launch_bounds__(256, PE ? BSX_WAVES_PER_EU_PE : BSX_WAVES_PER_EU_SE
         if (A.dbg_cycles && lane == 0) A.dbg_cycles[unit] = (uint32_t)min((u64)0xffffffffull, (u64)__builtin_readcyclecounter() - t_begin);
         wave_fence();
     }
-    if (lane == 0) flush_counters(A, C, n_units_done, n_aligned, n_aligned_pairs);
+    if (lane == 0) flush_counters(A, C, n_units_done, n_aligned, n_aligned_pairs, true);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1457,16 +1461,19 @@ struct HMate {
 };
 struct HState {
     uint32_t want;  // tasks of a request the pool refused (0: none): the unit is only restored once that many are free
-    int32_t level, sub, orient;
-    uint32_t c, W;
-    int32_t paired, have;
-    uint32_t t0, n_tasks, win_c0, win_n;  // the published window: tasks t0.. cover candidates [win_c0, win_c0+win_n)
+    int32_t level, sub;
+    int32_t paired;
+    // per list cursor (slot = mate): both mates of a pair publish their lists of a level in the same visit (their SnpAlign calls
+    // are independent, pairs.cpp:165-166), so each keeps its own orientation / position / window
+    int32_t orient[2], have[2];
+    uint32_t c[2], W[2];
+    uint32_t t0[2], n_tasks[2], win_c0[2], win_n[2];  // the published window: tasks t0.. cover candidates [win_c0, win_c0+win_n)
     Counters C;
     uint32_t pcnt_reg[64];
     HMate mate[2];
-    ListReq req;
+    ListReq req[2];
 };
-struct HTask { uint32_t h, c0, n, key; };  // key: index entry the task starts at (tasks are scanned in key order, see bsx_api.hip)
+struct HTask { uint32_t h, c0, n, key; };  // h: unit (bits 0-30) and list slot (bit 31); key: index entry the task starts at (tasks are scanned in key order, see bsx_api.hip)
 struct HTaskOut { uint32_t count, overflow, acc[4], pad[2]; SurvRec surv[HS_SCAP]; };
 struct HeavyArgs {
     HState *state; uint8_t *slabs; uint32_t *active_in, *active_out, *n_active_out; HTask *tasks; HTaskOut *tout; uint32_t *n_tasks, *queue;
@@ -1508,7 +1515,7 @@ __device__ void load_mate(const HMate &d, Mate &M, MateLds &L, int lane)
     wave_fence();
 }
 
-struct HCursor { int level, sub, orient, have, paired; uint32_t c, W, n_active, want; u64 vc[6]; uint32_t vn[6]; };  // vc/vn: per-visit category clocks and counts (diagnostics)
+struct HCursor { int level, sub, paired; int orient[2], have[2]; uint32_t c[2], W[2], n_active, want; u64 vc[6]; uint32_t vn[6]; };  // vc/vn: per-visit category clocks and counts (diagnostics)
 
 // diagnostic category clocks of k_hctrl (only when the caller asked for unit cycles): 0 prepare/restore, 1 inline scans,
 // 2 survivor replay, 3 sort+pairs, 4 save/finish, 5 recount after events
@@ -1531,11 +1538,11 @@ __device__ __forceinline__ u64 surv_coords(const DevParams &P, const BlockLds &B
 // resumable SnpAlign for a deferred unit: 0 = call complete, 1 = the reference's SnpAlign returned early, 2 = a window
 // of the current list was published and the unit must wait for k_hscan
 __device__ __forceinline__ int snp_align_heavy(const AlignArgs &A, const HeavyArgs &H, HState *S, uint32_t hidx, const BlockLds &BL, const MateLds &L, Mate &M,
-                               const Slab &SL, int mode, HCursor &K, int lane, Counters &C)
+                               const Slab &SL, int mode, HCursor &K, int ms, int lane, Counters &C)
 {
     const DevParams &P = A.P;
-    for (; K.orient < 2; K.orient++, K.c = 0, K.W = HS_WIN0) {
-        const int orient = K.orient;
+    for (; K.orient[ms] < 2; K.orient[ms]++, K.c[ms] = 0, K.W[ms] = HS_WIN0) {
+        const int orient = K.orient[ms];
         if (!((M.u->flags >> orient) & 1)) continue;
         const int seg = L.order[orient][mode];
         const CandList cl = make_list<true>(P, BL, L, M, orient, seg, lane);
@@ -1546,12 +1553,12 @@ __device__ __forceinline__ int snp_align_heavy(const AlignArgs &A, const HeavyAr
             if (r_ == 2) { wave_fence(); return 1; }
             continue;
         }
-        while (K.c < cl.total) {
-            if (K.have) {
-                K.have = 0;
+        while (K.c[ms] < cl.total) {
+            if (K.have[ms]) {
+                K.have[ms] = 0;
                 // (task descriptors in the pool may already have been reused by other units of this pass: the window is
                 //  reconstructed from the unit's own state, only the task OUTPUTS are read from the pool)
-                const uint32_t t0 = rfl(S->t0), nt = rfl(S->n_tasks), req_thres = rfl(S->req.thres), win_c0 = rfl(S->win_c0), win_n = rfl(S->win_n);
+                const uint32_t t0 = rfl(S->t0[ms]), nt = rfl(S->n_tasks[ms]), req_thres = rfl(S->req[ms].thres), win_c0 = rfl(S->win_c0[ms]), win_n = rfl(S->win_n[ms]);
                 bool restart = false;
                 for (uint32_t tg = 0; tg < nt && !restart; tg += 64) {
                     // 64 task headers at a time: tasks without survivors only contribute their work counters
@@ -1608,13 +1615,13 @@ __device__ __forceinline__ int snp_align_heavy(const AlignArgs &A, const HeavyAr
                                 if (!e) {
                                     done_upto = bend;
                                     special &= bend >= 64 ? 0ull : ~((1ull << bend) - 1);
-                                    if (bend >= gn) { K.c = win_c0 + min(win_n, (tg + gn) * HS_TASK); break; }
+                                    if (bend >= gn) { K.c[ms] = win_c0 + min(win_n, (tg + gn) * HS_TASK); break; }
                                     continue;
                                 }
                                 // count exactly the candidates of the event's task up to and including the one that caused it
                                 const uint32_t tc0e = win_c0 + (tg + upto) * HS_TASK, Xe = tc0e + (rl(r.w_ord, ls) >> 8);
                                 { CAT_BEGIN(A); wave_scan_range<true, 4>(P, BL, L, M, SL, cl, orient, seg, mode, tc0e, Xe + 1, req_thres, lane, C); CAT_END(A, 5); }
-                                K.c = Xe + 1;
+                                K.c[ms] = Xe + 1;
                                 if (e == 2) { wave_fence(); return 1; }
                                 restart = true;
                                 continue;
@@ -1625,7 +1632,7 @@ __device__ __forceinline__ int snp_align_heavy(const AlignArgs &A, const HeavyAr
                         const bool mine = (uint32_t)lane >= done_upto && (uint32_t)lane < nxt;
                         C.n_cand += wave_sum(mine ? h0 : 0);
                         C.sum_w += wave_sum(mine ? hw : 0);
-                        if (nxt >= gn) { K.c = win_c0 + min(win_n, (tg + gn) * HS_TASK); break; }
+                        if (nxt >= gn) { K.c[ms] = win_c0 + min(win_n, (tg + gn) * HS_TASK); break; }
                         special &= special - 1;
                         done_upto = nxt + 1;
                         const uint32_t t = tg + nxt;
@@ -1636,7 +1643,7 @@ __device__ __forceinline__ int snp_align_heavy(const AlignArgs &A, const HeavyAr
                             const int r = wave_scan_range<false, 4>(P, BL, L, M, SL, cl, orient, seg, mode, tc0, tc0 + tn, 0, lane, C);
                             CAT_END(A, 1);
                             if (r == 2) { wave_fence(); return 1; }
-                            K.c = tc0 + tn;
+                            K.c[ms] = tc0 + tn;
                             if (r == 1) restart = true;  // later tasks were evaluated under the old threshold
                             continue;
                         }
@@ -1667,43 +1674,43 @@ __device__ __forceinline__ int snp_align_heavy(const AlignArgs &A, const HeavyAr
                         if (!event) {
                             C.n_cand += rl(h0, (int)nxt);
                             C.sum_w += rl(hw, (int)nxt);
-                            K.c = tc0 + tn;
+                            K.c[ms] = tc0 + tn;
                         } else {  // count exactly the candidates up to and including the one that caused the event
                             { CAT_BEGIN(A); wave_scan_range<true, 4>(P, BL, L, M, SL, cl, orient, seg, mode, tc0, X + 1, req_thres, lane, C); CAT_END(A, 5); }
-                            K.c = X + 1;
+                            K.c[ms] = X + 1;
                             if (event == 2) { wave_fence(); return 1; }
                             restart = true;
                         }
                     }
                 }
-                if (!restart) K.W = min(K.W * HS_GROW, (uint32_t)HS_WINMAX);
+                if (!restart) K.W[ms] = min(K.W[ms] * HS_GROW, (uint32_t)HS_WINMAX);
             } else {
-                const uint32_t weff = K.n_active < 2048u ? (uint32_t)HS_WINMAX : K.W;  // few units left: scanning capacity is idle, speculate the whole list
+                const uint32_t weff = K.n_active < 2048u ? (uint32_t)HS_WINMAX : K.W[ms];  // few units left: scanning capacity is idle, speculate the whole list
                 const uint32_t wpool = (u64)H.task_cap * HS_TASK < (u64)weff ? H.task_cap * HS_TASK : weff;  // a window must fit the task pool
-                const uint32_t wn = min(wpool, cl.total - K.c), nt = (wn + HS_TASK - 1) / HS_TASK;
+                const uint32_t wn = min(wpool, cl.total - K.c[ms]), nt = (wn + HS_TASK - 1) / HS_TASK;
                 uint32_t t0 = 0;
                 if (lane == 0) t0 = atomicAdd(H.n_tasks, nt);
                 t0 = rfl(t0);
                 if (t0 + nt <= H.task_cap) {
                     for (uint32_t tb = 0; tb < nt; tb += 64) {
                         const uint32_t t = tb + lane;
-                        HTask tk; tk.h = hidx; tk.c0 = K.c + t * HS_TASK; tk.n = min((uint32_t)HS_TASK, wn - t * HS_TASK); tk.key = 0;
+                        HTask tk; tk.h = hidx | ((uint32_t)ms << 31); tk.c0 = K.c[ms] + t * HS_TASK; tk.n = min((uint32_t)HS_TASK, wn - t * HS_TASK); tk.key = 0;
                         for (int s_ = 0; s_ < cl.nsub; s_++) {  // the index entry the task starts at
                             const uint32_t ps_ = rl(cl.sub_pre, s_), ns_ = rl(cl.sub_n, s_), sb_ = rl(cl.sub_base, s_);
                             if (tk.c0 >= ps_ && tk.c0 < ps_ + ns_) tk.key = sb_ + (tk.c0 - ps_);
                         }
                         if (t < nt) H.tasks[t0 + t] = tk;
                     }
-                    ListReq &R = S->req;
+                    ListReq &R = S->req[ms];
                     if (lane < 32) { R.sub_pre[lane] = cl.sub_pre; R.sub_n[lane] = cl.sub_n; R.sub_base[lane] = cl.sub_base; R.sub_h[lane] = cl.sub_h; }
                     if (lane < 9) { R.rw[lane] = L.w[orient][lane]; R.rm[lane] = L.m[orient][lane]; }
                     if (lane == 0) {
                         R.nsub = (uint32_t)cl.nsub; R.total = cl.total; R.nwords = (uint32_t)((M.u->len + 15) >> 4); R.len = (uint32_t)M.u->len; R.thres = M.u->snp_thres;
                         R.rrbs = P.rrbs ? 1u : 0u;  // tag filter of align.cpp:187,229: forward reads want their segment, rc reads cmodeindex with the direction bit flipped
                         R.tag_xor = orient ? 0x1000000u : 0u; R.tag_want = orient ? (uint32_t)(M.u->nfull - 1 - seg) : (uint32_t)seg;
-                        S->t0 = t0; S->n_tasks = nt; S->win_c0 = K.c; S->win_n = wn;
+                        S->t0[ms] = t0; S->n_tasks[ms] = nt; S->win_c0[ms] = K.c[ms]; S->win_n[ms] = wn;
                     }
-                    K.have = 1;
+                    K.have[ms] = 1;
                 } else {
                     K.want = nt;  // the request is repeated in a later iteration, once the pool can take it
                     if (t0 < H.task_cap)  // pool exhausted mid-way: neutralise the slots that were reserved
@@ -1728,32 +1735,40 @@ __device__ __forceinline__ bool heavy_advance(const AlignArgs &A, const HeavyArg
         const int maxi = max(MA.u->max_snp, MB.u->max_snp);  // PairAlign::RunAlign (pairs.cpp:163-172)
         for (;;) {
             if (K.level > maxi) return true;
-            if (K.sub == 0) {
-                if (K.level < MA.u->seedseg && snp_align_heavy(A, H, S, hidx, BL, LA, MA, U.SA, K.level, K, lane, C) == 2) return false;
-                K.sub = 1; K.orient = 0; K.c = 0; K.W = HS_WIN0; K.have = 0;
+            // the two SnpAlign calls of a level (pairs.cpp:165-166) touch disjoint state: both mates go as far as they can in the same
+            // visit and publish their windows together — half the visits and passes of taking them in turn.  Bit m of K.sub: mate m's
+            // call of this level is complete.
+            bool waiting = false;
+            for (int m = 0; m < 2; m++) {
+                if ((K.sub >> m) & 1) continue;
+                Mate &M = m ? MB : MA;
+                if (K.level < M.u->seedseg && snp_align_heavy(A, H, S, hidx, BL, m ? LB : LA, M, m ? U.SB : U.SA, K.level, K, m, lane, C) == 2) { waiting = true; continue; }
+                K.sub |= 1 << m;
             }
-            if (K.sub == 1) {
-                if (K.level < MB.u->seedseg && snp_align_heavy(A, H, S, hidx, BL, LB, MB, U.SB, K.level, K, lane, C) == 2) return false;
-                K.sub = 2;
+            if (waiting) {
+                if (K.have[0] | K.have[1]) K.want = 0;  // a published window must be replayed in the next pass (its records live one pass): never parked
+                return false;
             }
             CAT_BEGIN(A);
             const int np_ = pair_level_post(P, MA, MB, U, pcnt_reg, K.level, lane, lds_sort);
             CAT_END(A, 3);
             if (np_ > 0) { K.paired = K.level + 1; return true; }
-            K.level++; K.sub = 0; K.orient = 0; K.c = 0; K.W = HS_WIN0; K.have = 0;
+            K.level++; K.sub = 0;
+            for (int m = 0; m < 2; m++) { K.orient[m] = 0; K.c[m] = 0; K.W[m] = HS_WIN0; K.have[m] = 0; }
         }
     }
-    // SingleAlign::RunAlign (align.cpp:445-449) for each surviving mate in turn; K.sub selects the mate
+    // SingleAlign::RunAlign (align.cpp:445-449) for each surviving mate in turn; K.sub selects the mate (and its cursor slot)
     for (;;) {
         if (K.sub > (PE ? 1 : 0)) return true;
         const bool second = K.sub == 1;
+        const int ms = second ? 1 : 0;
         Mate &M = second ? MB : MA;
-        if (M.u->filtered || K.level >= M.u->seedseg) { K.sub++; K.level = 0; K.orient = 0; K.c = 0; K.W = HS_WIN0; K.have = 0; continue; }
-        if (snp_align_heavy(A, H, S, hidx, BL, second ? LB : LA, M, second ? U.SB : U.SA, K.level, K, lane, C) == 2) return false;
+        if (M.u->filtered || K.level >= M.u->seedseg) { K.sub++; K.level = 0; continue; }
+        if (snp_align_heavy(A, H, S, hidx, BL, second ? LB : LA, M, second ? U.SB : U.SA, K.level, K, ms, lane, C) == 2) return false;
         const u64 nz = P.rrbs ? 0ull : bsx_ballot(M.cnt_reg != 0 && (lane & 15) <= K.level && lane < 32);  // RRBS runs all rounds (align.cpp:448)
         if (nz) { K.sub++; K.level = 0; }
         else K.level++;
-        K.orient = 0; K.c = 0; K.W = HS_WIN0; K.have = 0;
+        K.orient[ms] = 0; K.c[ms] = 0; K.W[ms] = HS_WIN0; K.have[ms] = 0;
     }
 }
 
@@ -1827,7 +1842,8 @@ __global__ __launch_bounds__(256, PE ? BSX_HCTRL_WAVES : BSX_HCTRL_WAVES_SE) voi
         const u64 cat_prep0 = A.dbg_cat ? __builtin_readcyclecounter() : 0;
         if (H.fresh) {
             unit_prepare<PE, true>(A, BL, LA, LB, MA, MB, unit, lane, C);
-            K.level = 0; K.sub = 0; K.orient = 0; K.have = 0; K.paired = 0; K.c = 0; K.W = HS_WIN0;
+            K.level = 0; K.sub = 0; K.paired = 0;
+            for (int m_ = 0; m_ < 2; m_++) { K.orient[m_] = 0; K.have[m_] = 0; K.c[m_] = 0; K.W[m_] = HS_WIN0; }
         } else {
             load_mate(S->mate[0], MA, LA, lane);
             if (PE) load_mate(S->mate[1], MB, LB, lane); else MB = MA;
@@ -1835,8 +1851,8 @@ __global__ __launch_bounds__(256, PE ? BSX_HCTRL_WAVES : BSX_HCTRL_WAVES_SE) voi
             C.n_lookup = (u64)rfl((uint32_t)(C.n_lookup >> 32)) << 32 | rfl((uint32_t)C.n_lookup); C.n_cand = (u64)rfl((uint32_t)(C.n_cand >> 32)) << 32 | rfl((uint32_t)C.n_cand);
             C.sum_w = (u64)rfl((uint32_t)(C.sum_w >> 32)) << 32 | rfl((uint32_t)C.sum_w); C.n_orient = (u64)rfl((uint32_t)(C.n_orient >> 32)) << 32 | rfl((uint32_t)C.n_orient);
             pcnt_reg = S->pcnt_reg[lane];
-            K.level = (int)rfl((uint32_t)S->level); K.sub = (int)rfl((uint32_t)S->sub); K.orient = (int)rfl((uint32_t)S->orient);
-            K.have = (int)rfl((uint32_t)S->have); K.paired = (int)rfl((uint32_t)S->paired); K.c = rfl(S->c); K.W = rfl(S->W);
+            K.level = (int)rfl((uint32_t)S->level); K.sub = (int)rfl((uint32_t)S->sub); K.paired = (int)rfl((uint32_t)S->paired);
+            for (int m_ = 0; m_ < 2; m_++) { K.orient[m_] = (int)rfl((uint32_t)S->orient[m_]); K.have[m_] = (int)rfl((uint32_t)S->have[m_]); K.c[m_] = rfl(S->c[m_]); K.W[m_] = rfl(S->W[m_]); }
         }
         if (A.dbg_cat && lane == 0) { const u64 d_ = (u64)__builtin_readcyclecounter() - cat_prep0; atomicAdd((u64 *)&A.dbg_cat[0], d_); atomicMax((u64 *)&A.dbg_cat[8], d_); }
         const u64 cat_adv0 = A.dbg_cat ? __builtin_readcyclecounter() : 0;
@@ -1862,7 +1878,8 @@ __global__ __launch_bounds__(256, PE ? BSX_HCTRL_WAVES : BSX_HCTRL_WAVES_SE) voi
             if (PE) save_mate(S->mate[1], MB, LB, lane);
             S->pcnt_reg[lane] = pcnt_reg;
             if (lane == 0) {
-                S->want = K.want; S->C = C; S->level = K.level; S->sub = K.sub; S->orient = K.orient; S->have = K.have; S->paired = K.paired; S->c = K.c; S->W = K.W;
+                S->want = K.want; S->C = C; S->level = K.level; S->sub = K.sub; S->paired = K.paired;
+                for (int m_ = 0; m_ < 2; m_++) { S->orient[m_] = K.orient[m_]; S->have[m_] = K.have[m_]; S->c[m_] = K.c[m_]; S->W[m_] = K.W[m_]; }
                 H.active_out[atomicAdd(H.n_active_out, 1u)] = hidx;
             }
         }
@@ -1893,6 +1910,9 @@ __global__ __launch_bounds__(256, PE ? BSX_HCTRL_WAVES : BSX_HCTRL_WAVES_SE) voi
 // The work accounting of the reference's two early-outs (align.h:189-197; 1, 2 or 5 64-bit words per candidate) needs no
 // ballots: with w0ref <= p48 <= w01ref, a task of n candidates touches  2 n - #(w0ref > thres) + 3 #(w01ref <= thres)
 // words; both counts are accumulated per lane and reduced once per task.
+#ifndef BSX_HSCAN_TMV
+#define BSX_HSCAN_TMV 9  /* T-masks kept in vector registers (first three: stage 1) */
+#endif
 #define HS_QCAP 256u  /* FIFO slots per wave (16 bytes each): at most 63 left over + 2 chunks of 64 pushed between drains */
 struct ScanAcc { uint32_t c1, f5, nv; };  // per lane: candidates with w0ref > thres / evaluated in full with w01ref <= thres / (RRBS) candidates at all
 struct ScanCtx {
@@ -1904,9 +1924,9 @@ struct ScanCtx {
     bool overflow;
     HTaskOut *o;
     ScanAcc acc;
-#ifdef BSX_SPAN_STATS
-    uint32_t span[4];
-#endif
+    // T-masks of the read words (bsx_tmask) held in VECTOR registers: a VOP3 instruction reads one scalar operand only, so with both
+    // the read word and its mask in SGPRs every v_bitop3 of the mismatch rule came with a v_mov (3 of the first stage's 33 per chunk)
+    uint32_t tv[9];
 };
 
 // stage 2 for the first n (<= 64) queued candidates
@@ -1920,15 +1940,6 @@ __device__ __forceinline__ void hscan_drain(ScanCtx &X, uint32_t n, const uint32
     r1.a = r1.b = r1.c = r1.d = 0; r2.a = r2.b = 0;
     if (act && X.nwords > 3) r1 = *reinterpret_cast<const U4 *>(rp + 4);
     if (act && X.nwords > 7) r2 = *reinterpret_cast<const U2 *>(rp + 8);
-#if defined(BSX_DUP) && BSX_DUP == 2  /* timing diagnostic (results unchanged): the second stage's loads twice */
-    {
-        const uint32_t *rq = rp; asm volatile("" : "+v"(rq));
-        U4 d1; U2 d2; d1.a = d1.b = d1.c = d1.d = 0; d2.a = d2.b = 0;
-        if (act && X.nwords > 3) d1 = *reinterpret_cast<const U4 *>(rq + 4);
-        if (act && X.nwords > 7) d2 = *reinterpret_cast<const U2 *>(rq + 8);
-        r1.a |= (d1.a ^ r1.a) | (d1.d ^ r1.d); r2.b |= d2.b ^ r2.b;
-    }
-#endif
     const uint32_t sh = mad30(it.w, 30);
     const uint32_t him = (uint32_t)((int32_t)0x80000000 >> (mad30(it.w, 29) & 31u));
     const uint32_t p48 = it.y & 0xffu;
@@ -1937,32 +1948,17 @@ __device__ __forceinline__ void hscan_drain(ScanCtx &X, uint32_t n, const uint32
 #pragma unroll
     for (int t = 3; t < 9; t++) {
         const uint32_t f = __builtin_amdgcn_alignbit(wd[t - 3], wd[t - 2], sh);
-        const uint32_t mm = bsx_mismatch_hi(rw[t], bsx_tmask(rw[t], rm[t]), f);
+        const uint32_t mm = bsx_mismatch_hi(rw[t], X.tv[t], f);
         tot += __popc(mm);
         if (t == 3) w01ref += __popc(mm & him);
     }
-#if defined(BSX_DUP) && BSX_DUP == 1  /* timing diagnostic: the second stage's arithmetic twice */
-    {
-        uint32_t v_[7];
-        for (int t = 0; t < 7; t++) { v_[t] = wd[t]; asm volatile("" : "+v"(v_[t])); }
-        uint32_t tot2 = p48;
-#pragma unroll
-        for (int t = 3; t < 9; t++) {
-            const uint32_t f = __builtin_amdgcn_alignbit(v_[t - 3], v_[t - 2], sh);
-            const uint32_t mm = bsx_mismatch_hi(rw[t], bsx_tmask(rw[t], rm[t]), f);
-            tot2 += __popc(mm);
-            if (t == 3) tot2 += __popc(mm & him) & 0u;
-        }
-        tot |= tot2 ^ tot;
-    }
-#endif
     X.acc.f5 += (act && w01ref <= X.thres0) ? 1u : 0u;
     // (chromosome / end-of-sequence test and hit coordinates are left to the control kernel's replay: the record carries
     //  the strand copy and the global position)
     const bool pass = act && tot <= X.thres0;
     const u64 m = bsx_ballot(pass);
     if (m) {
-        const uint32_t pos = X.nsurv + (uint32_t)__builtin_popcountll(m & lanemask_lt(X.lane));
+        const uint32_t pos = X.nsurv + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
         if (pass && pos < HS_SCAP) { SurvRec r; r.w_ord = tot | ((it.y & 0x7fffff00u)); r.hchr = it.y >> 31; r.hloc = it.w + 1; r.hkey = 0; X.o->surv[pos] = r; }
         X.nsurv += (uint32_t)__builtin_popcountll(m);
         if (X.nsurv > HS_SCAP) X.overflow = true;
@@ -1980,25 +1976,16 @@ __device__ __forceinline__ void hscan_eval(ScanCtx &X, const U4 r0, uint32_t pm1
     const uint32_t sh = mad30(pm1, 30);
     const uint32_t him = (uint32_t)((int32_t)0x80000000 >> (mad30(pm1, 29) & 31u));
     const uint32_t f0 = __builtin_amdgcn_alignbit(r0.a, r0.b, sh), f1 = __builtin_amdgcn_alignbit(r0.b, r0.c, sh), f2 = __builtin_amdgcn_alignbit(r0.c, r0.d, sh);
-    const uint32_t m1 = bsx_mismatch_hi(rw[1], bsx_tmask(rw[1], rm[1]), f1);
-    const uint32_t c0 = __popc(bsx_mismatch_hi(rw[0], bsx_tmask(rw[0], rm[0]), f0));
+    const uint32_t m1 = bsx_mismatch_hi(rw[1], X.tv[1], f1);
+    const uint32_t c0 = __popc(bsx_mismatch_hi(rw[0], X.tv[0], f0));
     const uint32_t w0ref = __popc(m1 & him) + c0;
-    uint32_t p48 = __popc(bsx_mismatch_hi(rw[2], bsx_tmask(rw[2], rm[2]), f2)) + (__popc(m1) + c0);
-#if defined(BSX_DUP) && BSX_DUP == 4  /* timing diagnostic: the first stage's arithmetic twice */
-    {
-        uint32_t a_ = r0.a, b_ = r0.b, c_ = r0.c, d_ = r0.d; asm volatile("" : "+v"(a_), "+v"(b_), "+v"(c_), "+v"(d_));
-        const uint32_t g0 = __builtin_amdgcn_alignbit(a_, b_, sh), g1 = __builtin_amdgcn_alignbit(b_, c_, sh), g2 = __builtin_amdgcn_alignbit(c_, d_, sh);
-        const uint32_t n1_ = bsx_mismatch_hi(rw[1], bsx_tmask(rw[1], rm[1]), g1);
-        const uint32_t q48 = __popc(bsx_mismatch_hi(rw[2], bsx_tmask(rw[2], rm[2]), g2)) + (__popc(n1_) + __popc(bsx_mismatch_hi(rw[0], bsx_tmask(rw[0], rm[0]), g0))) + __popc(n1_ & him);
-        p48 |= (q48 - w0ref) ^ p48;
-    }
-#endif
+    uint32_t p48 = __popc(bsx_mismatch_hi(rw[2], X.tv[2], f2)) + (__popc(m1) + c0);
     const bool need = (!MASKED || valid) && p48 <= X.thres0;
     X.acc.c1 += ((!MASKED || valid) && w0ref > X.thres0) ? 1u : 0u;
     const u64 nm = bsx_ballot(need);
     if (nm) {
         if (need) {
-            const uint32_t pos = X.qh + X.qn + (uint32_t)__builtin_popcountll(nm & lanemask_lt(lane));
+            const uint32_t pos = X.qh + X.qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(nm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nm, 0u));
             X.Q[pos & (HS_QCAP - 1)] = make_uint4(boff, p48 | tag, r0.d, pm1);
         }
         X.qn += (uint32_t)__builtin_popcountll(nm);
@@ -2037,16 +2024,18 @@ __device__ __forceinline__ void hscan_step_rrbs(ScanCtx &X, const U2 *__restrict
 
 // stage 1 for 256 consecutive candidates of one sub-range (four chunks of 64; lane l of chunk u holds candidate
 // cb + 64u + l).  FULL: all 256 exist (every step of a sub-range but its last).
+// e[]: the step's index entries, already in registers — loaded one step ahead, so that a step is ONE exposed memory round trip
+// (its reference gathers) instead of two dependent ones (entries, then gathers); a FULL step requests the entries of the step
+// behind it from `nextq` (one address + immediate offsets; may run up to 255 entries past the sub-range: loaded, never used —
+// BSX_ENTRY_PAD zeroed words lie behind the last entry).
 template <bool FULL>
-__device__ __forceinline__ void hscan_step(ScanCtx &X, const uint32_t *__restrict__ q, uint32_t ref_off, uint32_t hm1, uint32_t n_here, uint32_t ord0,
+__device__ __forceinline__ void hscan_step(ScanCtx &X, uint32_t (&e)[4], const uint32_t *__restrict__ nextq, uint32_t ref_off, uint32_t hm1, uint32_t n_here, uint32_t ord0,
                                            uint32_t strand, const uint32_t (&rw)[9], const uint32_t (&rm)[9])
 {
     const int lane = X.lane;
-    uint32_t e[4], pm1[4], boff[4];
+    uint32_t pm1[4], boff[4];
     bool valid[4];
     U4 r0[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) e[u] = q[u * 64];  // one address + immediate offsets (may run up to 255 entries past the sub-range: loaded, never used)
 #pragma unroll
     for (int u = 0; u < 4; u++) {
         valid[u] = FULL || (uint32_t)(u * 64 + lane) < n_here;
@@ -2055,24 +2044,11 @@ __device__ __forceinline__ void hscan_step(ScanCtx &X, const uint32_t *__restric
     }
 #pragma unroll
     for (int u = 0; u < 4; u++) r0[u] = *reinterpret_cast<const U4 *>(reinterpret_cast<const uint8_t *>(X.refall) + boff[u]);
-#if defined(BSX_DUP) && BSX_DUP == 3  /* timing diagnostic: the first stage's gathers twice */
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-        uint32_t bo = boff[u]; asm volatile("" : "+v"(bo));
-        const U4 d = *reinterpret_cast<const U4 *>(reinterpret_cast<const uint8_t *>(X.refall) + bo);
-        r0[u].a |= d.a ^ r0[u].a; r0[u].d |= d.d ^ r0[u].d;
-    }
-#endif
-    const uint32_t tag = (ord0 + (uint32_t)lane) << 8 | strand << 31;
-#ifdef BSX_SPAN_STATS  /* diagnostic build: how tightly clustered are the 64 candidates of a chunk? */
     if (FULL) {
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const uint32_t span = rl(e[u], 63) - rl(e[u], 0);
-            X.span[0]++; X.span[1] += span <= 848; X.span[2] += span <= 1872; X.span[3] += span <= 3920;
-        }
+        for (int u = 0; u < 4; u++) e[u] = nextq[u * 64];
     }
-#endif
+    const uint32_t tag = (ord0 + (uint32_t)lane) << 8 | strand << 31;
 #pragma unroll
     for (int u = 0; u < 4; u++) hscan_eval<!FULL>(X, r0[u], pm1[u], boff[u], valid[u], tag + ((uint32_t)u << 14), u, rw, rm);
 }
@@ -2082,10 +2058,6 @@ __global__ __launch_bounds__(64 * BSX_HSCAN_WPB, BSX_HSCAN_WAVES) void k_hscan(A
     __shared__ uint32_t TAB[BSX_HSCAN_WPB][4][32];
     __shared__ uint4 QBUF[BSX_HSCAN_WPB][HS_QCAP];
     __shared__ uint32_t ANCH[BSX_LDS_CHR + 1];  // RRBS: chromosome anchors (entries carry chromosome-local positions)
-#ifdef BSX_HSCAN_PAD  /* occupancy experiments: extra LDS per block limits the resident waves */
-    __shared__ uint32_t PAD[BSX_HSCAN_PAD / 4];
-    if (threadIdx.x == 0 && A.n_units == 0xffffffffu) PAD[0] = 1;
-#endif
     const DevParams &P = A.P;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (P.rrbs) {
@@ -2097,17 +2069,22 @@ __global__ __launch_bounds__(64 * BSX_HSCAN_WPB, BSX_HSCAN_WAVES) void k_hscan(A
     const uint32_t n_tasks = min(*H.n_tasks, H.task_cap);
     // Tasks are taken in key order (= by the index entries they walk): the reads that walk the same giant bucket then do
     // so at the same time, and each line of entries / reference is fetched from memory once for all of them
+    // (the grid is sized for the whole task pool — the host does not know the count —: blocks beyond the tasks of this pass leave at once)
     uint32_t slot = blockIdx.x * BSX_HSCAN_WPB + (uint32_t)wv;
-    if (H.xcd_map) slot = ((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3)) * BSX_HSCAN_WPB + (uint32_t)wv;
+    if (H.xcd_map) {  // blocks of one XCD (dispatched round-robin) take a contiguous part of the order
+        const uint32_t per_xcd = ((n_tasks + BSX_HSCAN_WPB - 1) / BSX_HSCAN_WPB + 7u) >> 3;
+        if ((blockIdx.x >> 3) >= per_xcd) return;
+        slot = ((blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3)) * BSX_HSCAN_WPB + (uint32_t)wv;
+    }
     if (slot >= n_tasks) return;
     const uint32_t t = H.order ? rfl(H.order[slot]) : slot;
-    const uint32_t hidx = rfl(H.tasks[t].h), tc0 = rfl(H.tasks[t].c0), tn = rfl(H.tasks[t].n);
+    const uint32_t hraw = rfl(H.tasks[t].h), hidx = hraw & 0x7fffffffu, tc0 = rfl(H.tasks[t].c0), tn = rfl(H.tasks[t].n);
     HTaskOut *o = &H.tout[t];
     if (tn == 0) {  // slot neutralised by a refused request: its unit has not published a list (ListReq may be stale)
         if (lane == 0) { o->count = 0; o->overflow = 0; o->acc[0] = o->acc[1] = o->acc[2] = o->acc[3] = 0; }
         return;
     }
-    const ListReq &R = H.state[hidx].req;
+    const ListReq &R = H.state[hidx].req[hraw >> 31];
     if (lane < 32) { TAB[wv][0][lane] = R.sub_pre[lane]; TAB[wv][1][lane] = R.sub_n[lane]; TAB[wv][2][lane] = R.sub_base[lane]; TAB[wv][3][lane] = R.sub_h[lane]; }
     uint32_t rw[9], rm[9];
 #pragma unroll
@@ -2117,9 +2094,8 @@ __global__ __launch_bounds__(64 * BSX_HSCAN_WPB, BSX_HSCAN_WAVES) void k_hscan(A
     ScanCtx X;
     X.refall = P.refcat; X.Q = QBUF[wv]; X.qh = 0; X.qn = 0; X.thres0 = rfl(R.thres); X.nsurv = 0; X.nwords = (int)rfl(R.nwords); X.lane = lane;
     X.overflow = false; X.o = o; X.acc.c1 = 0; X.acc.f5 = 0; X.acc.nv = 0;
-#ifdef BSX_SPAN_STATS
-    X.span[0] = X.span[1] = X.span[2] = X.span[3] = 0;
-#endif
+#pragma unroll
+    for (int k = 0; k < 9; k++) { X.tv[k] = bsx_tmask(rw[k], rm[k]); if (k < BSX_HSCAN_TMV) asm volatile("" : "+v"(X.tv[k])); }
     const uint32_t cref_off = (uint32_t)((const uint8_t *)P.crefcat - (const uint8_t *)P.refcat);  // both copies live in one allocation (bsx_api.hip)
     const uint32_t c_end = tc0 + tn;
     const bool rrbs = rfl(R.rrbs) != 0;
@@ -2141,8 +2117,11 @@ __global__ __launch_bounds__(64 * BSX_HSCAN_WPB, BSX_HSCAN_WAVES) void k_hscan(A
         const uint32_t hm1 = rfl(TAB[wv][3][sidx]) - 1u, strand = sidx & 1;
         const uint32_t ref_off = strand ? cref_off : 0u;
         uint32_t cb = lo;
-        for (; cb + 256 <= hi && !X.overflow; cb += 256) hscan_step<true>(X, ent + (cb - ps) + lane, ref_off, hm1, 256, cb - tc0, strand, rw, rm);
-        if (cb < hi && !X.overflow) hscan_step<false>(X, ent + (cb - ps) + lane, ref_off, hm1, hi - cb, cb - tc0, strand, rw, rm);
+        uint32_t e[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) e[u] = (ent + (cb - ps) + lane)[u * 64];
+        for (; cb + 256 <= hi && !X.overflow; cb += 256) hscan_step<true>(X, e, ent + (cb + 256 - ps) + lane, ref_off, hm1, 256, cb - tc0, strand, rw, rm);
+        if (cb < hi && !X.overflow) hscan_step<false>(X, e, nullptr, ref_off, hm1, hi - cb, cb - tc0, strand, rw, rm);
     }
     while (X.qn && !X.overflow) hscan_drain(X, min(X.qn, 64u), rw, rm);
     const uint32_t n1 = wave_sum(X.acc.c1), n5 = wave_sum(X.acc.f5);
@@ -2156,9 +2135,6 @@ __global__ __launch_bounds__(64 * BSX_HSCAN_WPB, BSX_HSCAN_WAVES) void k_hscan(A
             u64 *sh = (u64 *)A.scan_stats + (size_t)(blockIdx.x & 63u) * 8;
             atomicAdd((u64 *)&sh[0], (u64)n_cand); atomicAdd((u64 *)&sh[1], (u64)words);
             atomicAdd((u64 *)&sh[2], (u64)n1); atomicAdd((u64 *)&sh[3], (u64)n5);
-#ifdef BSX_SPAN_STATS
-            for (int k_ = 0; k_ < 4; k_++) atomicAdd((u64 *)&sh[4 + k_], (u64)X.span[k_]);
-#endif
         }
     }
 }
@@ -2219,7 +2195,7 @@ __global__ __launch_bounds__(256, 4) void k_hscan_shared(AlignArgs A, HeavyArgs 
         const HTask tk = H.tasks[tid];
         th = tk.h; tc0 = tk.c0; tn = tk.n; tkey = tk.key;
         if (tn) {
-            const ListReq &R = H.state[th].req;
+            const ListReq &R = H.state[th & 0x7fffffffu].req[th >> 31];
             tkey = R.sub_base[0] + (tc0 - R.sub_pre[0]);  // first entry of the window
             sh_ = R.sub_h[0]; stx = R.tag_xor; stw = R.tag_want; snw = R.nwords;
         } else {  // slot neutralised by a refused request: its unit has not published a list
@@ -2242,7 +2218,7 @@ __global__ __launch_bounds__(256, 4) void k_hscan_shared(AlignArgs A, HeavyArgs 
             const uint32_t x = xb + (uint32_t)lane, k = min(x / 20u, K - 1u), f = x - k * 20u;
             const uint32_t hk = (uint32_t)__shfl((int)th, (int)(i0 + k)), tk = (uint32_t)__shfl((int)tid, (int)(i0 + k));  // (all lanes take part)
             if (x < K * 20u) {
-                const ListReq &R = H.state[hk].req;
+                const ListReq &R = H.state[hk & 0x7fffffffu].req[hk >> 31];
                 uint32_t v;
                 if (f < 9) v = R.rw[f];
                 else if (f < 18) v = bsx_tmask(R.rw[f - 9], R.rm[f - 9]);
@@ -2356,52 +2332,131 @@ void bsx_launch_hctrl(const AlignArgs &A, const HeavyArgsRaw &R, int paired, int
     else hipLaunchKernelGGL(k_hctrl<false>, dim3(grid_blocks), dim3(256), 0, stream, A, H);
 }
 
-void bsx_launch_hscan_shared(const AlignArgs &A, const HeavyArgsRaw &R, uint32_t n_tasks, hipStream_t stream)
+// The scan launches are sized for the group's whole task pool: the number of tasks a control pass published stays on the device
+// (H.n_tasks), blocks beyond it exit at once (28 us for 131 072 empty blocks, profiles/r03_launch_cost.json) — no host read-back
+// between a control pass and its scan.
+void bsx_launch_hscan_shared(const AlignArgs &A, const HeavyArgsRaw &R, hipStream_t stream)
 {
     const HeavyArgs H = typed(R);
-    const uint32_t jobs = (n_tasks + HS_SHARE - 1) / HS_SHARE;
+    const uint32_t jobs = (R.task_cap + HS_SHARE - 1) / HS_SHARE;
     hipLaunchKernelGGL(k_hscan_shared, dim3((jobs + 3) / 4), dim3(256), 0, stream, A, H);
 }
 
-void bsx_launch_hscan(const AlignArgs &A, const HeavyArgsRaw &R, uint32_t n_tasks, hipStream_t stream)
+void bsx_launch_hscan(const AlignArgs &A, const HeavyArgsRaw &R, hipStream_t stream)
 {
     const HeavyArgs H = typed(R);
-    uint32_t blocks = (n_tasks + BSX_HSCAN_WPB - 1) / BSX_HSCAN_WPB;
+    uint32_t blocks = (R.task_cap + BSX_HSCAN_WPB - 1) / BSX_HSCAN_WPB;
     if (H.xcd_map) blocks = (blocks + 7u) & ~7u;  // the same number of blocks for each of the 8 XCDs
     hipLaunchKernelGGL(k_hscan, dim3(blocks), dim3(64 * BSX_HSCAN_WPB), 0, stream, A, H);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// scan order of a pass: task ids ordered by the index entry their window starts at, at a granularity of 2^shift entries
+// (a counting sort over bins; the count of tasks stays on the device).  Tasks that walk the same part of a big bucket then
+// run together and share its cache lines; exact order inside a bin does not matter for that, and results
+// never depend on the order (every task writes its own record).
+//   k_task_bins   : rank[i] = arrival number of task i in its bin; also zeroes the count block the NEXT control pass writes
+//   k_bin_scan    : per chunk of BIN_CHUNK bins an exclusive prefix (counts -> starts, counts zeroed for the next pass) and the chunk total
+//   k_task_order  : order[chunk_start + start + rank] = i
+// ---------------------------------------------------------------------------------------------------------------
 namespace {
-__global__ void k_task_keys(const HTask *tasks, const uint32_t *n_tasks_ptr, uint32_t cap, uint32_t *keys, uint32_t *ids)
+#define BIN_CHUNK 2048u
+// Thousands of reads walk the same window of a giant bucket: their tasks fall into ONE bin, and one memory word takes only ~88 atomics
+// per microsecond (300-400 us per pass when every task went to the counter itself).  A block first counts its 1024 tasks per bin in
+// an LDS table and then adds each bin's count to memory once.
+#define BIN_LDS 2048u
+__global__ __launch_bounds__(256) void k_task_bins(const HTask *tasks, const uint32_t *n_tasks_ptr, uint32_t cap, uint32_t shift, uint32_t n_bins, uint32_t *bins,
+                                                    uint32_t *rank, uint32_t *zero_blk)
 {
-    const uint32_t n = min(*n_tasks_ptr, cap), i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) { keys[i] = tasks[i].key; ids[i] = i; }
-}
-}  // namespace
-namespace {
-// diagnostic (BSX_SHARE_STATS): the read offset h of the sub-range each task starts in
-__global__ void k_task_sig(const HTask *tasks, const HState *state, uint32_t n, uint32_t *sig)
-{
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const HTask tk = tasks[i];
-    uint32_t v = 0xffffffffu;
-    if (tk.n) {
-        const ListReq &R = state[tk.h].req;
-        for (uint32_t s_ = 0; s_ < min(R.nsub, 32u); s_++)
-            if (tk.c0 >= R.sub_pre[s_] && tk.c0 < R.sub_pre[s_] + R.sub_n[s_]) v = R.sub_h[s_] ^ (tk.c0 + tk.n > R.sub_pre[s_] + R.sub_n[s_] ? 0x80000000u : 0u);
+    __shared__ uint32_t hkey[BIN_LDS], hcnt[BIN_LDS];
+    if (zero_blk && blockIdx.x == 0 && threadIdx.x < 4) zero_blk[threadIdx.x] = 0;
+    const uint32_t n = min(*n_tasks_ptr, cap);
+    for (uint32_t chunk = blockIdx.x * 1024u; chunk < n; chunk += gridDim.x * 1024u) {
+        for (uint32_t i = threadIdx.x; i < BIN_LDS; i += 256) { hkey[i] = 0xffffffffu; hcnt[i] = 0; }
+        __syncthreads();
+        uint32_t sl[4], lr[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t i = chunk + (uint32_t)k * 256u + threadIdx.x;
+            sl[k] = 0; lr[k] = 0;
+            if (i < n) {
+                const uint32_t bin = min(tasks[i].key >> shift, n_bins - 1u);
+                uint32_t slot = (bin * 0x9E3779B1u) >> 21;  // 11 bits
+                for (;;) {
+                    const uint32_t prev = atomicCAS(&hkey[slot], 0xffffffffu, bin);
+                    if (prev == 0xffffffffu || prev == bin) break;
+                    slot = (slot + 1) & (BIN_LDS - 1);
+                }
+                sl[k] = slot; lr[k] = atomicAdd(&hcnt[slot], 1u);
+            }
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < BIN_LDS; i += 256)
+            if (hkey[i] != 0xffffffffu) hcnt[i] = atomicAdd(&bins[hkey[i]], hcnt[i]);  // count -> first rank of this block's tasks in the bin
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t i = chunk + (uint32_t)k * 256u + threadIdx.x;
+            if (i < n) rank[i] = hcnt[sl[k]] + lr[k];
+        }
+        __syncthreads();
     }
-    sig[i] = v;
+}
+__global__ __launch_bounds__(256) void k_bin_scan(const uint32_t *n_tasks_ptr, uint32_t *bins, uint32_t *bstart, uint32_t *chunk_tot, uint32_t n_bins)
+{
+    __shared__ uint32_t part[256];
+    if (*n_tasks_ptr == 0) return;  // (all counts are zero and stay zero; nothing reads the starts)
+    const uint32_t base = blockIdx.x * BIN_CHUNK + threadIdx.x * 8u;
+    uint32_t v[8], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) { v[k] = base + k < n_bins ? bins[base + k] : 0u; sum += v[k]; }
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (uint32_t o = 1; o < 256; o <<= 1) {
+        const uint32_t t = threadIdx.x >= o ? part[threadIdx.x - o] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += t;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - sum;  // exclusive prefix of this thread's eight bins inside the chunk
+#pragma unroll
+    for (int k = 0; k < 8; k++) { if (base + k < n_bins) { bstart[base + k] = run; if (v[k]) bins[base + k] = 0; } run += v[k]; }
+    if (threadIdx.x == 255) chunk_tot[blockIdx.x] = part[255];
+}
+__global__ __launch_bounds__(256) void k_task_order(const HTask *tasks, const uint32_t *n_tasks_ptr, uint32_t cap, uint32_t shift, uint32_t n_bins, const uint32_t *bstart,
+                                                     const uint32_t *chunk_tot, uint32_t n_chunks, const uint32_t *rank, uint32_t *order)
+{
+    __shared__ uint32_t cstart[1024];
+    const uint32_t n = min(*n_tasks_ptr, cap);
+    if (n == 0) return;
+    // exclusive prefix of the chunk totals (n_chunks <= 1024), redone by every block: cheaper than one more launch
+    for (uint32_t i = threadIdx.x; i < 1024; i += 256) cstart[i] = i < n_chunks ? chunk_tot[i] : 0u;
+    __syncthreads();
+    for (uint32_t o = 1; o < 1024; o <<= 1) {
+        uint32_t t[4];
+        for (int k = 0; k < 4; k++) { const uint32_t i = threadIdx.x + 256 * k; t[k] = i >= o ? cstart[i - o] : 0u; }
+        __syncthreads();
+        for (int k = 0; k < 4; k++) cstart[threadIdx.x + 256 * k] += t[k];
+        __syncthreads();
+    }
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const uint32_t b = min(tasks[i].key >> shift, n_bins - 1u), c = b / BIN_CHUNK;
+        order[(c ? cstart[c - 1] : 0u) + bstart[b] + rank[i]] = i;
+    }
 }
 }  // namespace
-void bsx_launch_task_sig(const HeavyArgsRaw &R, uint32_t n_tasks, uint32_t *sig, hipStream_t stream)
-{
-    hipLaunchKernelGGL(k_task_sig, dim3((n_tasks + 255) / 256), dim3(256), 0, stream, (const HTask *)R.tasks, (const HState *)R.state, n_tasks, sig);
-}
 
-void bsx_launch_task_keys(const HeavyArgsRaw &R, uint32_t n_tasks, uint32_t *keys, uint32_t *ids, hipStream_t stream)
+uint32_t bsx_bin_chunks(uint32_t n_bins) { return (n_bins + BIN_CHUNK - 1) / BIN_CHUNK; }
+
+// bins: [n_bins] zero on entry and on exit; bstart: [n_bins]; chunk_tot: [bsx_bin_chunks(n_bins)] (<= 1024 chunks); rank, order: [task_cap];
+// zero_blk: four words to clear (or null)
+void bsx_launch_task_order(const HeavyArgsRaw &R, uint32_t shift, uint32_t n_bins, uint32_t *bins, uint32_t *bstart, uint32_t *chunk_tot, uint32_t *rank, uint32_t *order,
+                           uint32_t *zero_blk, hipStream_t stream)
 {
-    hipLaunchKernelGGL(k_task_keys, dim3((n_tasks + 255) / 256), dim3(256), 0, stream, (const HTask *)R.tasks, R.n_tasks, R.task_cap, keys, ids);
+    const uint32_t grid = std::max(1u, std::min(512u, (R.task_cap + 255u) / 256u)), n_chunks = bsx_bin_chunks(n_bins);
+    hipLaunchKernelGGL(k_task_bins, dim3(std::max(1u, std::min(256u, (R.task_cap + 1023u) / 1024u))), dim3(256), 0, stream, (const HTask *)R.tasks, R.n_tasks, R.task_cap, shift, n_bins, bins, rank, zero_blk);
+    hipLaunchKernelGGL(k_bin_scan, dim3(n_chunks), dim3(256), 0, stream, R.n_tasks, bins, bstart, chunk_tot, n_bins);
+    hipLaunchKernelGGL(k_task_order, dim3(grid), dim3(256), 0, stream, (const HTask *)R.tasks, R.n_tasks, R.task_cap, shift, n_bins, bstart, chunk_tot, n_chunks, rank, order);
 }
 
 size_t bsx_hstate_bytes(void) { return sizeof(HState); }
@@ -2414,5 +2469,13 @@ int bsx_align_occupancy(int paired)
     hipError_t e = paired ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_align<true, false>, 256, 0)
                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_align<false, false>, 256, 0);
     if (e != hipSuccess || nb < 1) nb = 2;
+    return nb;
+}
+
+int bsx_hctrl_occupancy(int paired)
+{
+    int nb = 0;
+    hipError_t e = paired ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_hctrl<true>, 256, 0) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_hctrl<false>, 256, 0);
+    if (e != hipSuccess || nb < 1) nb = 1;
     return nb;
 }

@@ -16,7 +16,6 @@
 #include "bsx_kernel_args.h"
 
 static int g_waves_per_cu = 0;
-static int g_heavy_groups = 2;      // unit groups of the heavy pipeline that run out of phase (1 = strictly alternating passes)
 static int g_heavy_threshold = 0;  // candidate-list length that sends a unit to the heavy pipeline; 0 = by mode (heavy_threshold_for)
 
 extern "C" int bsx_set_waves_per_cu(int w) { g_waves_per_cu = w; return BSX_OK; }
@@ -206,6 +205,8 @@ void bsx_fill_devparams(const bsx_ref *r, DevParams &d)
 // ---------------------------------------------------------------------------------------------------------------
 // batches
 // ---------------------------------------------------------------------------------------------------------------
+#define BSX_MAX_GROUPS 8
+#define BSX_POLL_SLOTS 4
 struct bsx_batch {
     bsx_ref *ref = nullptr;
     int paired = 0, debug = 0, has_qual = 0, leak_exact = 0;
@@ -214,8 +215,17 @@ struct bsx_batch {
     uint64_t *d_hist_off[2] = {nullptr, nullptr};
     uint8_t *d_leak_rec = nullptr;
     uint32_t max_units = 0, n_units = 0, first_index = 0;
-    hipStream_t stream = nullptr, stream_hi = nullptr;  // stream_hi: control passes of the heavy pipeline
-    hipEvent_t ev_ctrl[2] = {nullptr, nullptr}, ev_scan[2] = {nullptr, nullptr}, ev_sync = nullptr;
+    hipStream_t stream = nullptr;
+    // heavy pipeline: unit groups whose passes run out of phase — the scan passes of all groups on `stream`, the control passes of
+    // group g on its own high-priority stream, ordered against each other by events on the device (no host read-back per pass)
+    struct Group {
+        hipStream_t s_ctrl = nullptr;
+        hipEvent_t ev_ctrl = nullptr, ev_scan = nullptr, ev_poll[BSX_POLL_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+        uint32_t *d_bins = nullptr, *d_bstart = nullptr, *d_chunk_tot = nullptr, *d_rank = nullptr, *d_order = nullptr;
+    } grp[BSX_MAX_GROUPS];
+    int n_groups = 1, chunk_passes = 2, trace = 0, hctrl_blocks_per_cu = 1;
+    uint32_t bin_shift = 0, n_bins = 1;
+    hipEvent_t ev_sync = nullptr;
     std::vector<hipEvent_t> scan_ev;  // pairs of timing events around every k_hscan launch of the last run (pool grows on demand)
     size_t scan_ev_used = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -231,9 +241,7 @@ struct bsx_batch {
     uint32_t *d_heavy_list = nullptr, *d_heavy_count = nullptr;
     // heavy pipeline pools
     uint8_t *d_hstate = nullptr, *d_hslabs = nullptr, *d_htasks = nullptr, *d_htout = nullptr;
-    uint32_t *d_tsort[4] = {nullptr, nullptr, nullptr, nullptr};  // keys in / out, ids in / out of the task sort
-    void *d_sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
-    uint32_t *d_hactive[4] = {nullptr, nullptr, nullptr, nullptr}, *d_hcnt = nullptr;  // d_hcnt: per group two ping-pong blocks {n_active, n_tasks, queue[2]}
+    uint32_t *d_hactive[2] = {nullptr, nullptr}, *d_hcnt = nullptr;  // d_hcnt: per group two ping-pong blocks {n_active, n_tasks, queue[2]}
     uint32_t hcap = 0, task_cap = 0;
     uint32_t *h_pinned = nullptr;  // pinned host words for the per-pass count read-backs
     int n_cu = 0;
@@ -284,6 +292,11 @@ static int ensure_scratch(bsx_batch *b)
     if (grid > need) grid = need > 0 ? need : 1;
     b->grid_blocks = grid;
     b->n_cu = prop.multiProcessorCount;
+    // control blocks per CU: one, although two fit.  A control wave holds half of its SIMD's registers: with two blocks per CU the scan
+    // kernel's waves cannot be resident beside them and the two only alternate; with one, four scan waves per SIMD run beside it
+    // (C3 with two batches in flight 136.5 -> 131.3 ms per step, C4 211 -> 195; BSX_HCTRL_BLOCKS: tuning knob)
+    b->hctrl_blocks_per_cu = 1;
+    if (const char *e = getenv("BSX_HCTRL_BLOCKS")) b->hctrl_blocks_per_cu = std::max(1, std::min(bsx_hctrl_occupancy(b->paired), atoi(e)));
     if (!b->d_heavy_list) {
         // deferred units handled per round (more than this: several rounds): what 26 GB of slabs hold — 24 576 units of the 1.07 MB
         // paired -v 6 slab, 111 K of the 234 KB single-end -v 2 one (RRBS defers a third of its reads: Alu-like fragments)
@@ -293,7 +306,7 @@ static int ensure_scratch(bsx_batch *b)
         b->task_cap = g_user_limits ? g_task_cap : std::min<uint32_t>(g_task_cap, std::max<uint32_t>(4096u, 64u * b->hcap));
         HIP_TRY(hipMalloc((void **)&b->d_heavy_list, ((size_t)b->max_units + 1) * 4));
         HIP_TRY(hipMalloc((void **)&b->d_heavy_count, 256));
-        HIP_TRY(hipHostMalloc((void **)&b->h_pinned, 256, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void **)&b->h_pinned, 1024, hipHostMallocDefault));
         HIP_TRY(hipMalloc((void **)&b->d_hstate, (size_t)b->hcap * bsx_hstate_bytes()));
         if (getenv("BSX_POISON")) HIP_TRY(hipMemsetAsync(b->d_hstate, 0xA5, (size_t)b->hcap * bsx_hstate_bytes(), b->stream));  // test hook: recycled memory is not zero
         HIP_TRY(hipMalloc((void **)&b->d_hslabs, (size_t)b->hcap * b->hslab_bytes));
@@ -305,9 +318,24 @@ static int ensure_scratch(bsx_batch *b)
             HIP_TRY(hipMemsetAsync(b->d_htout, 0xA5, (size_t)b->task_cap * bsx_htaskout_bytes(), b->stream));
             HIP_TRY(hipMemsetAsync(b->d_htasks, 0xA5, (size_t)b->task_cap * bsx_htask_bytes(), b->stream));
         }
-        for (int k = 0; k < 4; k++) HIP_TRY(hipMalloc((void **)&b->d_hactive[k], (size_t)b->hcap * 4));
-        for (int k = 0; k < 4; k++) HIP_TRY(hipMalloc((void **)&b->d_tsort[k], (size_t)b->task_cap * 4));
-        HIP_TRY(hipMalloc((void **)&b->d_hcnt, 256));
+        for (int k = 0; k < 2; k++) HIP_TRY(hipMalloc((void **)&b->d_hactive[k], (size_t)b->hcap * 4));
+        HIP_TRY(hipMalloc((void **)&b->d_hcnt, BSX_MAX_GROUPS * 64));
+        // scan order of a pass: bins of 2^shift index entries, at most 2^20 of them (bsx_launch_task_order)
+        const uint64_t ne = std::max<uint64_t>(1, b->ref->n_entries);
+        b->bin_shift = 0;
+        const uint32_t bin_log2 = getenv("BSX_BIN_LOG2") ? (uint32_t)std::max(8, std::min(21, atoi(getenv("BSX_BIN_LOG2")))) : 20u;  // tuning knob
+        while (((ne >> b->bin_shift) + 1) > (1u << bin_log2)) b->bin_shift++;
+        b->n_bins = (uint32_t)(ne >> b->bin_shift) + 1;
+        const uint32_t tcap = b->task_cap / (uint32_t)b->n_groups;
+        for (int g = 0; g < b->n_groups; g++) {
+            bsx_batch::Group &q = b->grp[g];
+            HIP_TRY(hipMalloc((void **)&q.d_bins, (size_t)b->n_bins * 4));
+            HIP_TRY(hipMemsetAsync(q.d_bins, 0, (size_t)b->n_bins * 4, b->stream));
+            HIP_TRY(hipMalloc((void **)&q.d_bstart, (size_t)b->n_bins * 4));
+            HIP_TRY(hipMalloc((void **)&q.d_chunk_tot, (size_t)bsx_bin_chunks(b->n_bins) * 4));
+            HIP_TRY(hipMalloc((void **)&q.d_rank, (size_t)tcap * 4));
+            HIP_TRY(hipMalloc((void **)&q.d_order, (size_t)tcap * 4));
+        }
     }
     const uint64_t slots = b->debug ? b->max_units : (uint64_t)grid * 4;
     const size_t bytes = (size_t)(slots * b->slab_bytes);
@@ -333,14 +361,26 @@ extern "C" int bsx_batch_create(bsx_ref *r, uint32_t max_units, int paired, bsx_
     b->hslab_bytes = slab_size(r->P, b->paired, b->rowcap, true);
     int rc = BSX_OK;
     auto fail = [&](int code) { bsx_batch_destroy(b); return code; };
-    if (const char *e = getenv("BSX_HEAVY_GROUPS")) g_heavy_groups = atoi(e) == 1 ? 1 : 2;  // diagnostic: 1 = alternate control and scan passes strictly
+    // tuning / diagnostic knobs are read once, here (a batch keeps its settings): unit groups of the heavy pipeline (default 1: the
+    // control and scan passes of a batch alternate and overlap those of the OTHER batch in flight — measured best with two batches in
+    // flight, C3 131 ms per step against 148 with two groups each; a caller that keeps a single batch in flight gains from 2: 158 against
+    // 177 ms), passes enqueued per host poll
+    if (const char *e = getenv("BSX_HEAVY_GROUPS")) b->n_groups = std::max(1, std::min(BSX_MAX_GROUPS, atoi(e)));
+    if (const char *e = getenv("BSX_HEAVY_CHUNK")) b->chunk_passes = std::max(1, std::min(64, atoi(e)));
+    b->trace = getenv("BSX_TRACE_HEAVY") != nullptr;
     if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) return fail(BSX_ERR_DEVICE);
     {
         int lo_p = 0, hi_p = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo_p, &hi_p);
-        if (hipStreamCreateWithPriority(&b->stream_hi, hipStreamNonBlocking, hi_p) != hipSuccess) return fail(BSX_ERR_DEVICE);
-        for (hipEvent_t *e : {&b->ev_ctrl[0], &b->ev_ctrl[1], &b->ev_scan[0], &b->ev_scan[1], &b->ev_sync})
-            if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) return fail(BSX_ERR_DEVICE);
+        for (int g = 0; g < b->n_groups; g++) {
+            bsx_batch::Group &q = b->grp[g];
+            if (hipStreamCreateWithPriority(&q.s_ctrl, hipStreamNonBlocking, hi_p) != hipSuccess) return fail(BSX_ERR_DEVICE);
+            for (hipEvent_t *e : {&q.ev_ctrl, &q.ev_scan})
+                if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) return fail(BSX_ERR_DEVICE);
+            for (int k = 0; k < BSX_POLL_SLOTS; k++)  // the host sleeps on these (no spinning: one driver thread per device batch)
+                if (hipEventCreateWithFlags(&q.ev_poll[k], hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) return fail(BSX_ERR_DEVICE);
+        }
+        if (hipEventCreateWithFlags(&b->ev_sync, hipEventDisableTiming) != hipSuccess) return fail(BSX_ERR_DEVICE);
     }
     if (hipEventCreate(&b->ev0) != hipSuccess || hipEventCreate(&b->ev1) != hipSuccess) return fail(BSX_ERR_DEVICE);
     const int nm = b->paired ? 2 : 1;
@@ -372,15 +412,20 @@ extern "C" void bsx_batch_destroy(bsx_batch *b)
         for (void *q : {(void *)b->d_seq[m], (void *)b->d_qual[m], (void *)b->d_off[m], (void *)b->d_cc[m]})
             if (q) (void)hipFree(q);
     for (void *q : {(void *)b->d_hits, (void *)b->d_pairs, (void *)b->d_npairs, (void *)b->d_scratch, (void *)b->d_dbg, (void *)b->d_queue, (void *)b->d_counters, (void *)b->d_scan_stats, (void *)b->d_cycles, (void *)b->d_heavy_list, (void *)b->d_heavy_count,
-                    (void *)b->d_hstate, (void *)b->d_hslabs, (void *)b->d_htasks, (void *)b->d_htout, (void *)b->d_hactive[0], (void *)b->d_hactive[1], (void *)b->d_hactive[2], (void *)b->d_hactive[3], (void *)b->d_hcnt, (void *)b->d_tsort[0], (void *)b->d_tsort[1], (void *)b->d_tsort[2], (void *)b->d_tsort[3], b->d_sort_tmp, (void *)b->d_redo})
+                    (void *)b->d_hstate, (void *)b->d_hslabs, (void *)b->d_htasks, (void *)b->d_htout, (void *)b->d_hactive[0], (void *)b->d_hactive[1], (void *)b->d_hcnt, (void *)b->d_redo})
         if (q) (void)hipFree(q);
     for (int m = 0; m < 2; m++) for (void *q : {(void *)b->d_hist_seq[m], (void *)b->d_hist_qual[m], (void *)b->d_hist_off[m]}) if (q) (void)hipFree(q);
     if (b->d_leak_rec) (void)hipFree(b->d_leak_rec);
     if (b->h_pinned) (void)hipHostFree(b->h_pinned);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
-    if (b->stream_hi) { (void)hipStreamSynchronize(b->stream_hi); (void)hipStreamDestroy(b->stream_hi); }
-    for (hipEvent_t e : {b->ev_ctrl[0], b->ev_ctrl[1], b->ev_scan[0], b->ev_scan[1], b->ev_sync}) if (e) (void)hipEventDestroy(e);
+    for (int g = 0; g < BSX_MAX_GROUPS; g++) {
+        bsx_batch::Group &q = b->grp[g];
+        if (q.s_ctrl) { (void)hipStreamSynchronize(q.s_ctrl); (void)hipStreamDestroy(q.s_ctrl); }
+        for (hipEvent_t e : {q.ev_ctrl, q.ev_scan, q.ev_poll[0], q.ev_poll[1], q.ev_poll[2], q.ev_poll[3]}) if (e) (void)hipEventDestroy(e);
+        for (void *p_ : {(void *)q.d_bins, (void *)q.d_bstart, (void *)q.d_chunk_tot, (void *)q.d_rank, (void *)q.d_order}) if (p_) (void)hipFree(p_);
+    }
+    if (b->ev_sync) (void)hipEventDestroy(b->ev_sync);
     for (hipEvent_t e : b->scan_ev) (void)hipEventDestroy(e);
     if (b->stream) (void)hipStreamDestroy(b->stream);
     delete b;
@@ -524,130 +569,116 @@ extern "C" int bsx_batch_run_range(bsx_batch *b, uint32_t first_unit, uint32_t n
     HIP_TRY(hipGetLastError());
     b->last_heavy = 0; b->last_heavy_iters = 0; b->last_redo = 0; b->scan_ev_used = 0;
     if (A.heavy_threshold) {
-        // heavy pipeline: iterate k_hctrl / k_hscan until every deferred unit is finished (host-driven, so this call
-        // returns only after the deferred units are done; units that were not deferred are already complete)
+        // heavy pipeline: passes of k_hctrl / k_hscan until every deferred unit is finished (this call returns once the last pass
+        // is queued and known to be the last; units that were not deferred are already complete)
         HIP_TRY(hipMemcpyAsync(b->h_pinned, b->d_heavy_count, 4, hipMemcpyDeviceToHost, b->stream));
         HIP_TRY(hipStreamSynchronize(b->stream));
         const uint32_t n_heavy = b->h_pinned[0];
         b->last_heavy = n_heavy;
-        // Each round handles up to hcap deferred units.  One pass = k_hctrl (advance every active unit, publish scan
-        // tasks) -> read the two counts back -> order the tasks by the index address they start at, so that tasks walking
-        // the same part of a big bucket run together and share its cache lines -> k_hscan.
-        // Each round handles up to hcap deferred units, split into two groups that run their passes out of phase: while
-        // k_hscan evaluates the tasks of one group (main stream), k_hctrl advances the other group (high-priority
-        // stream) — control passes are latency-bound chains of a few thousand waves and disappear beside the scan.
-        // One pass of a group = k_hctrl (advance every active unit, publish scan tasks) -> counts read back -> k_hscan.
-        const bool trace = getenv("BSX_TRACE_HEAVY") != nullptr;
-        const bool sort_tasks = !getenv("BSX_SORT_TASKS") || atoi(getenv("BSX_SORT_TASKS")) != 0;
-        const bool xcd_map = !getenv("BSX_XCD_MAP") || atoi(getenv("BSX_XCD_MAP")) != 0;
-        const bool share_stats = getenv("BSX_SHARE_STATS") != nullptr;
-        const bool shared_scan = b->ref->P.rrbs && (!getenv("BSX_SHARED_SCAN") || atoi(getenv("BSX_SHARED_SCAN")) != 0);
-        uint64_t share_same = 0, share_same_h = 0, share_total = 0, share_hist[16] = {0};
-        const int n_groups = g_heavy_groups;
-        struct Group { uint32_t n_act = 0, iter = 0; int cur = 0; bool done = true, scan_pending = false; HeavyArgsRaw H; uint32_t *blk[2]; };
+        // Each round handles up to hcap deferred units, split into unit groups whose passes run out of phase.  One pass of a group =
+        //   k_hctrl (advance every active unit of the group, publish scan tasks)          on the group's high-priority stream
+        //   task order (bsx_launch_task_order) + k_hscan over the published tasks          on the batch's stream
+        // chained by events on the device: the counts a control pass leaves (active units, tasks) stay there — the next control
+        // pass reads its input count from memory, the scan launches are sized for the whole task pool and their surplus blocks exit.
+        // The host enqueues `chunk_passes` passes per group at a time, keeps two such chunks queued ahead, and only looks at a
+        // group's active count once per chunk (sleeping on an event) to learn when the group is finished; passes that were queued
+        // beyond that point find nothing to do.  While k_hscan evaluates the tasks of one group, the control kernels of the others
+        // run beside it — they are latency-bound chains of a few thousand waves.
+        const bool shared_scan = b->ref->P.rrbs != 0;  // RRBS: runs of tasks over one window, scanned together
+        const int n_groups = b->n_groups;
+        struct Group { uint32_t n0 = 0, passes = 0, polls = 0, polled = 0; int cur = 0; bool done = true; HeavyArgsRaw H; uint32_t *blk[2]; };
+        volatile uint32_t *pinned = (volatile uint32_t *)b->h_pinned;
         for (uint32_t base = 0; base < n_heavy; base += b->hcap) {
             const uint32_t n_round = std::min(b->hcap, n_heavy - base);
-            Group G[2];
+            Group G[BSX_MAX_GROUPS];
             HIP_TRY(hipEventRecord(b->ev_sync, b->stream));             // everything queued so far (k_align, earlier rounds)
-            HIP_TRY(hipStreamWaitEvent(b->stream_hi, b->ev_sync, 0));
-            auto launch_ctrl = [&](int g) -> int {
+            auto enqueue_pass = [&](int g) -> int {
                 Group &q = G[g];
-                uint32_t *out = q.blk[q.cur ^ 1];
-                if (q.scan_pending) { HIP_TRY(hipStreamWaitEvent(b->stream_hi, b->ev_scan[g], 0)); q.scan_pending = false; }
-                HIP_TRY(hipMemsetAsync(out, 0, 16, b->stream_hi));
+                bsx_batch::Group &hw = b->grp[g];
+                uint32_t *in = q.blk[q.cur], *out = q.blk[q.cur ^ 1];
+                const bool fresh = q.passes == 0;
+                if (fresh) {
+                    HIP_TRY(hipStreamWaitEvent(hw.s_ctrl, b->ev_sync, 0));
+                    HIP_TRY(hipMemsetAsync(out, 0, 16, hw.s_ctrl));
+                } else HIP_TRY(hipStreamWaitEvent(hw.s_ctrl, hw.ev_scan, 0));  // the scan of the previous pass (its first kernel also cleared `out`)
                 q.H.active_in = b->d_hactive[q.cur] + q.H.hidx_base; q.H.active_out = b->d_hactive[q.cur ^ 1] + q.H.hidx_base;
-                q.H.n_active_in_ptr = q.blk[q.cur]; q.H.n_active_in = q.n_act; q.H.n_active_out = out; q.H.n_tasks = out + 1; q.H.queue = out + 2;
-                bsx_launch_hctrl(A, q.H, b->paired, (int)std::min<uint32_t>((q.n_act + 3) / 4, (uint32_t)b->n_cu * 4), b->stream_hi);
+                q.H.n_active_in_ptr = in; q.H.n_active_in = q.n0; q.H.n_active_out = out; q.H.n_tasks = out + 1; q.H.queue = out + 2;
+                q.H.fresh = fresh ? 1 : 0;
+                // (no more blocks than are resident at once — two per CU by their LDS —: blocks of a high-priority kernel that wait for a slot
+                //  keep the dispatcher from placing the kernels of the normal-priority stream, 300 us per pass when the grid was twice that)
+                bsx_launch_hctrl(A, q.H, b->paired, (int)std::min<uint32_t>((q.n0 + 3) / 4, (uint32_t)b->n_cu * b->hctrl_blocks_per_cu), hw.s_ctrl);
                 HIP_TRY(hipGetLastError());
-                HIP_TRY(hipMemcpyAsync(b->h_pinned + 8 + 4 * g, out, 8, hipMemcpyDeviceToHost, b->stream_hi));
-                HIP_TRY(hipEventRecord(b->ev_ctrl[g], b->stream_hi));
+                // scan order of the tasks this pass published, still on the group's stream: done by the time the main stream gets to the scan
+                q.H.order = hw.d_order; q.H.xcd_map = 1;
+                bsx_launch_task_order(q.H, b->bin_shift, b->n_bins, hw.d_bins, hw.d_bstart, hw.d_chunk_tot, hw.d_rank, hw.d_order, in, hw.s_ctrl);
+                HIP_TRY(hipEventRecord(hw.ev_ctrl, hw.s_ctrl));
+                HIP_TRY(hipStreamWaitEvent(b->stream, hw.ev_ctrl, 0));
+                if (b->scan_ev_used + 2 > b->scan_ev.size()) {
+                    hipEvent_t e0, e1;
+                    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+                    b->scan_ev.push_back(e0); b->scan_ev.push_back(e1);
+                }
+                HIP_TRY(hipEventRecord(b->scan_ev[b->scan_ev_used], b->stream));
+                if (shared_scan) bsx_launch_hscan_shared(A, q.H, b->stream);
+                else bsx_launch_hscan(A, q.H, b->stream);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipEventRecord(b->scan_ev[b->scan_ev_used + 1], b->stream));
+                b->scan_ev_used += 2;
+                HIP_TRY(hipEventRecord(hw.ev_scan, b->stream));
+                q.cur ^= 1; q.passes++;
+                b->last_heavy_iters++;
                 return BSX_OK;
             };
+            // one chunk: `chunk_passes` passes of every open group, interleaved pass by pass — the main stream takes the scans in the order
+            // they are queued, and the scan of group g's next pass can only start after that group's control pass, which runs beside
+            // the scans of the other groups — then the counts each group's last control pass of the chunk left: {active units, tasks}
+            auto enqueue_chunk = [&]() -> int {
+                for (int k = 0; k < b->chunk_passes; k++)
+                    for (int g = 0; g < n_groups; g++)
+                        if (!G[g].done) { int rc = enqueue_pass(g); if (rc) return rc; }
+                for (int g = 0; g < n_groups; g++) {
+                    Group &q = G[g];
+                    if (q.done) continue;
+                    const uint32_t slot = q.polls % BSX_POLL_SLOTS;
+                    HIP_TRY(hipMemcpyAsync(b->h_pinned + 32 + 16 * g + 2 * slot, q.blk[q.cur], 8, hipMemcpyDeviceToHost, b->grp[g].s_ctrl));
+                    HIP_TRY(hipEventRecord(b->grp[g].ev_poll[slot], b->grp[g].s_ctrl));
+                    q.polls++;
+                }
+                return BSX_OK;
+            };
+            int n_open = 0;
             for (int g = 0; g < n_groups; g++) {
                 Group &q = G[g];
                 const uint32_t lo = (uint32_t)((uint64_t)n_round * g / n_groups), hi = (uint32_t)((uint64_t)n_round * (g + 1) / n_groups);
-                q.n_act = hi - lo; q.done = q.n_act == 0;
+                q.n0 = hi - lo; q.done = q.n0 == 0;
                 memset(&q.H, 0, sizeof(q.H));
                 const uint32_t tcap = b->task_cap / n_groups, toff = tcap * g;
                 q.H.state = b->d_hstate; q.H.slabs = b->d_hslabs;
                 q.H.tasks = b->d_htasks + (size_t)toff * bsx_htask_bytes(); q.H.tout = b->d_htout + (size_t)toff * bsx_htaskout_bytes();
-                q.H.task_cap = tcap; q.H.list_base = base; q.H.hidx_base = lo; q.H.fresh = 1;
+                q.H.task_cap = tcap; q.H.list_base = base; q.H.hidx_base = lo;
                 q.blk[0] = b->d_hcnt + 16 * g; q.blk[1] = b->d_hcnt + 16 * g + 8;
-                if (!q.done) { int rc = launch_ctrl(g); if (rc) return rc; }
+                if (!q.done) n_open++;
             }
-            for (;;) {
-                bool any = false;
-                for (int g = 0; g < n_groups; g++) {
+            for (int depth = 0; depth < 2; depth++) { int rc = enqueue_chunk(); if (rc) return rc; }
+            while (n_open > 0) {
+                for (int g = 0; g < n_groups; g++) {  // the oldest chunk in flight
                     Group &q = G[g];
                     if (q.done) continue;
-                    any = true;
-                    HIP_TRY(hipEventSynchronize(b->ev_ctrl[g]));
-                    const uint32_t cnt[2] = {((volatile uint32_t *)b->h_pinned)[8 + 4 * g], ((volatile uint32_t *)b->h_pinned)[9 + 4 * g]};
-                    if (trace && (q.iter < 40 || q.iter % 2000 == 0))
-                        fprintf(stderr, "[bsx heavy] paired %d base %u group %d iter %u active %u -> %u tasks %u t=%ld\n", b->paired, base, g, q.iter, q.n_act, cnt[0], cnt[1], (long)clock());
-                    if (++q.iter > 100000) { g_bsx_err = "heavy pipeline did not converge"; return BSX_ERR_DEVICE; }
-                    b->last_heavy_iters++;
-                    q.n_act = cnt[0];
-                    q.cur ^= 1; q.H.fresh = 0;
-                    if (q.n_act == 0) { q.done = true; continue; }
-                    const uint32_t n_tasks = std::min(cnt[1], q.H.task_cap);
-                    if (n_tasks) {
-                        // (the counters of this pass live in the block the control kernel just wrote: blk[cur] after the flip)
-                        q.H.n_tasks = q.blk[q.cur] + 1; q.H.queue = q.blk[q.cur] + 2;
-                        HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_ctrl[g], 0));
-                        if (b->scan_ev_used + 2 > b->scan_ev.size()) {
-                            hipEvent_t e0, e1;
-                            HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
-                            b->scan_ev.push_back(e0); b->scan_ev.push_back(e1);
-                        }
-                        q.H.order = nullptr; q.H.xcd_map = xcd_map ? 1 : 0;
-                        if (sort_tasks && n_tasks > 64) {
-                            // (two groups share the four sort arrays: their sorts and scans are ordered on the main stream)
-                            bsx_launch_task_keys(q.H, n_tasks, b->d_tsort[0], b->d_tsort[2], b->stream);
-                            int rcs = bsx_sort_pairs_u32(&b->d_sort_tmp, &b->sort_tmp_bytes, b->d_tsort[0], b->d_tsort[1], b->d_tsort[2], b->d_tsort[3], n_tasks, b->stream);
-                            if (rcs) return rcs;
-                            q.H.order = b->d_tsort[3];
-                            if (share_stats) {  // diagnostic: how many scan tasks of a pass cover exactly the window of their neighbour in scan order?
-                                std::vector<uint32_t> ord(n_tasks);
-                                std::vector<uint32_t> tk((size_t)n_tasks * 4);
-                                HIP_TRY(hipStreamSynchronize(b->stream));
-                                HIP_TRY(hipMemcpy(ord.data(), b->d_tsort[3], (size_t)n_tasks * 4, hipMemcpyDeviceToHost));
-                                HIP_TRY(hipMemcpy(tk.data(), q.H.tasks, (size_t)n_tasks * 16, hipMemcpyDeviceToHost));
-                                std::vector<uint32_t> sig(n_tasks);
-                                bsx_launch_task_sig(q.H, n_tasks, b->d_tsort[0], b->stream);  // (the unsorted keys are no longer needed)
-                                HIP_TRY(hipStreamSynchronize(b->stream));
-                                HIP_TRY(hipMemcpy(sig.data(), b->d_tsort[0], (size_t)n_tasks * 4, hipMemcpyDeviceToHost));
-                                uint64_t same = 0, run = 1;
-                                for (uint32_t i = 1; i <= n_tasks; i++) {
-                                    const bool eq = i < n_tasks && tk[4 * (size_t)ord[i] + 3] == tk[4 * (size_t)ord[i - 1] + 3] && tk[4 * (size_t)ord[i] + 2] == tk[4 * (size_t)ord[i - 1] + 2];
-                                    if (eq && sig[ord[i]] == sig[ord[i - 1]] && !(sig[ord[i]] >> 31)) share_same_h++;
-                                    if (eq) { same++; run++; }
-                                    else { share_hist[std::min<uint64_t>(15, (uint64_t)std::log2((double)run))]++; run = 1; }
-                                }
-                                share_same += same; share_total += n_tasks;
-                            }
-                        }
-                        HIP_TRY(hipEventRecord(b->scan_ev[b->scan_ev_used], b->stream));
-                        if (shared_scan && q.H.order) bsx_launch_hscan_shared(A, q.H, n_tasks, b->stream);  // RRBS: runs of tasks over one window, scanned together
-                        else bsx_launch_hscan(A, q.H, n_tasks, b->stream);
-                        HIP_TRY(hipGetLastError());
-                        HIP_TRY(hipEventRecord(b->scan_ev[b->scan_ev_used + 1], b->stream));
-                        b->scan_ev_used += 2;
-                        HIP_TRY(hipEventRecord(b->ev_scan[g], b->stream));
-                        q.scan_pending = true;
-                    }
-                    int rc = launch_ctrl(g);
-                    if (rc) return rc;
+                    const uint32_t slot = q.polled % BSX_POLL_SLOTS;
+                    HIP_TRY(hipEventSynchronize(b->grp[g].ev_poll[slot]));
+                    const uint32_t n_act = pinned[32 + 16 * g + 2 * slot], n_tasks = pinned[32 + 16 * g + 2 * slot + 1];
+                    q.polled++;
+                    if (b->trace) fprintf(stderr, "[bsx heavy] paired %d base %u group %d passes %u active %u tasks %u\n", b->paired, base, g, q.polled * b->chunk_passes, n_act, n_tasks);
+                    if (n_act == 0) { q.done = true; n_open--; }  // (passes already queued for this group find no active unit)
+                    else if (q.passes > 200000) { g_bsx_err = "heavy pipeline did not converge"; return BSX_ERR_DEVICE; }
                 }
-                if (!any) break;
+                if (n_open > 0) { int rc = enqueue_chunk(); if (rc) return rc; }
             }
-            HIP_TRY(hipEventRecord(b->ev_sync, b->stream_hi));            // the main stream continues behind the last control pass
-            HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_sync, 0));
-        }
-        if (share_stats) {
-            fprintf(stderr, "share_stats: %llu of %llu scan tasks repeat their neighbour's window (%llu with the same read offset, inside one sub-range); runs by log2(length):", (unsigned long long)share_same, (unsigned long long)share_total, (unsigned long long)share_same_h);
-            for (int i = 0; i < 16; i++) fprintf(stderr, " %llu", (unsigned long long)share_hist[i]);
-            fprintf(stderr, "\n");
+            for (int g = 0; g < n_groups; g++) {   // the main stream continues behind the last control pass of every group
+                if (G[g].passes == 0) continue;
+                HIP_TRY(hipEventRecord(b->grp[g].ev_ctrl, b->grp[g].s_ctrl));
+                HIP_TRY(hipStreamWaitEvent(b->stream, b->grp[g].ev_ctrl, 0));
+            }
         }
     }
     if (A.heavy_threshold && b->last_heavy) {

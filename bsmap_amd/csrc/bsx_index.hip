@@ -237,19 +237,3 @@ int bsx_index_build_rrbs(bsx_ref *r, const std::vector<uint32_t> &refcat, const 
     r->has_index = true;
     return BSX_OK;
 }
-
-
-// (key, id) pairs of the heavy pipeline's scan tasks, sorted by key (see bsx_api.hip); library primitive, as in the index build
-int bsx_sort_pairs_u32(void **temp, size_t *temp_bytes, const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *vals_in, uint32_t *vals_out, uint32_t n, hipStream_t stream)
-{
-    size_t need = 0;
-    HIP_TRY(rocprim::radix_sort_pairs(nullptr, need, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u, 32u, stream));
-    if (need > *temp_bytes) {
-        if (*temp) (void)hipFree(*temp);
-        *temp = nullptr; *temp_bytes = 0;
-        HIP_TRY(hipMalloc(temp, need * 2));
-        *temp_bytes = need * 2;
-    }
-    HIP_TRY(rocprim::radix_sort_pairs(*temp, need, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u, 32u, stream));
-    return BSX_OK;
-}

@@ -59,13 +59,14 @@ void bsx_launch_align(const AlignArgs &A, int paired, int grid_blocks, hipStream
 void bsx_launch_leak(const AlignArgs &A, int paired, int grid_blocks, hipStream_t stream);
 size_t bsx_leakrec_bytes(void);
 void bsx_launch_hctrl(const AlignArgs &A, const HeavyArgsRaw &H, int paired, int grid_blocks, hipStream_t stream);
-void bsx_launch_hscan(const AlignArgs &A, const HeavyArgsRaw &H, uint32_t n_tasks, hipStream_t stream);
-void bsx_launch_task_sig(const HeavyArgsRaw &H, uint32_t n_tasks, uint32_t *sig, hipStream_t stream);  // diagnostic
-void bsx_launch_hscan_shared(const AlignArgs &A, const HeavyArgsRaw &H, uint32_t n_tasks, hipStream_t stream);  // RRBS: up to 16 tasks of one window per wave
-void bsx_launch_task_keys(const HeavyArgsRaw &H, uint32_t n_tasks, uint32_t *keys, uint32_t *ids, hipStream_t stream);
-// bsx_index.hip: stable radix sort of (key, id) pairs (rocPRIM); temp grows on demand
-int bsx_sort_pairs_u32(void **temp, size_t *temp_bytes, const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *vals_in, uint32_t *vals_out, uint32_t n, hipStream_t stream);
+void bsx_launch_hscan(const AlignArgs &A, const HeavyArgsRaw &H, hipStream_t stream);         // grid sized for H.task_cap; the count stays on the device
+void bsx_launch_hscan_shared(const AlignArgs &A, const HeavyArgsRaw &H, hipStream_t stream);  // RRBS: up to 16 tasks of one window per wave
+// scan order of a pass (task ids by the index entry they start at, 2^shift entries per bin), computed on the device
+uint32_t bsx_bin_chunks(uint32_t n_bins);
+void bsx_launch_task_order(const HeavyArgsRaw &H, uint32_t shift, uint32_t n_bins, uint32_t *bins, uint32_t *bstart, uint32_t *chunk_tot, uint32_t *rank, uint32_t *order,
+                           uint32_t *zero_blk, hipStream_t stream);
 size_t bsx_hstate_bytes(void);
 size_t bsx_htask_bytes(void);
 size_t bsx_htaskout_bytes(void);
 int bsx_align_occupancy(int paired);
+int bsx_hctrl_occupancy(int paired);  // resident blocks of the control kernel per CU

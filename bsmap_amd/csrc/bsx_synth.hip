@@ -62,7 +62,10 @@ __host__ __device__ inline int synth_base(u64 seed, uint32_t c, uint32_t p, uint
     if (p < g.tel || p >= len - g.tel || (p >= g.cen_begin && p < g.cen_end)) return 4;
     const uint32_t win = p >> 9, in = p & 511;
     const u64 wh = h3(seed, ((u64)c << 32) | win, 0x57494E);
-    const uint32_t sel = (uint32_t)(wh % 1000);
+    // bits 56-63 of the seed select a variant of the repeat content (bench.py's sensitivity leg): 0 as described above, 1 half the
+    // microsatellite windows, 2 no repeat elements at all.  Everything else — and every genome made with a seed below 2^56 — is unchanged.
+    const uint32_t variant = (uint32_t)(seed >> 56);
+    const uint32_t sel = variant == 2 ? 1000u : (uint32_t)(wh % 1000);
     if (sel < 182) {  // Alu-like
         const uint32_t off = (uint32_t)((wh >> 12) % (512 - 300));
         if (in >= off && in < off + 300) {
@@ -88,7 +91,7 @@ __host__ __device__ inline int synth_base(u64 seed, uint32_t c, uint32_t p, uint
             if (u01_24(mh) < (uint32_t)(0.10 * 16777216.0)) b = mutate_base(b, mh);
             return b;
         }
-    } else if (sel < 455) {  // microsatellite
+    } else if (sel < (variant == 1 ? 360u : 455u)) {  // microsatellite
         const uint32_t mlen = 20 + (uint32_t)((wh >> 12) % 121), off = (uint32_t)((wh >> 24) % (513 - mlen));
         if (in >= off && in < off + mlen) {
             const uint32_t kind = (uint32_t)((wh >> 36) % 6), k = in - off;

@@ -143,8 +143,9 @@ typedef struct bsx_pair {
  * algorithm touches), 3 n_orient, 4 reads/pairs processed, 5 aligned reads (n_aligned semantics), 6 aligned pairs,
  * 7 candidates evaluated by the scan kernel of the heavy pipeline (k_hscan; a subset of 1 plus the little it evaluates
  * speculatively), 8 their reference words (as 2), 9 / 10 how many of them stopped after the first word / went through all
- * five, 11 spare */
-#define BSX_N_COUNTERS 12
+ * five, 11-14 the share of 0-3 that the main kernel (k_align) did itself — units it did not hand to the heavy pipeline —, so
+ * that each kernel's algorithmic bytes can be recomputed from the counters, 15 spare */
+#define BSX_N_COUNTERS 16
 
 int bsx_batch_create(bsx_ref *r, uint32_t max_units, int paired, bsx_batch **out);
 void bsx_batch_destroy(bsx_batch *b);

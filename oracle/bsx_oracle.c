@@ -1152,32 +1152,83 @@ int bso_pe_align(bso_aligner *sa, bso_aligner *sb, uint32_t index, const char *s
 /* ------------------------------------------------------------------------------------------------
  * batch helpers (threading model of main.cpp:49-73: workers pull fixed-size chunks of reads)
  * ---------------------------------------------------------------------------------------------- */
+typedef struct { uint8_t filtered, len; } read_meta;
 typedef struct {
     const bso_params *p; const bso_ref *r; uint32_t n; const char *sa; const uint64_t *oa; const char *qa;
     const char *sb; const uint64_t *ob; const char *qb; uint32_t first; void *res; int pe;
     volatile uint32_t *next; uint32_t chunk; uint64_t cnt[4];
+    /* leak_mode 1 ("-p 1 exact"): the reference's planner state (align.h:82-91) runs through the whole input in order.  The
+     * batch driver still works in parallel chunks: before a chunk, its worker re-establishes the state the sequential run has
+     * at the chunk's first read by replaying the PLANNER ONLY (FilterReads, ConvertBinaySeq, ReorderSeed - no SnpAlign) from a
+     * read that overwrites everything earlier reads left behind: the nearest unfiltered read before the chunk that sets the
+     * start offset ((len - I + 1) % S != 0) and is as long as any unfiltered read before the chunk (entries beyond its last hash
+     * were then never written: zero, as in a fresh object).  meta[mate][i] = FilterReads' verdict and trimmed length of read i,
+     * pmax[mate][i] = longest unfiltered read among reads [0, i).  tests/test_oracle_golden.py checks this driver against one
+     * aligner object fed in order. */
+    int leak_mode; const read_meta *meta[2]; const uint8_t *pmax[2];
 } batch_job;
 /* units per grab: fine enough that every thread gets work even on a bounded sample (the reference's threads grab 50 000
  * reads at a time, main.cpp:49-73 — far coarser) */
 
+static void plan_only(bso_aligner *a, uint32_t index, int readset, const char *seq, const char *qual)
+{
+    set_read(a, index, readset, seq, qual);
+    if (filter_reads(a)) return;              /* RunAlign is not called for a rejected read: state untouched (align.cpp:598) */
+    prepare_align(a);
+    convert_binary_seq(a);
+    a->snp_thres = (uint32_t)a->read_max_snp_num;
+    a->cseed_offset = (uint32_t)a->len % a->P->seed_size;
+    reorder_seed(a);
+}
+
+static void fetch_read(const char *s, const uint64_t *o, const char *q, uint32_t i, char *sbuf, char *qbuf)
+{
+    uint64_t l = o[i + 1] - o[i]; if (l > FIXSIZE) l = FIXSIZE;
+    memcpy(sbuf, s + o[i], l); sbuf[l] = 0;
+    if (q) { memcpy(qbuf, q + o[i], l); qbuf[l] = 0; }
+}
+
+/* first read of the planner-only replay that gives mate stream m its sequential state at read lo */
+static uint32_t replay_start(const batch_job *jb, int m, uint32_t lo)
+{
+    const int S = jb->p->seed_size, I = jb->p->index_interval;
+    const uint8_t top = jb->pmax[m][lo];
+    if (top == 0) return lo;                  /* no unfiltered read before lo: the state is still the initial one */
+    for (uint32_t i = lo; i-- > 0;) {
+        const read_meta t = jb->meta[m][i];
+        if (!t.filtered && t.len == top && (t.len - I + 1) % S != 0) return i;
+    }
+    return 0;                                 /* the longest reads never set the offset: replay the whole prefix */
+}
+
 static void *batch_worker(void *arg)
 {
     batch_job *jb = arg;
-    bso_aligner *a = bso_aligner_new(jb->p, jb->r, 0), *b = jb->pe ? bso_aligner_new(jb->p, jb->r, 0) : NULL;
+    bso_aligner *a = bso_aligner_new(jb->p, jb->r, jb->leak_mode), *b = jb->pe ? bso_aligner_new(jb->p, jb->r, jb->leak_mode) : NULL;
     char s1[FIXSIZE + 64], q1[FIXSIZE + 64], s2[FIXSIZE + 64], q2[FIXSIZE + 64];
     while (1) {
         uint32_t lo = __sync_fetch_and_add(jb->next, jb->chunk);
         if (lo >= jb->n) break;
         uint32_t hi = lo + jb->chunk < jb->n ? lo + jb->chunk : jb->n;
+        if (jb->leak_mode) {
+            bso_aligner *al[2] = {a, b};
+            for (int m = 0; m < (jb->pe ? 2 : 1); m++) {
+                bso_aligner *x = al[m];
+                const uint64_t keep[4] = {x->n_lookup, x->n_cand, x->sum_w, x->n_orient};
+                x->seed_start_offset = x->cseed_start_offset = 0;
+                memset(x->seed_array, 0, sizeof(x->seed_array)); memset(x->cseed_array, 0, sizeof(x->cseed_array));
+                for (uint32_t i = replay_start(jb, m, lo); i < lo; i++) {
+                    fetch_read(m ? jb->sb : jb->sa, m ? jb->ob : jb->oa, m ? jb->qb : jb->qa, i, s1, q1);
+                    plan_only(x, jb->first + i, jb->pe ? m + 1 : 0, s1, (m ? jb->qb : jb->qa) ? q1 : NULL);
+                }
+                x->n_lookup = keep[0]; x->n_cand = keep[1]; x->sum_w = keep[2]; x->n_orient = keep[3];
+            }
+        }
         for (uint32_t i = lo; i < hi; i++) {
-            uint64_t l = jb->oa[i + 1] - jb->oa[i]; if (l > FIXSIZE) l = FIXSIZE;
-            memcpy(s1, jb->sa + jb->oa[i], l); s1[l] = 0;
-            if (jb->qa) { memcpy(q1, jb->qa + jb->oa[i], l); q1[l] = 0; }
+            fetch_read(jb->sa, jb->oa, jb->qa, i, s1, q1);
             if (!jb->pe) bso_se_align(a, jb->first + i, 0, s1, jb->qa ? q1 : NULL, &((bso_read_result *)jb->res)[i]);
             else {
-                uint64_t l2 = jb->ob[i + 1] - jb->ob[i]; if (l2 > FIXSIZE) l2 = FIXSIZE;
-                memcpy(s2, jb->sb + jb->ob[i], l2); s2[l2] = 0;
-                if (jb->qb) { memcpy(q2, jb->qb + jb->ob[i], l2); q2[l2] = 0; }
+                fetch_read(jb->sb, jb->ob, jb->qb, i, s2, q2);
                 bso_pe_align(a, b, jb->first + i, s1, jb->qa ? q1 : NULL, s2, jb->qb ? q2 : NULL, &((bso_pair_result *)jb->res)[i]);
             }
         }
@@ -1195,6 +1246,26 @@ static int run_batch(batch_job *proto, int n_threads, uint64_t counters[4])
     volatile uint32_t next = 0;
     uint32_t chunk = proto->n / ((uint32_t)n_threads * 8u);
     proto->chunk = chunk < 16 ? 16 : chunk > 2048 ? 2048 : chunk;
+    read_meta *meta[2] = {NULL, NULL}; uint8_t *pmax[2] = {NULL, NULL};
+    if (proto->leak_mode) {   /* FilterReads' verdict and trimmed length of every read (no index access: cheap, sequential) */
+        bso_aligner *t = bso_aligner_new(proto->p, proto->r, 0);
+        char s[FIXSIZE + 64], q[FIXSIZE + 64];
+        for (int m = 0; m < (proto->pe ? 2 : 1); m++) {
+            meta[m] = calloc((size_t)proto->n + 1, sizeof(read_meta)); pmax[m] = calloc((size_t)proto->n + 1, 1);
+            const char *sq = m ? proto->sb : proto->sa, *ql = m ? proto->qb : proto->qa; const uint64_t *of = m ? proto->ob : proto->oa;
+            uint8_t top = 0;
+            for (uint32_t i = 0; i < proto->n; i++) {
+                pmax[m][i] = top;
+                fetch_read(sq, of, ql, i, s, q);
+                set_read(t, proto->first + i, proto->pe ? m + 1 : 0, s, ql ? q : NULL);
+                meta[m][i].filtered = (uint8_t)filter_reads(t); meta[m][i].len = (uint8_t)t->len;
+                if (!meta[m][i].filtered && meta[m][i].len > top) top = meta[m][i].len;
+            }
+            pmax[m][proto->n] = top;
+            proto->meta[m] = meta[m]; proto->pmax[m] = pmax[m];
+        }
+        bso_aligner_free(t);
+    }
     batch_job *jobs = calloc(n_threads, sizeof(batch_job));
     pthread_t *th = calloc(n_threads, sizeof(pthread_t));
     for (int t = 0; t < n_threads; t++) { jobs[t] = *proto; jobs[t].next = &next; }
@@ -1203,22 +1274,34 @@ static int run_batch(batch_job *proto, int n_threads, uint64_t counters[4])
     for (int t = 1; t < n_threads; t++) pthread_join(th[t], NULL);
     if (counters) { memset(counters, 0, 32); for (int t = 0; t < n_threads; t++) for (int k = 0; k < 4; k++) counters[k] += jobs[t].cnt[k]; }
     free(jobs); free(th);
+    for (int m = 0; m < 2; m++) { free(meta[m]); free(pmax[m]); }
     return 0;
 }
 
+int bso_se_batch_leak(const bso_params *p, const bso_ref *r, uint32_t n_reads, const char *seqs, const uint64_t *off,
+                      const char *quals, uint32_t first_index, int n_threads, int leak_mode, bso_read_result *results, uint64_t counters[4])
+{
+    batch_job j; memset(&j, 0, sizeof(j));
+    j.p = p; j.r = r; j.n = n_reads; j.sa = seqs; j.oa = off; j.qa = quals; j.first = first_index; j.res = results; j.pe = 0; j.leak_mode = leak_mode;
+    return run_batch(&j, n_threads, counters);
+}
+int bso_pe_batch_leak(const bso_params *p, const bso_ref *r, uint32_t n_pairs, const char *seqs_a, const uint64_t *off_a,
+                      const char *quals_a, const char *seqs_b, const uint64_t *off_b, const char *quals_b,
+                      uint32_t first_index, int n_threads, int leak_mode, bso_pair_result *results, uint64_t counters[4])
+{
+    batch_job j; memset(&j, 0, sizeof(j));
+    j.p = p; j.r = r; j.n = n_pairs; j.sa = seqs_a; j.oa = off_a; j.qa = quals_a; j.sb = seqs_b; j.ob = off_b; j.qb = quals_b;
+    j.first = first_index; j.res = results; j.pe = 1; j.leak_mode = leak_mode;
+    return run_batch(&j, n_threads, counters);
+}
 int bso_se_batch(const bso_params *p, const bso_ref *r, uint32_t n_reads, const char *seqs, const uint64_t *off,
                  const char *quals, uint32_t first_index, int n_threads, bso_read_result *results, uint64_t counters[4])
 {
-    batch_job j; memset(&j, 0, sizeof(j));
-    j.p = p; j.r = r; j.n = n_reads; j.sa = seqs; j.oa = off; j.qa = quals; j.first = first_index; j.res = results; j.pe = 0;
-    return run_batch(&j, n_threads, counters);
+    return bso_se_batch_leak(p, r, n_reads, seqs, off, quals, first_index, n_threads, 0, results, counters);
 }
 int bso_pe_batch(const bso_params *p, const bso_ref *r, uint32_t n_pairs, const char *seqs_a, const uint64_t *off_a,
                  const char *quals_a, const char *seqs_b, const uint64_t *off_b, const char *quals_b,
                  uint32_t first_index, int n_threads, bso_pair_result *results, uint64_t counters[4])
 {
-    batch_job j; memset(&j, 0, sizeof(j));
-    j.p = p; j.r = r; j.n = n_pairs; j.sa = seqs_a; j.oa = off_a; j.qa = quals_a; j.sb = seqs_b; j.ob = off_b; j.qb = quals_b;
-    j.first = first_index; j.res = results; j.pe = 1;
-    return run_batch(&j, n_threads, counters);
+    return bso_pe_batch_leak(p, r, n_pairs, seqs_a, off_a, quals_a, seqs_b, off_b, quals_b, first_index, n_threads, 0, results, counters);
 }

@@ -135,6 +135,15 @@ int bso_pe_batch(const bso_params *p, const bso_ref *r, uint32_t n_pairs, const 
                  const uint64_t *off_a, const char *quals_a, const char *seqs_b, const uint64_t *off_b,
                  const char *quals_b, uint32_t first_index, int n_threads, bso_pair_result *results,
                  uint64_t counters[4]);
+/* the same with the aligner objects in leak_mode (1: planner state runs through the input in order, as with `bsmap -p 1`;
+ * the chunks re-establish it by a planner-only replay, see batch_job in bsx_oracle.c) */
+int bso_se_batch_leak(const bso_params *p, const bso_ref *r, uint32_t n_reads, const char *seqs,
+                      const uint64_t *off, const char *quals, uint32_t first_index, int n_threads, int leak_mode,
+                      bso_read_result *results, uint64_t counters[4]);
+int bso_pe_batch_leak(const bso_params *p, const bso_ref *r, uint32_t n_pairs, const char *seqs_a,
+                      const uint64_t *off_a, const char *quals_a, const char *seqs_b, const uint64_t *off_b,
+                      const char *quals_b, uint32_t first_index, int n_threads, int leak_mode,
+                      bso_pair_result *results, uint64_t counters[4]);
 #ifdef __cplusplus
 }
 #endif

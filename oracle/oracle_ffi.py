@@ -115,10 +115,10 @@ def lib():
         L.bso_counters.argtypes = [C.c_void_p] + [C.POINTER(C.c_uint64)] * 4
         L.bso_myrand.argtypes = [C.POINTER(Params), C.c_uint32, C.POINTER(C.c_uint32)]
         L.bso_myrand.restype = C.c_uint32
-        L.bso_se_batch.argtypes = [C.POINTER(Params), C.POINTER(Ref), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
-                                   C.c_uint32, C.c_int, C.c_void_p, C.POINTER(C.c_uint64)]
-        L.bso_pe_batch.argtypes = [C.POINTER(Params), C.POINTER(Ref), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
-                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.POINTER(C.c_uint64)]
+        L.bso_se_batch_leak.argtypes = [C.POINTER(Params), C.POINTER(Ref), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_uint64)]
+        L.bso_pe_batch_leak.argtypes = [C.POINTER(Params), C.POINTER(Ref), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_uint64)]
         _lib = L
     return _lib
 
@@ -259,22 +259,23 @@ def pack_reads(seqs):
     return buf, off
 
 
-def se_batch(oref, seqs_buf, off, quals_buf=None, first_index=0, threads=1):
+def se_batch(oref, seqs_buf, off, quals_buf=None, first_index=0, threads=1, leak_mode=0):
+    """leak_mode 1: the planner state runs through the reads in input order (`bsmap -p 1`), whatever the thread count"""
     L = lib()
     n = len(off) - 1
     res = np.zeros(n, dtype=READ_RESULT_DTYPE)
     cnt = (C.c_uint64 * 4)()
-    L.bso_se_batch(C.byref(oref.params), oref.ptr, n, seqs_buf.ctypes.data, off.ctypes.data,
-                   quals_buf.ctypes.data if quals_buf is not None else None, first_index, threads, res.ctypes.data, cnt)
+    L.bso_se_batch_leak(C.byref(oref.params), oref.ptr, n, seqs_buf.ctypes.data, off.ctypes.data,
+                        quals_buf.ctypes.data if quals_buf is not None else None, first_index, threads, leak_mode, res.ctypes.data, cnt)
     return res, list(cnt)
 
 
-def pe_batch(oref, sa, oa, sb, ob, qa=None, qb=None, first_index=0, threads=1):
+def pe_batch(oref, sa, oa, sb, ob, qa=None, qb=None, first_index=0, threads=1, leak_mode=0):
     L = lib()
     n = len(oa) - 1
     res = np.zeros(n, dtype=PAIR_RESULT_DTYPE)
     cnt = (C.c_uint64 * 4)()
-    L.bso_pe_batch(C.byref(oref.params), oref.ptr, n, sa.ctypes.data, oa.ctypes.data, qa.ctypes.data if qa is not None else None,
-                   sb.ctypes.data, ob.ctypes.data, qb.ctypes.data if qb is not None else None, first_index, threads,
-                   res.ctypes.data, cnt)
+    L.bso_pe_batch_leak(C.byref(oref.params), oref.ptr, n, sa.ctypes.data, oa.ctypes.data, qa.ctypes.data if qa is not None else None,
+                        sb.ctypes.data, ob.ctypes.data, qb.ctypes.data if qb is not None else None, first_index, threads, leak_mode,
+                        res.ctypes.data, cnt)
     return res, list(cnt)

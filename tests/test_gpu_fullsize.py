@@ -1,8 +1,9 @@
 """BASELINE-sized checks (hg38-sized synthetic genome, 3.09 Gbp, 1.48 G index entries; the bench workload).
-The oracle cannot chew the whole batch in test time, so parity at this size is shown through size-independent
-properties plus an oracle comparison on a sample:
-  * a sample of units (including the heaviest ones) equals the oracle run against the SAME reference + index copied
-    back from HBM — picks, class counts, pair lists' sizes;
+Parity at this size:
+  * WHOLE batches (131 072 units of C2 / C3, 65 536 of C2 -n 1 / C4 / C5) re-aligned by the oracle's batch driver on the host
+    cores against the SAME reference + index copied back from HBM (RRBS: the oracle's own build from the text): every
+    record field and the four work counters; C5 also in exact mode against the oracle's `-p 1` state;
+    a summary goes to gpurun_out/validate/r03_validate_<cfg>.json (copied into profiles/);
   * idempotence: the same batch twice gives byte-identical records and counters;
   * partition invariance: aligning in two halves equals aligning the whole batch;
   * path invariance: results do not depend on which units go through the heavy pipeline (default threshold vs none);
@@ -69,33 +70,21 @@ def test_heavy_path_invariance(big):
     assert o2[:2048].tobytes() == out[:2048].tobytes() and a2[:2048].tobytes() == ca[:2048].tobytes() and n2[:2048].tobytes() == npairs[:2048].tobytes()
 
 
-def test_sample_equals_oracle_on_the_same_index(big, oracle):
+def test_whole_batch_equals_oracle_c3(big, oracle):
+    """every unit of the batch re-aligned by the oracle's batch driver against the same reference + index (copied back from
+    HBM): every record field and the four work counters (the roofline numerator)"""
+    import wholebatch as W
     ref, pa, out, ca, cb, npairs, cnt = big
     f, c = ref.words()
     a, s, r = ref.info()
     off, nf, ent = ref.index()
     oref = oracle.OracleRef.wrap(oracle.make_params(**KW), f, c, a, s, r, off, nf, ent)
-    b1, o1 = pa.download_reads(0)
-    b2, o2 = pa.download_reads(1)
-    # first 1500 units + the 60 units with the most hits (the heavy tail)
-    load = ca["n_hit"].sum(1).astype(np.int64) + cb["n_chit"].sum(1) + ca["n_chit"].sum(1) + cb["n_hit"].sum(1)
-    sample = np.unique(np.concatenate([np.arange(1500), np.argsort(load)[-60:]]))
-    L = 144
-    s1 = np.concatenate([b1[int(o1[i]):int(o1[i + 1])] for i in sample])
-    s2 = np.concatenate([b2[int(o2[i]):int(o2[i + 1])] for i in sample])
-    oo = (np.arange(len(sample) + 1) * L).astype(np.uint64)
-    al = oracle.OracleAligner(oref, 0)
-    for k, u in enumerate(sample):
-        o = al.pe(int(u), bytes(b1[int(o1[u]):int(o1[u + 1])]).decode(), bytes(b2[int(o2[u]):int(o2[u + 1])]).decode())
-        g = out[u]
-        assert o.paired == g["paired"] and list(o.n_pairs)[:13] == list(npairs[u][:13]), u
-        assert list(o.a.n_hit)[:7] == list(ca[u]["n_hit"][:7]) and list(o.b.n_chit)[:7] == list(cb[u]["n_chit"][:7]), u
-        if o.paired and o.tmp == 0:
-            pk = o.pick
-            assert (pk.a.chr, pk.a.loc, pk.b.chr, pk.b.loc, pk.insert, pk.na, pk.nb) == \
-                   (g["a_chr"], g["a_loc"], g["b_chr"], g["b_loc"], g["insert"], g["na"], g["nb"]), u
-    al.free()
-    assert s1.size == s2.size == len(sample) * L and oo[-1] == s1.size
+    ores, ocnt, t_cpu = W.run_oracle(oracle, oref, pa, True, False, N)
+    bad, info = W.compare_pe(ores, out, ca, cb, npairs, KW["v"] + 1)
+    W.record("c3", dict(info, units=N, oracle_s=round(t_cpu, 1), counters_gpu=[int(x) for x in cnt[:4]], counters_oracle=ocnt, mismatching_fields=bad,
+                        options=KW, heavy_units=int(pa.heavy_units())))
+    assert not bad, bad
+    assert [int(x) for x in cnt[:4]] == ocnt
 
 
 def test_pair_geometry(big):
@@ -191,12 +180,9 @@ def test_other_configs_closure_idempotence_partition(other):
         assert (hits["n_best"] > 0).mean() > (0.85 if name != "c4" else 0.8)
 
 
-def test_other_configs_sample_equals_oracle(other, oracle):
-    """a sample of units incl. the ones with the most hits, re-aligned by the oracle — WGBS: against the reference + index
-    copied back from HBM; RRBS: against the oracle's OWN packing, site tables and index of the genome text"""
-    name, cfg, ref, al, res, cnt = other
-    kw, n, L = cfg["kw"], cfg["n"], cfg["L"]
-    if name == "c4":
+def _oracle_ref(name, cfg, ref, oracle):
+    kw = cfg["kw"]
+    if name == "c4":   # RRBS: the oracle's OWN packing, site tables and index of the genome text
         parts = []
         for c, nm in enumerate(ref.names()):
             parts += [np.frombuffer(f">{nm}\n".encode(), np.uint8), ref.synth_bytes(c), np.frombuffer(b"\n", np.uint8)]
@@ -207,49 +193,54 @@ def test_other_configs_sample_equals_oracle(other, oracle):
         assert sum(len(oref.sites(c)) for c in range(ref.n_chr)) == sum(len(ref.sites(c)) for c in range(ref.n_chr))
         assert np.array_equal(oref.sites(3), ref.sites(3))
         assert np.array_equal(oref.rrbs_entries(), ref.index()[2])
-    else:
-        f, c = ref.words()
-        a, s, r = ref.info()
-        off, nf, ent = ref.index()
-        oref = oracle.OracleRef.wrap(oracle.make_params(**kw), f, c, a, s, r, off, nf, ent)
-    b1, o1 = al.download_reads(0)
-    q1 = al.download_quals(0) if cfg["kind"] == 1 else None
-    if cfg["pe"]:
-        b2, o2 = al.download_reads(1)
-        q2 = al.download_quals(1) if cfg["kind"] == 1 else None
-        out, ca, cb, npairs = res
-        load = ca["n_hit"].sum(1).astype(np.int64) + cb["n_chit"].sum(1) + ca["n_chit"].sum(1) + cb["n_hit"].sum(1)
-    else:
-        hits, cc = res
-        load = cc["n_hit"].sum(1).astype(np.int64) + cc["n_chit"].sum(1)
-    sample = np.unique(np.concatenate([np.arange(1000), np.argsort(load)[-40:]]))
-    oa = oracle.OracleAligner(oref, 0)
-    nv = kw.get("v", 2) + 1
+        return oref
+    f, c = ref.words()
+    a, s, r = ref.info()
+    off, nf, ent = ref.index()
+    return oracle.OracleRef.wrap(oracle.make_params(**kw), f, c, a, s, r, off, nf, ent)
 
-    def txt(buf, off_, u):
-        return bytes(buf[int(off_[u]):int(off_[u + 1])]).decode()
 
-    for u in sample:
-        u = int(u)
+def test_other_configs_whole_batch_equals_oracle(other, oracle):
+    """every unit of the batch re-aligned by the oracle's batch driver — WGBS: against the reference + index copied back from
+    HBM; RRBS: against the oracle's own build from the 3.1 GB text — every record field and the four work counters; C5 also in
+    exact mode (bsx_batch_set_leak_exact) against the oracle's `-p 1` state (leak_mode 1)"""
+    import wholebatch as W
+    name, cfg, ref, al, res, cnt = other
+    kw, n = cfg["kw"], cfg["n"]
+    nclass = kw.get("v", 2) + 1
+    quals = cfg["kind"] == 1
+    oref = _oracle_ref(name, cfg, ref, oracle)
+    try:
+        ores, ocnt, t_cpu = W.run_oracle(oracle, oref, al, cfg["pe"], quals, n)
         if cfg["pe"]:
-            o = oa.pe(u, txt(b1, o1, u), txt(b2, o2, u), txt(q1, o1, u) if q1 is not None else None, txt(q2, o2, u) if q2 is not None else None)
-            g = out[u]
-            assert (o.a.filtered, o.b.filtered) == (g["a"]["flags"] & 1, g["b"]["flags"] & 1), u
-            assert (o.a.len, o.b.len) == (g["a"]["len"], g["b"]["len"]), u
-            assert o.paired == g["paired"] and list(o.n_pairs)[:2 * nv - 1] == list(npairs[u][:2 * nv - 1]), u
-            assert list(o.a.n_hit)[:nv] == list(ca[u]["n_hit"][:nv]) and list(o.b.n_chit)[:nv] == list(cb[u]["n_chit"][:nv]), u
-            if o.paired and o.tmp == 0:
-                pk = o.pick
-                assert (pk.a.chr, pk.a.loc, pk.b.chr, pk.b.loc, pk.insert, pk.na, pk.nb) == \
-                       (g["a_chr"], g["a_loc"], g["b_chr"], g["b_loc"], g["insert"], g["na"], g["nb"]), u
+            bad, info = W.compare_pe(ores, res[0], res[1], res[2], res[3], nclass)
         else:
-            o = oa.se(u, txt(b1, o1, u))
-            g = hits[u]
-            assert o.filtered == (g["flags"] & 1) and o.len == g["len"], u
-            if not o.filtered:
-                assert list(o.n_hit)[:nv] == list(cc[u]["n_hit"][:nv]) and list(o.n_chit)[:nv] == list(cc[u]["n_chit"][:nv]), u
-                assert o.n_best == g["n_best"], u
-                if o.n_best > 0:
-                    assert (o.chr, o.loc, o.best_class) == (g["chr"], g["loc"], g["best_class"]), u
-    oa.free()
-    oref.free()
+            bad, info = W.compare_se(ores, res[0], res[1], nclass)
+        rec = dict(info, units=n, oracle_s=round(t_cpu, 1), counters_gpu=[int(x) for x in cnt[:4]], counters_oracle=ocnt, mismatching_fields=bad,
+                   options={k: v for k, v in kw.items()}, heavy_units=int(al.heavy_units()), redo_units=int(al.redo_units()))
+        if name == "c5":   # the only BASELINE config whose reads leak planner state ((len - I + 1) % S == 0 after trimming)
+            ex = B.PairAlign(ref, n).set_leak_exact()
+            try:
+                ex.synth_reads(n, cfg["L"], seed=17, kind=cfg["kind"])
+                ex.Do_Batch()
+                eres = ex.results()
+                ecnt = [int(x) for x in ex.counters()[:4]]
+            finally:
+                ex.close()
+            lres, lcnt, t_leak = W.run_oracle(oracle, oref, al, True, True, n, leak_mode=1)
+            ebad, _ = W.compare_pe(lres, eres[0], eres[1], eres[2], eres[3], nclass)
+            S, I = kw["s"], kw["I"]
+            leaky = sum(int((((lres[m]["len"] - I + 1) % S == 0) & (lres[m]["filtered"] == 0)).sum()) for m in ("a", "b"))
+            differ = int((eres[0].tobytes() != res[0].tobytes()))
+            rec["exact_mode"] = dict(oracle_s=round(t_leak, 1), counters_gpu=ecnt, counters_oracle=lcnt, mismatching_fields=ebad, leaky_reads=leaky,
+                                     records_differ_from_default_mode=bool(differ))
+            W.record(name, rec)
+            assert leaky > n // 50
+            assert not ebad, ebad
+            assert ecnt == lcnt
+        else:
+            W.record(name, rec)
+        assert not bad, bad
+        assert [int(x) for x in cnt[:4]] == ocnt
+    finally:
+        oref.free()
