@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("BSX_LIB") or os.path.join(HERE, "libbsx.so")  # BSX_L
 CSRC = os.path.join(HERE, "csrc")
 
 BSX_N_COUNTERS = 16
+LEAK_STATE_BYTES = 2576
 F_FILTERED, F_CHAIN = 1, 2
 
 
@@ -63,7 +64,7 @@ EXPORTS = [
     "bsx_ref_n_chr", "bsx_ref_n_words", "bsx_ref_n_blocks", "bsx_ref_info", "bsx_ref_chr_name", "bsx_ref_blocks",
     "bsx_ref_download_words", "bsx_index_build", "bsx_index_n_entries", "bsx_index_download", "bsx_ref_n_sites", "bsx_ref_sites",
     "bsx_batch_create", "bsx_batch_destroy", "bsx_batch_upload_se", "bsx_batch_upload_pe", "bsx_batch_synth_reads", "bsx_batch_synth_reads_kind", "bsx_batch_download_quals",
-    "bsx_batch_run", "bsx_batch_run_range", "bsx_batch_sync", "bsx_batch_set_leak_exact", "bsx_batch_set_history", "bsx_batch_kernel_ms", "bsx_batch_scan_ms", "bsx_batch_results_se", "bsx_batch_results_pe",
+    "bsx_batch_run", "bsx_batch_run_range", "bsx_batch_sync", "bsx_batch_set_leak_exact", "bsx_batch_set_history", "bsx_batch_set_leak_state", "bsx_batch_get_leak_state", "bsx_batch_kernel_ms", "bsx_batch_scan_ms", "bsx_batch_results_se", "bsx_batch_results_pe",
     "bsx_batch_counters", "bsx_batch_reset_counters", "bsx_batch_download_reads", "bsx_batch_set_debug", "bsx_batch_unit_cycles", "bsx_batch_ctrl_clocks",
     "bsx_batch_debug_hits", "bsx_batch_debug_pairs", "bsx_batch_debug_plan", "bsx_set_waves_per_cu", "bsx_set_heavy_threshold", "bsx_set_heavy_limits", "bsx_batch_last_heavy_units", "bsx_batch_last_redo_units", "bsx_pinned_alloc", "bsx_pinned_free", "bsx_probe_memory", "bsx_thread_device",
     "bsx_meth_create", "bsx_meth_destroy", "bsx_meth_set_reference", "bsx_meth_add", "bsx_meth_combine_cpg", "bsx_meth_valid_mappings",
@@ -119,6 +120,8 @@ def lib():
         L.bsx_batch_sync.argtypes = [vp]
         L.bsx_batch_set_leak_exact.argtypes = [vp, i32]
         L.bsx_batch_set_history.argtypes = [vp, u32, vp, vp, vp, vp, vp, vp]
+        L.bsx_batch_set_leak_state.argtypes = [vp, vp, C.c_size_t]
+        L.bsx_batch_get_leak_state.argtypes = [vp, vp, C.c_size_t]
         L.bsx_batch_kernel_ms.argtypes = [vp]
         L.bsx_batch_kernel_ms.restype = C.c_float
         L.bsx_batch_results_se.argtypes = [vp, vp, vp]
@@ -320,6 +323,16 @@ class _Batch:
         p = lambda a: a.ctypes.data if a is not None else None
         _check(lib().bsx_batch_set_history(self.h, len(seqs_a), p(ba), p(oa), p(qa), p(bb), p(ob), p(qb)))
         return self
+    def get_leak_state(self):
+        """planner state behind the batch's last read (exact mode chaining, include/bsx.h)"""
+        st = np.zeros(LEAK_STATE_BYTES, np.uint8)
+        _check(lib().bsx_batch_get_leak_state(self.h, st.ctypes.data, st.size))
+        return st
+
+    def set_leak_state(self, st):
+        _check(lib().bsx_batch_set_leak_state(self.h, st.ctypes.data if st is not None else None, LEAK_STATE_BYTES if st is not None else 0))
+        return self
+
     def scan_ms(self):
         """(sum of the k_hscan launch durations of the last run in ms, number of launches)"""
         t, n = C.c_float(), C.c_uint32()

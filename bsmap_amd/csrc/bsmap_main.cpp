@@ -428,24 +428,7 @@ struct Slot {
     vector<Text> out, out_unpair;
     int stage = 0;  // 0 free, 1 parsed, 2 aligned, 3 formatted
     long batch = -1;  // ordinal of the batch the slot holds while stage != 0
-    // BSX_P1_EXACT: the reads that precede this batch in each mate stream (the tail of the previous batch), see Hist
-    struct Hist { string seq, qual; vector<uint64_t> off; } hist[2];
 };
-
-// the last reads of a batch, kept by the parser for the next batch's Slot::hist
-void keep_tail(const ReadSet &r, size_t n_reads, size_t keep, Slot::Hist &h)
-{
-    const size_t n = min(n_reads, keep), lo = n_reads - n;
-    h.seq.clear(); h.qual.clear(); h.off.assign(1, 0);
-    for (size_t i = lo; i < n_reads; i++) {
-        const size_t sl = r.soff[i + 1] - r.soff[i], ql = r.qoff[i + 1] - r.qoff[i];
-        h.seq.append(r.seq.data() + r.soff[i], sl);
-        string q(sl, 'I');
-        memcpy(&q[0], r.qual.data() + r.qoff[i], min(sl, ql));
-        h.qual += q;
-        h.off.push_back(h.seq.size());
-    }
-}
 
 struct Ring {
     const int NS;
@@ -618,13 +601,15 @@ int main(int argc, char **argv)
     const double t_map0 = now_s();
 
     // BSX_P1_EXACT=1: reproduce the single-threaded reference also for the reads whose planner state leaks from earlier
-    // reads (bsx_batch_set_leak_exact); every batch carries the last 64 reads of its predecessor as history
+    // reads (bsx_batch_set_leak_exact).  The state is handed from batch to batch as a value: batch k starts from the state
+    // behind the last read of batch k-1 (bsx_batch_get_leak_state -> set), whichever device batch or GPU ran that one — it depends on the
+    // reads only, so it is computed right after the upload and the alignment of consecutive batches still overlaps.
     const bool p1_exact = getenv("BSX_P1_EXACT") && atoi(getenv("BSX_P1_EXACT")) != 0;
     if (p1_exact) for (int g = 0; g < NG; g++) bsx_batch_set_leak_exact(batches[g], 1);
+    struct LeakChain { mutex mu; condition_variable cv; long have = -1; vector<unsigned char> state; } chain;  // state behind batch `have`
+    chain.state.assign(BSX_LEAK_STATE_BYTES, 0);
     thread t_parse([&] {
         long k = 0;
-        Slot::Hist prev[2];
-        prev[0].off.assign(1, 0); prev[1].off.assign(1, 0);
         for (;; k++) {
             ring.acquire(k, 0);
             const double t = now_s();
@@ -638,11 +623,6 @@ int main(int argc, char **argv)
             if (!n1) break;
             s.n = n1;
             s.total_after = ra.index - o.read_start + 1;
-            if (p1_exact) {
-                s.hist[0] = prev[0]; s.hist[1] = prev[1];
-                keep_tail(s.A, n1, 64, prev[0]);
-                if (pe) keep_tail(s.B, min(n1, n2), 64, prev[1]);
-            }
             if (pe && n1 != n2) {
                 // Mate files of unequal length.  The reference reads 50000 pairs per batch and stops at the first batch whose
                 // two counts differ (main.cpp:88-93): it maps the first floor(min(N1,N2)/50000)*50000 pairs.  The batches here
@@ -660,6 +640,15 @@ int main(int argc, char **argv)
         ring.finish(k);
     });
     mutex mu_busy;
+    auto chain_state = [&](bsx_batch *batch, long k) {   // exact mode, after the upload of batch k
+        vector<unsigned char> st(BSX_LEAK_STATE_BYTES);
+        { unique_lock<mutex> lk(chain.mu); chain.cv.wait(lk, [&] { return chain.have == k - 1; }); st = chain.state; }
+        int r = bsx_batch_set_leak_state(batch, st.data(), st.size());
+        if (!r) r = bsx_batch_get_leak_state(batch, st.data(), st.size());
+        if (r) die(r, "chaining the planner state");
+        { lock_guard<mutex> lk(chain.mu); chain.state = st; chain.have = k; }
+        chain.cv.notify_all();
+    };
     auto gpu_stage = [&](int g) {
         bsx_batch *batch = batches[g];
         for (long k = g; ring.acquire(k, 1); k += NG) {
@@ -668,16 +657,10 @@ int main(int argc, char **argv)
             Slot &s = ring.at(k);
             const uint32_t n = (uint32_t)s.n;
             int r;
-            if (p1_exact) {
-                const uint32_t nh = (uint32_t)s.hist[0].off.size() - 1;
-                const bool q = ra.format != 1 && (!pe || rb.format != 1);
-                r = bsx_batch_set_history(batch, nh, s.hist[0].seq.data(), s.hist[0].off.data(), q ? s.hist[0].qual.data() : nullptr,
-                                          pe ? s.hist[1].seq.data() : nullptr, pe ? s.hist[1].off.data() : nullptr, pe && q ? s.hist[1].qual.data() : nullptr);
-                if (r) die(r, "attaching the history");
-            }
             if (!pe) {
                 r = bsx_batch_upload_se(batch, n, s.A.seq.data(), s.A.soff.data(), ra.format != 1 ? s.A.upload_qual() : nullptr, s.A.first_index);
                 if (r) die(r, "uploading reads");
+                if (p1_exact) chain_state(batch, k);
                 t1 = now_s();
                 if ((r = bsx_batch_run(batch)) || (r = bsx_batch_sync(batch))) die(r, "aligning");
                 t2 = now_s();
@@ -688,6 +671,7 @@ int main(int argc, char **argv)
                 r = bsx_batch_upload_pe(batch, n, s.A.seq.data(), s.A.soff.data(), q ? s.A.upload_qual() : nullptr, s.B.seq.data(), s.B.soff.data(),
                                         q ? s.B.upload_qual() : nullptr, s.A.first_index);
                 if (r) die(r, "uploading reads");
+                if (p1_exact) chain_state(batch, k);
                 t1 = now_s();
                 if ((r = bsx_batch_run(batch)) || (r = bsx_batch_sync(batch))) die(r, "aligning");
                 t2 = now_s();

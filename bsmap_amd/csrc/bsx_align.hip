@@ -1147,50 +1147,192 @@ __device__ __forceinline__ UnitSlabs carve_slab(uint8_t *slab, uint32_t nclass, 
 // (len - I + 1) % S == 0 skips the loop that sets the offset (align.cpp:458-468) and plans with the value the last read of
 // its stream left behind, and its start offsets then reach seed_array entries behind its own last hash — values written by
 // earlier, longer reads.  Both are pure functions of the earlier reads of the stream (mate 1 and mate 2 are separate
-// streams: PairAlign owns two SingleAlign objects), so the wave that owns such a read walks back through the stream — units
-// of this batch, then the history the caller attached — until it has the offset of the last read that set one and every
-// tail entry it can reach; what nothing ever wrote is zero (the oracle's and the bridge's zero-initialised state).
+// streams: PairAlign owns two SingleAlign objects).  A stream here = the history the caller attached, then the units of the
+// batch; before its first read the state is the one the caller handed over (bsx_batch_set_leak_state) or zero (a fresh object —
+// the oracle's and the bridge's zero-initialised state).
+//   k_leak_meta    : FilterReads' verdict and trimmed length of every read of the stream (2 bytes each), and per block of
+//                    LEAK_BLK reads whether one of them sets the offset and the longest unfiltered one
+//   leak_find      : the last read before a position that sets the offset / that wrote seed_array entry e — a backward search over
+//                    those 2-byte records, 64 per step, skipping whole blocks by their summaries: a few steps whatever the input
+//                    (a run of a million reads that never set the offset costs each of them ~20 steps, not a walk over all of them)
+//   k_leak_resolve : per leaky read, the offset of the read leak_find names (planned once more: bucket sizes, first minimum) and
+//                    the tail entries from the reads that wrote them -> LeakRec for the align kernels
+//   k_leak_final   : the state behind the stream's last read (bsx_batch_get_leak_state: the next batch starts from it)
+#define LEAK_BLK 4096
+__device__ void init_block_lds(const DevParams &P, BlockLds &BL, int tid, int nthreads);
+#define LEAK_KEYS 160
+struct LeakState { uint32_t key[2][2][LEAK_KEYS]; uint32_t so[2][2]; };  // [mate][orientation]
+
 template <bool PE>
-__device__ void resolve_leak(const AlignArgs &A, const BlockLds &BL, MateLds &LS, MateLds &L, const Mate &M, int mate, uint32_t unit, int lane)
+__global__ __launch_bounds__(256) void k_leak_meta(AlignArgs A)
+{
+    __shared__ MateLds LM[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const DevParams &P = A.P;
+    const uint32_t n_stream = A.n_hist + A.n_units_all;
+    for (uint32_t pos = blockIdx.x * 4 + wv; pos < n_stream; pos += gridDim.x * 4) {
+        for (int mate = 0; mate < (PE ? 2 : 1); mate++) {
+            Mate M;
+            M.u = lds_mate(&LM[wv].u);
+            M.u->index = 0;
+            load_and_filter(A, LM[wv], M, mate, (long)pos - (long)A.n_hist, lane);
+            const int len = M.u->len;
+            const bool ok = !M.u->filtered;
+            if (lane == 0) {
+                A.leak_meta[mate][pos] = ok ? (uint16_t)len : (uint16_t)0xffff;
+                if (ok) {
+                    atomicMax(&A.leak_blkmax[mate][pos / LEAK_BLK], (uint32_t)(len - P.seed_size + 1));
+                    if ((len - P.index_interval + 1) % P.seed_size != 0) atomicOr(&A.leak_blkset[mate][pos / LEAK_BLK], 1u);
+                }
+            }
+            wave_fence();
+        }
+    }
+}
+
+// the last position j < p of mate stream `mate` whose read sets the offset (kind 0) or has more than e seed offsets, i.e. wrote
+// seed_array entry e (kind 1); -1 if there is none
+__device__ long leak_find(const AlignArgs &A, int mate, long p, int kind, int e, int lane)
+{
+    const uint16_t *meta = A.leak_meta[mate];
+    const int S = A.P.seed_size, I = A.P.index_interval;
+    auto pred = [&](uint32_t v) { return v != 0xffffu && (kind == 0 ? ((int)v - I + 1) % S != 0 : (int)v - S + 1 > e); };
+    auto scan_back = [&](long lo, long hi) -> long {   // the last position in [lo, hi) that satisfies pred
+        for (long base = hi; base > lo; base -= 64) {
+            const long idx = base - 1 - lane;
+            const u64 m = bsx_ballot(idx >= lo && pred(meta[idx]));
+            if (m) return base - 1 - (long)__builtin_ctzll(m);
+        }
+        return -1;
+    };
+    if (p <= 0) return -1;
+    const long blk_lo = (p - 1) / LEAK_BLK * LEAK_BLK;
+    long j = scan_back(blk_lo, p);   // the rest of p's own block
+    if (j >= 0) return j;
+    for (long bb = blk_lo / LEAK_BLK; bb > 0; bb -= 64) {   // earlier blocks by their summaries, 64 per step
+        const long bi = bb - 1 - lane;
+        const u64 m = bsx_ballot(bi >= 0 && (kind == 0 ? A.leak_blkset[mate][bi] != 0 : (int)A.leak_blkmax[mate][bi] > e));
+        if (m) { const long bsel = bb - 1 - (long)__builtin_ctzll(m); return scan_back(bsel * LEAK_BLK, (bsel + 1) * LEAK_BLK); }
+    }
+    return -1;
+}
+
+// what k_leak_resolve leaves for a unit's mate (exact mode): the stale tail entries and start offsets
+struct LeakRec { uint32_t key[2][16]; uint8_t so[2]; uint8_t pad[6]; };
+
+// offset of the stream's state before position p (per orientation the stream builds) -> so[]; the initial state where no read set one
+template <bool PE>
+__device__ void leak_offsets(const AlignArgs &A, const BlockLds &BL, MateLds &LS, int mate, long p, uint32_t flags, int lane, uint32_t (&so)[2])
 {
     const DevParams &P = A.P;
-    const int S = P.seed_size, I = P.index_interval, noff = M.u->len - S + 1;
-    if (lane < 32) (&L.stale_key[0][0])[lane] = 0;
-    if (lane < 2) L.stale_so[lane] = 0;
-    wave_fence();
-    uint32_t need_so = M.u->flags & 3u;
-    uint32_t need_tail[2] = {(M.u->flags & 1u) ? 0xffffu : 0u, (M.u->flags & 2u) ? 0xffffu : 0u};
+    const LeakState *init = (const LeakState *)A.leak_init;
+    so[0] = init ? init->so[mate][0] : 0u; so[1] = init ? init->so[mate][1] : 0u;
     Counters dummy = {0, 0, 0, 0};
-    for (long j = (long)unit - 1; (need_so | need_tail[0] | need_tail[1]) && j >= -(long)A.n_hist; j--) {
+    uint32_t need = flags & 3u;
+    for (long j = leak_find(A, mate, p, 0, 0, lane); j >= 0 && need; j = leak_find(A, mate, j, 0, 0, lane)) {
         Mate MJ;
         MJ.u = lds_mate(&LS.u);
         MJ.u->index = 0;
-        load_and_filter(A, LS, MJ, mate, j, lane);
-        if (MJ.u->filtered) continue;  // RunAlign is not called for a read FilterReads rejects (align.cpp:598, pairs.cpp:199-213): state untouched
+        load_and_filter(A, LS, MJ, mate, j - (long)A.n_hist, lane);
         pack_read(P, LS, MJ, PE ? mate + 1 : 0, lane, dummy);
-        const int noff_j = MJ.u->len - S + 1;
         for (int orient = 0; orient < 2; orient++) {
-            if (!((MJ.u->flags >> orient) & 1)) continue;
-            if (need_tail[orient]) {  // ConvertBinaySeq wrote entries [0, noff_j) of this read (align.cpp:101-105)
-                const int idx = noff + lane;
-                const bool got = lane < 16 && ((need_tail[orient] >> lane) & 1) && idx < noff_j;
-                if (got) L.stale_key[orient][lane] = seed_key_at(P, LS.w[orient], idx);
-                need_tail[orient] &= ~(uint32_t)bsx_ballot(got);
-            }
-            if (((need_so >> orient) & 1) && (MJ.u->len - I + 1) % S != 0) {  // this read ran the offset loop
-                plan_counts<false>(P, LS, MJ, orient, lane, false);
-                const int so = plan_best_offset(P, BL, LS, MJ, orient, lane);
-                if (so >= 0) { if (lane == 0) L.stale_so[orient] = (uint8_t)so; need_so &= ~(1u << orient); }
-            }
+            if (!((need >> orient) & 1)) continue;
+            plan_counts<false>(P, LS, MJ, orient, lane, false);
+            const int v = plan_best_offset(P, BL, LS, MJ, orient, lane);
+            if (v >= 0) { so[orient] = (uint32_t)v; need &= ~(1u << orient); }   // (a read whose totals never beat the initial minimum leaves the offset alone)
         }
         wave_fence();
     }
-    wave_fence();
+}
+
+// seed_array / cseed_array entries [e0, e0 + n) (n <= 64 per call, lane i = entry e0 + i) of the stream's state before position p
+template <bool PE>
+__device__ void leak_entries(const AlignArgs &A, MateLds &LS, int mate, long p, uint32_t flags, int e0, int n, int lane, uint32_t (&key)[2])
+{
+    const DevParams &P = A.P;
+    const LeakState *init = (const LeakState *)A.leak_init;
+    const int mye = e0 + lane;
+    key[0] = (init && lane < n && mye < LEAK_KEYS) ? init->key[mate][0][mye] : 0u;
+    key[1] = (init && lane < n && mye < LEAK_KEYS) ? init->key[mate][1][mye] : 0u;
+    Counters dummy = {0, 0, 0, 0};
+    int e = e0;
+    long cur = p;
+    while (e < e0 + n) {
+        const long j = leak_find(A, mate, cur, 1, e, lane);   // the most recent read that wrote entry e wrote everything below its own end, too
+        if (j < 0) break;
+        Mate MJ;
+        MJ.u = lds_mate(&LS.u);
+        MJ.u->index = 0;
+        load_and_filter(A, LS, MJ, mate, j - (long)A.n_hist, lane);
+        pack_read(P, LS, MJ, PE ? mate + 1 : 0, lane, dummy);
+        const int noff_j = MJ.u->len - P.seed_size + 1;
+        for (int orient = 0; orient < 2; orient++) {
+            if (!((flags >> orient) & 1)) continue;
+            if (lane < n && mye >= e && mye < noff_j) key[orient] = seed_key_at(P, LS.w[orient], mye);   // ConvertBinaySeq wrote entries [0, noff_j) (align.cpp:101-105)
+        }
+        wave_fence();
+        e = noff_j; cur = j;
+    }
+}
+
+template <bool PE>
+__global__ __launch_bounds__(256) void k_leak_resolve(AlignArgs A)
+{
+    __shared__ BlockLds BL;
+    __shared__ MateLds LSC[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    init_block_lds(A.P, BL, threadIdx.x, 256);
+    __syncthreads();
+    const DevParams &P = A.P;
+    for (uint32_t unit = A.first_unit + blockIdx.x * 4 + wv; unit < A.n_units; unit += gridDim.x * 4) {
+        for (int mate = 0; mate < (PE ? 2 : 1); mate++) {
+            const long pos = (long)A.n_hist + unit;
+            const uint32_t v = rfl(A.leak_meta[mate][pos]);
+            if (v == 0xffffu || ((int)v - P.index_interval + 1) % P.seed_size != 0) continue;   // filtered, or a read that sets its own offset
+            const int readset = PE ? mate + 1 : 0;
+            const uint32_t flags = ((P.chains || readset < 2) ? 1u : 0u) | ((P.chains || readset == 2) ? 2u : 0u);  // align.cpp:93-94
+            uint32_t so[2], key[2];
+            leak_offsets<PE>(A, BL, LSC[wv], mate, pos, flags, lane, so);
+            leak_entries<PE>(A, LSC[wv], mate, pos, flags, (int)v - P.seed_size + 1, 16, lane, key);
+            LeakRec *r = (LeakRec *)A.leak_rec + ((size_t)unit * 2 + mate);
+            if (lane < 16) { r->key[0][lane] = key[0]; r->key[1][lane] = key[1]; }
+            if (lane < 2) r->so[lane] = (uint8_t)so[lane];
+        }
+        wave_fence();
+    }
+}
+
+// the state behind the last read of the stream: block = mate
+template <bool PE>
+__global__ __launch_bounds__(64) void k_leak_final(AlignArgs A, LeakState *out)
+{
+    __shared__ BlockLds BL;
+    __shared__ MateLds LSC;
+    const int lane = threadIdx.x & 63, mate = blockIdx.x;
+    init_block_lds(A.P, BL, threadIdx.x, 64);
+    __syncthreads();
+    const DevParams &P = A.P;
+    const LeakState *init = (const LeakState *)A.leak_init;
+    if (!PE && mate == 1) {   // no second stream: its state passes through
+        for (int i = lane; i < (int)(sizeof(out->key[1]) / 4); i += 64) (&out->key[1][0][0])[i] = init ? (&init->key[1][0][0])[i] : 0u;
+        if (lane < 2) out->so[1][lane] = init ? init->so[1][lane] : 0u;
+        return;
+    }
+    const long pos = (long)A.n_hist + A.n_units_all;
+    const int readset = PE ? mate + 1 : 0;
+    const uint32_t flags = ((P.chains || readset < 2) ? 1u : 0u) | ((P.chains || readset == 2) ? 2u : 0u);
+    uint32_t so[2];
+    leak_offsets<PE>(A, BL, LSC, mate, pos, flags, lane, so);
+    if (lane < 2) out->so[mate][lane] = so[lane];
+    for (int e0 = 0; e0 < LEAK_KEYS; e0 += 64) {
+        uint32_t key[2];
+        const int n = min(64, LEAK_KEYS - e0);
+        leak_entries<PE>(A, LSC, mate, pos, flags, e0, n, lane, key);
+        if (lane < n) { out->key[mate][0][e0 + lane] = key[0]; out->key[mate][1][e0 + lane] = key[1]; }
+    }
 }
 
 // FilterReads + ConvertBinaySeq + ReorderSeed for the mate(s) of a unit
-// what k_leak left for a unit's mate (exact mode): the stale tail entries and start offsets
-struct LeakRec { uint32_t key[2][16]; uint8_t so[2]; uint8_t pad[6]; };
 __device__ __forceinline__ void load_leak_rec(const AlignArgs &A, MateLds &L, uint32_t unit, int mate, int lane)
 {
     const LeakRec *r = (const LeakRec *)A.leak_rec + ((size_t)unit * 2 + mate);
@@ -1346,36 +1488,6 @@ __device__ void flush_counters(const AlignArgs &A, const Counters &C, u64 n_unit
     atomicAdd((u64 *)&A.counters[6], n_aligned_pairs);
 }
 
-// "-p 1 exact" mode, pre-pass: one wave per unit finds, for every mate whose planner state leaks, what the reference's state
-// holds at that point of the stream (resolve_leak) and leaves it in A.leak_rec for the align kernels — kept out of the main
-// kernel, whose per-unit function must stay a leaf (a call inside it cost 18 ms per 2^20 pairs even when never taken)
-template <bool PE>
-__global__ __launch_bounds__(256) void k_leak(AlignArgs A)
-{
-    __shared__ BlockLds BL;
-    __shared__ MateLds LM[4], LSC[4];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    init_block_lds(A.P, BL, threadIdx.x, 256);
-    __syncthreads();
-    const DevParams &P = A.P;
-    Counters dummy = {0, 0, 0, 0};
-    for (uint32_t unit = A.first_unit + blockIdx.x * 4 + wv; unit < A.n_units; unit += gridDim.x * 4) {
-        for (int mate = 0; mate < (PE ? 2 : 1); mate++) {
-            Mate M;
-            M.u = lds_mate(&LM[wv].u);
-            M.u->index = 0;
-            load_and_filter(A, LM[wv], M, mate, (long)unit, lane);
-            if (M.u->filtered || (M.u->len - P.index_interval + 1) % P.seed_size != 0) continue;
-            pack_read(P, LM[wv], M, PE ? mate + 1 : 0, lane, dummy);
-            resolve_leak<PE>(A, BL, LSC[wv], LM[wv], M, mate, unit, lane);
-            LeakRec *r = (LeakRec *)A.leak_rec + ((size_t)unit * 2 + mate);
-            if (lane < 32) (&r->key[0][0])[lane] = (&LM[wv].stale_key[0][0])[lane];
-            if (lane < 2) r->so[lane] = LM[wv].stale_so[lane];
-        }
-        wave_fence();
-    }
-}
-
 #ifndef BSX_WAVES_PER_EU_SE
 #define BSX_WAVES_PER_EU_SE 6
 #endif
@@ -1459,6 +1571,7 @@ struct HMate {
     uint8_t start[2][16], order[2][16];
     uint32_t stale_key[2][16];  // "-p 1 exact" mode: make_list needs the tail entries again on later visits
 };
+#define HS_NSLOT 2  /* list slots of a unit: the list each mate is working on */
 struct HState {
     uint32_t want;  // tasks of a request the pool refused (0: none): the unit is only restored once that many are free
     int32_t level, sub;
@@ -1467,13 +1580,13 @@ struct HState {
     // are independent, pairs.cpp:165-166), so each keeps its own orientation / position / window
     int32_t orient[2], have[2];
     uint32_t c[2], W[2];
-    uint32_t t0[2], n_tasks[2], win_c0[2], win_n[2];  // the published window: tasks t0.. cover candidates [win_c0, win_c0+win_n)
+    uint32_t t0[HS_NSLOT], n_tasks[HS_NSLOT], win_c0[HS_NSLOT], win_n[HS_NSLOT];  // the published window: tasks t0.. cover candidates [win_c0, win_c0+win_n)
     Counters C;
     uint32_t pcnt_reg[64];
     HMate mate[2];
-    ListReq req[2];
+    ListReq req[HS_NSLOT];
 };
-struct HTask { uint32_t h, c0, n, key; };  // h: unit (bits 0-30) and list slot (bit 31); key: index entry the task starts at (tasks are scanned in key order, see bsx_api.hip)
+struct HTask { uint32_t h, c0, n, key; };  // h: unit (bits 0-29) and list slot (bits 30-31); key: index entry the task starts at (tasks are scanned in key order, see bsx_api.hip)
 struct HTaskOut { uint32_t count, overflow, acc[4], pad[2]; SurvRec surv[HS_SCAP]; };
 struct HeavyArgs {
     HState *state; uint8_t *slabs; uint32_t *active_in, *active_out, *n_active_out; HTask *tasks; HTaskOut *tout; uint32_t *n_tasks, *queue;
@@ -1533,6 +1646,41 @@ __device__ __forceinline__ u64 surv_coords(const DevParams &P, const BlockLds &B
         r.hchr = hchr; r.hloc = hloc; r.hkey = hkey;
     }
     return bsx_ballot(ok);
+}
+
+// publish candidates [c0, c0 + wn) of list `cl` as scan tasks of list slot `slot`; false if the task pool cannot take them
+__device__ __forceinline__ bool publish_window(const DevParams &P, const HeavyArgs &H, HState *S, uint32_t hidx, int slot, const CandList &cl, int orient, int seg,
+                                               const MateLds &L, const Mate &M, uint32_t c0, uint32_t wn, int lane, uint32_t &nt_out)
+{
+    const uint32_t nt = (wn + HS_TASK - 1) / HS_TASK;
+    nt_out = nt;
+    uint32_t t0 = 0;
+    if (lane == 0) t0 = atomicAdd(H.n_tasks, nt);
+    t0 = rfl(t0);
+    if (t0 + nt > H.task_cap) {
+        if (t0 < H.task_cap)  // pool exhausted mid-way: neutralise the slots that were reserved
+            for (uint32_t t = t0 + lane; t < H.task_cap; t += 64) { HTask tk; tk.h = hidx; tk.c0 = 0; tk.n = 0; tk.key = 0xffffffffu; H.tasks[t] = tk; }
+        return false;
+    }
+    for (uint32_t tb = 0; tb < nt; tb += 64) {
+        const uint32_t t = tb + lane;
+        HTask tk; tk.h = hidx | ((uint32_t)slot << 30); tk.c0 = c0 + t * HS_TASK; tk.n = min((uint32_t)HS_TASK, wn - t * HS_TASK); tk.key = 0;
+        for (int s_ = 0; s_ < cl.nsub; s_++) {  // the index entry the task starts at
+            const uint32_t ps_ = rl(cl.sub_pre, s_), ns_ = rl(cl.sub_n, s_), sb_ = rl(cl.sub_base, s_);
+            if (tk.c0 >= ps_ && tk.c0 < ps_ + ns_) tk.key = sb_ + (tk.c0 - ps_);
+        }
+        if (t < nt) H.tasks[t0 + t] = tk;
+    }
+    ListReq &R = S->req[slot];
+    if (lane < 32) { R.sub_pre[lane] = cl.sub_pre; R.sub_n[lane] = cl.sub_n; R.sub_base[lane] = cl.sub_base; R.sub_h[lane] = cl.sub_h; }
+    if (lane < 9) { R.rw[lane] = L.w[orient][lane]; R.rm[lane] = L.m[orient][lane]; }
+    if (lane == 0) {
+        R.nsub = (uint32_t)cl.nsub; R.total = cl.total; R.nwords = (uint32_t)((M.u->len + 15) >> 4); R.len = (uint32_t)M.u->len; R.thres = M.u->snp_thres;
+        R.rrbs = P.rrbs ? 1u : 0u;  // tag filter of align.cpp:187,229: forward reads want their segment, rc reads cmodeindex with the direction bit flipped
+        R.tag_xor = orient ? 0x1000000u : 0u; R.tag_want = orient ? (uint32_t)(M.u->nfull - 1 - seg) : (uint32_t)seg;
+        S->t0[slot] = t0; S->n_tasks[slot] = nt; S->win_c0[slot] = c0; S->win_n[slot] = wn;
+    }
+    return true;
 }
 
 // resumable SnpAlign for a deferred unit: 0 = call complete, 1 = the reference's SnpAlign returned early, 2 = a window
@@ -1687,35 +1835,10 @@ __device__ __forceinline__ int snp_align_heavy(const AlignArgs &A, const HeavyAr
             } else {
                 const uint32_t weff = K.n_active < 2048u ? (uint32_t)HS_WINMAX : K.W[ms];  // few units left: scanning capacity is idle, speculate the whole list
                 const uint32_t wpool = (u64)H.task_cap * HS_TASK < (u64)weff ? H.task_cap * HS_TASK : weff;  // a window must fit the task pool
-                const uint32_t wn = min(wpool, cl.total - K.c[ms]), nt = (wn + HS_TASK - 1) / HS_TASK;
-                uint32_t t0 = 0;
-                if (lane == 0) t0 = atomicAdd(H.n_tasks, nt);
-                t0 = rfl(t0);
-                if (t0 + nt <= H.task_cap) {
-                    for (uint32_t tb = 0; tb < nt; tb += 64) {
-                        const uint32_t t = tb + lane;
-                        HTask tk; tk.h = hidx | ((uint32_t)ms << 31); tk.c0 = K.c[ms] + t * HS_TASK; tk.n = min((uint32_t)HS_TASK, wn - t * HS_TASK); tk.key = 0;
-                        for (int s_ = 0; s_ < cl.nsub; s_++) {  // the index entry the task starts at
-                            const uint32_t ps_ = rl(cl.sub_pre, s_), ns_ = rl(cl.sub_n, s_), sb_ = rl(cl.sub_base, s_);
-                            if (tk.c0 >= ps_ && tk.c0 < ps_ + ns_) tk.key = sb_ + (tk.c0 - ps_);
-                        }
-                        if (t < nt) H.tasks[t0 + t] = tk;
-                    }
-                    ListReq &R = S->req[ms];
-                    if (lane < 32) { R.sub_pre[lane] = cl.sub_pre; R.sub_n[lane] = cl.sub_n; R.sub_base[lane] = cl.sub_base; R.sub_h[lane] = cl.sub_h; }
-                    if (lane < 9) { R.rw[lane] = L.w[orient][lane]; R.rm[lane] = L.m[orient][lane]; }
-                    if (lane == 0) {
-                        R.nsub = (uint32_t)cl.nsub; R.total = cl.total; R.nwords = (uint32_t)((M.u->len + 15) >> 4); R.len = (uint32_t)M.u->len; R.thres = M.u->snp_thres;
-                        R.rrbs = P.rrbs ? 1u : 0u;  // tag filter of align.cpp:187,229: forward reads want their segment, rc reads cmodeindex with the direction bit flipped
-                        R.tag_xor = orient ? 0x1000000u : 0u; R.tag_want = orient ? (uint32_t)(M.u->nfull - 1 - seg) : (uint32_t)seg;
-                        S->t0[ms] = t0; S->n_tasks[ms] = nt; S->win_c0[ms] = K.c[ms]; S->win_n[ms] = wn;
-                    }
-                    K.have[ms] = 1;
-                } else {
-                    K.want = nt;  // the request is repeated in a later iteration, once the pool can take it
-                    if (t0 < H.task_cap)  // pool exhausted mid-way: neutralise the slots that were reserved
-                        for (uint32_t t = t0 + lane; t < H.task_cap; t += 64) { HTask tk; tk.h = hidx; tk.c0 = 0; tk.n = 0; tk.key = 0xffffffffu; H.tasks[t] = tk; }
-                }
+                const uint32_t wn = min(wpool, cl.total - K.c[ms]);
+                uint32_t nt = 0;
+                if (publish_window(P, H, S, hidx, ms, cl, orient, seg, L, M, K.c[ms], wn, lane, nt)) K.have[ms] = 1;
+                else K.want = nt;  // the request is repeated in a later iteration, once the pool can take it
                 wave_fence();
                 return 2;
             }
@@ -1852,7 +1975,9 @@ __global__ __launch_bounds__(256, PE ? BSX_HCTRL_WAVES : BSX_HCTRL_WAVES_SE) voi
             C.sum_w = (u64)rfl((uint32_t)(C.sum_w >> 32)) << 32 | rfl((uint32_t)C.sum_w); C.n_orient = (u64)rfl((uint32_t)(C.n_orient >> 32)) << 32 | rfl((uint32_t)C.n_orient);
             pcnt_reg = S->pcnt_reg[lane];
             K.level = (int)rfl((uint32_t)S->level); K.sub = (int)rfl((uint32_t)S->sub); K.paired = (int)rfl((uint32_t)S->paired);
-            for (int m_ = 0; m_ < 2; m_++) { K.orient[m_] = (int)rfl((uint32_t)S->orient[m_]); K.have[m_] = (int)rfl((uint32_t)S->have[m_]); K.c[m_] = rfl(S->c[m_]); K.W[m_] = rfl(S->W[m_]); }
+            for (int m_ = 0; m_ < 2; m_++) {
+                K.orient[m_] = (int)rfl((uint32_t)S->orient[m_]); K.have[m_] = (int)rfl((uint32_t)S->have[m_]); K.c[m_] = rfl(S->c[m_]); K.W[m_] = rfl(S->W[m_]);
+            }
         }
         if (A.dbg_cat && lane == 0) { const u64 d_ = (u64)__builtin_readcyclecounter() - cat_prep0; atomicAdd((u64 *)&A.dbg_cat[0], d_); atomicMax((u64 *)&A.dbg_cat[8], d_); }
         const u64 cat_adv0 = A.dbg_cat ? __builtin_readcyclecounter() : 0;
@@ -1879,7 +2004,9 @@ __global__ __launch_bounds__(256, PE ? BSX_HCTRL_WAVES : BSX_HCTRL_WAVES_SE) voi
             S->pcnt_reg[lane] = pcnt_reg;
             if (lane == 0) {
                 S->want = K.want; S->C = C; S->level = K.level; S->sub = K.sub; S->paired = K.paired;
-                for (int m_ = 0; m_ < 2; m_++) { S->orient[m_] = K.orient[m_]; S->have[m_] = K.have[m_]; S->c[m_] = K.c[m_]; S->W[m_] = K.W[m_]; }
+                for (int m_ = 0; m_ < 2; m_++) {
+                    S->orient[m_] = K.orient[m_]; S->have[m_] = K.have[m_]; S->c[m_] = K.c[m_]; S->W[m_] = K.W[m_];
+                }
                 H.active_out[atomicAdd(H.n_active_out, 1u)] = hidx;
             }
         }
@@ -1972,7 +2099,6 @@ template <bool MASKED>
 __device__ __forceinline__ void hscan_eval(ScanCtx &X, const U4 r0, uint32_t pm1, uint32_t boff, bool valid, uint32_t tag, int u, const uint32_t (&rw)[9],
                                            const uint32_t (&rm)[9])
 {
-    const int lane = X.lane;
     const uint32_t sh = mad30(pm1, 30);
     const uint32_t him = (uint32_t)((int32_t)0x80000000 >> (mad30(pm1, 29) & 31u));
     const uint32_t f0 = __builtin_amdgcn_alignbit(r0.a, r0.b, sh), f1 = __builtin_amdgcn_alignbit(r0.b, r0.c, sh), f2 = __builtin_amdgcn_alignbit(r0.c, r0.d, sh);
@@ -2078,13 +2204,13 @@ __global__ __launch_bounds__(64 * BSX_HSCAN_WPB, BSX_HSCAN_WAVES) void k_hscan(A
     }
     if (slot >= n_tasks) return;
     const uint32_t t = H.order ? rfl(H.order[slot]) : slot;
-    const uint32_t hraw = rfl(H.tasks[t].h), hidx = hraw & 0x7fffffffu, tc0 = rfl(H.tasks[t].c0), tn = rfl(H.tasks[t].n);
+    const uint32_t hraw = rfl(H.tasks[t].h), hidx = hraw & 0x3fffffffu, tc0 = rfl(H.tasks[t].c0), tn = rfl(H.tasks[t].n);
     HTaskOut *o = &H.tout[t];
     if (tn == 0) {  // slot neutralised by a refused request: its unit has not published a list (ListReq may be stale)
         if (lane == 0) { o->count = 0; o->overflow = 0; o->acc[0] = o->acc[1] = o->acc[2] = o->acc[3] = 0; }
         return;
     }
-    const ListReq &R = H.state[hidx].req[hraw >> 31];
+    const ListReq &R = H.state[hidx].req[hraw >> 30];
     if (lane < 32) { TAB[wv][0][lane] = R.sub_pre[lane]; TAB[wv][1][lane] = R.sub_n[lane]; TAB[wv][2][lane] = R.sub_base[lane]; TAB[wv][3][lane] = R.sub_h[lane]; }
     uint32_t rw[9], rm[9];
 #pragma unroll
@@ -2195,7 +2321,7 @@ __global__ __launch_bounds__(256, 4) void k_hscan_shared(AlignArgs A, HeavyArgs 
         const HTask tk = H.tasks[tid];
         th = tk.h; tc0 = tk.c0; tn = tk.n; tkey = tk.key;
         if (tn) {
-            const ListReq &R = H.state[th & 0x7fffffffu].req[th >> 31];
+            const ListReq &R = H.state[th & 0x3fffffffu].req[th >> 30];
             tkey = R.sub_base[0] + (tc0 - R.sub_pre[0]);  // first entry of the window
             sh_ = R.sub_h[0]; stx = R.tag_xor; stw = R.tag_want; snw = R.nwords;
         } else {  // slot neutralised by a refused request: its unit has not published a list
@@ -2218,7 +2344,7 @@ __global__ __launch_bounds__(256, 4) void k_hscan_shared(AlignArgs A, HeavyArgs 
             const uint32_t x = xb + (uint32_t)lane, k = min(x / 20u, K - 1u), f = x - k * 20u;
             const uint32_t hk = (uint32_t)__shfl((int)th, (int)(i0 + k)), tk = (uint32_t)__shfl((int)tid, (int)(i0 + k));  // (all lanes take part)
             if (x < K * 20u) {
-                const ListReq &R = H.state[hk & 0x7fffffffu].req[hk >> 31];
+                const ListReq &R = H.state[hk & 0x3fffffffu].req[hk >> 30];
                 uint32_t v;
                 if (f < 9) v = R.rw[f];
                 else if (f < 18) v = bsx_tmask(R.rw[f - 9], R.rm[f - 9]);
@@ -2309,12 +2435,29 @@ __global__ __launch_bounds__(256, 4) void k_hscan_shared(AlignArgs A, HeavyArgs 
 }
 }  // namespace
 
-void bsx_launch_leak(const AlignArgs &A, int paired, int grid_blocks, hipStream_t stream)
+// exact mode pre-pass (see k_leak_meta): with_meta = the stream's records are not up to date (new reads / history); `final_out` != null:
+// also leave the state behind the stream's last read there
+void bsx_launch_leak(const AlignArgs &A, int paired, int n_cu, bool with_meta, bool resolve, void *final_out, hipStream_t stream)
 {
-    if (paired) hipLaunchKernelGGL(k_leak<true>, dim3(grid_blocks), dim3(256), 0, stream, A);
-    else hipLaunchKernelGGL(k_leak<false>, dim3(grid_blocks), dim3(256), 0, stream, A);
+    const uint32_t n_stream = A.n_hist + A.n_units_all;
+    if (with_meta) {
+        const int g = (int)std::max<uint32_t>(1, std::min<uint32_t>((n_stream + 3) / 4, (uint32_t)n_cu * 8));
+        if (paired) hipLaunchKernelGGL(k_leak_meta<true>, dim3(g), dim3(256), 0, stream, A);
+        else hipLaunchKernelGGL(k_leak_meta<false>, dim3(g), dim3(256), 0, stream, A);
+    }
+    if (resolve) {
+        const int g = (int)std::max<uint32_t>(1, std::min<uint32_t>((A.n_units - A.first_unit + 3) / 4, (uint32_t)n_cu * 8));
+        if (paired) hipLaunchKernelGGL(k_leak_resolve<true>, dim3(g), dim3(256), 0, stream, A);
+        else hipLaunchKernelGGL(k_leak_resolve<false>, dim3(g), dim3(256), 0, stream, A);
+    }
+    if (final_out) {
+        if (paired) hipLaunchKernelGGL(k_leak_final<true>, dim3(2), dim3(64), 0, stream, A, (LeakState *)final_out);
+        else hipLaunchKernelGGL(k_leak_final<false>, dim3(2), dim3(64), 0, stream, A, (LeakState *)final_out);
+    }
 }
 size_t bsx_leakrec_bytes(void) { return sizeof(LeakRec); }
+size_t bsx_leakstate_bytes(void) { return sizeof(LeakState); }
+uint32_t bsx_leak_blk(void) { return LEAK_BLK; }
 
 void bsx_launch_align(const AlignArgs &A, int paired, int grid_blocks, hipStream_t stream)
 {

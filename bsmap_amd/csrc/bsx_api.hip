@@ -24,7 +24,7 @@ extern "C" int bsx_set_heavy_threshold(int t) { g_heavy_threshold = t < 0 ? 0 : 
 // cost the main kernel a millisecond each (one wave, 4 MB slab) and go through the scan kernel instead
 static uint32_t heavy_threshold_for(const bsx_params &p) { return g_heavy_threshold > 0 ? (uint32_t)g_heavy_threshold : (p.rrbs ? 4096u : 32768u); }
 static bool g_user_limits = false;
-static uint32_t g_hcap = 24576, g_task_cap = 524288;  // a 2^20-pair batch defers ~9.4 K units (C3) to ~17.3 K (C5, trimmed reads)
+static uint32_t g_hcap = 24576, g_task_cap = 1048576;  // a 2^20-pair batch defers ~9.4 K units (C3) to ~17.3 K (C5, trimmed reads)
 extern "C" int bsx_set_heavy_limits(uint32_t units_per_round, uint32_t task_pool)
 {
     if (units_per_round < 1 || task_pool < 2 || task_pool > (1u << 22)) return BSX_ERR_ARG;  // (a task record is 8 KB: 2^22 tasks = 34 GB)
@@ -214,6 +214,12 @@ struct bsx_batch {
     uint8_t *d_hist_seq[2] = {nullptr, nullptr}, *d_hist_qual[2] = {nullptr, nullptr};
     uint64_t *d_hist_off[2] = {nullptr, nullptr};
     uint8_t *d_leak_rec = nullptr;
+    // exact mode: per-position records of the mate streams (k_leak_meta), block summaries, the state before / behind the stream
+    uint16_t *d_leak_meta[2] = {nullptr, nullptr};
+    uint32_t *d_leak_blk = nullptr;   // [4][n_blk]: blkmax mate 0 / 1, blkset mate 0 / 1
+    uint32_t leak_nblk = 0;
+    uint8_t *d_leak_init = nullptr, *d_leak_final = nullptr;
+    bool leak_meta_valid = false, leak_has_init = false;
     uint32_t max_units = 0, n_units = 0, first_index = 0;
     hipStream_t stream = nullptr;
     // heavy pipeline: unit groups whose passes run out of phase — the scan passes of all groups on `stream`, the control passes of
@@ -298,12 +304,16 @@ static int ensure_scratch(bsx_batch *b)
     b->hctrl_blocks_per_cu = 1;
     if (const char *e = getenv("BSX_HCTRL_BLOCKS")) b->hctrl_blocks_per_cu = std::max(1, std::min(bsx_hctrl_occupancy(b->paired), atoi(e)));
     if (!b->d_heavy_list) {
-        // deferred units handled per round (more than this: several rounds): what 26 GB of slabs hold — 24 576 units of the 1.07 MB
-        // paired -v 6 slab, 111 K of the 234 KB single-end -v 2 one (RRBS defers a third of its reads: Alu-like fragments)
-        b->hcap = g_user_limits ? g_hcap : (uint32_t)std::min<uint64_t>(262144, std::max<uint64_t>(g_hcap, (26ull << 30) / b->hslab_bytes));
+        // deferred units handled per round (more than this: several rounds): what 26 GB of slabs hold — 24 576 units of the 1.07 MB paired
+        // -v 6 slab, 111 K of the 234 KB single-end -v 2 one.  RRBS defers a third of its reads (Alu-like fragments) and its scan kernel
+        // shares work between the reads that walk one window in the same pass: the more units a round holds, the longer those runs — 40 GB
+        // of slabs (170 K units) and 2 M tasks: C4 195 -> 159 ms per step.  Task records (8 KB each): 1 M for WGBS (C5 358 -> 328 ms against
+        // 512 K: fewer requests refused), following the batch size for small batches.
+        const uint64_t slab_budget = b->ref->P.rrbs ? (40ull << 30) : (26ull << 30);
+        b->hcap = g_user_limits ? g_hcap : (uint32_t)std::min<uint64_t>(262144, std::max<uint64_t>(g_hcap, slab_budget / b->hslab_bytes));
         b->hcap = std::min<uint32_t>(b->max_units, b->hcap);
-        // the pools follow the batch size: a small batch does not reserve the 4 GB of task records a 2^20-unit one may use
-        b->task_cap = g_user_limits ? g_task_cap : std::min<uint32_t>(g_task_cap, std::max<uint32_t>(4096u, 64u * b->hcap));
+        const uint32_t task_default = b->ref->P.rrbs ? 2u * g_task_cap : g_task_cap;
+        b->task_cap = g_user_limits ? g_task_cap : std::min<uint32_t>(task_default, std::max<uint32_t>(4096u, 64u * b->hcap));
         HIP_TRY(hipMalloc((void **)&b->d_heavy_list, ((size_t)b->max_units + 1) * 4));
         HIP_TRY(hipMalloc((void **)&b->d_heavy_count, 256));
         HIP_TRY(hipHostMalloc((void **)&b->h_pinned, 1024, hipHostMallocDefault));
@@ -415,7 +425,7 @@ extern "C" void bsx_batch_destroy(bsx_batch *b)
                     (void *)b->d_hstate, (void *)b->d_hslabs, (void *)b->d_htasks, (void *)b->d_htout, (void *)b->d_hactive[0], (void *)b->d_hactive[1], (void *)b->d_hcnt, (void *)b->d_redo})
         if (q) (void)hipFree(q);
     for (int m = 0; m < 2; m++) for (void *q : {(void *)b->d_hist_seq[m], (void *)b->d_hist_qual[m], (void *)b->d_hist_off[m]}) if (q) (void)hipFree(q);
-    if (b->d_leak_rec) (void)hipFree(b->d_leak_rec);
+    for (void *q : {(void *)b->d_leak_rec, (void *)b->d_leak_meta[0], (void *)b->d_leak_meta[1], (void *)b->d_leak_blk, (void *)b->d_leak_init, (void *)b->d_leak_final}) if (q) (void)hipFree(q);
     if (b->h_pinned) (void)hipHostFree(b->h_pinned);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
@@ -470,7 +480,7 @@ extern "C" int bsx_batch_upload_se(bsx_batch *b, uint32_t n, const char *seqs, c
     HIP_TRY(hipSetDevice(b->ref->device));
     int rc = upload_mate(b, 0, n, seqs, off, quals);
     if (rc) return rc;
-    b->n_units = n; b->first_index = first_index; b->has_qual = quals != nullptr;
+    b->n_units = n; b->first_index = first_index; b->has_qual = quals != nullptr; b->leak_meta_valid = false;
     HIP_TRY(hipStreamSynchronize(b->stream));  // host buffers may be reused by the caller
     return BSX_OK;
 }
@@ -484,7 +494,7 @@ extern "C" int bsx_batch_upload_pe(bsx_batch *b, uint32_t n, const char *seqs_a,
     int rc = upload_mate(b, 0, n, seqs_a, off_a, quals_a);
     if (rc == BSX_OK) rc = upload_mate(b, 1, n, seqs_b, off_b, quals_b);
     if (rc) return rc;
-    b->n_units = n; b->first_index = first_index; b->has_qual = quals_a != nullptr;
+    b->n_units = n; b->first_index = first_index; b->has_qual = quals_a != nullptr; b->leak_meta_valid = false;
     HIP_TRY(hipStreamSynchronize(b->stream));
     return BSX_OK;
 }
@@ -517,7 +527,7 @@ extern "C" int bsx_batch_set_history(bsx_batch *b, uint32_t n, const char *seqs_
         HIP_TRY(hipMemcpy(b->d_hist_off[m], of[m], ((size_t)n + 1) * 8, hipMemcpyHostToDevice));
         if (ql[m]) { HIP_TRY(hipMalloc((void **)&b->d_hist_qual[m], bytes + 256)); HIP_TRY(hipMemcpy(b->d_hist_qual[m], ql[m], bytes, hipMemcpyHostToDevice)); }
     }
-    b->n_hist = n;
+    b->n_hist = n; b->leak_meta_valid = false;
     return BSX_OK;
 }
 
@@ -530,6 +540,68 @@ extern "C" int bsx_batch_set_debug(bsx_batch *b, int keep)
     if (keep == 0 && b->d_cycles) { (void)hipFree(b->d_cycles); b->d_cycles = nullptr; }
     if (keep == 1 && !b->d_dbg) HIP_TRY(hipMalloc((void **)&b->d_dbg, (size_t)b->max_units * 128));
     return ensure_scratch(b);
+}
+
+// exact mode: device arrays of the pre-pass and the argument fields that describe the mate streams
+static int leak_prepare(bsx_batch *b, AlignArgs &A)
+{
+    const uint32_t cap = b->max_units + 65536u, nblk = cap / bsx_leak_blk() + 2;
+    if (!b->d_leak_meta[0]) {
+        for (int m = 0; m < (b->paired ? 2 : 1); m++) HIP_TRY(hipMalloc((void **)&b->d_leak_meta[m], (size_t)cap * 2));
+        HIP_TRY(hipMalloc((void **)&b->d_leak_blk, (size_t)nblk * 16));
+        HIP_TRY(hipMalloc((void **)&b->d_leak_final, bsx_leakstate_bytes()));
+        HIP_TRY(hipMalloc((void **)&b->d_leak_rec, (size_t)b->max_units * 2 * bsx_leakrec_bytes()));
+        b->leak_nblk = nblk;
+    }
+    for (int m = 0; m < 2; m++) { A.leak_meta[m] = b->d_leak_meta[m]; A.leak_blkmax[m] = b->d_leak_blk + (size_t)m * nblk; A.leak_blkset[m] = b->d_leak_blk + (size_t)(2 + m) * nblk; }
+    A.leak_init = b->leak_has_init ? b->d_leak_init : nullptr;
+    A.leak_rec = b->d_leak_rec;
+    A.n_units_all = b->n_units;
+    A.n_hist = b->n_hist;
+    if (!b->leak_meta_valid) HIP_TRY(hipMemsetAsync(b->d_leak_blk, 0, (size_t)nblk * 16, b->stream));
+    return BSX_OK;
+}
+
+static void fill_stream_args(bsx_batch *b, AlignArgs &A)
+{
+    memset(&A, 0, sizeof(A));
+    bsx_fill_devparams(b->ref, A.P);
+    A.first_index = b->first_index;
+    for (int m = 0; m < 2; m++) {
+        A.seq[m] = b->d_seq[m]; A.off[m] = b->d_off[m]; A.qual[m] = b->has_qual ? b->d_qual[m] : nullptr;
+        A.hist_seq[m] = b->d_hist_seq[m]; A.hist_off[m] = b->d_hist_off[m]; A.hist_qual[m] = b->d_hist_qual[m];
+    }
+}
+
+extern "C" int bsx_batch_set_leak_state(bsx_batch *b, const void *state, size_t bytes)
+{
+    if (!b || (state && bytes != bsx_leakstate_bytes())) return BSX_ERR_ARG;
+    HIP_TRY(hipSetDevice(b->ref->device));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    if (!state) { b->leak_has_init = false; return BSX_OK; }
+    if (!b->d_leak_init) HIP_TRY(hipMalloc((void **)&b->d_leak_init, bsx_leakstate_bytes()));
+    HIP_TRY(hipMemcpy(b->d_leak_init, state, bytes, hipMemcpyHostToDevice));
+    b->leak_has_init = true;
+    return BSX_OK;
+}
+
+extern "C" int bsx_batch_get_leak_state(bsx_batch *b, void *state, size_t bytes)
+{
+    if (!b || !state || bytes != bsx_leakstate_bytes()) return BSX_ERR_ARG;
+    if (b->n_units == 0) return BSX_ERR_STATE;
+    if (b->ref->P.rrbs) { memset(state, 0, bytes); return BSX_OK; }   // RRBS plans every read from offset 0 (align.cpp:456): no state
+    HIP_TRY(hipSetDevice(b->ref->device));
+    AlignArgs A;
+    fill_stream_args(b, A);
+    A.n_units = b->n_units; A.first_unit = 0;
+    int rc = leak_prepare(b, A);
+    if (rc) return rc;
+    bsx_launch_leak(A, b->paired, b->n_cu, !b->leak_meta_valid, false, b->d_leak_final, b->stream);
+    HIP_TRY(hipGetLastError());
+    b->leak_meta_valid = true;
+    HIP_TRY(hipMemcpyAsync(state, b->d_leak_final, bytes, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return BSX_OK;
 }
 
 extern "C" int bsx_batch_run(bsx_batch *b) { return b ? bsx_batch_run_range(b, 0, b->n_units) : BSX_ERR_ARG; }
@@ -551,7 +623,7 @@ extern "C" int bsx_batch_run_range(bsx_batch *b, uint32_t first_unit, uint32_t n
     A.hits_out = b->d_hits; A.pairs_out = b->d_pairs; A.npairs_out = b->d_npairs;
     A.scratch = b->d_scratch; A.slab_bytes = b->slab_bytes; A.queue = b->d_queue; A.counters = b->d_counters; A.scan_stats = b->d_scan_stats; A.dbg_plan = b->d_dbg; A.dbg_cycles = b->d_cycles; A.dbg_cat = b->d_cycles ? b->d_counters + 16 : nullptr;
     A.heavy_list = b->d_heavy_list; A.heavy_count = b->d_heavy_count;
-    A.leak_exact = b->leak_exact; A.n_hist = b->leak_exact ? b->n_hist : 0;
+    A.leak_exact = b->leak_exact; A.n_hist = b->leak_exact ? b->n_hist : 0; A.n_units_all = b->n_units;
     for (int m = 0; m < 2; m++) { A.hist_seq[m] = b->d_hist_seq[m]; A.hist_off[m] = b->d_hist_off[m]; A.hist_qual[m] = b->d_hist_qual[m]; }
     A.heavy_threshold = heavy_threshold_for(b->ref->P);
     HIP_TRY(hipMemsetAsync(b->d_queue, 0, 4, b->stream));
@@ -560,10 +632,11 @@ extern "C" int bsx_batch_run_range(bsx_batch *b, uint32_t first_unit, uint32_t n
     if (b->debug) HIP_TRY(hipMemsetAsync(b->d_scratch, 0, (size_t)b->max_units * b->slab_bytes, b->stream));
     HIP_TRY(hipEventRecord(b->ev0, b->stream));
     if (b->leak_exact && !b->ref->P.rrbs) {  // pre-pass of the exact mode: planner state that leaks from earlier reads
-        if (!b->d_leak_rec) HIP_TRY(hipMalloc((void **)&b->d_leak_rec, (size_t)b->max_units * 2 * bsx_leakrec_bytes()));
-        A.leak_rec = b->d_leak_rec;
-        bsx_launch_leak(A, b->paired, (int)std::min<uint32_t>((n_units + 3) / 4, (uint32_t)b->n_cu * 8), b->stream);
+        int rc = leak_prepare(b, A);
+        if (rc) return rc;
+        bsx_launch_leak(A, b->paired, b->n_cu, !b->leak_meta_valid, true, nullptr, b->stream);
         HIP_TRY(hipGetLastError());
+        b->leak_meta_valid = true;
     }
     bsx_launch_align(A, b->paired, b->grid_blocks, b->stream);
     HIP_TRY(hipGetLastError());
@@ -890,7 +963,7 @@ extern "C" int bsx_batch_synth_reads_kind(bsx_batch *b, uint32_t n, uint32_t rea
     int rc = bsx_synth_reads_launch(b->ref, n, read_len, b->paired, seed, first_index, b->d_seq[0], b->d_seq[1], b->stream, kind, q ? b->d_qual[0] : nullptr,
                                     q && b->paired ? b->d_qual[1] : nullptr);
     if (rc) return rc;
-    b->n_units = n; b->first_index = first_index; b->has_qual = q ? 1 : 0;
+    b->n_units = n; b->first_index = first_index; b->has_qual = q ? 1 : 0; b->leak_meta_valid = false;
     return BSX_OK;
 }
 

@@ -34,8 +34,12 @@ struct AlignArgs {
     // "-p 1 exact" mode (bsx_batch_set_leak_exact): reads whose planner state the reference inherits from earlier reads of the
     // same stream (align.h:82-91, never reset) look those reads up — in this batch, then in the history the caller attached
     int32_t leak_exact;
-    const uint8_t *leak_rec;   // [n_units][2] LeakRec written by k_leak (exact mode only)
+    const uint8_t *leak_rec;   // [n_units][2] LeakRec written by k_leak_resolve (exact mode only)
     uint32_t n_hist;           // reads of history per mate stream (the reads that precede unit 0 in the input)
+    uint32_t n_units_all;      // units of the whole batch (a run may cover a range; the stream of the exact mode is the whole batch)
+    uint16_t *leak_meta[2];    // per stream position (history, then units): trimmed length, 0xffff = rejected by FilterReads
+    uint32_t *leak_blkmax[2], *leak_blkset[2];  // per block of 4096 positions: most seed offsets of an unfiltered read / a read sets the offset
+    const void *leak_init;     // LeakState before the stream's first read (null: zero)
     const uint8_t *hist_seq[2];
     const uint64_t *hist_off[2];
     const uint8_t *hist_qual[2];
@@ -56,8 +60,10 @@ struct HeavyArgsRaw {
 };
 
 void bsx_launch_align(const AlignArgs &A, int paired, int grid_blocks, hipStream_t stream);
-void bsx_launch_leak(const AlignArgs &A, int paired, int grid_blocks, hipStream_t stream);
+void bsx_launch_leak(const AlignArgs &A, int paired, int n_cu, bool with_meta, bool resolve, void *final_out, hipStream_t stream);
 size_t bsx_leakrec_bytes(void);
+size_t bsx_leakstate_bytes(void);
+uint32_t bsx_leak_blk(void);
 void bsx_launch_hctrl(const AlignArgs &A, const HeavyArgsRaw &H, int paired, int grid_blocks, hipStream_t stream);
 void bsx_launch_hscan(const AlignArgs &A, const HeavyArgsRaw &H, hipStream_t stream);         // grid sized for H.task_cap; the count stays on the device
 void bsx_launch_hscan_shared(const AlignArgs &A, const HeavyArgsRaw &H, hipStream_t stream);  // RRBS: up to 16 tasks of one window per wave

@@ -181,6 +181,14 @@ int bsx_batch_sync(bsx_batch *b);
 int bsx_batch_set_leak_exact(bsx_batch *b, int on);
 int bsx_batch_set_history(bsx_batch *b, uint32_t n, const char *seqs_a, const uint64_t *off_a, const char *quals_a, const char *seqs_b,
                           const uint64_t *off_b, const char *quals_b);
+/* The same state as an explicit value, for callers that cut an input into batches: `bsx_batch_get_leak_state` returns the planner state
+ * behind the last read of the batch's streams (history, then every unit of the batch; a pure function of those reads and of the state
+ * before them), `bsx_batch_set_leak_state` makes a state the one before the streams' first read (null: the zero state of a fresh
+ * SingleAlign object).  Chaining get -> set from batch to batch reproduces `bsmap -p 1` for any input, however far back the read
+ * that set a value lies; no history needs to be attached then.  BSX_LEAK_STATE_BYTES bytes, opaque. */
+#define BSX_LEAK_STATE_BYTES 2576
+int bsx_batch_set_leak_state(bsx_batch *b, const void *state, size_t bytes);
+int bsx_batch_get_leak_state(bsx_batch *b, void *state, size_t bytes);
 float bsx_batch_kernel_ms(bsx_batch *b);          /* HIP-event time of the last run's align kernel (after sync) */
 /* the scan kernel's launches of the last run: their number and the sum of their HIP-event durations on the stream they
  * were launched on (control kernels of the other unit group may run beside them on another stream) */

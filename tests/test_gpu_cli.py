@@ -319,3 +319,27 @@ def test_c1_at_baseline_size_matches_reference_binary(tmp_path):
     got = _body(open(out).read())
     diff = sum(a != b for a, b in zip(got, exp)) + abs(len(got) - len(exp))
     assert diff <= 40, diff
+
+
+LEAKRUN = json.load(gzip.open(os.path.join(G.GOLDEN, "cli_leakrun.json.gz"), "rt"))
+
+
+@pytest.mark.parametrize("key", sorted(LEAKRUN))
+@pytest.mark.parametrize("env", [{"BSX_BATCH": "50"}, {"BSX_BATCH": "31", "BSX_GPU_BATCHES": "3"}, {"BSX_BATCH": "64", "G": "0,0"}])
+def test_cli_exact_mode_state_crosses_many_batches(key, env, tmp_path):
+    """runs of 90-260 consecutive reads that never set the planner's start offset, behind one read that does, cut into batches of a
+    few dozen reads: the state (offset and the tail entries of seed_array a long read wrote) has to travel through several batches —
+    further than any fixed window of earlier reads.  The command line hands it from batch to batch as a value (bsx_batch_get/set_leak_state),
+    also across device batches and GPU replicas.  Byte-identical to the REAL `bsmap -p 1` (tests/golden/make_golden_leakrun.py)."""
+    case = LEAKRUN[key]
+    meta = dict(kind=case["kind"], reads=case["reads"], kw={})
+    files = _write_fastq(meta, tmp_path, "lr")
+    out = str(tmp_path / "o.sam")
+    env = dict(env)
+    extra = ["-G", env.pop("G")] if "G" in env else []
+    _run_cli(meta, os.path.join(G.GOLDEN, "genome_wgbs.fa"), files, out, case["options"] + ["-p", "2"] + extra, dict(env, BSX_P1_EXACT="1"))
+    assert _body(open(out).read()) == _body(case["out"])
+    if case.get("differ"):   # the input really needs the state: without the mode some of those reads come out differently
+        plain = str(tmp_path / "plain.sam")
+        _run_cli(meta, os.path.join(G.GOLDEN, "genome_wgbs.fa"), files, plain, case["options"] + ["-p", "2"], {"BSX_BATCH": "50"})
+        assert _body(open(plain).read()) != _body(case["out"])

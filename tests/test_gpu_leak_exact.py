@@ -150,3 +150,129 @@ def test_exact_mode_history_and_variable_lengths(pe, oracle):
         for b in (whole, half, plain):
             b.close()
     al.free(); gref.close(); oref.free()
+
+
+@pytest.mark.parametrize("pe", [False, True])
+def test_exact_mode_state_chained_from_batch_to_batch(pe, oracle):
+    """an input cut into four batches of unequal size, each started from the state the one before it returns
+    (bsx_batch_get_leak_state -> bsx_batch_set_leak_state), equals the whole input in one batch and the oracle in call order — with a
+    setter that lies thousands of reads back (one long read, then only reads that never set the offset)"""
+    g = td.make_genome(seed=23, chr_lens=(120_000,), gc=0.45)
+    fasta = td.fasta_text(g)
+    kw = dict(s=16, v=4, I=4, S=2, r=1, n=1) if not pe else dict(s=16, v=6, I=4, S=2, r=1, m=28, x=500, pairend=1)
+    oref = oracle.OracleRef(oracle.make_params(**kw), fasta_text=fasta)
+    gref = B.RefSeq(B.make_params(**kw)).Run_ConvertBinseq(fasta_text=fasta).CreateIndex()
+    rng = np.random.default_rng(8)
+    n = 6000
+    leaky = [131, 115, 99, 83, 67, 51]
+    la = [144, 143, 142, 141, 140] + [int(x) for x in rng.choice(leaky, n - 5)]
+    lb = [140, 144, 139, 138, 137] + [int(x) for x in rng.choice(leaky, n - 5)]
+    la[4000], lb[2500] = 100, 126   # one more setter per stream late in the input (the offsets they leave differ)
+    cuts = [0, 1700, 1701, 4300, n]
+
+    def offset_setters(seqs, readset):
+        """full-length reads whose planned start offsets are all > 0 (so the offset they leave behind is not the initial 0): on a small
+        random genome most reads tie at offset 0 (first minimum wins, align.cpp:462), and a state of 0 would test nothing"""
+        al = oracle.OracleAligner(oref, 0)
+        good = []
+        for i, sq in enumerate(seqs[:1500]):
+            if len(sq) < 144:
+                continue
+            o = al.se(i, sq, readset=readset)
+            st = list(o.cseed_start_array if readset == 2 else o.seed_start_array)[:max(1, o.seedseg_num)]
+            if not o.filtered and min(st) > 0:
+                good.append(sq)
+        al.free()
+        return good
+
+    if pe:
+        pairs = td.make_pe_reads(g, n, 144, seed=12)
+        g1, g2 = offset_setters([p["seq1"] for p in pairs], 1), offset_setters([p["seq2"] for p in pairs], 2)
+        assert g1 and g2
+        for k, pos in enumerate((4, 4000)):
+            pairs[pos]["seq1"], la[pos] = g1[k % len(g1)], 144
+        for k, pos in enumerate((4, 2500)):
+            pairs[pos]["seq2"], lb[pos] = g2[k % len(g2)], 144
+        s1 = [p["seq1"][:l] for p, l in zip(pairs, la)]
+        s2 = [p["seq2"][:l] for p, l in zip(pairs, lb)]
+        b1, o1 = oracle.pack_reads(s1)
+        b2, o2 = oracle.pack_reads(s2)
+        exp, ecnt = oracle.pe_batch(oref, b1, o1, b2, o2, threads=4, leak_mode=1)
+        whole = B.PairAlign(gref, n).set_leak_exact()
+        whole.ImportBatchReads(s1, s2).Do_Batch()
+        out, ca, cb, npairs = whole.results()
+        assert [int(x) for x in whole.counters()[:4]] == ecnt
+        assert np.array_equal(exp["paired"], out["paired"]) and np.array_equal(exp["a"]["n_hit"][:, :7], ca["n_hit"][:, :7]) and np.array_equal(exp["b"]["n_chit"][:, :7], cb["n_chit"][:, :7])
+        st = None
+        part = B.PairAlign(gref, n).set_leak_exact()
+        for lo, hi in zip(cuts, cuts[1:]):
+            part.set_leak_state(st)
+            part.ImportBatchReads(s1[lo:hi], s2[lo:hi], first_index=lo).Do_Batch()
+            o_, a_, b_, n_ = part.results()
+            assert o_.tobytes() == out[lo:hi].tobytes() and a_.tobytes() == ca[lo:hi].tobytes() and b_.tobytes() == cb[lo:hi].tobytes(), lo
+            st = part.get_leak_state()
+        assert st.tobytes() == whole.get_leak_state().tobytes() and st.any()
+        plain = B.PairAlign(gref, n)
+        plain.ImportBatchReads(s1, s2).Do_Batch()
+        assert [int(x) for x in plain.counters()[:3]] != ecnt[:3]   # the plans differ (the hits they lead to need not)
+        for b in (whole, part, plain):
+            b.close()
+    else:
+        reads = td.make_se_reads(g, n, 144, seed=12, junk_frac=0.0)
+        good = offset_setters([r["seq"] for r in reads], 0)
+        assert good
+        for k, pos in enumerate((4, 4000)):
+            reads[pos]["seq"], la[pos] = good[k % len(good)], 144
+        ss = [r["seq"][:l] for r, l in zip(reads, la)]
+        b1, o1 = oracle.pack_reads(ss)
+        exp, ecnt = oracle.se_batch(oref, b1, o1, threads=4, leak_mode=1)
+        whole = B.SingleAlign(gref, n).set_leak_exact()
+        whole.ImportBatchReads(ss).Do_Batch()
+        hits, cc = whole.results()
+        assert [int(x) for x in whole.counters()[:4]] == ecnt
+        assert np.array_equal(exp["n_hit"][:, :5], cc["n_hit"][:, :5]) and np.array_equal(exp["n_chit"][:, :5], cc["n_chit"][:, :5])
+        st = None
+        part = B.SingleAlign(gref, n).set_leak_exact()
+        for lo, hi in zip(cuts, cuts[1:]):
+            part.set_leak_state(st)
+            part.ImportBatchReads(ss[lo:hi], first_index=lo).Do_Batch()
+            h_, c_ = part.results()
+            assert h_.tobytes() == hits[lo:hi].tobytes() and c_.tobytes() == cc[lo:hi].tobytes(), lo
+            st = part.get_leak_state()
+        assert st.tobytes() == whole.get_leak_state().tobytes() and st.any()
+        plain = B.SingleAlign(gref, n)
+        plain.ImportBatchReads(ss).Do_Batch()
+        assert [int(x) for x in plain.counters()[:3]] != ecnt[:3]   # the plans differ (the hits they lead to need not)
+        for b in (whole, part, plain):
+            b.close()
+    gref.close(); oref.free()
+
+
+def test_exact_mode_when_no_read_ever_sets_the_offset():
+    """uniform 51-nt reads with -s 16 -I 4: (len - I + 1) % S == 0 for every read, nothing ever sets the start offset and nothing writes
+    the tail entries — the search for a setter must give up through the block summaries, not walk the whole stream for every read
+    (2^18 reads: a per-read walk is 10^10 steps); the state stays the initial one, so the records equal the default mode's"""
+    import time
+    g = td.make_genome(seed=24, chr_lens=(200_000,), gc=0.5)
+    kw = dict(s=16, v=2, I=4, S=1, r=1)
+    gref = B.RefSeq(B.make_params(**kw)).Run_ConvertBinseq(fasta_text=td.fasta_text(g)).CreateIndex()
+    n = 1 << 18
+    base = td.make_se_reads(g, 4096, 51, seed=3, junk_frac=0.0)
+    ss = [base[i % 4096]["seq"] for i in range(n)]
+    ex = B.SingleAlign(gref, n).set_leak_exact()
+    ex.ImportBatchReads(ss)
+    ex.Do_Batch()
+    t0 = time.time()
+    ex.Do_Batch()
+    dt = time.time() - t0
+    h1, c1 = ex.results()
+    pl = B.SingleAlign(gref, n)
+    pl.ImportBatchReads(ss).Do_Batch()
+    h2, c2 = pl.results()
+    assert h1.tobytes() == h2.tobytes() and c1.tobytes() == c2.tobytes()
+    st = ex.get_leak_state().view(np.uint32)
+    assert not st[2 * 2 * 160:].any()                      # no start offset was ever set
+    key00 = st[:160]                                       # mate stream 0, forward orientation: the last read's hashes, nothing behind them
+    assert key00[:51 - 16 + 1].any() and not key00[51 - 16 + 1:].any()
+    assert dt < 5.0, dt
+    ex.close(); pl.close(); gref.close()
