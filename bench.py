@@ -106,6 +106,8 @@ def main():
     ap.add_argument("--mode", default="pe", choices=sorted(MODES), help="pe = C3 (default, the metric's config); se = C2; rrbs = C4; trim = C5")
     ap.add_argument("--profile-serial", action="store_true", help="profiling mode: one batch in flight, one unit group (control and scan passes "
                     "strictly alternate), no CPU / end-to-end / transfer legs — no two kernels overlap, so per-kernel durations add up to at most the step time")
+    ap.add_argument("--exact", action="store_true", help="run with bsx_batch_set_leak_exact (the single-threaded reference's planner state for every read): "
+                    "the line then includes the pre-pass that finds that state (k_leak_meta / k_leak_resolve)")
     ap.add_argument("--sensitivity", type=int, default=1, help="1: also run the workload on two variants of the synthetic genome (microsatellite share halved; no repeat "
                     "elements) — the headline depends on the generator's repeat content; 0 = skip")
     ap.add_argument("--selftest-launch", action="store_true", help=argparse.SUPPRESS)
@@ -160,6 +162,9 @@ def main():
     Align = B.PairAlign if pe else B.SingleAlign
     t0 = time.time()
     batches = [Align(ref, n_total) for _ in range(nfl)]
+    if args.exact:
+        for bt in batches:
+            bt.set_leak_exact()
     t_batches = time.time() - t0
     batch = batches[0]
     # reads are sharded by rank: unit ids of rank r start at r * n_total (independent units, no data-path collective);
@@ -257,7 +262,7 @@ def main():
         "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u32", "data": "synthetic" if not real_fa else "synthetic reads sampled from " + os.path.basename(real_fa),
         "config": {"workload": M["workload"], "pairs_per_step" if pe else "reads_per_step": B_, "genome_bp": int(sum(lens)), "index_entries": int(ref.n_entries),
-                   "parallelism": f"read-sharded x{world}", "batches_in_flight": nfl, "lib_sha16": sha,
+                   "parallelism": f"read-sharded x{world}", "batches_in_flight": nfl, "lib_sha16": sha, "exact_mode": bool(args.exact),
                    "setup_s": {"genome": round(t_gen, 2), "index_build_gpu": round(t_index, 2), "device_batches": round(t_batches, 2)},
                    "aligned_fraction": float((2 * tot_counters[6] + tot_counters[5]) / max(1.0, n_reads_rank * world)) if pe
                    else float(tot_counters[5] / max(1.0, n_reads_rank * world))},

@@ -13,6 +13,7 @@
 // (bsx_bam_out.h).
 // Parsing, the GPU, formatting (-p threads) and writing run as a pipeline over a ring of batches; the output is always
 // in input order (the reference's order is nondeterministic for -p > 1).
+#include <sys/resource.h>
 #include <algorithm>
 #include <chrono>
 #include <condition_variable>
@@ -216,15 +217,51 @@ struct Rd {
     void reverse_qual() { reverse(qual, qual + qlen); }
 };
 
-// append-only text buffer with the few conversions the SAM/BSP lines need (same digits as printf's %d / %u)
+// append-only text buffer with the few conversions the SAM/BSP lines need (same digits as printf's %d / %u).  A plain byte array with
+// inlined appends: through std::string::append (a library call per field, a terminator per character) the formatters spent a
+// microsecond per read, 25 calls each — formatting was the slowest stage of the command line (12.6 M reads/s on 12 workers).
+struct TextBuf {
+    char *p = nullptr;
+    size_t n = 0, cap = 0;
+    TextBuf() {}
+    TextBuf(const TextBuf &) = delete;
+    TextBuf &operator=(const TextBuf &) = delete;
+    TextBuf(TextBuf &&o) noexcept : p(o.p), n(o.n), cap(o.cap) { o.p = nullptr; o.n = o.cap = 0; }
+    TextBuf &operator=(TextBuf &&o) noexcept { if (this != &o) { free(p); p = o.p; n = o.n; cap = o.cap; o.p = nullptr; o.n = o.cap = 0; } return *this; }
+    ~TextBuf() { free(p); }
+    void reserve(size_t c)
+    {
+        if (c <= cap) return;
+        size_t nc = cap ? cap : 4096;
+        while (nc < c) nc += nc / 2 + 4096;
+        char *q = nullptr;
+        if (nc >= (8u << 20)) {   // big buffers: 2 MB aligned and advised huge — a fresh 80 MB buffer per worker and ring slot is 20 000 page faults otherwise
+            nc = (nc + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1);
+            if (posix_memalign((void **)&q, 2u << 20, nc)) q = nullptr;
+            if (q) { madvise(q, nc, MADV_HUGEPAGE); if (n) memcpy(q, p, n); free(p); }
+        } else q = (char *)realloc(p, nc);
+        if (!q) { cerr << "out of memory (text buffer)\n"; exit(1); }
+        p = q; cap = nc;
+    }
+    void clear() { n = 0; }
+    bool empty() const { return n == 0; }
+    size_t size() const { return n; }
+    const char *data() const { return p; }
+};
 struct Text {
-    string s;
-    void put(const char *p, size_t n) { s.append(p, n); }
-    void put(const char *z) { s.append(z); }
-    void put(const string &z) { s.append(z); }
-    void put(char c) { s.push_back(c); }
-    void put_u(uint64_t v) { char b[24]; int n = 0; do { b[n++] = (char)('0' + v % 10); v /= 10; } while (v); while (n) s.push_back(b[--n]); }
-    void put_i(int64_t v) { if (v < 0) { s.push_back('-'); put_u((uint64_t)(-v)); } else put_u((uint64_t)v); }
+    TextBuf s;
+    inline void need(size_t k) { if (s.n + k > s.cap) s.reserve(s.n + k); }
+    inline void put(const char *q, size_t k) { need(k); memcpy(s.p + s.n, q, k); s.n += k; }
+    template <size_t N> inline void put(const char (&z)[N]) { need(N - 1); memcpy(s.p + s.n, z, N - 1); s.n += N - 1; }  // string literals: the length is known
+    inline void put(const string &z) { put(z.data(), z.size()); }
+    inline void put(char c) { need(1); s.p[s.n++] = c; }
+    inline void put_u(uint64_t v)
+    {
+        char b[24]; int k = 24;
+        do { b[--k] = (char)('0' + v % 10); v /= 10; } while (v);
+        put(b + k, (size_t)(24 - k));
+    }
+    inline void put_i(int64_t v) { if (v < 0) { put('-'); put_u((uint64_t)(-v)); } else put_u((uint64_t)v); }
 };
 
 struct Formatter {
@@ -564,7 +601,7 @@ int main(int argc, char **argv)
         h.put("@HD\tVN:1.0\n");
         for (uint32_t c = 0; c < n_chr; c++) { h.put("@SQ\tSN:"); h.put(rv.names[c]); h.put("\tLN:"); h.put_u(rv.chr_size[c]); h.put('\n'); }
         h.put("@PG\tID:BSMAP_"); h.put(version); h.put('\n');
-        if (bam_out) bam.open(o.out_file, h.s, rv.names, rv.chr_size);
+        if (bam_out) bam.open(o.out_file, string(h.s.data(), h.s.size()), rv.names, rv.chr_size);
         else {
             write_all(fout, h.s.data(), h.s.size(), 0);
             off_out = (off_t)h.s.size();
@@ -599,6 +636,7 @@ int main(int argc, char **argv)
     double busy[4] = {0, 0, 0, 0}, gpu_part[3] = {0, 0, 0};  // gpu_part: upload, align, read-back
     t_pin.join();
     const double t_map0 = now_s();
+    struct rusage ru0; getrusage(RUSAGE_SELF, &ru0);
 
     // BSX_P1_EXACT=1: reproduce the single-threaded reference also for the reads whose planner state leaks from earlier
     // reads (bsx_batch_set_leak_exact).  The state is handed from batch to batch as a value: batch k starts from the state
@@ -690,7 +728,7 @@ int main(int argc, char **argv)
             Slot &s = ring.at(k);
             const int W = (int)min<size_t>((size_t)workers, max<size_t>(1, s.n / 1024));
             // the slot's text buffers keep their capacity from batch to batch (a fresh 0.7 GB per batch would be page-faulted in again)
-            if ((int)s.out.size() != W) { s.out.assign(W, Text()); s.out_unpair.assign(W, Text()); }
+            if ((int)s.out.size() != W) { s.out.clear(); s.out_unpair.clear(); s.out.resize(W); s.out_unpair.resize(W); }
             else for (int w = 0; w < W; w++) { s.out[w].s.clear(); s.out_unpair[w].s.clear(); }
             vector<Formatter> fm(W, Formatter(o, rv));
             auto work = [&](int w) {
@@ -766,6 +804,9 @@ int main(int argc, char **argv)
         bam.finish();
     }
     const double t_map1 = now_s();
+    struct rusage ru1; getrusage(RUSAGE_SELF, &ru1);
+    const double ru_user = (ru1.ru_utime.tv_sec - ru0.ru_utime.tv_sec) + 1e-6 * (ru1.ru_utime.tv_usec - ru0.ru_utime.tv_usec),
+                 ru_sys = (ru1.ru_stime.tv_sec - ru0.ru_stime.tv_sec) + 1e-6 * (ru1.ru_stime.tv_usec - ru0.ru_stime.tv_usec);
     const Formatter &fmt = totals;
     char pct[64];
     if (pe) {
@@ -785,9 +826,10 @@ int main(int argc, char **argv)
     cout << "Finished at " << ctime(&t_end);
     cout << "Total time consumed:  " << t_end - t_begin << " secs\n";
     if (getenv("BSX_TIMING"))  // machine-readable phase times (extension; stderr so that stdout keeps the reference's lines)
-        fprintf(stderr, "{\"load_reference_s\": %.3f, \"index_build_s\": %.3f, \"mapping_s\": %.3f, \"units\": %u, \"reads\": %u, \"workers\": %d, "
+        fprintf(stderr, "{\"load_reference_s\": %.3f, \"index_build_s\": %.3f, \"mapping_s\": %.3f, \"units\": %u, \"reads\": %u, \"workers\": %d, \"usable_cpus\": %u, "
+                        "\"mapping_cpu_s\": {\"user\": %.2f, \"sys\": %.2f}, "
                         "\"stage_busy_s\": {\"parse\": %.3f, \"gpu\": %.3f, \"format\": %.3f, \"write\": %.3f, \"gpu_upload\": %.3f, \"gpu_align\": %.3f, \"gpu_readback\": %.3f}}\n",
-                t_loaded - t0, t_indexed - t_loaded, t_map1 - t_map0, total, pe ? 2 * total : total, workers, busy[0], busy[1], busy[2], busy[3], gpu_part[0], gpu_part[1], gpu_part[2]);
+                t_loaded - t0, t_indexed - t_loaded, t_map1 - t_map0, total, pe ? 2 * total : total, workers, ncpu, ru_user, ru_sys, busy[0], busy[1], busy[2], busy[3], gpu_part[0], gpu_part[1], gpu_part[2]);
     for (int g = 0; g < NG; g++) bsx_batch_destroy(batches[g]);
     for (bsx_ref *r : refs) bsx_ref_destroy(r);
     return 0;

@@ -133,12 +133,21 @@ inline bool sam_to_bam(const char *s, size_t n, const std::unordered_map<std::st
     return true;
 }
 
+// every write of the BAM / run / index files is checked: a full disk ends the run with a message and a non-zero exit code instead of a
+// truncated file behind the usual closing lines (the reference's sam2bam.sh fails loudly there)
+inline void wr(const void *p, size_t size, size_t n, FILE *f, const char *what)
+{
+    if (n && fwrite(p, size, n, f) != n) { fprintf(stderr, "bsx: write error on %s\n", what); exit(1); }
+}
+inline void cl(FILE *f, const char *what) { if (fclose(f) != 0) { fprintf(stderr, "bsx: write error on %s\n", what); exit(1); } }
+
 // BGZF writer (SAM spec §4.1; samtools bgzf.c): gzip members with the BC extra field, <= 64 KB each
 class Bgzf {
     FILE *fp = nullptr;
     std::vector<uint8_t> buf, out;
     uint64_t file_pos = 0;
-    static const size_t BLOCK = 0xff00;
+    static const size_t BLOCK = 0x10000;  // samtools 0.1.7a: DEFAULT_BLOCK_SIZE = 64 * 1024 uncompressed bytes per block (bgzf.c:56)
+    bool failed = false;
 public:
     bool open(const std::string &path) { fp = fopen(path.c_str(), "wb"); buf.reserve(BLOCK); out.resize(0x10000 + 64); return fp != nullptr; }
     uint64_t tell() const { return file_pos << 16 | (uint64_t)buf.size(); }  // virtual offset of the next byte (bam_tell)
@@ -150,7 +159,7 @@ public:
             memset(&zs, 0, sizeof zs);
             deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
             zs.next_in = buf.data(); zs.avail_in = (uInt)take;
-            zs.next_out = out.data() + 18; zs.avail_out = (uInt)(0x10000 - 18 - 8);
+            zs.next_out = out.data() + 18; zs.avail_out = (uInt)(0x10000 - 18 - 8);  // MAX_BLOCK_SIZE less header and footer (bgzf.c:266)
             const int st = deflate(&zs, Z_FINISH);
             const size_t clen = zs.total_out;
             deflateEnd(&zs);
@@ -161,7 +170,7 @@ public:
             memcpy(out.data() + 16, &bsize, 2);
             const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), buf.data(), (uInt)take), isz = (uint32_t)take;
             memcpy(out.data() + 18 + clen, &crc, 4); memcpy(out.data() + 18 + clen + 4, &isz, 4);
-            fwrite(out.data(), 1, clen + 26, fp);
+            if (fwrite(out.data(), 1, clen + 26, fp) != clen + 26) failed = true;  // (a full disk must not leave a truncated file behind a zero exit code)
             file_pos += clen + 26;
             buf.erase(buf.begin(), buf.begin() + (long)take);
             return;
@@ -182,8 +191,8 @@ public:
     {
         flush();
         static const uint8_t eof[28] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 66, 67, 2, 0, 27, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        fwrite(eof, 1, 28, fp);
-        const bool ok = fclose(fp) == 0;
+        if (fwrite(eof, 1, 28, fp) != 28) failed = true;
+        const bool ok = (fclose(fp) == 0) && !failed;
         fp = nullptr;
         return ok;
     }
@@ -196,7 +205,7 @@ class Sink {
     std::vector<uint32_t> lens;
     std::string header_text;
     std::unordered_map<std::string, int> tids;
-    struct Item { uint64_t key, seq; uint32_t off, len; };
+    struct Item { uint64_t key, seq; uint32_t off, len; };  // off: 32 bits, so the arena stays below 4 GiB (budget clamped in open())
     std::vector<uint8_t> arena;
     std::vector<Item> items;
     std::vector<std::string> runs;
@@ -213,8 +222,8 @@ class Sink {
         const std::string rp = path + ".run" + std::to_string(runs.size());
         FILE *f = fopen(rp.c_str(), "wb");
         if (!f) { fprintf(stderr, "cannot create %s\n", rp.c_str()); exit(1); }
-        for (const Item &it : items) { fwrite(&it.len, 4, 1, f); fwrite(arena.data() + it.off, 1, it.len, f); }
-        fclose(f);
+        for (const Item &it : items) { wr(&it.len, 4, 1, f, rp.c_str()); wr(arena.data() + it.off, 1, it.len, f, rp.c_str()); }
+        cl(f, rp.c_str());
         runs.push_back(rp);
         items.clear(); arena.clear();
     }
@@ -233,6 +242,7 @@ public:
         path = bam_path; header_text = sam_header; names = ref_names; lens = ref_lens;
         for (size_t i = 0; i < names.size(); i++) tids.emplace(names[i], (int)i);  // bam_get_tid: the first target of a name wins
         budget = getenv("BSX_BAM_SORT_MEM") ? (size_t)atoll(getenv("BSX_BAM_SORT_MEM")) : ((size_t)1 << 30);
+        budget = std::min(budget, (size_t)0xfff00000u);  // Item::off is 32 bits
     }
     void add_text(const char *s, size_t n)  // whole lines, possibly with a partial one at the end
     {
@@ -315,7 +325,7 @@ public:
             for (size_t i = 0; i < runs.size(); i++) { fclose(R[i].f); remove(runs[i].c_str()); }
         }
         if (save_tid >= 0 && save_bin != 0xffffffffu) bins[(size_t)save_tid][save_bin].emplace_back(save_off, bz.tell());
-        bz.close();
+        if (!bz.close()) { fprintf(stderr, "bsx: write error on %s\n", path.c_str()); exit(1); }
         // merge_chunks: chunks of a bin that touch inside one BGZF block become one
         for (auto &rb : bins)
             for (auto &kv : rb) {
@@ -326,22 +336,22 @@ public:
             }
         FILE *f = fopen((path + ".bai").c_str(), "wb");
         if (!f) { fprintf(stderr, "cannot create %s.bai\n", path.c_str()); exit(1); }
-        fwrite("BAI\1", 1, 4, f);
+        wr("BAI\1", 1, 4, f, "the .bai index");
         const int32_t nr = (int32_t)n_ref;
-        fwrite(&nr, 4, 1, f);
+        wr(&nr, 4, 1, f, "the .bai index");
         for (size_t t = 0; t < n_ref; t++) {
             const int32_t nb = (int32_t)bins[t].size();
-            fwrite(&nb, 4, 1, f);
+            wr(&nb, 4, 1, f, "the .bai index");
             for (const auto &kv : bins[t]) {
                 const uint32_t b = kv.first; const int32_t nc = (int32_t)kv.second.size();
-                fwrite(&b, 4, 1, f); fwrite(&nc, 4, 1, f);
-                for (const auto &c : kv.second) { fwrite(&c.first, 8, 1, f); fwrite(&c.second, 8, 1, f); }
+                wr(&b, 4, 1, f, "the .bai index"); wr(&nc, 4, 1, f, "the .bai index");
+                for (const auto &c : kv.second) { wr(&c.first, 8, 1, f, "the .bai index"); wr(&c.second, 8, 1, f, "the .bai index"); }
             }
             const int32_t ni = (int32_t)lin[t].size();
-            fwrite(&ni, 4, 1, f);
-            if (ni) fwrite(lin[t].data(), 8, (size_t)ni, f);
+            wr(&ni, 4, 1, f, "the .bai index");
+            if (ni) wr(lin[t].data(), 8, (size_t)ni, f, "the .bai index");
         }
-        fclose(f);
+        cl(f, "the .bai index");
     }
 };
 

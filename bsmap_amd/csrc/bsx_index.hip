@@ -140,6 +140,9 @@ int bsx_index_build_rrbs(bsx_ref *r, const std::vector<uint32_t> &refcat, const 
     const bsx_params &P = r->P;
     HIP_TRY(hipSetDevice(r->device));
     const uint32_t K = P.total_kmers, S = P.seed_size;
+    // the kernels take a read's candidates from the (segment, direction) group of its bucket: 16 segments per direction (RRBS forces
+    // seed 12, i.e. 12 segments of a 144-nt read; a shorter seed would need more groups than the table has)
+    if (P.max_seedseg_num > 16) { g_bsx_err = "RRBS index: more than 16 seed segments per read"; return BSX_ERR_LIMIT; }
     auto seed_at = [&](uint32_t chr, uint32_t loc) {
         const uint32_t *m = ((chr & 1) ? crefcat.data() : refcat.data()) + r->anchor[chr >> 1] / BSX_SEGLEN + (loc >> 4);
         const uint64_t v = ((uint64_t)m[0] << 32) | m[1];
@@ -176,7 +179,7 @@ int bsx_index_build_rrbs(bsx_ref *r, const std::vector<uint32_t> &refcat, const 
     // the entries of one group is unchanged, and that is all the reference's loop observes — with an offset table per
     // (bucket, group), so a read's candidates are one contiguous range (24 x fewer entries streamed at hg38 size).
     // bsx_index_download still returns the reference's own order (kept on the host).
-    bool grouped = P.max_seedseg_num <= 16;
+    const bool grouped = true;
     std::vector<uint32_t> goff, gent;
     if (grouped) {
         goff.assign((size_t)K * 32 + 1, 0);

@@ -167,7 +167,12 @@ int bsx_batch_synth_reads(bsx_batch *b, uint32_t n, uint32_t read_len, uint64_t 
  * at Q2-Q15, 30 % of the fragments 30-149 nt long so that the reads run into the adapter AGATCGGAAGAGC...; 2 RRBS — single
  * reads that start at the digestion sites of an RRBS reference, fragments read_len..220 nt */
 int bsx_batch_synth_reads_kind(bsx_batch *b, uint32_t n, uint32_t read_len, uint64_t seed, uint32_t first_index, int kind);
-/* Do_Batch (align.cpp:591-606 / pairs.cpp:192-218): asynchronous launch on the batch's HIP stream */
+/* Do_Batch (align.cpp:591-606 / pairs.cpp:192-218).  The main kernel is queued on the batch's HIP stream.  Units it hands to the heavy
+ * pipeline (reads whose candidate lists run into the tens of thousands) are then taken through passes of control and scan kernels that
+ * are chained on the device; the calling thread queues those passes and looks at one counter per two passes to learn when the batch
+ * is finished — it SLEEPS on an event meanwhile, it does not spin — so the call returns when the last pass is queued, which for such a
+ * batch is close to the end of its device work.  bsx_batch_sync waits for the rest.  To keep a GPU busy through the latency-bound tail
+ * of a batch, run two batches per GPU from two host threads (bench.py, the command line): their kernels interleave on the device. */
 int bsx_batch_run(bsx_batch *b);
 /* the same over units [first_unit, first_unit+n_units) of the uploaded batch (ReadInf.index = first_index + unit) */
 int bsx_batch_run_range(bsx_batch *b, uint32_t first_unit, uint32_t n_units);

@@ -55,3 +55,22 @@ def test_bam_sink_equals_vendored_samtools(key, mem, harness, tmp_path):
     subprocess.run([harness, str(sam), out, "777"], check=True, env=env, timeout=120)
     assert compare_with_gold(out, GOLD[key]) > 300
     assert not [f for f in os.listdir(tmp_path) if ".run" in f]
+
+
+def test_bam_and_bai_bytes_equal_vendored_samtools_on_a_multi_block_file(harness, tmp_path):
+    """the BGZF writer cuts its blocks where samtools 0.1.7a does (64 KiB of uncompressed data, shrinking by 1 KiB when a block does
+    not compress into 64 KiB: bgzf.c:56,281), so the files — not only the records — are the ones `sam2bam.sh` leaves: x.bam and its
+    .bai compared by SHA-256 with the vendored samtools' output on a file of several blocks (tests/golden/make_golden_bam_multiblock.py)"""
+    import hashlib
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_golden_bam_multiblock as M
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "bam_multiblock.json")))
+    sam = tmp_path / "in.sam"
+    sam.write_text(M.big_sam())
+    out = str(tmp_path / "x.bam")
+    subprocess.run([harness, str(sam), out, "777"], check=True, timeout=120)
+    for n, path in (("x.bam", out), ("x.bam.bai", out + ".bai")):
+        b = open(path, "rb").read()
+        assert len(b) == gold[n]["bytes"] and hashlib.sha256(b).hexdigest() == gold[n]["sha256"], n
+    assert gold["x.bam"]["bytes"] > 100_000   # several BGZF blocks
