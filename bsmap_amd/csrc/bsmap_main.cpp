@@ -630,7 +630,9 @@ int main(int argc, char **argv)
     // format workers: the CPUs this process may use (affinity mask and cgroup quota, not the hardware thread count) less the
     // parse, GPU-driver and write threads; oversubscribing a quota throttles every thread, the ones feeding the GPU included
     const unsigned ncpu = bsx_usable_cpus();
-    const int workers = o.num_procs > 0 ? o.num_procs : (int)min(64u, max(1u, ncpu > 8 ? ncpu - 4 : ncpu));
+    // (measured on the 16-CPU quota of the GPU boxes with the GPU stage nearly free, tools/host_threads.sh: 10 workers 10.0 M reads/s, 12: 10.6,
+    //  14: 12.8 — the driver threads of the device batches sleep on events and the two parse threads are light)
+    const int workers = o.num_procs > 0 ? o.num_procs : (int)min(64u, max(1u, ncpu > 4 ? ncpu - 2 : ncpu));
     Formatter totals(o, rv);
     unsigned total = 0;
     double busy[4] = {0, 0, 0, 0}, gpu_part[3] = {0, 0, 0};  // gpu_part: upload, align, read-back

@@ -231,7 +231,7 @@ struct bsx_batch {
     } grp[BSX_MAX_GROUPS];
     int n_groups = 1, chunk_passes = 2, trace = 0, hctrl_blocks_per_cu = 1;
     uint32_t bin_shift = 0, n_bins = 1;
-    hipEvent_t ev_sync = nullptr;
+    hipEvent_t ev_sync = nullptr, ev_wait = nullptr;
     std::vector<hipEvent_t> scan_ev;  // pairs of timing events around every k_hscan launch of the last run (pool grows on demand)
     size_t scan_ev_used = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -262,6 +262,11 @@ struct bsx_batch {
     bool ran = false;
 };
 
+// wait for everything queued on the batch's stream WITHOUT spinning: hipStreamSynchronize busy-waits, and the driver threads of a
+// command line share a CPU quota with its format and write workers — an event with the blocking-sync flag lets the
+// thread sleep
+static hipError_t stream_wait(bsx_batch *b);
+
 // duplicate-suppression set of one mate slab (Slab in bsx_align.hip).  WGBS and paired RRBS: every remembered coordinate is a
 // hit, the -w caps bound them.  Single-end RRBS also remembers the coordinates its fragment-size filter rejects
 // (align.cpp:201-207), which nothing caps: a poly-T read of the hg38-sized genome collects thousands — 2^18 keys, 2^19 slots.
@@ -284,6 +289,14 @@ static uint64_t slab_size(const bsx_params &p, int paired, uint32_t rowcap, bool
     uint64_t s = mate;
     if (paired) s = 2 * mate + (2 * (uint64_t)p.max_snp_num + 2) * rowcap * 24;
     return (s + 255) & ~255ull;
+}
+
+static hipError_t stream_wait(bsx_batch *b)
+{
+    if (!b->ev_wait) return hipStreamSynchronize(b->stream);
+    hipError_t e = hipEventRecord(b->ev_wait, b->stream);
+    if (e != hipSuccess) return e;
+    return hipEventSynchronize(b->ev_wait);
 }
 
 static int ensure_scratch(bsx_batch *b)
@@ -391,6 +404,7 @@ extern "C" int bsx_batch_create(bsx_ref *r, uint32_t max_units, int paired, bsx_
                 if (hipEventCreateWithFlags(&q.ev_poll[k], hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) return fail(BSX_ERR_DEVICE);
         }
         if (hipEventCreateWithFlags(&b->ev_sync, hipEventDisableTiming) != hipSuccess) return fail(BSX_ERR_DEVICE);
+        if (hipEventCreateWithFlags(&b->ev_wait, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) return fail(BSX_ERR_DEVICE);
     }
     if (hipEventCreate(&b->ev0) != hipSuccess || hipEventCreate(&b->ev1) != hipSuccess) return fail(BSX_ERR_DEVICE);
     const int nm = b->paired ? 2 : 1;
@@ -436,6 +450,7 @@ extern "C" void bsx_batch_destroy(bsx_batch *b)
         for (void *p_ : {(void *)q.d_bins, (void *)q.d_bstart, (void *)q.d_chunk_tot, (void *)q.d_rank, (void *)q.d_order}) if (p_) (void)hipFree(p_);
     }
     if (b->ev_sync) (void)hipEventDestroy(b->ev_sync);
+    if (b->ev_wait) (void)hipEventDestroy(b->ev_wait);
     for (hipEvent_t e : b->scan_ev) (void)hipEventDestroy(e);
     if (b->stream) (void)hipStreamDestroy(b->stream);
     delete b;
@@ -481,7 +496,7 @@ extern "C" int bsx_batch_upload_se(bsx_batch *b, uint32_t n, const char *seqs, c
     int rc = upload_mate(b, 0, n, seqs, off, quals);
     if (rc) return rc;
     b->n_units = n; b->first_index = first_index; b->has_qual = quals != nullptr; b->leak_meta_valid = false;
-    HIP_TRY(hipStreamSynchronize(b->stream));  // host buffers may be reused by the caller
+    HIP_TRY(stream_wait(b));  // host buffers may be reused by the caller
     return BSX_OK;
 }
 
@@ -495,7 +510,7 @@ extern "C" int bsx_batch_upload_pe(bsx_batch *b, uint32_t n, const char *seqs_a,
     if (rc == BSX_OK) rc = upload_mate(b, 1, n, seqs_b, off_b, quals_b);
     if (rc) return rc;
     b->n_units = n; b->first_index = first_index; b->has_qual = quals_a != nullptr; b->leak_meta_valid = false;
-    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(stream_wait(b));
     return BSX_OK;
 }
 
@@ -512,7 +527,7 @@ extern "C" int bsx_batch_set_history(bsx_batch *b, uint32_t n, const char *seqs_
     if (!b || n > 65536) return BSX_ERR_ARG;
     if (n && (!seqs_a || !off_a || (b->paired && (!seqs_b || !off_b)))) return BSX_ERR_ARG;
     HIP_TRY(hipSetDevice(b->ref->device));
-    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(stream_wait(b));
     const char *sq[2] = {seqs_a, seqs_b}, *ql[2] = {quals_a, quals_b};
     const uint64_t *of[2] = {off_a, off_b};
     for (int m = 0; m < (b->paired ? 2 : 1); m++) {
@@ -577,7 +592,7 @@ extern "C" int bsx_batch_set_leak_state(bsx_batch *b, const void *state, size_t 
 {
     if (!b || (state && bytes != bsx_leakstate_bytes())) return BSX_ERR_ARG;
     HIP_TRY(hipSetDevice(b->ref->device));
-    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(stream_wait(b));
     if (!state) { b->leak_has_init = false; return BSX_OK; }
     if (!b->d_leak_init) HIP_TRY(hipMalloc((void **)&b->d_leak_init, bsx_leakstate_bytes()));
     HIP_TRY(hipMemcpy(b->d_leak_init, state, bytes, hipMemcpyHostToDevice));
@@ -600,7 +615,7 @@ extern "C" int bsx_batch_get_leak_state(bsx_batch *b, void *state, size_t bytes)
     HIP_TRY(hipGetLastError());
     b->leak_meta_valid = true;
     HIP_TRY(hipMemcpyAsync(state, b->d_leak_final, bytes, hipMemcpyDeviceToHost, b->stream));
-    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(stream_wait(b));
     return BSX_OK;
 }
 
@@ -645,7 +660,7 @@ extern "C" int bsx_batch_run_range(bsx_batch *b, uint32_t first_unit, uint32_t n
         // heavy pipeline: passes of k_hctrl / k_hscan until every deferred unit is finished (this call returns once the last pass
         // is queued and known to be the last; units that were not deferred are already complete)
         HIP_TRY(hipMemcpyAsync(b->h_pinned, b->d_heavy_count, 4, hipMemcpyDeviceToHost, b->stream));
-        HIP_TRY(hipStreamSynchronize(b->stream));
+        HIP_TRY(stream_wait(b));
         const uint32_t n_heavy = b->h_pinned[0];
         b->last_heavy = n_heavy;
         // Each round handles up to hcap deferred units, split into unit groups whose passes run out of phase.  One pass of a group =
@@ -758,7 +773,7 @@ extern "C" int bsx_batch_run_range(bsx_batch *b, uint32_t first_unit, uint32_t n
         // deferred units whose small duplicate set overflowed (single-end RRBS only, see k_hctrl): the main kernel redoes them,
         // undeferred, with its large per-wave set
         HIP_TRY(hipMemcpyAsync(b->h_pinned, b->d_redo, 4, hipMemcpyDeviceToHost, b->stream));
-        HIP_TRY(hipStreamSynchronize(b->stream));
+        HIP_TRY(stream_wait(b));
         const uint32_t n_redo = b->h_pinned[0];
         b->last_redo = n_redo;
         if (n_redo) {
@@ -778,7 +793,7 @@ extern "C" int bsx_batch_sync(bsx_batch *b)
 {
     if (!b) return BSX_ERR_ARG;
     HIP_TRY(hipSetDevice(b->ref->device));
-    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(stream_wait(b));
     return BSX_OK;
 }
 
@@ -795,7 +810,7 @@ extern "C" int bsx_batch_scan_ms(bsx_batch *b, float *total_ms, uint32_t *launch
     if (!b || !total_ms || !launches) return BSX_ERR_ARG;
     if (!b->ran) return BSX_ERR_STATE;
     HIP_TRY(hipSetDevice(b->ref->device));
-    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(stream_wait(b));
     float sum = 0.f;
     for (size_t i = 0; i + 1 < b->scan_ev_used; i += 2) { float ms = 0.f; HIP_TRY(hipEventElapsedTime(&ms, b->scan_ev[i], b->scan_ev[i + 1])); sum += ms; }
     *total_ms = sum; *launches = (uint32_t)(b->scan_ev_used / 2);
@@ -807,7 +822,7 @@ extern "C" int bsx_batch_results_se(bsx_batch *b, bsx_hit *out, bsx_class_counts
     if (!b || b->paired || !out) return BSX_ERR_ARG;
     if (!b->ran) return BSX_ERR_STATE;
     HIP_TRY(hipSetDevice(b->ref->device));
-    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(stream_wait(b));
     HIP_TRY(hipMemcpy(out, b->d_hits, (size_t)b->n_units * sizeof(bsx_hit), hipMemcpyDeviceToHost));
     if (counts) HIP_TRY(hipMemcpy(counts, b->d_cc[0], (size_t)b->n_units * sizeof(bsx_class_counts), hipMemcpyDeviceToHost));
     return BSX_OK;
@@ -818,7 +833,7 @@ extern "C" int bsx_batch_results_pe(bsx_batch *b, bsx_pair *out, bsx_class_count
     if (!b || !b->paired || !out) return BSX_ERR_ARG;
     if (!b->ran) return BSX_ERR_STATE;
     HIP_TRY(hipSetDevice(b->ref->device));
-    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(stream_wait(b));
     HIP_TRY(hipMemcpy(out, b->d_pairs, (size_t)b->n_units * sizeof(bsx_pair), hipMemcpyDeviceToHost));
     if (ca) HIP_TRY(hipMemcpy(ca, b->d_cc[0], (size_t)b->n_units * sizeof(bsx_class_counts), hipMemcpyDeviceToHost));
     if (cb) HIP_TRY(hipMemcpy(cb, b->d_cc[1], (size_t)b->n_units * sizeof(bsx_class_counts), hipMemcpyDeviceToHost));
@@ -834,7 +849,7 @@ extern "C" int bsx_batch_counters(bsx_batch *b, uint64_t c[BSX_N_COUNTERS])
 {
     if (!b || !c) return BSX_ERR_ARG;
     HIP_TRY(hipSetDevice(b->ref->device));
-    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(stream_wait(b));
     HIP_TRY(hipMemcpy(c, b->d_counters, BSX_N_COUNTERS * 8, hipMemcpyDeviceToHost));
     uint64_t sh[64 * 8];
     HIP_TRY(hipMemcpy(sh, b->d_scan_stats, sizeof(sh), hipMemcpyDeviceToHost));
@@ -852,7 +867,7 @@ extern "C" int bsx_batch_reset_counters(bsx_batch *b)
     HIP_TRY(hipSetDevice(b->ref->device));
     HIP_TRY(hipMemsetAsync(b->d_counters, 0, BSX_N_COUNTERS * 8, b->stream));
     HIP_TRY(hipMemsetAsync(b->d_scan_stats, 0, 64 * 64, b->stream));
-    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(stream_wait(b));
     return BSX_OK;
 }
 
@@ -860,7 +875,7 @@ extern "C" int bsx_batch_download_reads(bsx_batch *b, int mate, char *seqs, uint
 {
     if (!b || mate < 0 || mate > (b->paired ? 1 : 0) || !off) return BSX_ERR_ARG;
     HIP_TRY(hipSetDevice(b->ref->device));
-    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(stream_wait(b));
     HIP_TRY(hipMemcpy(off, b->d_off[mate], ((size_t)b->n_units + 1) * 8, hipMemcpyDeviceToHost));
     if (seqs) HIP_TRY(hipMemcpy(seqs, b->d_seq[mate], off[b->n_units], hipMemcpyDeviceToHost));
     return BSX_OK;
@@ -873,7 +888,7 @@ extern "C" int bsx_batch_debug_hits(bsx_batch *b, uint32_t unit, int mate, int o
 {
     if (!b || !b->debug || unit >= b->n_units || !b->ran) return BSX_ERR_STATE;
     HIP_TRY(hipSetDevice(b->ref->device));
-    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(stream_wait(b));
     const uint64_t nclass = (uint64_t)b->ref->P.max_snp_num + 1, rowcap = b->rowcap;
     const uint64_t mbytes = mate_bytes(b->ref->P, b->rowcap);
     bsx_class_counts cc;
@@ -891,7 +906,7 @@ extern "C" int bsx_batch_debug_pairs(bsx_batch *b, uint32_t unit, int w, uint32_
 {
     if (!b || !b->debug || !b->paired || unit >= b->n_units || !b->ran) return BSX_ERR_STATE;
     HIP_TRY(hipSetDevice(b->ref->device));
-    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(stream_wait(b));
     const uint64_t rowcap = b->rowcap;
     const uint64_t mbytes = mate_bytes(b->ref->P, b->rowcap);
     uint16_t np[32];
@@ -907,7 +922,7 @@ extern "C" int bsx_batch_last_heavy_units(bsx_batch *b)
 {
     if (!b || !b->ran) return BSX_ERR_STATE;
     HIP_TRY(hipSetDevice(b->ref->device));
-    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(stream_wait(b));
     return (int)b->last_heavy;
 }
 
@@ -915,7 +930,7 @@ extern "C" int bsx_batch_last_redo_units(bsx_batch *b)
 {
     if (!b || !b->ran) return BSX_ERR_STATE;
     HIP_TRY(hipSetDevice(b->ref->device));
-    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(stream_wait(b));
     return (int)b->last_redo;
 }
 
@@ -923,7 +938,7 @@ extern "C" int bsx_batch_ctrl_clocks(bsx_batch *b, uint64_t out[24])
 {
     if (!b || !out) return BSX_ERR_ARG;
     HIP_TRY(hipSetDevice(b->ref->device));
-    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(stream_wait(b));
     HIP_TRY(hipMemcpy(out, b->d_counters + 16, 192, hipMemcpyDeviceToHost));
     return BSX_OK;
 }
@@ -932,7 +947,7 @@ extern "C" int bsx_batch_unit_cycles(bsx_batch *b, uint32_t *out)
 {
     if (!b || !b->d_cycles || !b->ran || !out) return BSX_ERR_STATE;
     HIP_TRY(hipSetDevice(b->ref->device));
-    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(stream_wait(b));
     HIP_TRY(hipMemcpy(out, b->d_cycles, (size_t)b->n_units * 4, hipMemcpyDeviceToHost));
     return BSX_OK;
 }
@@ -941,7 +956,7 @@ extern "C" int bsx_batch_debug_plan(bsx_batch *b, uint32_t unit, int mate, int32
 {
     if (!b || !b->debug || unit >= b->n_units || !b->ran) return BSX_ERR_STATE;
     HIP_TRY(hipSetDevice(b->ref->device));
-    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(stream_wait(b));
     uint8_t buf[64];
     HIP_TRY(hipMemcpy(buf, b->d_dbg + (size_t)unit * 128 + (mate ? 64 : 0), 64, hipMemcpyDeviceToHost));
     for (int i = 0; i < 32; i++) { start32[i] = buf[i]; order32[i] = buf[32 + i]; }
@@ -977,7 +992,7 @@ extern "C" int bsx_batch_download_quals(bsx_batch *b, int mate, char *quals)
     if (!b || mate < 0 || mate > (b->paired ? 1 : 0) || !quals) return BSX_ERR_ARG;
     if (!b->has_qual) return BSX_ERR_STATE;
     HIP_TRY(hipSetDevice(b->ref->device));
-    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(stream_wait(b));
     uint64_t end = 0;
     HIP_TRY(hipMemcpy(&end, b->d_off[mate] + b->n_units, 8, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(quals, b->d_qual[mate], end, hipMemcpyDeviceToHost));
