@@ -97,8 +97,9 @@ def main():
     ap.add_argument("--genome", default="hg38", help="hg38 (3.09 Gbp synthetic, the bench config) or a fraction like 0.05 for quick checks")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of each cpu_baseline sample (0 = skip)")
     ap.add_argument("--e2e-pairs", type=int, default=16 << 20, help="pairs of the end-to-end CLI run (FASTQ -> SAM in /dev/shm) reported beside the metric; 0 = skip")
-    ap.add_argument("--in-flight", type=int, default=2, help="batches in flight per GPU (host threads, one device batch each): the main kernel of one "
-                    "batch (bound by random HBM requests) overlaps the scan passes of the other; 1 = strictly one Do_Batch at a time")
+    ap.add_argument("--in-flight", type=int, default=0, help="batches in flight per GPU (host threads, one device batch each): the main kernel and the "
+                    "latency-bound tail of one batch overlap the scan passes of the other; 1 = strictly one Do_Batch at a time; default 2 (3 for "
+                    "--mode trim, whose control passes are long: 296-303 against 327 ms per step)")
     ap.add_argument("--transfer-steps", type=int, default=6, help="steps of the PCIe-inclusive leg (upload -> Do_Batch -> results per step); 0 = skip")
     ap.add_argument("--waves-per-cu", type=int, default=0)
     ap.add_argument("--heavy-limits", default="", help="tuning: units per round,scan-task pool of the heavy pipeline")
@@ -116,6 +117,8 @@ def main():
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     if args.selftest_launch:
         return selftest_launch()
+    if args.in_flight <= 0:
+        args.in_flight = 3 if args.mode == "trim" else 2
     if args.profile_serial:
         args.in_flight, args.cpu_seconds, args.e2e_pairs, args.transfer_steps = 1, 0.0, 0, 0
         os.environ["BSX_HEAVY_GROUPS"] = "1"  # read by bsx_batch_create (also the default)

@@ -2380,7 +2380,9 @@ __global__ __launch_bounds__(256, 4) void k_hscan_shared(AlignArgs A, HeavyArgs 
                 const uint32_t w0ref = __popc(m1 & him) + c0;
                 uint32_t tot = __popc(bsx_mismatch_hi(a0.z, a2.w, f[2])) + (__popc(m1) + c0);
                 uint32_t w01ref = tot;
-                if (nwords > 3) {
+                // (the words behind the first 48 nt only matter for candidates still within the threshold there: where no lane of the chunk
+                //  is — half of the chunks of an RRBS repeat family — they are skipped; both early-out classes and the survivors are settled)
+                if (nwords > 3 && (bsx_ballot(tot <= thr) & vm)) {
                     const uint32_t m3 = bsx_mismatch_hi(a0.w, a3.x, f[3]);
                     tot += __popc(m3); w01ref += __popc(m3 & him);
                     tot += __popc(bsx_mismatch_hi(a1.x, a3.y, f[4]));

@@ -22,7 +22,7 @@ extern "C" int bsx_set_waves_per_cu(int w) { g_waves_per_cu = w; return BSX_OK; 
 extern "C" int bsx_set_heavy_threshold(int t) { g_heavy_threshold = t < 0 ? 0 : t; return BSX_OK; }
 // measured on the BASELINE configs: WGBS is flat from 8 192 to 65 536; RRBS reads of the mid-size repeat families
 // cost the main kernel a millisecond each (one wave, 4 MB slab) and go through the scan kernel instead
-static uint32_t heavy_threshold_for(const bsx_params &p) { return g_heavy_threshold > 0 ? (uint32_t)g_heavy_threshold : (p.rrbs ? 4096u : 32768u); }
+static uint32_t heavy_threshold_for(const bsx_params &p) { return g_heavy_threshold > 0 ? (uint32_t)g_heavy_threshold : (p.rrbs ? 2048u : 32768u); }
 static bool g_user_limits = false;
 static uint32_t g_hcap = 24576, g_task_cap = 1048576;  // a 2^20-pair batch defers ~9.4 K units (C3) to ~17.3 K (C5, trimmed reads)
 extern "C" int bsx_set_heavy_limits(uint32_t units_per_round, uint32_t task_pool)
