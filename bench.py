@@ -457,7 +457,7 @@ def incl_transfers(B, ref, src, Align, pe, B_, steps, nfl, reads_per_unit, first
             q[:] = src.download_quals(m)[lo:hi]
             pins.append(pq)
         host.append((a, (off[first_unit:first_unit + steps * B_ + 1] - off[first_unit]).astype(np.uint64), q))
-    nt = nfl + 1  # one more batch than the resident-input run keeps in flight: a batch that is moving data does not compute
+    nt = min(nfl + 1, 3)  # one more batch than the resident-input run keeps in flight (a batch that is moving data does not compute); at most 3: each holds ~39 GB of pools
     small = [Align(ref, B_) for _ in range(nt)]
     L = B.lib()
     sinks = []    # page-locked result arrays per batch
