@@ -262,7 +262,22 @@ struct Text {
         put(b + k, (size_t)(24 - k));
     }
     inline void put_i(int64_t v) { if (v < 0) { put('-'); put_u((uint64_t)(-v)); } else put_u((uint64_t)v); }
+    // the same without the capacity test, for the formatters: the worker reserves room for a whole unit's lines first (BSX_REC_MAX)
+    inline void uput(const char *q, size_t k) { memcpy(s.p + s.n, q, k); s.n += k; }
+    template <size_t N> inline void uput(const char (&z)[N]) { memcpy(s.p + s.n, z, N - 1); s.n += N - 1; }
+    inline void uput(const string &z) { uput(z.data(), z.size()); }
+    inline void uput(char c) { s.p[s.n++] = c; }
+    inline void uput_u(uint64_t v)
+    {
+        char b[24]; int k = 24;
+        do { b[--k] = (char)('0' + v % 10); v /= 10; } while (v);
+        uput(b + k, (size_t)(24 - k));
+    }
+    inline void uput_i(int64_t v) { if (v < 0) { uput('-'); uput_u((uint64_t)(-v)); } else uput_u((uint64_t)v); }
 };
+// room a unit's output lines can take at most: two lines of name (< 1000 characters, reads.cpp's getline limit) + two chromosome names +
+// read, qualities, reference string and the fixed fields
+#define BSX_REC_MAX 16384
 
 struct Formatter {
     const Opts &o;
@@ -280,11 +295,11 @@ struct Formatter {
         }
         for (size_t ii = 0; ii < len + 2; ii++) m[k++] = rv.nt(chr >> 1, loc + (uint32_t)ii);
         m[k - 1] += 32; m[k - 2] += 32;
-        os.put(m, k);
+        os.uput(m, k);
     }
     void put_unmapped(const Rd &r, int flag, Text &os) const
     {
-        os.put(r.name, r.nlen); os.put('\t'); os.put_i(flag); os.put("\t*\t0\t0\t*\t*\t0\t0\t"); os.put(r.seq, r.slen); os.put('\t'); os.put(r.qual, r.qlen); os.put('\n');
+        os.uput(r.name, r.nlen); os.uput('\t'); os.uput_i(flag); os.uput("\t*\t0\t0\t*\t*\t0\t0\t"); os.uput(r.seq, r.slen); os.uput('\t'); os.uput(r.qual, r.qlen); os.uput('\n');
     }
 
     // SingleAlign::s_OutHit (align.cpp:631-765).  counts: _cur_n_hit+_cur_n_chit per class (BSP column 10)
@@ -304,42 +319,42 @@ struct Formatter {
             n_aligned++;
             if (n > 1) flag |= 0x100;
             if (rev) { flag |= 0x10; r.revcomp_seq(); r.reverse_qual(); }
-            os.put(r.name, r.nlen); os.put('\t'); os.put_i(flag); os.put('\t'); os.put(rv.names[chr >> 1]); os.put('\t'); os.put_u(loc + 1);
-            os.put("\t255\t"); os.put_u(r.slen); os.put("M\t*\t0\t0\t"); os.put(r.seq, r.slen); os.put('\t'); os.put(r.qual, r.qlen);
-            os.put("\tNM:i:"); os.put_i(nsnps);
-            if (o.out_ref) { os.put("\tXR:Z:"); put_map_seq(chr, loc, r.slen, os); }
-            if (p.rrbs) { uint32_t f; int s; rv.seglen(chr, loc, (int)r.slen, f, s); os.put("\tZP:i:"); os.put_i((int)f); os.put("\tZL:i:"); os.put_i(s); }
-            os.put("\tZS:Z:"); os.put(chain_flag[chr % 2]); os.put(chain_flag[chain]); os.put('\n');
+            os.uput(r.name, r.nlen); os.uput('\t'); os.uput_i(flag); os.uput('\t'); os.uput(rv.names[chr >> 1]); os.uput('\t'); os.uput_u(loc + 1);
+            os.uput("\t255\t"); os.uput_u(r.slen); os.uput("M\t*\t0\t0\t"); os.uput(r.seq, r.slen); os.uput('\t'); os.uput(r.qual, r.qlen);
+            os.uput("\tNM:i:"); os.uput_i(nsnps);
+            if (o.out_ref) { os.uput("\tXR:Z:"); put_map_seq(chr, loc, r.slen, os); }
+            if (p.rrbs) { uint32_t f; int s; rv.seglen(chr, loc, (int)r.slen, f, s); os.uput("\tZP:i:"); os.uput_i((int)f); os.uput("\tZL:i:"); os.uput_i(s); }
+            os.uput("\tZS:Z:"); os.uput(chain_flag[chr % 2]); os.uput(chain_flag[chain]); os.uput('\n');
             return;
         }
         // BSP
         if (!o.out_unmap && (n <= 0 || (n > 1 && p.report_repeat_hits == 0))) return;
-        os.put(r.name, r.nlen); os.put('\t');
+        os.uput(r.name, r.nlen); os.uput('\t');
         if (rev) { r.revcomp_seq(); r.reverse_qual(); }
-        os.put(r.seq, r.slen); os.put('\t'); os.put(r.qual, r.qlen); os.put('\t');
-        if (n < 0) os.put("QC"); else if (n == 0) os.put("NM"); else if (n == 1) os.put("UM"); else if (n >= p.max_num_hits) os.put("OF"); else os.put("MA");
+        os.uput(r.seq, r.slen); os.uput('\t'); os.uput(r.qual, r.qlen); os.uput('\t');
+        if (n < 0) os.uput("QC"); else if (n == 0) os.uput("NM"); else if (n == 1) os.uput("UM"); else if (n >= p.max_num_hits) os.uput("OF"); else os.uput("MA");
         if ((n > 0 && p.report_repeat_hits == 1) || (n == 1 && p.report_repeat_hits == 0)) {
             n_aligned++;
-            os.put('\t'); os.put(rv.names[chr >> 1]); os.put('\t'); os.put_u(loc + 1); os.put('\t'); os.put(chain_flag[chr % 2]); os.put(chain_flag[chain]);
-            os.put('\t'); os.put_i(insert_size); os.put('\t'); put_map_seq(chr, loc, r.slen, os); os.put('\t'); os.put_i(nsnps); os.put('\t');
+            os.uput('\t'); os.uput(rv.names[chr >> 1]); os.uput('\t'); os.uput_u(loc + 1); os.uput('\t'); os.uput(chain_flag[chr % 2]); os.uput(chain_flag[chain]);
+            os.uput('\t'); os.uput_i(insert_size); os.uput('\t'); put_map_seq(chr, loc, r.slen, os); os.uput('\t'); os.uput_i(nsnps); os.uput('\t');
             for (int ii = 0; ii <= max_snp; ii++) {
-                os.put_i(cc ? (int)cc->n_hit[ii] + (int)cc->n_chit[ii] : 0);
-                if (ii < max_snp) os.put(':');
+                os.uput_i(cc ? (int)cc->n_hit[ii] + (int)cc->n_chit[ii] : 0);
+                if (ii < max_snp) os.uput(':');
             }
         }
-        os.put('\n');
+        os.uput('\n');
         if (rev) { r.revcomp_seq(); r.reverse_qual(); }
     }
 
     void sam_tail(const Rd &r, uint32_t chr, uint32_t loc, bool pair_tags, uint32_t seg_start, int insert, int strand, int chain, Text &os) const
     {
-        if (o.out_ref) { os.put("\tXR:Z:"); put_map_seq(chr, loc, r.slen, os); }
+        if (o.out_ref) { os.uput("\tXR:Z:"); put_map_seq(chr, loc, r.slen, os); }
         if (o.p.rrbs) {
             uint32_t f = seg_start; int s = insert;
             if (!pair_tags) rv.seglen(chr, loc, (int)r.slen, f, s);
-            os.put("\tZP:i:"); os.put_i((int)f); os.put("\tZL:i:"); os.put_i(s);
+            os.uput("\tZP:i:"); os.uput_i((int)f); os.uput("\tZL:i:"); os.uput_i(s);
         }
-        os.put("\tZS:Z:"); os.put(chain_flag[strand]); os.put(chain_flag[chain]); os.put('\n');
+        os.uput("\tZS:Z:"); os.uput(chain_flag[strand]); os.uput(chain_flag[chain]); os.uput('\n');
     }
 
     // PairAlign::s_OutHitPair (pairs.cpp:288-424)
@@ -372,9 +387,9 @@ struct Formatter {
             if (chain ^ (int)(chr % 2)) { flag |= 0x10; seg_start = mloc + 1; pp_insert = -pp.insert; r.revcomp_seq(); r.reverse_qual(); }
             else { flag |= 0x20; seg_start = loc + 1; pp_insert = pp.insert; }
             flag |= 0x40 * (mate + 1);
-            os.put(r.name, r.nlen); os.put('\t'); os.put_i(flag); os.put('\t'); os.put(rv.names[chr >> 1]); os.put('\t'); os.put_u(loc + 1);
-            os.put("\t255\t"); os.put_u(r.slen); os.put("M\t=\t"); os.put_u(mloc + 1); os.put('\t'); os.put_i(pp_insert); os.put('\t');
-            os.put(r.seq, r.slen); os.put('\t'); os.put(r.qual, r.qlen); os.put("\tNM:i:"); os.put_i(mate ? pp.nb : pp.na);
+            os.uput(r.name, r.nlen); os.uput('\t'); os.uput_i(flag); os.uput('\t'); os.uput(rv.names[chr >> 1]); os.uput('\t'); os.uput_u(loc + 1);
+            os.uput("\t255\t"); os.uput_u(r.slen); os.uput("M\t=\t"); os.uput_u(mloc + 1); os.uput('\t'); os.uput_i(pp_insert); os.uput('\t');
+            os.uput(r.seq, r.slen); os.uput('\t'); os.uput(r.qual, r.qlen); os.uput("\tNM:i:"); os.uput_i(mate ? pp.nb : pp.na);
             sam_tail(r, chr, loc, true, seg_start, pp.insert, chr % 2, chain, os);
         }
     }
@@ -397,8 +412,8 @@ struct Formatter {
             if (mate_unmapped) { flag |= 0x008; put_unmapped(r, flag, os); }
             else {
                 if (chain_b ^ (int)(mate.chr % 2)) flag |= 0x020;
-                os.put(r.name, r.nlen); os.put('\t'); os.put_i(flag); os.put("\t*\t0\t0\t*\t"); os.put(rv.names[mate.chr >> 1]); os.put('\t'); os.put_u(mate.loc + 1);
-                os.put("\t0\t"); os.put(r.seq, r.slen); os.put('\t'); os.put(r.qual, r.qlen); os.put('\n');
+                os.uput(r.name, r.nlen); os.uput('\t'); os.uput_i(flag); os.uput("\t*\t0\t0\t*\t"); os.uput(rv.names[mate.chr >> 1]); os.uput('\t'); os.uput_u(mate.loc + 1);
+                os.uput("\t0\t"); os.uput(r.seq, r.slen); os.uput('\t'); os.uput(r.qual, r.qlen); os.uput('\n');
             }
             return;
         }
@@ -407,11 +422,11 @@ struct Formatter {
         if (chain_a ^ (int)(me.chr % 2)) { flag |= 0x010; r.revcomp_seq(); r.reverse_qual(); }
         if (mate_unmapped) flag |= 0x008;
         else if (chain_b ^ (int)(mate.chr % 2)) flag |= 0x020;
-        os.put(r.name, r.nlen); os.put('\t'); os.put_i(flag); os.put('\t'); os.put(rv.names[me.chr >> 1]); os.put('\t'); os.put_u(me.loc + 1);
-        os.put("\t255\t"); os.put_u(r.slen); os.put("M\t");
-        if (mate_unmapped) os.put("*\t0");
-        else { os.put(rv.names[mate.chr >> 1]); os.put('\t'); os.put_u(mate.loc + 1); }
-        os.put("\t0\t"); os.put(r.seq, r.slen); os.put('\t'); os.put(r.qual, r.qlen); os.put("\tNM:i:"); os.put_i(na);
+        os.uput(r.name, r.nlen); os.uput('\t'); os.uput_i(flag); os.uput('\t'); os.uput(rv.names[me.chr >> 1]); os.uput('\t'); os.uput_u(me.loc + 1);
+        os.uput("\t255\t"); os.uput_u(r.slen); os.uput("M\t");
+        if (mate_unmapped) os.uput("*\t0");
+        else { os.uput(rv.names[mate.chr >> 1]); os.uput('\t'); os.uput_u(mate.loc + 1); }
+        os.uput("\t0\t"); os.uput(r.seq, r.slen); os.uput('\t'); os.uput(r.qual, r.qlen); os.uput("\tNM:i:"); os.uput_i(na);
         sam_tail(r, me.chr, me.loc, false, 0, 0, me.chr % 2, chain_a, os);
     }
 };
@@ -521,6 +536,12 @@ int main(int argc, char **argv)
     const int NG = ND * NB;                                                                          // GPU-stage threads
     Ring &ring = *new Ring(max(6, NG + 4));  // never freed: error paths exit() while side threads may still touch it
     const bool pe = !o.a_file.empty() && !o.b_file.empty();
+    // format workers: the CPUs this process may use (affinity mask and cgroup quota, not the hardware thread count) less the
+    // parse, GPU-driver and write threads; oversubscribing a quota throttles every thread, the ones feeding the GPU included
+    const unsigned ncpu = bsx_usable_cpus();
+    // (measured on the 16-CPU quota of the GPU boxes with the GPU stage nearly free, tools/host_threads.sh: 10 workers 10.0 M reads/s, 12: 10.6,
+    //  14: 12.8 — the driver threads of the device batches sleep on events and the two parse threads are light)
+    const int workers = o.num_procs > 0 ? o.num_procs : (int)min(64u, max(1u, ncpu > 4 ? ncpu - 2 : ncpu));
     thread t_pin([&] {
         bsx_thread_device(o.devices[0]);  // the page-locked ring belongs to a context: not implicitly device 0's
         auto fsize = [](const string &f) { struct stat st; return (!f.empty() && stat(f.c_str(), &st) == 0) ? (size_t)st.st_size : (size_t)0; };
@@ -535,6 +556,16 @@ int main(int argc, char **argv)
             s.A.seq.reserve(ca); s.A.qual.reserve(ca); s.A.soff.reserve(units + 1); s.cca.reserve(units);
             if (pe) { s.B.seq.reserve(cb); s.B.qual.reserve(cb); s.B.soff.reserve(units + 1); s.pairs.reserve(units); s.ccb.reserve(units); }
             else s.hits.reserve(units);
+            // the text buffers of the slot, touched now (while the reference loads) instead of inside the first batches' format stage:
+            // first use of a fresh 80 MB buffer costs the formatter 1.8 us per read in page faults against 0.2 us of formatting
+            if (units >= (size_t)workers * 1024) {
+                s.out.resize(workers); s.out_unpair.resize(workers);
+                for (int w = 0; w < workers; w++) {
+                    Text &t = s.out[w];
+                    t.s.reserve((units / workers + 1) * (pe ? 900 : 450));
+                    for (size_t q = 0; q < t.s.cap; q += 4096) t.s.p[q] = 0;
+                }
+            }
         }
     });
     // One replica of reference + index per GPU (7.8 GB of 288 at hg38 size); the replicas load and index concurrently.
@@ -627,12 +658,6 @@ int main(int argc, char **argv)
         for (int d = 0; d < ND; d++) dl += (d ? "," : "") + to_string(o.devices[d]);
         if (pe) cout << "Pair-end alignment(GPU " << dl << ")\n"; else cout << "Single read alignment(GPU " << dl << ")\n";
     }
-    // format workers: the CPUs this process may use (affinity mask and cgroup quota, not the hardware thread count) less the
-    // parse, GPU-driver and write threads; oversubscribing a quota throttles every thread, the ones feeding the GPU included
-    const unsigned ncpu = bsx_usable_cpus();
-    // (measured on the 16-CPU quota of the GPU boxes with the GPU stage nearly free, tools/host_threads.sh: 10 workers 10.0 M reads/s, 12: 10.6,
-    //  14: 12.8 — the driver threads of the device batches sleep on events and the two parse threads are light)
-    const int workers = o.num_procs > 0 ? o.num_procs : (int)min(64u, max(1u, ncpu > 4 ? ncpu - 2 : ncpu));
     Formatter totals(o, rv);
     unsigned total = 0;
     double busy[4] = {0, 0, 0, 0}, gpu_part[3] = {0, 0, 0};  // gpu_part: upload, align, read-back
@@ -740,6 +765,7 @@ int main(int argc, char **argv)
                 Formatter &fmt = fm[w];
                 Rd a, b;
                 for (size_t i = lo; i < hi; i++) {
+                    os.need(BSX_REC_MAX); os_unpair.need(BSX_REC_MAX);
                     a.load(s.A, i);
                     if (!pe) {
                         const bsx_hit &h = s.hits[i];
