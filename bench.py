@@ -296,7 +296,7 @@ def main():
             out["roofline"]["peak_measured"] = {"error": str(e)[:200]}
     if world == 1 and args.transfer_steps > 0:
         try:
-            out["value_incl_transfers"] = incl_transfers(B, ref, batch, Align, pe, B_, min(args.transfer_steps, args.steps), nfl, reads_per_unit, args.warmup * B_, M["kind"] == 1)
+            out["value_incl_transfers"] = incl_transfers(B, ref, batch, Align, pe, B_, min(args.transfer_steps, args.steps), 0 if kw.get("D") else nfl, reads_per_unit, args.warmup * B_, M["kind"] == 1)
         except Exception as e:
             out["value_incl_transfers"] = {"error": str(e)[:300]}
     if world == 1 and args.cpu_seconds > 0:
@@ -457,7 +457,7 @@ def incl_transfers(B, ref, src, Align, pe, B_, steps, nfl, reads_per_unit, first
             q[:] = src.download_quals(m)[lo:hi]
             pins.append(pq)
         host.append((a, (off[first_unit:first_unit + steps * B_ + 1] - off[first_unit]).astype(np.uint64), q))
-    nt = min(nfl + 1, 3)  # one more batch than the resident-input run keeps in flight (a batch that is moving data does not compute); at most 3: each holds ~39 GB of pools
+    nt = min(nfl + 1, 3)  # (RRBS: one — a batch holds 74 GB there)  one more batch than the resident-input run keeps in flight (a batch that is moving data does not compute); at most 3: each holds ~39 GB of pools
     small = [Align(ref, B_) for _ in range(nt)]
     L = B.lib()
     sinks = []    # page-locked result arrays per batch
