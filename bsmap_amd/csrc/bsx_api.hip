@@ -257,7 +257,7 @@ struct bsx_batch {
     uint64_t *d_counters = nullptr, *d_scan_stats = nullptr;
     uint64_t slab_bytes = 0, hslab_bytes = 0;
     uint32_t *d_redo = nullptr;  // [max_units + 1]: count, then unit ids
-    uint32_t rowcap = 0;
+    uint32_t rowcap = 0, hkcap = 0;  // hkcap: key capacity of a deferred unit's duplicate set (BSX_HEAVY_KCAP test hook, read at creation)
     int grid_blocks = 0;
     bool ran = false;
 };
@@ -382,6 +382,7 @@ extern "C" int bsx_batch_create(bsx_ref *r, uint32_t max_units, int paired, bsx_
     b->rowcap = BSX_ROWCAP;
     b->slab_bytes = slab_size(r->P, b->paired, b->rowcap);
     b->hslab_bytes = slab_size(r->P, b->paired, b->rowcap, true);
+    b->hkcap = heavy_key_cap(r->P, b->rowcap);
     int rc = BSX_OK;
     auto fail = [&](int code) { bsx_batch_destroy(b); return code; };
     // tuning / diagnostic knobs are read once, here (a batch keeps its settings): unit groups of the heavy pipeline (default 1: the
@@ -631,7 +632,7 @@ extern "C" int bsx_batch_run_range(bsx_batch *b, uint32_t first_unit, uint32_t n
     memset(&A, 0, sizeof(A));
     bsx_fill_devparams(b->ref, A.P);
     A.n_units = first_unit + n_units; A.first_index = b->first_index; A.debug = b->debug; A.rowcap = b->rowcap; A.kcap = key_cap(b->ref->P, b->rowcap); A.hbits = hset_bits(b->ref->P);
-    A.hkcap = heavy_key_cap(b->ref->P, b->rowcap); A.hhbits = BSX_HSET_BITS; A.hslab_bytes = b->hslab_bytes;
+    A.hkcap = b->hkcap; A.hhbits = BSX_HSET_BITS; A.hslab_bytes = b->hslab_bytes;
     A.redo_count = b->d_redo; A.redo_list = b->d_redo + 1; A.unit_list = nullptr;
     A.first_unit = first_unit;
     for (int m = 0; m < 2; m++) { A.seq[m] = b->d_seq[m]; A.off[m] = b->d_off[m]; A.qual[m] = b->has_qual ? b->d_qual[m] : nullptr; A.cc[m] = b->d_cc[m]; }
@@ -854,11 +855,6 @@ extern "C" int bsx_batch_counters(bsx_batch *b, uint64_t c[BSX_N_COUNTERS])
     uint64_t sh[64 * 8];
     HIP_TRY(hipMemcpy(sh, b->d_scan_stats, sizeof(sh), hipMemcpyDeviceToHost));
     for (int i = 0; i < 64; i++) for (int k = 0; k < 4; k++) c[7 + k] += sh[i * 8 + k];
-    if (getenv("BSX_SPAN_STATS")) {  // diagnostic builds (-DBSX_SPAN_STATS): chunks of 64 candidates by the span of their index entries
-        uint64_t t[4] = {0, 0, 0, 0};
-        for (int i = 0; i < 64; i++) for (int k = 0; k < 4; k++) t[k] += sh[i * 8 + 4 + k];
-        fprintf(stderr, "[bsx span] full chunks %llu, span <= 848 nt %llu, <= 1872 %llu, <= 3920 %llu\n", (unsigned long long)t[0], (unsigned long long)t[1], (unsigned long long)t[2], (unsigned long long)t[3]);
-    }
     return BSX_OK;
 }
 extern "C" int bsx_batch_reset_counters(bsx_batch *b)

@@ -26,9 +26,10 @@ timeout 1200 python3 bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err; ech
 for m in se rrbs trim; do
   timeout 900 python3 bench.py --mode $m --e2e-pairs 0 > $O/${TAG}_bench_$m.json 2> $O/${TAG}_bench_$m.err; echo "$m rc=$?"
 done
-timeout 900 python3 bench.py --mode trim --in-flight 3 --cpu-seconds 0 --e2e-pairs 0 --transfer-steps 0 > $O/${TAG}_bench_trim_f3.json 2> $O/${TAG}_bench_trim_f3.err; echo "trim f3 rc=$?"
+timeout 900 python3 bench.py --mode trim --in-flight 2 --cpu-seconds 0 --e2e-pairs 0 --transfer-steps 0 > $O/${TAG}_bench_trim_f2.json 2> $O/${TAG}_bench_trim_f2.err; echo "trim f2 rc=$?"
 timeout 900 python3 bench.py --mode trim --exact --cpu-seconds 0 --e2e-pairs 0 --transfer-steps 0 > $O/${TAG}_bench_trim_exact.json 2> $O/${TAG}_bench_trim_exact.err; echo "trim exact rc=$?"
 timeout 900 python3 bench.py --in-flight 1 --cpu-seconds 0 --e2e-pairs 0 --transfer-steps 0 --sensitivity 0 > $O/${TAG}_bench_one_in_flight.json 2> $O/${TAG}_bench_one_in_flight.err; echo "one in flight rc=$?"
 bash $R/tools/host_ceiling.sh ${TAG} > $O/${TAG}_host_ceiling.txt 2>&1; cp $R/gpurun_out/${TAG}_hc_*.json $O/ 2>/dev/null; cat $O/${TAG}_host_ceiling.txt
 $R/tools/microbench/valu_issue > $O/${TAG}_valu_issue.json 2>/dev/null; echo "valu rc=$?"
 rm -rf $S; ls -la $O | head -30
+timeout 900 python3 tools/validate_fullsize.py --mode pe > $O/${TAG}_validate_full_c3.json 2>/dev/null; echo "validate full rc=$?"
