@@ -211,8 +211,9 @@ def main():
     # flight the launches of different batches overlap and their durations say nothing about one kernel
     serial = None
     if nfl > 1 and world == 1 and args.steps >= 2:
-        sb = Align(ref, n_total)   # (one unit group per batch, the default: control and scan passes alternate strictly)
-        sb.synth_reads(n_total, read_len, seed=3, first_index=rank * n_total, kind=M["kind"])
+        n_serial = B_ * (args.warmup + 2)   # (the replay only touches the steps it runs: the same reads, same unit ids)
+        sb = Align(ref, n_serial)   # (one unit group per batch, the default: control and scan passes alternate strictly)
+        sb.synth_reads(n_serial, read_len, seed=3, first_index=rank * n_total, kind=M["kind"])
         sb.run_range(0, B_, sync=True)
         sb.reset_counters()
         s_ms, s_scan = [], []
