@@ -13,6 +13,7 @@
 // (bsx_bam_out.h).
 // Parsing, the GPU, formatting (-p threads) and writing run as a pipeline over a ring of batches; the output is always
 // in input order (the reference's order is nondeterministic for -p > 1).
+#include <atomic>
 #include <sys/resource.h>
 #include <algorithm>
 #include <chrono>
@@ -458,6 +459,9 @@ void apply_trim(Rd &r, const bsx_hit &h, const Opts &o)
     if (r.qlen > h.len) r.qlen = h.len;
 }
 
+// CPU time of the calling thread (what a stage really costs under a CPU quota, beside its wall time)
+inline double thread_cpu_s() { struct timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+
 void die(int rc, const char *what)
 {
     cerr << "bsx: " << what << ": " << bsx_strerror(rc) << " (" << bsx_last_error_detail() << ")\n";
@@ -539,6 +543,11 @@ int main(int argc, char **argv)
     // format workers: the CPUs this process may use (affinity mask and cgroup quota, not the hardware thread count) less the
     // parse, GPU-driver and write threads; oversubscribing a quota throttles every thread, the ones feeding the GPU included
     const unsigned ncpu = bsx_usable_cpus();
+    // under a quota: keep the whole process on as many CPUs of the GPU's NUMA node as the quota is worth (BSX_PIN=0: leave the mask alone)
+    if (!getenv("BSX_PIN") || atoi(getenv("BSX_PIN")) != 0) {
+        const unsigned pinned = bsx_pin_to_node(bsx_device_numa_node(o.devices[0]), ncpu);
+        if (pinned && getenv("BSX_TIMING")) cerr << "bsx: pinned to " << pinned << " CPUs of NUMA node " << bsx_device_numa_node(o.devices[0]) << endl;
+    }
     // (measured on the 16-CPU quota of the GPU boxes with the GPU stage nearly free, tools/host_threads.sh: 10 workers 10.0 M reads/s, 12: 10.6,
     //  14: 12.8 — the driver threads of the device batches sleep on events and the two parse threads are light)
     const int workers = o.num_procs > 0 ? o.num_procs : (int)min(64u, max(1u, ncpu > 4 ? ncpu - 2 : ncpu));
@@ -661,6 +670,9 @@ int main(int argc, char **argv)
     Formatter totals(o, rv);
     unsigned total = 0;
     double busy[4] = {0, 0, 0, 0}, gpu_part[3] = {0, 0, 0};  // gpu_part: upload, align, read-back
+    std::atomic<long long> cpu_ns[4];  // CPU time of the stages' threads: parse, gpu drivers, format workers, write threads
+    for (auto &c : cpu_ns) c = 0;
+    auto add_cpu = [&](int st, double t0) { cpu_ns[st] += (long long)((thread_cpu_s() - t0) * 1e9); };
     t_pin.join();
     const double t_map0 = now_s();
     struct rusage ru0; getrusage(RUSAGE_SELF, &ru0);
@@ -681,8 +693,10 @@ int main(int argc, char **argv)
             Slot &s = ring.at(k);
             size_t n2 = 0;
             thread tb;
-            if (pe) tb = thread([&] { n2 = load_reads(rb, s.B, o.batch, ro, 2); });
+            if (pe) tb = thread([&] { const double c0 = thread_cpu_s(); n2 = load_reads(rb, s.B, o.batch, ro, 2); add_cpu(0, c0); });
+            const double c0 = thread_cpu_s();
             const size_t n1 = load_reads(ra, s.A, o.batch, ro, pe ? 1 : 0);
+            add_cpu(0, c0);
             if (pe) tb.join();
             busy[0] += now_s() - t;
             if (!n1) break;
@@ -717,7 +731,7 @@ int main(int argc, char **argv)
     auto gpu_stage = [&](int g) {
         bsx_batch *batch = batches[g];
         for (long k = g; ring.acquire(k, 1); k += NG) {
-            const double t = now_s();
+            const double t = now_s(), c0 = thread_cpu_s();
             double t1 = t, t2 = t;
             Slot &s = ring.at(k);
             const uint32_t n = (uint32_t)s.n;
@@ -743,6 +757,7 @@ int main(int argc, char **argv)
                 s.pairs.resize(n); s.cca.resize(n); s.ccb.resize(n);
                 if ((r = bsx_batch_results_pe(batch, s.pairs.data(), s.cca.data(), s.ccb.data(), nullptr))) die(r, "reading results");
             }
+            add_cpu(1, c0);
             { const double t3 = now_s(); lock_guard<mutex> lk(mu_busy); busy[1] += t3 - t; gpu_part[0] += t1 - t; gpu_part[1] += t2 - t1; gpu_part[2] += t3 - t2; }
             ring.release(k, 2);
         }
@@ -759,6 +774,7 @@ int main(int argc, char **argv)
             else for (int w = 0; w < W; w++) { s.out[w].s.clear(); s.out_unpair[w].s.clear(); }
             vector<Formatter> fm(W, Formatter(o, rv));
             auto work = [&](int w) {
+                const double c0 = thread_cpu_s();
                 const size_t lo = s.n * w / W, hi = s.n * (w + 1) / W;
                 Text &os = s.out[w], &os_unpair = s.out_unpair[w];
                 os.s.reserve((hi - lo) * (pe ? 900 : 450));
@@ -785,6 +801,7 @@ int main(int argc, char **argv)
                         }
                     }
                 }
+                add_cpu(2, c0);
             };
             vector<thread> th;
             for (int w = 1; w < W; w++) th.emplace_back(work, w);
@@ -806,14 +823,14 @@ int main(int argc, char **argv)
                 if (x.s.empty()) continue;
                 const off_t at = off_out;
                 off_out += (off_t)x.s.size();
-                wt.emplace_back([&write_all, &x, at, fout] { write_all(fout, x.s.data(), x.s.size(), at); });
+                wt.emplace_back([&write_all, &add_cpu, &x, at, fout] { const double c0 = thread_cpu_s(); write_all(fout, x.s.data(), x.s.size(), at); add_cpu(3, c0); });
             }
             if (fout_unpair >= 0)
                 for (const Text &x : s.out_unpair) {
                     if (x.s.empty()) continue;
                     const off_t at = off_unpair;
                     off_unpair += (off_t)x.s.size();
-                    wt.emplace_back([&write_all, &x, at, fout_unpair] { write_all(fout_unpair, x.s.data(), x.s.size(), at); });
+                    wt.emplace_back([&write_all, &add_cpu, &x, at, fout_unpair] { const double c0 = thread_cpu_s(); write_all(fout_unpair, x.s.data(), x.s.size(), at); add_cpu(3, c0); });
                 }
             for (thread &t : wt) t.join();
         }
@@ -855,9 +872,9 @@ int main(int argc, char **argv)
     cout << "Total time consumed:  " << t_end - t_begin << " secs\n";
     if (getenv("BSX_TIMING"))  // machine-readable phase times (extension; stderr so that stdout keeps the reference's lines)
         fprintf(stderr, "{\"load_reference_s\": %.3f, \"index_build_s\": %.3f, \"mapping_s\": %.3f, \"units\": %u, \"reads\": %u, \"workers\": %d, \"usable_cpus\": %u, "
-                        "\"mapping_cpu_s\": {\"user\": %.2f, \"sys\": %.2f}, "
+                        "\"mapping_cpu_s\": {\"user\": %.2f, \"sys\": %.2f, \"parse_threads\": %.2f, \"gpu_driver_threads\": %.2f, \"format_workers\": %.2f, \"write_threads\": %.2f}, "
                         "\"stage_busy_s\": {\"parse\": %.3f, \"gpu\": %.3f, \"format\": %.3f, \"write\": %.3f, \"gpu_upload\": %.3f, \"gpu_align\": %.3f, \"gpu_readback\": %.3f}}\n",
-                t_loaded - t0, t_indexed - t_loaded, t_map1 - t_map0, total, pe ? 2 * total : total, workers, ncpu, ru_user, ru_sys, busy[0], busy[1], busy[2], busy[3], gpu_part[0], gpu_part[1], gpu_part[2]);
+                t_loaded - t0, t_indexed - t_loaded, t_map1 - t_map0, total, pe ? 2 * total : total, workers, ncpu, ru_user, ru_sys, cpu_ns[0] * 1e-9, cpu_ns[1] * 1e-9, cpu_ns[2] * 1e-9, cpu_ns[3] * 1e-9, busy[0], busy[1], busy[2], busy[3], gpu_part[0], gpu_part[1], gpu_part[2]);
     for (int g = 0; g < NG; g++) bsx_batch_destroy(batches[g]);
     for (bsx_ref *r : refs) bsx_ref_destroy(r);
     return 0;

@@ -32,6 +32,17 @@ extern "C" int bsx_set_heavy_limits(uint32_t units_per_round, uint32_t task_pool
     return BSX_OK;
 }
 
+extern "C" int bsx_device_numa_node(int device)
+{
+    char id[64] = {0};
+    if (hipDeviceGetPCIBusId(id, (int)sizeof id, device) != hipSuccess) return -1;
+    for (char *q = id; *q; q++) *q = (char)tolower((unsigned char)*q);
+    const std::string path = std::string("/sys/bus/pci/devices/") + id + "/numa_node";
+    int node = -1;
+    if (FILE *f = fopen(path.c_str(), "r")) { if (fscanf(f, "%d", &node) != 1) node = -1; fclose(f); }
+    return node;
+}
+
 extern "C" int bsx_device_count(void)
 {
     int n = 0;

@@ -75,6 +75,9 @@ int bsx_params_finish(bsx_params *p);                          /* SetAlign + Set
 /* ---- reference genome: RefSeq::Run_ConvertBinseq (dbseq.cpp:215-282) --------------------------- */
 typedef struct bsx_ref bsx_ref;
 int bsx_device_count(void);
+/* NUMA node the device hangs on (from its PCI address; -1 if unknown): a host program under a CPU quota does well to keep its threads
+ * and buffers on that node (bsmap_amd/csrc/bsx_cpus.h) */
+int bsx_device_numa_node(int device);
 /* parse FASTA text on the host with the reference's tokenisation, pack both strands, upload to `device` */
 int bsx_ref_create_from_fasta(const bsx_params *p, const char *text, uint64_t n_bytes, int device, bsx_ref **out);
 int bsx_ref_create_from_file(const bsx_params *p, const char *path, int device, bsx_ref **out);

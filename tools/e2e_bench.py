@@ -81,6 +81,8 @@ def _run(a):
     cmd = [os.path.join(os.path.dirname(B.__file__), "bsmap"), "-a", fq[0], "-b", fq[1], "-d", fa, "-o", out, "-s", "16", "-v", "6", "-m", "28", "-x", "500", "-S", "1"]
     if a.threads:
         cmd += ["-p", str(a.threads)]
+    if os.environ.get("BSX_TASKSET"):   # experiment: pin the whole command line to a CPU list (one NUMA node)
+        cmd = ["taskset", "-c", os.environ["BSX_TASKSET"]] + cmd
     t0 = time.time()
     res = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, BSX_TIMING="1"))
     wall = time.time() - t0
