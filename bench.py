@@ -569,6 +569,14 @@ def cpu_baseline(ref, batch, pe, kw, target_s, first_unit, quals):
     import numpy as np
     from oracle import oracle_ffi as O
     cores, hw = usable_cpus(), os.cpu_count() or 1
+    # Under a CPU quota far below the visible CPUs the scheduler spreads the threads over both sockets; pinned to the quota's worth of
+    # CPUs on one NUMA node — before the reference and index are copied back, so that their pages land on that node too — the port
+    # runs 1.3-1.4 x faster (35.9 K vs 28.0 K reads/s): the CPU gets that, too.
+    import bsmap_amd as B_
+    old_aff = os.sched_getaffinity(0)
+    pin = node_cpus(max(0, B_.lib().bsx_device_numa_node(0)), cores)
+    if pin:
+        os.sched_setaffinity(0, pin)
     if kw.get("D"):   # RRBS: site tables and the {tag, loc} index are the oracle's own, built from the genome text pulled back from HBM
         parts = []
         for c, nm in enumerate(ref.names()):
@@ -604,14 +612,6 @@ def cpu_baseline(ref, batch, pe, kw, target_s, first_unit, quals):
             t0 = time.perf_counter()
             O.se_batch(oref, sa, oa, qa, first_index=lo, threads=threads)
         return time.perf_counter() - t0
-
-    # Under a CPU quota far below the visible CPUs the scheduler spreads the threads over both sockets; pinned to the quota's worth of
-    # CPUs on one NUMA node the port runs 1.3-1.4 x faster (35.9 K vs 28.0 K reads/s) — the CPU gets that, too.
-    import bsmap_amd as B_
-    old_aff = os.sched_getaffinity(0)
-    pin = node_cpus(max(0, B_.lib().bsx_device_numa_node(0)), cores)
-    if pin:
-        os.sched_setaffinity(0, pin)
 
     def sample(threads):
         n0 = min(2000 if threads <= 8 else 20000, len(o1) - 1 - first_unit)
