@@ -952,10 +952,11 @@ static void fill_state(const bso_aligner *a, int filtered, bso_read_result *o)
     if (filtered) return;
     o->read_max_snp_num = a->read_max_snp_num; o->seedseg_num = a->seedseg_num;
     o->flag_chain = a->flag_chain; o->cflag_chain = a->cflag_chain;
-    for (int i = 0; i < 16; i++) { o->seed_start_array[i] = a->seed_start_array[i]; o->cseed_start_array[i] = a->cseed_start_array[i]; }
+    /* only what this read's ReorderSeed wrote: entries from seedseg_num on (and the arrays of a chain the read does not search)
+     * still hold what earlier reads of the same aligner left there - the worker that happened to run them, under threads */
     for (int i = 0; i < a->seedseg_num && i < 16; i++) {
-        if (a->flag_chain) { o->seedindex[i] = a->seedindex[i].idx; o->seedcount[i] = a->seedindex[i].cnt; }
-        if (a->cflag_chain) { o->cseedindex[i] = a->cseedindex[i].idx; o->cseedcount[i] = a->cseedindex[i].cnt; }
+        if (a->flag_chain) { o->seed_start_array[i] = a->seed_start_array[i]; o->seedindex[i] = a->seedindex[i].idx; o->seedcount[i] = a->seedindex[i].cnt; }
+        if (a->cflag_chain) { o->cseed_start_array[i] = a->cseed_start_array[i]; o->cseedindex[i] = a->cseedindex[i].idx; o->cseedcount[i] = a->cseedindex[i].cnt; }
     }
     for (int i = 0; i <= a->P->max_snp_num && i < 16; i++) { o->n_hit[i] = a->n_hit[i]; o->n_chit[i] = a->n_chit[i]; }
     o->snp_thres = a->snp_thres;
