@@ -111,6 +111,8 @@ def main():
                     "the line then includes the pre-pass that finds that state (k_leak_meta / k_leak_resolve)")
     ap.add_argument("--sensitivity", type=int, default=1, help="1: also run the workload on two variants of the synthetic genome (microsatellite share halved; no repeat "
                     "elements) — the headline depends on the generator's repeat content; 0 = skip")
+    ap.add_argument("--other-configs", type=int, default=1, help="1 (with the default mode, one GPU): after the metric's own config, run BASELINE's other single-GPU configs (C2, C4, C5) "
+                    "for a few steps each in child processes and report them under other_configs — parity-test cases, not the metric")
     ap.add_argument("--selftest-launch", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
@@ -309,6 +311,8 @@ def main():
         out["sensitivity"] = sensitivity(B, Align, kw, lens, read_len, B_, nfl, M["kind"], value)
     if world == 1 and args.mode == "pe" and args.e2e_pairs > 0:
         out["end_to_end"] = end_to_end(args.e2e_pairs, args.genome)
+    if world == 1 and args.mode == "pe" and args.other_configs and not args.profile_serial and not args.exact:
+        out["other_configs"] = other_configs(args)
     print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
@@ -424,6 +428,28 @@ def sensitivity(B, Align, kw, lens, read_len, B_, nfl, kind, headline):
             bt.close()
         ref.close()
     return out
+
+
+def other_configs(args):
+    """BASELINE.json's other single-GPU configs, each in a child process of its own (this process has released its device memory): the same
+    timed region as the metric's (inputs in HBM, barrier + synchronize on both sides), fewer steps, none of the side legs."""
+    import subprocess
+    res = {}
+    for mode in ("se", "rrbs", "trim"):
+        cmd = [sys.executable, os.path.abspath(__file__), "--mode", mode, "--steps", "6", "--warmup", "3", "--genome", str(args.genome), "--pairs-per-step", str(args.pairs_per_step),
+               "--cpu-seconds", "0", "--transfer-steps", "0", "--e2e-pairs", "0", "--other-configs", "0"]
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+            dk = j["roofline"].get("dominant_kernel") or {}
+            res[MODES[mode]["tag"]] = {"workload": j["config"]["workload"], "reads_per_s": j["value"], "ms_per_step": j["ms_per_step"], "steps": j["steps"],
+                                       "batches_in_flight": j["config"]["batches_in_flight"], "aligned_fraction": j["config"]["aligned_fraction"],
+                                       "candidates_per_read": j["roofline"]["per_read"]["n_cand"], "dominant_kernel": {k: dk.get(k) for k in ("name", "ms_per_step", "candidates_per_s")},
+                                       "wall_s": round(time.perf_counter() - t0, 1)}
+        except Exception as e:
+            res[MODES[mode]["tag"]] = {"error": str(e)[:300]}
+    return res
 
 
 def pinned_array(B, C, nbytes):
