@@ -12,6 +12,6 @@ try:
 except Exception as e:
     print("$v: no line:", e)
 PY
-  timeout 600 python3 bench.py --steps 6 --warmup 2 --cpu-seconds 0 --e2e-pairs 0 --transfer-steps 0 --sensitivity 0 > $O/${TAG}_${v}_default.json 2>> $O/${TAG}_$v.err
+  timeout 600 python3 bench.py --steps 6 --warmup 2 --cpu-seconds 0 --e2e-pairs 0 --transfer-steps 0 --sensitivity 0 --other-configs 0 > $O/${TAG}_${v}_default.json 2>> $O/${TAG}_$v.err
   python3 -c "import json;d=json.load(open('$O/${TAG}_${v}_default.json'));print('$v: default ms/step %.1f  reads/s %.0f' % (d['ms_per_step'], d['value']))"
 done
