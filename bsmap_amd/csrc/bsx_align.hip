@@ -2041,7 +2041,10 @@ __global__ __launch_bounds__(256, PE ? BSX_HCTRL_WAVES : BSX_HCTRL_WAVES_SE) voi
 #define BSX_HSCAN_TMV 9  /* T-masks kept in vector registers (first three: stage 1) */
 #endif
 #define HS_QCAP 256u  /* FIFO slots per wave (16 bytes each): at most 63 left over + 2 chunks of 64 pushed between drains */
-struct ScanAcc { uint32_t c1, f5, nv; };  // per lane: candidates with w0ref > thres / evaluated in full with w01ref <= thres / (RRBS) candidates at all
+#ifndef BSX_HSCAN_VVV
+#define BSX_HSCAN_VVV 1
+#endif
+struct ScanAcc { uint32_t c1, f5, nv; };  // per wave (scalar registers, counted with s_bcnt1 on the compare masks): candidates with w0ref > thres / evaluated in full with w01ref <= thres / (RRBS) candidates at all
 struct ScanCtx {
     const uint32_t *refall;  // forward copy; the rc copy follows it in the same allocation
     uint4 *Q;                // this wave's FIFO
@@ -2054,7 +2057,39 @@ struct ScanCtx {
     // T-masks of the read words (bsx_tmask) held in VECTOR registers: a VOP3 instruction reads one scalar operand only, so with both
     // the read word and its mask in SGPRs every v_bitop3 of the mismatch rule came with a v_mov (3 of the first stage's 33 per chunk)
     uint32_t tv[9];
+#if BSX_HSCAN_VVV
+    // ... and so do the read words themselves and the 0xAAAAAAAA of the rule: v_bitop3 with an SGPR operand issues at the rate of the shift /
+    // popcount class (2.6 SIMD cycles per wave64 instruction), with three VGPR operands at that of v_xor (1.5; profiles/r03c_valu_issue.json)
+    uint32_t rv[9], kA;
+#endif
 };
+// bsx_mismatch_hi with all operands in vector registers and the shift as an add (both in the fast VALU class)
+__device__ __forceinline__ uint32_t mism_vvv(uint32_t kA, uint32_t read, uint32_t tmask, uint32_t ref)
+{
+    const uint32_t y = (read ^ ref) & tmask;
+    uint32_t y2;
+    asm("v_add_u32 %0, %1, %1" : "=v"(y2) : "v"(y));
+    return (y2 | y) & kA;
+}
+#if BSX_HSCAN_VVV
+__device__ __forceinline__ uint32_t hscan_mism(const ScanCtx &X, const uint32_t (&rw)[9], int t, uint32_t f)
+{
+    const uint32_t y = (X.rv[t] ^ f) & X.tv[t];
+    uint32_t y2;
+    asm("v_add_u32 %0, %1, %1" : "=v"(y2) : "v"(y));  // y << 1 as an add: v_lshlrev is in the slow class
+    return (y2 | y) & X.kA;
+}
+#else
+__device__ __forceinline__ uint32_t hscan_mism(const ScanCtx &X, const uint32_t (&rw)[9], int t, uint32_t f) { return bsx_mismatch_hi(rw[t], X.tv[t], f); }
+#endif
+
+// popcount(x) + acc in one instruction (the compiler prefers separate counts and a v_add3)
+__device__ __forceinline__ uint32_t popc_acc(uint32_t x, uint32_t acc)
+{
+    uint32_t d;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(acc));
+    return d;
+}
 
 // stage 2 for the first n (<= 64) queued candidates
 __device__ __forceinline__ void hscan_drain(ScanCtx &X, uint32_t n, const uint32_t (&rw)[9], const uint32_t (&rm)[9])
@@ -2068,18 +2103,18 @@ __device__ __forceinline__ void hscan_drain(ScanCtx &X, uint32_t n, const uint32
     if (act && X.nwords > 3) r1 = *reinterpret_cast<const U4 *>(rp + 4);
     if (act && X.nwords > 7) r2 = *reinterpret_cast<const U2 *>(rp + 8);
     const uint32_t sh = mad30(it.w, 30);
-    const uint32_t him = (uint32_t)((int32_t)0x80000000 >> (mad30(it.w, 29) & 31u));
+    const uint32_t him = (uint32_t)((int32_t)0x80000000 >> ((sh - 1u) & 31u));  // (30 pm1 + 29) mod 32
     const uint32_t p48 = it.y & 0xffu;
     const uint32_t wd[7] = {it.z, r1.a, r1.b, r1.c, r1.d, r2.a, r2.b};
     uint32_t tot = p48, w01ref = p48;
 #pragma unroll
     for (int t = 3; t < 9; t++) {
         const uint32_t f = __builtin_amdgcn_alignbit(wd[t - 3], wd[t - 2], sh);
-        const uint32_t mm = bsx_mismatch_hi(rw[t], X.tv[t], f);
-        tot += __popc(mm);
-        if (t == 3) w01ref += __popc(mm & him);
+        const uint32_t mm = hscan_mism(X, rw, t, f);
+        tot = popc_acc(mm, tot);
+        if (t == 3) w01ref = popc_acc(mm & him, w01ref);
     }
-    X.acc.f5 += (act && w01ref <= X.thres0) ? 1u : 0u;
+    X.acc.f5 += (uint32_t)__builtin_popcountll(bsx_ballot(act && w01ref <= X.thres0));
     // (chromosome / end-of-sequence test and hit coordinates are left to the control kernel's replay: the record carries
     //  the strand copy and the global position)
     const bool pass = act && tot <= X.thres0;
@@ -2100,14 +2135,14 @@ __device__ __forceinline__ void hscan_eval(ScanCtx &X, const U4 r0, uint32_t pm1
                                            const uint32_t (&rm)[9])
 {
     const uint32_t sh = mad30(pm1, 30);
-    const uint32_t him = (uint32_t)((int32_t)0x80000000 >> (mad30(pm1, 29) & 31u));
+    const uint32_t him = (uint32_t)((int32_t)0x80000000 >> ((sh - 1u) & 31u));  // (30 pm1 + 29) mod 32
     const uint32_t f0 = __builtin_amdgcn_alignbit(r0.a, r0.b, sh), f1 = __builtin_amdgcn_alignbit(r0.b, r0.c, sh), f2 = __builtin_amdgcn_alignbit(r0.c, r0.d, sh);
-    const uint32_t m1 = bsx_mismatch_hi(rw[1], X.tv[1], f1);
-    const uint32_t c0 = __popc(bsx_mismatch_hi(rw[0], X.tv[0], f0));
-    const uint32_t w0ref = __popc(m1 & him) + c0;
-    uint32_t p48 = __popc(bsx_mismatch_hi(rw[2], X.tv[2], f2)) + (__popc(m1) + c0);
+    const uint32_t m1 = hscan_mism(X, rw, 1, f1);
+    const uint32_t c0 = __popc(hscan_mism(X, rw, 0, f0));
+    const uint32_t w0ref = popc_acc(m1 & him, c0);
+    uint32_t p48 = popc_acc(hscan_mism(X, rw, 2, f2), popc_acc(m1, c0));
     const bool need = (!MASKED || valid) && p48 <= X.thres0;
-    X.acc.c1 += ((!MASKED || valid) && w0ref > X.thres0) ? 1u : 0u;
+    X.acc.c1 += (uint32_t)__builtin_popcountll(bsx_ballot((!MASKED || valid) && w0ref > X.thres0));
     const u64 nm = bsx_ballot(need);
     if (nm) {
         if (need) {
@@ -2140,7 +2175,7 @@ __device__ __forceinline__ void hscan_step_rrbs(ScanCtx &X, const U2 *__restrict
         pm1[u] = valid[u] ? anchor[rchr >> 1] + (e[u].b - h) - 1u : 15u;
         boff[u] = ((pm1[u] >> 2) & 0x3ffffffcu) + ((rchr & 1u) ? cref_off : 0u);
         tag[u] = (ord0 + (uint32_t)(u * 64 + lane)) << 8 | (rchr & 1u) << 31;
-        X.acc.nv += valid[u] ? 1u : 0u;
+        X.acc.nv += (uint32_t)__builtin_popcountll(bsx_ballot(valid[u]));
     }
 #pragma unroll
     for (int u = 0; u < 4; u++) r0[u] = *reinterpret_cast<const U4 *>(reinterpret_cast<const uint8_t *>(X.refall) + (valid[u] ? boff[u] : 0u));
@@ -2222,6 +2257,11 @@ __global__ __launch_bounds__(64 * BSX_HSCAN_WPB, BSX_HSCAN_WAVES) void k_hscan(A
     X.overflow = false; X.o = o; X.acc.c1 = 0; X.acc.f5 = 0; X.acc.nv = 0;
 #pragma unroll
     for (int k = 0; k < 9; k++) { X.tv[k] = bsx_tmask(rw[k], rm[k]); if (k < BSX_HSCAN_TMV) asm volatile("" : "+v"(X.tv[k])); }
+#if BSX_HSCAN_VVV
+#pragma unroll
+    for (int k = 0; k < 9; k++) { X.rv[k] = rw[k]; asm volatile("" : "+v"(X.rv[k])); }
+    X.kA = 0xAAAAAAAAu; asm volatile("" : "+v"(X.kA));
+#endif
     const uint32_t cref_off = (uint32_t)((const uint8_t *)P.crefcat - (const uint8_t *)P.refcat);  // both copies live in one allocation (bsx_api.hip)
     const uint32_t c_end = tc0 + tn;
     const bool rrbs = rfl(R.rrbs) != 0;
@@ -2250,8 +2290,8 @@ __global__ __launch_bounds__(64 * BSX_HSCAN_WPB, BSX_HSCAN_WAVES) void k_hscan(A
         if (cb < hi && !X.overflow) hscan_step<false>(X, e, nullptr, ref_off, hm1, hi - cb, cb - tc0, strand, rw, rm);
     }
     while (X.qn && !X.overflow) hscan_drain(X, min(X.qn, 64u), rw, rm);
-    const uint32_t n1 = wave_sum(X.acc.c1), n5 = wave_sum(X.acc.f5);
-    const uint32_t n_cand = rrbs ? wave_sum(X.acc.nv) : tn;  // RRBS: only the entries that passed the tag filter are candidates
+    const uint32_t n1 = X.acc.c1, n5 = X.acc.f5;
+    const uint32_t n_cand = rrbs ? X.acc.nv : tn;  // RRBS: only the entries that passed the tag filter are candidates
     const uint32_t words = 2u * n_cand - n1 + 3u * n5;  // 1, 2 or 5 words per candidate (see above)
     if (lane == 0) {
         o->count = X.overflow ? 0 : X.nsurv; o->overflow = X.overflow ? 1 : 0; o->acc[0] = n_cand; o->acc[1] = words; o->acc[2] = 0; o->acc[3] = 0;
@@ -2330,6 +2370,7 @@ __global__ __launch_bounds__(256, 4) void k_hscan_shared(AlignArgs A, HeavyArgs 
         }
     }
     u64 st_cand = 0, st_words = 0, st_n1 = 0, st_n5 = 0;  // statistics of the scan kernel (lane 0)
+    uint32_t kA = 0xAAAAAAAAu; asm volatile("" : "+v"(kA));   // in a VGPR: see hscan_mism
     for (uint32_t i0 = 0; i0 < nj;) {
         if (rl(tn, (int)i0) == 0) { i0++; continue; }
         // the run of tasks from i0 that cover exactly the same window
@@ -2364,7 +2405,7 @@ __global__ __launch_bounds__(256, 4) void k_hscan_shared(AlignArgs A, HeavyArgs 
             if (more) nxt = shared_load(ent2, cb + 64 + (uint32_t)lane, cb + 64 + (uint32_t)lane < n, h, tx, tw, anchor, P.refcat, cref_off, nwords);
             // the candidate's reference words in the read frame — the same for every read of the run
             const uint32_t shf = mad30(cur.pm1, 30);
-            const uint32_t him = (uint32_t)((int32_t)0x80000000 >> (mad30(cur.pm1, 29) & 31u));
+            const uint32_t him = (uint32_t)((int32_t)0x80000000 >> ((shf - 1u) & 31u));  // (30 pm1 + 29) mod 32
             uint32_t f[9];
 #pragma unroll
             for (int t = 0; t < 9; t++) f[t] = __builtin_amdgcn_alignbit(cur.wd[t], cur.wd[t + 1], shf);
@@ -2375,23 +2416,23 @@ __global__ __launch_bounds__(256, 4) void k_hscan_shared(AlignArgs A, HeavyArgs 
             for (uint32_t k = 0; k < K; k++, up += 5) {
                 const uint4 a0 = up[0], a1 = up[1], a2 = up[2], a3 = up[3], a4 = up[4];  // read words 0-3 | 4-7 | 8, masks 0-2 | masks 3-6 | masks 7-8, threshold, task id
                 const uint32_t thr = a4.z;
-                const uint32_t m1 = bsx_mismatch_hi(a0.y, a2.z, f[1]);
-                const uint32_t c0 = __popc(bsx_mismatch_hi(a0.x, a2.y, f[0]));
-                const uint32_t w0ref = __popc(m1 & him) + c0;
-                uint32_t tot = __popc(bsx_mismatch_hi(a0.z, a2.w, f[2])) + (__popc(m1) + c0);
+                const uint32_t m1 = mism_vvv(kA, a0.y, a2.z, f[1]);
+                const uint32_t c0 = __popc(mism_vvv(kA, a0.x, a2.y, f[0]));
+                const uint32_t w0ref = popc_acc(m1 & him, c0);
+                uint32_t tot = popc_acc(mism_vvv(kA, a0.z, a2.w, f[2]), popc_acc(m1, c0));
                 uint32_t w01ref = tot;
                 // (the words behind the first 48 nt only matter for candidates still within the threshold there: where no lane of the chunk
                 //  is — half of the chunks of an RRBS repeat family — they are skipped; both early-out classes and the survivors are settled)
                 if (nwords > 3 && (bsx_ballot(tot <= thr) & vm)) {
-                    const uint32_t m3 = bsx_mismatch_hi(a0.w, a3.x, f[3]);
-                    tot += __popc(m3); w01ref += __popc(m3 & him);
-                    tot += __popc(bsx_mismatch_hi(a1.x, a3.y, f[4]));
+                    const uint32_t m3 = mism_vvv(kA, a0.w, a3.x, f[3]);
+                    tot = popc_acc(m3, tot); w01ref = popc_acc(m3 & him, w01ref);
+                    tot = popc_acc(mism_vvv(kA, a1.x, a3.y, f[4]), tot);
                     if (nwords > 5) {
-                        tot += __popc(bsx_mismatch_hi(a1.y, a3.z, f[5]));
-                        tot += __popc(bsx_mismatch_hi(a1.z, a3.w, f[6]));
+                        tot = popc_acc(mism_vvv(kA, a1.y, a3.z, f[5]), tot);
+                        tot = popc_acc(mism_vvv(kA, a1.z, a3.w, f[6]), tot);
                         if (nwords > 7) {
-                            tot += __popc(bsx_mismatch_hi(a1.w, a4.x, f[7]));
-                            tot += __popc(bsx_mismatch_hi(a2.x, a4.y, f[8]));
+                            tot = popc_acc(mism_vvv(kA, a1.w, a4.x, f[7]), tot);
+                            tot = popc_acc(mism_vvv(kA, a2.x, a4.y, f[8]), tot);
                         }
                     }
                 }
