@@ -91,8 +91,8 @@ def selftest_launch():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=12)   # a multiple of 2, 3 and 4: every batch in flight runs the same number of steps
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs-per-step", type=int, default=1 << 20, help="units (pairs, or single reads) per step")
     ap.add_argument("--genome", default="hg38", help="hg38 (3.09 Gbp synthetic, the bench config) or a fraction like 0.05 for quick checks")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of each cpu_baseline sample (0 = skip)")
@@ -100,7 +100,7 @@ def main():
     ap.add_argument("--in-flight", type=int, default=0, help="batches in flight per GPU (host threads, one device batch each): the main kernel and the "
                     "latency-bound tail of one batch overlap the scan passes of the other; 1 = strictly one Do_Batch at a time; default 2 (3 for "
                     "--mode trim, whose control passes are long: 296-303 against 327 ms per step)")
-    ap.add_argument("--transfer-steps", type=int, default=6, help="steps of the PCIe-inclusive leg (upload -> Do_Batch -> results per step); 0 = skip")
+    ap.add_argument("--transfer-steps", type=int, default=8, help="steps of the PCIe-inclusive leg (upload -> Do_Batch -> results per step); 0 = skip")
     ap.add_argument("--waves-per-cu", type=int, default=0)
     ap.add_argument("--heavy-limits", default="", help="tuning: units per round,scan-task pool of the heavy pipeline")
     ap.add_argument("--heavy-threshold", type=int, default=0, help="tuning: candidate-list length that defers a unit to the heavy pipeline (0 = library default)")
@@ -510,8 +510,14 @@ def incl_transfers(B, ref, src, Align, pe, B_, steps, nfl, reads_per_unit, first
         b.Do_Batch()
         b.results(into=sinks[j])
 
-    def worker(j, lo, hi):
-        for i in range(lo + j, hi, nt):
+    nxt, lock = [0], threading.Lock()
+
+    def worker(j, lo, hi):  # a batch takes the next step that nobody has started (a fixed stride would leave batches idle when nt does not divide the steps)
+        while True:
+            with lock:
+                i = nxt[0]; nxt[0] += 1
+            if i >= hi:
+                return
             step(j, i)
     for j in range(nt):  # untimed warm-up of each small batch
         step(j, 0)
