@@ -380,7 +380,8 @@ def kernel_bound():
         k = json.load(open(sq))["kernels"]["k_hscan"]["derived"]
         vif = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_valu_issue.json")))[-1]
         vi = json.load(open(vif))
-        mix = [m for m in vi["mixes"] if m["mix"].startswith("k_hscan head word")][0]["by_waves_per_simd"]
+        # (the kernel's own mix: since round 3 the word with every operand in a VGPR and the shift as an add)
+        mix = ([m for m in vi["mixes"] if m["mix"].startswith("k_hscan head word, VGPR")] or [m for m in vi["mixes"] if m["mix"].startswith("k_hscan head word")])[0]["by_waves_per_simd"]
         ceil = max(v["chip_G_wave_instr_per_s"] for v in mix.values()) * 1e9
         fr = {"valu_issue": k["valu_instr_per_s"] / ceil, "texture_addresser_busy": k.get("ta_busy_frac"), "l2_hit": k.get("l2_hit_frac"),
               "waiting_on_instruction_issue": k.get("wait_inst_frac")}

@@ -36,6 +36,10 @@
 // the head word of k_hscan: funnel shift, (read ^ ref) & tmask, << 1, (t | y) & 0xAAAAAAAA, popcount (5 instructions)
 #define MIX_HEAD(c)  asm volatile("v_alignbit_b32 %0, %0, %1, %2\n v_bitop3_b32 %0, %3, %0, %1 bitop3:0x60\n v_lshlrev_b32 %1, 1, %0\n" \
                                   "v_bitop3_b32 %0, %1, %4, %0 bitop3:0xc8\n v_bcnt_u32_b32 %0, %0, %1" : "+v"(a[c]), "+v"(b[c]) : "v"(sh), "s"(sc), "s"(sd));
+// the same word as k_hscan issues it since round 3: every operand in a VGPR, the shift as an add
+#define MIX_HEADV(c) asm volatile("v_alignbit_b32 %0, %0, %1, %2\n v_bitop3_b32 %0, %3, %0, %1 bitop3:0x60\n v_add_u32 %1, %0, %0\n" \
+                                  "v_bitop3_b32 %0, %1, %4, %0 bitop3:0xc8\n v_bcnt_u32_b32 %0, %0, %1" : "+v"(a[c]), "+v"(b[c]) : "v"(sh), "v"(sc), "v"(sd));
+#define MIX_ADD(c)   asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[c]) : "v"(b[c]));
 
 template <int MIX> struct Info;
 #define DEF(ID, NAME, BODY, N) \
@@ -55,7 +59,9 @@ DEF(10, "v_cmp_gt_u32 (vcc)", MIX_CMP, 1)
 DEF(11, "v_cmp + v_addc_co", MIX_CMPADDC, 2)
 DEF(12, "v_cndmask_b32", MIX_CNDMASK, 1)
 DEF(13, "k_hscan head word (alignbit,bitop3,lshl,bitop3,bcnt)", MIX_HEAD, 5)
-constexpr int N_MIX = 14;
+DEF(14, "v_add_u32", MIX_ADD, 1)
+DEF(15, "k_hscan head word, VGPR operands (alignbit,bitop3 vvv,add,bitop3 vvv,bcnt)", MIX_HEADV, 5)
+constexpr int N_MIX = 16;
 
 template <int MIX> __global__ __launch_bounds__(256) void k_issue(uint32_t *out, unsigned long long *clk, int iters, uint32_t seed)
 {
