@@ -536,7 +536,12 @@ int main(int argc, char **argv)
     static const RawAlloc pinned = {bsx_pinned_alloc, bsx_pinned_free};
     if (o.devices.empty()) o.devices.push_back(0);
     const int ND = (int)o.devices.size();
-    const int NB = getenv("BSX_GPU_BATCHES") ? max(1, min(4, atoi(getenv("BSX_GPU_BATCHES")))) : 2;  // device batches in flight per GPU
+    // device batches per GPU.  Runs that start together end together (equal work, the GPU shared evenly), so with two batches per GPU
+    // every upload and read-back happened beside an idle GPU; with three the runs no longer line up and one batch's transfers fall under
+    // the others' kernels (12.6 -> 13.1 M reads/s end to end at hg38 size).  BSX_GPU_COMPUTE < BSX_GPU_BATCHES additionally limits how
+    // many may be in their kernels at once (measured: no better — whichever thread wins the slot, results are consumed in input order).
+    const int NB = getenv("BSX_GPU_BATCHES") ? max(1, min(4, atoi(getenv("BSX_GPU_BATCHES")))) : 3;
+    const int NC = getenv("BSX_GPU_COMPUTE") ? max(1, min(NB, atoi(getenv("BSX_GPU_COMPUTE")))) : NB;
     const int NG = ND * NB;                                                                          // GPU-stage threads
     Ring &ring = *new Ring(max(6, NG + 4));  // never freed: error paths exit() while side threads may still touch it
     const bool pe = !o.a_file.empty() && !o.b_file.empty();
@@ -670,6 +675,12 @@ int main(int argc, char **argv)
     Formatter totals(o, rv);
     unsigned total = 0;
     double busy[4] = {0, 0, 0, 0}, gpu_part[3] = {0, 0, 0};  // gpu_part: upload, align, read-back
+    // BSX_TIMING=2: when which batch was in which stage (0 parse, 1 upload, 2 align, 3 read-back, 4 format, 5 write)
+    struct Ev { long k; int stage; double t0, t1; };
+    vector<Ev> events;
+    mutex mu_ev;
+    const bool ev_on = getenv("BSX_TIMING") && atoi(getenv("BSX_TIMING")) >= 2;
+    auto log_ev = [&](long k, int stage, double a, double b) { if (ev_on) { lock_guard<mutex> lk(mu_ev); events.push_back({k, stage, a, b}); } };
     std::atomic<long long> cpu_ns[4];  // CPU time of the stages' threads: parse, gpu drivers, format workers, write threads
     for (auto &c : cpu_ns) c = 0;
     auto add_cpu = [&](int st, double t0) { cpu_ns[st] += (long long)((thread_cpu_s() - t0) * 1e9); };
@@ -699,6 +710,7 @@ int main(int argc, char **argv)
             add_cpu(0, c0);
             if (pe) tb.join();
             busy[0] += now_s() - t;
+            log_ev(k, 0, t, now_s());
             if (!n1) break;
             s.n = n1;
             s.total_after = ra.index - o.read_start + 1;
@@ -728,6 +740,18 @@ int main(int argc, char **argv)
         { lock_guard<mutex> lk(chain.mu); chain.state = st; chain.have = k; }
         chain.cv.notify_all();
     };
+    struct Gate { mutex mu; condition_variable cv; int free_slots; };
+    vector<Gate> gates(ND);
+    for (Gate &x : gates) x.free_slots = NC;
+    auto run_gated = [&](int g, bsx_batch *batch) {
+        Gate &G = gates[g % ND];
+        { unique_lock<mutex> lk(G.mu); G.cv.wait(lk, [&] { return G.free_slots > 0; }); G.free_slots--; }
+        int r = bsx_batch_run(batch);
+        if (!r) r = bsx_batch_sync(batch);
+        { lock_guard<mutex> lk(G.mu); G.free_slots++; }
+        G.cv.notify_one();
+        return r;
+    };
     auto gpu_stage = [&](int g) {
         bsx_batch *batch = batches[g];
         for (long k = g; ring.acquire(k, 1); k += NG) {
@@ -741,7 +765,7 @@ int main(int argc, char **argv)
                 if (r) die(r, "uploading reads");
                 if (p1_exact) chain_state(batch, k);
                 t1 = now_s();
-                if ((r = bsx_batch_run(batch)) || (r = bsx_batch_sync(batch))) die(r, "aligning");
+                if ((r = run_gated(g, batch))) die(r, "aligning");
                 t2 = now_s();
                 s.hits.resize(n); s.cca.resize(n);
                 if ((r = bsx_batch_results_se(batch, s.hits.data(), s.cca.data()))) die(r, "reading results");
@@ -752,13 +776,14 @@ int main(int argc, char **argv)
                 if (r) die(r, "uploading reads");
                 if (p1_exact) chain_state(batch, k);
                 t1 = now_s();
-                if ((r = bsx_batch_run(batch)) || (r = bsx_batch_sync(batch))) die(r, "aligning");
+                if ((r = run_gated(g, batch))) die(r, "aligning");
                 t2 = now_s();
                 s.pairs.resize(n); s.cca.resize(n); s.ccb.resize(n);
                 if ((r = bsx_batch_results_pe(batch, s.pairs.data(), s.cca.data(), s.ccb.data(), nullptr))) die(r, "reading results");
             }
             add_cpu(1, c0);
-            { const double t3 = now_s(); lock_guard<mutex> lk(mu_busy); busy[1] += t3 - t; gpu_part[0] += t1 - t; gpu_part[1] += t2 - t1; gpu_part[2] += t3 - t2; }
+            { const double t3 = now_s(); lock_guard<mutex> lk(mu_busy); busy[1] += t3 - t; gpu_part[0] += t1 - t; gpu_part[1] += t2 - t1; gpu_part[2] += t3 - t2;
+              log_ev(k, 1, t, t1); log_ev(k, 2, t1, t2); log_ev(k, 3, t2, t3); }
             ring.release(k, 2);
         }
     };
@@ -809,6 +834,7 @@ int main(int argc, char **argv)
             for (thread &x : th) x.join();
             for (const Formatter &f : fm) { totals.n_aligned += f.n_aligned; totals.n_aligned_pairs += f.n_aligned_pairs; totals.n_aligned_a += f.n_aligned_a; totals.n_aligned_b += f.n_aligned_b; }
             busy[2] += now_s() - t;
+            log_ev(k, 4, t, now_s());
             ring.release(k, 3);
         }
     });
@@ -836,6 +862,7 @@ int main(int argc, char **argv)
         }
         total = s.total_after;
         busy[3] += now_s() - t;
+        log_ev(k, 5, t, now_s());
         cout << total << " reads finished. " << time(NULL) - t_begin << " secs passed" << endl;
         ring.release(k, 0);
     }
@@ -875,6 +902,12 @@ int main(int argc, char **argv)
                         "\"mapping_cpu_s\": {\"user\": %.2f, \"sys\": %.2f, \"parse_threads\": %.2f, \"gpu_driver_threads\": %.2f, \"format_workers\": %.2f, \"write_threads\": %.2f}, "
                         "\"stage_busy_s\": {\"parse\": %.3f, \"gpu\": %.3f, \"format\": %.3f, \"write\": %.3f, \"gpu_upload\": %.3f, \"gpu_align\": %.3f, \"gpu_readback\": %.3f}}\n",
                 t_loaded - t0, t_indexed - t_loaded, t_map1 - t_map0, total, pe ? 2 * total : total, workers, ncpu, ru_user, ru_sys, cpu_ns[0] * 1e-9, cpu_ns[1] * 1e-9, cpu_ns[2] * 1e-9, cpu_ns[3] * 1e-9, busy[0], busy[1], busy[2], busy[3], gpu_part[0], gpu_part[1], gpu_part[2]);
+    if (ev_on) {
+        fprintf(stderr, "{\"events\": [");
+        for (size_t i = 0; i < events.size(); i++)
+            fprintf(stderr, "%s[%ld, %d, %.4f, %.4f]", i ? ", " : "", events[i].k, events[i].stage, events[i].t0 - t_map0, events[i].t1 - t_map0);
+        fprintf(stderr, "]}\n");
+    }
     for (int g = 0; g < NG; g++) bsx_batch_destroy(batches[g]);
     for (bsx_ref *r : refs) bsx_ref_destroy(r);
     return 0;

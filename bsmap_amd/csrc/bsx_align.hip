@@ -2044,6 +2044,9 @@ __global__ __launch_bounds__(256, PE ? BSX_HCTRL_WAVES : BSX_HCTRL_WAVES_SE) voi
 #ifndef BSX_HSCAN_VVV
 #define BSX_HSCAN_VVV 1
 #endif
+#ifndef BSX_HSCAN_RV
+#define BSX_HSCAN_RV 3  /* read words kept in vector registers as well (stage 1) */
+#endif
 struct ScanAcc { uint32_t c1, f5, nv; };  // per wave (scalar registers, counted with s_bcnt1 on the compare masks): candidates with w0ref > thres / evaluated in full with w01ref <= thres / (RRBS) candidates at all
 struct ScanCtx {
     const uint32_t *refall;  // forward copy; the rc copy follows it in the same allocation
@@ -2060,7 +2063,7 @@ struct ScanCtx {
 #if BSX_HSCAN_VVV
     // ... and so do the read words themselves and the 0xAAAAAAAA of the rule: v_bitop3 with an SGPR operand issues at the rate of the shift /
     // popcount class (2.6 SIMD cycles per wave64 instruction), with three VGPR operands at that of v_xor (1.5; profiles/r03c_valu_issue.json)
-    uint32_t rv[9], kA;
+    uint32_t rv[BSX_HSCAN_RV], kA;
 #endif
 };
 // bsx_mismatch_hi with all operands in vector registers and the shift as an add (both in the fast VALU class)
@@ -2074,7 +2077,7 @@ __device__ __forceinline__ uint32_t mism_vvv(uint32_t kA, uint32_t read, uint32_
 #if BSX_HSCAN_VVV
 __device__ __forceinline__ uint32_t hscan_mism(const ScanCtx &X, const uint32_t (&rw)[9], int t, uint32_t f)
 {
-    const uint32_t y = (X.rv[t] ^ f) & X.tv[t];
+    const uint32_t y = ((t < BSX_HSCAN_RV ? X.rv[t] : rw[t]) ^ f) & X.tv[t];  // (stage 2 keeps its read words in SGPRs: six registers that decide between 6 waves per SIMD with and without spills)
     uint32_t y2;
     asm("v_add_u32 %0, %1, %1" : "=v"(y2) : "v"(y));  // y << 1 as an add: v_lshlrev is in the slow class
     return (y2 | y) & X.kA;
@@ -2214,30 +2217,11 @@ __device__ __forceinline__ void hscan_step(ScanCtx &X, uint32_t (&e)[4], const u
     for (int u = 0; u < 4; u++) hscan_eval<!FULL>(X, r0[u], pm1[u], boff[u], valid[u], tag + ((uint32_t)u << 14), u, rw, rm);
 }
 
-__global__ __launch_bounds__(64 * BSX_HSCAN_WPB, BSX_HSCAN_WAVES) void k_hscan(AlignArgs A, HeavyArgs H)
+// one scan task (a window of up to HS_TASK candidates of one published list) on one wave
+__device__ __forceinline__ void hscan_task(const AlignArgs &A, const HeavyArgs &H, uint32_t slot, int lane, int wv, uint32_t (&TAB)[BSX_HSCAN_WPB][4][32],
+                                           uint4 (&QBUF)[BSX_HSCAN_WPB][HS_QCAP], const uint32_t *ANCH)
 {
-    __shared__ uint32_t TAB[BSX_HSCAN_WPB][4][32];
-    __shared__ uint4 QBUF[BSX_HSCAN_WPB][HS_QCAP];
-    __shared__ uint32_t ANCH[BSX_LDS_CHR + 1];  // RRBS: chromosome anchors (entries carry chromosome-local positions)
     const DevParams &P = A.P;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (P.rrbs) {
-        if (P.n_chr <= BSX_LDS_CHR) for (uint32_t i = threadIdx.x; i <= P.n_chr; i += 64 * BSX_HSCAN_WPB) ANCH[i] = P.anchor[i];
-        __syncthreads();
-    }
-    // one task per wave, no queue: the blocks of a pass retire one by one, so the control kernel of the other unit
-    // group (high-priority stream) finds free slots while this kernel is still running
-    const uint32_t n_tasks = min(*H.n_tasks, H.task_cap);
-    // Tasks are taken in key order (= by the index entries they walk): the reads that walk the same giant bucket then do
-    // so at the same time, and each line of entries / reference is fetched from memory once for all of them
-    // (the grid is sized for the whole task pool — the host does not know the count —: blocks beyond the tasks of this pass leave at once)
-    uint32_t slot = blockIdx.x * BSX_HSCAN_WPB + (uint32_t)wv;
-    if (H.xcd_map) {  // blocks of one XCD (dispatched round-robin) take a contiguous part of the order
-        const uint32_t per_xcd = ((n_tasks + BSX_HSCAN_WPB - 1) / BSX_HSCAN_WPB + 7u) >> 3;
-        if ((blockIdx.x >> 3) >= per_xcd) return;
-        slot = ((blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3)) * BSX_HSCAN_WPB + (uint32_t)wv;
-    }
-    if (slot >= n_tasks) return;
     const uint32_t t = H.order ? rfl(H.order[slot]) : slot;
     const uint32_t hraw = rfl(H.tasks[t].h), hidx = hraw & 0x3fffffffu, tc0 = rfl(H.tasks[t].c0), tn = rfl(H.tasks[t].n);
     HTaskOut *o = &H.tout[t];
@@ -2259,7 +2243,7 @@ __global__ __launch_bounds__(64 * BSX_HSCAN_WPB, BSX_HSCAN_WAVES) void k_hscan(A
     for (int k = 0; k < 9; k++) { X.tv[k] = bsx_tmask(rw[k], rm[k]); if (k < BSX_HSCAN_TMV) asm volatile("" : "+v"(X.tv[k])); }
 #if BSX_HSCAN_VVV
 #pragma unroll
-    for (int k = 0; k < 9; k++) { X.rv[k] = rw[k]; asm volatile("" : "+v"(X.rv[k])); }
+    for (int k = 0; k < BSX_HSCAN_RV; k++) { X.rv[k] = rw[k]; asm volatile("" : "+v"(X.rv[k])); }
     X.kA = 0xAAAAAAAAu; asm volatile("" : "+v"(X.kA));
 #endif
     const uint32_t cref_off = (uint32_t)((const uint8_t *)P.crefcat - (const uint8_t *)P.refcat);  // both copies live in one allocation (bsx_api.hip)
@@ -2302,6 +2286,39 @@ __global__ __launch_bounds__(64 * BSX_HSCAN_WPB, BSX_HSCAN_WAVES) void k_hscan(A
             atomicAdd((u64 *)&sh[0], (u64)n_cand); atomicAdd((u64 *)&sh[1], (u64)words);
             atomicAdd((u64 *)&sh[2], (u64)n1); atomicAdd((u64 *)&sh[3], (u64)n5);
         }
+    }
+}
+
+__global__ __launch_bounds__(64 * BSX_HSCAN_WPB, BSX_HSCAN_WAVES) void k_hscan(AlignArgs A, HeavyArgs H)
+{
+    __shared__ uint32_t TAB[BSX_HSCAN_WPB][4][32];
+    __shared__ uint4 QBUF[BSX_HSCAN_WPB][HS_QCAP];
+    __shared__ uint32_t ANCH[BSX_LDS_CHR + 1];  // RRBS: chromosome anchors (entries carry chromosome-local positions)
+    const DevParams &P = A.P;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (P.rrbs) {
+        if (P.n_chr <= BSX_LDS_CHR) for (uint32_t i = threadIdx.x; i <= P.n_chr; i += 64 * BSX_HSCAN_WPB) ANCH[i] = P.anchor[i];
+        __syncthreads();
+    }
+    // one task per wave and sweep, no queue: the blocks of a pass retire one by one, so the control kernel of the other unit
+    // group (high-priority stream) finds free slots while this kernel is still running
+    const uint32_t n_tasks = min(*H.n_tasks, H.task_cap);
+    // Tasks are taken in key order (= by the index entries they walk): the reads that walk the same giant bucket then do
+    // so at the same time, and each line of entries / reference is fetched from memory once for all of them.
+    // The host does not know the count: it sizes the grid for the whole task pool (blocks beyond the tasks of the pass leave at once)
+    // or, in the tail of a batch, for a few thousand tasks — then a block sweeps over the order with the stride of the grid.
+    const uint32_t nvb = (n_tasks + BSX_HSCAN_WPB - 1) / BSX_HSCAN_WPB, per_xcd = (nvb + 7u) >> 3;
+    for (uint32_t vb = blockIdx.x;; vb += gridDim.x) {
+        uint32_t slot;
+        if (H.xcd_map) {  // blocks of one XCD (dispatched round-robin; the grid is a multiple of 8) take a contiguous part of the order
+            if ((vb >> 3) >= per_xcd) break;
+            slot = ((vb & 7u) * per_xcd + (vb >> 3)) * BSX_HSCAN_WPB + (uint32_t)wv;
+        } else {
+            if (vb >= nvb) break;
+            slot = vb * BSX_HSCAN_WPB + (uint32_t)wv;
+        }
+        if (slot < n_tasks) hscan_task(A, H, slot, lane, wv, TAB, QBUF, ANCH);
+        wave_fence();
     }
 }
 
@@ -2350,10 +2367,11 @@ __global__ __launch_bounds__(256, 4) void k_hscan_shared(AlignArgs A, HeavyArgs 
     __syncthreads();
     const uint32_t *anchor = P.n_chr <= BSX_LDS_CHR ? ANCH : P.anchor;
     const uint32_t n_tasks = min(*H.n_tasks, H.task_cap);
-    const uint32_t s0 = (blockIdx.x * 4u + (uint32_t)wv) * HS_SHARE;
-    if (s0 >= n_tasks) return;
-    const uint32_t nj = min(HS_SHARE, n_tasks - s0);
     const uint32_t cref_off = (uint32_t)((const uint8_t *)P.crefcat - (const uint8_t *)P.refcat);
+    uint32_t kA = 0xAAAAAAAAu; asm volatile("" : "+v"(kA));   // in a VGPR: see hscan_mism
+    // (grid sized for the task pool, or — in the tail of a batch — smaller: then a wave sweeps over the order with the stride of the grid)
+    for (uint32_t s0 = (blockIdx.x * 4u + (uint32_t)wv) * HS_SHARE; s0 < n_tasks; s0 += gridDim.x * 4u * HS_SHARE) {
+    const uint32_t nj = min(HS_SHARE, n_tasks - s0);
     // lane j < nj: task j of this wave, in scan order, and the signature of its window
     uint32_t tid = 0, th = 0, tc0 = 0, tn = 0, tkey = 0, sh_ = 0, stx = 0, stw = 0, snw = 0;
     if ((uint32_t)lane < nj) {
@@ -2370,7 +2388,6 @@ __global__ __launch_bounds__(256, 4) void k_hscan_shared(AlignArgs A, HeavyArgs 
         }
     }
     u64 st_cand = 0, st_words = 0, st_n1 = 0, st_n5 = 0;  // statistics of the scan kernel (lane 0)
-    uint32_t kA = 0xAAAAAAAAu; asm volatile("" : "+v"(kA));   // in a VGPR: see hscan_mism
     for (uint32_t i0 = 0; i0 < nj;) {
         if (rl(tn, (int)i0) == 0) { i0++; continue; }
         // the run of tasks from i0 that cover exactly the same window
@@ -2475,6 +2492,8 @@ __global__ __launch_bounds__(256, 4) void k_hscan_shared(AlignArgs A, HeavyArgs 
         u64 *sh = (u64 *)A.scan_stats + (size_t)(blockIdx.x & 63u) * 8;
         atomicAdd((u64 *)&sh[0], st_cand); atomicAdd((u64 *)&sh[1], st_words); atomicAdd((u64 *)&sh[2], st_n1); atomicAdd((u64 *)&sh[3], st_n5);
     }
+    wave_fence();
+    }
 }
 }  // namespace
 
@@ -2521,18 +2540,19 @@ void bsx_launch_hctrl(const AlignArgs &A, const HeavyArgsRaw &R, int paired, int
 // The scan launches are sized for the group's whole task pool: the number of tasks a control pass published stays on the device
 // (H.n_tasks), blocks beyond it exit at once (28 us for 131 072 empty blocks, profiles/r03_launch_cost.json) — no host read-back
 // between a control pass and its scan.
-void bsx_launch_hscan_shared(const AlignArgs &A, const HeavyArgsRaw &R, hipStream_t stream)
+// max_tasks: 0 = a grid for the whole task pool; otherwise a grid for that many tasks, whose blocks sweep over whatever the pass published
+void bsx_launch_hscan_shared(const AlignArgs &A, const HeavyArgsRaw &R, hipStream_t stream, uint32_t max_tasks)
 {
     const HeavyArgs H = typed(R);
-    const uint32_t jobs = (R.task_cap + HS_SHARE - 1) / HS_SHARE;
+    const uint32_t jobs = ((max_tasks ? std::min(max_tasks, R.task_cap) : R.task_cap) + HS_SHARE - 1) / HS_SHARE;
     hipLaunchKernelGGL(k_hscan_shared, dim3((jobs + 3) / 4), dim3(256), 0, stream, A, H);
 }
 
-void bsx_launch_hscan(const AlignArgs &A, const HeavyArgsRaw &R, hipStream_t stream)
+void bsx_launch_hscan(const AlignArgs &A, const HeavyArgsRaw &R, hipStream_t stream, uint32_t max_tasks)
 {
     const HeavyArgs H = typed(R);
-    uint32_t blocks = (R.task_cap + BSX_HSCAN_WPB - 1) / BSX_HSCAN_WPB;
-    if (H.xcd_map) blocks = (blocks + 7u) & ~7u;  // the same number of blocks for each of the 8 XCDs
+    uint32_t blocks = ((max_tasks ? std::min(max_tasks, R.task_cap) : R.task_cap) + BSX_HSCAN_WPB - 1) / BSX_HSCAN_WPB;
+    blocks = (blocks + 7u) & ~7u;  // the same number of blocks for each of the 8 XCDs (k_hscan's sweep relies on a multiple of 8)
     hipLaunchKernelGGL(k_hscan, dim3(blocks), dim3(64 * BSX_HSCAN_WPB), 0, stream, A, H);
 }
 

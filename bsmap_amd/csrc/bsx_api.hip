@@ -241,6 +241,7 @@ struct bsx_batch {
         uint32_t *d_bins = nullptr, *d_bstart = nullptr, *d_chunk_tot = nullptr, *d_rank = nullptr, *d_order = nullptr;
     } grp[BSX_MAX_GROUPS];
     int n_groups = 1, chunk_passes = 2, trace = 0, hctrl_blocks_per_cu = 1;
+    uint32_t tail_tasks = 16384, tail_grid_tasks = 4096;  // a group whose passes publish fewer tasks than tail_tasks scans them with a grid for tail_grid_tasks on its control stream
     uint32_t bin_shift = 0, n_bins = 1;
     hipEvent_t ev_sync = nullptr, ev_wait = nullptr;
     std::vector<hipEvent_t> scan_ev;  // pairs of timing events around every k_hscan launch of the last run (pool grows on demand)
@@ -327,6 +328,8 @@ static int ensure_scratch(bsx_batch *b)
     // (C3 with two batches in flight 136.5 -> 131.3 ms per step, C4 211 -> 195; BSX_HCTRL_BLOCKS: tuning knob)
     b->hctrl_blocks_per_cu = 1;
     if (const char *e = getenv("BSX_HCTRL_BLOCKS")) b->hctrl_blocks_per_cu = std::max(1, std::min(bsx_hctrl_occupancy(b->paired), atoi(e)));
+    if (const char *e = getenv("BSX_TAIL_TASKS")) b->tail_tasks = (uint32_t)std::max(0, atoi(e));           // 0: no tail mode (tuning)
+    if (const char *e = getenv("BSX_TAIL_GRID")) b->tail_grid_tasks = (uint32_t)std::max(64, atoi(e));
     if (!b->d_heavy_list) {
         // deferred units handled per round (more than this: several rounds): what 26 GB of slabs hold — 24 576 units of the 1.07 MB paired
         // -v 6 slab, 111 K of the 234 KB single-end -v 2 one.  RRBS defers a third of its reads (Alu-like fragments) and its scan kernel
@@ -686,7 +689,7 @@ extern "C" int bsx_batch_run_range(bsx_batch *b, uint32_t first_unit, uint32_t n
         // run beside it — they are latency-bound chains of a few thousand waves.
         const bool shared_scan = b->ref->P.rrbs != 0;  // RRBS: runs of tasks over one window, scanned together
         const int n_groups = b->n_groups;
-        struct Group { uint32_t n0 = 0, passes = 0, polls = 0, polled = 0; int cur = 0; bool done = true; HeavyArgsRaw H; uint32_t *blk[2]; };
+        struct Group { uint32_t n0 = 0, passes = 0, polls = 0, polled = 0; int cur = 0; bool done = true, tail = false; HeavyArgsRaw H; uint32_t *blk[2]; };
         volatile uint32_t *pinned = (volatile uint32_t *)b->h_pinned;
         for (uint32_t base = 0; base < n_heavy; base += b->hcap) {
             const uint32_t n_round = std::min(b->hcap, n_heavy - base);
@@ -711,20 +714,29 @@ extern "C" int bsx_batch_run_range(bsx_batch *b, uint32_t first_unit, uint32_t n
                 // scan order of the tasks this pass published, still on the group's stream: done by the time the main stream gets to the scan
                 q.H.order = hw.d_order; q.H.xcd_map = 1;
                 bsx_launch_task_order(q.H, b->bin_shift, b->n_bins, hw.d_bins, hw.d_bstart, hw.d_chunk_tot, hw.d_rank, hw.d_order, in, hw.s_ctrl);
-                HIP_TRY(hipEventRecord(hw.ev_ctrl, hw.s_ctrl));
-                HIP_TRY(hipStreamWaitEvent(b->stream, hw.ev_ctrl, 0));
+                // The scan: on the batch's stream with a grid for the whole task pool — or, once the group is in its tail (few tasks per
+                // pass, see the poll loop), behind the control kernel on the group's own high-priority stream with a small grid whose
+                // blocks sweep: beside ANOTHER batch's bulk scans a pool-sized grid of mostly empty blocks only trickles through the
+                // dispatcher, which stretched the tail of the older batch until the younger one's bulk was done — two batches in flight
+                // always finished together, and their transfers never overlapped the other's kernels.
+                hipStream_t s_scan = b->stream;
+                if (q.tail) s_scan = hw.s_ctrl;
+                else {
+                    HIP_TRY(hipEventRecord(hw.ev_ctrl, hw.s_ctrl));
+                    HIP_TRY(hipStreamWaitEvent(b->stream, hw.ev_ctrl, 0));
+                }
                 if (b->scan_ev_used + 2 > b->scan_ev.size()) {
                     hipEvent_t e0, e1;
                     HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
                     b->scan_ev.push_back(e0); b->scan_ev.push_back(e1);
                 }
-                HIP_TRY(hipEventRecord(b->scan_ev[b->scan_ev_used], b->stream));
-                if (shared_scan) bsx_launch_hscan_shared(A, q.H, b->stream);
-                else bsx_launch_hscan(A, q.H, b->stream);
+                HIP_TRY(hipEventRecord(b->scan_ev[b->scan_ev_used], s_scan));
+                if (shared_scan) bsx_launch_hscan_shared(A, q.H, s_scan, q.tail ? b->tail_grid_tasks : 0);
+                else bsx_launch_hscan(A, q.H, s_scan, q.tail ? b->tail_grid_tasks : 0);
                 HIP_TRY(hipGetLastError());
-                HIP_TRY(hipEventRecord(b->scan_ev[b->scan_ev_used + 1], b->stream));
+                HIP_TRY(hipEventRecord(b->scan_ev[b->scan_ev_used + 1], s_scan));
                 b->scan_ev_used += 2;
-                HIP_TRY(hipEventRecord(hw.ev_scan, b->stream));
+                HIP_TRY(hipEventRecord(hw.ev_scan, s_scan));
                 q.cur ^= 1; q.passes++;
                 b->last_heavy_iters++;
                 return BSX_OK;
@@ -770,6 +782,7 @@ extern "C" int bsx_batch_run_range(bsx_batch *b, uint32_t first_unit, uint32_t n
                     q.polled++;
                     if (b->trace) fprintf(stderr, "[bsx heavy] paired %d base %u group %d passes %u active %u tasks %u\n", b->paired, base, g, q.polled * b->chunk_passes, n_act, n_tasks);
                     if (n_act == 0) { q.done = true; n_open--; }  // (passes already queued for this group find no active unit)
+                    else if (b->tail_tasks && n_tasks < b->tail_tasks) q.tail = true;  // (the counts are two chunks old: a later pass may publish more — its blocks then sweep)
                     else if (q.passes > 200000) { g_bsx_err = "heavy pipeline did not converge"; return BSX_ERR_DEVICE; }
                 }
                 if (n_open > 0) { int rc = enqueue_chunk(); if (rc) return rc; }

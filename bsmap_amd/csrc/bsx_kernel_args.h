@@ -65,8 +65,8 @@ size_t bsx_leakrec_bytes(void);
 size_t bsx_leakstate_bytes(void);
 uint32_t bsx_leak_blk(void);
 void bsx_launch_hctrl(const AlignArgs &A, const HeavyArgsRaw &H, int paired, int grid_blocks, hipStream_t stream);
-void bsx_launch_hscan(const AlignArgs &A, const HeavyArgsRaw &H, hipStream_t stream);         // grid sized for H.task_cap; the count stays on the device
-void bsx_launch_hscan_shared(const AlignArgs &A, const HeavyArgsRaw &H, hipStream_t stream);  // RRBS: up to 16 tasks of one window per wave
+void bsx_launch_hscan(const AlignArgs &A, const HeavyArgsRaw &H, hipStream_t stream, uint32_t max_tasks = 0);         // grid sized for H.task_cap (or max_tasks: the blocks sweep); the count stays on the device
+void bsx_launch_hscan_shared(const AlignArgs &A, const HeavyArgsRaw &H, hipStream_t stream, uint32_t max_tasks = 0);  // RRBS: up to 16 tasks of one window per wave
 // scan order of a pass (task ids by the index entry they start at, 2^shift entries per bin), computed on the device
 uint32_t bsx_bin_chunks(uint32_t n_bins);
 void bsx_launch_task_order(const HeavyArgsRaw &H, uint32_t shift, uint32_t n_bins, uint32_t *bins, uint32_t *bstart, uint32_t *chunk_tot, uint32_t *rank, uint32_t *order,

@@ -84,11 +84,18 @@ def _run(a):
     if os.environ.get("BSX_TASKSET"):   # experiment: pin the whole command line to a CPU list (one NUMA node)
         cmd = ["taskset", "-c", os.environ["BSX_TASKSET"]] + cmd
     t0 = time.time()
-    res = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, BSX_TIMING="1"))
+    res = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, BSX_TIMING=os.environ.get("BSX_TIMING", "1")))
     wall = time.time() - t0
     if res.returncode != 0:
         raise RuntimeError("bsmap failed: " + res.stdout[-2000:] + res.stderr[-2000:])
-    tim = json.loads([l for l in res.stderr.split("\n") if l.startswith("{")][-1])
+    js = [json.loads(l) for l in res.stderr.split("\n") if l.startswith("{")]
+    tim = [j for j in js if "mapping_s" in j][-1]
+    ev = [j for j in js if "events" in j]
+    pt = [l for l in res.stderr.split("\n") if l.startswith("pace:")]
+    if pt:
+        tim["pace_trace"] = pt
+    if ev:   # BSX_TIMING=2: per batch, when it was in which stage (tools/e2e_gantt.py)
+        tim["events"] = ev[-1]["events"]
     sam_bytes = os.path.getsize(out)
     summary = [l for l in res.stdout.split("\n") if l.startswith(("pairs", "single"))]
     r = {"pairs": n, "genome_bp": int(sum(lens)), "fasta_bytes": os.path.getsize(fa), "fastq_bytes": sum(os.path.getsize(p) for p in fq), "sam_bytes": sam_bytes,
