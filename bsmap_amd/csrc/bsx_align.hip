@@ -2295,7 +2295,7 @@ __global__ __launch_bounds__(64 * BSX_HSCAN_WPB, BSX_HSCAN_WAVES) void k_hscan(A
     __shared__ uint4 QBUF[BSX_HSCAN_WPB][HS_QCAP];
     __shared__ uint32_t ANCH[BSX_LDS_CHR + 1];  // RRBS: chromosome anchors (entries carry chromosome-local positions)
     const DevParams &P = A.P;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = (int)rfl(threadIdx.x >> 6);  // (the wave number as a scalar: what depends on it stays wave-uniform for the compiler)
     if (P.rrbs) {
         if (P.n_chr <= BSX_LDS_CHR) for (uint32_t i = threadIdx.x; i <= P.n_chr; i += 64 * BSX_HSCAN_WPB) ANCH[i] = P.anchor[i];
         __syncthreads();
@@ -2334,6 +2334,9 @@ __global__ __launch_bounds__(64 * BSX_HSCAN_WPB, BSX_HSCAN_WAVES) void k_hscan(A
 // Results per task are exactly those of k_hscan: survivors in list order, candidate count and word count (align.h:189-197).
 // ---------------------------------------------------------------------------------------------------------------
 #define HS_SHARE 16u  /* tasks per wave */
+#ifndef BSX_HSHARED_WAVES
+#define BSX_HSHARED_WAVES 5  /* waves per SIMD the register budget is set for */
+#endif
 struct SharedChunk { uint32_t wd[10]; uint32_t pm1, strand; bool valid; };
 
 __device__ __forceinline__ SharedChunk shared_load(const U2 *__restrict__ ent2, uint32_t idx, bool in_range, uint32_t h, uint32_t tag_xor, uint32_t tag_want,
@@ -2357,12 +2360,12 @@ __device__ __forceinline__ SharedChunk shared_load(const U2 *__restrict__ ent2, 
     return c;
 }
 
-__global__ __launch_bounds__(256, 4) void k_hscan_shared(AlignArgs A, HeavyArgs H)
+__global__ __launch_bounds__(256, BSX_HSHARED_WAVES) void k_hscan_shared(AlignArgs A, HeavyArgs H)
 {
     __shared__ __attribute__((aligned(16))) uint32_t UW[4][HS_SHARE][20];   // per read of the run: 9 read words, 9 T-masks, threshold, task id
     __shared__ uint32_t ANCH[BSX_LDS_CHR + 1];
     const DevParams &P = A.P;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = (int)rfl(threadIdx.x >> 6);  // (the wave number as a scalar: what depends on it stays wave-uniform for the compiler)
     if (P.n_chr <= BSX_LDS_CHR) for (uint32_t i = threadIdx.x; i <= P.n_chr; i += 256) ANCH[i] = P.anchor[i];
     __syncthreads();
     const uint32_t *anchor = P.n_chr <= BSX_LDS_CHR ? ANCH : P.anchor;
