@@ -479,6 +479,18 @@ def test_heavy_units_redone_when_their_duplicate_set_overflows(pe, heavy_genome,
     assert test_heavy_pipeline_large_buckets.last_redo > 20
 
 
+@pytest.mark.parametrize("env", [dict(BSX_TAIL_TASKS="100000000", BSX_TAIL_GRID="64"), dict(BSX_TAIL_TASKS="0"), dict(BSX_HEAVY_GROUPS="2", BSX_TAIL_TASKS="100000000")],
+                         ids=["tail_from_the_start_tiny_grid", "no_tail_mode", "two_groups_tail"])
+@pytest.mark.parametrize("pe", [False, True], ids=["se", "pe"])
+def test_heavy_pipeline_scan_grids_and_streams_do_not_matter(pe, env, heavy_genome, oracle, monkeypatch):
+    """the scan kernels take their tasks in a grid-stride sweep, so any grid is correct: the tail mode (small grids on the group's
+    high-priority stream) forced on from the first pass with a grid for 64 tasks, switched off, and combined with two unit groups —
+    records and work counters equal the oracle's each time"""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    test_heavy_pipeline_large_buckets(pe, heavy_genome, oracle)
+
+
 @pytest.mark.parametrize("extra", [dict(w=20), dict(w=3, r=0), dict(w=150, n=1), dict(r=0, v=3)], ids=["w20", "w3_r0", "w150_n1", "r0_v3"])
 def test_heavy_pipeline_caps_and_early_returns(extra, heavy_genome, oracle):
     """-w caps and -r 0 on reads with hundreds of hits: the 64-at-a-time survivor acceptance has to cut its groups at
