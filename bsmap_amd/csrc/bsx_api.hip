@@ -4,6 +4,7 @@
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <time.h>
 
 #include <cstdio>
 #include <cstdlib>
@@ -274,9 +275,22 @@ struct bsx_batch {
     bool ran = false;
 };
 
-// wait for everything queued on the batch's stream WITHOUT spinning: hipStreamSynchronize busy-waits, and the driver threads of a
-// command line share a CPU quota with its format and write workers — an event with the blocking-sync flag lets the
-// thread sleep
+// Waiting without burning a CPU.  hipStreamSynchronize busy-waits, and so — measured on this ROCm (tools/driver_cpu.py: thread CPU time =
+// wall time of a Do_Batch) — does hipEventSynchronize on an event created with hipEventBlockingSync.  The thread that drives a batch
+// therefore polls the event and sleeps in between: 50 us at first (short waits stay short), 200 us after that.  The waits that sit on a
+// batch's critical path are two (the deferred-unit count behind the main kernel, the end of the run); the per-chunk polls of the heavy
+// pipeline run two chunks behind the queue.  Eight GPUs x three batches are 24 such threads under one CPU quota.
+static hipError_t wait_event(hipEvent_t ev)
+{
+    for (int n = 0;; n++) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e == hipSuccess) return hipSuccess;
+        if (e != hipErrorNotReady) return e;
+        (void)hipGetLastError();  // (hipErrorNotReady is sticky for hipGetLastError)
+        struct timespec ts = {0, n < 8 ? 50000L : 200000L};
+        nanosleep(&ts, nullptr);
+    }
+}
 static hipError_t stream_wait(bsx_batch *b);
 
 // duplicate-suppression set of one mate slab (Slab in bsx_align.hip).  WGBS and paired RRBS: every remembered coordinate is a
@@ -308,7 +322,7 @@ static hipError_t stream_wait(bsx_batch *b)
     if (!b->ev_wait) return hipStreamSynchronize(b->stream);
     hipError_t e = hipEventRecord(b->ev_wait, b->stream);
     if (e != hipSuccess) return e;
-    return hipEventSynchronize(b->ev_wait);
+    return wait_event(b->ev_wait);
 }
 
 static int ensure_scratch(bsx_batch *b)
@@ -777,7 +791,7 @@ extern "C" int bsx_batch_run_range(bsx_batch *b, uint32_t first_unit, uint32_t n
                     Group &q = G[g];
                     if (q.done) continue;
                     const uint32_t slot = q.polled % BSX_POLL_SLOTS;
-                    HIP_TRY(hipEventSynchronize(b->grp[g].ev_poll[slot]));
+                    HIP_TRY(wait_event(b->grp[g].ev_poll[slot]));
                     const uint32_t n_act = pinned[32 + 16 * g + 2 * slot], n_tasks = pinned[32 + 16 * g + 2 * slot + 1];
                     q.polled++;
                     if (b->trace) fprintf(stderr, "[bsx heavy] paired %d base %u group %d passes %u active %u tasks %u\n", b->paired, base, g, q.polled * b->chunk_passes, n_act, n_tasks);
