@@ -429,7 +429,7 @@ extern "C" int bsx_batch_create(bsx_ref *r, uint32_t max_units, int paired, bsx_
             if (hipStreamCreateWithPriority(&q.s_ctrl, hipStreamNonBlocking, hi_p) != hipSuccess) return fail(BSX_ERR_DEVICE);
             for (hipEvent_t *e : {&q.ev_ctrl, &q.ev_scan})
                 if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) return fail(BSX_ERR_DEVICE);
-            for (int k = 0; k < BSX_POLL_SLOTS; k++)  // the host sleeps on these (no spinning: one driver thread per device batch)
+            for (int k = 0; k < BSX_POLL_SLOTS; k++)  // the host polls these and sleeps in between (wait_event: one driver thread per device batch)
                 if (hipEventCreateWithFlags(&q.ev_poll[k], hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) return fail(BSX_ERR_DEVICE);
         }
         if (hipEventCreateWithFlags(&b->ev_sync, hipEventDisableTiming) != hipSuccess) return fail(BSX_ERR_DEVICE);
@@ -698,7 +698,7 @@ extern "C" int bsx_batch_run_range(bsx_batch *b, uint32_t first_unit, uint32_t n
         // chained by events on the device: the counts a control pass leaves (active units, tasks) stay there — the next control
         // pass reads its input count from memory, the scan launches are sized for the whole task pool and their surplus blocks exit.
         // The host enqueues `chunk_passes` passes per group at a time, keeps two such chunks queued ahead, and only looks at a
-        // group's active count once per chunk (sleeping on an event) to learn when the group is finished; passes that were queued
+        // group's active count once per chunk (polling an event, asleep in between) to learn when the group is finished; passes that were queued
         // beyond that point find nothing to do.  While k_hscan evaluates the tasks of one group, the control kernels of the others
         // run beside it — they are latency-bound chains of a few thousand waves.
         const bool shared_scan = b->ref->P.rrbs != 0;  // RRBS: runs of tasks over one window, scanned together
