@@ -540,7 +540,8 @@ int main(int argc, char **argv)
     // every upload and read-back happened beside an idle GPU; with three the runs no longer line up and one batch's transfers fall under
     // the others' kernels (12.6 -> 13.1 M reads/s end to end at hg38 size).  BSX_GPU_COMPUTE < BSX_GPU_BATCHES additionally limits how
     // many may be in their kernels at once (measured: no better — whichever thread wins the slot, results are consumed in input order).
-    const int NB = getenv("BSX_GPU_BATCHES") ? max(1, min(4, atoi(getenv("BSX_GPU_BATCHES")))) : 3;
+    // (RRBS: two — a batch of 2^20 reads keeps 74 GB of work pools there, and three of them leave no room on a 288 GB device.)
+    const int NB = getenv("BSX_GPU_BATCHES") ? max(1, min(4, atoi(getenv("BSX_GPU_BATCHES")))) : (p.rrbs ? 2 : 3);
     const int NC = getenv("BSX_GPU_COMPUTE") ? max(1, min(NB, atoi(getenv("BSX_GPU_COMPUTE")))) : NB;
     const int NG = ND * NB;                                                                          // GPU-stage threads
     Ring &ring = *new Ring(max(6, NG + 4));  // never freed: error paths exit() while side threads may still touch it
