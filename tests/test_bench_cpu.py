@@ -1,0 +1,56 @@
+"""bench.py's host-side logic that runs without a GPU: argument defaults, the CPU helpers, the other_configs command lines"""
+import json
+import os
+import subprocess
+import sys
+import types
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench as BN
+
+
+def test_default_steps_are_a_multiple_of_every_in_flight_count():
+    """with 2, 3 or 4 batches in flight every batch runs the same number of timed steps (a ragged last round costs 5-10 %)"""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    import re
+    steps = int(re.search(r'"--steps", type=int, default=(\d+)', src).group(1))
+    warm = int(re.search(r'"--warmup", type=int, default=(\d+)', src).group(1))
+    assert steps % 2 == 0 and steps % 3 == 0 and steps % 4 == 0 and warm >= 2
+
+
+def test_modes_cover_baseline_configs():
+    tags = sorted(m["tag"] for m in BN.MODES.values())
+    assert tags == ["C2", "C3", "C4", "C5"]
+    assert BN.MODES["pe"]["metric"].startswith("aligned reads/sec")
+    for m in BN.MODES.values():
+        assert m["workload"].startswith(m["tag"] + ":")
+
+
+def test_usable_cpus_and_node_cpus():
+    n = BN.usable_cpus()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    pin = BN.node_cpus(0, n)
+    assert pin is None or (len(pin) <= n and set(pin) <= set(range(os.cpu_count() or 1)))
+
+
+def test_other_configs_runs_every_other_mode_in_a_child(monkeypatch):
+    """the leg starts one child per mode with the side legs off and copies the child's line; a failing child is reported, not fatal"""
+    calls = []
+
+    def fake_run(cmd, capture_output, text, timeout):
+        calls.append(cmd)
+        mode = cmd[cmd.index("--mode") + 1]
+        if mode == "rrbs":
+            return types.SimpleNamespace(stdout="no json here\n", stderr="", returncode=1)
+        line = {"value": 1e6, "ms_per_step": 100.0, "steps": 6, "config": {"workload": "w", "batches_in_flight": 2, "aligned_fraction": 1.0},
+                "roofline": {"per_read": {"n_cand": 5.0}, "dominant_kernel": {"name": "k", "ms_per_step": 1.0, "candidates_per_s": 2.0}}}
+        return types.SimpleNamespace(stdout="noise\n" + json.dumps(line) + "\n", stderr="", returncode=0)
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    res = BN.other_configs(types.SimpleNamespace(genome="hg38", pairs_per_step=1 << 20))
+    assert [c[c.index("--mode") + 1] for c in calls] == ["se", "rrbs", "trim"]
+    for c in calls:
+        assert c[c.index("--other-configs") + 1] == "0" and c[c.index("--cpu-seconds") + 1] == "0" and int(c[c.index("--steps") + 1]) % 6 == 0
+    assert res["C2"]["reads_per_s"] == 1e6 and res["C5"]["dominant_kernel"]["name"] == "k" and "error" in res["C4"]
