@@ -539,9 +539,9 @@ int main(int argc, char **argv)
     // device batches per GPU.  Runs that start together end together (equal work, the GPU shared evenly), so with two batches per GPU
     // every upload and read-back happened beside an idle GPU; with three the runs no longer line up and one batch's transfers fall under
     // the others' kernels (12.6 -> 13.1 M reads/s end to end at hg38 size).  BSX_GPU_COMPUTE < BSX_GPU_BATCHES additionally limits how
-    // many may be in their kernels at once (measured: no better — whichever thread wins the slot, results are consumed in input order).
+    // many may be in their kernels at once, slots granted in batch order (measured with 4 to 6 batches and 2 or 3 slots: 11.9–12.8 M, no better).
     // (RRBS: two — a batch of 2^20 reads keeps 74 GB of work pools there, and three of them leave no room on a 288 GB device.)
-    const int NB = getenv("BSX_GPU_BATCHES") ? max(1, min(4, atoi(getenv("BSX_GPU_BATCHES")))) : (p.rrbs ? 2 : 3);
+    const int NB = getenv("BSX_GPU_BATCHES") ? max(1, min(8, atoi(getenv("BSX_GPU_BATCHES")))) : (p.rrbs ? 2 : 3);
     const int NC = getenv("BSX_GPU_COMPUTE") ? max(1, min(NB, atoi(getenv("BSX_GPU_COMPUTE")))) : NB;
     const int NG = ND * NB;                                                                          // GPU-stage threads
     Ring &ring = *new Ring(max(6, NG + 4));  // never freed: error paths exit() while side threads may still touch it
@@ -741,16 +741,16 @@ int main(int argc, char **argv)
         { lock_guard<mutex> lk(chain.mu); chain.state = st; chain.have = k; }
         chain.cv.notify_all();
     };
-    struct Gate { mutex mu; condition_variable cv; int free_slots; };
+    // compute slots per GPU, granted in batch order (a later batch never overtakes an earlier one: results are consumed in input order)
+    struct Gate { mutex mu; condition_variable cv; int free_slots; long next; };
     vector<Gate> gates(ND);
-    for (Gate &x : gates) x.free_slots = NC;
-    auto run_gated = [&](int g, bsx_batch *batch) {
+    for (int d = 0; d < ND; d++) { gates[d].free_slots = NC; gates[d].next = d; }   // GPU d runs the batches k with (k % NG) % ND == d ...
+    auto run_gated = [&](int g, long k, bsx_batch *batch) {
         Gate &G = gates[g % ND];
-        { unique_lock<mutex> lk(G.mu); G.cv.wait(lk, [&] { return G.free_slots > 0; }); G.free_slots--; }
+        if (NC < NB) { unique_lock<mutex> lk(G.mu); G.cv.wait(lk, [&] { return G.free_slots > 0 && G.next == k; }); G.free_slots--; G.next = k + ND; lk.unlock(); G.cv.notify_all(); }
         int r = bsx_batch_run(batch);
         if (!r) r = bsx_batch_sync(batch);
-        { lock_guard<mutex> lk(G.mu); G.free_slots++; }
-        G.cv.notify_one();
+        if (NC < NB) { { lock_guard<mutex> lk(G.mu); G.free_slots++; } G.cv.notify_all(); }
         return r;
     };
     auto gpu_stage = [&](int g) {
@@ -766,7 +766,7 @@ int main(int argc, char **argv)
                 if (r) die(r, "uploading reads");
                 if (p1_exact) chain_state(batch, k);
                 t1 = now_s();
-                if ((r = run_gated(g, batch))) die(r, "aligning");
+                if ((r = run_gated(g, k, batch))) die(r, "aligning");
                 t2 = now_s();
                 s.hits.resize(n); s.cca.resize(n);
                 if ((r = bsx_batch_results_se(batch, s.hits.data(), s.cca.data()))) die(r, "reading results");
@@ -777,7 +777,7 @@ int main(int argc, char **argv)
                 if (r) die(r, "uploading reads");
                 if (p1_exact) chain_state(batch, k);
                 t1 = now_s();
-                if ((r = run_gated(g, batch))) die(r, "aligning");
+                if ((r = run_gated(g, k, batch))) die(r, "aligning");
                 t2 = now_s();
                 s.pairs.resize(n); s.cca.resize(n); s.ccb.resize(n);
                 if ((r = bsx_batch_results_pe(batch, s.pairs.data(), s.cca.data(), s.ccb.data(), nullptr))) die(r, "reading results");
