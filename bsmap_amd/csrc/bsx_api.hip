@@ -344,6 +344,16 @@ static int ensure_scratch(bsx_batch *b)
     if (const char *e = getenv("BSX_HCTRL_BLOCKS")) b->hctrl_blocks_per_cu = std::max(1, std::min(bsx_hctrl_occupancy(b->paired), atoi(e)));
     if (const char *e = getenv("BSX_TAIL_TASKS")) b->tail_tasks = (uint32_t)std::max(0, atoi(e));           // 0: no tail mode (tuning)
     if (const char *e = getenv("BSX_TAIL_GRID")) b->tail_grid_tasks = (uint32_t)std::max(64, atoi(e));
+    // (the main kernel's per-wave slabs first: what cannot shrink; the pools below take what is left)
+    const uint64_t slots = b->debug ? b->max_units : (uint64_t)grid * 4;
+    const size_t bytes = (size_t)(slots * b->slab_bytes);
+    if (bytes > b->scratch_bytes) {
+        if (b->d_scratch) (void)hipFree(b->d_scratch);
+        b->d_scratch = nullptr;
+        HIP_TRY(hipMalloc((void **)&b->d_scratch, bytes));
+        HIP_TRY(hipMemsetAsync(b->d_scratch, 0, bytes, b->stream));  // the per-slab hash sets must start empty (same stream as the kernels)
+        b->scratch_bytes = bytes;
+    }
     if (!b->d_heavy_list) {
         // deferred units handled per round (more than this: several rounds): what 26 GB of slabs hold — 24 576 units of the 1.07 MB paired
         // -v 6 slab, 111 K of the 234 KB single-end -v 2 one.  RRBS defers a third of its reads (Alu-like fragments) and its scan kernel
@@ -358,18 +368,7 @@ static int ensure_scratch(bsx_batch *b)
         HIP_TRY(hipMalloc((void **)&b->d_heavy_list, ((size_t)b->max_units + 1) * 4));
         HIP_TRY(hipMalloc((void **)&b->d_heavy_count, 256));
         HIP_TRY(hipHostMalloc((void **)&b->h_pinned, 1024, hipHostMallocDefault));
-        HIP_TRY(hipMalloc((void **)&b->d_hstate, (size_t)b->hcap * bsx_hstate_bytes()));
-        if (getenv("BSX_POISON")) HIP_TRY(hipMemsetAsync(b->d_hstate, 0xA5, (size_t)b->hcap * bsx_hstate_bytes(), b->stream));  // test hook: recycled memory is not zero
-        HIP_TRY(hipMalloc((void **)&b->d_hslabs, (size_t)b->hcap * b->hslab_bytes));
-        HIP_TRY(hipMemsetAsync(b->d_hslabs, 0, (size_t)b->hcap * b->hslab_bytes, b->stream));
         HIP_TRY(hipMalloc((void **)&b->d_redo, ((size_t)b->max_units + 1) * 4));
-        HIP_TRY(hipMalloc((void **)&b->d_htasks, (size_t)b->task_cap * bsx_htask_bytes()));
-        HIP_TRY(hipMalloc((void **)&b->d_htout, (size_t)b->task_cap * bsx_htaskout_bytes()));
-        if (getenv("BSX_POISON")) {
-            HIP_TRY(hipMemsetAsync(b->d_htout, 0xA5, (size_t)b->task_cap * bsx_htaskout_bytes(), b->stream));
-            HIP_TRY(hipMemsetAsync(b->d_htasks, 0xA5, (size_t)b->task_cap * bsx_htask_bytes(), b->stream));
-        }
-        for (int k = 0; k < 2; k++) HIP_TRY(hipMalloc((void **)&b->d_hactive[k], (size_t)b->hcap * 4));
         HIP_TRY(hipMalloc((void **)&b->d_hcnt, BSX_MAX_GROUPS * 64));
         // scan order of a pass: bins of 2^shift index entries, at most 2^20 of them (bsx_launch_task_order)
         const uint64_t ne = std::max<uint64_t>(1, b->ref->n_entries);
@@ -377,25 +376,58 @@ static int ensure_scratch(bsx_batch *b)
         const uint32_t bin_log2 = getenv("BSX_BIN_LOG2") ? (uint32_t)std::max(8, std::min(21, atoi(getenv("BSX_BIN_LOG2")))) : 20u;  // tuning knob
         while (((ne >> b->bin_shift) + 1) > (1u << bin_log2)) b->bin_shift++;
         b->n_bins = (uint32_t)(ne >> b->bin_shift) + 1;
-        const uint32_t tcap = b->task_cap / (uint32_t)b->n_groups;
-        for (int g = 0; g < b->n_groups; g++) {
-            bsx_batch::Group &q = b->grp[g];
-            HIP_TRY(hipMalloc((void **)&q.d_bins, (size_t)b->n_bins * 4));
-            HIP_TRY(hipMemsetAsync(q.d_bins, 0, (size_t)b->n_bins * 4, b->stream));
-            HIP_TRY(hipMalloc((void **)&q.d_bstart, (size_t)b->n_bins * 4));
-            HIP_TRY(hipMalloc((void **)&q.d_chunk_tot, (size_t)bsx_bin_chunks(b->n_bins) * 4));
-            HIP_TRY(hipMalloc((void **)&q.d_rank, (size_t)tcap * 4));
-            HIP_TRY(hipMalloc((void **)&q.d_order, (size_t)tcap * 4));
+        // The pools proper.  Their default sizes are for a device that holds two or three batches (31 GB each for WGBS, 74 GB for RRBS);
+        // where that much is not free — more batches per device, a smaller or shared device — the pools are halved until they fit
+        // (more rounds and refused requests then, same results) instead of failing the batch.
+        auto free_pools = [&]() {
+            void **ptrs[] = {(void **)&b->d_hstate, (void **)&b->d_hslabs, (void **)&b->d_htasks, (void **)&b->d_htout, (void **)&b->d_hactive[0], (void **)&b->d_hactive[1]};
+            for (void **q : ptrs) { if (*q) (void)hipFree(*q); *q = nullptr; }
+            for (int g = 0; g < b->n_groups; g++) {
+                bsx_batch::Group &q = b->grp[g];
+                void **gp[] = {(void **)&q.d_bins, (void **)&q.d_bstart, (void **)&q.d_chunk_tot, (void **)&q.d_rank, (void **)&q.d_order};
+                for (void **x : gp) { if (*x) (void)hipFree(*x); *x = nullptr; }
+            }
+        };
+        auto alloc_pools = [&]() -> hipError_t {
+            hipError_t e;
+#define POOL_TRY(x) do { if ((e = (x)) != hipSuccess) return e; } while (0)
+            POOL_TRY(hipMalloc((void **)&b->d_hstate, (size_t)b->hcap * bsx_hstate_bytes()));
+            POOL_TRY(hipMalloc((void **)&b->d_hslabs, (size_t)b->hcap * b->hslab_bytes));
+            POOL_TRY(hipMalloc((void **)&b->d_htasks, (size_t)b->task_cap * bsx_htask_bytes()));
+            POOL_TRY(hipMalloc((void **)&b->d_htout, (size_t)b->task_cap * bsx_htaskout_bytes()));
+            for (int k = 0; k < 2; k++) POOL_TRY(hipMalloc((void **)&b->d_hactive[k], (size_t)b->hcap * 4));
+            const uint32_t tcap = b->task_cap / (uint32_t)b->n_groups;
+            for (int g = 0; g < b->n_groups; g++) {
+                bsx_batch::Group &q = b->grp[g];
+                POOL_TRY(hipMalloc((void **)&q.d_bins, (size_t)b->n_bins * 4));
+                POOL_TRY(hipMalloc((void **)&q.d_bstart, (size_t)b->n_bins * 4));
+                POOL_TRY(hipMalloc((void **)&q.d_chunk_tot, (size_t)bsx_bin_chunks(b->n_bins) * 4));
+                POOL_TRY(hipMalloc((void **)&q.d_rank, (size_t)tcap * 4));
+                POOL_TRY(hipMalloc((void **)&q.d_order, (size_t)tcap * 4));
+            }
+#undef POOL_TRY
+            return hipSuccess;
+        };
+        for (int attempt = 0;; attempt++) {
+            hipError_t e = alloc_pools();
+            if (e == hipSuccess) {  // ... and leave room for what comes later (the reads of a batch, result arrays, other batches' buffers)
+                size_t fr = 0, tot = 0;
+                if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr >= ((size_t)4 << 30) || b->hcap <= 1024) break;
+                e = hipErrorOutOfMemory;
+            }
+            free_pools();
+            if (e != hipErrorOutOfMemory || g_user_limits || attempt == 6 || b->hcap <= 1024) return bsx_hip_fail(e, "hipMalloc (work pools of the heavy pipeline)", __FILE__, __LINE__);
+            (void)hipGetLastError();
+            b->hcap = std::max<uint32_t>(1024u, b->hcap / 2);
+            b->task_cap = std::max<uint32_t>(4096u, b->task_cap / 2);
         }
-    }
-    const uint64_t slots = b->debug ? b->max_units : (uint64_t)grid * 4;
-    const size_t bytes = (size_t)(slots * b->slab_bytes);
-    if (bytes > b->scratch_bytes) {
-        if (b->d_scratch) (void)hipFree(b->d_scratch);
-        b->d_scratch = nullptr;
-        HIP_TRY(hipMalloc((void **)&b->d_scratch, bytes));
-        HIP_TRY(hipMemsetAsync(b->d_scratch, 0, bytes, b->stream));  // the per-slab hash sets must start empty (same stream as the kernels)
-        b->scratch_bytes = bytes;
+        if (getenv("BSX_POISON")) HIP_TRY(hipMemsetAsync(b->d_hstate, 0xA5, (size_t)b->hcap * bsx_hstate_bytes(), b->stream));  // test hook: recycled memory is not zero
+        HIP_TRY(hipMemsetAsync(b->d_hslabs, 0, (size_t)b->hcap * b->hslab_bytes, b->stream));
+        if (getenv("BSX_POISON")) {
+            HIP_TRY(hipMemsetAsync(b->d_htout, 0xA5, (size_t)b->task_cap * bsx_htaskout_bytes(), b->stream));
+            HIP_TRY(hipMemsetAsync(b->d_htasks, 0xA5, (size_t)b->task_cap * bsx_htask_bytes(), b->stream));
+        }
+        for (int g = 0; g < b->n_groups; g++) HIP_TRY(hipMemsetAsync(b->grp[g].d_bins, 0, (size_t)b->n_bins * 4, b->stream));
     }
     return BSX_OK;
 }
