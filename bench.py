@@ -368,8 +368,18 @@ def dominant_kernel(counters, scan_ms, steps, nfl, rrbs=False):
          "class_shares": {"one_word": float(counters[9]) / max(cand, 1.0), "five_words": float(counters[10]) / max(cand, 1.0)},
          "timing_note": "launch durations overlap other kernels when batches_in_flight > 1" if nfl > 1 else "serial: no other kernel runs beside it"}
     if rrbs:  # the RRBS scan kernel evaluates runs of reads over one window of candidates: the gather is shared, the rest is arithmetic
+        ev = {"note": "the one-read kernel on the same workload: TA_BUSY 0.94, L2 hit 0.99, 204 G candidates/s (DESIGN.md §3.2)"}
+        try:   # counter passes of this kernel kept under profiles/ (tools/profile_mode.sh <tag> --mode rrbs; the summary files it by its name's prefix)
+            import glob
+            f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sq_rrbs.json")))[-1]
+            k = json.load(open(f))["kernels"]["k_hscan"]["derived"]
+            ev.update({"source": os.path.basename(f), "fractions": {"valu_issue_4_cycles_per_instruction": k.get("valu_busy_frac_4cyc"), "texture_addresser_busy": k.get("ta_busy_frac"),
+                                                                     "l2_hit": k.get("l2_hit_frac"), "scalar_per_vector_instruction": k.get("salu_per_valu"),
+                                                                     "waiting_for_data": k.get("wait_any_frac")}})
+        except Exception:
+            pass
         d.update({"bound": "VALU issue (reference words are loaded and shifted once per candidate for up to 16 reads; about 34 VALU per 64 candidates and read)",
-                  "bound_evidence": "DESIGN.md §3.2; the one-read kernel on the same workload: TA_BUSY 0.94, L2 hit 0.99, 204 G candidates/s"})
+                  "bound_evidence": ev})
     else:
         d.update(kernel_bound())
     return d
