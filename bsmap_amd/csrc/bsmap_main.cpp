@@ -15,6 +15,9 @@
 // in input order (the reference's order is nondeterministic for -p > 1).
 #include <atomic>
 #include <sys/resource.h>
+#include <sys/mman.h>
+#include <sys/vfs.h>
+#include <csignal>
 #include <algorithm>
 #include <chrono>
 #include <condition_variable>
@@ -631,10 +634,54 @@ int main(int argc, char **argv)
     // output files are written with pwrite at running offsets: the chunks of a batch go out in parallel
     const bool bam_out = o.out_sam == 2;
     bsx_bam::Sink bam;
-    const int fout = ::open(o.out_file.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    int fout = ::open(o.out_file.c_str(), O_RDWR | O_CREAT | O_TRUNC, 0644);   // (read access: a shared mapping of the file needs it)
+    if (fout < 0) fout = ::open(o.out_file.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
     if (fout < 0) { cerr << "failed to open output file (check -o option): " << o.out_file << endl; exit(1); }
     int fout_unpair = -1;
     off_t off_out = 0, off_unpair = 0;
+    // Output on tmpfs (/dev/shm) goes through a shared mapping of the file instead of pwrite: buffered writes into ONE file hold the inode's
+    // lock, so 1 or 14 threads move the same 5-6 GB/s (tools/microbench/shm_write.cpp), while page faults on a mapping run in parallel
+    // (8 threads: 8 GB/s).  BSX_WRITE=pwrite|mmap overrides the choice.  A full file system then shows up as SIGBUS, reported like a write error.
+    auto use_map = [](int fd) {
+        if (const char *e = getenv("BSX_WRITE")) return strcmp(e, "mmap") == 0;
+        struct statfs sf;
+        return fstatfs(fd, &sf) == 0 && (unsigned long)sf.f_type == 0x01021994ul;  // TMPFS_MAGIC
+    };
+    const bool map_out = use_map(fout);
+    const int map_threads = getenv("BSX_WRITE_THREADS") ? max(1, atoi(getenv("BSX_WRITE_THREADS"))) : 12;  // (4 / 8 / 14 threads: 18 / 21 / 22 M reads/s with the GPU stage nearly free; pwrite 16)
+    if (map_out) {
+        struct sigaction sa; memset(&sa, 0, sizeof(sa));
+        sa.sa_handler = [](int) { static const char m[] = "write error on the output file (no space left?)\n"; ssize_t r = write(2, m, sizeof(m) - 1); (void)r; _exit(1); };
+        sigaction(SIGBUS, &sa, nullptr);
+    }
+    // copy the pieces [p_i, p_i + n_i) to consecutive offsets of fd starting at `at`, with up to `nthreads` threads
+    auto map_write = [](int fd, const vector<pair<const char *, size_t>> &pieces, off_t at, int nthreads) -> bool {
+        size_t total = 0;
+        for (auto &x : pieces) total += x.second;
+        if (!total) return true;
+        if (ftruncate(fd, at + (off_t)total) != 0) return false;
+        const long pg = sysconf(_SC_PAGESIZE);
+        const off_t base = at / pg * pg;
+        const size_t lead = (size_t)(at - base), len = lead + total;
+        char *m = (char *)mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_SHARED, fd, base);
+        if (m == MAP_FAILED) return false;
+        // split the byte range evenly over the threads, whatever the pieces are
+        vector<size_t> start(pieces.size() + 1, 0);
+        for (size_t i = 0; i < pieces.size(); i++) start[i + 1] = start[i] + pieces[i].second;
+        auto copy_range = [&](size_t lo, size_t hi) {
+            for (size_t i = 0; i < pieces.size() && start[i] < hi; i++) {
+                const size_t a = max(lo, start[i]), b = min(hi, start[i + 1]);
+                if (a < b) memcpy(m + lead + a, pieces[i].first + (a - start[i]), b - a);
+            }
+        };
+        const int T = (int)max<size_t>(1, min<size_t>((size_t)nthreads, total >> 20));  // at least 1 MB per thread
+        vector<thread> th;
+        for (int t = 1; t < T; t++) th.emplace_back(copy_range, total * t / T, total * (t + 1) / T);
+        copy_range(0, total / T);
+        for (thread &x : th) x.join();
+        munmap(m, len);
+        return true;
+    };
     auto write_all = [](int fd, const char *p_, size_t n_, off_t at) {
         while (n_) {
             const ssize_t w = pwrite(fd, p_, n_, at);
@@ -846,7 +893,17 @@ int main(int argc, char **argv)
             for (const Text &x : s.out) bam.add_text(x.s.data(), x.s.size());  // records are sorted and written at the end
         } else {
             vector<thread> wt;
-            for (const Text &x : s.out) {
+            bool mapped = false;
+            if (map_out) {
+                vector<pair<const char *, size_t>> pieces;
+                size_t tot = 0;
+                for (const Text &x : s.out) if (!x.s.empty()) { pieces.emplace_back(x.s.data(), x.s.size()); tot += x.s.size(); }
+                const double c0 = thread_cpu_s();
+                mapped = map_write(fout, pieces, off_out, map_threads);
+                add_cpu(3, c0);   // (the helper threads' CPU time is not in this figure)
+                if (mapped) off_out += (off_t)tot;
+            }
+            if (!mapped) for (const Text &x : s.out) {
                 if (x.s.empty()) continue;
                 const off_t at = off_out;
                 off_out += (off_t)x.s.size();

@@ -321,6 +321,28 @@ def test_c1_at_baseline_size_matches_reference_binary(tmp_path):
     assert diff <= 40, diff
 
 
+def test_output_through_a_shared_mapping_equals_pwrite(tmp_path):
+    """on tmpfs the text output goes through a shared mapping of the file, copied by several threads at page-unaligned offsets
+    (bsmap_main.cpp, map_write); forced on here whatever the file system is: the file equals the one written with pwrite, over
+    several batches and with enough bytes per batch for a dozen copy threads"""
+    import bsx_testdata as td
+    fa, fq, _ = td.c1_full_inputs(str(tmp_path))
+    big = str(tmp_path / "big.fq")
+    recs = open(fq).read().split("\n")
+    with open(big, "w") as f:
+        for rep in range(12):
+            for i in range(0, len(recs) - 3, 4):
+                f.write(f"{recs[i]}_{rep}\n{recs[i + 1]}\n+\n{recs[i + 3]}\n")
+    outs = {}
+    for mode in ("pwrite", "mmap"):
+        out = str(tmp_path / f"{mode}.sam")
+        res = subprocess.run([BIN, "-a", big, "-d", fa, "-o", out, "-s", "12", "-v", "2", "-u"], capture_output=True, text=True, timeout=600,
+                             env=dict(os.environ, BSX_WRITE=mode, BSX_BATCH="50000"))
+        assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-1500:]
+        outs[mode] = open(out, "rb").read()
+    assert len(outs["mmap"]) > (12 << 20) and outs["mmap"] == outs["pwrite"]
+
+
 LEAKRUN = json.load(gzip.open(os.path.join(G.GOLDEN, "cli_leakrun.json.gz"), "rt"))
 
 
