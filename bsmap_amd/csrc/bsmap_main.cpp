@@ -36,6 +36,7 @@
 #include "bsx_cpus.h"
 #include "bsx_reads.h"
 #include "bsx_bam_out.h"
+#include "bsx_textout.h"
 
 using namespace std;
 using bsx_reads::Reader; using bsx_reads::ReadSet; using bsx_reads::ReadOpts; using bsx_reads::load_reads; using bsx_reads::Buf; using bsx_reads::RawAlloc;
@@ -654,34 +655,7 @@ int main(int argc, char **argv)
         sa.sa_handler = [](int) { static const char m[] = "write error on the output file (no space left?)\n"; ssize_t r = write(2, m, sizeof(m) - 1); (void)r; _exit(1); };
         sigaction(SIGBUS, &sa, nullptr);
     }
-    // copy the pieces [p_i, p_i + n_i) to consecutive offsets of fd starting at `at`, with up to `nthreads` threads
-    auto map_write = [](int fd, const vector<pair<const char *, size_t>> &pieces, off_t at, int nthreads) -> bool {
-        size_t total = 0;
-        for (auto &x : pieces) total += x.second;
-        if (!total) return true;
-        if (ftruncate(fd, at + (off_t)total) != 0) return false;
-        const long pg = sysconf(_SC_PAGESIZE);
-        const off_t base = at / pg * pg;
-        const size_t lead = (size_t)(at - base), len = lead + total;
-        char *m = (char *)mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_SHARED, fd, base);
-        if (m == MAP_FAILED) return false;
-        // split the byte range evenly over the threads, whatever the pieces are
-        vector<size_t> start(pieces.size() + 1, 0);
-        for (size_t i = 0; i < pieces.size(); i++) start[i + 1] = start[i] + pieces[i].second;
-        auto copy_range = [&](size_t lo, size_t hi) {
-            for (size_t i = 0; i < pieces.size() && start[i] < hi; i++) {
-                const size_t a = max(lo, start[i]), b = min(hi, start[i + 1]);
-                if (a < b) memcpy(m + lead + a, pieces[i].first + (a - start[i]), b - a);
-            }
-        };
-        const int T = (int)max<size_t>(1, min<size_t>((size_t)nthreads, total >> 20));  // at least 1 MB per thread
-        vector<thread> th;
-        for (int t = 1; t < T; t++) th.emplace_back(copy_range, total * t / T, total * (t + 1) / T);
-        copy_range(0, total / T);
-        for (thread &x : th) x.join();
-        munmap(m, len);
-        return true;
-    };
+    auto map_write = bsx_textout::map_write;
     auto write_all = [](int fd, const char *p_, size_t n_, off_t at) {
         while (n_) {
             const ssize_t w = pwrite(fd, p_, n_, at);

@@ -1,0 +1,48 @@
+// bsx_textout.h - text output through a shared mapping of the output file (host-only, header-only; used by bsmap_main.cpp).
+//
+// Buffered writes into ONE file hold the inode's lock: 1 or 14 threads calling pwrite at disjoint offsets move the same 5-6 GB/s into a
+// file on tmpfs (tools/microbench/shm_write.cpp), which capped the command line at 16-18 M reads/s of SAM text.  Page faults on a shared
+// mapping run in parallel: the file is extended to the end of the new range, the range is mapped, and the pieces are copied in by several
+// threads that split the BYTES evenly (whatever the pieces are), at whatever page offset the range starts.
+#pragma once
+#include <sys/mman.h>
+#include <unistd.h>
+#include <algorithm>
+#include <cstring>
+#include <thread>
+#include <utility>
+#include <vector>
+
+namespace bsx_textout {
+
+// copy the pieces [p_i, p_i + n_i) to consecutive offsets of fd starting at `at`, with up to `nthreads` threads (at least 1 MB each);
+// false: nothing was written (the file cannot be extended or mapped) - the caller falls back to pwrite
+inline bool map_write(int fd, const std::vector<std::pair<const char *, size_t>> &pieces, off_t at, int nthreads)
+{
+    size_t total = 0;
+    for (auto &x : pieces) total += x.second;
+    if (!total) return true;
+    if (ftruncate(fd, at + (off_t)total) != 0) return false;
+    const long pg = sysconf(_SC_PAGESIZE);
+    const off_t base = at / pg * pg;
+    const size_t lead = (size_t)(at - base), len = lead + total;
+    char *m = (char *)mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_SHARED, fd, base);
+    if (m == MAP_FAILED) return false;
+    std::vector<size_t> start(pieces.size() + 1, 0);
+    for (size_t i = 0; i < pieces.size(); i++) start[i + 1] = start[i] + pieces[i].second;
+    auto copy_range = [&](size_t lo, size_t hi) {
+        for (size_t i = 0; i < pieces.size() && start[i] < hi; i++) {
+            const size_t a = std::max(lo, start[i]), b = std::min(hi, start[i + 1]);
+            if (a < b) memcpy(m + lead + a, pieces[i].first + (a - start[i]), b - a);
+        }
+    };
+    const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, nthreads), total >> 20));
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; t++) th.emplace_back(copy_range, total * t / T, total * (t + 1) / T);
+    copy_range(0, total / T);
+    for (std::thread &x : th) x.join();
+    munmap(m, len);
+    return true;
+}
+
+}  // namespace bsx_textout
