@@ -940,7 +940,14 @@ static void set_read(bso_aligner *a, uint32_t index, int readset, const char *se
     if (n > p->max_readlen) n = p->max_readlen; /* reads.cpp:115-117 */
     if (n > FIXSIZE) n = FIXSIZE;
     memcpy(a->seq, seq, n); a->seq[n] = 0; a->len = n;
-    if (qual) { int q = (int)strlen(qual); if (q > n) q = n; memcpy(a->qual, qual, q); a->qual[q] = 0; a->qlen = q; }
+    if (qual) {
+        /* the quality string keeps its own length (a malformed record may carry more or fewer characters than bases): the reader only cuts it
+         * where it cuts the read (reads.cpp:115-117), and TrimLowQual scans the whole of it (align.cpp:69-78) */
+        int q = (int)strlen(qual);
+        if ((int)strlen(seq) > p->max_readlen && q > p->max_readlen) q = p->max_readlen;
+        if (q > FIXSIZE + 63) q = FIXSIZE + 63;
+        memcpy(a->qual, qual, q); a->qual[q] = 0; a->qlen = q;
+    }
     else { memset(a->qual, p->zero_qual + 40, n); a->qual[n] = 0; a->qlen = n; } /* reads.cpp:108 default_qual */
     a->index = index; a->readset = readset;
 }

@@ -136,7 +136,7 @@ def make_se_reads(genome, n, length, seed=1, sub_rate=0.005, n_rate=0.001, stran
         seq = mutate(seq, rng, sub_rate, n_rate)
         qual = "I" * L
         if adapter is not None and rng.random() < 0.3:
-            ins = int(rng.integers(30, L))
+            ins = int(rng.integers(min(30, L - 1), L))  # (the same draw for L > 30)
             seq = (seq[:ins] + adapter + random_seq(rng, L).tobytes().decode())[:L]
         if qual_tail:
             t = int(rng.integers(0, 60))

@@ -67,9 +67,9 @@ def test_se(case, genome, oracle):
     if kw["s"] <= 12:
         off, nf, ent = ref.csr()
         assert np.array_equal(off, o.bucket_off()) and np.array_equal(nf, o.bucket_nfwd()) and np.array_equal(ent, o.entries())
-    reads = td.make_se_reads(g, case.get("n", 1500), case["length"], seed=2, sub_rate=case["sub"], var_len=case.get("var", False),
-                             strands=case.get("strands", ("++", "-+", "+-", "--")), qual_tail=case.get("trim", False),
-                             adapter=ADAPTER if case.get("trim") else None)
+    reads = case.get("reads") or td.make_se_reads(g, case.get("n", 1500), case["length"], seed=2, sub_rate=case["sub"], var_len=case.get("var", False),
+                                                  strands=case.get("strands", ("++", "-+", "+-", "--")), qual_tail=case.get("trim", False),
+                                                  adapter=ADAPTER if case.get("trim") else None)
     al = oracle.OracleAligner(o, leak_mode=1)
     nclass = kw["v"] + 1
     names = o.names()
@@ -158,6 +158,28 @@ def test_rrbs(kw, genome, oracle):
                 assert ref.se_hits(orient, w, n) == al.se_hits(orient, w, n)
     al.free()
     o.free()
+
+
+@pytest.mark.parametrize("q", [5, 20])
+def test_quality_string_longer_or_shorter_than_the_read(q, genome, oracle):
+    """a malformed FASTQ record may carry more or fewer quality characters than bases: the reference keeps both lengths, and its
+    TrimLowQual scans the whole quality string (align.cpp:69-78) — a good character beyond the last base keeps the read untrimmed, a
+    short string cuts the read to its length.  (At the C ABI a batch has one offset array for bases and qualities, so the device path
+    never sees such a record; the command line cuts or pads the quality string to the read)"""
+    g, fa, _, _ = genome
+    kw = dict(s=14, v=4, I=1, S=54, r=0, n=1, w=50, out_sam=1, q=q)
+    rng = np.random.default_rng(5)
+    reads = td.make_se_reads(g, 120, 60, seed=9, sub_rate=0.004, strands=("++", "-+"))
+    for i, r in enumerate(reads):
+        L = len(r["seq"])
+        tail = "".join(chr(int(x)) for x in rng.integers(35, 49, 30))
+        if i % 3 == 0:
+            r["qual"] = "I" * (L - 25) + tail[:25] + tail            # longer than the read, low tail with a few good characters beyond it
+        elif i % 3 == 1:
+            r["qual"] = "I" * (L - 20)                               # shorter than the read
+        else:
+            r["qual"] = "I" * (L - 30) + tail                        # same length, low tail
+    test_se(dict(kw=kw, reads=reads), genome, oracle)
 
 
 def _random_case(seed):
