@@ -198,13 +198,13 @@ def _random_case(seed):
     return kw, trim, rng
 
 
-@pytest.mark.parametrize("seed", list(range(301, 321)))
+@pytest.mark.parametrize("seed", list(range(301, 333)))
 def test_se_random_options(seed, genome, oracle):
     kw, trim, rng = _random_case(seed)
     test_se(dict(kw=kw, length=rng.choice([150, 120, 80, 40]), sub=0.006, var=rng.random() < 0.5, trim=trim, n=500), genome, oracle)
 
 
-@pytest.mark.parametrize("seed", list(range(401, 413)))
+@pytest.mark.parametrize("seed", list(range(401, 421)))
 def test_pe_random_options(seed, genome, oracle):
     kw, trim, rng = _random_case(seed)
     kw.pop("n")
@@ -212,7 +212,7 @@ def test_pe_random_options(seed, genome, oracle):
     test_pe(dict(kw=kw, length=rng.choice([150, 120, 80]), trim=trim), genome, oracle)
 
 
-@pytest.mark.parametrize("seed", list(range(501, 509)))
+@pytest.mark.parametrize("seed", list(range(501, 515)))
 def test_rrbs_random_options(seed, genome, oracle):
     import random
     rng = random.Random(seed)
