@@ -1562,7 +1562,8 @@ __global__ __launch_bounds__(256, PE ? BSX_WAVES_PER_EU_PE : BSX_WAVES_PER_EU_SE
 struct SurvRec { uint32_t w_ord, hchr, hloc, hkey; };  // w in bits 0-7, ordinal inside the task in bits 8+
 
 struct ListReq { uint32_t nsub, total, nwords, len, thres, rrbs, tag_xor, tag_want;  // rrbs: the list is one bucket of {tag, loc} pairs; entries with ((tag ^ tag_xor) >> 16) == tag_want are its candidates
-                 uint32_t sub_pre[32], sub_n[32], sub_base[32], sub_h[32]; uint32_t rw[12], rm[12]; };
+                 uint32_t sub_pre[32], sub_n[32], sub_base[32], sub_h[32]; uint32_t rw[12], rm[12];
+                 uint32_t px[8], py[8], pm[8]; };  // the read as bit planes (bsx_dev.h): low bits, high bits, not-N bits of nt [32 j, 32 j + 32); words 5-7 zero
 struct HMate {
     int32_t len, raw_len, max_snp, seedseg, filtered;
     uint32_t flags, snp_thres, nkeys, index, nfull, pad[6];
@@ -1674,6 +1675,11 @@ __device__ __forceinline__ bool publish_window(const DevParams &P, const HeavyAr
     ListReq &R = S->req[slot];
     if (lane < 32) { R.sub_pre[lane] = cl.sub_pre; R.sub_n[lane] = cl.sub_n; R.sub_base[lane] = cl.sub_base; R.sub_h[lane] = cl.sub_h; }
     if (lane < 9) { R.rw[lane] = L.w[orient][lane]; R.rm[lane] = L.m[orient][lane]; }
+    if (lane < 8) {  // the same read as bit planes for the scan kernels (L.w / L.m hold 10 packed words; a not-N nt has both mask bits set)
+        const bool in = lane < 5;
+        const uint32_t wa = in ? L.w[orient][2 * lane] : 0u, wb = in ? L.w[orient][2 * lane + 1] : 0u, ma = in ? L.m[orient][2 * lane] : 0u, mb = in ? L.m[orient][2 * lane + 1] : 0u;
+        R.px[lane] = bsx_plane_word(wa, wb, 0); R.py[lane] = bsx_plane_word(wa, wb, 1); R.pm[lane] = bsx_plane_word(ma, mb, 0);
+    }
     if (lane == 0) {
         R.nsub = (uint32_t)cl.nsub; R.total = cl.total; R.nwords = (uint32_t)((M.u->len + 15) >> 4); R.len = (uint32_t)M.u->len; R.thres = M.u->snp_thres;
         R.rrbs = P.rrbs ? 1u : 0u;  // tag filter of align.cpp:187,229: forward reads want their segment, rc reads cmodeindex with the direction bit flipped
@@ -2289,17 +2295,249 @@ __device__ __forceinline__ void hscan_task(const AlignArgs &A, const HeavyArgs &
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// k_hscan on bit planes (BSX_HSCAN_PLANES, the default).  The candidate's reference comes from the PLANE copy (DevParams::refplane:
+// per 32 nt a {low bits, high bits} pair) and is compared where it lies; the READ is what gets shifted — once per task, into a
+// per-wave LDS table of its 32 possible shifts (the reference's own scheme, align.cpp:107-161, on 32-nt words).  Per 32 nt a
+// candidate then costs three v_bitop3 and one v_bcnt (bsx_plane_mismatch) — no funnel shifts, no per-candidate shift amounts
+// or masks — against five instructions per 16 nt on the packed copy.
+//   table  PT[q][s] (q = 0..9, 8 bytes each; s = candidate position mod 32): the 20 dwords of shift s are
+//          X0 Y0 | M0 M1 | X1 Y1 | B X2 | Y2 M2 | X3 Y3 | M3 X4 | Y4 M4 | X5 Y5 | M5 -      (Xj / Yj / Mj: low / high / not-N plane of frame
+//          word j, B: bsx_plane_bmask).  ds_read_b64 serves 32 lanes per LDS cycle over 64 banks: with the 32 shifts of one q in 32
+//          different 8-byte units no pattern of shifts conflicts (ds_read_b128 / ds_read2_b64 serve 16 lanes over 16 units:
+//          shifts s and s + 16 would collide in nearly every group).  The reads are inline assembly for that reason — the compiler
+//          would merge neighbouring ds_read_b64 into ds_read2_b64.
+//   stage 1 (every candidate): one 16-byte gather = pairs k, k+1 (k = position >> 5) against frame words 0, 1: read nt [0, 64 - s),
+//          33..64 of them.  That settles the reference's first early-out (w0ref = word 0 + word 1 & B) for every candidate.
+//   stage 2 (candidates still within the threshold): pairs k+2 .. k+5 against words 2..5, through the per-wave FIFO as before
+//          (8-byte items: position, partial count | ordinal | strand).
+// Work accounting as before: w0ref <= p64 <= w01ref, so  words = 2 n - #(w0ref > thres) + 3 #(w01ref <= thres).
+// ---------------------------------------------------------------------------------------------------------------
+#ifndef BSX_HSCAN_PLANES
+#define BSX_HSCAN_PLANES 1
+#endif
+#define HP_QCAP 128u  /* FIFO slots per wave (8 bytes each): at most 63 left over + one chunk of 64 pushed between drains */
+#define HP_PAIRS 10u
+typedef unsigned long long q64;
+__device__ __forceinline__ uint32_t qlo(q64 v) { return (uint32_t)v; }
+__device__ __forceinline__ uint32_t qhi(q64 v) { return (uint32_t)(v >> 32); }
+// table pairs 0..3 of the shift whose first pair lies at LDS byte address `addr` (a pair of the next q lies 256 bytes further)
+__device__ __forceinline__ void hp_lds4(uint32_t addr, q64 &a, q64 &b, q64 &c, q64 &d)
+{
+    asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:256\n\tds_read_b64 %2, %4 offset:512\n\tds_read_b64 %3, %4 offset:768"
+                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(addr));
+}
+// pairs 3..9
+__device__ __forceinline__ void hp_lds7(uint32_t addr, q64 (&q)[7])
+{
+    asm volatile("ds_read_b64 %0, %7 offset:768\n\tds_read_b64 %1, %7 offset:1024\n\tds_read_b64 %2, %7 offset:1280\n\tds_read_b64 %3, %7 offset:1536\n\t"
+                 "ds_read_b64 %4, %7 offset:1792\n\tds_read_b64 %5, %7 offset:2048\n\tds_read_b64 %6, %7 offset:2304"
+                 : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3]), "=&v"(q[4]), "=&v"(q[5]), "=&v"(q[6]) : "v"(addr));
+}
+// (the compiler does not see the loads above: every value goes through the wait that makes it valid)
+#define HP_WAIT4N(n, a, b, c, d) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
+
+// (x << 3) + c in one instruction (the compiler turns ((p >> 5) << 3) + c into shift, mask, add)
+__device__ __forceinline__ uint32_t shl3_add(uint32_t x, uint32_t c) { uint32_t d; asm("v_lshl_add_u32 %0, %1, 3, %2" : "=v"(d) : "v"(x), "v"(c)); return d; }
+__device__ __forceinline__ uint32_t hp_boff(uint32_t p, uint32_t strand_off) { return shl3_add(p >> 5, strand_off); }           // byte offset of the pair that holds position p
+__device__ __forceinline__ uint32_t hp_taddr(uint32_t tbase, uint32_t p) { return shl3_add(p & 31u, tbase); }                   // LDS address of table pair 0 of shift p mod 32
+
+struct PlaneCtx {
+    const uint8_t *plane;    // plane copy, forward strand copy first
+    uint32_t rc_off;         // byte offset of the rc strand copy
+    uint32_t tbase;          // LDS byte address of this wave's table
+    uint2 *Q;                // this wave's FIFO
+    uint32_t qh, qn;         // head slot, items queued (wave-uniform)
+    uint32_t thres0, nsurv;
+    int nW, lane;            // nW: frame words a read of this length can reach (2..6)
+    bool overflow;
+    HTaskOut *o;
+    ScanAcc acc;
+};
+
+// the table of one read: lane s < 32 writes the 20 dwords of shift s
+__device__ __forceinline__ void hp_build_table(const ListReq &R, uint2 *T, int lane)
+{
+    uint32_t x[7], y[7], m[7];  // [j + 1] = plane word j of the read; words -1 and 5 are empty
+    x[0] = y[0] = m[0] = 0; x[6] = y[6] = m[6] = 0;
+#pragma unroll
+    for (int j = 0; j < 5; j++) { x[j + 1] = rfl(R.px[j]); y[j + 1] = rfl(R.py[j]); m[j + 1] = rfl(R.pm[j]); }
+    if (lane < 32) {
+        const uint32_t s = (uint32_t)lane;
+        uint32_t X[6], Y[6], M[6];
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            X[j] = __builtin_amdgcn_alignbit(x[j], x[j + 1], s); Y[j] = __builtin_amdgcn_alignbit(y[j], y[j + 1], s); M[j] = __builtin_amdgcn_alignbit(m[j], m[j + 1], s);
+        }
+        T[0 * 32 + s] = make_uint2(X[0], Y[0]); T[1 * 32 + s] = make_uint2(M[0], M[1]); T[2 * 32 + s] = make_uint2(X[1], Y[1]);
+        T[3 * 32 + s] = make_uint2(bsx_plane_bmask(s), X[2]); T[4 * 32 + s] = make_uint2(Y[2], M[2]); T[5 * 32 + s] = make_uint2(X[3], Y[3]);
+        T[6 * 32 + s] = make_uint2(M[3], X[4]); T[7 * 32 + s] = make_uint2(Y[4], M[4]); T[8 * 32 + s] = make_uint2(X[5], Y[5]);
+        T[9 * 32 + s] = make_uint2(M[5], 0u);
+    }
+}
+
+// stage 2 for the first n (<= 64) queued candidates
+__device__ __forceinline__ void hp_drain(PlaneCtx &X, uint32_t n)
+{
+    const bool act = (uint32_t)X.lane < n;
+    const uint2 it = X.Q[(X.qh + (uint32_t)X.lane) & (HP_QCAP - 1)];  // x position, y p64 | ordinal << 8 | strand << 31
+    X.qh = (X.qh + n) & (HP_QCAP - 1); X.qn -= n;
+    const uint32_t p = it.x;
+    const uint32_t boff = hp_boff(p, (uint32_t)((int32_t)it.y >> 31) & X.rc_off);
+    const uint32_t taddr = hp_taddr(X.tbase, p);
+    q64 q[7];
+    hp_lds7(taddr, q);
+    U4 g1, g2;
+    g1.a = g1.b = g1.c = g1.d = 0; g2.a = g2.b = g2.c = g2.d = 0;
+    if (act && X.nW > 2) g1 = *reinterpret_cast<const U4 *>(X.plane + boff + 16);
+    if (act && X.nW > 4) g2 = *reinterpret_cast<const U4 *>(X.plane + boff + 32);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]));
+    const uint32_t p64 = it.y & 0xffu;
+    const uint32_t mm2 = bsx_plane_mismatch(g1.a, g1.b, qhi(q[0]), qlo(q[1]), qhi(q[1]));
+    uint32_t tot = popc_acc(mm2, p64);
+    const uint32_t w01ref = popc_acc(mm2 & qlo(q[0]), p64);
+    tot = popc_acc(bsx_plane_mismatch(g1.c, g1.d, qlo(q[2]), qhi(q[2]), qlo(q[3])), tot);
+    tot = popc_acc(bsx_plane_mismatch(g2.a, g2.b, qhi(q[3]), qlo(q[4]), qhi(q[4])), tot);
+    tot = popc_acc(bsx_plane_mismatch(g2.c, g2.d, qlo(q[5]), qhi(q[5]), qlo(q[6])), tot);
+    X.acc.f5 += (uint32_t)__builtin_popcountll(bsx_ballot(act && w01ref <= X.thres0));
+    // (chromosome / end-of-sequence test and hit coordinates are left to the control kernel's replay: the record carries
+    //  the strand copy and the global position)
+    const bool pass = act && tot <= X.thres0;
+    const u64 m = bsx_ballot(pass);
+    if (m) {
+        const uint32_t pos = X.nsurv + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if (pass && pos < HS_SCAP) { SurvRec r; r.w_ord = tot | ((it.y & 0x7fffff00u)); r.hchr = it.y >> 31; r.hloc = p; r.hkey = 0; X.o->surv[pos] = r; }
+        X.nsurv += (uint32_t)__builtin_popcountll(m);
+        if (X.nsurv > HS_SCAP) X.overflow = true;
+    }
+}
+
+// stage 1 for one chunk: lane l holds one candidate (p its position, r0 its first two reference pairs, q0..q3 the first four
+// table pairs of its shift); candidates still within the threshold go into the FIFO.  MASKED: some lanes hold no candidate.
+template <bool MASKED>
+__device__ __forceinline__ void hp_eval(PlaneCtx &X, const U4 r0, q64 q0, q64 q1, q64 q2, q64 q3, uint32_t p, bool valid, uint32_t tag)
+{
+    const uint32_t mm0 = bsx_plane_mismatch(r0.a, r0.b, qlo(q0), qhi(q0), qlo(q1));
+    const uint32_t mm1 = bsx_plane_mismatch(r0.c, r0.d, qlo(q2), qhi(q2), qhi(q1));
+    const uint32_t c0 = __popc(mm0);
+    const uint32_t w0ref = popc_acc(mm1 & qlo(q3), c0), p64 = popc_acc(mm1, c0);
+    const bool need = (!MASKED || valid) && p64 <= X.thres0;
+    X.acc.c1 += (uint32_t)__builtin_popcountll(bsx_ballot((!MASKED || valid) && w0ref > X.thres0));
+    const u64 nm = bsx_ballot(need);
+    if (nm) {
+        if (need) {
+            const uint32_t pos = X.qh + X.qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(nm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nm, 0u));
+            X.Q[pos & (HP_QCAP - 1)] = make_uint2(p, p64 | tag);
+        }
+        X.qn += (uint32_t)__builtin_popcountll(nm);
+    }
+    while (X.qn >= 64 && !X.overflow) hp_drain(X, 64);  // (FIFO writes and reads of a wave are ordered: same wave, same LDS)
+}
+
+// stage 1 for 256 consecutive candidates of one WGBS sub-range (see hscan_step: entries one step ahead)
+template <bool FULL>
+__device__ __forceinline__ void hp_step(PlaneCtx &X, uint32_t (&e)[4], const uint32_t *__restrict__ nextq, uint32_t ref_off, uint32_t h, uint32_t n_here, uint32_t ord0,
+                                        uint32_t strand)
+{
+    const int lane = X.lane;
+    uint32_t p[4], boff[4], tag[4];
+    bool valid[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        valid[u] = FULL || (uint32_t)(u * 64 + lane) < n_here;
+        p[u] = (FULL || valid[u]) ? e[u] + h : 16u;
+        boff[u] = hp_boff(p[u], ref_off);
+        tag[u] = (ord0 + (uint32_t)(u * 64 + lane)) << 8 | strand << 31;
+    }
+    U4 r0[4];
+    q64 q[2][4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) r0[u] = *reinterpret_cast<const U4 *>(X.plane + boff[u]);
+    if (FULL) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) e[u] = nextq[u * 64];
+    }
+    // table reads one chunk ahead (two register sets): LDS operations of a wave complete in order, so once all but the four youngest
+    // are done the older chunk's pairs are there, whatever the compiler issued in between
+    hp_lds4(hp_taddr(X.tbase, p[0]), q[0][0], q[0][1], q[0][2], q[0][3]);
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        if (u < 3) { hp_lds4(hp_taddr(X.tbase, p[u + 1]), q[(u + 1) & 1][0], q[(u + 1) & 1][1], q[(u + 1) & 1][2], q[(u + 1) & 1][3]); HP_WAIT4N(4, q[u & 1][0], q[u & 1][1], q[u & 1][2], q[u & 1][3]); }
+        else HP_WAIT4N(0, q[u & 1][0], q[u & 1][1], q[u & 1][2], q[u & 1][3]);
+        hp_eval<!FULL>(X, r0[u], q[u & 1][0], q[u & 1][1], q[u & 1][2], q[u & 1][3], p[u], valid[u], tag[u]);
+    }
+}
+
+// one scan task on one wave, plane form (same contract as hscan_task)
+__device__ __forceinline__ void hp_task(const AlignArgs &A, const HeavyArgs &H, uint32_t slot, int lane, int wv, uint32_t (&TAB)[BSX_HSCAN_WPB][4][32],
+                                        uint2 (&PT)[BSX_HSCAN_WPB][HP_PAIRS * 32], uint2 (&QB)[BSX_HSCAN_WPB][HP_QCAP])
+{
+    const DevParams &P = A.P;
+    const uint32_t t = H.order ? rfl(H.order[slot]) : slot;
+    const uint32_t hraw = rfl(H.tasks[t].h), hidx = hraw & 0x3fffffffu, tc0 = rfl(H.tasks[t].c0), tn = rfl(H.tasks[t].n);
+    HTaskOut *o = &H.tout[t];
+    if (tn == 0) {  // slot neutralised by a refused request: its unit has not published a list (ListReq may be stale)
+        if (lane == 0) { o->count = 0; o->overflow = 0; o->acc[0] = o->acc[1] = o->acc[2] = o->acc[3] = 0; }
+        return;
+    }
+    const ListReq &R = H.state[hidx].req[hraw >> 30];
+    if (lane < 32) { TAB[wv][0][lane] = R.sub_pre[lane]; TAB[wv][1][lane] = R.sub_n[lane]; TAB[wv][2][lane] = R.sub_base[lane]; TAB[wv][3][lane] = R.sub_h[lane]; }
+    hp_build_table(R, PT[wv], lane);
+    const uint32_t nsub = min(rfl(R.nsub), 32u);
+    wave_fence();
+    PlaneCtx X;
+    X.plane = reinterpret_cast<const uint8_t *>(P.refplane); X.rc_off = P.plane_rc_off;
+    X.tbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint2 *)PT[wv];
+    X.Q = QB[wv]; X.qh = 0; X.qn = 0; X.thres0 = rfl(R.thres); X.nsurv = 0; X.nW = (int)((rfl(R.len) + 31u + 31u) >> 5); X.lane = lane;
+    X.overflow = false; X.o = o; X.acc.c1 = 0; X.acc.f5 = 0; X.acc.nv = 0;
+    const uint32_t c_end = tc0 + tn;
+    // (WGBS lists only: RRBS lists — one bucket of {tag, loc} pairs — always go to k_hscan_shared, bsx_api.hip)
+    for (uint32_t sidx = 0; sidx < nsub && !X.overflow; sidx++) {
+        const uint32_t ps = rfl(TAB[wv][0][sidx]), ns = rfl(TAB[wv][1][sidx]);
+        const uint32_t lo = max(tc0, ps), hi = min(c_end, ps + ns);
+        if (lo >= hi) continue;
+        const uint32_t *ent = P.entries + rfl(TAB[wv][2][sidx]);
+        const uint32_t h = rfl(TAB[wv][3][sidx]), strand = sidx & 1;
+        const uint32_t ref_off = strand ? X.rc_off : 0u;
+        uint32_t cb = lo;
+        uint32_t e[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) e[u] = (ent + (cb - ps) + lane)[u * 64];
+        for (; cb + 256 <= hi && !X.overflow; cb += 256) hp_step<true>(X, e, ent + (cb + 256 - ps) + lane, ref_off, h, 256, cb - tc0, strand);
+        if (cb < hi && !X.overflow) hp_step<false>(X, e, nullptr, ref_off, h, hi - cb, cb - tc0, strand);
+    }
+    while (X.qn && !X.overflow) hp_drain(X, min(X.qn, 64u));
+    const uint32_t n1 = X.acc.c1, n5 = X.acc.f5;
+    const uint32_t n_cand = tn;
+    const uint32_t words = 2u * n_cand - n1 + 3u * n5;  // 1, 2 or 5 words per candidate (see above)
+    if (lane == 0) {
+        o->count = X.overflow ? 0 : X.nsurv; o->overflow = X.overflow ? 1 : 0; o->acc[0] = n_cand; o->acc[1] = words; o->acc[2] = 0; o->acc[3] = 0;
+        if (!X.overflow) {  // (sharded statistics: see hscan_task)
+            u64 *sh = (u64 *)A.scan_stats + (size_t)(blockIdx.x & 63u) * 8;
+            atomicAdd((u64 *)&sh[0], (u64)n_cand); atomicAdd((u64 *)&sh[1], (u64)words);
+            atomicAdd((u64 *)&sh[2], (u64)n1); atomicAdd((u64 *)&sh[3], (u64)n5);
+        }
+    }
+}
+
 __global__ __launch_bounds__(64 * BSX_HSCAN_WPB, BSX_HSCAN_WAVES) void k_hscan(AlignArgs A, HeavyArgs H)
 {
     __shared__ uint32_t TAB[BSX_HSCAN_WPB][4][32];
+#if BSX_HSCAN_PLANES
+    __shared__ uint2 PT[BSX_HSCAN_WPB][HP_PAIRS * 32];   // the read of each wave's task at its 32 shifts
+    __shared__ uint2 QBUF[BSX_HSCAN_WPB][HP_QCAP];
+#else
     __shared__ uint4 QBUF[BSX_HSCAN_WPB][HS_QCAP];
+#endif
+    const int lane = threadIdx.x & 63, wv = (int)rfl(threadIdx.x >> 6);  // (the wave number as a scalar: what depends on it stays wave-uniform for the compiler)
+#if !BSX_HSCAN_PLANES
     __shared__ uint32_t ANCH[BSX_LDS_CHR + 1];  // RRBS: chromosome anchors (entries carry chromosome-local positions)
     const DevParams &P = A.P;
-    const int lane = threadIdx.x & 63, wv = (int)rfl(threadIdx.x >> 6);  // (the wave number as a scalar: what depends on it stays wave-uniform for the compiler)
     if (P.rrbs) {
         if (P.n_chr <= BSX_LDS_CHR) for (uint32_t i = threadIdx.x; i <= P.n_chr; i += 64 * BSX_HSCAN_WPB) ANCH[i] = P.anchor[i];
         __syncthreads();
     }
+#endif
     // one task per wave and sweep, no queue: the blocks of a pass retire one by one, so the control kernel of the other unit
     // group (high-priority stream) finds free slots while this kernel is still running
     const uint32_t n_tasks = min(*H.n_tasks, H.task_cap);
@@ -2317,7 +2555,11 @@ __global__ __launch_bounds__(64 * BSX_HSCAN_WPB, BSX_HSCAN_WAVES) void k_hscan(A
             if (vb >= nvb) break;
             slot = vb * BSX_HSCAN_WPB + (uint32_t)wv;
         }
+#if BSX_HSCAN_PLANES
+        if (slot < n_tasks) hp_task(A, H, slot, lane, wv, TAB, PT, QBUF);
+#else
         if (slot < n_tasks) hscan_task(A, H, slot, lane, wv, TAB, QBUF, ANCH);
+#endif
         wave_fence();
     }
 }
@@ -2337,6 +2579,171 @@ __global__ __launch_bounds__(64 * BSX_HSCAN_WPB, BSX_HSCAN_WAVES) void k_hscan(A
 #ifndef BSX_HSHARED_WAVES
 #define BSX_HSHARED_WAVES 5  /* waves per SIMD the register budget is set for */
 #endif
+#if BSX_HSCAN_PLANES
+// Plane form: the candidate's pairs of the plane copy are funnel-shifted into the READ's frame once per candidate (all reads of a run
+// have the same offset, hence the same shift) and every read of the run is compared 32 nt at a time: three v_bitop3 and one v_bcnt
+// per word (bsx_plane_mismatch) against four instructions per 16 nt on the packed copy.  Read frame word j holds read nt
+// [32 j, 32 j + 32); the reference's first 64-bit word holds read nt [0, 32 - k), k = position mod 16: `him` on word 0, and on
+// word 1 for its second early-out (align.h:189-197).
+struct SharedChunk { uint32_t wd[12]; uint32_t pm1, strand; bool valid; };  // wd: pairs (pm1 >> 5) .. + 5 of the plane copy, {low, high} each
+
+__device__ __forceinline__ SharedChunk shared_load(const U2 *__restrict__ ent2, uint32_t idx, bool in_range, uint32_t h, uint32_t tag_xor, uint32_t tag_want,
+                                                   const uint32_t *anchor, const uint8_t *plane, uint32_t rc_off, int nwr)
+{
+    SharedChunk c;
+    U2 e; e.a = e.b = 0;
+    if (in_range) e = ent2[idx];
+    const uint32_t rchr = e.a & 0xffffu;
+    c.valid = in_range && ((e.a ^ tag_xor) >> 16) == tag_want && e.b >= h;  // mode or strand not match / underflow the start of refseq
+    c.pm1 = c.valid ? anchor[rchr >> 1] + (e.b - h) - 1u : 31u;
+    c.strand = rchr & 1u;
+    // one pair early when the position is pair-aligned, so that the shift into the read's frame is one v_alignbit with a 5-bit amount
+    const uint32_t boff = c.valid ? hp_boff(c.pm1, c.strand ? rc_off : 0u) : 0u;
+    const U4 r0 = *reinterpret_cast<const U4 *>(plane + boff);
+    U4 r1, r2;
+    r1.a = r1.b = r1.c = r1.d = 0; r2.a = r2.b = r2.c = r2.d = 0;
+    if (c.valid && nwr > 1) r1 = *reinterpret_cast<const U4 *>(plane + boff + 16);
+    if (c.valid && nwr > 3) r2 = *reinterpret_cast<const U4 *>(plane + boff + 32);
+    c.wd[0] = r0.a; c.wd[1] = r0.b; c.wd[2] = r0.c; c.wd[3] = r0.d; c.wd[4] = r1.a; c.wd[5] = r1.b; c.wd[6] = r1.c; c.wd[7] = r1.d;
+    c.wd[8] = r2.a; c.wd[9] = r2.b; c.wd[10] = r2.c; c.wd[11] = r2.d;
+    return c;
+}
+
+__global__ __launch_bounds__(256, BSX_HSHARED_WAVES) void k_hscan_shared(AlignArgs A, HeavyArgs H)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t UW[4][HS_SHARE][20];   // per read of the run: planes X, Y, M of words 0-4 (15), threshold, task id
+    __shared__ uint32_t ANCH[BSX_LDS_CHR + 1];
+    const DevParams &P = A.P;
+    const int lane = threadIdx.x & 63, wv = (int)rfl(threadIdx.x >> 6);  // (the wave number as a scalar: what depends on it stays wave-uniform for the compiler)
+    if (P.n_chr <= BSX_LDS_CHR) for (uint32_t i = threadIdx.x; i <= P.n_chr; i += 256) ANCH[i] = P.anchor[i];
+    __syncthreads();
+    const uint32_t *anchor = P.n_chr <= BSX_LDS_CHR ? ANCH : P.anchor;
+    const uint32_t n_tasks = min(*H.n_tasks, H.task_cap);
+    const uint8_t *plane = reinterpret_cast<const uint8_t *>(P.refplane);
+    const uint32_t rc_off = P.plane_rc_off;
+    // (grid sized for the task pool, or — in the tail of a batch — smaller: then a wave sweeps over the order with the stride of the grid)
+    for (uint32_t s0 = (blockIdx.x * 4u + (uint32_t)wv) * HS_SHARE; s0 < n_tasks; s0 += gridDim.x * 4u * HS_SHARE) {
+    const uint32_t nj = min(HS_SHARE, n_tasks - s0);
+    // lane j < nj: task j of this wave, in scan order, and the signature of its window
+    uint32_t tid = 0, th = 0, tc0 = 0, tn = 0, tkey = 0, sh_ = 0, stx = 0, stw = 0, snw = 0;
+    if ((uint32_t)lane < nj) {
+        tid = H.order ? H.order[s0 + lane] : s0 + (uint32_t)lane;
+        const HTask tk = H.tasks[tid];
+        th = tk.h; tc0 = tk.c0; tn = tk.n; tkey = tk.key;
+        if (tn) {
+            const ListReq &R = H.state[th & 0x3fffffffu].req[th >> 30];
+            tkey = R.sub_base[0] + (tc0 - R.sub_pre[0]);  // first entry of the window
+            sh_ = R.sub_h[0]; stx = R.tag_xor; stw = R.tag_want; snw = (R.len + 31u) >> 5;  // snw: read words of 32 nt
+        } else {  // slot neutralised by a refused request: its unit has not published a list
+            HTaskOut *o = &H.tout[tid];
+            o->count = 0; o->overflow = 0; o->acc[0] = o->acc[1] = o->acc[2] = o->acc[3] = 0;
+        }
+    }
+    u64 st_cand = 0, st_words = 0, st_n1 = 0, st_n5 = 0;  // statistics of the scan kernel (lane 0)
+    for (uint32_t i0 = 0; i0 < nj;) {
+        if (rl(tn, (int)i0) == 0) { i0++; continue; }
+        // the run of tasks from i0 that cover exactly the same window
+        const bool same = (uint32_t)lane >= i0 && (uint32_t)lane < nj && tn == rl(tn, (int)i0) && tkey == rl(tkey, (int)i0) && sh_ == rl(sh_, (int)i0) &&
+                          stx == rl(stx, (int)i0) && stw == rl(stw, (int)i0) && snw == rl(snw, (int)i0);
+        const u64 sm = bsx_ballot(same) >> i0;
+        const uint32_t K = (uint32_t)__builtin_ctzll(~sm);  // (bit 0 is set: the task equals itself)
+        const uint32_t key = rl(tkey, (int)i0), n = rl(tn, (int)i0), h = rl(sh_, (int)i0), tx = rl(stx, (int)i0), tw = rl(stw, (int)i0);
+        const int nwr = (int)rl(snw, (int)i0);
+        wave_fence();
+        for (uint32_t xb = 0; xb < K * 20u; xb += 64) {
+            const uint32_t x = xb + (uint32_t)lane, k = min(x / 20u, K - 1u), f = x - k * 20u;
+            const uint32_t hk = (uint32_t)__shfl((int)th, (int)(i0 + k)), tk = (uint32_t)__shfl((int)tid, (int)(i0 + k));  // (all lanes take part)
+            if (x < K * 20u) {
+                const ListReq &R = H.state[hk & 0x3fffffffu].req[hk >> 30];
+                uint32_t v = 0;
+                if (f < 15) { const uint32_t j = f / 3u, c = f - 3u * j; v = c == 0 ? R.px[j] : c == 1 ? R.py[j] : R.pm[j]; }
+                else if (f == 15) v = R.thres;
+                else if (f == 16) v = tk;
+                UW[wv][k][f] = v;
+            }
+        }
+        uint32_t c15 = 0, nsv = 0;  // lane k: counters of read k (see the loop)
+        wave_fence();
+        const U2 *ent2 = reinterpret_cast<const U2 *>(P.entries) + key;
+        SharedChunk cur = shared_load(ent2, (uint32_t)lane, (uint32_t)lane < n, h, tx, tw, anchor, plane, rc_off, nwr);
+        uint32_t nv = 0;
+        for (uint32_t cb = 0; cb < n; cb += 64) {
+            SharedChunk nxt;
+            const bool more = cb + 64 < n;
+            if (more) nxt = shared_load(ent2, cb + 64 + (uint32_t)lane, cb + 64 + (uint32_t)lane < n, h, tx, tw, anchor, plane, rc_off, nwr);
+            // the candidate's reference planes in the read frame — the same for every read of the run
+            const uint32_t shf = 31u - (cur.pm1 & 31u);                       // 32 - ((pm1 & 31) + 1)
+            const uint32_t him = 0xFFFFFFFFu << ((cur.pm1 + 1u) & 15u);      // read nt [0, 32 - k), k = position mod 16
+            uint32_t flo[5], fhi[5];
+#pragma unroll
+            for (int t = 0; t < 5; t++) { flo[t] = __builtin_amdgcn_alignbit(cur.wd[2 * t], cur.wd[2 * t + 2], shf); fhi[t] = __builtin_amdgcn_alignbit(cur.wd[2 * t + 1], cur.wd[2 * t + 3], shf); }
+            nv += cur.valid ? 1u : 0u;
+            const uint32_t ord = (cb + (uint32_t)lane) << 8;
+            const u64 vm = bsx_ballot(cur.valid);
+            const uint4 *up = reinterpret_cast<const uint4 *>(UW[wv][0]);
+            for (uint32_t k = 0; k < K; k++, up += 5) {
+                const uint4 a0 = up[0], a1 = up[1], a2 = up[2], a3 = up[3];  // X0 Y0 M0 X1 | Y1 M1 X2 Y2 | M2 X3 Y3 M3 | X4 Y4 M4 threshold
+                const uint32_t thr = a3.w;
+                const uint32_t m0 = bsx_plane_mismatch(flo[0], fhi[0], a0.x, a0.y, a0.z);
+                const uint32_t c0 = __popc(m0);
+                const uint32_t w0ref = __popc(m0 & him);
+                uint32_t tot = c0, w01ref = c0;
+                if (nwr > 1) {
+                    const uint32_t m1 = bsx_plane_mismatch(flo[1], fhi[1], a0.w, a1.x, a1.y);
+                    tot = popc_acc(m1, c0); w01ref = popc_acc(m1 & him, c0);
+                    // (the words behind the first 64 nt only matter for candidates still within the threshold there: where no lane of the
+                    //  chunk is, they are skipped — both early-out classes and the survivors are settled)
+                    if (nwr > 2 && (bsx_ballot(tot <= thr) & vm)) {
+                        tot = popc_acc(bsx_plane_mismatch(flo[2], fhi[2], a1.z, a1.w, a2.x), tot);
+                        if (nwr > 3) {
+                            tot = popc_acc(bsx_plane_mismatch(flo[3], fhi[3], a2.y, a2.z, a2.w), tot);
+                            if (nwr > 4) tot = popc_acc(bsx_plane_mismatch(flo[4], fhi[4], a3.x, a3.y, a3.z), tot);
+                        }
+                    }
+                }
+                const u64 b1 = bsx_ballot(w0ref > thr) & vm, b5 = bsx_ballot(w01ref <= thr) & vm, bp = bsx_ballot(tot <= thr) & vm;
+                // lane k keeps read k's counters: candidates beyond the first word | five-word candidates << 16, survivors
+                const uint32_t add15 = (uint32_t)__builtin_popcountll(b1) | ((uint32_t)__builtin_popcountll(b5) << 16);
+                if ((uint32_t)lane == k) c15 += add15;
+                if (bp) {
+                    const uint32_t base = rl_u(nsv, k);
+                    const uint32_t pos = base + (uint32_t)__builtin_popcountll(bp & lanemask_lt(lane));
+                    if (((bp >> lane) & 1) && pos < HS_SCAP) {
+                        SurvRec r; r.w_ord = tot | ord; r.hchr = cur.strand; r.hloc = cur.pm1 + 1; r.hkey = 0;
+                        H.tout[UW[wv][k][16]].surv[pos] = r;
+                    }
+                    if ((uint32_t)lane == k) nsv += (uint32_t)__builtin_popcountll(bp);
+                }
+            }
+            if (more) cur = nxt;
+        }
+        wave_fence();
+        const uint32_t n_cand = wave_sum(nv);
+        {
+            const bool mine = (uint32_t)lane < K;
+            const uint32_t ns = nsv, n1 = c15 & 0xffffu, n5 = c15 >> 16;
+            const bool ov = ns > HS_SCAP;
+            if (mine) {
+                HTaskOut *o = &H.tout[UW[wv][lane][16]];
+                o->count = ov ? 0 : ns; o->overflow = ov ? 1 : 0; o->acc[0] = n_cand; o->acc[1] = 2u * n_cand - n1 + 3u * n5; o->acc[2] = 0; o->acc[3] = 0;
+            }
+            // work of the scan kernel (incl. speculation); an overflowed task is redone by the control kernel
+            const bool cnt = mine && !ov;
+            const uint32_t kk = (uint32_t)__builtin_popcountll(bsx_ballot(cnt));
+            const uint32_t s1 = wave_sum(cnt ? n1 : 0), s5 = wave_sum(cnt ? n5 : 0);
+            st_cand += (u64)kk * n_cand; st_n1 += s1; st_n5 += s5; st_words += 2ull * kk * n_cand - s1 + 3ull * s5;
+        }
+        wave_fence();
+        i0 += K;
+    }
+    if (lane == 0) {
+        u64 *sh = (u64 *)A.scan_stats + (size_t)(blockIdx.x & 63u) * 8;
+        atomicAdd((u64 *)&sh[0], st_cand); atomicAdd((u64 *)&sh[1], st_words); atomicAdd((u64 *)&sh[2], st_n1); atomicAdd((u64 *)&sh[3], st_n5);
+    }
+    wave_fence();
+    }
+}
+#else
 struct SharedChunk { uint32_t wd[10]; uint32_t pm1, strand; bool valid; };
 
 __device__ __forceinline__ SharedChunk shared_load(const U2 *__restrict__ ent2, uint32_t idx, bool in_range, uint32_t h, uint32_t tag_xor, uint32_t tag_want,
@@ -2498,6 +2905,7 @@ __global__ __launch_bounds__(256, BSX_HSHARED_WAVES) void k_hscan_shared(AlignAr
     wave_fence();
     }
 }
+#endif
 }  // namespace
 
 // exact mode pre-pass (see k_leak_meta): with_meta = the stream's records are not up to date (new reads / history); `final_out` != null:

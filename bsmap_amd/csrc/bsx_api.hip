@@ -88,7 +88,7 @@ static int finish_ref_upload(bsx_ref *r, const std::vector<uint32_t> &refcat, co
     if ((rc = upload(&r->d_anchor, r->anchor.data(), r->anchor.size()))) return rc;
     if ((rc = upload(&r->d_chr_size, r->chr_size.data(), r->chr_size.size()))) return rc;
     if ((rc = upload(&r->d_rc_offset, r->rc_offset.data(), r->rc_offset.size()))) return rc;
-    return BSX_OK;
+    return bsx_planes_build(r);
 }
 
 extern "C" int bsx_ref_create_from_fasta(const bsx_params *p, const char *text, uint64_t n_bytes, int device, bsx_ref **out)
@@ -128,7 +128,7 @@ extern "C" void bsx_ref_destroy(bsx_ref *r)
 {
     if (!r) return;
     (void)hipSetDevice(r->device);
-    for (void *q : {(void *)r->d_refcat, (void *)r->d_anchor, (void *)r->d_chr_size, (void *)r->d_rc_offset,
+    for (void *q : {(void *)r->d_refcat, (void *)r->d_refplane, (void *)r->d_anchor, (void *)r->d_chr_size, (void *)r->d_rc_offset,
                     (void *)r->d_bucket_off, (void *)r->d_bucket_nfwd, (void *)r->d_entries, (void *)r->d_sites, (void *)r->d_site_off, (void *)r->d_rrbs_goff, (void *)r->d_site_bin, (void *)r->d_site_bin_off})
         if (q) (void)hipFree(q);
     delete r;
@@ -209,6 +209,7 @@ void bsx_fill_devparams(const bsx_ref *r, DevParams &d)
     }
     memcpy(d.digest_site, p.digest_site, 16);
     d.n_chr = r->n_chr;
+    d.refplane = r->d_refplane; d.plane_rc_off = r->plane_rc_off;
     d.refcat = r->d_refcat; d.crefcat = r->d_crefcat; d.anchor = r->d_anchor; d.chr_size = r->d_chr_size; d.rc_offset = r->d_rc_offset;
     d.bucket_off = r->d_bucket_off; d.bucket_nfwd = r->d_bucket_nfwd; d.entries = r->d_entries;
     d.sites = r->d_sites; d.site_off = r->d_site_off; d.rrbs_goff = r->d_rrbs_goff; d.site_bin = r->d_site_bin; d.site_bin_off = r->d_site_bin_off;
@@ -828,8 +829,11 @@ extern "C" int bsx_batch_run_range(bsx_batch *b, uint32_t first_unit, uint32_t n
                     q.polled++;
                     if (b->trace) fprintf(stderr, "[bsx heavy] paired %d base %u group %d passes %u active %u tasks %u\n", b->paired, base, g, q.polled * b->chunk_passes, n_act, n_tasks);
                     if (n_act == 0) { q.done = true; n_open--; }  // (passes already queued for this group find no active unit)
-                    else if (b->tail_tasks && n_tasks < b->tail_tasks) q.tail = true;  // (the counts are two chunks old: a later pass may publish more — its blocks then sweep)
-                    else if (q.passes > 200000) { g_bsx_err = "heavy pipeline did not converge"; return BSX_ERR_DEVICE; }
+                    else {
+                        // (tested before the tail decision: a stuck unit publishes few tasks per pass — exactly what the tail mode looks like)
+                        if (q.passes > 200000) { g_bsx_err = "heavy pipeline did not converge"; return BSX_ERR_DEVICE; }
+                        if (b->tail_tasks && n_tasks < b->tail_tasks) q.tail = true;  // (the counts are two chunks old: a later pass may publish more — its blocks then sweep)
+                    }
                 }
                 if (n_open > 0) { int rc = enqueue_chunk(); if (rc) return rc; }
             }

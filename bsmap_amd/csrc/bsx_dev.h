@@ -37,6 +37,43 @@ __host__ __device__ inline uint32_t bsx_mismatch_hi(uint32_t read, uint32_t tmas
     return ((y << 1) | y) & 0xAAAAAAAAu;
 }
 
+// Bit planes.  A packed word holds 16 nt, 2 bits each, first nt in the top bits (dbseq.cpp:58-111); a PLANE word holds one bit of
+// 32 consecutive nt, first nt in bit 31.  bsx_plane_half: the low (which = 0) or high (which = 1) bit of the 16 nt of a packed word,
+// first nt in bit 15.  The scan kernels compare 32 nt per word pair of the plane copy of the reference: the mismatch rule above
+// on planes is  ((Rlo ^ X) & M) | ((Rhi ^ Y) & ~(X & Y) & M)  with X / Y the read's low / high plane and M its not-N plane
+// (read T = X & Y: only the low bit is compared, so reference C and T both match) — three three-input operations and ONE
+// popcount per 32 nt instead of four operations and a popcount per 16.
+__host__ __device__ inline uint32_t bsx_plane_half(uint32_t w, int which)
+{
+    uint32_t x = (which ? (w >> 1) : w) & 0x55555555u;
+    x = (x | (x >> 1)) & 0x33333333u;
+    x = (x | (x >> 2)) & 0x0F0F0F0Fu;
+    x = (x | (x >> 4)) & 0x00FF00FFu;
+    return (x | (x >> 8)) & 0xFFFFu;
+}
+__host__ __device__ inline uint32_t bsx_plane_word(uint32_t w_first, uint32_t w_second, int which) { return (bsx_plane_half(w_first, which) << 16) | bsx_plane_half(w_second, which); }
+// mismatch bits (one per nt) of 32 read nt (planes X, Y, not-N plane M) against 32 reference nt (planes rlo, rhi)
+__host__ __device__ inline uint32_t bsx_plane_mismatch(uint32_t rlo, uint32_t rhi, uint32_t X, uint32_t Y, uint32_t M)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    // one v_bitop3_b32 per step (truth tables over 0xF0 / 0xCC / 0xAA); left to itself the compiler spends a fourth instruction on X & Y
+    const uint32_t a = __builtin_amdgcn_bitop3_b32(rlo, X, M, 0x28), b = __builtin_amdgcn_bitop3_b32(rhi, Y, X, 0x34);
+    return __builtin_amdgcn_bitop3_b32(a, b, M, 0xF8);
+#else
+    const uint32_t a = (rlo ^ X) & M, b = (rhi ^ Y) & ~(X & Y);
+    return a | (b & M);
+#endif
+}
+
+// The scan kernel keeps, per task, the read pre-shifted by every s = 0..31 nt (s = candidate position mod 32), so that a
+// candidate's reference pairs are compared where they lie — the reference's own scheme (16 shifted copies of the read,
+// align.cpp:107-161) on 32-nt planes.  Word j of the read shifted by s: its nt i sits at frame position s + i.
+__host__ __device__ inline uint32_t bsx_plane_shift(uint32_t prev, uint32_t cur, uint32_t s) { return s ? (prev << (32 - s)) | (cur >> s) : cur; }
+// The reference's CountMismatch works on 64-bit words of its own 16-nt grid: the word that holds the read's first nt starts at
+// frame position 0 when s < 16 and at 16 when s >= 16.  Its first early-out looks at frame word 0 plus, for s >= 16, the first
+// 16 nt of word 1 (this mask); its second early-out at the same one word further (align.h:189-197).
+__host__ __device__ inline uint32_t bsx_plane_bmask(uint32_t s) { return (s & 16u) ? 0xFFFF0000u : 0u; }
+
 // deterministic pick used for equal-best hits: reference utilities.cpp:44-48 (the -S != 0 branch)
 __host__ __device__ inline uint32_t bsx_myrand(uint32_t index, int32_t randseed)
 {

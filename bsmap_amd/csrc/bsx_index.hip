@@ -43,6 +43,16 @@ __global__ void k_enumerate(BlockTab t, uint64_t total, const uint32_t *__restri
     }
 }
 
+// plane copy of one strand copy: pair g = {low bits, high bits} of nt [32 g, 32 g + 32) (bsx_dev.h)
+__global__ void k_planes(const uint32_t *__restrict__ words, uint64_t n_words, uint32_t *__restrict__ planes, uint64_t n_pairs)
+{
+    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_pairs; g += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t a = 2 * g < n_words ? words[2 * g] : 0u, b = 2 * g + 1 < n_words ? words[2 * g + 1] : 0u;
+        planes[2 * g] = bsx_plane_word(a, b, 0);
+        planes[2 * g + 1] = bsx_plane_word(a, b, 1);
+    }
+}
+
 // bucket_off[k] = first ordinal with key >= 2k ; bucket_nfwd[k] = (first ordinal with key >= 2k+1) - bucket_off[k]
 __global__ void k_boundaries(const uint32_t *__restrict__ skeys, uint64_t total, uint32_t n_buckets, uint32_t *__restrict__ bucket_off,
                              uint32_t *__restrict__ bucket_nfwd)
@@ -68,6 +78,25 @@ template <class T> struct DevBuf {
 };
 
 }  // namespace
+
+// Plane copy of the packed reference for the scan kernels of the heavy pipeline (k_hscan, k_hscan_shared): 2 bits per nt like
+// the packed copy (2 x 0.77 GB at hg38 size).  BSX_PLANE_PAD pairs behind each strand copy: a candidate's last gather reaches
+// six pairs from its first.
+#define BSX_PLANE_PAD 16
+int bsx_planes_build(bsx_ref *r)
+{
+    const uint64_t n_pairs = (r->n_words + 1) / 2 + BSX_PLANE_PAD;
+    if (n_pairs * 16 >= 0xFFFFFFFFull) { g_bsx_err = "reference too long for 32-bit plane offsets"; return BSX_ERR_LIMIT; }
+    if (r->d_refplane) { (void)hipFree(r->d_refplane); r->d_refplane = nullptr; }
+    HIP_TRY(hipMalloc((void **)&r->d_refplane, 2 * n_pairs * 8));
+    r->plane_rc_off = (uint32_t)(n_pairs * 8);
+    const int grid = (int)std::min<uint64_t>((n_pairs + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(k_planes, dim3(grid), dim3(256), 0, 0, r->d_refcat, r->n_words, r->d_refplane, n_pairs);
+    hipLaunchKernelGGL(k_planes, dim3(grid), dim3(256), 0, 0, r->d_crefcat, r->n_words, r->d_refplane + 2 * n_pairs, n_pairs);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    return BSX_OK;
+}
 
 int bsx_index_build_wgbs(bsx_ref *r)
 {

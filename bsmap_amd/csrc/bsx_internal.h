@@ -30,6 +30,10 @@ struct DevParams {
     // reference
     uint32_t n_chr;
     const uint32_t *refcat, *crefcat, *anchor, *chr_size, *rc_offset;
+    // plane copy of both strand copies (bsx_planes_build): per 32 nt a {low-bit word, high-bit word} pair; the rc copy starts
+    // plane_rc_off bytes behind the forward one
+    const uint32_t *refplane;
+    uint32_t plane_rc_off;
     // index (CSR)
     const uint32_t *bucket_off, *bucket_nfwd, *entries;
     // RRBS site table
@@ -57,6 +61,8 @@ struct bsx_ref {
     std::vector<std::vector<std::vector<uint32_t>>> ccgg_index;  // [seg][2*chr + strand]
     // device
     uint32_t *d_refcat = nullptr, *d_crefcat = nullptr, *d_anchor = nullptr, *d_chr_size = nullptr, *d_rc_offset = nullptr;
+    uint32_t *d_refplane = nullptr;   // plane copy (bsx_planes_build)
+    uint32_t plane_rc_off = 0;
     uint32_t *d_bucket_off = nullptr, *d_bucket_nfwd = nullptr, *d_entries = nullptr;
     uint32_t *d_sites = nullptr, *d_site_off = nullptr, *d_rrbs_goff = nullptr, *d_site_bin = nullptr, *d_site_bin_off = nullptr;
     std::vector<uint32_t> rrbs_entries_host;  // RRBS entries in the reference's order (the device copy is grouped, see bsx_index_build_rrbs)
@@ -77,6 +83,7 @@ int bsx_hip_fail(hipError_t e, const char *what, const char *file, int line);
 int bsx_pack_fasta(const bsx_params &P, const char *text, uint64_t n, bsx_ref &r, std::vector<uint32_t> &refcat,
                    std::vector<uint32_t> &crefcat);
 // bsx_index.hip
+int bsx_planes_build(bsx_ref *r);   // the plane copy of the packed reference (d_refcat / d_crefcat must be filled)
 int bsx_index_build_wgbs(bsx_ref *r);
 int bsx_index_build_rrbs(bsx_ref *r, const std::vector<uint32_t> &refcat, const std::vector<uint32_t> &crefcat);
 // bsx_synth.hip

@@ -333,6 +333,7 @@ extern "C" int bsx_ref_create_synthetic(const bsx_params *p, uint32_t n_chr, con
         hipLaunchKernelGGL(k_synth_pack, dim3(grid), dim3(256), 0, 0, (u64)seed, c, chr_len[c], nw, bnp, r->d_refcat + w0, r->d_crefcat + w0);
     }
     if (hipDeviceSynchronize() != hipSuccess) return fail(BSX_ERR_DEVICE);
+    { const int prc = bsx_planes_build(r); if (prc != BSX_OK) return fail(prc); }
     if (hipMalloc((void **)&r->d_anchor, r->anchor.size() * 4) != hipSuccess || hipMalloc((void **)&r->d_chr_size, n_chr * 4) != hipSuccess ||
         hipMalloc((void **)&r->d_rc_offset, n_chr * 4) != hipSuccess) return fail(BSX_ERR_NOMEM);
     (void)hipMemcpy(r->d_anchor, r->anchor.data(), r->anchor.size() * 4, hipMemcpyHostToDevice);

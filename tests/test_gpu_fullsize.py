@@ -1,14 +1,20 @@
 """BASELINE-sized checks (hg38-sized synthetic genome, 3.09 Gbp, 1.48 G index entries; the bench workload).
 Parity at this size:
+  * the seed index itself: the oracle packs and indexes the genome TEXT pulled back from the device (its restatement of
+    dbseq.cpp:308-481, one thread, minutes) and every packed word, bucket offset, forward count and entry of the GPU-built
+    index (k_enumerate -> radix sort -> k_boundaries, 1.476 G entries) must equal it — once per session for WGBS (-s 16 -I 4,
+    all WGBS configs share it), and for the RRBS {tag, loc} index of C4;
   * WHOLE batches (131 072 units of C2 / C3, 65 536 of C2 -n 1 / C4 / C5) re-aligned by the oracle's batch driver on the host
-    cores against the SAME reference + index copied back from HBM (RRBS: the oracle's own build from the text): every
-    record field and the four work counters; C5 also in exact mode against the oracle's `-p 1` state;
-    a summary goes to gpurun_out/validate/r03_validate_<cfg>.json (copied into profiles/);
+    cores against the ORACLE-BUILT reference + index: every record field and the four work counters; C5 also in exact mode
+    against the oracle's `-p 1` state; a summary goes to gpurun_out/validate/r04_validate_<cfg>.json (copied into profiles/);
   * idempotence: the same batch twice gives byte-identical records and counters;
   * partition invariance: aligning in two halves equals aligning the whole batch;
   * path invariance: results do not depend on which units go through the heavy pipeline (default threshold vs none);
   * geometry: reads were sampled as 50..480 nt fragments; reported pairs are same-chromosome, insert in range, >95 % unique;
   * counter closure: units processed == units submitted."""
+import hashlib
+import time
+
 import numpy as np
 import pytest
 
@@ -31,9 +37,80 @@ def big():
     pa.Do_Batch()
     out, ca, cb, npairs = pa.results()
     cnt = pa.counters().copy()
+    HEAVY["c3"] = int(pa.heavy_units())   # of THIS run (later tests run parts of the batch again)
     yield ref, pa, out.copy(), ca.copy(), cb.copy(), npairs.copy(), cnt
     pa.close()
     ref.close()
+
+
+HEAVY = {}
+
+
+def _genome_text(ref):
+    parts = []
+    for c, nm in enumerate(ref.names()):
+        parts += [np.frombuffer(f">{nm}\n".encode(), np.uint8), ref.synth_bytes(c), np.frombuffer(b"\n", np.uint8)]
+    return np.concatenate(parts).tobytes()
+
+
+class _OracleWgbs:
+    """The oracle's OWN reference + WGBS index of the hg38-sized genome, built once per session from the genome text (-s 16 -I 4:
+    what every WGBS config here uses), and the proof that a GPU-built reference equals it."""
+
+    def __init__(self, oracle):
+        self.oracle, self.base, self.info = oracle, None, None
+
+    def _build(self, ref):
+        text = _genome_text(ref)
+        t0 = time.time()
+        self.base = self.oracle.OracleRef(self.oracle.make_params(**KW), fasta_text=text)
+        self.build_s = time.time() - t0
+
+    def check(self, ref, name):
+        """every word / offset / count / entry of the GPU-built reference `ref` against the oracle's build"""
+        if self.base is None:
+            self._build(ref)
+        o = self.base
+        f, c = ref.words()
+        assert np.array_equal(f, o.refcat()) and np.array_equal(c, o.crefcat())
+        a, s, r = ref.info()
+        assert np.array_equal(a, o.anchor()) and np.array_equal(s, o.chr_size()) and np.array_equal(r, o.rc_offset())
+        del f, c
+        off, nf, ent = ref.index()
+        assert len(ent) == o.r.n_entries == ref.n_entries
+        assert np.array_equal(off, o.bucket_off()), "bucket offsets"
+        assert np.array_equal(nf, o.bucket_nfwd()), "forward counts"
+        assert np.array_equal(ent, o.entries()), "entries"
+        if self.info is None:
+            sizes = np.diff(off.astype(np.int64))
+            self.info = dict(entries=int(len(ent)), buckets=int(len(nf)), non_empty_buckets=int((sizes > 0).sum()), largest_bucket=int(sizes.max()),
+                             entries_sha256=hashlib.sha256(ent.tobytes()).hexdigest(), bucket_off_sha256=hashlib.sha256(off.tobytes()).hexdigest(),
+                             oracle_build_s=round(self.build_s, 1), checked=[])
+        self.info["checked"].append(name)
+        import wholebatch as W
+        W.record("index", self.info)
+
+    def ref_for(self, kw):
+        """the oracle-built arrays under another config's parameters (same -s / -I)"""
+        o = self.base
+        return self.oracle.OracleRef.wrap(self.oracle.make_params(**kw), o.refcat(), o.crefcat(), o.anchor(), o.chr_size(), o.rc_offset(),
+                                          o.bucket_off(), o.bucket_nfwd(), o.entries())
+
+
+@pytest.fixture(scope="session")
+def oracle_wgbs(oracle):
+    w = _OracleWgbs(oracle)
+    yield w
+    if w.base is not None:
+        w.base.free()
+
+
+def test_gpu_built_index_equals_the_oracles_own_build(big, oracle_wgbs):
+    """RefSeq::CreateIndex at BASELINE size (dbseq.cpp:308-481): 1.476 G entries through 64-bit enumeration, 32-bit keys and a
+    radix sort on the device against the oracle's count / prefix / fill from the genome text"""
+    ref = big[0]
+    oracle_wgbs.check(ref, "c3")
+    assert oracle_wgbs.info["entries"] > 1_400_000_000
 
 
 def test_sizes_and_closure(big):
@@ -70,19 +147,18 @@ def test_heavy_path_invariance(big):
     assert o2[:2048].tobytes() == out[:2048].tobytes() and a2[:2048].tobytes() == ca[:2048].tobytes() and n2[:2048].tobytes() == npairs[:2048].tobytes()
 
 
-def test_whole_batch_equals_oracle_c3(big, oracle):
-    """every unit of the batch re-aligned by the oracle's batch driver against the same reference + index (copied back from
-    HBM): every record field and the four work counters (the roofline numerator)"""
+def test_whole_batch_equals_oracle_c3(big, oracle, oracle_wgbs):
+    """every unit of the batch re-aligned by the oracle's batch driver against the ORACLE's own reference + index (shown equal
+    to the device's in the test above): every record field and the four work counters (the roofline numerator)"""
     import wholebatch as W
     ref, pa, out, ca, cb, npairs, cnt = big
-    f, c = ref.words()
-    a, s, r = ref.info()
-    off, nf, ent = ref.index()
-    oref = oracle.OracleRef.wrap(oracle.make_params(**KW), f, c, a, s, r, off, nf, ent)
+    if oracle_wgbs.base is None:
+        oracle_wgbs.check(ref, "c3")
+    oref = oracle_wgbs.ref_for(KW)
     ores, ocnt, t_cpu = W.run_oracle(oracle, oref, pa, True, False, N)
     bad, info = W.compare_pe(ores, out, ca, cb, npairs, KW["v"] + 1)
     W.record("c3", dict(info, units=N, oracle_s=round(t_cpu, 1), counters_gpu=[int(x) for x in cnt[:4]], counters_oracle=ocnt, mismatching_fields=bad,
-                        options=KW, heavy_units=int(pa.heavy_units())))
+                        options=KW, heavy_units=HEAVY["c3"], reference="oracle-built from the genome text"))
     assert not bad, bad
     assert [int(x) for x in cnt[:4]] == ocnt
 
@@ -150,6 +226,7 @@ def other(request):
     al.Do_Batch()
     res = tuple(x.copy() for x in al.results())
     cnt = al.counters().copy()
+    HEAVY[request.param] = (int(al.heavy_units()), int(al.redo_units()))   # of THIS run
     yield request.param, cfg, ref, al, res, cnt
     al.close()
     ref.close()
@@ -180,36 +257,30 @@ def test_other_configs_closure_idempotence_partition(other):
         assert (hits["n_best"] > 0).mean() > (0.85 if name != "c4" else 0.8)
 
 
-def _oracle_ref(name, cfg, ref, oracle):
+def _oracle_ref(name, cfg, ref, oracle, oracle_wgbs):
     kw = cfg["kw"]
     if name == "c4":   # RRBS: the oracle's OWN packing, site tables and index of the genome text
-        parts = []
-        for c, nm in enumerate(ref.names()):
-            parts += [np.frombuffer(f">{nm}\n".encode(), np.uint8), ref.synth_bytes(c), np.frombuffer(b"\n", np.uint8)]
-        text = np.concatenate(parts).tobytes()
-        del parts
+        text = _genome_text(ref)
         oref = oracle.OracleRef(oracle.make_params(**kw), fasta_text=text)
         del text
         assert sum(len(oref.sites(c)) for c in range(ref.n_chr)) == sum(len(ref.sites(c)) for c in range(ref.n_chr))
         assert np.array_equal(oref.sites(3), ref.sites(3))
         assert np.array_equal(oref.rrbs_entries(), ref.index()[2])
         return oref
-    f, c = ref.words()
-    a, s, r = ref.info()
-    off, nf, ent = ref.index()
-    return oracle.OracleRef.wrap(oracle.make_params(**kw), f, c, a, s, r, off, nf, ent)
+    oracle_wgbs.check(ref, name)   # this config's own GPU-built reference + index against the oracle's build
+    return oracle_wgbs.ref_for(kw)
 
 
-def test_other_configs_whole_batch_equals_oracle(other, oracle):
-    """every unit of the batch re-aligned by the oracle's batch driver — WGBS: against the reference + index copied back from
-    HBM; RRBS: against the oracle's own build from the 3.1 GB text — every record field and the four work counters; C5 also in
-    exact mode (bsx_batch_set_leak_exact) against the oracle's `-p 1` state (leak_mode 1)"""
+def test_other_configs_whole_batch_equals_oracle(other, oracle, oracle_wgbs):
+    """every unit of the batch re-aligned by the oracle's batch driver against the oracle's OWN build of reference + index from
+    the 3.1 GB genome text (WGBS and RRBS alike; the device's copy is compared with it first) — every record field and the four
+    work counters; C5 also in exact mode (bsx_batch_set_leak_exact) against the oracle's `-p 1` state (leak_mode 1)"""
     import wholebatch as W
     name, cfg, ref, al, res, cnt = other
     kw, n = cfg["kw"], cfg["n"]
     nclass = kw.get("v", 2) + 1
     quals = cfg["kind"] == 1
-    oref = _oracle_ref(name, cfg, ref, oracle)
+    oref = _oracle_ref(name, cfg, ref, oracle, oracle_wgbs)
     try:
         ores, ocnt, t_cpu = W.run_oracle(oracle, oref, al, cfg["pe"], quals, n)
         if cfg["pe"]:
@@ -217,7 +288,8 @@ def test_other_configs_whole_batch_equals_oracle(other, oracle):
         else:
             bad, info = W.compare_se(ores, res[0], res[1], nclass)
         rec = dict(info, units=n, oracle_s=round(t_cpu, 1), counters_gpu=[int(x) for x in cnt[:4]], counters_oracle=ocnt, mismatching_fields=bad,
-                   options={k: v for k, v in kw.items()}, heavy_units=int(al.heavy_units()), redo_units=int(al.redo_units()))
+                   options={k: v for k, v in kw.items()}, heavy_units=HEAVY[name][0], redo_units=HEAVY[name][1],
+                   reference="oracle-built from the genome text")
         if name == "c5":   # the only BASELINE config whose reads leak planner state ((len - I + 1) % S == 0 after trimming)
             ex = B.PairAlign(ref, n).set_leak_exact()
             try:

@@ -87,11 +87,14 @@ def run_oracle(O, oref, al, pe, quals, K, leak_mode=0):
     return res, [int(x) for x in cnt], time.time() - t0
 
 
+ROUND = "r04"
+
+
 def record(name, info):
-    """profiles/r03_validate_<cfg>.json is a copy of what this writes on the GPU box (gpurun_out/ travels back)"""
+    """profiles/<round>_validate_<cfg>.json is a copy of what this writes on the GPU box (gpurun_out/ travels back)"""
     import bench
     d = os.environ.get("BSX_VALIDATE_DIR") or os.path.join(ROOT, "gpurun_out", "validate")
     os.makedirs(d, exist_ok=True)
     info = dict(info, config=name, lib_sha16=bench.lib_sha16(), oracle_threads=usable_cpus())
-    with open(os.path.join(d, f"r03_validate_{name}.json"), "w") as f:
+    with open(os.path.join(d, f"{ROUND}_validate_{name}.json"), "w") as f:
         json.dump(info, f, indent=1, sort_keys=True)
