@@ -267,7 +267,7 @@ struct Text {
         put(b + k, (size_t)(24 - k));
     }
     inline void put_i(int64_t v) { if (v < 0) { put('-'); put_u((uint64_t)(-v)); } else put_u((uint64_t)v); }
-    // the same without the capacity test, for the formatters: the worker reserves room for a whole unit's lines first (BSX_REC_MAX)
+    // the same without the capacity test, for the formatters: the worker reserves room for a whole unit's lines first (g_rec_max)
     inline void uput(const char *q, size_t k) { memcpy(s.p + s.n, q, k); s.n += k; }
     template <size_t N> inline void uput(const char (&z)[N]) { memcpy(s.p + s.n, z, N - 1); s.n += N - 1; }
     inline void uput(const string &z) { uput(z.data(), z.size()); }
@@ -280,9 +280,11 @@ struct Text {
     }
     inline void uput_i(int64_t v) { if (v < 0) { uput('-'); uput_u((uint64_t)(-v)); } else uput_u((uint64_t)v); }
 };
-// room a unit's output lines can take at most: two lines of name (< 1000 characters, reads.cpp's getline limit) + two chromosome names +
-// read, qualities, reference string and the fixed fields
-#define BSX_REC_MAX 16384
+// room a unit's output lines can take at most: two lines of name (< 1000 characters, reads.cpp's getline limit), up to four chromosome
+// names (a FASTA header token has no length limit: the longest one of the loaded reference counts, g_rec_max is set once it is known),
+// reads, qualities, reference strings and the fixed fields
+#define BSX_REC_FIXED 16384
+static size_t g_rec_max = BSX_REC_FIXED;
 
 struct Formatter {
     const Opts &o;
@@ -554,9 +556,17 @@ int main(int argc, char **argv)
     // parse, GPU-driver and write threads; oversubscribing a quota throttles every thread, the ones feeding the GPU included
     const unsigned ncpu = bsx_usable_cpus();
     // under a quota: keep the whole process on as many CPUs of the GPU's NUMA node as the quota is worth (BSX_PIN=0: leave the mask alone)
+    // (only when every GPU of the run hangs on the same node: pinned to one socket, the threads that drive and feed GPUs of the other
+    //  socket would run cross-node)
     if (!getenv("BSX_PIN") || atoi(getenv("BSX_PIN")) != 0) {
-        const unsigned pinned = bsx_pin_to_node(bsx_device_numa_node(o.devices[0]), ncpu);
-        if (pinned && getenv("BSX_TIMING")) cerr << "bsx: pinned to " << pinned << " CPUs of NUMA node " << bsx_device_numa_node(o.devices[0]) << endl;
+        const int node0 = bsx_device_numa_node(o.devices[0]);
+        bool one_node = true;
+        for (int d = 1; d < ND; d++) one_node = one_node && bsx_device_numa_node(o.devices[d]) == node0;
+        const unsigned pinned = one_node ? bsx_pin_to_node(node0, ncpu) : 0u;
+        if (getenv("BSX_TIMING")) {
+            if (pinned) cerr << "bsx: pinned to " << pinned << " CPUs of NUMA node " << node0 << endl;
+            else if (!one_node) cerr << "bsx: GPUs on several NUMA nodes, CPU mask left alone" << endl;
+        }
     }
     // (measured on the 16-CPU quota of the GPU boxes with the GPU stage nearly free, tools/host_threads.sh: 10 workers 10.0 M reads/s, 12: 10.6,
     //  14: 12.8 — the driver threads of the device batches sleep on events and the two parse threads are light)
@@ -612,7 +622,9 @@ int main(int argc, char **argv)
     rv.anchor.resize(n_chr + 1); rv.chr_size.resize(n_chr); rv.rc_offset.resize(n_chr);
     bsx_ref_info(rv.ref, rv.anchor.data(), rv.chr_size.data(), rv.rc_offset.data());
     uint64_t sum_len = 0;
-    for (uint32_t c = 0; c < n_chr; c++) { rv.names.push_back(bsx_ref_chr_name(rv.ref, c)); sum_len += rv.chr_size[c]; }
+    size_t longest_name = 0;
+    for (uint32_t c = 0; c < n_chr; c++) { rv.names.push_back(bsx_ref_chr_name(rv.ref, c)); sum_len += rv.chr_size[c]; longest_name = max(longest_name, rv.names.back().size()); }
+    g_rec_max = BSX_REC_FIXED + 4 * longest_name;
     cout << "Load in " << n_chr << " db seqs, total size " << sum_len << " bp. " << time(NULL) - t_begin << " secs passed" << endl;
     cout << "total_kmers: " << p.total_kmers << endl;
     rc = bsx_index_build(rv.ref);
@@ -649,10 +661,18 @@ int main(int argc, char **argv)
         return fstatfs(fd, &sf) == 0 && (unsigned long)sf.f_type == 0x01021994ul;  // TMPFS_MAGIC
     };
     const bool map_out = use_map(fout);
-    const int map_threads = getenv("BSX_WRITE_THREADS") ? max(1, atoi(getenv("BSX_WRITE_THREADS"))) : 12;  // (4 / 8 / 14 threads: 18 / 21 / 22 M reads/s with the GPU stage nearly free; pwrite 16)
+    const int map_threads = getenv("BSX_WRITE_THREADS") ? max(1, atoi(getenv("BSX_WRITE_THREADS"))) : (int)max(1u, min(12u, ncpu));  // (4 / 8 / 14 threads: 18 / 21 / 22 M reads/s with the GPU stage nearly free; pwrite 16)
     if (map_out) {
+        // the input files are memory-mapped too (bsx_reads.h): only a fault inside the range map_write has mapped is the output's
         struct sigaction sa; memset(&sa, 0, sizeof(sa));
-        sa.sa_handler = [](int) { static const char m[] = "write error on the output file (no space left?)\n"; ssize_t r = write(2, m, sizeof(m) - 1); (void)r; _exit(1); };
+        sa.sa_flags = SA_SIGINFO;
+        sa.sa_sigaction = [](int, siginfo_t *si, void *) {
+            const uintptr_t a = (uintptr_t)si->si_addr, lo = bsx_textout::g_map_lo.load(std::memory_order_relaxed), hi = bsx_textout::g_map_hi.load(std::memory_order_relaxed);
+            static const char m_out[] = "write error on the output file (no space left?)\n", m_other[] = "bus error on a mapped file (an input file truncated while it was read?)\n";
+            const bool out = a >= lo && a < hi;
+            ssize_t r = write(2, out ? m_out : m_other, (out ? sizeof(m_out) : sizeof(m_other)) - 1); (void)r;
+            _exit(1);
+        };
         sigaction(SIGBUS, &sa, nullptr);
     }
     auto map_write = bsx_textout::map_write;
@@ -828,7 +848,7 @@ int main(int argc, char **argv)
                 Formatter &fmt = fm[w];
                 Rd a, b;
                 for (size_t i = lo; i < hi; i++) {
-                    os.need(BSX_REC_MAX); os_unpair.need(BSX_REC_MAX);
+                    os.need(g_rec_max); os_unpair.need(g_rec_max);
                     a.load(s.A, i);
                     if (!pe) {
                         const bsx_hit &h = s.hits[i];

@@ -200,22 +200,25 @@ void pack_record(const bsx_params &P, const char *text, const Rec &R, uint32_t c
             for (size_t k = 0; k < dl && ok; k++) ok = toupper((uint8_t)buf[q + k]) == P.digest_site[k];
             if (ok) o.sites.push_back((uint32_t)q + P.digest_pos);
         }
-        const uint32_t tmp_offset = (uint32_t)padded - P.seed_size, tmp_max = L - P.seed_size;
+        // Seed positions of the restriction fragments (the rest of find_CCGG).  A fragment between neighbouring cuts no further
+        // apart than -x is indexed from both of its ends: a read of the forward strand starts at the fragment's left cut, so its
+        // segment g lies at cut + g S on the forward copy; a read of the other strand starts at the right end of the fragment
+        // (right cut + site length - 2 cut offsets), which on the rc copy is position padded - end, and its segment g lies g S
+        // behind that.  Each segment's two lists are filled in ascending site order — CCGG_index[g][2c] / [2c + 1].
+        const uint32_t S = (uint32_t)P.seed_size, span = (uint32_t)dl - 2u * (uint32_t)P.digest_pos, reach = (uint32_t)P.max_insert;
+        const uint32_t last_start = L - S;   // (32-bit arithmetic as in the reference: wraps for a record shorter than one seed)
+        const std::vector<uint32_t> &cuts = o.sites;
+        const size_t nc = cuts.size();
         o.ccgg_f.assign(P.max_seedseg_num, {}); o.ccgg_r.assign(P.max_seedseg_num, {});
-        const std::vector<uint32_t> &sites = o.sites;
-        if (sites.size() > 1) {
-            for (size_t k = 0; k + 1 < sites.size(); k++)
-                if (sites[k + 1] - sites[k] <= (uint32_t)P.max_insert) {
-                    int seedloc = (int)sites[k];
-                    for (int sg = 0; sg < P.max_seedseg_num && (uint32_t)seedloc <= tmp_max; sg++, seedloc += P.seed_size)
-                        o.ccgg_f[sg].push_back((uint32_t)seedloc);
-                }
-            for (size_t k = 1; k < sites.size(); k++)
-                if (sites[k] - sites[k - 1] <= (uint32_t)P.max_insert) {
-                    int seedloc = (int)((size_t)sites[k] + dl - 2 * P.digest_pos - P.seed_size);
-                    for (int sg = 0; sg < P.max_seedseg_num && seedloc >= 0; sg++, seedloc -= P.seed_size)
-                        o.ccgg_r[sg].push_back(tmp_offset - (uint32_t)seedloc);
-                }
+        for (int g = 0; g < P.max_seedseg_num; g++) {
+            std::vector<uint32_t> &fwd = o.ccgg_f[g], &rev = o.ccgg_r[g];
+            const uint32_t shift = (uint32_t)g * S;
+            for (size_t k = 0; k < nc; k++) {
+                const bool is_left_cut = k + 1 < nc && cuts[k + 1] - cuts[k] <= reach, is_right_cut = k > 0 && cuts[k] - cuts[k - 1] <= reach;
+                if (is_left_cut && cuts[k] + shift <= last_start) fwd.push_back(cuts[k] + shift);
+                const uint32_t end = cuts[k] + span;   // one past the fragment on the forward copy
+                if (is_right_cut && (uint64_t)end >= (uint64_t)shift + S) rev.push_back((uint32_t)padded - end + shift);
+            }
         }
     }
 }

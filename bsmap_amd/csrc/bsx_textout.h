@@ -8,12 +8,18 @@
 #include <sys/mman.h>
 #include <unistd.h>
 #include <algorithm>
+#include <atomic>
+#include <cstdint>
 #include <cstring>
 #include <thread>
 #include <utility>
 #include <vector>
 
 namespace bsx_textout {
+
+// the range map_write is copying into right now (one writer at a time), for a SIGBUS handler that has to tell a full output file
+// system from a fault on some other mapping (the memory-mapped input files)
+inline std::atomic<uintptr_t> g_map_lo{0}, g_map_hi{0};
 
 // copy the pieces [p_i, p_i + n_i) to consecutive offsets of fd starting at `at`, with up to `nthreads` threads (at least 1 MB each);
 // false: nothing was written (the file cannot be extended or mapped) - the caller falls back to pwrite
@@ -28,6 +34,7 @@ inline bool map_write(int fd, const std::vector<std::pair<const char *, size_t>>
     const size_t lead = (size_t)(at - base), len = lead + total;
     char *m = (char *)mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_SHARED, fd, base);
     if (m == MAP_FAILED) return false;
+    g_map_lo.store((uintptr_t)m, std::memory_order_relaxed); g_map_hi.store((uintptr_t)m + len, std::memory_order_relaxed);
     std::vector<size_t> start(pieces.size() + 1, 0);
     for (size_t i = 0; i < pieces.size(); i++) start[i + 1] = start[i] + pieces[i].second;
     auto copy_range = [&](size_t lo, size_t hi) {
@@ -41,6 +48,7 @@ inline bool map_write(int fd, const std::vector<std::pair<const char *, size_t>>
     for (int t = 1; t < T; t++) th.emplace_back(copy_range, total * t / T, total * (t + 1) / T);
     copy_range(0, total / T);
     for (std::thread &x : th) x.join();
+    g_map_hi.store(0, std::memory_order_relaxed); g_map_lo.store(0, std::memory_order_relaxed);
     munmap(m, len);
     return true;
 }

@@ -199,7 +199,9 @@ int bsx_batch_set_leak_state(bsx_batch *b, const void *state, size_t bytes);
 int bsx_batch_get_leak_state(bsx_batch *b, void *state, size_t bytes);
 float bsx_batch_kernel_ms(bsx_batch *b);          /* HIP-event time of the last run's align kernel (after sync) */
 /* the scan kernel's launches of the last run: their number and the sum of their HIP-event durations on the stream they
- * were launched on (control kernels of the other unit group may run beside them on another stream) */
+ * were launched on (control kernels of the other unit group may run beside them on another stream).  Passes are queued two
+ * chunks ahead of what the host knows (bsx_batch_run), so the count includes the launches queued behind a group's last pass:
+ * they find no task, their grids exit at once (tens of microseconds each) and they are part of the sum. */
 int bsx_batch_scan_ms(bsx_batch *b, float *total_ms, uint32_t *launches);
 int bsx_batch_results_se(bsx_batch *b, bsx_hit *out, bsx_class_counts *counts /* may be NULL */);
 int bsx_batch_results_pe(bsx_batch *b, bsx_pair *out, bsx_class_counts *counts_a, bsx_class_counts *counts_b, uint16_t *n_pairs31);

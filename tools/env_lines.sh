@@ -1,4 +1,4 @@
-# quick default-mode lines under env settings.  usage: bash tools/r03_g.sh <tag> <mode> <in-flight> "ENV1=a ENV2=b" "ENV1=c" ...
+# quick default-mode lines under env settings.  usage: bash tools/env_lines.sh <tag> <mode> <in-flight> "ENV1=a ENV2=b" "ENV1=c" ...
 TAG=$1; M=$2; NF=$3; shift 3
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
 i=0

@@ -1,4 +1,4 @@
-# like r03_g.sh with extra bench args.  usage: bash tools/r03_g2.sh <tag> <mode> <in-flight> "<bench args>" "ENV..." ...
+# like env_lines.sh with extra bench args.  usage: bash tools/env_lines_args.sh <tag> <mode> <in-flight> "<bench args>" "ENV..." ...
 TAG=$1; M=$2; NF=$3; ARGS=$4; shift 4
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
 i=0

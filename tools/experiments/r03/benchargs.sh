@@ -1,4 +1,4 @@
-# GPU box: the bench under argument combinations a driver might pass.  usage: bash tools/r03_benchargs.sh <tag>
+# GPU box: the bench under argument combinations a driver might pass.  usage: bash tools/experiments/r03/benchargs.sh <tag>
 TAG=$1; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
 i=0
 for args in "--gpus 1 --steps 5 --warmup 2" "--gpus 1 --steps 1 --warmup 0" "--gpus 1 --steps 20 --warmup 5" "--steps 3 --warmup 1 --mode se" ; do

@@ -1,4 +1,4 @@
-# GPU box: parity subset + quick bench lines of the current build.  usage: bash tools/r03_check.sh <tag> [groups list] [modes]
+# GPU box: parity subset + quick bench lines of the current build.  usage: bash tools/experiments/r03/check.sh <tag> [groups list] [modes]
 TAG=${1:-chk}; GROUPS_LIST=${2:-"2 4"}; MODES=${3:-"pe rrbs trim"}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd $R

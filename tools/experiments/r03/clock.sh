@@ -1,4 +1,4 @@
-# GPU box: clock / power while the serial-mode bench and the VALU microbench run.  usage: bash tools/r03_clock.sh <tag>
+# GPU box: clock / power while the serial-mode bench and the VALU microbench run.  usage: bash tools/experiments/r03/clock.sh <tag>
 TAG=$1; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
 
 

@@ -1,4 +1,4 @@
-# GPU box: design evidence for the device-driven heavy pipeline (round 3).  usage: bash tools/r03_diag.sh  -> gpurun_out/r03diag/
+# GPU box: design evidence for the device-driven heavy pipeline (round 3).  usage: bash tools/experiments/r03/diag.sh  -> gpurun_out/r03diag/
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03diag; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 $R/tools/microbench/launch_cost > $O/launch_cost.json 2> $O/launch_cost.err; echo "launch_cost rc=$?"; cat $O/launch_cost.json

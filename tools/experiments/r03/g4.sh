@@ -1,4 +1,4 @@
-# GPU box: unit groups on C4 / C5 with the default batches in flight.  usage: bash tools/r03_g4.sh <tag>
+# GPU box: unit groups on C4 / C5 with the default batches in flight.  usage: bash tools/experiments/r03/g4.sh <tag>
 TAG=$1; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
 for m in rrbs trim; do
 for g in 1 2; do

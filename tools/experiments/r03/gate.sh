@@ -1,4 +1,4 @@
-# GPU box: device batches per GPU and how many of them may compute at once (slots granted in batch order).  usage: bash tools/r03_gate.sh <tag>
+# GPU box: device batches per GPU and how many of them may compute at once (slots granted in batch order).  usage: bash tools/experiments/r03/gate.sh <tag>
 TAG=$1; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
 for rep in 1 2; do
 for cfg in "3 3" "4 2" "4 3" "5 3" "6 3"; do

@@ -1,4 +1,4 @@
-# GPU box: unit groups with ONE batch in flight.  usage: bash tools/r03_groups1.sh <tag>
+# GPU box: unit groups with ONE batch in flight.  usage: bash tools/experiments/r03/groups1.sh <tag>
 TAG=$1; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
 for m in pe trim rrbs; do
 for g in 1 2 3; do

@@ -1,4 +1,4 @@
-# GPU box: output through a shared mapping against pwrite (host-only ceiling and full size), then the byte-identity tests.  usage: bash tools/r03_mapwrite.sh <tag>
+# GPU box: output through a shared mapping against pwrite (host-only ceiling and full size), then the byte-identity tests.  usage: bash tools/experiments/r03/mapwrite.sh <tag>
 TAG=$1; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
 for rep in 1 2; do
 for cfg in "mmap 8" "pwrite 0" "mmap 4" "mmap 14"; do

@@ -1,4 +1,4 @@
-# GPU box: transfer leg after the scheduling change; three / four batches in flight on C3.  usage: bash tools/r03_misc.sh <tag>
+# GPU box: transfer leg after the scheduling change; three / four batches in flight on C3.  usage: bash tools/experiments/r03/misc.sh <tag>
 TAG=$1; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
 python3 bench.py --cpu-seconds 0 --e2e-pairs 0 --sensitivity 0 --other-configs 0 > $O/tr.json 2> $O/tr.err
 python3 -c "

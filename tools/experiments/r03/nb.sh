@@ -1,4 +1,4 @@
-# GPU box: device batches per GPU in the command line (BSX_GPU_BATCHES).  usage: bash tools/r03_nb.sh <tag>
+# GPU box: device batches per GPU in the command line (BSX_GPU_BATCHES).  usage: bash tools/experiments/r03/nb.sh <tag>
 TAG=$1; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
 for rep in 1 2; do
 for nb in 2 3 4; do

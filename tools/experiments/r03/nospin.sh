@@ -1,4 +1,4 @@
-# GPU box: the driver threads after the change from hipEventSynchronize to poll + sleep.  usage: bash tools/r03_nospin.sh <tag>
+# GPU box: the driver threads after the change from hipEventSynchronize to poll + sleep.  usage: bash tools/experiments/r03/nospin.sh <tag>
 TAG=$1; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
 python3 tools/driver_cpu.py > $O/driver_cpu.json 2> $O/driver_cpu.err; cut -c1-500 $O/driver_cpu.json
 for nf in 2 1; do

@@ -1,4 +1,4 @@
-# GPU box: C4 with three batches in flight and smaller pools.  usage: bash tools/r03_rrbs3.sh <tag>
+# GPU box: C4 with three batches in flight and smaller pools.  usage: bash tools/experiments/r03/rrbs3.sh <tag>
 TAG=$1; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
 for cfg in "2 0" "3 110000,1400000" "3 85000,1048576" "2 110000,1400000"; do
   set -- $cfg

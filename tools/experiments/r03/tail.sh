@@ -1,4 +1,4 @@
-# GPU box: tail mode of the heavy pipeline (small scan grids on the control stream) — parity subset, bench lines, command-line timeline.  usage: bash tools/r03_tail.sh <tag>
+# GPU box: tail mode of the heavy pipeline (small scan grids on the control stream) — parity subset, bench lines, command-line timeline.  usage: bash tools/experiments/r03/tail.sh <tag>
 TAG=$1; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
 timeout 1500 python3 -m pytest tests/test_gpu_fullsize.py tests/test_gpu_synth.py -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest.log
 for tt in 16384 0; do

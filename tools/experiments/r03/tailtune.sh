@@ -1,4 +1,4 @@
-# GPU box: tail-mode threshold / grid.  usage: bash tools/r03_tailtune.sh <tag>
+# GPU box: tail-mode threshold / grid.  usage: bash tools/experiments/r03/tailtune.sh <tag>
 TAG=$1; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
 for cfg in "16384 4096" "65536 4096" "65536 16384" "262144 16384" "1048576 65536"; do
   set -- $cfg

@@ -1,4 +1,4 @@
-# GPU box: format workers of the command line now that the driver threads sleep (tiny genome and full size).  usage: bash tools/r03_workers.sh <tag>
+# GPU box: format workers of the command line now that the driver threads sleep (tiny genome and full size).  usage: bash tools/experiments/r03/workers.sh <tag>
 TAG=$1; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
 for g in 0.002 1.0; do
 for p in 12 14 16 20; do

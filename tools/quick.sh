@@ -1,4 +1,4 @@
-# GPU box: parity subset (golden / synthetic / whole-batch) + one default-mode bench line per mode.  usage: bash tools/r03_quick.sh <tag> [modes]
+# GPU box: parity subset (golden / synthetic / whole-batch) + one default-mode bench line per mode.  usage: bash tools/quick.sh <tag> [modes]
 TAG=${1:-q}; MODES=${2:-"pe se rrbs trim"}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
 [ -n "$NOPYTEST" ] || { timeout 1500 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_synth.py tests/test_gpu_fullsize.py -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest.log; }

@@ -1,0 +1,18 @@
+# GPU box: SQ / TA / TCP / TCC / LDS counter passes of the serial-mode bench for the CURRENT build (or BSX_LIB), summarised per kernel.
+# usage: bash tools/sq_passes.sh <tag> [bench args]   ->  gpurun_out/<tag>/<tag>_sq.json
+TAG=${1:-sq}; shift
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O
+export BSX_PROFILES_DIR=$O
+S=/tmp/bsx_sq_$$; mkdir -p $S
+cd /tmp && export TMPDIR=/tmp
+DIRS=""
+for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS" \
+           "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM SQ_WAIT_ANY SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE" \
+           "TA_TA_BUSY_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum" \
+           "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_LDS_ADDR_CONFLICT"; do
+  t=$(echo $set | cut -d' ' -f1)
+  rocprofv3 --pmc $set --kernel-trace -d $S/pmc_$t -o p --output-format csv -- python3 $R/bench.py --profile-serial --steps 2 --warmup 1 --cpu-seconds 0 --e2e-pairs 0 --transfer-steps 0 "$@" > /dev/null 2> $S/pmc_$t.log; rc=$?
+  echo "$t rc=$rc"; [ $rc = 0 ] && DIRS="$DIRS $S/pmc_$t" || tail -3 $S/pmc_$t.log
+done
+python3 $R/tools/summarize_sq.py $TAG $DIRS > $O/${TAG}_sq_derived.json; echo "summarize rc=$?"
+rm -rf $S

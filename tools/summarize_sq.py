@@ -96,6 +96,16 @@ def main():
                 d["quad_cycles_per_wave"] = g("SQ_WAVE_CYCLES") / g("SQ_WAVES")
         if g("TA_TA_BUSY_sum"):
             d["ta_busy_frac"] = g("TA_TA_BUSY_sum") / (N_CU * clk * t("TA_TA_BUSY_sum"))
+        if g("TCP_TOTAL_CACHE_ACCESSES_sum") and g("TCP_TCC_READ_REQ_sum") is not None:
+            d["l1_miss_per_access"] = g("TCP_TCC_READ_REQ_sum") / g("TCP_TOTAL_CACHE_ACCESSES_sum")
+        if g("TA_TA_BUSY_sum") and g("SQ_INSTS_VMEM_RD"):
+            d["ta_busy_cycles_per_vmem_instr"] = g("TA_TA_BUSY_sum") / g("SQ_INSTS_VMEM_RD")
+        if g("SQ_LDS_IDX_ACTIVE") is not None and g("GRBM_GUI_ACTIVE"):   # LDS-array cycles over the CUs' cycles (counter passes differ: same kernel, same work)
+            d["lds_active_frac"] = g("SQ_LDS_IDX_ACTIVE") / (N_CU * g("GRBM_GUI_ACTIVE") / 8)
+            if g("SQ_LDS_BANK_CONFLICT") is not None:
+                d["lds_conflict_frac_of_active"] = g("SQ_LDS_BANK_CONFLICT") / max(1.0, g("SQ_LDS_IDX_ACTIVE"))
+        if g("SQ_WAIT_INST_LDS") is not None and g("SQ_WAVE_CYCLES"):
+            d["wait_inst_lds_frac"] = g("SQ_WAIT_INST_LDS") / g("SQ_WAVE_CYCLES")
         if g("TCC_HIT_sum") is not None and g("TCC_MISS_sum") is not None and g("TCC_HIT_sum") + g("TCC_MISS_sum") > 0:
             d["l2_hit_frac"] = g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum"))
         e["derived"] = d

@@ -1,4 +1,4 @@
-# usage: bash tools/r03_trace.sh <tag> <groups> <in-flight> <mode> [n] [skip]
+# usage: bash tools/trace_step.sh <tag> <groups> <in-flight> <mode> [n] [skip]
 TAG=$1; G=$2; NF=$3; M=$4; N=${5:-120}; SK=${6:-0}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
