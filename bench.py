@@ -100,7 +100,7 @@ def main():
     ap.add_argument("--in-flight", type=int, default=0, help="batches in flight per GPU (host threads, one device batch each): the main kernel and the "
                     "latency-bound tail of one batch overlap the scan passes of the other; 1 = strictly one Do_Batch at a time; default 2 (3 for "
                     "--mode trim, whose control passes are long: 296-303 against 327 ms per step)")
-    ap.add_argument("--transfer-steps", type=int, default=8, help="steps of the PCIe-inclusive leg (upload -> Do_Batch -> results per step); 0 = skip")
+    ap.add_argument("--transfer-steps", type=int, default=-1, help="steps of the PCIe-inclusive leg (upload -> Do_Batch -> results per step); -1 = as many as --steps (the same window length as the metric's), 0 = skip")
     ap.add_argument("--waves-per-cu", type=int, default=0)
     ap.add_argument("--heavy-limits", default="", help="tuning: units per round,scan-task pool of the heavy pipeline")
     ap.add_argument("--heavy-threshold", type=int, default=0, help="tuning: candidate-list length that defers a unit to the heavy pipeline (0 = library default)")
@@ -213,6 +213,7 @@ def main():
     sync_all()
     dt = time.perf_counter() - t0
     counters = sum(bt.counters().astype(np.float64) for bt in batches)
+    heavy_last = [int(batch.heavy_units()), int(batch.redo_units())]
     # per-kernel evidence comes from a serial replay (one batch, control and scan passes strictly alternating): with batches in
     # flight the launches of different batches overlap and their durations say nothing about one kernel
     serial = None
@@ -282,12 +283,15 @@ def main():
         "roofline": {"bound": bound, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_note, "hbm_traffic": hbm,
                      "kernel": "one Do_Batch = k_align + heavy pipeline (k_hctrl/k_hscan passes)", "kernel_ms": k_ms,
-                     "event_ms_per_do_batch": float(np.mean(kernel_ms)), "heavy_units_last_step": int(batch.heavy_units()), "redo_units_last_step": int(batch.redo_units()), "algorithmic_bytes_per_launch": alg_bytes_launch,
+                     "event_ms_per_do_batch": float(np.mean(kernel_ms)), "heavy_units_last_step": heavy_last[0], "redo_units_last_step": heavy_last[1], "algorithmic_bytes_per_launch": alg_bytes_launch,
                      "per_read": {"n_lookup": float(counters[0]) / n_reads_rank, "n_cand": float(counters[1]) / n_reads_rank,
                                   "ref_words64": float(counters[2]) / n_reads_rank},
+                     "multi_share": float(counters[15]) / max(1.0, float(counters[7])),   # of the scan kernel's candidates: evaluated in runs of tasks over one window (k_hscan_multi)
                      "per_kernel": per_kernel_split(counters, args.steps, n_reads_rank, pmc_j, serial),
                      "dominant_kernel": dk},
     }
+    if world == 1 and not args.profile_serial:
+        out["workload_shape"] = workload_shape(ref, counters, args.steps, B_, reads_per_unit, heavy_last[0])
     if serial:
         out["roofline"]["serial_replay"] = {"ms_per_step": serial["ms_per_step"], "event_ms_per_do_batch": serial["event_ms_per_do_batch"],
                                             "note": "two steps with one batch in flight and one unit group after the timed region: the source of dominant_kernel"}
@@ -301,9 +305,15 @@ def main():
                                                         "the access pattern of the scan; its rate does not improve for windows down to 64 MiB (profiles/r02e_probe_sweep.json)"}
         except Exception as e:
             out["roofline"]["peak_measured"] = {"error": str(e)[:200]}
+    if args.transfer_steps < 0:
+        args.transfer_steps = args.steps
     if world == 1 and args.transfer_steps > 0:
         try:
-            out["value_incl_transfers"] = incl_transfers(B, ref, batch, Align, pe, B_, min(args.transfer_steps, args.steps), 0 if kw.get("D") else nfl, reads_per_unit, args.warmup * B_, M["kind"] == 1)
+            vt = incl_transfers(B, ref, batch, Align, pe, B_, min(args.transfer_steps, args.steps), 0 if kw.get("D") else nfl, reads_per_unit, args.warmup * B_, M["kind"] == 1)
+            # SURVEY 8(d)'s window is "first batch submitted -> last result returned"; `value` keeps reads and records in HBM (the contract's
+            # definition): the same steps with the PCIe legs inside the window, and how far the two are apart
+            vt["vs_resident"] = vt["value"] / value
+            out["value_incl_transfers"] = vt
         except Exception as e:
             out["value_incl_transfers"] = {"error": str(e)[:300]}
     if world == 1 and args.cpu_seconds > 0:
@@ -320,6 +330,33 @@ def main():
     print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def workload_shape(ref, c, steps, units_per_step, reads_per_unit, heavy_units):
+    """what the headline depends on: the bucket-size distribution of the seed index (3-letter buckets of repeats hold millions of entries)
+    and how the candidates split between the units the main kernel finishes itself and the few it hands to the heavy pipeline"""
+    import numpy as np
+    out = {}
+    try:
+        off = ref.index()[0].astype(np.int64)
+        sizes = np.diff(off)
+        ne = sizes[sizes > 0]
+        tot = float(sizes.sum())
+        out["index_buckets"] = {"buckets": int(len(sizes)), "non_empty": int(len(ne)), "entries": int(tot), "mean_non_empty": float(ne.mean()), "median_non_empty": float(np.median(ne)),
+                                "p99_non_empty": float(np.percentile(ne, 99)), "p99.99_non_empty": float(np.percentile(ne, 99.99)), "max": int(sizes.max()),
+                                "share_of_entries_in_buckets_over_64k": float(sizes[sizes > 65536].sum() / tot), "buckets_over_64k": int((sizes > 65536).sum()),
+                                "share_of_entries_in_buckets_over_1k": float(sizes[sizes > 1024].sum() / tot)}
+        del off, sizes, ne
+    except Exception as e:
+        out["index_buckets"] = {"error": str(e)[:200]}
+    units = float(steps * units_per_step)
+    hv = float(heavy_units) * steps   # (units deferred in the last step x steps: every step aligns different reads of the same distribution)
+    main_c, all_c = float(c[12]), float(c[1])
+    out["candidates_by_unit_class"] = {
+        "finished_by_the_main_kernel": {"share_of_units": (units - hv) / units, "candidates_per_read": main_c / max(1.0, (units - hv) * reads_per_unit), "share_of_candidates": main_c / max(1.0, all_c)},
+        "deferred_to_the_heavy_pipeline": {"share_of_units": hv / units, "candidates_per_read": (all_c - main_c) / max(1.0, hv * reads_per_unit), "share_of_candidates": (all_c - main_c) / max(1.0, all_c),
+                                           "note": "units with a seed in a repeat bucket: a candidate list of 32 768 or more (RRBS 2 048)"}}
+    return out
 
 
 def per_kernel_split(c, steps, n_reads, pmc_j, serial):

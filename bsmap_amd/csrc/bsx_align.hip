@@ -1587,8 +1587,9 @@ struct HState {
     HMate mate[2];
     ListReq req[HS_NSLOT];
 };
-struct HTask { uint32_t h, c0, n, key; };  // h: unit (bits 0-29) and list slot (bits 30-31); key: index entry the task starts at (tasks are scanned in key order, see bsx_api.hip)
-struct HTaskOut { uint32_t count, overflow, acc[4], pad[2]; SurvRec surv[HS_SCAP]; };
+struct HTask { uint32_t h, c0, n, key;   // h: unit (bits 0-29) and list slot (bits 30-31); key: index entry the task starts at (tasks are scanned in key order, see bsx_api.hip)
+               uint32_t sub_h, flags, pad[2]; };  // of the sub-range the task starts in: its offset h; flags bit 0 strand copy, bit 1 the task lies inside that one sub-range
+struct HTaskOut { uint32_t count, overflow, acc[4], c0, n; SurvRec surv[HS_SCAP]; };  // c0, n: the task's candidates [c0, c0 + n) of its list, echoed by the scan kernel (the replay reads the geometry of a window from here: task descriptors are reused during a control pass, outputs are not)
 struct HeavyArgs {
     HState *state; uint8_t *slabs; uint32_t *active_in, *active_out, *n_active_out; HTask *tasks; HTaskOut *tout; uint32_t *n_tasks, *queue;
     const uint32_t *n_active_in_ptr;
@@ -1649,26 +1650,76 @@ __device__ __forceinline__ u64 surv_coords(const DevParams &P, const BlockLds &B
     return bsx_ballot(ok);
 }
 
+// How a window of a list is cut into scan tasks.  Thousands of reads walk the same giant bucket in the same pass; cut at multiples
+// of HS_TASK from each read's own window start, their tasks would cover the bucket's entries in shifted pieces.  Instead every
+// LARGE sub-range (>= HS_TASK candidates: one strand part of one bucket) is cut on the grid of ABSOLUTE index entries (entry
+// index mod HS_TASK == 0), so that the tasks of all the reads that walk it cover identical entry ranges — which is what lets the
+// scan kernel evaluate many reads against one fetch of the candidates' reference windows (k_hscan_multi).  A task never leaves
+// its segment: a large sub-range, or a maximal run of small ones (cut every HS_TASK from the run's start, as before).
+// Lane i < n holds segment i: candidates [lo, hi) of the list, cut points at ordinals c with (c - ph) % HS_TASK == 0.
+struct SegTab { uint32_t lo, hi, ph; int n; };
+__device__ __forceinline__ SegTab list_segments(const CandList &cl, int lane)
+{
+    SegTab g; g.lo = g.hi = g.ph = 0;
+    int n = 0;
+    bool open = false;  // the current segment is a run of small sub-ranges
+    for (int s_ = 0; s_ < cl.nsub; s_++) {
+        const uint32_t ps = rl(cl.sub_pre, s_), ns = rl(cl.sub_n, s_), sb = rl(cl.sub_base, s_);
+        if (ns == 0) continue;
+        if (ns >= HS_TASK) {
+            if (lane == n) { g.lo = ps; g.hi = ps + ns; g.ph = ps - (sb % HS_TASK); }  // entry index of ordinal c is sb + (c - ps)  (mod 2^32 throughout: HS_TASK divides it)
+            n++; open = false;
+        } else if (open) { if (lane == n - 1) g.hi = ps + ns; }
+        else { if (lane == n) { g.lo = ps; g.hi = ps + ns; g.ph = ps; } n++; open = true; }
+    }
+    g.n = n;
+    return g;
+}
+// tasks of window [c0, c0 + wn): lane i gets the number of tasks its segment contributes (cnt), their first cell (cell0) and the part of the window inside the segment
+struct SegCut { uint32_t cnt, cell0, lo, hi; };
+__device__ __forceinline__ SegCut window_cuts(const SegTab &g, uint32_t c0, uint32_t wn, int lane)
+{
+    SegCut w; w.cnt = 0; w.cell0 = 0;
+    w.lo = max(c0, g.lo); w.hi = min(c0 + wn, g.hi);
+    if (lane < g.n && w.lo < w.hi) { w.cell0 = (w.lo - g.ph) / HS_TASK; w.cnt = (w.hi - 1u - g.ph) / HS_TASK - w.cell0 + 1u; }
+    return w;
+}
+
 // publish candidates [c0, c0 + wn) of list `cl` as scan tasks of list slot `slot`; false if the task pool cannot take them
 __device__ __forceinline__ bool publish_window(const DevParams &P, const HeavyArgs &H, HState *S, uint32_t hidx, int slot, const CandList &cl, int orient, int seg,
                                                const MateLds &L, const Mate &M, uint32_t c0, uint32_t wn, int lane, uint32_t &nt_out)
 {
-    const uint32_t nt = (wn + HS_TASK - 1) / HS_TASK;
+    const SegTab G = list_segments(cl, lane);
+    const SegCut W = window_cuts(G, c0, wn, lane);
+    uint32_t pre = W.cnt;  // inclusive prefix over segments
+#pragma unroll
+    for (int o_ = 1; o_ < 32; o_ <<= 1) { const uint32_t v_ = __shfl_up(pre, o_); if (lane >= o_) pre += v_; }
+    const uint32_t nt = rl(pre, 31);   // (at most 32 segments)
     nt_out = nt;
     uint32_t t0 = 0;
     if (lane == 0) t0 = atomicAdd(H.n_tasks, nt);
     t0 = rfl(t0);
     if (t0 + nt > H.task_cap) {
         if (t0 < H.task_cap)  // pool exhausted mid-way: neutralise the slots that were reserved
-            for (uint32_t t = t0 + lane; t < H.task_cap; t += 64) { HTask tk; tk.h = hidx; tk.c0 = 0; tk.n = 0; tk.key = 0xffffffffu; H.tasks[t] = tk; }
+            for (uint32_t t = t0 + lane; t < H.task_cap; t += 64) { HTask tk; tk.h = hidx; tk.c0 = 0; tk.n = 0; tk.key = 0xffffffffu; tk.sub_h = 0; tk.flags = 0; tk.pad[0] = tk.pad[1] = 0; H.tasks[t] = tk; }
         return false;
     }
     for (uint32_t tb = 0; tb < nt; tb += 64) {
         const uint32_t t = tb + lane;
-        HTask tk; tk.h = hidx | ((uint32_t)slot << 30); tk.c0 = c0 + t * HS_TASK; tk.n = min((uint32_t)HS_TASK, wn - t * HS_TASK); tk.key = 0;
-        for (int s_ = 0; s_ < cl.nsub; s_++) {  // the index entry the task starts at
-            const uint32_t ps_ = rl(cl.sub_pre, s_), ns_ = rl(cl.sub_n, s_), sb_ = rl(cl.sub_base, s_);
-            if (tk.c0 >= ps_ && tk.c0 < ps_ + ns_) tk.key = sb_ + (tk.c0 - ps_);
+        HTask tk; tk.h = hidx | ((uint32_t)slot << 30); tk.c0 = 0; tk.n = 0; tk.key = 0;
+        for (int i_ = 0; i_ < G.n; i_++) {  // the segment task t lies in
+            const uint32_t end_ = rl(pre, i_), cnt_ = rl(W.cnt, i_);
+            if (cnt_ && t >= end_ - cnt_ && t < end_) {
+                const uint32_t j_ = t - (end_ - cnt_), cell = rl(W.cell0, i_) + j_, ph = rl(G.ph, i_);
+                // (ph + cell * HS_TASK may lie before ordinal 0 for the first cell — a wrapped number: only cells behind the first start on the grid)
+                const uint32_t a_ = j_ ? ph + cell * HS_TASK : rl(W.lo, i_), b_ = min(rl(W.hi, i_), ph + (cell + 1u) * HS_TASK);
+                tk.c0 = a_; tk.n = b_ - a_;
+            }
+        }
+        tk.sub_h = 0; tk.flags = 0; tk.pad[0] = tk.pad[1] = 0;
+        for (int s_ = 0; s_ < cl.nsub; s_++) {  // the index entry the task starts at, and what a scan kernel needs to know about that sub-range
+            const uint32_t ps_ = rl(cl.sub_pre, s_), ns_ = rl(cl.sub_n, s_), sb_ = rl(cl.sub_base, s_), sh_ = rl(cl.sub_h, s_);
+            if (tk.c0 >= ps_ && tk.c0 < ps_ + ns_) { tk.key = sb_ + (tk.c0 - ps_); tk.sub_h = sh_; tk.flags = ((uint32_t)s_ & 1u) | ((tk.c0 + tk.n <= ps_ + ns_ && !P.rrbs) ? 2u : 0u); }
         }
         if (t < nt) H.tasks[t0 + t] = tk;
     }
@@ -1712,15 +1763,15 @@ __device__ __forceinline__ int snp_align_heavy(const AlignArgs &A, const HeavyAr
                 K.have[ms] = 0;
                 // (task descriptors in the pool may already have been reused by other units of this pass: the window is
                 //  reconstructed from the unit's own state, only the task OUTPUTS are read from the pool)
-                const uint32_t t0 = rfl(S->t0[ms]), nt = rfl(S->n_tasks[ms]), req_thres = rfl(S->req[ms].thres), win_c0 = rfl(S->win_c0[ms]), win_n = rfl(S->win_n[ms]);
+                const uint32_t t0 = rfl(S->t0[ms]), nt = rfl(S->n_tasks[ms]), req_thres = rfl(S->req[ms].thres);
                 bool restart = false;
                 for (uint32_t tg = 0; tg < nt && !restart; tg += 64) {
                     // 64 task headers at a time: tasks without survivors only contribute their work counters
                     const uint32_t tl = tg + lane;
-                    uint32_t hc = 0, hov = 0, h0 = 0, hw = 0;
+                    uint32_t hc = 0, hov = 0, h0 = 0, hw = 0, gc0 = 0, gn_ = 0;  // gc0 / gn_: the task's candidates [gc0, gc0 + gn_) (publish_window's cuts)
                     if (tl < nt) {
                         const HTaskOut *oh = &H.tout[t0 + tl];
-                        hc = oh->count; hov = oh->overflow; h0 = oh->acc[0]; hw = oh->acc[1] + 2 * oh->acc[2] + 5 * oh->acc[3];
+                        hc = oh->count; hov = oh->overflow; h0 = oh->acc[0]; hw = oh->acc[1] + 2 * oh->acc[2] + 5 * oh->acc[3]; gc0 = oh->c0; gn_ = oh->n;
                     }
                     u64 special = bsx_ballot(tl < nt && (hc != 0 || hov != 0));
                     uint32_t done_upto = 0;  // tasks [tg, tg+done_upto) of this group are fully accounted
@@ -1769,11 +1820,11 @@ __device__ __forceinline__ int snp_align_heavy(const AlignArgs &A, const HeavyAr
                                 if (!e) {
                                     done_upto = bend;
                                     special &= bend >= 64 ? 0ull : ~((1ull << bend) - 1);
-                                    if (bend >= gn) { K.c[ms] = win_c0 + min(win_n, (tg + gn) * HS_TASK); break; }
+                                    if (bend >= gn) { K.c[ms] = rl(gc0, (int)gn - 1) + rl(gn_, (int)gn - 1); break; }
                                     continue;
                                 }
                                 // count exactly the candidates of the event's task up to and including the one that caused it
-                                const uint32_t tc0e = win_c0 + (tg + upto) * HS_TASK, Xe = tc0e + (rl(r.w_ord, ls) >> 8);
+                                const uint32_t tc0e = rl(gc0, (int)upto), Xe = tc0e + (rl(r.w_ord, ls) >> 8);
                                 { CAT_BEGIN(A); wave_scan_range<true, 4>(P, BL, L, M, SL, cl, orient, seg, mode, tc0e, Xe + 1, req_thres, lane, C); CAT_END(A, 5); }
                                 K.c[ms] = Xe + 1;
                                 if (e == 2) { wave_fence(); return 1; }
@@ -1786,11 +1837,11 @@ __device__ __forceinline__ int snp_align_heavy(const AlignArgs &A, const HeavyAr
                         const bool mine = (uint32_t)lane >= done_upto && (uint32_t)lane < nxt;
                         C.n_cand += wave_sum(mine ? h0 : 0);
                         C.sum_w += wave_sum(mine ? hw : 0);
-                        if (nxt >= gn) { K.c[ms] = win_c0 + min(win_n, (tg + gn) * HS_TASK); break; }
+                        if (nxt >= gn) { K.c[ms] = rl(gc0, (int)gn - 1) + rl(gn_, (int)gn - 1); break; }
                         special &= special - 1;
                         done_upto = nxt + 1;
                         const uint32_t t = tg + nxt;
-                        const uint32_t tc0 = win_c0 + t * HS_TASK, tn = min((uint32_t)HS_TASK, win_n - t * HS_TASK);
+                        const uint32_t tc0 = rl(gc0, (int)nxt), tn = rl(gn_, (int)nxt);
                         const HTaskOut *o = &H.tout[t0 + t];
                         if (rl(hov, (int)nxt)) {  // too many survivors for the record: redo this task with the one-wave path
                             CAT_BEGIN(A);
@@ -1840,7 +1891,8 @@ __device__ __forceinline__ int snp_align_heavy(const AlignArgs &A, const HeavyAr
                 if (!restart) K.W[ms] = min(K.W[ms] * HS_GROW, (uint32_t)HS_WINMAX);
             } else {
                 const uint32_t weff = K.n_active < 2048u ? (uint32_t)HS_WINMAX : K.W[ms];  // few units left: scanning capacity is idle, speculate the whole list
-                const uint32_t wpool = (u64)H.task_cap * HS_TASK < (u64)weff ? H.task_cap * HS_TASK : weff;  // a window must fit the task pool
+                const uint32_t tfit = H.task_cap > 128u ? H.task_cap - 64u : H.task_cap / 2u;   // (a window of w candidates makes at most w / HS_TASK + 2 tasks per segment, 32 segments)
+                const uint32_t wpool = (u64)tfit * HS_TASK < (u64)weff ? tfit * HS_TASK : weff;  // a window must fit the task pool
                 const uint32_t wn = min(wpool, cl.total - K.c[ms]);
                 uint32_t nt = 0;
                 if (publish_window(P, H, S, hidx, ms, cl, orient, seg, L, M, K.c[ms], wn, lane, nt)) K.have[ms] = 1;
@@ -2232,7 +2284,7 @@ __device__ __forceinline__ void hscan_task(const AlignArgs &A, const HeavyArgs &
     const uint32_t hraw = rfl(H.tasks[t].h), hidx = hraw & 0x3fffffffu, tc0 = rfl(H.tasks[t].c0), tn = rfl(H.tasks[t].n);
     HTaskOut *o = &H.tout[t];
     if (tn == 0) {  // slot neutralised by a refused request: its unit has not published a list (ListReq may be stale)
-        if (lane == 0) { o->count = 0; o->overflow = 0; o->acc[0] = o->acc[1] = o->acc[2] = o->acc[3] = 0; }
+        if (lane == 0) { o->count = 0; o->overflow = 0; o->acc[0] = o->acc[1] = o->acc[2] = o->acc[3] = 0; o->c0 = 0; o->n = 0; }
         return;
     }
     const ListReq &R = H.state[hidx].req[hraw >> 30];
@@ -2284,7 +2336,7 @@ __device__ __forceinline__ void hscan_task(const AlignArgs &A, const HeavyArgs &
     const uint32_t n_cand = rrbs ? X.acc.nv : tn;  // RRBS: only the entries that passed the tag filter are candidates
     const uint32_t words = 2u * n_cand - n1 + 3u * n5;  // 1, 2 or 5 words per candidate (see above)
     if (lane == 0) {
-        o->count = X.overflow ? 0 : X.nsurv; o->overflow = X.overflow ? 1 : 0; o->acc[0] = n_cand; o->acc[1] = words; o->acc[2] = 0; o->acc[3] = 0;
+        o->count = X.overflow ? 0 : X.nsurv; o->overflow = X.overflow ? 1 : 0; o->acc[0] = n_cand; o->acc[1] = words; o->acc[2] = 0; o->acc[3] = 0; o->c0 = tc0; o->n = tn;
         if (!X.overflow) {  // work of the scan kernel (incl. speculation); an overflowed task is redone by the control kernel.
             // Millions of tasks per batch: one counter word takes ~88 atomics per microsecond, so these statistics are
             // sharded over 64 cache lines (summed by bsx_batch_counters) instead of being added to four hot words
@@ -2469,35 +2521,34 @@ __device__ __forceinline__ void hp_step(PlaneCtx &X, uint32_t (&e)[4], const uin
 }
 
 // one scan task on one wave, plane form (same contract as hscan_task)
-__device__ __forceinline__ void hp_task(const AlignArgs &A, const HeavyArgs &H, uint32_t slot, int lane, int wv, uint32_t (&TAB)[BSX_HSCAN_WPB][4][32],
-                                        uint2 (&PT)[BSX_HSCAN_WPB][HP_PAIRS * 32], uint2 (&QB)[BSX_HSCAN_WPB][HP_QCAP])
+// (TABw / PTw / Qw: this wave's sub-range table, read table and FIFO in LDS)
+__device__ __forceinline__ void hp_task(const AlignArgs &A, const HeavyArgs &H, uint32_t t, int lane, uint32_t (&TABw)[4][32], uint2 *PTw, uint2 *Qw)
 {
     const DevParams &P = A.P;
-    const uint32_t t = H.order ? rfl(H.order[slot]) : slot;
     const uint32_t hraw = rfl(H.tasks[t].h), hidx = hraw & 0x3fffffffu, tc0 = rfl(H.tasks[t].c0), tn = rfl(H.tasks[t].n);
     HTaskOut *o = &H.tout[t];
     if (tn == 0) {  // slot neutralised by a refused request: its unit has not published a list (ListReq may be stale)
-        if (lane == 0) { o->count = 0; o->overflow = 0; o->acc[0] = o->acc[1] = o->acc[2] = o->acc[3] = 0; }
+        if (lane == 0) { o->count = 0; o->overflow = 0; o->acc[0] = o->acc[1] = o->acc[2] = o->acc[3] = 0; o->c0 = 0; o->n = 0; }
         return;
     }
     const ListReq &R = H.state[hidx].req[hraw >> 30];
-    if (lane < 32) { TAB[wv][0][lane] = R.sub_pre[lane]; TAB[wv][1][lane] = R.sub_n[lane]; TAB[wv][2][lane] = R.sub_base[lane]; TAB[wv][3][lane] = R.sub_h[lane]; }
-    hp_build_table(R, PT[wv], lane);
+    if (lane < 32) { TABw[0][lane] = R.sub_pre[lane]; TABw[1][lane] = R.sub_n[lane]; TABw[2][lane] = R.sub_base[lane]; TABw[3][lane] = R.sub_h[lane]; }
+    hp_build_table(R, PTw, lane);
     const uint32_t nsub = min(rfl(R.nsub), 32u);
     wave_fence();
     PlaneCtx X;
     X.plane = reinterpret_cast<const uint8_t *>(P.refplane); X.rc_off = P.plane_rc_off;
-    X.tbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint2 *)PT[wv];
-    X.Q = QB[wv]; X.qh = 0; X.qn = 0; X.thres0 = rfl(R.thres); X.nsurv = 0; X.nW = (int)((rfl(R.len) + 31u + 31u) >> 5); X.lane = lane;
+    X.tbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint2 *)PTw;
+    X.Q = Qw; X.qh = 0; X.qn = 0; X.thres0 = rfl(R.thres); X.nsurv = 0; X.nW = (int)((rfl(R.len) + 31u + 31u) >> 5); X.lane = lane;
     X.overflow = false; X.o = o; X.acc.c1 = 0; X.acc.f5 = 0; X.acc.nv = 0;
     const uint32_t c_end = tc0 + tn;
     // (WGBS lists only: RRBS lists — one bucket of {tag, loc} pairs — always go to k_hscan_shared, bsx_api.hip)
     for (uint32_t sidx = 0; sidx < nsub && !X.overflow; sidx++) {
-        const uint32_t ps = rfl(TAB[wv][0][sidx]), ns = rfl(TAB[wv][1][sidx]);
+        const uint32_t ps = rfl(TABw[0][sidx]), ns = rfl(TABw[1][sidx]);
         const uint32_t lo = max(tc0, ps), hi = min(c_end, ps + ns);
         if (lo >= hi) continue;
-        const uint32_t *ent = P.entries + rfl(TAB[wv][2][sidx]);
-        const uint32_t h = rfl(TAB[wv][3][sidx]), strand = sidx & 1;
+        const uint32_t *ent = P.entries + rfl(TABw[2][sidx]);
+        const uint32_t h = rfl(TABw[3][sidx]), strand = sidx & 1;
         const uint32_t ref_off = strand ? X.rc_off : 0u;
         uint32_t cb = lo;
         uint32_t e[4];
@@ -2511,7 +2562,7 @@ __device__ __forceinline__ void hp_task(const AlignArgs &A, const HeavyArgs &H, 
     const uint32_t n_cand = tn;
     const uint32_t words = 2u * n_cand - n1 + 3u * n5;  // 1, 2 or 5 words per candidate (see above)
     if (lane == 0) {
-        o->count = X.overflow ? 0 : X.nsurv; o->overflow = X.overflow ? 1 : 0; o->acc[0] = n_cand; o->acc[1] = words; o->acc[2] = 0; o->acc[3] = 0;
+        o->count = X.overflow ? 0 : X.nsurv; o->overflow = X.overflow ? 1 : 0; o->acc[0] = n_cand; o->acc[1] = words; o->acc[2] = 0; o->acc[3] = 0; o->c0 = tc0; o->n = tn;
         if (!X.overflow) {  // (sharded statistics: see hscan_task)
             u64 *sh = (u64 *)A.scan_stats + (size_t)(blockIdx.x & 63u) * 8;
             atomicAdd((u64 *)&sh[0], (u64)n_cand); atomicAdd((u64 *)&sh[1], (u64)words);
@@ -2556,11 +2607,277 @@ __global__ __launch_bounds__(64 * BSX_HSCAN_WPB, BSX_HSCAN_WAVES) void k_hscan(A
             slot = vb * BSX_HSCAN_WPB + (uint32_t)wv;
         }
 #if BSX_HSCAN_PLANES
-        if (slot < n_tasks) hp_task(A, H, slot, lane, wv, TAB, PT, QBUF);
+        if (slot < n_tasks) hp_task(A, H, H.order ? rfl(H.order[slot]) : slot, lane, TAB[wv], PT[wv], QBUF[wv]);
 #else
         if (slot < n_tasks) hscan_task(A, H, slot, lane, wv, TAB, QBUF, ANCH);
 #endif
         wave_fence();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_hscan_multi — WGBS: sixteen reads against ONE fetch of the candidates' reference windows.
+// Thousands of reads walk the same giant bucket in the same pass, and since publish_window cuts large sub-ranges on the grid of
+// absolute index entries, their tasks cover identical entry ranges: in scan order, runs of tasks with the same first entry, length
+// and strand copy.  A 64-lane gather costs the texture path the same for 4, 8 or 16 bytes per lane (39 CU cycles from L1, 144-158
+// from L2: tools/microbench/gather_cost.hip, profiles/r04b_gather_cost.json) and k_hscan spends 1.8 of them per 64 candidates and
+// read.  Here a block of four waves takes a run of up to 16 such tasks — each read with its own offset h into the candidate, hence
+// its own shift — and per round of 256 candidates
+//   * every wave fetches one chunk's entries and, per candidate, the 12 pairs of the plane copy that cover all the reads of the
+//     run (positions entry + hmin .. entry + hmax + read), six 16-byte gathers, into LDS: STG[chunk][pair][lane];
+//   * after a barrier every wave evaluates all four chunks for ITS four reads from LDS: candidate pairs by ds_read_b64 at
+//     [pair0 + d][lane] (32 lanes of a row are 32 different 8-byte units: no bank conflict whatever d is per lane), the read's
+//     pre-shifted tables as in k_hscan (hp_build_table, one table per read), the same two stages through one FIFO per wave whose
+//     items carry the read's slot; stage 2 reads the staged pairs too, so the FIFO is emptied before the round's buffer is released.
+// 0.375 gathers per 64 candidates and read instead of 1.8.  Results per task are exactly k_hscan's: survivors in list order,
+// candidate count, word count.  Runs shorter than HM_MINRUN, and tasks of small segments, go one task per wave through hp_task.
+// ---------------------------------------------------------------------------------------------------------------
+#define HM_TASKS 16u   /* tasks a block takes per group */
+#define HM_WAVES 8     /* waves per block */
+#define HM_SLOTS 2     /* reads per wave: HM_WAVES * HM_SLOTS = HM_TASKS */
+#define HM_MINRUN 4u
+#define HM_PAIRS 12u   /* staged pairs per candidate: ((31 + hmax - hmin) >> 5) + 6 of them are needed */
+#define HM_QCAP 128u
+struct MultiLds {
+    uint2 PT[HM_TASKS][HP_PAIRS * 32];  // read tables: wave w owns PT[HM_SLOTS w ..] (the one-task path uses the first)
+    uint2 STG[4][HM_PAIRS][64];         // the round's four chunks: pairs of the plane copy from each candidate's first pair on
+    uint32_t ENT[4][64];                // their index entries
+    uint2 Q[HM_WAVES][HM_QCAP];         // FIFO of each wave
+    uint32_t TAB[HM_WAVES][4][32];      // sub-range tables of the one-task path
+};
+__device__ __forceinline__ void hm_lds2(uint32_t addr, q64 &a, q64 &b)   // rows d, d + 1 of a staged chunk (a row is 512 bytes)
+{
+    asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:512" : "=&v"(a), "=&v"(b) : "v"(addr));
+}
+__device__ __forceinline__ void hm_lds4(uint32_t addr, q64 &a, q64 &b, q64 &c, q64 &d)
+{
+    asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:512\n\tds_read_b64 %2, %4 offset:1024\n\tds_read_b64 %3, %4 offset:1536"
+                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(addr));
+}
+struct MultiCtx {
+    uint32_t tbase, sbase;      // LDS byte addresses: this wave's first table, the staging buffer
+    uint2 *Q; uint32_t qh, qn;
+    uint32_t thr[HM_SLOTS], tid[HM_SLOTS];    // per read slot: threshold, task id (outputs)
+    uint32_t thr_pack;          // the thresholds, one byte each (a threshold is at most 15)
+    uint32_t c1[HM_SLOTS], f5[HM_SLOTS], ns[HM_SLOTS];
+    uint32_t valid_slots;       // bit q: slot q holds a read
+    HTaskOut *tout;
+    int lane;
+    uint32_t strand;
+};
+
+// stage 2 for the first n (<= 64) queued candidates of this wave's reads
+__device__ __forceinline__ void hm_drain(MultiCtx &X, uint32_t n)
+{
+    const bool act = (uint32_t)X.lane < n;
+    const uint2 it = X.Q[(X.qh + (uint32_t)X.lane) & (HM_QCAP - 1)];  // x position, y p64 | ordinal << 8 | slot << 21 | pair offset << 23
+    X.qh = (X.qh + n) & (HM_QCAP - 1); X.qn -= n;
+    const uint32_t p = it.x, y = it.y;
+    const uint32_t q = (y >> 21) & 3u, d = (y >> 23) & 7u, ord = (y >> 8) & 0x1fffu;
+    const uint32_t taddr = hp_taddr(X.tbase + q * (HP_PAIRS * 32u * 8u), p);
+    const uint32_t saddr = X.sbase + ((((ord >> 6) & 3u) * HM_PAIRS + d + 2u) * 64u + (ord & 63u)) * 8u;
+    q64 t7[7], r4[4];
+    hm_lds4(saddr, r4[0], r4[1], r4[2], r4[3]);
+    hp_lds7(taddr, t7);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t7[0]), "+v"(t7[1]), "+v"(t7[2]), "+v"(t7[3]), "+v"(t7[4]), "+v"(t7[5]), "+v"(t7[6]), "+v"(r4[0]), "+v"(r4[1]), "+v"(r4[2]), "+v"(r4[3]));
+    const uint32_t thr = (X.thr_pack >> (q << 3)) & 0xffu;   // (a chain of selects becomes a chain of branches)
+    const uint32_t p64 = y & 0xffu;
+    const uint32_t mm2 = bsx_plane_mismatch(qlo(r4[0]), qhi(r4[0]), qhi(t7[0]), qlo(t7[1]), qhi(t7[1]));
+    uint32_t tot = popc_acc(mm2, p64);
+    const uint32_t w01ref = popc_acc(mm2 & qlo(t7[0]), p64);
+    tot = popc_acc(bsx_plane_mismatch(qlo(r4[1]), qhi(r4[1]), qlo(t7[2]), qhi(t7[2]), qlo(t7[3])), tot);
+    tot = popc_acc(bsx_plane_mismatch(qlo(r4[2]), qhi(r4[2]), qhi(t7[3]), qlo(t7[4]), qhi(t7[4])), tot);
+    tot = popc_acc(bsx_plane_mismatch(qlo(r4[3]), qhi(r4[3]), qlo(t7[5]), qhi(t7[5]), qlo(t7[6])), tot);
+    const u64 am = bsx_ballot(act), b0 = bsx_ballot((q & 1u) != 0);
+    const u64 m5 = bsx_ballot(w01ref <= thr) & am, mp = bsx_ballot(tot <= thr) & am;
+#pragma unroll
+    for (int k = 0; k < HM_SLOTS; k++) {
+        const u64 mk = (k & 1) ? b0 : ~b0;
+        X.f5[k] += (uint32_t)__builtin_popcountll(m5 & mk);
+        const u64 ms = mp & mk;
+        if (ms) {
+            const uint32_t pos = X.ns[k] + __builtin_amdgcn_mbcnt_hi((uint32_t)(ms >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ms, 0u));
+            if (((ms >> X.lane) & 1) && pos < HS_SCAP) { SurvRec r; r.w_ord = tot | (ord << 8); r.hchr = X.strand; r.hloc = p; r.hkey = 0; X.tout[X.tid[k]].surv[pos] = r; }
+            X.ns[k] += (uint32_t)__builtin_popcountll(ms);
+        }
+    }
+}
+
+// a run of K (HM_MINRUN..16) tasks over the same n index entries from `key` on, strand copy `strand`: lane j of every wave holds task
+// i0 + j's (tid, th, hh) — task id, unit | slot, offset h of its sub-range.  All waves of the block call this together (barriers inside).
+__device__ __forceinline__ void hm_run(const AlignArgs &A, const HeavyArgs &H, MultiLds &L, int lane, int wv, uint32_t i0, uint32_t K, uint32_t tid, uint32_t th, uint32_t hh,
+                                       uint32_t tc0, uint32_t key, uint32_t n, uint32_t strand, int hmin)
+{
+    static_assert(HM_SLOTS == 2, "slot masks of hm_drain");
+    const DevParams &P = A.P;
+    MultiCtx X;
+    X.tbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint2 *)L.PT[HM_SLOTS * wv];
+    X.sbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint2 *)&L.STG[0][0][0];
+    X.Q = L.Q[wv]; X.qh = 0; X.qn = 0; X.tout = H.tout; X.lane = lane; X.strand = strand; X.valid_slots = 0; X.thr_pack = 0;
+    uint32_t hq[HM_SLOTS], c0q[HM_SLOTS];
+#pragma unroll
+    for (int q = 0; q < HM_SLOTS; q++) {   // slot q of wave w: task i0 + w + HM_WAVES q of the run (an empty slot repeats the run's first task and is ignored)
+        const uint32_t j = (uint32_t)wv + (uint32_t)HM_WAVES * (uint32_t)q;
+        const bool ok = j < K;
+        const uint32_t src = i0 + (ok ? j : 0u);
+        X.tid[q] = rl_u(tid, src); hq[q] = rl_u(hh, src); c0q[q] = rl_u(tc0, src);
+        const uint32_t thq = rl_u(th, src);
+        const ListReq &R = H.state[thq & 0x3fffffffu].req[thq >> 30];
+        X.thr[q] = rfl(R.thres);
+        X.thr_pack |= (X.thr[q] & 0xffu) << (8 * q);
+        if (ok) X.valid_slots |= 1u << q;
+        hp_build_table(R, L.PT[HM_SLOTS * wv + q], lane);
+        X.c1[q] = 0; X.f5[q] = 0; X.ns[q] = 0;
+    }
+    const uint8_t *plane = reinterpret_cast<const uint8_t *>(P.refplane);
+    const uint32_t ref_off = strand ? P.plane_rc_off : 0u;
+    const uint32_t *ent = P.entries + key;
+    const uint32_t uhmin = (uint32_t)hmin;
+    wave_fence();
+    // Software pipeline over the rounds: the gathers of round r + 1 are in flight while round r is evaluated, and the entries they
+    // start from were loaded a round earlier still.  Waves 0-3 stage one chunk each.
+    //   e_cur: this wave's entries of the round whose pairs sit in g[] ; e_nxt: of the round after it
+    const bool stager = wv < 4;
+    const uint32_t my = 64u * (uint32_t)(wv & 3) + (uint32_t)lane;
+    uint32_t e_cur = (stager && my < n) ? ent[my] : 1024u;   // (a lane without a candidate: any position that keeps e + h from wrapping — its pair offsets stay inside the staged rows)
+    uint32_t e_nxt = (stager && 256u + my < n) ? ent[256u + my] : 1024u;
+    U4 g[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) g[i].a = g[i].b = g[i].c = g[i].d = 0;
+    if (stager) {
+        const uint8_t *src = plane + hp_boff(e_cur + uhmin, ref_off);
+#pragma unroll
+        for (int i = 0; i < 6; i++) g[i] = *reinterpret_cast<const U4 *>(src + 16 * i);
+    }
+    for (uint32_t cb = 0; cb < n; cb += 256) {
+        if (stager) {
+            // stage chunk `wv` of this round (the barrier at the end of the last round freed the buffer)
+            L.ENT[wv][lane] = e_cur;
+#pragma unroll
+            for (int i = 0; i < 6; i++) { L.STG[wv][2 * i][lane] = make_uint2(g[i].a, g[i].b); L.STG[wv][2 * i + 1][lane] = make_uint2(g[i].c, g[i].d); }
+            // the next round's gathers, and the entries of the one after it
+            e_cur = e_nxt;
+            if (cb + 256 < n) {
+                const uint8_t *src = plane + hp_boff(e_cur + uhmin, ref_off);
+#pragma unroll
+                for (int i = 0; i < 6; i++) g[i] = *reinterpret_cast<const U4 *>(src + 16 * i);
+                e_nxt = cb + 512u + my < n ? ent[cb + 512u + my] : 1024u;
+            }
+        }
+        __syncthreads();
+        // The round's (chunk, slot) evaluations as one flat sequence with the LDS reads of an evaluation issued TWO evaluations ahead
+        // (three rotating register sets; s_waitcnt lgkmcnt counts to 15: twelve reads may stay in flight).  Chunks beyond the run's
+        // end evaluate the dummy entries of their empty lanes and count nothing.
+        uint32_t ev[4], pair0[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) { ev[c] = L.ENT[c][lane]; pair0[c] = (ev[c] + uhmin) >> 5; }
+        q64 tq[3][4], rq[3][2];
+        uint32_t pq[3], dq[3];
+        auto issue = [&](int set, int it) {
+            const int c = it / HM_SLOTS, q = it % HM_SLOTS;
+            pq[set] = ev[c] + hq[q]; dq[set] = (pq[set] >> 5) - pair0[c];
+            hm_lds2(X.sbase + ((uint32_t)c * HM_PAIRS * 64u + (uint32_t)lane) * 8u + dq[set] * 512u, rq[set][0], rq[set][1]);
+            hp_lds4(hp_taddr(X.tbase + (uint32_t)q * (HP_PAIRS * 32u * 8u), pq[set]), tq[set][0], tq[set][1], tq[set][2], tq[set][3]);
+        };
+        constexpr int NIT = 4 * HM_SLOTS;
+        issue(0, 0); issue(1, 1);
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int c = it / HM_SLOTS, q = it % HM_SLOTS, cur = it % 3;
+            if (it + 2 < NIT) {
+                issue((it + 2) % 3, it + 2);
+                asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(rq[cur][0]), "+v"(rq[cur][1]), "+v"(tq[cur][0]), "+v"(tq[cur][1]), "+v"(tq[cur][2]), "+v"(tq[cur][3]));
+            } else if (it + 1 < NIT) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(rq[cur][0]), "+v"(rq[cur][1]), "+v"(tq[cur][0]), "+v"(tq[cur][1]), "+v"(tq[cur][2]), "+v"(tq[cur][3]));
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rq[cur][0]), "+v"(rq[cur][1]), "+v"(tq[cur][0]), "+v"(tq[cur][1]), "+v"(tq[cur][2]), "+v"(tq[cur][3]));
+            const uint32_t ord = cb + 64u * (uint32_t)c + (uint32_t)lane;
+            const bool validc = ord < n;
+            // (validity as a scalar mask: a ballot of a compare ANDed with another lane condition goes through a 0/1 register and a second compare)
+            const u64 okm = ((X.valid_slots >> q) & 1u) ? bsx_ballot(validc) : 0ull;
+            const uint32_t mm0 = bsx_plane_mismatch(qlo(rq[cur][0]), qhi(rq[cur][0]), qlo(tq[cur][0]), qhi(tq[cur][0]), qlo(tq[cur][1]));
+            const uint32_t mm1 = bsx_plane_mismatch(qlo(rq[cur][1]), qhi(rq[cur][1]), qlo(tq[cur][2]), qhi(tq[cur][2]), qhi(tq[cur][1]));
+            const uint32_t cnt0 = __popc(mm0);
+            const uint32_t w0ref = popc_acc(mm1 & qlo(tq[cur][3]), cnt0), p64 = popc_acc(mm1, cnt0);
+            const bool within = p64 <= X.thr[q];
+            X.c1[q] += (uint32_t)__builtin_popcountll(bsx_ballot(w0ref > X.thr[q]) & okm);
+            const u64 nm = bsx_ballot(within) & okm;
+            if (nm) {
+                if (within && validc && ((X.valid_slots >> q) & 1u)) {
+                    const uint32_t pos = X.qh + X.qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(nm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nm, 0u));
+                    X.Q[pos & (HM_QCAP - 1)] = make_uint2(pq[cur], p64 | (ord << 8) | ((uint32_t)q << 21) | (dq[cur] << 23));
+                }
+                X.qn += (uint32_t)__builtin_popcountll(nm);
+            }
+            while (X.qn >= 64) hm_drain(X, 64);
+        }
+        while (X.qn) hm_drain(X, min(X.qn, 64u));   // stage 2 reads the staged pairs: nothing may be left when the buffer is released
+        __syncthreads();
+    }
+    // results of this wave's reads
+    u64 st_cand = 0, st_words = 0, st_n1 = 0, st_n5 = 0;
+#pragma unroll
+    for (int q = 0; q < HM_SLOTS; q++) {
+        if (!((X.valid_slots >> q) & 1u)) continue;
+        const bool ov = X.ns[q] > HS_SCAP;
+        const uint32_t words = 2u * n - X.c1[q] + 3u * X.f5[q];
+        if (lane == 0) {
+            HTaskOut *o = &H.tout[X.tid[q]];
+            o->count = ov ? 0 : X.ns[q]; o->overflow = ov ? 1 : 0; o->acc[0] = n; o->acc[1] = words; o->acc[2] = 0; o->acc[3] = 0; o->c0 = c0q[q]; o->n = n;
+        }
+        if (!ov) { st_cand += n; st_words += words; st_n1 += X.c1[q]; st_n5 += X.f5[q]; }
+    }
+    if (lane == 0 && st_cand) {
+        u64 *sh = (u64 *)A.scan_stats + (size_t)((blockIdx.x * (uint32_t)HM_WAVES + (uint32_t)wv) & 63u) * 8;
+        atomicAdd((u64 *)&sh[0], st_cand); atomicAdd((u64 *)&sh[1], st_words); atomicAdd((u64 *)&sh[2], st_n1); atomicAdd((u64 *)&sh[3], st_n5);
+        atomicAdd((u64 *)&sh[4], st_cand);   // counter 15: the share of counter 7 that went through shared fetches
+    }
+}
+
+__global__ __launch_bounds__(64 * HM_WAVES, 4) void k_hscan_multi(AlignArgs A, HeavyArgs H)
+{
+    __shared__ MultiLds L;
+    const int lane = threadIdx.x & 63, wv = (int)rfl(threadIdx.x >> 6);
+    const uint32_t n_tasks = min(*H.n_tasks, H.task_cap);
+    const uint32_t ngrp = (n_tasks + HM_TASKS - 1) / HM_TASKS, per_xcd = (ngrp + 7u) >> 3;
+    for (uint32_t vb = blockIdx.x;; vb += gridDim.x) {
+        // (blocks of one XCD — dispatched round-robin, the grid is a multiple of 8 — take a contiguous part of the scan order: neighbours share an L2)
+        if ((vb >> 3) >= per_xcd) break;
+        const uint32_t s0 = ((vb & 7u) * per_xcd + (vb >> 3)) * HM_TASKS;
+        if (s0 >= n_tasks) continue;
+        const uint32_t nj = min(HM_TASKS, n_tasks - s0);
+        // lane j < nj: task j of the group, in scan order, and the signature of its window
+        uint32_t tid = 0, th = 0, tc0 = 0, tn = 0, key = 0, hh = 0, strand = 0;
+        bool single = false;
+        if ((uint32_t)lane < nj) {
+            tid = H.order ? H.order[s0 + lane] : s0 + (uint32_t)lane;
+            const HTask tk = H.tasks[tid];
+            th = tk.h; tc0 = tk.c0; tn = tk.n;
+            key = tk.key; hh = tk.sub_h; strand = tk.flags & 1u; single = tn != 0 && (tk.flags & 2u) != 0;   // (publish_window: the sub-range the task starts in, and whether it ends there too)
+        }
+        for (uint32_t i0 = 0; i0 < nj;) {
+            const uint32_t n = rl_u(tn, i0);
+            uint32_t K = 1;
+            int hmin = 0, hmax = 0;
+            if (n && rl_u(single ? 1u : 0u, i0)) {
+                const uint32_t key0 = rl_u(key, i0), st0 = rl_u(strand, i0);
+                const bool same = (uint32_t)lane >= i0 && (uint32_t)lane < nj && single && tn == n && key == key0 && strand == st0;
+                K = (uint32_t)__builtin_ctzll(~(bsx_ballot(same) >> i0));   // (bit 0 is set: the task equals itself)
+                const bool in_run = (uint32_t)lane >= i0 && (uint32_t)lane < i0 + K;
+                int lo_ = in_run ? (int)hh : 0x7fffffff, hi_ = in_run ? (int)hh : (int)0x80000000;
+#pragma unroll
+                for (int o_ = 32; o_; o_ >>= 1) { lo_ = min(lo_, __shfl_xor(lo_, o_)); hi_ = max(hi_, __shfl_xor(hi_, o_)); }
+                hmin = lo_; hmax = hi_;
+            }
+            if (K >= HM_MINRUN && ((31 + hmax - hmin) >> 5) + 6 <= (int)HM_PAIRS) {
+                hm_run(A, H, L, lane, wv, i0, K, tid, th, hh, tc0, rl_u(key, i0), n, rl_u(strand, i0), hmin);
+            } else {
+                for (uint32_t j = i0 + (uint32_t)wv; j < i0 + K; j += HM_WAVES) {   // one task per wave
+                    hp_task(A, H, rl_u(tid, j), lane, L.TAB[wv], L.PT[HM_SLOTS * wv], L.Q[wv]);
+                    wave_fence();
+                }
+            }
+            i0 += K;
+        }
+        __syncthreads();
     }
 }
 
@@ -2636,7 +2953,7 @@ __global__ __launch_bounds__(256, BSX_HSHARED_WAVES) void k_hscan_shared(AlignAr
             sh_ = R.sub_h[0]; stx = R.tag_xor; stw = R.tag_want; snw = (R.len + 31u) >> 5;  // snw: read words of 32 nt
         } else {  // slot neutralised by a refused request: its unit has not published a list
             HTaskOut *o = &H.tout[tid];
-            o->count = 0; o->overflow = 0; o->acc[0] = o->acc[1] = o->acc[2] = o->acc[3] = 0;
+            o->count = 0; o->overflow = 0; o->acc[0] = o->acc[1] = o->acc[2] = o->acc[3] = 0; o->c0 = 0; o->n = 0;
         }
     }
     u64 st_cand = 0, st_words = 0, st_n1 = 0, st_n5 = 0;  // statistics of the scan kernel (lane 0)
@@ -2721,11 +3038,12 @@ __global__ __launch_bounds__(256, BSX_HSHARED_WAVES) void k_hscan_shared(AlignAr
         const uint32_t n_cand = wave_sum(nv);
         {
             const bool mine = (uint32_t)lane < K;
+            const uint32_t my_c0 = (uint32_t)__shfl((int)tc0, (int)min(i0 + (uint32_t)lane, 63u));  // (all lanes take part) the list ordinal read `lane`'s task starts at
             const uint32_t ns = nsv, n1 = c15 & 0xffffu, n5 = c15 >> 16;
             const bool ov = ns > HS_SCAP;
             if (mine) {
                 HTaskOut *o = &H.tout[UW[wv][lane][16]];
-                o->count = ov ? 0 : ns; o->overflow = ov ? 1 : 0; o->acc[0] = n_cand; o->acc[1] = 2u * n_cand - n1 + 3u * n5; o->acc[2] = 0; o->acc[3] = 0;
+                o->count = ov ? 0 : ns; o->overflow = ov ? 1 : 0; o->acc[0] = n_cand; o->acc[1] = 2u * n_cand - n1 + 3u * n5; o->acc[2] = 0; o->acc[3] = 0; o->c0 = my_c0; o->n = n;
             }
             // work of the scan kernel (incl. speculation); an overflowed task is redone by the control kernel
             const bool cnt = mine && !ov;
@@ -2794,7 +3112,7 @@ __global__ __launch_bounds__(256, BSX_HSHARED_WAVES) void k_hscan_shared(AlignAr
             sh_ = R.sub_h[0]; stx = R.tag_xor; stw = R.tag_want; snw = R.nwords;
         } else {  // slot neutralised by a refused request: its unit has not published a list
             HTaskOut *o = &H.tout[tid];
-            o->count = 0; o->overflow = 0; o->acc[0] = o->acc[1] = o->acc[2] = o->acc[3] = 0;
+            o->count = 0; o->overflow = 0; o->acc[0] = o->acc[1] = o->acc[2] = o->acc[3] = 0; o->c0 = 0; o->n = 0;
         }
     }
     u64 st_cand = 0, st_words = 0, st_n1 = 0, st_n5 = 0;  // statistics of the scan kernel (lane 0)
@@ -2883,11 +3201,12 @@ __global__ __launch_bounds__(256, BSX_HSHARED_WAVES) void k_hscan_shared(AlignAr
         const uint32_t n_cand = wave_sum(nv);
         {
             const bool mine = (uint32_t)lane < K;
+            const uint32_t my_c0 = (uint32_t)__shfl((int)tc0, (int)min(i0 + (uint32_t)lane, 63u));  // (all lanes take part) the list ordinal read `lane`'s task starts at
             const uint32_t ns = nsv, n1 = c15 & 0xffffu, n5 = c15 >> 16;
             const bool ov = ns > HS_SCAP;
             if (mine) {
                 HTaskOut *o = &H.tout[UW[wv][lane][19]];
-                o->count = ov ? 0 : ns; o->overflow = ov ? 1 : 0; o->acc[0] = n_cand; o->acc[1] = 2u * n_cand - n1 + 3u * n5; o->acc[2] = 0; o->acc[3] = 0;
+                o->count = ov ? 0 : ns; o->overflow = ov ? 1 : 0; o->acc[0] = n_cand; o->acc[1] = 2u * n_cand - n1 + 3u * n5; o->acc[2] = 0; o->acc[3] = 0; o->c0 = my_c0; o->n = n;
             }
             // work of the scan kernel (incl. speculation); an overflowed task is redone by the control kernel
             const bool cnt = mine && !ov;
@@ -2957,6 +3276,14 @@ void bsx_launch_hscan_shared(const AlignArgs &A, const HeavyArgsRaw &R, hipStrea
     const HeavyArgs H = typed(R);
     const uint32_t jobs = ((max_tasks ? std::min(max_tasks, R.task_cap) : R.task_cap) + HS_SHARE - 1) / HS_SHARE;
     hipLaunchKernelGGL(k_hscan_shared, dim3((jobs + 3) / 4), dim3(256), 0, stream, A, H);
+}
+
+void bsx_launch_hscan_multi(const AlignArgs &A, const HeavyArgsRaw &R, hipStream_t stream, uint32_t max_tasks)
+{
+    const HeavyArgs H = typed(R);
+    uint32_t blocks = ((max_tasks ? std::min(max_tasks, R.task_cap) : R.task_cap) + HM_TASKS - 1) / HM_TASKS;
+    blocks = (blocks + 7u) & ~7u;  // the same number of blocks for each of the 8 XCDs (the sweep relies on a multiple of 8)
+    hipLaunchKernelGGL(k_hscan_multi, dim3(blocks), dim3(64 * HM_WAVES), 0, stream, A, H);
 }
 
 void bsx_launch_hscan(const AlignArgs &A, const HeavyArgsRaw &R, hipStream_t stream, uint32_t max_tasks)

@@ -735,6 +735,10 @@ extern "C" int bsx_batch_run_range(bsx_batch *b, uint32_t first_unit, uint32_t n
         // beyond that point find nothing to do.  While k_hscan evaluates the tasks of one group, the control kernels of the others
         // run beside it — they are latency-bound chains of a few thousand waves.
         const bool shared_scan = b->ref->P.rrbs != 0;  // RRBS: runs of tasks over one window, scanned together
+        // WGBS, BSX_MULTI=1: runs of tasks over one window share the fetch of the candidates' reference (k_hscan_multi).  Measured and NOT the default:
+        // 98 % of the candidates run that way and the texture path falls from 0.72 to 0.12 busy, but the kernel spends 53 instead of 42 vector
+        // instructions per 64 candidates and its waves wait at two barriers per round: 356 against 491 G candidates/s (profiles/r04g_*)
+        const bool multi_scan = !shared_scan && getenv("BSX_MULTI") && atoi(getenv("BSX_MULTI")) == 1;
         const int n_groups = b->n_groups;
         struct Group { uint32_t n0 = 0, passes = 0, polls = 0, polled = 0; int cur = 0; bool done = true, tail = false; HeavyArgsRaw H; uint32_t *blk[2]; };
         volatile uint32_t *pinned = (volatile uint32_t *)b->h_pinned;
@@ -779,6 +783,7 @@ extern "C" int bsx_batch_run_range(bsx_batch *b, uint32_t first_unit, uint32_t n
                 }
                 HIP_TRY(hipEventRecord(b->scan_ev[b->scan_ev_used], s_scan));
                 if (shared_scan) bsx_launch_hscan_shared(A, q.H, s_scan, q.tail ? b->tail_grid_tasks : 0);
+                else if (multi_scan) bsx_launch_hscan_multi(A, q.H, s_scan, q.tail ? b->tail_grid_tasks : 0);
                 else bsx_launch_hscan(A, q.H, s_scan, q.tail ? b->tail_grid_tasks : 0);
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipEventRecord(b->scan_ev[b->scan_ev_used + 1], s_scan));
@@ -928,7 +933,7 @@ extern "C" int bsx_batch_counters(bsx_batch *b, uint64_t c[BSX_N_COUNTERS])
     HIP_TRY(hipMemcpy(c, b->d_counters, BSX_N_COUNTERS * 8, hipMemcpyDeviceToHost));
     uint64_t sh[64 * 8];
     HIP_TRY(hipMemcpy(sh, b->d_scan_stats, sizeof(sh), hipMemcpyDeviceToHost));
-    for (int i = 0; i < 64; i++) for (int k = 0; k < 4; k++) c[7 + k] += sh[i * 8 + k];
+    for (int i = 0; i < 64; i++) { for (int k = 0; k < 4; k++) c[7 + k] += sh[i * 8 + k]; c[15] += sh[i * 8 + 4]; }
     return BSX_OK;
 }
 extern "C" int bsx_batch_reset_counters(bsx_batch *b)

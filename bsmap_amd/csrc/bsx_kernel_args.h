@@ -66,6 +66,7 @@ size_t bsx_leakstate_bytes(void);
 uint32_t bsx_leak_blk(void);
 void bsx_launch_hctrl(const AlignArgs &A, const HeavyArgsRaw &H, int paired, int grid_blocks, hipStream_t stream);
 void bsx_launch_hscan(const AlignArgs &A, const HeavyArgsRaw &H, hipStream_t stream, uint32_t max_tasks = 0);         // grid sized for H.task_cap (or max_tasks: the blocks sweep); the count stays on the device
+void bsx_launch_hscan_multi(const AlignArgs &A, const HeavyArgsRaw &H, hipStream_t stream, uint32_t max_tasks = 0);   // WGBS: runs of tasks over one window, four waves x four reads per block
 void bsx_launch_hscan_shared(const AlignArgs &A, const HeavyArgsRaw &H, hipStream_t stream, uint32_t max_tasks = 0);  // RRBS: up to 16 tasks of one window per wave
 // scan order of a pass (task ids by the index entry they start at, 2^shift entries per bin), computed on the device
 uint32_t bsx_bin_chunks(uint32_t n_bins);
