@@ -277,18 +277,12 @@ def main():
                    "setup_s": {"genome": round(t_gen, 2), "index_build_gpu": round(t_index, 2), "device_batches": round(t_batches, 2)},
                    "aligned_fraction": float((2 * tot_counters[6] + tot_counters[5]) / max(1.0, n_reads_rank * world)) if pe
                    else float(tot_counters[5] / max(1.0, n_reads_rank * world))},
-        # `achieved` / `frac` follow the SURVEY 8(d) formula (algorithmic bytes of a step over its wall time against the HBM peak): a rate
-        # of algorithmic bytes, NOT HBM utilisation — the sorted scan order serves most of those bytes from L2.  `bound` names what
-        # the counters say limits the step, `hbm_traffic` what the memory system really moved, `per_kernel` each kernel's share.
-        "roofline": {"bound": bound, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "traffic_source": traffic_note, "hbm_traffic": hbm,
-                     "kernel": "one Do_Batch = k_align + heavy pipeline (k_hctrl/k_hscan passes)", "kernel_ms": k_ms,
-                     "event_ms_per_do_batch": float(np.mean(kernel_ms)), "heavy_units_last_step": heavy_last[0], "redo_units_last_step": heavy_last[1], "algorithmic_bytes_per_launch": alg_bytes_launch,
-                     "per_read": {"n_lookup": float(counters[0]) / n_reads_rank, "n_cand": float(counters[1]) / n_reads_rank,
-                                  "ref_words64": float(counters[2]) / n_reads_rank},
-                     "multi_share": float(counters[15]) / max(1.0, float(counters[7])),   # of the scan kernel's candidates: evaluated in runs of tasks over one window (k_hscan_multi)
-                     "per_kernel": per_kernel_split(counters, args.steps, n_reads_rank, pmc_j, serial),
-                     "dominant_kernel": dk},
+        # The roofline of the dominant kernel against the unit that binds it: `achieved` = candidates per second of k_hscan measured live (HIP events
+        # on its stream, device counters), `frac` = the utilisation of its busiest unit (counter passes of this kernel under profiles/), `peak` =
+        # achieved / frac — the rate at which that unit would be saturated.  The SURVEY 8(d) formula (algorithmic bytes of a step over its
+        # wall time against the HBM peak) is kept under `formula_rate`: it is a rate of ALGORITHMIC bytes, not HBM utilisation — the sorted
+        # scan order serves most of those bytes from L2 — and can exceed 1.  `hbm_traffic` is what the memory system really moved.
+        "roofline": roofline_block(dk, bound, achieved, traffic, traffic_note, hbm, k_ms, kernel_ms, heavy_last, alg_bytes_launch, counters, n_reads_rank, args, pmc_j, serial, np),
     }
     if world == 1 and not args.profile_serial:
         out["workload_shape"] = workload_shape(ref, counters, args.steps, B_, reads_per_unit, heavy_last[0])
@@ -330,6 +324,25 @@ def main():
     print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def roofline_block(dk, bound, achieved, traffic, traffic_note, hbm, k_ms, kernel_ms, heavy_last, alg_bytes_launch, counters, n_reads_rank, args, pmc_j, serial, np):
+    dk = dk or {}
+    util = dk.get("binding_unit_utilisation")
+    cand_s = dk.get("candidates_per_s")
+    r = {"bound": dk.get("bound") or bound,
+         "achieved": cand_s / 1e9 if cand_s else None, "peak": (cand_s / util / 1e9) if (cand_s and util) else None, "unit": "G candidates/s (" + str(dk.get("name")) + ")",
+         "frac": util,
+         "formula_rate": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                          "note": "SURVEY 8(d): algorithmic bytes of a step / its wall time, against the HBM peak; " + bound},
+         "traffic": traffic, "traffic_source": traffic_note, "hbm_traffic": hbm,
+         "kernel": "one Do_Batch = k_align + heavy pipeline (k_hctrl/k_hscan passes)", "kernel_ms": k_ms,
+         "event_ms_per_do_batch": float(np.mean(kernel_ms)), "heavy_units_last_step": heavy_last[0], "redo_units_last_step": heavy_last[1], "algorithmic_bytes_per_launch": alg_bytes_launch,
+         "per_read": {"n_lookup": float(counters[0]) / n_reads_rank, "n_cand": float(counters[1]) / n_reads_rank, "ref_words64": float(counters[2]) / n_reads_rank},
+         "multi_share": float(counters[15]) / max(1.0, float(counters[7])),   # of the scan kernel's candidates: evaluated in runs of tasks over one window (k_hscan_multi, BSX_MULTI=1)
+         "per_kernel": per_kernel_split(counters, args.steps, n_reads_rank, pmc_j, serial),
+         "dominant_kernel": dk}
+    return r
 
 
 def workload_shape(ref, c, steps, units_per_step, reads_per_unit, heavy_units):
@@ -415,32 +428,41 @@ def dominant_kernel(counters, scan_ms, steps, nfl, rrbs=False):
                                                                      "waiting_for_data": k.get("wait_any_frac")}})
         except Exception:
             pass
-        d.update({"bound": "VALU issue (reference words are loaded and shifted once per candidate for up to 16 reads; about 34 VALU per 64 candidates and read)",
-                  "bound_evidence": ev})
+        vu = (ev.get("fractions") or {}).get("valu_issue_4_cycles_per_instruction")
+        d.update({"bound": "VALU issue (reference planes are loaded and shifted once per candidate for up to 16 reads; the rest is arithmetic per candidate and read)",
+                  "binding_unit": "valu_issue", "binding_unit_utilisation": vu, "bound_evidence": ev})
     else:
         d.update(kernel_bound())
     return d
 
 
 def kernel_bound():
-    """bound of k_hscan from measurements kept under profiles/: SQ / TA counter passes of the kernel (tools/summarize_sq.py) and
-    the VALU issue ceiling of its instruction mix (tools/microbench/valu_issue.hip)"""
+    """utilisation of k_hscan's units from measurements kept under profiles/: SQ / TA / LDS counter passes of the kernel (tools/sq_passes.sh,
+    tools/summarize_sq.py) and the VALU issue ceiling of its instruction mix (tools/microbench/valu_issue.hip).  The binding unit is
+    the busiest one; `same_build` says whether the counters were taken with the library this process runs."""
     try:
         import glob
-        sq = [f for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sq.json"))) if "k_hscan" in json.load(open(f)).get("kernels", {})][-1]
+        sqs = [f for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sq.json")), key=os.path.getmtime) if "k_hscan" in json.load(open(f)).get("kernels", {})
+               and not json.load(open(f)).get("bsx_multi")]
+        sha = lib_sha16()
+        same = [f for f in sqs if json.load(open(f)).get("lib_sha16") == sha]
+        sq = (same or sqs)[-1]
         k = json.load(open(sq))["kernels"]["k_hscan"]["derived"]
         vif = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_valu_issue.json")))[-1]
         vi = json.load(open(vif))
-        # (the kernel's own mix: since round 3 the word with every operand in a VGPR and the shift as an add)
+        # (the ceiling of wave64 vector instructions per second: the slow class — shifts, popcounts — of the kernel's own mix)
         mix = ([m for m in vi["mixes"] if m["mix"].startswith("k_hscan head word, VGPR")] or [m for m in vi["mixes"] if m["mix"].startswith("k_hscan head word")])[0]["by_waves_per_simd"]
         ceil = max(v["chip_G_wave_instr_per_s"] for v in mix.values()) * 1e9
-        fr = {"valu_issue": k["valu_instr_per_s"] / ceil, "texture_addresser_busy": k.get("ta_busy_frac"), "l2_hit": k.get("l2_hit_frac"),
-              "waiting_on_instruction_issue": k.get("wait_inst_frac")}
-        top = max((v, n) for n, v in fr.items() if v is not None and n in ("valu_issue", "texture_addresser_busy"))
-        return {"bound": f"{top[1]} ({top[0]:.2f}), co-limited with the other of VALU issue / gather rate; not HBM (L2 hit {fr['l2_hit']:.2f})",
-                "bound_evidence": {"fractions": fr, "valu_ceiling_G_wave_instr_per_s": ceil / 1e9, "sources": [os.path.basename(sq), os.path.basename(vif), "r02k_hscan_marginal_costs.json"]}}
+        fr = {"valu_issue": k["valu_instr_per_s"] / ceil, "texture_addresser_busy": k.get("ta_busy_frac"), "lds_active": k.get("lds_active_frac"), "l2_hit": k.get("l2_hit_frac"),
+              "l1_miss_per_access": k.get("l1_miss_per_access"), "waiting_on_instruction_issue": k.get("wait_inst_frac"), "waiting_for_data": k.get("wait_any_frac")}
+        top = max((v, n) for n, v in fr.items() if v is not None and n in ("valu_issue", "texture_addresser_busy", "lds_active"))
+        names = {"valu_issue": "VALU issue", "texture_addresser_busy": "texture path (64-lane gathers: the addresser's busy time)", "lds_active": "LDS"}
+        return {"bound": f"{names[top[1]]} at {top[0]:.2f}; the others: " + ", ".join(f"{names[n]} {fr[n]:.2f}" for n in names if n != top[1] and fr[n] is not None) + f"; not HBM (L2 hit {fr['l2_hit']:.2f})",
+                "binding_unit": top[1], "binding_unit_utilisation": top[0],
+                "bound_evidence": {"fractions": fr, "valu_ceiling_G_wave_instr_per_s": ceil / 1e9, "same_build": bool(same),
+                                   "sources": [os.path.basename(sq), os.path.basename(vif), "r04b_gather_cost.json"]}}
     except Exception:
-        return {"bound": None, "bound_evidence": "no counter summary under profiles/"}
+        return {"bound": None, "binding_unit": None, "binding_unit_utilisation": None, "bound_evidence": "no counter summary under profiles/"}
 
 
 def sensitivity(B, Align, kw, lens, read_len, B_, nfl, kind, headline):

@@ -37,6 +37,8 @@
 #include "bsx_reads.h"
 #include "bsx_bam_out.h"
 #include "bsx_textout.h"
+#include "bsx_lanes.h"
+#include <sys/wait.h>
 
 using namespace std;
 using bsx_reads::Reader; using bsx_reads::ReadSet; using bsx_reads::ReadOpts; using bsx_reads::load_reads; using bsx_reads::Buf; using bsx_reads::RawAlloc;
@@ -49,7 +51,26 @@ struct Opts {
     int out_sam = 0, out_ref = 0, out_unmap = 0, num_procs = 0;
     unsigned read_start = 1, read_end = ~0u;
     vector<int> devices;            // -G: ordinals, or every visible device for "all" (extension; default {0})
+    bool devices_all = false;       // -G all: resolved when the devices are first needed (never in a process that is going to fork lanes)
     unsigned batch = 1050000;       // units per batch: a multiple of the reference's BatchNum 50000 (see the parse stage)
+    // --lanes[=N]: cut the input into N ranges of reads (default: one per -G device) and map every range in a process of its own —
+    // the reference's -B / -E shards (README.txt:83-86) on one node; --lane-files: leave one output file per lane (<out>.<lane>)
+    int lanes = 0;                  // 0 off, -1 one per device, N
+    bool lane_files = false;
+};
+
+// what a lane process knows about its place in the run (index < 0: the ordinary single pipeline)
+struct LaneInfo {
+    int index = -1, n = 1, stats_fd = -1;
+    size_t off_a = ~(size_t)0, off_b = ~(size_t)0;
+    unsigned cpus = 0;                 // this lane's share of the CPUs the run may use
+    vector<int> lane_devices;          // GPU of every lane of the run (a lane takes the CPU range of its NUMA node that follows the earlier lanes on that node)
+    string final_out, final_unpair;    // the names the user asked for (the lane writes <name>.<index>)
+};
+struct LaneStats {
+    unsigned long long total, n_aligned, n_pairs, n_a, n_b;
+    double load_s, index_s, mapping_s, cpu_user, cpu_sys, stage_cpu[4], busy[4], gpu_part[3];
+    int workers;
 };
 
 const char chain_flag[2] = {'+', '-'};
@@ -98,6 +119,9 @@ void usage()
          << "       -x  <int>   maximal insert size allowed, default=500\n"
          << "       -2  <str>   output file of unpaired alignment hits\n"
          << "       -G  <str>   GPU ordinal(s): N, a list N,M,... or 'all'; batches are dealt to the GPUs in turn, default 0 (extension)\n"
+         << "       --lanes[=N] cut the reads into N ranges (default: one per -G device), one process, GPU and output stream per range,\n"
+         << "                   like -B / -E shards on one node; the output is joined in input order (extension)\n"
+         << "       --lane-files  with --lanes: leave one output file per range, <out>.<lane> (extension)\n"
          << "       -h          help\n\n";
     exit(1);
 }
@@ -109,6 +133,8 @@ int parse_options(int argc, char **argv, Opts &o)
     bool rrbs = false;
     for (int i = 1; i < argc; i++) {
         if (argv[i][0] != '-') return i;
+        if (!strncmp(argv[i], "--lanes", 7) && (argv[i][7] == 0 || argv[i][7] == '=')) { o.lanes = argv[i][7] ? max(1, atoi(argv[i] + 8)) : -1; continue; }
+        if (!strcmp(argv[i], "--lane-files")) { o.lane_files = true; if (!o.lanes) o.lanes = -1; continue; }
         const char c = argv[i][1];
         const char *val = nullptr;
         const bool flag_only = (c == 'R' || c == 'u' || c == 'h');
@@ -158,8 +184,9 @@ int parse_options(int argc, char **argv, Opts &o)
         case 'S': p.randseed = atoi(val); break;
         case 'G':
             o.devices.clear();
-            if (!strcmp(val, "all")) { const int n = bsx_device_count(); for (int d = 0; d < n; d++) o.devices.push_back(d); }
-            else for (const char *q = val; *q;) { o.devices.push_back(atoi(q)); while (*q && *q != ',') q++; if (*q == ',') q++; }
+            o.devices_all = !strcmp(val, "all");
+            if (o.devices_all) break;
+            for (const char *q = val; *q;) { o.devices.push_back(atoi(q)); while (*q && *q != ',') q++; if (*q == ',') q++; }
             break;
         case 'h': usage(); break;
         default: return i;
@@ -515,6 +542,170 @@ struct Ring {
 
 double now_s() { return chrono::duration<double>(chrono::steady_clock::now().time_since_epoch()).count(); }
 
+// ---- lanes ----------------------------------------------------------------------------------------------------------------
+// `--lanes`: the run is cut into ranges of reads and every range is mapped by a process of its own with its own GPU, reader,
+// format workers and output file — the reference's `-B / -E` shards (README.txt:83-86) started on one node, so that the host side
+// scales with the GPUs instead of funnelling every read through one parser and one writer.  The parent never touches a GPU: it
+// counts the lines of the read files (bsx_lanes.h), forks, waits, adds up the lanes' counters (the reference's mutex_fout sum,
+// main.cpp:70-72), joins the lane files in input order (parallel copies at known offsets) and prints the reference's summary lines.
+int count_devices_in_a_child()   // -G all before forking lanes: the count comes from a throw-away process, this one stays free of the GPU runtime
+{
+    int fd[2];
+    if (pipe(fd) != 0) return 0;
+    const pid_t pid = fork();
+    if (pid == 0) { ::close(fd[0]); const int n = bsx_device_count(); ssize_t r = write(fd[1], &n, sizeof n); (void)r; _exit(0); }
+    ::close(fd[1]);
+    int n = 0;
+    if (pid < 0 || read(fd[0], &n, sizeof n) != (ssize_t)sizeof n) n = 0;
+    ::close(fd[0]);
+    if (pid > 0) waitpid(pid, nullptr, 0);
+    return n;
+}
+
+// join `parts` (lane files, in lane order) into `dst`: part 0 becomes the file, the others are copied behind it by parallel threads
+bool join_files(const string &dst, const vector<string> &parts)
+{
+    vector<off_t> size(parts.size(), 0), at(parts.size(), 0);
+    off_t total = 0;
+    for (size_t i = 0; i < parts.size(); i++) { struct stat st; if (stat(parts[i].c_str(), &st) != 0) return false; size[i] = st.st_size; at[i] = total; total += st.st_size; }
+    if (rename(parts[0].c_str(), dst.c_str()) != 0) return false;
+    const int out = ::open(dst.c_str(), O_WRONLY);
+    if (out < 0 || ftruncate(out, total) != 0) return false;
+    std::atomic<bool> ok(true);
+    vector<thread> th;
+    for (size_t i = 1; i < parts.size(); i++)
+        th.emplace_back([&, i] {
+            const int in = ::open(parts[i].c_str(), O_RDONLY);
+            if (in < 0) { ok = false; return; }
+            off_t src = 0, dst_off = at[i], left = size[i];
+            while (left > 0) {
+                ssize_t w = copy_file_range(in, &src, out, &dst_off, (size_t)left, 0);
+                if (w <= 0) {   // (a file system without it: plain copy)
+                    static thread_local vector<char> buf(1 << 22);
+                    const ssize_t r = pread(in, buf.data(), (size_t)min<off_t>(left, (off_t)buf.size()), src);
+                    if (r <= 0 || pwrite(out, buf.data(), (size_t)r, dst_off) != r) { ok = false; break; }
+                    src += r; dst_off += r; w = r;
+                }
+                left -= w;
+            }
+            ::close(in);
+            unlink(parts[i].c_str());
+        });
+    for (thread &t : th) t.join();
+    ::close(out);
+    return ok;
+}
+
+// Returns -1 when the run is not cut (no --lanes, or the input cannot be cut: the caller goes on as the single pipeline), the lane
+// index in a lane process (LaneInfo filled in, Opts narrowed to the lane's range, device and output file), and does not return in
+// the parent, which exits with the run's status once every lane is done.
+int fork_lanes(Opts &o, LaneInfo &lane, time_t t_begin)
+{
+    if (!o.lanes) return -1;
+    const bool pe = !o.a_file.empty() && !o.b_file.empty();
+    const char *why = nullptr;
+    if (o.out_sam == 2) why = "BAM output is sorted over the whole run";
+    else if (getenv("BSX_P1_EXACT") && atoi(getenv("BSX_P1_EXACT")) != 0) why = "BSX_P1_EXACT chains the planner state through the whole input";
+    if (o.devices_all) { o.devices.clear(); const int n = count_devices_in_a_child(); for (int d = 0; d < n; d++) o.devices.push_back(d); o.devices_all = false; }
+    if (o.devices.empty()) o.devices.push_back(0);
+    const int want = o.lanes > 0 ? o.lanes : (int)o.devices.size();
+    bsx_lanes::LineIndex ia, ib;
+    bsx_lanes::Plan plan;
+    if (!why) {
+        const unsigned nthreads = bsx_usable_cpus();
+        thread tb;
+        if (pe) tb = thread([&] { bsx_lanes::index_lines(o.b_file, (int)max(1u, nthreads / 2), ib); });
+        bsx_lanes::index_lines(o.a_file, (int)max(1u, pe ? nthreads / 2 : nthreads), ia);
+        if (pe) tb.join();
+        plan = bsx_lanes::plan_lanes(ia, pe ? &ib : nullptr, want, o.read_start, o.read_end);
+        if (plan.lanes.empty()) why = plan.why_not.c_str();
+    }
+    if (why) { cerr << "bsx: --lanes: the run is not cut (" << why << "); one pipeline\n"; o.lanes = 0; return -1; }
+    if (plan.mates_differ)
+        cerr << "warning: mate files differ in length (" << plan.n_a << " vs " << plan.n_b << " reads); like the reference, mapping stops after pair "
+             << (o.read_start - 1) + plan.total << endl;
+    const int L = (int)plan.lanes.size();
+    const unsigned ncpu = bsx_usable_cpus(), share = max(2u, ncpu / (unsigned)L);
+    vector<pid_t> pids(L, -1);
+    vector<int> fds(L, -1);
+    const string out0 = o.out_file, unpair0 = o.out_unpair;
+    const vector<int> devs = o.devices;
+    const unsigned end0 = o.read_end;
+    cout.flush(); cerr.flush();
+    for (int l = 0; l < L; l++) {
+        int fd[2];
+        if (pipe(fd) != 0) { cerr << "bsx: pipe failed\n"; exit(1); }
+        const pid_t pid = fork();
+        if (pid < 0) { cerr << "bsx: fork failed\n"; exit(1); }
+        if (pid == 0) {
+            for (int k = 0; k < l; k++) ::close(fds[k]);
+            ::close(fd[0]);
+            const bsx_lanes::Lane &R = plan.lanes[l];
+            lane.index = l; lane.n = L; lane.stats_fd = fd[1]; lane.off_a = R.off_a; lane.off_b = R.off_b;
+            lane.cpus = share; lane.final_out = out0; lane.final_unpair = unpair0;
+            for (int k = 0; k < L; k++) lane.lane_devices.push_back(devs[(size_t)k % devs.size()]);
+            o.read_start = (unsigned)(R.first + 1);
+            // the last lane keeps the user's -E when nothing was cut off: a ragged tail of the file is then parsed exactly as one pipeline would
+            o.read_end = (l == L - 1 && !plan.mates_differ) ? end0 : (unsigned)(R.first + R.count);
+            o.devices.assign(1, devs[(size_t)l % devs.size()]);
+            o.out_file = out0 + "." + to_string(l);
+            if (!unpair0.empty()) o.out_unpair = unpair0 + "." + to_string(l);
+            if (l > 0) { if (!freopen("/dev/null", "w", stdout)) {} }   // lane 0 keeps the reference's progress lines
+            return l;
+        }
+        ::close(fd[1]);
+        pids[l] = pid; fds[l] = fd[0];
+    }
+    // parent: collect
+    LaneStats tot; memset(&tot, 0, sizeof tot);
+    bool ok = true;
+    double map_max = 0, load_max = 0, index_max = 0;
+    for (int l = 0; l < L; l++) {
+        LaneStats st; memset(&st, 0, sizeof st);
+        size_t got = 0;
+        while (got < sizeof st) { const ssize_t r = read(fds[l], (char *)&st + got, sizeof st - got); if (r <= 0) break; got += (size_t)r; }
+        ::close(fds[l]);
+        int status = 0;
+        waitpid(pids[l], &status, 0);
+        if (got != sizeof st || !WIFEXITED(status) || WEXITSTATUS(status) != 0) { cerr << "bsx: lane " << l << " failed\n"; ok = false; continue; }
+        tot.total += st.total; tot.n_aligned += st.n_aligned; tot.n_pairs += st.n_pairs; tot.n_a += st.n_a; tot.n_b += st.n_b;
+        tot.cpu_user += st.cpu_user; tot.cpu_sys += st.cpu_sys; tot.workers += st.workers;
+        for (int k = 0; k < 4; k++) { tot.stage_cpu[k] += st.stage_cpu[k]; tot.busy[k] = max(tot.busy[k], st.busy[k]); }
+        for (int k = 0; k < 3; k++) tot.gpu_part[k] += st.gpu_part[k];
+        map_max = max(map_max, st.mapping_s); load_max = max(load_max, st.load_s); index_max = max(index_max, st.index_s);
+    }
+    if (!ok) exit(1);
+    const double t_join0 = now_s();
+    if (!o.lane_files) {
+        vector<string> parts, parts2;
+        for (int l = 0; l < L; l++) { parts.push_back(out0 + "." + to_string(l)); if (!unpair0.empty() && !o.out_sam && pe) parts2.push_back(unpair0 + "." + to_string(l)); }
+        if (!join_files(out0, parts) || (!parts2.empty() && !join_files(unpair0, parts2))) { cerr << "write error on the output file (joining the lanes)\n"; exit(1); }
+    }
+    const double join_s = now_s() - t_join0;
+    char pct[64];
+    const double total = (double)tot.total;
+    if (pe) {
+        cout << "Total number of aligned reads: \n";
+        snprintf(pct, sizeof(pct), "%.2g", total ? 100.0 * tot.n_pairs / total : 0.0); cout << "pairs:       " << tot.n_pairs << " (" << pct << "%)\n";
+        snprintf(pct, sizeof(pct), "%.2g", total ? 100.0 * tot.n_a / total : 0.0); cout << "single a:    " << tot.n_a << " (" << pct << "%)\n";
+        snprintf(pct, sizeof(pct), "%.2g", total ? 100.0 * tot.n_b / total : 0.0); cout << "single b:    " << tot.n_b << " (" << pct << "%)\n";
+    } else {
+        snprintf(pct, sizeof(pct), "%.2g", total ? 100.0 * tot.n_aligned / total : 0.0);
+        cout << "Total number of aligned reads: " << tot.n_aligned << " (" << pct << "%)\n";
+    }
+    cout << "Done.\n";
+    time_t t_end = time(NULL);
+    cout << "Finished at " << ctime(&t_end);
+    cout << "Total time consumed:  " << t_end - t_begin << " secs\n";
+    if (getenv("BSX_TIMING"))
+        fprintf(stderr, "{\"lanes\": %d, \"load_reference_s\": %.3f, \"index_build_s\": %.3f, \"mapping_s\": %.3f, \"join_s\": %.3f, \"units\": %llu, \"reads\": %llu, \"workers\": %d, \"usable_cpus\": %u, "
+                        "\"mapping_cpu_s\": {\"user\": %.2f, \"sys\": %.2f, \"parse_threads\": %.2f, \"gpu_driver_threads\": %.2f, \"format_workers\": %.2f, \"write_threads\": %.2f}, "
+                        "\"stage_busy_s\": {\"parse\": %.3f, \"gpu\": %.3f, \"format\": %.3f, \"write\": %.3f, \"gpu_upload\": %.3f, \"gpu_align\": %.3f, \"gpu_readback\": %.3f}}\n",
+                L, load_max, index_max, map_max + join_s, join_s, tot.total, pe ? 2 * tot.total : tot.total, tot.workers, ncpu, tot.cpu_user, tot.cpu_sys,
+                tot.stage_cpu[0], tot.stage_cpu[1], tot.stage_cpu[2], tot.stage_cpu[3], tot.busy[0], tot.busy[1], tot.busy[2], tot.busy[3], tot.gpu_part[0], tot.gpu_part[1], tot.gpu_part[2]);
+    exit(0);
+}
+
 }  // namespace
 
 int main(int argc, char **argv)
@@ -537,6 +728,10 @@ int main(int argc, char **argv)
     if (rc) die(rc, "bad option value");
     const bsx_params &p = o.p;
     { ifstream t(o.ref_file.c_str()); if (!t) { cerr << "fatal error: failed to open ref file\n"; exit(1); } }
+    // --lanes: from here on a lane process sees its own range of reads, its GPU and its output file; the parent does not come back
+    LaneInfo lane;
+    fork_lanes(o, lane, t_begin);
+    if (o.devices_all) { o.devices.clear(); const int n = bsx_device_count(); for (int d = 0; d < n; d++) o.devices.push_back(d); }
     // The ring's upload / download buffers are page-locked (the transfers are then plain DMA).  Locking gigabytes of pages
     // takes seconds, so it happens on a side thread while the reference is loaded and indexed.
     static const RawAlloc pinned = {bsx_pinned_alloc, bsx_pinned_free};
@@ -554,7 +749,7 @@ int main(int argc, char **argv)
     const bool pe = !o.a_file.empty() && !o.b_file.empty();
     // format workers: the CPUs this process may use (affinity mask and cgroup quota, not the hardware thread count) less the
     // parse, GPU-driver and write threads; oversubscribing a quota throttles every thread, the ones feeding the GPU included
-    const unsigned ncpu = bsx_usable_cpus();
+    const unsigned ncpu = lane.index >= 0 ? lane.cpus : bsx_usable_cpus();   // (a lane: its share of the run's CPUs)
     // under a quota: keep the whole process on as many CPUs of the GPU's NUMA node as the quota is worth (BSX_PIN=0: leave the mask alone)
     // (only when every GPU of the run hangs on the same node: pinned to one socket, the threads that drive and feed GPUs of the other
     //  socket would run cross-node)
@@ -562,7 +757,9 @@ int main(int argc, char **argv)
         const int node0 = bsx_device_numa_node(o.devices[0]);
         bool one_node = true;
         for (int d = 1; d < ND; d++) one_node = one_node && bsx_device_numa_node(o.devices[d]) == node0;
-        const unsigned pinned = one_node ? bsx_pin_to_node(node0, ncpu) : 0u;
+        unsigned skip = 0;   // a lane: behind the CPU ranges of the earlier lanes whose GPUs hang on the same node
+        for (int k = 0; k < lane.index; k++) if (bsx_device_numa_node(lane.lane_devices[(size_t)k]) == node0) skip += ncpu;
+        const unsigned pinned = one_node ? bsx_pin_to_node(node0, ncpu, skip) : 0u;
         if (getenv("BSX_TIMING")) {
             if (pinned) cerr << "bsx: pinned to " << pinned << " CPUs of NUMA node " << node0 << endl;
             else if (!one_node) cerr << "bsx: GPUs on several NUMA nodes, CPU mask left alone" << endl;
@@ -689,7 +886,7 @@ int main(int argc, char **argv)
         for (uint32_t c = 0; c < n_chr; c++) { h.put("@SQ\tSN:"); h.put(rv.names[c]); h.put("\tLN:"); h.put_u(rv.chr_size[c]); h.put('\n'); }
         h.put("@PG\tID:BSMAP_"); h.put(version); h.put('\n');
         if (bam_out) bam.open(o.out_file, string(h.s.data(), h.s.size()), rv.names, rv.chr_size);
-        else {
+        else if (lane.index <= 0 || o.lane_files) {   // (lanes behind the first: the joined file has one header)
             write_all(fout, h.s.data(), h.s.size(), 0);
             off_out = (off_t)h.s.size();
         }
@@ -707,8 +904,9 @@ int main(int argc, char **argv)
     ReadOpts ro;
     ro.read_start = o.read_start; ro.read_end = o.read_end; ro.max_readlen = p.max_readlen; ro.zero_qual = p.zero_qual;
     Reader ra, rb;
-    ra.open(o.a_file, ro);
-    if (pe) rb.open(o.b_file, ro);
+    { ReadOpts roa = ro, rob = ro; roa.start_offset = lane.off_a; rob.start_offset = lane.off_b;   // a lane starts at the byte its first read begins at
+      ra.open(o.a_file, roa);
+      if (pe) rb.open(o.b_file, rob); }
     {
         string dl;
         for (int d = 0; d < ND; d++) dl += (d ? "," : "") + to_string(o.devices[d]);
@@ -932,6 +1130,19 @@ int main(int argc, char **argv)
     const double ru_user = (ru1.ru_utime.tv_sec - ru0.ru_utime.tv_sec) + 1e-6 * (ru1.ru_utime.tv_usec - ru0.ru_utime.tv_usec),
                  ru_sys = (ru1.ru_stime.tv_sec - ru0.ru_stime.tv_sec) + 1e-6 * (ru1.ru_stime.tv_usec - ru0.ru_stime.tv_usec);
     const Formatter &fmt = totals;
+    if (lane.index >= 0) {   // a lane reports to the parent, which prints the run's summary
+        LaneStats st; memset(&st, 0, sizeof st);
+        st.total = total; st.n_aligned = fmt.n_aligned; st.n_pairs = fmt.n_aligned_pairs; st.n_a = fmt.n_aligned_a; st.n_b = fmt.n_aligned_b;
+        st.load_s = t_loaded - t0; st.index_s = t_indexed - t_loaded; st.mapping_s = t_map1 - t_map0; st.cpu_user = ru_user; st.cpu_sys = ru_sys; st.workers = workers;
+        for (int k = 0; k < 4; k++) { st.stage_cpu[k] = cpu_ns[k] * 1e-9; st.busy[k] = busy[k]; }
+        for (int k = 0; k < 3; k++) st.gpu_part[k] = gpu_part[k];
+        for (int g = 0; g < NG; g++) bsx_batch_destroy(batches[g]);
+        for (bsx_ref *r : refs) bsx_ref_destroy(r);
+        const ssize_t w = write(lane.stats_fd, &st, sizeof st);
+        ::close(lane.stats_fd);
+        cout.flush();
+        _exit(w == (ssize_t)sizeof st ? 0 : 1);
+    }
     char pct[64];
     if (pe) {
         cout << "Total number of aligned reads: \n";

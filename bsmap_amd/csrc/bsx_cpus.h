@@ -32,11 +32,12 @@ inline unsigned bsx_usable_cpus()
 // the command line's host side (tools/host_numa.sh): format workers 22.8 -> 8.7 CPU-seconds per 33.5 M reads, 12.5 -> 15.3 M reads/s.
 // bsx_pin_to_node restricts the process to the first `n_cpus` CPUs of NUMA node `node` that it may use (the node the GPU hangs on);
 // threads created afterwards inherit the mask.  Returns the number of CPUs in the new mask, 0 if nothing was changed.
-inline unsigned bsx_pin_to_node(int node, unsigned n_cpus)
+// `skip`: leave out the node's first `skip` usable CPUs (lane k of several on one node takes CPUs [k n, k n + n)).
+inline unsigned bsx_pin_to_node(int node, unsigned n_cpus, unsigned skip = 0)
 {
     cpu_set_t have, want;
     if (node < 0 || sched_getaffinity(0, sizeof have, &have) != 0) return 0;
-    if ((unsigned)CPU_COUNT(&have) <= n_cpus) return 0;   // nothing to gain: the quota does not bite
+    if ((unsigned)CPU_COUNT(&have) <= n_cpus + skip) return 0;   // nothing to gain: the quota does not bite
     char path[96], buf[4096];
     snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
     FILE *f = fopen(path, "r");
@@ -52,7 +53,7 @@ inline unsigned bsx_pin_to_node(int node, unsigned n_cpus)
         if (e == q) break;
         if (*e == '-') { q = e + 1; b = strtol(q, &e, 10); }
         for (long c = a; c <= b && got < n_cpus; c++)
-            if (c >= 0 && c < CPU_SETSIZE && CPU_ISSET((int)c, &have)) { CPU_SET((int)c, &want); got++; }
+            if (c >= 0 && c < CPU_SETSIZE && CPU_ISSET((int)c, &have)) { if (skip) { skip--; continue; } CPU_SET((int)c, &want); got++; }
         q = (*e == ',') ? e + 1 : e;
         if (*e != ',' && *e != '-') break;
     }

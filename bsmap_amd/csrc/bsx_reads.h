@@ -20,7 +20,9 @@ namespace bsx_reads {
 
 using std::cerr; using std::endl; using std::min; using std::string; using std::vector;
 
-struct ReadOpts { unsigned read_start = 1, read_end = ~0u; int max_readlen = 144; int zero_qual = 33; };
+// start_offset: byte offset of read `read_start` in the file, if the caller knows it (bsx_lanes.h: a lane of a run cut into
+// several): the reader starts there instead of skipping (read_start - 1) * 4 lines one by one
+struct ReadOpts { unsigned read_start = 1, read_end = ~0u; int max_readlen = 144; int zero_qual = 33; size_t start_offset = ~(size_t)0; };
 
 // Growable array over a pluggable allocator: the driver passes the library's page-locked allocator (bsx_pinned_alloc) so
 // that the upload is a straight DMA from these buffers; the default is malloc.
@@ -206,10 +208,13 @@ struct Reader {
             return;
         } else { cerr << "fatal error: unrecognizable format of reads file.\n"; exit(1); }
         cur = base; failed = false; eof_hit = false;
-        const unsigned skip = (o.read_start - 1) * (format == 0 ? 4 : 2);
-        for (unsigned i = 0; i < skip; i++) {  // getline(ch, 1000) per skipped line
-            if (eof_hit) break;
-            rest_of_line();
+        if (o.start_offset != ~(size_t)0) cur = base + std::min(o.start_offset, map_len);
+        else {
+            const unsigned skip = (o.read_start - 1) * (format == 0 ? 4 : 2);
+            for (unsigned i = 0; i < skip; i++) {  // getline(ch, 1000) per skipped line
+                if (eof_hit) break;
+                rest_of_line();
+            }
         }
         index = o.read_start - 1;
     }

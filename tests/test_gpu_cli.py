@@ -365,3 +365,71 @@ def test_cli_exact_mode_state_crosses_many_batches(key, env, tmp_path):
         plain = str(tmp_path / "plain.sam")
         _run_cli(meta, os.path.join(G.GOLDEN, "genome_wgbs.fa"), files, plain, case["options"] + ["-p", "2"], {"BSX_BATCH": "50"})
         assert _body(open(plain).read()) != _body(case["out"])
+
+
+def _names_by_kind():
+    se = [n for n in sorted(CLI) if G.load(n)[0]["kind"] == "se" and CLI[n]["sam_Ru"]["out"]]
+    pe = [n for n in sorted(CLI) if G.load(n)[0]["kind"] == "pe" and CLI[n]["sam_Ru"]["out"]]
+    return se[:1] + pe[:2]
+
+
+@pytest.mark.parametrize("name", _names_by_kind())
+def test_cli_lanes_write_the_bytes_of_one_pipeline(name, tmp_path):
+    """`--lanes`: the reads are cut into ranges (the reference's -B / -E shards, README.txt:83-86), each mapped by a process of its own
+    — reader positioned by byte offset, own GPU replica, formatters, output file — and the lane files are joined in input order:
+    the same bytes and the same summary lines as the single pipeline, for 2 / 3 lanes, with -G lists, with -B / -E, for SAM and for
+    BSP with its -2 file; `--lane-files` leaves the shards, each equal to what `-B / -E` of one pipeline writes for that range."""
+    meta, arr, fasta = G.load(name)
+    pe = meta["kind"] == "pe"
+    run = CLI[name]["sam_Ru"]
+    opts = [o for i, o in enumerate(run["options"]) if not (o == "-D" or (i and run["options"][i - 1] == "-D"))]
+    files = _write_fastq(meta, tmp_path, "in")
+    n = len(meta["reads"])
+    base = str(tmp_path / "base.sam")
+    r0 = _run_cli(meta, fasta, files, base, opts, {})
+    want = open(base, "rb").read()
+    summary = [l for l in r0.stdout.split("\n") if "aligned" in l or l.startswith(("pairs", "single"))]
+    assert len(want) > 1000 and summary
+    for tag, extra in (("l3", ["--lanes=3"]), ("l2g", ["-G", "0,0", "--lanes"]), ("lall", ["-G", "all", "--lanes=2", "-p", "2"])):
+        out = str(tmp_path / f"{tag}.sam")
+        r = _run_cli(meta, fasta, files, out, opts + extra, {"BSX_BATCH": "29"})
+        assert open(out, "rb").read() == want, tag
+        assert [l for l in r.stdout.split("\n") if "aligned" in l or l.startswith(("pairs", "single"))] == summary, tag
+        assert not os.path.exists(out + ".1")
+    # a sub-range of the reads
+    lo, hi = n // 5 + 1, n - n // 7
+    sub, sub_l = str(tmp_path / "sub.sam"), str(tmp_path / "sub_l.sam")
+    _run_cli(meta, fasta, files, sub, opts + ["-B", str(lo), "-E", str(hi)], {})
+    _run_cli(meta, fasta, files, sub_l, opts + ["-B", str(lo), "-E", str(hi), "--lanes=3"], {})
+    assert open(sub_l, "rb").read() == open(sub, "rb").read() and len(_body(open(sub).read())) > 10
+    # the shards themselves: lane k of 3 = reads [n k / 3, n (k + 1) / 3)
+    shard = str(tmp_path / "sh.sam")
+    _run_cli(meta, fasta, files, shard, opts + ["--lanes=3", "--lane-files"], {})
+    assert not os.path.exists(shard)
+    pieces = [open(f"{shard}.{k}", "rb").read() for k in range(3)]
+    for k in range(3):
+        one = str(tmp_path / f"one{k}.sam")
+        _run_cli(meta, fasta, files, one, opts + ["-B", str(n * k // 3 + 1), "-E", str(n * (k + 1) // 3)], {})
+        assert pieces[k] == open(one, "rb").read(), k
+    if pe:   # BSP: paired hits in -o, the rest in -2; both joined
+        b0, b02 = str(tmp_path / "b0.bsp"), str(tmp_path / "b0u.bsp")
+        b1, b12 = str(tmp_path / "b1.bsp"), str(tmp_path / "b1u.bsp")
+        _run_cli(meta, fasta, files, b0, opts + ["-2", b02], {})
+        _run_cli(meta, fasta, files, b1, opts + ["-2", b12, "--lanes=3"], {})
+        assert open(b1, "rb").read() == open(b0, "rb").read() and open(b12, "rb").read() == open(b02, "rb").read()
+
+
+def test_cli_lanes_fall_back_to_one_pipeline_when_the_input_cannot_be_cut(tmp_path):
+    """FASTQ files whose records are not four lines each (blank lines: legal for the reference's token reader) are not cut — the cut is
+    by lines, as the reference's own -B skip — and neither is a run with BAM output; the single pipeline maps them and says why"""
+    name = _names_by_kind()[0]
+    meta, arr, fasta = G.load(name)
+    f1 = str(tmp_path / "gaps.fq")
+    with open(f1, "w") as f:
+        for i, r in enumerate(meta["reads"]):
+            f.write(f"@{r['name']}\n{r['seq']}\n+\n{r['qual']}\n" + ("\n" if i % 5 == 0 else ""))
+    plain = _write_fastq(meta, tmp_path, "plain")
+    a, b = str(tmp_path / "a.sam"), str(tmp_path / "b.sam")
+    _run_cli(meta, fasta, plain, a, [], {})
+    r = _run_cli(meta, fasta, [f1], b, ["--lanes=4"], {})
+    assert "one pipeline" in r.stderr and open(a, "rb").read() == open(b, "rb").read()

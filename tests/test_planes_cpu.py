@@ -14,6 +14,6 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
 def test_plane_rule_equals_per_nt_definition(tmp_path):
     exe = str(tmp_path / "planes_check")
-    subprocess.check_call([HIPCC, "-O1", "-o", exe, os.path.join(ROOT, "tests", "native", "planes_check.cpp")], stderr=subprocess.DEVNULL)
+    subprocess.check_call([HIPCC, "-O1", "-o", exe, os.path.join(ROOT, "tests", "harness", "planes_check.cpp")], stderr=subprocess.DEVNULL)
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.startswith("ok"), out.stdout + out.stderr

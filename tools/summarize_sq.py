@@ -62,6 +62,13 @@ def read_pass(d):
 def main():
     tag, dirs = sys.argv[1], sys.argv[2:]
     out = {"tag": tag, "passes": [], "kernels": {}}
+    try:   # which build the counters belong to (bench.py only quotes a summary of the library it runs)
+        sys.path.insert(0, ROOT)
+        import bench
+        out["lib_sha16"] = bench.lib_sha16()
+        out["bsx_multi"] = os.environ.get("BSX_MULTI", "")
+    except Exception:
+        pass
     merged = collections.defaultdict(dict)
     for d in dirs:
         acc, disp = read_pass(d)
