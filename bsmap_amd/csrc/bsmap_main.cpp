@@ -62,6 +62,7 @@ struct Opts {
 // what a lane process knows about its place in the run (index < 0: the ordinary single pipeline)
 struct LaneInfo {
     int index = -1, n = 1, stats_fd = -1;
+    int ready_fd = -1, go_fd = -1;     // the lanes start mapping together: a lane says when its reference is loaded and indexed, the parent releases all of them
     size_t off_a = ~(size_t)0, off_b = ~(size_t)0;
     unsigned cpus = 0;                 // this lane's share of the CPUs the run may use
     vector<int> lane_devices;          // GPU of every lane of the run (a lane takes the CPU range of its NUMA node that follows the earlier lanes on that node)
@@ -70,6 +71,7 @@ struct LaneInfo {
 struct LaneStats {
     unsigned long long total, n_aligned, n_pairs, n_a, n_b;
     double load_s, index_s, mapping_s, cpu_user, cpu_sys, stage_cpu[4], busy[4], gpu_part[3];
+    double t_map0, t_map1;   // steady-clock times of the lane's mapping phase (one clock for every process of the machine)
     int workers;
 };
 
@@ -562,33 +564,34 @@ int count_devices_in_a_child()   // -G all before forking lanes: the count comes
     return n;
 }
 
-// join `parts` (lane files, in lane order) into `dst`: part 0 becomes the file, the others are copied behind it by parallel threads
-bool join_files(const string &dst, const vector<string> &parts)
+// join `parts` (lane files, in lane order) into `dst`: part 0 becomes the file, the others are copied behind it through a shared mapping
+// by several threads (bsx_textout.h; copy_file_range moved 3-4 GB/s on tmpfs whatever the thread count)
+bool join_files(const string &dst, const vector<string> &parts, int nthreads)
 {
     vector<off_t> size(parts.size(), 0), at(parts.size(), 0);
     off_t total = 0;
     for (size_t i = 0; i < parts.size(); i++) { struct stat st; if (stat(parts[i].c_str(), &st) != 0) return false; size[i] = st.st_size; at[i] = total; total += st.st_size; }
     if (rename(parts[0].c_str(), dst.c_str()) != 0) return false;
-    const int out = ::open(dst.c_str(), O_WRONLY);
-    if (out < 0 || ftruncate(out, total) != 0) return false;
+    const int out = ::open(dst.c_str(), O_RDWR);
+    if (out < 0) return false;
+    if (ftruncate(out, total) != 0) { ::close(out); return false; }
     std::atomic<bool> ok(true);
-    vector<thread> th;
+    vector<thread> th;   // every part by threads of its own (disjoint ranges of the file), the lane files deleted as they are done
+    const int per = max(1, nthreads / (int)max<size_t>(1, parts.size() - 1));
     for (size_t i = 1; i < parts.size(); i++)
         th.emplace_back([&, i] {
-            const int in = ::open(parts[i].c_str(), O_RDONLY);
-            if (in < 0) { ok = false; return; }
-            off_t src = 0, dst_off = at[i], left = size[i];
-            while (left > 0) {
-                ssize_t w = copy_file_range(in, &src, out, &dst_off, (size_t)left, 0);
-                if (w <= 0) {   // (a file system without it: plain copy)
-                    static thread_local vector<char> buf(1 << 22);
-                    const ssize_t r = pread(in, buf.data(), (size_t)min<off_t>(left, (off_t)buf.size()), src);
-                    if (r <= 0 || pwrite(out, buf.data(), (size_t)r, dst_off) != r) { ok = false; break; }
-                    src += r; dst_off += r; w = r;
+            if (size[i]) {
+                const int in = ::open(parts[i].c_str(), O_RDONLY);
+                void *m = in >= 0 ? mmap(nullptr, (size_t)size[i], PROT_READ, MAP_PRIVATE, in, 0) : MAP_FAILED;
+                if (in >= 0) ::close(in);
+                if (m == MAP_FAILED) { ok = false; return; }
+                vector<pair<const char *, size_t>> piece(1, make_pair((const char *)m, (size_t)size[i]));
+                if (!bsx_textout::map_write(out, piece, at[i], per)) {   // (a file that cannot be mapped: plain writes)
+                    size_t done = 0;
+                    while (done < (size_t)size[i]) { const ssize_t w = pwrite(out, (const char *)m + done, (size_t)size[i] - done, at[i] + (off_t)done); if (w <= 0) { ok = false; break; } done += (size_t)w; }
                 }
-                left -= w;
+                munmap(m, (size_t)size[i]);
             }
-            ::close(in);
             unlink(parts[i].c_str());
         });
     for (thread &t : th) t.join();
@@ -628,6 +631,8 @@ int fork_lanes(Opts &o, LaneInfo &lane, time_t t_begin)
     const unsigned ncpu = bsx_usable_cpus(), share = max(2u, ncpu / (unsigned)L);
     vector<pid_t> pids(L, -1);
     vector<int> fds(L, -1);
+    int ready[2], go[2];
+    if (pipe(ready) != 0 || pipe(go) != 0) { cerr << "bsx: pipe failed\n"; exit(1); }
     const string out0 = o.out_file, unpair0 = o.out_unpair;
     const vector<int> devs = o.devices;
     const unsigned end0 = o.read_end;
@@ -639,7 +644,8 @@ int fork_lanes(Opts &o, LaneInfo &lane, time_t t_begin)
         if (pid < 0) { cerr << "bsx: fork failed\n"; exit(1); }
         if (pid == 0) {
             for (int k = 0; k < l; k++) ::close(fds[k]);
-            ::close(fd[0]);
+            ::close(fd[0]); ::close(ready[0]); ::close(go[1]);
+            lane.ready_fd = ready[1]; lane.go_fd = go[0];
             const bsx_lanes::Lane &R = plan.lanes[l];
             lane.index = l; lane.n = L; lane.stats_fd = fd[1]; lane.off_a = R.off_a; lane.off_b = R.off_b;
             lane.cpus = share; lane.final_out = out0; lane.final_unpair = unpair0;
@@ -656,10 +662,14 @@ int fork_lanes(Opts &o, LaneInfo &lane, time_t t_begin)
         ::close(fd[1]);
         pids[l] = pid; fds[l] = fd[0];
     }
-    // parent: collect
+    // parent: once every lane has its reference and index (or has died: its end of the pipe closes), all start mapping
+    ::close(ready[1]); ::close(go[0]);
+    for (int got = 0; got < L;) { char c[64]; const ssize_t r = read(ready[0], c, sizeof c); if (r <= 0) break; got += (int)r; }
+    { const string all((size_t)L, 'g'); const ssize_t w = write(go[1], all.data(), all.size()); (void)w; }
+    ::close(ready[0]); ::close(go[1]);
     LaneStats tot; memset(&tot, 0, sizeof tot);
     bool ok = true;
-    double map_max = 0, load_max = 0, index_max = 0;
+    double map_max = 0, load_max = 0, index_max = 0, first_start = 1e300, last_end = 0;
     for (int l = 0; l < L; l++) {
         LaneStats st; memset(&st, 0, sizeof st);
         size_t got = 0;
@@ -673,13 +683,14 @@ int fork_lanes(Opts &o, LaneInfo &lane, time_t t_begin)
         for (int k = 0; k < 4; k++) { tot.stage_cpu[k] += st.stage_cpu[k]; tot.busy[k] = max(tot.busy[k], st.busy[k]); }
         for (int k = 0; k < 3; k++) tot.gpu_part[k] += st.gpu_part[k];
         map_max = max(map_max, st.mapping_s); load_max = max(load_max, st.load_s); index_max = max(index_max, st.index_s);
+        first_start = min(first_start, st.t_map0); last_end = max(last_end, st.t_map1);
     }
     if (!ok) exit(1);
     const double t_join0 = now_s();
     if (!o.lane_files) {
         vector<string> parts, parts2;
         for (int l = 0; l < L; l++) { parts.push_back(out0 + "." + to_string(l)); if (!unpair0.empty() && !o.out_sam && pe) parts2.push_back(unpair0 + "." + to_string(l)); }
-        if (!join_files(out0, parts) || (!parts2.empty() && !join_files(unpair0, parts2))) { cerr << "write error on the output file (joining the lanes)\n"; exit(1); }
+        if (!join_files(out0, parts, (int)ncpu) || (!parts2.empty() && !join_files(unpair0, parts2, (int)ncpu))) { cerr << "write error on the output file (joining the lanes)\n"; exit(1); }
     }
     const double join_s = now_s() - t_join0;
     char pct[64];
@@ -701,7 +712,7 @@ int fork_lanes(Opts &o, LaneInfo &lane, time_t t_begin)
         fprintf(stderr, "{\"lanes\": %d, \"load_reference_s\": %.3f, \"index_build_s\": %.3f, \"mapping_s\": %.3f, \"join_s\": %.3f, \"units\": %llu, \"reads\": %llu, \"workers\": %d, \"usable_cpus\": %u, "
                         "\"mapping_cpu_s\": {\"user\": %.2f, \"sys\": %.2f, \"parse_threads\": %.2f, \"gpu_driver_threads\": %.2f, \"format_workers\": %.2f, \"write_threads\": %.2f}, "
                         "\"stage_busy_s\": {\"parse\": %.3f, \"gpu\": %.3f, \"format\": %.3f, \"write\": %.3f, \"gpu_upload\": %.3f, \"gpu_align\": %.3f, \"gpu_readback\": %.3f}}\n",
-                L, load_max, index_max, map_max + join_s, join_s, tot.total, pe ? 2 * tot.total : tot.total, tot.workers, ncpu, tot.cpu_user, tot.cpu_sys,
+                L, load_max, index_max, (last_end - first_start) + join_s, join_s, tot.total, pe ? 2 * tot.total : tot.total, tot.workers, ncpu, tot.cpu_user, tot.cpu_sys,
                 tot.stage_cpu[0], tot.stage_cpu[1], tot.stage_cpu[2], tot.stage_cpu[3], tot.busy[0], tot.busy[1], tot.busy[2], tot.busy[3], tot.gpu_part[0], tot.gpu_part[1], tot.gpu_part[2]);
     exit(0);
 }
@@ -742,7 +753,11 @@ int main(int argc, char **argv)
     // the others' kernels (12.6 -> 13.1 M reads/s end to end at hg38 size).  BSX_GPU_COMPUTE < BSX_GPU_BATCHES additionally limits how
     // many may be in their kernels at once, slots granted in batch order (measured with 4 to 6 batches and 2 or 3 slots: 11.9–12.8 M, no better).
     // (RRBS: two — a batch of 2^20 reads keeps 74 GB of work pools there, and three of them leave no room on a 288 GB device.)
-    const int NB = getenv("BSX_GPU_BATCHES") ? max(1, min(8, atoi(getenv("BSX_GPU_BATCHES")))) : (p.rrbs ? 2 : 3);
+    // (lanes that share one GPU share its memory too: fewer device batches each, and smaller ones)
+    int lanes_on_gpu = 1;
+    if (lane.index >= 0) { lanes_on_gpu = 0; for (int d : lane.lane_devices) lanes_on_gpu += d == o.devices[0]; }
+    if (lanes_on_gpu > 1 && !getenv("BSX_BATCH")) o.batch = max(50000u, (o.batch / (unsigned)lanes_on_gpu + 49999u) / 50000u * 50000u);
+    const int NB = getenv("BSX_GPU_BATCHES") ? max(1, min(8, atoi(getenv("BSX_GPU_BATCHES")))) : max(1, (p.rrbs ? 2 : 3) / (lanes_on_gpu > 2 ? lanes_on_gpu - 1 : 1));
     const int NC = getenv("BSX_GPU_COMPUTE") ? max(1, min(NB, atoi(getenv("BSX_GPU_COMPUTE")))) : NB;
     const int NG = ND * NB;                                                                          // GPU-stage threads
     Ring &ring = *new Ring(max(6, NG + 4));  // never freed: error paths exit() while side threads may still touch it
@@ -925,6 +940,11 @@ int main(int argc, char **argv)
     for (auto &c : cpu_ns) c = 0;
     auto add_cpu = [&](int st, double t0) { cpu_ns[st] += (long long)((thread_cpu_s() - t0) * 1e9); };
     t_pin.join();
+    if (lane.index >= 0) {   // every lane is ready: the mapping phases start together (the index build / upload is not part of them)
+        char c = 'r';
+        ssize_t r = write(lane.ready_fd, &c, 1); ::close(lane.ready_fd);
+        r = read(lane.go_fd, &c, 1); (void)r; ::close(lane.go_fd);
+    }
     const double t_map0 = now_s();
     struct rusage ru0; getrusage(RUSAGE_SELF, &ru0);
 
@@ -1133,7 +1153,7 @@ int main(int argc, char **argv)
     if (lane.index >= 0) {   // a lane reports to the parent, which prints the run's summary
         LaneStats st; memset(&st, 0, sizeof st);
         st.total = total; st.n_aligned = fmt.n_aligned; st.n_pairs = fmt.n_aligned_pairs; st.n_a = fmt.n_aligned_a; st.n_b = fmt.n_aligned_b;
-        st.load_s = t_loaded - t0; st.index_s = t_indexed - t_loaded; st.mapping_s = t_map1 - t_map0; st.cpu_user = ru_user; st.cpu_sys = ru_sys; st.workers = workers;
+        st.load_s = t_loaded - t0; st.index_s = t_indexed - t_loaded; st.mapping_s = t_map1 - t_map0; st.t_map0 = t_map0; st.t_map1 = t_map1; st.cpu_user = ru_user; st.cpu_sys = ru_sys; st.workers = workers;
         for (int k = 0; k < 4; k++) { st.stage_cpu[k] = cpu_ns[k] * 1e-9; st.busy[k] = busy[k]; }
         for (int k = 0; k < 3; k++) st.gpu_part[k] = gpu_part[k];
         for (int g = 0; g < NG; g++) bsx_batch_destroy(batches[g]);

@@ -6,6 +6,7 @@
 // threads that split the BYTES evenly (whatever the pieces are), at whatever page offset the range starts.
 #pragma once
 #include <sys/mman.h>
+#include <sys/stat.h>
 #include <unistd.h>
 #include <algorithm>
 #include <atomic>
@@ -28,7 +29,11 @@ inline bool map_write(int fd, const std::vector<std::pair<const char *, size_t>>
     size_t total = 0;
     for (auto &x : pieces) total += x.second;
     if (!total) return true;
-    if (ftruncate(fd, at + (off_t)total) != 0) return false;
+    {   // extend the file to the end of the new range (never shorten it: ranges of one file may be written concurrently)
+        struct stat st;
+        if (fstat(fd, &st) != 0) return false;
+        if (st.st_size < at + (off_t)total && ftruncate(fd, at + (off_t)total) != 0) return false;
+    }
     const long pg = sysconf(_SC_PAGESIZE);
     const off_t base = at / pg * pg;
     const size_t lead = (size_t)(at - base), len = lead + total;

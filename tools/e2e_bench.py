@@ -77,8 +77,23 @@ def _run(a):
         f.close()
     pa.close(); ref.close()
     t_fq = time.time() - t0
+    variants = [v for v in (getattr(a, "variants", "") or "").split(";")] or [""]
+    results = []
+    for extra in variants:
+        r = _run_cli(a, fq, fa, lens, n, t_fa, t_fq, extra.split())
+        r["cli_args"] = extra
+        results.append(r)
+    if len(results) == 1:
+        return results[0]
+    return {"variants": results}
+
+
+def _run_cli(a, fq, fa, lens, n, t_fa, t_fq, extra):
     out = os.path.join(a.dir, "out.sam")
-    cmd = [os.path.join(os.path.dirname(B.__file__), "bsmap"), "-a", fq[0], "-b", fq[1], "-d", fa, "-o", out, "-s", "16", "-v", "6", "-m", "28", "-x", "500", "-S", "1"]
+    for f in [out] + [out + f".{k}" for k in range(64)]:
+        if os.path.exists(f):
+            os.remove(f)
+    cmd = [os.path.join(os.path.dirname(B.__file__), "bsmap"), "-a", fq[0], "-b", fq[1], "-d", fa, "-o", out, "-s", "16", "-v", "6", "-m", "28", "-x", "500", "-S", "1"] + list(extra)
     if a.threads:
         cmd += ["-p", str(a.threads)]
     if os.environ.get("BSX_TASKSET"):   # experiment: pin the whole command line to a CPU list (one NUMA node)
@@ -96,7 +111,7 @@ def _run(a):
         tim["pace_trace"] = pt
     if ev:   # BSX_TIMING=2: per batch, when it was in which stage (tools/e2e_gantt.py)
         tim["events"] = ev[-1]["events"]
-    sam_bytes = os.path.getsize(out)
+    sam_bytes = os.path.getsize(out) if os.path.exists(out) else sum(os.path.getsize(out + f".{k}") for k in range(64) if os.path.exists(out + f".{k}"))
     summary = [l for l in res.stdout.split("\n") if l.startswith(("pairs", "single"))]
     r = {"pairs": n, "genome_bp": int(sum(lens)), "fasta_bytes": os.path.getsize(fa), "fastq_bytes": sum(os.path.getsize(p) for p in fq), "sam_bytes": sam_bytes,
          "cli_wall_s": round(wall, 2), "timing": tim, "reads_per_s_mapping_phase": round(2 * n / tim["mapping_s"]), "reads_per_s_whole_process": round(2 * n / wall),
@@ -111,6 +126,7 @@ def main():
     ap.add_argument("--dir", default="/dev/shm/bsx_e2e")
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--keep", action="store_true")
+    ap.add_argument("--variants", default="", help="';'-separated lists of extra bsmap arguments: the same input files are mapped once per list (e.g. ';--lanes=2;--lanes=4')")
     print(json.dumps(run(ap.parse_args())))
 
 

@@ -14,12 +14,13 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $S/stats -o s --output-format csv -- python3 $R/bench.py --profile-serial --steps 3 --warmup 1 --cpu-seconds 0 --e2e-pairs 0 --transfer-steps 0 > $O/${TAG}_bench_serial.json 2> $S/stats.log; echo "stats rc=$?"
 rocprofv3 --kernel-trace --stats -d $S/stats_default -o s --output-format csv -- python3 $R/bench.py --cpu-seconds 0 --e2e-pairs 0 --transfer-steps 0 --sensitivity 0 --other-configs 0 --steps 4 --warmup 2 > $O/${TAG}_bench_under_rocprof.json 2> $S/stats_default.log; echo "stats default rc=$?"
 cut -c1-160 $S/stats_default/s_kernel_stats.csv > $O/${TAG}_default_kernel_stats.csv
-for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM SQ_WAIT_ANY SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE" "TA_TA_BUSY_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum" "FETCH_SIZE" "WRITE_SIZE"; do
+for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM SQ_WAIT_ANY SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE" "TA_TA_BUSY_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_LDS_ADDR_CONFLICT" "FETCH_SIZE" "WRITE_SIZE"; do
   t=$(echo $set | cut -d' ' -f1)
   rocprofv3 --pmc $set --kernel-trace -d $S/pmc_$t -o p --output-format csv -- python3 $R/bench.py --profile-serial --steps 2 --warmup 1 --cpu-seconds 0 --e2e-pairs 0 --transfer-steps 0 > /dev/null 2> $S/pmc_$t.log; echo "$t rc=$?"
 done
 python3 $R/tools/summarize_pmc.py $TAG $S/stats $S/pmc_FETCH_SIZE $S/pmc_WRITE_SIZE > /dev/null; echo "summarize_pmc rc=$?"
-python3 $R/tools/summarize_sq.py $TAG $S/pmc_SQ_WAVES $S/pmc_SQ_WAIT_INST_ANY $S/pmc_TA_TA_BUSY_sum > /dev/null; echo "summarize_sq rc=$?"
+python3 $R/tools/summarize_sq.py $TAG $S/pmc_SQ_WAVES $S/pmc_SQ_WAIT_INST_ANY $S/pmc_TA_TA_BUSY_sum $S/pmc_SQ_LDS_BANK_CONFLICT > /dev/null; echo "summarize_sq rc=$?"
+cp $O/${TAG}_sq.json $R/profiles/${TAG}_sq.json  # (on the box) the bench lines below quote this build's counter summary
 cp $O/pmc_latest.json $R/profiles/pmc_latest.json  # (on the box) so that the bench lines below carry this build's traffic
 cd $R
 timeout 1200 python3 bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err; echo "default rc=$?"
@@ -31,5 +32,7 @@ timeout 900 python3 bench.py --mode trim --exact --cpu-seconds 0 --e2e-pairs 0 -
 timeout 900 python3 bench.py --in-flight 1 --cpu-seconds 0 --e2e-pairs 0 --transfer-steps 0 --sensitivity 0 --other-configs 0 > $O/${TAG}_bench_one_in_flight.json 2> $O/${TAG}_bench_one_in_flight.err; echo "one in flight rc=$?"
 bash $R/tools/host_ceiling.sh ${TAG} > $O/${TAG}_host_ceiling.txt 2>&1; cp $R/gpurun_out/${TAG}_hc_*.json $O/ 2>/dev/null; cat $O/${TAG}_host_ceiling.txt
 $R/tools/microbench/valu_issue > $O/${TAG}_valu_issue.json 2>/dev/null; echo "valu rc=$?"
+$R/tools/microbench/gather_cost > $O/${TAG}_gather_cost.json 2>/dev/null; echo "gather rc=$?"
+bash $R/tools/lanes_scaling.sh ${TAG}_lanes > $O/${TAG}_lanes.txt 2>&1; cp $R/gpurun_out/${TAG}_lanes/*.json $O/ 2>/dev/null; cat $O/${TAG}_lanes.txt
 rm -rf $S; ls -la $O | head -30
 timeout 900 python3 tools/validate_fullsize.py --mode pe > $O/${TAG}_validate_full_c3.json 2>/dev/null; echo "validate full rc=$?"
