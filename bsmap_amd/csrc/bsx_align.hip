@@ -2347,6 +2347,30 @@ __device__ __forceinline__ void hscan_task(const AlignArgs &A, const HeavyArgs &
     }
 }
 
+// Which block of the scan order a block of the grid takes.  The grid's blocks go to the 8 XCDs round-robin (its size is a multiple
+// of 8) and every XCD has its own L2: neighbours in the order should share one.  mode 1 gives every XCD one contiguous eighth of the
+// order — but the order is sorted by index entry, the tasks of different buckets differ in cost, and the XCD with the expensive eighth
+// finishes long after the others (k_hscan 85 ms per step).  mode N >= 2 deals pieces of N blocks to the XCDs in turn: neighbours still
+// share an L2 and every XCD gets a sample of the whole order (N = 128: 69.5 ms; 16 / 32 / 64 / 256: 80.1 / 75.2 / 70.6 / 70.5).
+// Returns 0 = take block `b`, 1 = nothing for this grid block at this stride, 2 = the order is exhausted.
+__device__ __forceinline__ int order_block(uint32_t vb, uint32_t nvb, uint32_t mode, uint32_t &b)
+{
+    if (mode == 1) {
+        const uint32_t per_xcd = (nvb + 7u) >> 3;
+        if ((vb >> 3) >= per_xcd) return 2;
+        b = (vb & 7u) * per_xcd + (vb >> 3);
+        return b < nvb ? 0 : 1;
+    }
+    if (mode >= 2) {
+        const uint32_t local = vb >> 3, piece = local / mode, within = local - piece * mode;
+        if (piece * 8u * mode >= nvb) return 2;
+        b = (piece * 8u + (vb & 7u)) * mode + within;
+        return b < nvb ? 0 : 1;
+    }
+    b = vb;
+    return vb < nvb ? 0 : 2;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // k_hscan on bit planes (BSX_HSCAN_PLANES, the default).  The candidate's reference comes from the PLANE copy (DevParams::refplane:
 // per 32 nt a {low bits, high bits} pair) and is compared where it lies; the READ is what gets shifted — once per task, into a
@@ -2596,16 +2620,13 @@ __global__ __launch_bounds__(64 * BSX_HSCAN_WPB, BSX_HSCAN_WAVES) void k_hscan(A
     // so at the same time, and each line of entries / reference is fetched from memory once for all of them.
     // The host does not know the count: it sizes the grid for the whole task pool (blocks beyond the tasks of the pass leave at once)
     // or, in the tail of a batch, for a few thousand tasks — then a block sweeps over the order with the stride of the grid.
-    const uint32_t nvb = (n_tasks + BSX_HSCAN_WPB - 1) / BSX_HSCAN_WPB, per_xcd = (nvb + 7u) >> 3;
+    const uint32_t nvb = (n_tasks + BSX_HSCAN_WPB - 1) / BSX_HSCAN_WPB;
     for (uint32_t vb = blockIdx.x;; vb += gridDim.x) {
-        uint32_t slot;
-        if (H.xcd_map) {  // blocks of one XCD (dispatched round-robin; the grid is a multiple of 8) take a contiguous part of the order
-            if ((vb >> 3) >= per_xcd) break;
-            slot = ((vb & 7u) * per_xcd + (vb >> 3)) * BSX_HSCAN_WPB + (uint32_t)wv;
-        } else {
-            if (vb >= nvb) break;
-            slot = vb * BSX_HSCAN_WPB + (uint32_t)wv;
-        }
+        uint32_t b_;
+        const int st_ = order_block(vb, nvb, H.xcd_map, b_);
+        if (st_ == 2) break;
+        if (st_ == 1) continue;
+        const uint32_t slot = b_ * BSX_HSCAN_WPB + (uint32_t)wv;
 #if BSX_HSCAN_PLANES
         if (slot < n_tasks) hp_task(A, H, H.order ? rfl(H.order[slot]) : slot, lane, TAB[wv], PT[wv], QBUF[wv]);
 #else
@@ -2837,12 +2858,13 @@ __global__ __launch_bounds__(64 * HM_WAVES, 4) void k_hscan_multi(AlignArgs A, H
     __shared__ MultiLds L;
     const int lane = threadIdx.x & 63, wv = (int)rfl(threadIdx.x >> 6);
     const uint32_t n_tasks = min(*H.n_tasks, H.task_cap);
-    const uint32_t ngrp = (n_tasks + HM_TASKS - 1) / HM_TASKS, per_xcd = (ngrp + 7u) >> 3;
+    const uint32_t ngrp = (n_tasks + HM_TASKS - 1) / HM_TASKS;
     for (uint32_t vb = blockIdx.x;; vb += gridDim.x) {
-        // (blocks of one XCD — dispatched round-robin, the grid is a multiple of 8 — take a contiguous part of the scan order: neighbours share an L2)
-        if ((vb >> 3) >= per_xcd) break;
-        const uint32_t s0 = ((vb & 7u) * per_xcd + (vb >> 3)) * HM_TASKS;
-        if (s0 >= n_tasks) continue;
+        uint32_t b_;
+        const int st_ = order_block(vb, ngrp, H.xcd_map >= 2 ? max(2u, H.xcd_map / 8u) : H.xcd_map, b_);   // (a group is 16 tasks: 8 of k_hscan's blocks)
+        if (st_ == 2) break;
+        if (st_ == 1) continue;
+        const uint32_t s0 = b_ * HM_TASKS;
         const uint32_t nj = min(HM_TASKS, n_tasks - s0);
         // lane j < nj: task j of the group, in scan order, and the signature of its window
         uint32_t tid = 0, th = 0, tc0 = 0, tn = 0, key = 0, hh = 0, strand = 0;
@@ -2939,7 +2961,13 @@ __global__ __launch_bounds__(256, BSX_HSHARED_WAVES) void k_hscan_shared(AlignAr
     const uint8_t *plane = reinterpret_cast<const uint8_t *>(P.refplane);
     const uint32_t rc_off = P.plane_rc_off;
     // (grid sized for the task pool, or — in the tail of a batch — smaller: then a wave sweeps over the order with the stride of the grid)
-    for (uint32_t s0 = (blockIdx.x * 4u + (uint32_t)wv) * HS_SHARE; s0 < n_tasks; s0 += gridDim.x * 4u * HS_SHARE) {
+    const uint32_t nvb = (n_tasks + 4u * HS_SHARE - 1u) / (4u * HS_SHARE);
+    for (uint32_t vb = blockIdx.x;; vb += gridDim.x) {
+    uint32_t b_;
+    const int st_ = order_block(vb, nvb, H.xcd_map >= 2 ? max(2u, H.xcd_map / 32u) : H.xcd_map, b_);   // (a block takes 64 tasks: 32 of k_hscan's blocks)
+    if (st_ == 2) break;
+    const uint32_t s0 = (b_ * 4u + (uint32_t)wv) * HS_SHARE;
+    if (st_ == 1 || s0 >= n_tasks) continue;
     const uint32_t nj = min(HS_SHARE, n_tasks - s0);
     // lane j < nj: task j of this wave, in scan order, and the signature of its window
     uint32_t tid = 0, th = 0, tc0 = 0, tn = 0, tkey = 0, sh_ = 0, stx = 0, stw = 0, snw = 0;
@@ -3098,7 +3126,13 @@ __global__ __launch_bounds__(256, BSX_HSHARED_WAVES) void k_hscan_shared(AlignAr
     const uint32_t cref_off = (uint32_t)((const uint8_t *)P.crefcat - (const uint8_t *)P.refcat);
     uint32_t kA = 0xAAAAAAAAu; asm volatile("" : "+v"(kA));   // in a VGPR: see hscan_mism
     // (grid sized for the task pool, or — in the tail of a batch — smaller: then a wave sweeps over the order with the stride of the grid)
-    for (uint32_t s0 = (blockIdx.x * 4u + (uint32_t)wv) * HS_SHARE; s0 < n_tasks; s0 += gridDim.x * 4u * HS_SHARE) {
+    const uint32_t nvb = (n_tasks + 4u * HS_SHARE - 1u) / (4u * HS_SHARE);
+    for (uint32_t vb = blockIdx.x;; vb += gridDim.x) {
+    uint32_t b_;
+    const int st_ = order_block(vb, nvb, H.xcd_map >= 2 ? max(2u, H.xcd_map / 32u) : H.xcd_map, b_);   // (a block takes 64 tasks: 32 of k_hscan's blocks)
+    if (st_ == 2) break;
+    const uint32_t s0 = (b_ * 4u + (uint32_t)wv) * HS_SHARE;
+    if (st_ == 1 || s0 >= n_tasks) continue;
     const uint32_t nj = min(HS_SHARE, n_tasks - s0);
     // lane j < nj: task j of this wave, in scan order, and the signature of its window
     uint32_t tid = 0, th = 0, tc0 = 0, tn = 0, tkey = 0, sh_ = 0, stx = 0, stw = 0, snw = 0;
@@ -3275,7 +3309,7 @@ void bsx_launch_hscan_shared(const AlignArgs &A, const HeavyArgsRaw &R, hipStrea
 {
     const HeavyArgs H = typed(R);
     const uint32_t jobs = ((max_tasks ? std::min(max_tasks, R.task_cap) : R.task_cap) + HS_SHARE - 1) / HS_SHARE;
-    hipLaunchKernelGGL(k_hscan_shared, dim3((jobs + 3) / 4), dim3(256), 0, stream, A, H);
+    hipLaunchKernelGGL(k_hscan_shared, dim3(((jobs + 3) / 4 + 7u) & ~7u), dim3(256), 0, stream, A, H);   // (a multiple of 8: order_block)
 }
 
 void bsx_launch_hscan_multi(const AlignArgs &A, const HeavyArgsRaw &R, hipStream_t stream, uint32_t max_tasks)

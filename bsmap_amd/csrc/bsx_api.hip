@@ -263,6 +263,7 @@ struct bsx_batch {
     uint8_t *d_hstate = nullptr, *d_hslabs = nullptr, *d_htasks = nullptr, *d_htout = nullptr;
     uint32_t *d_hactive[2] = {nullptr, nullptr}, *d_hcnt = nullptr;  // d_hcnt: per group two ping-pong blocks {n_active, n_tasks, queue[2]}
     uint32_t hcap = 0, task_cap = 0;
+    uint32_t xcd_map = 128;   // order_block (bsx_align.hip): pieces of 128 scan blocks dealt to the XCDs in turn
     uint32_t *h_pinned = nullptr;  // pinned host words for the per-pass count read-backs
     int n_cu = 0;
     uint32_t last_heavy = 0, last_heavy_iters = 0, last_redo = 0;
@@ -451,6 +452,7 @@ extern "C" int bsx_batch_create(bsx_ref *r, uint32_t max_units, int paired, bsx_
     // flight, C3 131 ms per step against 148 with two groups each; a caller that keeps a single batch in flight gains from 2: 158 against
     // 177 ms), passes enqueued per host poll
     if (const char *e = getenv("BSX_HEAVY_GROUPS")) b->n_groups = std::max(1, std::min(BSX_MAX_GROUPS, atoi(e)));
+    if (const char *e = getenv("BSX_XCD_MAP")) b->xcd_map = (uint32_t)std::max(0, atoi(e));   // how k_hscan's blocks map onto the scan order: 0 as dispatched, 1 one contiguous eighth per XCD, N >= 2 pieces of N blocks dealt to the XCDs in turn
     if (const char *e = getenv("BSX_HEAVY_CHUNK")) b->chunk_passes = std::max(1, std::min(64, atoi(e)));
     b->trace = getenv("BSX_TRACE_HEAVY") != nullptr;
     if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) return fail(BSX_ERR_DEVICE);
@@ -763,7 +765,7 @@ extern "C" int bsx_batch_run_range(bsx_batch *b, uint32_t first_unit, uint32_t n
                 bsx_launch_hctrl(A, q.H, b->paired, (int)std::min<uint32_t>((q.n0 + 3) / 4, (uint32_t)b->n_cu * b->hctrl_blocks_per_cu), hw.s_ctrl);
                 HIP_TRY(hipGetLastError());
                 // scan order of the tasks this pass published, still on the group's stream: done by the time the main stream gets to the scan
-                q.H.order = hw.d_order; q.H.xcd_map = 1;
+                q.H.order = hw.d_order; q.H.xcd_map = b->xcd_map;
                 bsx_launch_task_order(q.H, b->bin_shift, b->n_bins, hw.d_bins, hw.d_bstart, hw.d_chunk_tot, hw.d_rank, hw.d_order, in, hw.s_ctrl);
                 // The scan: on the batch's stream with a grid for the whole task pool — or, once the group is in its tail (few tasks per
                 // pass, see the poll loop), behind the control kernel on the group's own high-priority stream with a small grid whose
