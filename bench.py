@@ -558,7 +558,9 @@ def incl_transfers(B, ref, src, Align, pe, B_, steps, nfl, reads_per_unit, first
             q[:] = src.download_quals(m)[lo:hi]
             pins.append(pq)
         host.append((a, (off[first_unit:first_unit + steps * B_ + 1] - off[first_unit]).astype(np.uint64), q))
-    nt = min(nfl + 1, 3)  # (RRBS: one — a batch holds 74 GB there)  one more batch than the resident-input run keeps in flight (a batch that is moving data does not compute); at most 3: each holds ~39 GB of pools
+    nt = min(nfl + 2, 4) if nfl else 1  # (RRBS: one — a batch holds 74 GB there)  two more batches than the resident-input run keeps in flight (a batch that is moving data does not compute: 3 / 4 batches 0.93 / 0.96 of the resident rate); at most 4: each holds ~39 GB of pools
+    nt = int(os.environ.get("BSX_T_BATCHES", nt))            # (experiments: batches of this leg, and how many of them may be inside Do_Batch at once)
+    gate = threading.Semaphore(int(os.environ.get("BSX_T_GATE", nt)))
     small = [Align(ref, B_) for _ in range(nt)]
     L = B.lib()
     sinks = []    # page-locked result arrays per batch
@@ -570,18 +572,32 @@ def incl_transfers(B, ref, src, Align, pe, B_, steps, nfl, reads_per_unit, first
             arrs.append(raw.view(dt))
         sinks.append(tuple(arrs))
 
+    # per step the arrays a caller hands over: bytes of the step's reads and their offsets from 0 (prepared before the window opens — packing the
+    # reads of a batch is the caller's parser, which `end_to_end` measures; the window is upload -> Do_Batch -> results)
+    step_off = []
+    for a, off, q in host:
+        per = []
+        for i in range(steps):
+            raw, p_ = pinned_array(B, C, (B_ + 1) * 8)   # (page-locked like the read bytes: a pageable source is staged through a bounce buffer)
+            pins.append(p_)
+            o = raw.view(np.uint64)
+            o[:] = off[i * B_:(i + 1) * B_ + 1] - off[i * B_]
+            per.append(o)
+        step_off.append(per)
+
     def step(j, i):
         b = small[j]
         sl = []
-        for a, off, q in host:
-            o = (off[i * B_:(i + 1) * B_ + 1] - off[i * B_]).copy()
+        for m_, (a, off, q) in enumerate(host):
+            o = step_off[m_][i]
             s0, s1 = int(off[i * B_]), int(off[(i + 1) * B_])
             sl.append((a[s0:s1], o, q[s0:s1] if q is not None else None))
         if pe:
             b.ImportBatchReads((sl[0][0], sl[0][1]), (sl[1][0], sl[1][1]), sl[0][2], sl[1][2], first_index=first_unit + i * B_)
         else:
             b.ImportBatchReads((sl[0][0], sl[0][1]), sl[0][2], first_index=first_unit + i * B_)
-        b.Do_Batch()
+        with gate:
+            b.Do_Batch()
         b.results(into=sinks[j])
 
     nxt, lock = [0], threading.Lock()
@@ -612,8 +628,7 @@ def incl_transfers(B, ref, src, Align, pe, B_, steps, nfl, reads_per_unit, first
     down = steps * B_ * ((64 + 128) if pe else (16 + 64))
     return {"value": steps * B_ * reads_per_unit / dt, "unit": "reads/s", "steps": steps, "ms_per_step": dt / steps * 1e3,
             "host_to_device_bytes_per_step": up / steps, "device_to_host_bytes_per_step": down / steps,
-            "window": "per step: bsx_batch_upload (page-locked host arrays) -> Do_Batch -> bsx_batch_results (page-locked), %d batches in flight; "
-                      "host numpy slicing of the step's arrays included" % nt}
+            "window": "per step: bsx_batch_upload (page-locked read bytes, per-step offset arrays prepared beforehand) -> Do_Batch -> bsx_batch_results (page-locked), %d batches in flight" % nt}
 
 
 def end_to_end(pairs, genome):

@@ -2347,30 +2347,6 @@ __device__ __forceinline__ void hscan_task(const AlignArgs &A, const HeavyArgs &
     }
 }
 
-// Which block of the scan order a block of the grid takes.  The grid's blocks go to the 8 XCDs round-robin (its size is a multiple
-// of 8) and every XCD has its own L2: neighbours in the order should share one.  mode 1 gives every XCD one contiguous eighth of the
-// order — but the order is sorted by index entry, the tasks of different buckets differ in cost, and the XCD with the expensive eighth
-// finishes long after the others (k_hscan 85 ms per step).  mode N >= 2 deals pieces of N blocks to the XCDs in turn: neighbours still
-// share an L2 and every XCD gets a sample of the whole order (N = 128: 69.5 ms; 16 / 32 / 64 / 256: 80.1 / 75.2 / 70.6 / 70.5).
-// Returns 0 = take block `b`, 1 = nothing for this grid block at this stride, 2 = the order is exhausted.
-__device__ __forceinline__ int order_block(uint32_t vb, uint32_t nvb, uint32_t mode, uint32_t &b)
-{
-    if (mode == 1) {
-        const uint32_t per_xcd = (nvb + 7u) >> 3;
-        if ((vb >> 3) >= per_xcd) return 2;
-        b = (vb & 7u) * per_xcd + (vb >> 3);
-        return b < nvb ? 0 : 1;
-    }
-    if (mode >= 2) {
-        const uint32_t local = vb >> 3, piece = local / mode, within = local - piece * mode;
-        if (piece * 8u * mode >= nvb) return 2;
-        b = (piece * 8u + (vb & 7u)) * mode + within;
-        return b < nvb ? 0 : 1;
-    }
-    b = vb;
-    return vb < nvb ? 0 : 2;
-}
-
 // ---------------------------------------------------------------------------------------------------------------
 // k_hscan on bit planes (BSX_HSCAN_PLANES, the default).  The candidate's reference comes from the PLANE copy (DevParams::refplane:
 // per 32 nt a {low bits, high bits} pair) and is compared where it lies; the READ is what gets shifted — once per task, into a
@@ -2623,7 +2599,7 @@ __global__ __launch_bounds__(64 * BSX_HSCAN_WPB, BSX_HSCAN_WAVES) void k_hscan(A
     const uint32_t nvb = (n_tasks + BSX_HSCAN_WPB - 1) / BSX_HSCAN_WPB;
     for (uint32_t vb = blockIdx.x;; vb += gridDim.x) {
         uint32_t b_;
-        const int st_ = order_block(vb, nvb, H.xcd_map, b_);
+        const int st_ = bsx_order_block(vb, nvb, H.xcd_map, b_);
         if (st_ == 2) break;
         if (st_ == 1) continue;
         const uint32_t slot = b_ * BSX_HSCAN_WPB + (uint32_t)wv;
@@ -2861,7 +2837,7 @@ __global__ __launch_bounds__(64 * HM_WAVES, 4) void k_hscan_multi(AlignArgs A, H
     const uint32_t ngrp = (n_tasks + HM_TASKS - 1) / HM_TASKS;
     for (uint32_t vb = blockIdx.x;; vb += gridDim.x) {
         uint32_t b_;
-        const int st_ = order_block(vb, ngrp, H.xcd_map >= 2 ? max(2u, H.xcd_map / 8u) : H.xcd_map, b_);   // (a group is 16 tasks: 8 of k_hscan's blocks)
+        const int st_ = bsx_order_block(vb, ngrp, H.xcd_map >= 2 ? max(2u, H.xcd_map / 8u) : H.xcd_map, b_);   // (a group is 16 tasks: 8 of k_hscan's blocks)
         if (st_ == 2) break;
         if (st_ == 1) continue;
         const uint32_t s0 = b_ * HM_TASKS;
@@ -2964,7 +2940,7 @@ __global__ __launch_bounds__(256, BSX_HSHARED_WAVES) void k_hscan_shared(AlignAr
     const uint32_t nvb = (n_tasks + 4u * HS_SHARE - 1u) / (4u * HS_SHARE);
     for (uint32_t vb = blockIdx.x;; vb += gridDim.x) {
     uint32_t b_;
-    const int st_ = order_block(vb, nvb, H.xcd_map >= 2 ? max(2u, H.xcd_map / 32u) : H.xcd_map, b_);   // (a block takes 64 tasks: 32 of k_hscan's blocks)
+    const int st_ = bsx_order_block(vb, nvb, H.xcd_map >= 2 ? max(2u, H.xcd_map / 32u) : H.xcd_map, b_);   // (a block takes 64 tasks: 32 of k_hscan's blocks)
     if (st_ == 2) break;
     const uint32_t s0 = (b_ * 4u + (uint32_t)wv) * HS_SHARE;
     if (st_ == 1 || s0 >= n_tasks) continue;
@@ -3129,7 +3105,7 @@ __global__ __launch_bounds__(256, BSX_HSHARED_WAVES) void k_hscan_shared(AlignAr
     const uint32_t nvb = (n_tasks + 4u * HS_SHARE - 1u) / (4u * HS_SHARE);
     for (uint32_t vb = blockIdx.x;; vb += gridDim.x) {
     uint32_t b_;
-    const int st_ = order_block(vb, nvb, H.xcd_map >= 2 ? max(2u, H.xcd_map / 32u) : H.xcd_map, b_);   // (a block takes 64 tasks: 32 of k_hscan's blocks)
+    const int st_ = bsx_order_block(vb, nvb, H.xcd_map >= 2 ? max(2u, H.xcd_map / 32u) : H.xcd_map, b_);   // (a block takes 64 tasks: 32 of k_hscan's blocks)
     if (st_ == 2) break;
     const uint32_t s0 = (b_ * 4u + (uint32_t)wv) * HS_SHARE;
     if (st_ == 1 || s0 >= n_tasks) continue;

@@ -83,3 +83,27 @@ __host__ __device__ inline uint32_t bsx_myrand(uint32_t index, int32_t randseed)
     v ^= v << 20; v ^= v >> 41; v ^= v << 5;
     return (uint32_t)v;
 }
+
+// Which block of the scan order a block of the grid takes.  The grid's blocks go to the 8 XCDs round-robin (its size is a multiple
+// of 8) and every XCD has its own L2: neighbours in the order should share one.  mode 1 gives every XCD one contiguous eighth of the
+// order — but the order is sorted by index entry, the tasks of different buckets differ in cost, and the XCD with the expensive eighth
+// finishes long after the others (k_hscan 85 ms per step).  mode N >= 2 deals pieces of N blocks to the XCDs in turn: neighbours still
+// share an L2 and every XCD gets a sample of the whole order (N = 128: 69.5 ms; 16 / 32 / 64 / 256: 80.1 / 75.2 / 70.6 / 70.5).
+// Returns 0 = take block `b`, 1 = nothing for this grid block at this stride, 2 = the order is exhausted.
+__host__ __device__ inline int bsx_order_block(uint32_t vb, uint32_t nvb, uint32_t mode, uint32_t &b)
+{
+    if (mode == 1) {
+        const uint32_t per_xcd = (nvb + 7u) >> 3;
+        if ((vb >> 3) >= per_xcd) return 2;
+        b = (vb & 7u) * per_xcd + (vb >> 3);
+        return b < nvb ? 0 : 1;
+    }
+    if (mode >= 2) {
+        const uint32_t local = vb >> 3, piece = local / mode, within = local - piece * mode;
+        if (piece * 8u * mode >= nvb) return 2;
+        b = (piece * 8u + (vb & 7u)) * mode + within;
+        return b < nvb ? 0 : 1;
+    }
+    b = vb;
+    return vb < nvb ? 0 : 2;
+}

@@ -17,3 +17,13 @@ def test_plane_rule_equals_per_nt_definition(tmp_path):
     subprocess.check_call([HIPCC, "-O1", "-o", exe, os.path.join(ROOT, "tests", "harness", "planes_check.cpp")], stderr=subprocess.DEVNULL)
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.startswith("ok"), out.stdout + out.stderr
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
+def test_scan_order_mapping_takes_every_block_exactly_once(tmp_path):
+    """bsx_order_block (which block of the scan order a grid block takes: as dispatched, one contiguous eighth per XCD, or pieces dealt to
+    the XCDs in turn) for every mode, order length and grid size, incl. grids that sweep: no block twice, none left out"""
+    exe = str(tmp_path / "order_check")
+    subprocess.check_call([HIPCC, "-O1", "-o", exe, os.path.join(ROOT, "tests", "harness", "order_check.cpp")], stderr=subprocess.DEVNULL)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.startswith("ok"), out.stdout + out.stderr
