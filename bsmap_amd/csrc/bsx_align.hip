@@ -39,6 +39,9 @@ struct __attribute__((packed, aligned(4))) U2 { uint32_t a, b; };
 #ifndef BSX_MAIN_NT
 #define BSX_MAIN_NT 0
 #endif
+#ifndef BSX_MAIN_PREFETCH
+#define BSX_MAIN_PREFETCH 1  /* the main kernel's scan requests the next chunk's index entries before this chunk's reference gather (wave_scan_range) */
+#endif
 typedef uint32_t v4u_a4 __attribute__((ext_vector_type(4), aligned(4)));
 typedef uint32_t v2u_a4 __attribute__((ext_vector_type(2), aligned(4)));
 __device__ __forceinline__ U4 ldm4(const uint32_t *p)
@@ -818,6 +821,18 @@ __device__ int wave_scan_range(const DevParams &P, const BlockLds &BL, const Mat
     // round trips per step instead of two per chunk; the threshold each chunk sees is still the one left by its
     // predecessors, and a chunk behind an early return is simply dropped).  The main kernel uses 1 (its lists are
     // short and its register budget is tight), the control kernel of the heavy pipeline 4.
+    // WGBS, one chunk per step (the main kernel): the index entry of the NEXT chunk is requested before this chunk's reference gather, so a
+    // chunk is two dependent memory round trips (gather, then the words behind 48 nt where a lane needs them) instead of three — the main
+    // kernel is a chain of such round trips (SQ_WAIT_ANY 0.76 of its wave cycles).  e_pf: the prefetched entry, hs_pf: its h << 1 | strand.
+    constexpr bool PREFETCH = BSX_SCAN_NB == 1 && BSX_MAIN_PREFETCH;
+    // (a macro, not a lambda: a closure over `cl` put the whole list descriptor into scratch — 1.1 KB per lane)
+#define BSX_LOCATE(idx_, e_idx_, hs_) do { e_idx_ = 0; hs_ = 0; \
+        for (int s_ = 0; s_ < cl.nsub; s_++) { \
+            const uint32_t ps_ = rl(cl.sub_pre, s_), ns_ = rl(cl.sub_n, s_); \
+            if ((idx_) >= ps_ && (idx_) < ps_ + ns_) { e_idx_ = rl(cl.sub_base, s_) + ((idx_) - ps_); hs_ = (rl(cl.sub_h, s_) << 1) | (uint32_t)(s_ & 1); } \
+        } } while (0)
+    uint32_t e_pf = 0, hs_pf = 0;
+    if (PREFETCH && !P.rrbs && c_begin < c_end) { uint32_t ei; const uint32_t i0_ = c_begin + (uint32_t)lane; BSX_LOCATE(i0_, ei, hs_pf); e_pf = ldm1(P.entries + ei); }
     for (uint32_t cs = c_begin; cs < c_end; cs += 64 * BSX_SCAN_NB) {
       uint32_t p_[BSX_SCAN_NB], aux_[BSX_SCAN_NB];  // aux: WGBS strand / RRBS chromosome id
       bool valid_[BSX_SCAN_NB];
@@ -837,6 +852,11 @@ __device__ int wave_scan_range(const DevParams &P, const BlockLds &BL, const Mat
                 strand = rchr & 1;
                 if (valid) p = (lds_chr ? BL.anchor[rchr >> 1] : P.anchor[rchr >> 1]) + (e.b - h);
             }
+        } else if (PREFETCH) {
+            const uint32_t e = e_pf, hs = hs_pf;
+            strand = hs & 1u;
+            if (valid) p = e + (uint32_t)((int32_t)hs >> 1);
+            if (cs + 64 < c_end) { uint32_t ei; const uint32_t in_ = idx + 64u; BSX_LOCATE(in_, ei, hs_pf); e_pf = ldm1(P.entries + ei); }   // (a lane behind the list's end reads entry 0: never used)
         } else {
             uint32_t e_idx = 0, h = 0;
             for (int s = 0; s < cl.nsub; s++) {
@@ -915,7 +935,7 @@ __device__ int wave_scan_range(const DevParams &P, const BlockLds &BL, const Mat
 // SnpAlign (align.cpp:168-347) in the main kernel.  A WGBS list of heavy_threshold candidates or more sets M.u->defer and
 // returns: the unit is redone from scratch by the heavy pipeline, which scans such lists with the whole chip.
 template <bool EXACT, bool PE>
-__device__ void snp_align(const DevParams &P, const BlockLds &BL, const MateLds &L, Mate &M, const Slab &SL, int mode, int lane,
+__device__ __forceinline__ void snp_align(const DevParams &P, const BlockLds &BL, const MateLds &L, Mate &M, const Slab &SL, int mode, int lane,
                           Counters &C, uint32_t heavy_threshold)
 {
     for (int orient = 0; orient < 2; orient++) {
@@ -923,14 +943,16 @@ __device__ void snp_align(const DevParams &P, const BlockLds &BL, const MateLds 
         const int seg = L.order[orient][mode];  // modeindex
         const CandList cl = make_list<EXACT>(P, BL, L, M, orient, seg, lane);
         if (heavy_threshold && cl.total >= heavy_threshold) { M.u->defer = 1; return; }
-        if (wave_scan_range<false, BSX_MAIN_NB, PE>(P, BL, L, M, SL, cl, orient, seg, mode, 0, cl.total, 0, lane, C) == 2) { wave_fence(); return; }
+        int r_;   // (inlined here whatever the inliner thinks of its size: as a call it costs the main kernel 1.1 KB of stack per lane)
+        [[clang::always_inline]] r_ = wave_scan_range<false, BSX_MAIN_NB, PE>(P, BL, L, M, SL, cl, orient, seg, mode, 0, cl.total, 0, lane, C);
+        if (r_ == 2) { wave_fence(); return; }
     }
     wave_fence();
 }
 
 // SingleAlign::RunAlign (align.cpp:435-452) after packing/planning
 template <bool EXACT, bool PE>
-__device__ void run_align_single(const DevParams &P, const BlockLds &BL, const MateLds &L, Mate &M, const Slab &SL, int lane, Counters &C,
+__device__ __forceinline__ void run_align_single(const DevParams &P, const BlockLds &BL, const MateLds &L, Mate &M, const Slab &SL, int lane, Counters &C,
                                  uint32_t heavy_threshold)
 {
     for (int i = 0; i < M.u->seedseg; i++) {
@@ -1446,7 +1468,7 @@ __device__ __forceinline__ bool process_unit(const AlignArgs &A, const BlockLds 
     U = carve_slab(slab, (uint32_t)P.max_snp_num + 1, A.rowcap, PE, A.kcap, A.hbits);
     Mate MA, MB;
     MA.u = lds_mate(&LA.u); MB.u = PE ? lds_mate(&LB.u) : lds_mate(&LA.u2);
-    unit_prepare<PE, EXACT>(A, BL, LA, LB, MA, MB, unit, lane, C);
+    [[clang::always_inline]] unit_prepare<PE, EXACT>(A, BL, LA, LB, MA, MB, unit, lane, C);
     uint32_t pcnt_reg = 0;  // lane c holds _cur_n_hits[c]
     int paired = 0;
     bool defer = false;
@@ -1456,14 +1478,16 @@ __device__ __forceinline__ bool process_unit(const AlignArgs &A, const BlockLds 
             if (i < MA.u->seedseg) snp_align<EXACT, PE>(P, BL, LA, MA, U.SA, i, lane, C, hthr);
             if (!MA.u->defer && i < MB.u->seedseg) snp_align<EXACT, PE>(P, BL, LB, MB, U.SB, i, lane, C, hthr);
             if (MA.u->defer || MB.u->defer) { defer = true; break; }
-            if (pair_level_post(P, MA, MB, U, pcnt_reg, i, lane) > 0) paired = i + 1;
+            int np_;
+            [[clang::always_inline]] np_ = pair_level_post(P, MA, MB, U, pcnt_reg, i, lane);
+            if (np_ > 0) paired = i + 1;
         }
     } else {
         if (!MA.u->filtered) { run_align_single<EXACT, PE>(P, BL, LA, MA, U.SA, lane, C, hthr); defer = MA.u->defer; }
         if (PE && !defer && !MB.u->filtered) { run_align_single<EXACT, PE>(P, BL, LB, MB, U.SB, lane, C, hthr); defer = MB.u->defer; }
     }
     if (defer) { forget_keys(MA, U.SA, lane); if (PE) forget_keys(MB, U.SB, lane); C = C0; return true; }
-    unit_finish<PE>(A, LA, LB, MA, MB, U, pcnt_reg, paired, unit, lane, n_aligned, n_aligned_pairs);
+    [[clang::always_inline]] unit_finish<PE>(A, LA, LB, MA, MB, U, pcnt_reg, paired, unit, lane, n_aligned, n_aligned_pairs);   // (the main kernel stays a leaf: a call costs it a kilobyte of stack per lane)
     return false;
 }
 
