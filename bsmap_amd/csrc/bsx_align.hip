@@ -1516,7 +1516,7 @@ __device__ void flush_counters(const AlignArgs &A, const Counters &C, u64 n_unit
 #define BSX_WAVES_PER_EU_SE 6
 #endif
 #ifndef BSX_WAVES_PER_EU_PE
-#define BSX_WAVES_PER_EU_PE 4
+#define BSX_WAVES_PER_EU_PE 5  /* round 4: 96 VGPRs, 112 B of scratch per lane; five waves per SIMD of a kernel that waits on memory 76 % of its cycles: 112.4-113.4 against 114.6-114.7 ms per step (4 waves: 128 VGPRs, 56 B) */
 #endif
 // main kernel: persistent waves, one unit per wave at a time
 template <bool PE, bool EXACT>
