@@ -1612,7 +1612,7 @@ struct HState {
     ListReq req[HS_NSLOT];
 };
 struct HTask { uint32_t h, c0, n, key;   // h: unit (bits 0-29) and list slot (bits 30-31); key: index entry the task starts at (tasks are scanned in key order, see bsx_api.hip)
-               uint32_t sub_h, flags, pad[2]; };  // of the sub-range the task starts in: its offset h; flags bit 0 strand copy, bit 1 the task lies inside that one sub-range
+               uint32_t sub_h, flags, pad[2]; };  // of the sub-range the task starts in: its offset h; flags bit 0 strand copy, bit 1 the task lies inside that one sub-range, bits 8-11 the read's 32-nt words
 struct HTaskOut { uint32_t count, overflow, acc[4], c0, n; SurvRec surv[HS_SCAP]; };  // c0, n: the task's candidates [c0, c0 + n) of its list, echoed by the scan kernel (the replay reads the geometry of a window from here: task descriptors are reused during a control pass, outputs are not)
 struct HeavyArgs {
     HState *state; uint8_t *slabs; uint32_t *active_in, *active_out, *n_active_out; HTask *tasks; HTaskOut *tout; uint32_t *n_tasks, *queue;
@@ -1620,6 +1620,7 @@ struct HeavyArgs {
     uint32_t n_active_in, task_cap, fresh, list_base, hidx_base;
     const uint32_t *order;  // scan order of the tasks (task ids sorted by key), null = pool order
     uint32_t xcd_map;       // 1: blocks of one XCD take a contiguous part of the order
+    const uint32_t *ghead, *glist;  // k_hscan_same: size of the group that starts at a scan slot; the start slots, their count in glist[task_cap] (k_task_groups)
 };
 __host__ HeavyArgs typed(const HeavyArgsRaw &r)
 {
@@ -1627,7 +1628,7 @@ __host__ HeavyArgs typed(const HeavyArgsRaw &r)
     h.state = (HState *)r.state; h.slabs = r.slabs; h.active_in = r.active_in; h.active_out = r.active_out; h.n_active_out = r.n_active_out;
     h.tasks = (HTask *)r.tasks; h.tout = (HTaskOut *)r.tout; h.n_tasks = r.n_tasks; h.queue = r.queue;
     h.n_active_in_ptr = r.n_active_in_ptr; h.n_active_in = r.n_active_in; h.task_cap = r.task_cap; h.fresh = r.fresh; h.list_base = r.list_base; h.hidx_base = r.hidx_base;
-    h.order = r.order; h.xcd_map = r.xcd_map;
+    h.order = r.order; h.xcd_map = r.xcd_map; h.ghead = r.ghead; h.glist = r.glist;
     return h;
 }
 
@@ -1743,7 +1744,7 @@ __device__ __forceinline__ bool publish_window(const DevParams &P, const HeavyAr
         tk.sub_h = 0; tk.flags = 0; tk.pad[0] = tk.pad[1] = 0;
         for (int s_ = 0; s_ < cl.nsub; s_++) {  // the index entry the task starts at, and what a scan kernel needs to know about that sub-range
             const uint32_t ps_ = rl(cl.sub_pre, s_), ns_ = rl(cl.sub_n, s_), sb_ = rl(cl.sub_base, s_), sh_ = rl(cl.sub_h, s_);
-            if (tk.c0 >= ps_ && tk.c0 < ps_ + ns_) { tk.key = sb_ + (tk.c0 - ps_); tk.sub_h = sh_; tk.flags = ((uint32_t)s_ & 1u) | ((tk.c0 + tk.n <= ps_ + ns_ && !P.rrbs) ? 2u : 0u); }
+            if (tk.c0 >= ps_ && tk.c0 < ps_ + ns_) { tk.key = sb_ + (tk.c0 - ps_); tk.sub_h = sh_; tk.flags = ((uint32_t)s_ & 1u) | ((tk.c0 + tk.n <= ps_ + ns_ && !P.rrbs) ? 2u : 0u) | ((uint32_t)((M.u->len + 31) >> 5) << 8); }
         }
         if (t < nt) H.tasks[t0 + t] = tk;
     }
@@ -2904,6 +2905,291 @@ __global__ __launch_bounds__(64 * HM_WAVES, 4) void k_hscan_multi(AlignArgs A, H
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// k_hscan_same — WGBS: the reads that walk one window of a giant bucket WITH THE SAME READ OFFSET share the fetch and the shift of
+// the candidates' reference.  publish_window cuts large sub-ranges on the grid of absolute index entries, so the tasks of all the
+// reads that walk a bucket cover identical entry ranges; a read reaches the bucket's seed at one of (segments x index interval)
+// offsets h, and the tasks of equal (first entry, length, strand copy, h, read words) are what a group is made of: for those the
+// candidate positions entry + h are the same numbers.  The task order (bsx_launch_task_order, spread) puts the tasks of one window
+// and offset class next to each other; a block takes 64 consecutive tasks, every wave splits them into the same groups of up to
+// HG_R tasks (any lanes, not only neighbours) and takes every HG_WAVES-th group.  Per group and step of HG_C chunks of 64 candidates
+//   * once: the entries, three 16-byte gathers per candidate (pairs k .. k + 5 of the plane copy, k = (position - 1) >> 5) and the
+//     funnel shift into the READ's frame (two v_alignbit per 32 nt);
+//   * per read: its plane words from LDS — ONE broadcast read of the row per step, not per chunk: a 16-byte LDS read of a wave
+//     returns 1 KB whatever the addresses, 8 cycles of the CU's LDS path, and four of them per chunk (k_hscan_shared's scheme)
+//     outweigh the 27 vector instructions of an evaluation — then 3 v_bitop3 + 1 v_bcnt per word and candidate, the two
+//     early-out classes of the reference (align.h:189-197) and the survivors, written in list order.
+// No second stage and no FIFO: on the hg38-sized workload 36-55 % of the candidates of a giant bucket are still within the
+// threshold after 64 nt, so a chunk of 64 practically always holds one that needs all the words.
+// Groups of one task, and tasks that span sub-ranges, go one per wave through hp_task.  Results per task are exactly k_hscan's.
+// ---------------------------------------------------------------------------------------------------------------
+#ifndef HG_WPB
+#define HG_WPB 2        /* waves (= groups) per block */
+#endif
+#ifndef HG_R
+#define HG_R 16u        /* tasks per group at most */
+#endif
+#ifndef HG_C
+#define HG_C 2          /* chunks per step */
+#endif
+#ifndef HG_PREFETCH
+#define HG_PREFETCH 1   /* the gathers of a step are issued a step earlier (13 registers per chunk) */
+#endif
+#ifndef BSX_HSAME_WAVES
+#define BSX_HSAME_WAVES 5
+#endif
+struct SameLds {
+    // per read of a group (row of 20 dwords): X0 Y0 M0 X1 | Y1 M1 X2 Y2 | M2 threshold X3 Y3 | M3 X4 Y4 M4 | task, first list ordinal, -, -
+    __attribute__((aligned(16))) uint32_t UW[HG_WPB][HG_R][20];
+    uint32_t TAB[HG_WPB][4][32];      // one-task path (hp_task)
+    uint2 PT[HG_WPB][HP_PAIRS * 32];
+    uint2 Q[HG_WPB][HP_QCAP];
+};
+struct SameChunk { U4 r0, r1, r2; uint32_t pm1; };   // pairs (pm1 >> 5) .. + 5 of the plane copy
+
+__device__ __forceinline__ SameChunk same_load(uint32_t entry, uint32_t hm1, const uint8_t *plane, uint32_t ref_off, int nwr)
+{
+    SameChunk c;
+    c.pm1 = entry + hm1;
+    const uint8_t *src = plane + hp_boff(c.pm1, ref_off);
+    c.r0 = *reinterpret_cast<const U4 *>(src);
+    c.r1.a = c.r1.b = c.r1.c = c.r1.d = 0; c.r2.a = c.r2.b = c.r2.c = c.r2.d = 0;
+    if (nwr > 1) c.r1 = *reinterpret_cast<const U4 *>(src + 16);
+    if (nwr > 3) c.r2 = *reinterpret_cast<const U4 *>(src + 32);
+    return c;
+}
+
+// the three counts of one candidate and read (align.h:189-197): first early-out word, second, whole read.
+// NWR: the read's 32-nt words if known at compile time (0: nwr_rt); PLAIN: the read has no N — only its last word is masked, the words
+// before it take two v_bitop3 instead of three
+template <int NWR, bool PLAIN>
+__device__ __forceinline__ void same_counts(const uint32_t (&flo)[5], const uint32_t (&fhi)[5], uint32_t him, int nwr_rt, const uint4 &a0, const uint4 &a1, const uint4 &a2,
+                                            const uint4 &a3, uint32_t &w0ref, uint32_t &w01ref, uint32_t &tot)
+{
+    static_assert(NWR != 0 || !PLAIN, "the plain form needs the word count");
+    const int nwr = NWR ? NWR : nwr_rt;
+#define SAME_MM(j, X, Y, M) ((PLAIN && (j) < NWR - 1) ? bsx_plane_mismatch_full(flo[j], fhi[j], X, Y) : bsx_plane_mismatch(flo[j], fhi[j], X, Y, M))
+    const uint32_t m0 = SAME_MM(0, a0.x, a0.y, a0.z);
+    const uint32_t c0 = __popc(m0);
+    w0ref = __popc(m0 & him); tot = c0; w01ref = c0;
+    if (nwr > 1) {
+        const uint32_t m1 = SAME_MM(1, a0.w, a1.x, a1.y);
+        tot = popc_acc(m1, c0); w01ref = popc_acc(m1 & him, c0);
+        if (nwr > 2) {
+            tot = popc_acc(SAME_MM(2, a1.z, a1.w, a2.x), tot);
+            if (nwr > 3) {
+                tot = popc_acc(SAME_MM(3, a2.z, a2.w, a3.x), tot);
+                if (nwr > 4) tot = popc_acc(SAME_MM(4, a3.y, a3.z, a3.w), tot);
+            }
+        }
+    }
+#undef SAME_MM
+}
+
+// one group of K (2 .. HG_R) tasks: lane j < K holds task j's id, unit | slot and first list ordinal; they cover the n index entries
+// from `key` on with read offset `hh`.  NWR: 5 for reads of 129-160 nt (the code of the headline configuration), 0 for any length.
+template <int NWR>
+__device__ __forceinline__ void hs_group(const AlignArgs &A, const HeavyArgs &H, SameLds &L, int lane, int wv, uint32_t K, uint32_t tid, uint32_t th, uint32_t tc0,
+                                         uint32_t key, uint32_t n, uint32_t hh, uint32_t flags)
+{
+    const DevParams &P = A.P;
+    uint32_t *uw = &L.UW[wv][0][0];
+    const int nwr = NWR ? NWR : (int)((flags >> 8) & 15u);
+    if ((uint32_t)lane < K) {   // the read of this lane's task -> its row
+        const ListReq &R = H.state[th & 0x3fffffffu].req[th >> 30];
+        uint32_t *row = uw + (uint32_t)lane * 20u;
+        uint32_t inner = 0xFFFFFFFFu;   // the not-N planes of the words before the last
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+            const int f = 3 * j, o = j < 3 ? 0 : 1;
+            const uint32_t pm = R.pm[j];
+            row[f + o] = R.px[j]; row[f + 1 + o] = R.py[j]; row[f + 2 + o] = pm;
+            if (j < nwr - 1) inner &= pm;
+        }
+        row[9] = R.thres | (inner == 0xFFFFFFFFu ? 0x10000u : 0u); row[16] = tid; row[17] = tc0;
+    }
+    wave_fence();
+    const uint8_t *plane = reinterpret_cast<const uint8_t *>(P.refplane);
+    const uint32_t strand = flags & 1u, ref_off = strand ? P.plane_rc_off : 0u;
+    const uint32_t *ent = P.entries + key;
+    const uint32_t hm1 = hh - 1u;
+    uint32_t c15 = 0, nsv = 0;   // lane k: counters of read k — candidates beyond the first word | five-word candidates << 16; survivors
+    // one step = HG_C chunks of 64 candidates.  nx: the gathers of the coming step (issued a step earlier); en: the entries of the step after it
+    // (a lane without a candidate takes entry 1024: any position inside the copy)
+    constexpr uint32_t STEP = 64u * HG_C;
+    SameChunk nx[HG_C];
+    uint32_t en[HG_C];
+#if HG_PREFETCH
+#pragma unroll
+    for (int u = 0; u < HG_C; u++) { const uint32_t i0 = (uint32_t)(u * 64 + lane); nx[u] = same_load(i0 < n ? ent[i0] : 1024u, hm1, plane, ref_off, nwr); }
+#pragma unroll
+    for (int u = 0; u < HG_C; u++) { const uint32_t i1 = STEP + (uint32_t)(u * 64 + lane); en[u] = i1 < n ? ent[i1] : 1024u; }
+#else
+#pragma unroll
+    for (int u = 0; u < HG_C; u++) { const uint32_t i0 = (uint32_t)(u * 64 + lane); en[u] = i0 < n ? ent[i0] : 1024u; }
+#endif
+    for (uint32_t cb = 0; cb < n; cb += STEP) {
+#if !HG_PREFETCH
+#pragma unroll
+        for (int u = 0; u < HG_C; u++) nx[u] = same_load(en[u], hm1, plane, ref_off, nwr);
+#pragma unroll
+        for (int u = 0; u < HG_C; u++) { const uint32_t i1 = cb + STEP + (uint32_t)(u * 64 + lane); en[u] = i1 < n ? ent[i1] : 1024u; }
+#endif
+        // the candidates' reference planes in the read frame — the same for every read of the group
+        uint32_t flo[HG_C][5], fhi[HG_C][5], him[HG_C], hloc[HG_C], ordsh[HG_C];
+        u64 vm[HG_C];
+#pragma unroll
+        for (int u = 0; u < HG_C; u++) {
+            const SameChunk &c = nx[u];
+            const uint32_t wd[12] = {c.r0.a, c.r0.b, c.r0.c, c.r0.d, c.r1.a, c.r1.b, c.r1.c, c.r1.d, c.r2.a, c.r2.b, c.r2.c, c.r2.d};
+            const uint32_t shf = 31u - (c.pm1 & 31u);                     // 32 - ((pm1 & 31) + 1)
+            him[u] = 0xFFFFFFFFu << ((c.pm1 + 1u) & 15u);                 // read nt [0, 32 - k), k = position mod 16
+#pragma unroll
+            for (int t = 0; t < 5; t++) { flo[u][t] = __builtin_amdgcn_alignbit(wd[2 * t], wd[2 * t + 2], shf); fhi[u][t] = __builtin_amdgcn_alignbit(wd[2 * t + 1], wd[2 * t + 3], shf); }
+            hloc[u] = c.pm1 + 1u;
+            const uint32_t ord = cb + (uint32_t)(u * 64 + lane);
+            ordsh[u] = ord << 8;
+            vm[u] = bsx_ballot(ord < n);
+        }
+#if HG_PREFETCH
+        if (cb + STEP < n) {   // the next step's gathers fly while this step is evaluated, and the entries of the step after it
+#pragma unroll
+            for (int u = 0; u < HG_C; u++) nx[u] = same_load(en[u], hm1, plane, ref_off, nwr);
+#pragma unroll
+            for (int u = 0; u < HG_C; u++) { const uint32_t i2 = cb + 2u * STEP + (uint32_t)(u * 64 + lane); en[u] = i2 < n ? ent[i2] : 1024u; }
+        }
+#endif
+        for (uint32_t k = 0; k < K; k++) {
+            // (a 16-byte LDS read of a wave moves 1 KB, 8 cycles of the CU's LDS path: one read of the row per step, not per chunk)
+            const uint4 *row = reinterpret_cast<const uint4 *>(uw + k * 20u);
+            const uint4 a0 = row[0], a1 = row[1], a2 = row[2];  // X0 Y0 M0 X1 | Y1 M1 X2 Y2 | M2 threshold X3 Y3 | M3 X4 Y4 M4
+            uint4 a3 = make_uint4(0u, 0u, 0u, 0u);
+            if (nwr > 3) a3 = row[3];
+            const uint32_t tp = rfl(a2.y), thr = tp & 0xffffu;
+            const bool plain = NWR != 0 && (tp >> 16) != 0;
+            SurvRec *const sv = H.tout[rl_u(tid, k)].surv;   // (wave-uniform: the address arithmetic stays on the scalar unit)
+            uint32_t nsk = rl_u(nsv, k), add15 = 0;
+#pragma unroll
+            for (int u = 0; u < HG_C; u++) {
+                uint32_t w0ref, w01ref, tot;
+                if (plain) same_counts<NWR, NWR != 0>(flo[u], fhi[u], him[u], nwr, a0, a1, a2, a3, w0ref, w01ref, tot);
+                else same_counts<NWR, false>(flo[u], fhi[u], him[u], nwr, a0, a1, a2, a3, w0ref, w01ref, tot);
+                const u64 b1 = bsx_ballot(w0ref > thr) & vm[u], b5 = bsx_ballot(w01ref <= thr) & vm[u], bp = bsx_ballot(tot <= thr) & vm[u];
+                add15 += (uint32_t)__builtin_popcountll(b1) + ((uint32_t)__builtin_popcountll(b5) << 16);
+                if (bp) {
+                    const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(bp >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bp, nsk));
+                    if (__builtin_amdgcn_inverse_ballot_w64(bp) && pos < HS_SCAP) { SurvRec r; r.w_ord = tot | ordsh[u]; r.hchr = strand; r.hloc = hloc[u]; r.hkey = 0; sv[pos] = r; }
+                    nsk += (uint32_t)__builtin_popcountll(bp);
+                }
+            }
+            if ((uint32_t)lane == k) { c15 += add15; nsv = nsk; }
+        }
+    }
+    wave_fence();
+    // results: lane j < K holds read j's counters
+    const bool mine = (uint32_t)lane < K;
+    const uint32_t n1 = c15 & 0xffffu, n5 = c15 >> 16, ns = nsv;
+    const bool ov = ns > HS_SCAP;
+    if (mine) {
+        HTaskOut *o = &H.tout[tid];
+        o->count = ov ? 0 : ns; o->overflow = ov ? 1 : 0; o->acc[0] = n; o->acc[1] = 2u * n - n1 + 3u * n5; o->acc[2] = 0; o->acc[3] = 0; o->c0 = tc0; o->n = n;
+    }
+    const bool cnt = mine && !ov;
+    const uint32_t kk = (uint32_t)__builtin_popcountll(bsx_ballot(cnt));
+    const uint32_t s1 = wave_sum(cnt ? n1 : 0), s5 = wave_sum(cnt ? n5 : 0);
+    if (lane == 0 && kk) {   // (sharded statistics: see hscan_task)
+        u64 *sh = (u64 *)A.scan_stats + (size_t)((blockIdx.x * (uint32_t)HG_WPB + (uint32_t)wv) & 63u) * 8;
+        atomicAdd((u64 *)&sh[0], (u64)kk * n); atomicAdd((u64 *)&sh[1], 2ull * kk * n - s1 + 3ull * s5); atomicAdd((u64 *)&sh[2], (u64)s1); atomicAdd((u64 *)&sh[3], (u64)s5);
+        atomicAdd((u64 *)&sh[4], (u64)kk * n);   // counter 15: candidates evaluated in groups
+        atomicAdd((u64 *)&sh[5], (u64)kk * n * K); if (K >= 4) atomicAdd((u64 *)&sh[6], (u64)kk * n); if (K >= 8) atomicAdd((u64 *)&sh[7], (u64)kk * n);  // diagnostics (BSX_SIGHIST)
+    }
+    wave_fence();
+}
+
+// Groups are formed before the scan (k_task_groups, below): behind it H.order holds the members of a group next to each other,
+// H.ghead[slot] the size of the group that starts at scan slot `slot` and H.glist the slots at which groups start (their number in
+// H.glist[task_cap]).  One group per wave, as k_hscan takes one task per wave: the waves of a pass retire one by one, every
+// launched wave has work, and consecutive waves walk the groups of one window at the same time.
+__global__ __launch_bounds__(64 * HG_WPB, BSX_HSAME_WAVES) void k_hscan_same(AlignArgs A, HeavyArgs H)
+{
+    __shared__ SameLds L;
+    const int lane = threadIdx.x & 63, wv = (int)rfl(threadIdx.x >> 6);
+    const uint32_t n_groups = min(H.glist[H.task_cap], H.task_cap);
+    const uint32_t nvb = (n_groups + HG_WPB - 1) / HG_WPB;
+    for (uint32_t vb = blockIdx.x;; vb += gridDim.x) {
+        uint32_t b_;
+        const int st_ = bsx_order_block(vb, nvb, H.xcd_map >= 2 ? max(2u, H.xcd_map * BSX_HSCAN_WPB / HG_WPB / 4u) : H.xcd_map, b_);   // (a group is 4-5 tasks on average)
+        if (st_ == 2) break;
+        if (st_ == 1) continue;
+        const uint32_t g = b_ * HG_WPB + (uint32_t)wv;
+        if (g >= n_groups) continue;
+        const uint32_t slot = rfl(H.glist[g]);
+        const uint32_t K = rfl(H.ghead[slot]);
+        // lane j < K: task j of the group
+        uint32_t tid = 0, th = 0, tc0 = 0, tn = 0, key = 0, hh = 0, flags = 0;
+        if ((uint32_t)lane < K) {
+            tid = H.order[slot + lane];
+            const HTask tk = H.tasks[tid];
+            th = tk.h; tc0 = tk.c0; tn = tk.n; key = tk.key; hh = tk.sub_h; flags = tk.flags;
+        }
+        const uint32_t n0 = rfl(tn);
+        if (n0 == 0) {   // slots neutralised by a refused request: their units have not published a list
+            if ((uint32_t)lane < K) { HTaskOut *o = &H.tout[tid]; o->count = 0; o->overflow = 0; o->acc[0] = o->acc[1] = o->acc[2] = o->acc[3] = 0; o->c0 = 0; o->n = 0; }
+        } else if (K > 1) {
+            const uint32_t f0 = rfl(flags);
+            if (((f0 >> 8) & 15u) == 5u) hs_group<5>(A, H, L, lane, wv, K, tid, th, tc0, rfl(key), n0, rfl(hh), f0);
+            else hs_group<0>(A, H, L, lane, wv, K, tid, th, tc0, rfl(key), n0, rfl(hh), f0);
+        }
+        else hp_task(A, H, rfl(tid), lane, L.TAB[wv], L.PT[wv], L.Q[wv]);
+        wave_fence();
+    }
+}
+
+// The groups of a pass: a wave takes 64 consecutive slots of the scan order, splits their tasks into groups of up to HG_R with equal
+// (first entry, length, strand copy, read offset, read words) — any of the 64, not only neighbours —, writes the slots back with
+// the members of each group next to each other, in the order the groups were opened, and the group sizes into ghead.  Tasks
+// that span sub-ranges are groups of one; neutralised slots (n = 0) form one group.  The start slots of the groups go into glist, a wave's
+// groups next to each other, the waves' parts in the order their atomic additions arrive — nearly the scan order, which is all the
+// scan kernel needs (neighbouring waves on the same cache lines); glist[cap] counts them (zeroed by k_bin_scan).
+__global__ __launch_bounds__(256) void k_task_groups(const HTask *tasks, const uint32_t *n_tasks_ptr, uint32_t cap, uint32_t *order, uint32_t *ghead, uint32_t *glist)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t n_tasks = min(*n_tasks_ptr, cap);
+    for (uint32_t s0 = (blockIdx.x * 4u + (threadIdx.x >> 6)) * 64u; s0 < n_tasks; s0 += gridDim.x * 256u) {
+        const uint32_t nj = min(64u, n_tasks - s0);
+        uint32_t tid = 0, tn = 0, key = 0, hh = 0, flags = 0;
+        if ((uint32_t)lane < nj) {
+            tid = order[s0 + lane];
+            const HTask tk = tasks[tid];
+            tn = tk.n; key = tk.key; hh = tk.sub_h; flags = tk.flags;
+        }
+        u64 todo = bsx_ballot((uint32_t)lane < nj);
+        uint32_t off = 0, head = 0, dst = 0;
+        while (todo) {
+            const uint32_t i0 = (uint32_t)__builtin_ctzll(todo);
+            const uint32_t n0 = rl_u(tn, i0), f0 = rl_u(flags, i0), key0 = rl_u(key, i0), h0 = rl_u(hh, i0);
+            const bool pending = (todo >> lane) & 1;
+            u64 mem = 1ull << i0;
+            if (n0 == 0) mem = bsx_ballot(pending && tn == 0);
+            else if (f0 & 2u) {
+                const bool same = pending && tn == n0 && key == key0 && hh == h0 && flags == f0;
+                mem = bsx_ballot(same);
+                if ((uint32_t)__builtin_popcountll(mem) > HG_R) mem = bsx_ballot(same && (uint32_t)__builtin_popcountll(mem & lanemask_lt(lane)) < HG_R);
+            }
+            const uint32_t K = (uint32_t)__builtin_popcountll(mem);
+            if ((mem >> lane) & 1) dst = off + (uint32_t)__builtin_popcountll(mem & lanemask_lt(lane));
+            if ((uint32_t)lane == off) head = K;
+            off += K; todo &= ~mem;
+        }
+        if ((uint32_t)lane < nj) { order[s0 + dst] = tid; ghead[s0 + lane] = head; }
+        const u64 hm = bsx_ballot(head != 0);
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&glist[cap], (uint32_t)__builtin_popcountll(hm));
+        base = rfl(base);
+        if (head != 0) glist[base + (uint32_t)__builtin_popcountll(hm & lanemask_lt(lane))] = s0 + (uint32_t)lane;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // k_hscan_shared — RRBS: one pass of the reference over a window of candidates for up to HS_SHARE reads at once.
 // RRBS reads start at restriction sites, so the reads that fall into one repeat family walk the same bucket with the same
 // read offset h (align.cpp:175-252: one seed per segment, all starts 0): after the task sort, runs of tasks that cover
@@ -2950,7 +3236,7 @@ __device__ __forceinline__ SharedChunk shared_load(const U2 *__restrict__ ent2, 
 
 __global__ __launch_bounds__(256, BSX_HSHARED_WAVES) void k_hscan_shared(AlignArgs A, HeavyArgs H)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t UW[4][HS_SHARE][20];   // per read of the run: planes X, Y, M of words 0-4 (15), threshold, task id
+    __shared__ __attribute__((aligned(16))) uint32_t UW[4][HS_SHARE][20];   // per read of the run: X0 Y0 M0 X1 | Y1 M1 X2 Y2 | M2 threshold X3 Y3 | M3 X4 Y4 M4 | task id
     __shared__ uint32_t ANCH[BSX_LDS_CHR + 1];
     const DevParams &P = A.P;
     const int lane = threadIdx.x & 63, wv = (int)rfl(threadIdx.x >> 6);  // (the wave number as a scalar: what depends on it stays wave-uniform for the compiler)
@@ -3004,7 +3290,7 @@ __global__ __launch_bounds__(256, BSX_HSHARED_WAVES) void k_hscan_shared(AlignAr
                 if (f < 15) { const uint32_t j = f / 3u, c = f - 3u * j; v = c == 0 ? R.px[j] : c == 1 ? R.py[j] : R.pm[j]; }
                 else if (f == 15) v = R.thres;
                 else if (f == 16) v = tk;
-                UW[wv][k][f] = v;
+                UW[wv][k][f < 9 ? f : f < 15 ? f + 1u : f == 15 ? 9u : f] = v;   // the threshold behind word 2: reads of up to 96 nt need three of the row's 16-byte units
             }
         }
         uint32_t c15 = 0, nsv = 0;  // lane k: counters of read k (see the loop)
@@ -3027,8 +3313,12 @@ __global__ __launch_bounds__(256, BSX_HSHARED_WAVES) void k_hscan_shared(AlignAr
             const u64 vm = bsx_ballot(cur.valid);
             const uint4 *up = reinterpret_cast<const uint4 *>(UW[wv][0]);
             for (uint32_t k = 0; k < K; k++, up += 5) {
-                const uint4 a0 = up[0], a1 = up[1], a2 = up[2], a3 = up[3];  // X0 Y0 M0 X1 | Y1 M1 X2 Y2 | M2 X3 Y3 M3 | X4 Y4 M4 threshold
-                const uint32_t thr = a3.w;
+                // (a 16-byte LDS read of a wave moves 1 KB — 8 cycles of the CU's LDS path, which the 25-30 vector instructions of an evaluation do
+                //  not hide four times over: the fourth unit only for reads of more than 96 nt)
+                const uint4 a0 = up[0], a1 = up[1], a2 = up[2];  // X0 Y0 M0 X1 | Y1 M1 X2 Y2 | M2 threshold X3 Y3 | M3 X4 Y4 M4
+                uint4 a3 = make_uint4(0u, 0u, 0u, 0u);
+                if (nwr > 3) a3 = up[3];
+                const uint32_t thr = a2.y;
                 const uint32_t m0 = bsx_plane_mismatch(flo[0], fhi[0], a0.x, a0.y, a0.z);
                 const uint32_t c0 = __popc(m0);
                 const uint32_t w0ref = __popc(m0 & him);
@@ -3041,8 +3331,8 @@ __global__ __launch_bounds__(256, BSX_HSHARED_WAVES) void k_hscan_shared(AlignAr
                     if (nwr > 2 && (bsx_ballot(tot <= thr) & vm)) {
                         tot = popc_acc(bsx_plane_mismatch(flo[2], fhi[2], a1.z, a1.w, a2.x), tot);
                         if (nwr > 3) {
-                            tot = popc_acc(bsx_plane_mismatch(flo[3], fhi[3], a2.y, a2.z, a2.w), tot);
-                            if (nwr > 4) tot = popc_acc(bsx_plane_mismatch(flo[4], fhi[4], a3.x, a3.y, a3.z), tot);
+                            tot = popc_acc(bsx_plane_mismatch(flo[3], fhi[3], a2.z, a2.w, a3.x), tot);
+                            if (nwr > 4) tot = popc_acc(bsx_plane_mismatch(flo[4], fhi[4], a3.y, a3.z, a3.w), tot);
                         }
                     }
                 }
@@ -3320,6 +3610,14 @@ void bsx_launch_hscan_multi(const AlignArgs &A, const HeavyArgsRaw &R, hipStream
     hipLaunchKernelGGL(k_hscan_multi, dim3(blocks), dim3(64 * HM_WAVES), 0, stream, A, H);
 }
 
+void bsx_launch_hscan_same(const AlignArgs &A, const HeavyArgsRaw &R, hipStream_t stream, uint32_t max_tasks)
+{
+    const HeavyArgs H = typed(R);
+    uint32_t blocks = ((max_tasks ? std::min(max_tasks, R.task_cap) : R.task_cap) + HG_WPB - 1) / HG_WPB;
+    blocks = (blocks + 7u) & ~7u;  // the same number of blocks for each of the 8 XCDs (the sweep relies on a multiple of 8)
+    hipLaunchKernelGGL(k_hscan_same, dim3(blocks), dim3(64 * HG_WPB), 0, stream, A, H);
+}
+
 void bsx_launch_hscan(const AlignArgs &A, const HeavyArgsRaw &R, hipStream_t stream, uint32_t max_tasks)
 {
     const HeavyArgs H = typed(R);
@@ -3343,7 +3641,20 @@ namespace {
 // per microsecond (300-400 us per pass when every task went to the counter itself).  A block first counts its 1024 tasks per bin in
 // an LDS table and then adds each bin's count to memory once.
 #define BIN_LDS 2048u
-__global__ __launch_bounds__(256) void k_task_bins(const HTask *tasks, const uint32_t *n_tasks_ptr, uint32_t cap, uint32_t shift, uint32_t n_bins, uint32_t *bins,
+// the bin of a task.  spread: a task that lies inside one sub-range (the pieces of a giant bucket) owns the bins its entries cover; the
+// tasks of all the reads that walk that piece are dealt over those bins (up to 16) by their read offset h, so that the tasks k_hscan_same
+// can evaluate together — same window, same offset — arrive next to each other, while the order by index entry is kept.
+__device__ __forceinline__ uint32_t task_bin(const HTask &tk, uint32_t shift, uint32_t n_bins, uint32_t spread)
+{
+    uint32_t bin = tk.key >> shift;
+    if (spread && (tk.flags & 2u)) {
+        const uint32_t span = tk.n >> shift;
+        const uint32_t nb = span >= 16u ? 16u : span >= 8u ? 8u : span >= 4u ? 4u : span >= 2u ? 2u : 1u;
+        bin += ((tk.sub_h * 0x9E3779B1u) >> 28) & (nb - 1u);
+    }
+    return min(bin, n_bins - 1u);
+}
+__global__ __launch_bounds__(256) void k_task_bins(const HTask *tasks, const uint32_t *n_tasks_ptr, uint32_t cap, uint32_t shift, uint32_t n_bins, uint32_t spread, uint32_t *bins,
                                                     uint32_t *rank, uint32_t *zero_blk)
 {
     __shared__ uint32_t hkey[BIN_LDS], hcnt[BIN_LDS];
@@ -3358,7 +3669,7 @@ __global__ __launch_bounds__(256) void k_task_bins(const HTask *tasks, const uin
             const uint32_t i = chunk + (uint32_t)k * 256u + threadIdx.x;
             sl[k] = 0; lr[k] = 0;
             if (i < n) {
-                const uint32_t bin = min(tasks[i].key >> shift, n_bins - 1u);
+                const uint32_t bin = task_bin(tasks[i], shift, n_bins, spread);
                 uint32_t slot = (bin * 0x9E3779B1u) >> 21;  // 11 bits
                 for (;;) {
                     const uint32_t prev = atomicCAS(&hkey[slot], 0xffffffffu, bin);
@@ -3380,9 +3691,10 @@ __global__ __launch_bounds__(256) void k_task_bins(const HTask *tasks, const uin
         __syncthreads();
     }
 }
-__global__ __launch_bounds__(256) void k_bin_scan(const uint32_t *n_tasks_ptr, uint32_t *bins, uint32_t *bstart, uint32_t *chunk_tot, uint32_t n_bins)
+__global__ __launch_bounds__(256) void k_bin_scan(const uint32_t *n_tasks_ptr, uint32_t *bins, uint32_t *bstart, uint32_t *chunk_tot, uint32_t n_bins, uint32_t *zero_word)
 {
     __shared__ uint32_t part[256];
+    if (zero_word && blockIdx.x == 0 && threadIdx.x == 0) *zero_word = 0;   // the group count of this pass (k_task_groups)
     if (*n_tasks_ptr == 0) return;  // (all counts are zero and stay zero; nothing reads the starts)
     const uint32_t base = blockIdx.x * BIN_CHUNK + threadIdx.x * 8u;
     uint32_t v[8], sum = 0;
@@ -3401,7 +3713,7 @@ __global__ __launch_bounds__(256) void k_bin_scan(const uint32_t *n_tasks_ptr, u
     for (int k = 0; k < 8; k++) { if (base + k < n_bins) { bstart[base + k] = run; if (v[k]) bins[base + k] = 0; } run += v[k]; }
     if (threadIdx.x == 255) chunk_tot[blockIdx.x] = part[255];
 }
-__global__ __launch_bounds__(256) void k_task_order(const HTask *tasks, const uint32_t *n_tasks_ptr, uint32_t cap, uint32_t shift, uint32_t n_bins, const uint32_t *bstart,
+__global__ __launch_bounds__(256) void k_task_order(const HTask *tasks, const uint32_t *n_tasks_ptr, uint32_t cap, uint32_t shift, uint32_t n_bins, uint32_t spread, const uint32_t *bstart,
                                                      const uint32_t *chunk_tot, uint32_t n_chunks, const uint32_t *rank, uint32_t *order)
 {
     __shared__ uint32_t cstart[1024];
@@ -3418,7 +3730,7 @@ __global__ __launch_bounds__(256) void k_task_order(const HTask *tasks, const ui
         __syncthreads();
     }
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const uint32_t b = min(tasks[i].key >> shift, n_bins - 1u), c = b / BIN_CHUNK;
+        const uint32_t b = task_bin(tasks[i], shift, n_bins, spread), c = b / BIN_CHUNK;
         order[(c ? cstart[c - 1] : 0u) + bstart[b] + rank[i]] = i;
     }
 }
@@ -3429,12 +3741,90 @@ uint32_t bsx_bin_chunks(uint32_t n_bins) { return (n_bins + BIN_CHUNK - 1) / BIN
 // bins: [n_bins] zero on entry and on exit; bstart: [n_bins]; chunk_tot: [bsx_bin_chunks(n_bins)] (<= 1024 chunks); rank, order: [task_cap];
 // zero_blk: four words to clear (or null)
 void bsx_launch_task_order(const HeavyArgsRaw &R, uint32_t shift, uint32_t n_bins, uint32_t *bins, uint32_t *bstart, uint32_t *chunk_tot, uint32_t *rank, uint32_t *order,
-                           uint32_t *zero_blk, hipStream_t stream)
+                           uint32_t *zero_blk, hipStream_t stream, uint32_t spread, bool groups)
 {
     const uint32_t grid = std::max(1u, std::min(512u, (R.task_cap + 255u) / 256u)), n_chunks = bsx_bin_chunks(n_bins);
-    hipLaunchKernelGGL(k_task_bins, dim3(std::max(1u, std::min(256u, (R.task_cap + 1023u) / 1024u))), dim3(256), 0, stream, (const HTask *)R.tasks, R.n_tasks, R.task_cap, shift, n_bins, bins, rank, zero_blk);
-    hipLaunchKernelGGL(k_bin_scan, dim3(n_chunks), dim3(256), 0, stream, R.n_tasks, bins, bstart, chunk_tot, n_bins);
-    hipLaunchKernelGGL(k_task_order, dim3(grid), dim3(256), 0, stream, (const HTask *)R.tasks, R.n_tasks, R.task_cap, shift, n_bins, bstart, chunk_tot, n_chunks, rank, order);
+    hipLaunchKernelGGL(k_task_bins, dim3(std::max(1u, std::min(256u, (R.task_cap + 1023u) / 1024u))), dim3(256), 0, stream, (const HTask *)R.tasks, R.n_tasks, R.task_cap, shift, n_bins, spread, bins, rank, zero_blk);
+    hipLaunchKernelGGL(k_bin_scan, dim3(n_chunks), dim3(256), 0, stream, R.n_tasks, bins, bstart, chunk_tot, n_bins, groups ? const_cast<uint32_t *>(R.glist) + R.task_cap : (uint32_t *)nullptr);
+    hipLaunchKernelGGL(k_task_order, dim3(grid), dim3(256), 0, stream, (const HTask *)R.tasks, R.n_tasks, R.task_cap, shift, n_bins, spread, bstart, chunk_tot, n_chunks, rank, order);
+    // (the ranks are spent: their array takes the group sizes)
+    if (groups) hipLaunchKernelGGL(k_task_groups, dim3(std::max(1u, std::min(1024u, (R.task_cap + 255u) / 256u))), dim3(256), 0, stream, (const HTask *)R.tasks, R.n_tasks, R.task_cap, order, rank, const_cast<uint32_t *>(R.glist));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Diagnostics (BSX_SIGHIST=1, bsx_api.hip): per pass, how many tasks cover exactly the same window (first entry, length, strand copy)
+// with the same read offset h — the tasks that could share one fetch AND one shift of the candidates' reference.  Candidates are
+// counted by the size R of their task's group: hist[k] for R in (2^(k-1), 2^k], hist[31] for tasks that span sub-ranges.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+__device__ __forceinline__ unsigned long long sig_of(const HTask &tk, bool with_h)
+{
+    unsigned long long x = ((unsigned long long)tk.key << 32) ^ ((unsigned long long)tk.n << 9) ^ (tk.flags & 1u) ^ (with_h ? (unsigned long long)tk.sub_h * 0x9E3779B97F4A7C15ull : 0ull);
+    x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32;
+    return x | 1ull;
+}
+__global__ __launch_bounds__(256) void k_sig_count(const HTask *tasks, const uint32_t *n_tasks_ptr, uint32_t cap, unsigned long long *tab, uint32_t mask, int with_h)
+{
+    const uint32_t n = min(*n_tasks_ptr, cap);
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const HTask tk = tasks[i];
+        if (!tk.n || !(tk.flags & 2u)) continue;
+        const unsigned long long sg = sig_of(tk, with_h != 0);
+        for (uint32_t slot = (uint32_t)(sg >> 20) & mask;; slot = (slot + 1) & mask) {
+            const unsigned long long prev = atomicCAS(&tab[2 * (size_t)slot], 0ull, sg);
+            if (prev == 0ull || prev == sg) { atomicAdd(&tab[2 * (size_t)slot + 1], 1ull); break; }
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_sig_hist(const HTask *tasks, const uint32_t *n_tasks_ptr, uint32_t cap, const unsigned long long *tab, uint32_t mask, int with_h, unsigned long long *hist)
+{
+    const uint32_t n = min(*n_tasks_ptr, cap);
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const HTask tk = tasks[i];
+        if (!tk.n) continue;
+        uint32_t k = 31;
+        if (tk.flags & 2u) {
+            const unsigned long long sg = sig_of(tk, with_h != 0);
+            uint32_t slot = (uint32_t)(sg >> 20) & mask;
+            while (tab[2 * (size_t)slot] != sg) slot = (slot + 1) & mask;
+            const unsigned long long r = tab[2 * (size_t)slot + 1];
+            k = r <= 1 ? 0u : 32u - (uint32_t)__builtin_clz((uint32_t)r - 1u);
+        }
+        atomicAdd(&hist[k], (unsigned long long)tk.n);
+        atomicAdd(&hist[32 + k], 1ull);
+    }
+}
+unsigned long long *g_sig_tab = nullptr, *g_sig_hist = nullptr;
+const uint32_t SIG_SLOTS = 1u << 23;
+}  // namespace
+
+void bsx_sig_hist_pass(const HeavyArgsRaw &R, hipStream_t stream)
+{
+    if (!g_sig_tab) {
+        if (hipMalloc((void **)&g_sig_tab, (size_t)SIG_SLOTS * 16) != hipSuccess || hipMalloc((void **)&g_sig_hist, 2 * 64 * 8) != hipSuccess) { g_sig_tab = nullptr; return; }
+        (void)hipMemsetAsync(g_sig_hist, 0, 2 * 64 * 8, stream);
+    }
+    for (int with_h = 0; with_h < 2; with_h++) {
+        (void)hipMemsetAsync(g_sig_tab, 0, (size_t)SIG_SLOTS * 16, stream);
+        hipLaunchKernelGGL(k_sig_count, dim3(1024), dim3(256), 0, stream, (const HTask *)R.tasks, R.n_tasks, R.task_cap, g_sig_tab, SIG_SLOTS - 1, with_h);
+        hipLaunchKernelGGL(k_sig_hist, dim3(1024), dim3(256), 0, stream, (const HTask *)R.tasks, R.n_tasks, R.task_cap, g_sig_tab, SIG_SLOTS - 1, with_h, g_sig_hist + 64 * with_h);
+    }
+}
+
+void bsx_sig_hist_report(void)
+{
+    if (!g_sig_tab) return;
+    unsigned long long h[128];
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(h, g_sig_hist, sizeof h, hipMemcpyDeviceToHost) != hipSuccess) return;
+    for (int with_h = 0; with_h < 2; with_h++) {
+        unsigned long long tot = 0, tt = 0;
+        for (int k = 0; k < 32; k++) { tot += h[64 * with_h + k]; tt += h[64 * with_h + 32 + k]; }
+        fprintf(stderr, "[sighist] same window%s: candidates %llu tasks %llu\n", with_h ? " and offset" : "", tot, tt);
+        for (int k = 0; k < 32; k++)
+            if (h[64 * with_h + 32 + k])
+                fprintf(stderr, "[sighist]   %s %-6u cand %.4f tasks %.4f\n", k == 31 ? "spanning" : "R <=", k == 31 ? 0u : 1u << k, (double)h[64 * with_h + k] / (double)std::max(1ull, tot), (double)h[64 * with_h + 32 + k] / (double)std::max(1ull, tt));
+    }
+    (void)hipMemset(g_sig_hist, 0, 2 * 64 * 8);
 }
 
 size_t bsx_hstate_bytes(void) { return sizeof(HState); }

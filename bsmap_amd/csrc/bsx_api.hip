@@ -240,7 +240,7 @@ struct bsx_batch {
     struct Group {
         hipStream_t s_ctrl = nullptr;
         hipEvent_t ev_ctrl = nullptr, ev_scan = nullptr, ev_poll[BSX_POLL_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
-        uint32_t *d_bins = nullptr, *d_bstart = nullptr, *d_chunk_tot = nullptr, *d_rank = nullptr, *d_order = nullptr;
+        uint32_t *d_bins = nullptr, *d_bstart = nullptr, *d_chunk_tot = nullptr, *d_rank = nullptr, *d_order = nullptr, *d_glist = nullptr;
     } grp[BSX_MAX_GROUPS];
     int n_groups = 1, chunk_passes = 2, trace = 0, hctrl_blocks_per_cu = 1;
     uint32_t tail_tasks = 16384, tail_grid_tasks = 4096;  // a group whose passes publish fewer tasks than tail_tasks scans them with a grid for tail_grid_tasks on its control stream
@@ -263,6 +263,7 @@ struct bsx_batch {
     uint8_t *d_hstate = nullptr, *d_hslabs = nullptr, *d_htasks = nullptr, *d_htout = nullptr;
     uint32_t *d_hactive[2] = {nullptr, nullptr}, *d_hcnt = nullptr;  // d_hcnt: per group two ping-pong blocks {n_active, n_tasks, queue[2]}
     uint32_t hcap = 0, task_cap = 0;
+    bool sig_hist = false;    // diagnostics: histogram of tasks per identical window (bsx_sig_hist_pass)
     uint32_t xcd_map = 128;   // order_block (bsx_align.hip): pieces of 128 scan blocks dealt to the XCDs in turn
     uint32_t *h_pinned = nullptr;  // pinned host words for the per-pass count read-backs
     int n_cu = 0;
@@ -386,7 +387,7 @@ static int ensure_scratch(bsx_batch *b)
             for (void **q : ptrs) { if (*q) (void)hipFree(*q); *q = nullptr; }
             for (int g = 0; g < b->n_groups; g++) {
                 bsx_batch::Group &q = b->grp[g];
-                void **gp[] = {(void **)&q.d_bins, (void **)&q.d_bstart, (void **)&q.d_chunk_tot, (void **)&q.d_rank, (void **)&q.d_order};
+                void **gp[] = {(void **)&q.d_bins, (void **)&q.d_bstart, (void **)&q.d_chunk_tot, (void **)&q.d_rank, (void **)&q.d_order, (void **)&q.d_glist};
                 for (void **x : gp) { if (*x) (void)hipFree(*x); *x = nullptr; }
             }
         };
@@ -406,6 +407,7 @@ static int ensure_scratch(bsx_batch *b)
                 POOL_TRY(hipMalloc((void **)&q.d_chunk_tot, (size_t)bsx_bin_chunks(b->n_bins) * 4));
                 POOL_TRY(hipMalloc((void **)&q.d_rank, (size_t)tcap * 4));
                 POOL_TRY(hipMalloc((void **)&q.d_order, (size_t)tcap * 4));
+                POOL_TRY(hipMalloc((void **)&q.d_glist, ((size_t)tcap + 4) * 4));   // (k_hscan_same: start slots of the groups, then their count)
             }
 #undef POOL_TRY
             return hipSuccess;
@@ -455,6 +457,7 @@ extern "C" int bsx_batch_create(bsx_ref *r, uint32_t max_units, int paired, bsx_
     if (const char *e = getenv("BSX_XCD_MAP")) b->xcd_map = (uint32_t)std::max(0, atoi(e));   // how k_hscan's blocks map onto the scan order: 0 as dispatched, 1 one contiguous eighth per XCD, N >= 2 pieces of N blocks dealt to the XCDs in turn
     if (const char *e = getenv("BSX_HEAVY_CHUNK")) b->chunk_passes = std::max(1, std::min(64, atoi(e)));
     b->trace = getenv("BSX_TRACE_HEAVY") != nullptr;
+    b->sig_hist = getenv("BSX_SIGHIST") != nullptr;
     if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) return fail(BSX_ERR_DEVICE);
     {
         int lo_p = 0, hi_p = 0;
@@ -496,6 +499,7 @@ extern "C" void bsx_batch_destroy(bsx_batch *b)
     if (!b) return;
     (void)hipSetDevice(b->ref->device);
     if (b->stream) (void)hipStreamSynchronize(b->stream);
+    if (b->sig_hist) bsx_sig_hist_report();
     for (int m = 0; m < 2; m++)
         for (void *q : {(void *)b->d_seq[m], (void *)b->d_qual[m], (void *)b->d_off[m], (void *)b->d_cc[m]})
             if (q) (void)hipFree(q);
@@ -511,7 +515,7 @@ extern "C" void bsx_batch_destroy(bsx_batch *b)
         bsx_batch::Group &q = b->grp[g];
         if (q.s_ctrl) { (void)hipStreamSynchronize(q.s_ctrl); (void)hipStreamDestroy(q.s_ctrl); }
         for (hipEvent_t e : {q.ev_ctrl, q.ev_scan, q.ev_poll[0], q.ev_poll[1], q.ev_poll[2], q.ev_poll[3]}) if (e) (void)hipEventDestroy(e);
-        for (void *p_ : {(void *)q.d_bins, (void *)q.d_bstart, (void *)q.d_chunk_tot, (void *)q.d_rank, (void *)q.d_order}) if (p_) (void)hipFree(p_);
+        for (void *p_ : {(void *)q.d_bins, (void *)q.d_bstart, (void *)q.d_chunk_tot, (void *)q.d_rank, (void *)q.d_order, (void *)q.d_glist}) if (p_) (void)hipFree(p_);
     }
     if (b->ev_sync) (void)hipEventDestroy(b->ev_sync);
     if (b->ev_wait) (void)hipEventDestroy(b->ev_wait);
@@ -741,6 +745,9 @@ extern "C" int bsx_batch_run_range(bsx_batch *b, uint32_t first_unit, uint32_t n
         // 98 % of the candidates run that way and the texture path falls from 0.72 to 0.12 busy, but the kernel spends 53 instead of 42 vector
         // instructions per 64 candidates and its waves wait at two barriers per round: 356 against 491 G candidates/s (profiles/r04g_*)
         const bool multi_scan = !shared_scan && getenv("BSX_MULTI") && atoi(getenv("BSX_MULTI")) == 1;
+        // WGBS, BSX_SAME=1: the tasks of one window AND read offset share fetch and shift (k_hscan_same)
+        const bool same_scan = !shared_scan && !multi_scan && getenv("BSX_SAME") && atoi(getenv("BSX_SAME")) == 1;
+        const uint32_t spread = getenv("BSX_SPREAD") ? (uint32_t)atoi(getenv("BSX_SPREAD")) : (same_scan ? 1u : 0u);
         const int n_groups = b->n_groups;
         struct Group { uint32_t n0 = 0, passes = 0, polls = 0, polled = 0; int cur = 0; bool done = true, tail = false; HeavyArgsRaw H; uint32_t *blk[2]; };
         volatile uint32_t *pinned = (volatile uint32_t *)b->h_pinned;
@@ -765,13 +772,14 @@ extern "C" int bsx_batch_run_range(bsx_batch *b, uint32_t first_unit, uint32_t n
                 bsx_launch_hctrl(A, q.H, b->paired, (int)std::min<uint32_t>((q.n0 + 3) / 4, (uint32_t)b->n_cu * b->hctrl_blocks_per_cu), hw.s_ctrl);
                 HIP_TRY(hipGetLastError());
                 // scan order of the tasks this pass published, still on the group's stream: done by the time the main stream gets to the scan
-                q.H.order = hw.d_order; q.H.xcd_map = b->xcd_map;
-                bsx_launch_task_order(q.H, b->bin_shift, b->n_bins, hw.d_bins, hw.d_bstart, hw.d_chunk_tot, hw.d_rank, hw.d_order, in, hw.s_ctrl);
+                q.H.order = hw.d_order; q.H.xcd_map = b->xcd_map; q.H.ghead = hw.d_rank; q.H.glist = hw.d_glist;
+                bsx_launch_task_order(q.H, b->bin_shift, b->n_bins, hw.d_bins, hw.d_bstart, hw.d_chunk_tot, hw.d_rank, hw.d_order, in, hw.s_ctrl, spread, same_scan);
                 // The scan: on the batch's stream with a grid for the whole task pool — or, once the group is in its tail (few tasks per
                 // pass, see the poll loop), behind the control kernel on the group's own high-priority stream with a small grid whose
                 // blocks sweep: beside ANOTHER batch's bulk scans a pool-sized grid of mostly empty blocks only trickles through the
                 // dispatcher, which stretched the tail of the older batch until the younger one's bulk was done — two batches in flight
                 // always finished together, and their transfers never overlapped the other's kernels.
+                if (b->sig_hist) bsx_sig_hist_pass(q.H, hw.s_ctrl);
                 hipStream_t s_scan = b->stream;
                 if (q.tail) s_scan = hw.s_ctrl;
                 else {
@@ -785,6 +793,7 @@ extern "C" int bsx_batch_run_range(bsx_batch *b, uint32_t first_unit, uint32_t n
                 }
                 HIP_TRY(hipEventRecord(b->scan_ev[b->scan_ev_used], s_scan));
                 if (shared_scan) bsx_launch_hscan_shared(A, q.H, s_scan, q.tail ? b->tail_grid_tasks : 0);
+                else if (same_scan) bsx_launch_hscan_same(A, q.H, s_scan, q.tail ? b->tail_grid_tasks : 0);
                 else if (multi_scan) bsx_launch_hscan_multi(A, q.H, s_scan, q.tail ? b->tail_grid_tasks : 0);
                 else bsx_launch_hscan(A, q.H, s_scan, q.tail ? b->tail_grid_tasks : 0);
                 HIP_TRY(hipGetLastError());
@@ -935,7 +944,11 @@ extern "C" int bsx_batch_counters(bsx_batch *b, uint64_t c[BSX_N_COUNTERS])
     HIP_TRY(hipMemcpy(c, b->d_counters, BSX_N_COUNTERS * 8, hipMemcpyDeviceToHost));
     uint64_t sh[64 * 8];
     HIP_TRY(hipMemcpy(sh, b->d_scan_stats, sizeof(sh), hipMemcpyDeviceToHost));
-    for (int i = 0; i < 64; i++) { for (int k = 0; k < 4; k++) c[7 + k] += sh[i * 8 + k]; c[15] += sh[i * 8 + 4]; }
+    uint64_t dg[3] = {0, 0, 0};
+    for (int i = 0; i < 64; i++) { for (int k = 0; k < 4; k++) c[7 + k] += sh[i * 8 + k]; c[15] += sh[i * 8 + 4]; for (int k = 0; k < 3; k++) dg[k] += sh[i * 8 + 5 + k]; }
+    if (b->sig_hist && c[15])
+        fprintf(stderr, "[sighist] scan kernel: %.4f of the candidates in groups, mean group %.2f reads, in groups of >= 4 %.4f, >= 8 %.4f\n", (double)c[15] / (double)std::max<uint64_t>(1, c[7]),
+                (double)dg[0] / (double)c[15], (double)dg[1] / (double)c[7], (double)dg[2] / (double)c[7]);
     return BSX_OK;
 }
 extern "C" int bsx_batch_reset_counters(bsx_batch *b)

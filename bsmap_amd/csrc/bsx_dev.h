@@ -65,6 +65,16 @@ __host__ __device__ inline uint32_t bsx_plane_mismatch(uint32_t rlo, uint32_t rh
 #endif
 }
 
+// the same for a word of the read without N and without the read's end (M all ones): two instructions
+__host__ __device__ inline uint32_t bsx_plane_mismatch_full(uint32_t rlo, uint32_t rhi, uint32_t X, uint32_t Y)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_bitop3_b32(__builtin_amdgcn_bitop3_b32(rhi, Y, X, 0x34), rlo, X, 0xF6);   // b | (rlo ^ X)
+#else
+    return (rlo ^ X) | ((rhi ^ Y) & ~(X & Y));
+#endif
+}
+
 // The scan kernel keeps, per task, the read pre-shifted by every s = 0..31 nt (s = candidate position mod 32), so that a
 // candidate's reference pairs are compared where they lie — the reference's own scheme (16 shifted copies of the read,
 // align.cpp:107-161) on 32-nt planes.  Word j of the read shifted by s: its nt i sits at frame position s + i.

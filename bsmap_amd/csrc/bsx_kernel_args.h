@@ -57,6 +57,7 @@ struct HeavyArgsRaw {
     uint32_t n_active_in, task_cap, fresh, list_base, hidx_base;
     const uint32_t *order;     // task ids in scan order (sorted by the index entry they start at), or null
     uint32_t xcd_map;
+    const uint32_t *ghead, *glist;   // k_hscan_same: group sizes by scan slot, start slots of the groups [task_cap] + their count (bsx_launch_task_order with groups)
 };
 
 void bsx_launch_align(const AlignArgs &A, int paired, int grid_blocks, hipStream_t stream);
@@ -67,11 +68,14 @@ uint32_t bsx_leak_blk(void);
 void bsx_launch_hctrl(const AlignArgs &A, const HeavyArgsRaw &H, int paired, int grid_blocks, hipStream_t stream);
 void bsx_launch_hscan(const AlignArgs &A, const HeavyArgsRaw &H, hipStream_t stream, uint32_t max_tasks = 0);         // grid sized for H.task_cap (or max_tasks: the blocks sweep); the count stays on the device
 void bsx_launch_hscan_multi(const AlignArgs &A, const HeavyArgsRaw &H, hipStream_t stream, uint32_t max_tasks = 0);   // WGBS: runs of tasks over one window, four waves x four reads per block
+void bsx_launch_hscan_same(const AlignArgs &A, const HeavyArgsRaw &H, hipStream_t stream, uint32_t max_tasks = 0);    // WGBS: tasks of one window and read offset share fetch and shift
 void bsx_launch_hscan_shared(const AlignArgs &A, const HeavyArgsRaw &H, hipStream_t stream, uint32_t max_tasks = 0);  // RRBS: up to 16 tasks of one window per wave
 // scan order of a pass (task ids by the index entry they start at, 2^shift entries per bin), computed on the device
 uint32_t bsx_bin_chunks(uint32_t n_bins);
 void bsx_launch_task_order(const HeavyArgsRaw &H, uint32_t shift, uint32_t n_bins, uint32_t *bins, uint32_t *bstart, uint32_t *chunk_tot, uint32_t *rank, uint32_t *order,
-                           uint32_t *zero_blk, hipStream_t stream);
+                           uint32_t *zero_blk, hipStream_t stream, uint32_t spread = 0, bool groups = false);   // spread: tasks inside one sub-range are dealt over the bins they cover by their read offset (k_hscan_same)
+void bsx_sig_hist_pass(const HeavyArgsRaw &H, hipStream_t stream);   // diagnostics, BSX_SIGHIST=1
+void bsx_sig_hist_report(void);
 size_t bsx_hstate_bytes(void);
 size_t bsx_htask_bytes(void);
 size_t bsx_htaskout_bytes(void);
