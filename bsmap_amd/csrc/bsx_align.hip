@@ -2923,13 +2923,17 @@ __global__ __launch_bounds__(64 * HM_WAVES, 4) void k_hscan_multi(AlignArgs A, H
 // Groups of one task, and tasks that span sub-ranges, go one per wave through hp_task.  Results per task are exactly k_hscan's.
 // ---------------------------------------------------------------------------------------------------------------
 #ifndef HG_WPB
-#define HG_WPB 2        /* waves (= groups) per block */
+#define HG_WPB 1        /* waves (= groups) per block: 1 measured best (1: 96.0-98.9, 2: 101.7-102.2, 4: 110.9 ms per step) — a block gives its slot back when its LAST wave ends */
 #endif
 #ifndef HG_R
 #define HG_R 16u        /* tasks per group at most */
 #endif
 #ifndef HG_C
 #define HG_C 2          /* chunks per step */
+#endif
+#ifndef HG_BIG
+#define HG_BIG 1u       /* groups of this many tasks and more are started first, the others fill the tail of the launch.  1 = plain scan order, measured best:
+                           from 4 tasks 103.5-104.2 against 99.4-100.3 ms per step, from 8 103.0 — the long groups of all windows at once lose the shared cache lines */
 #endif
 #ifndef HG_PREFETCH
 #define HG_PREFETCH 1   /* the gathers of a step are issued a step earlier (13 registers per chunk) */
@@ -3113,7 +3117,7 @@ __global__ __launch_bounds__(64 * HG_WPB, BSX_HSAME_WAVES) void k_hscan_same(Ali
 {
     __shared__ SameLds L;
     const int lane = threadIdx.x & 63, wv = (int)rfl(threadIdx.x >> 6);
-    const uint32_t n_groups = min(H.glist[H.task_cap], H.task_cap);
+    const uint32_t n_big = min(H.glist[H.task_cap], H.task_cap), n_groups = min(n_big + H.glist[H.task_cap + 1], H.task_cap);
     const uint32_t nvb = (n_groups + HG_WPB - 1) / HG_WPB;
     for (uint32_t vb = blockIdx.x;; vb += gridDim.x) {
         uint32_t b_;
@@ -3122,7 +3126,7 @@ __global__ __launch_bounds__(64 * HG_WPB, BSX_HSAME_WAVES) void k_hscan_same(Ali
         if (st_ == 1) continue;
         const uint32_t g = b_ * HG_WPB + (uint32_t)wv;
         if (g >= n_groups) continue;
-        const uint32_t slot = rfl(H.glist[g]);
+        const uint32_t slot = rfl(H.glist[g < n_big ? g : H.task_cap - 1u - (g - n_big)]);   // the groups of HG_BIG tasks and more first: the short ones fill the tail of the launch
         const uint32_t K = rfl(H.ghead[slot]);
         // lane j < K: task j of the group
         uint32_t tid = 0, th = 0, tc0 = 0, tn = 0, key = 0, hh = 0, flags = 0;
@@ -3149,7 +3153,7 @@ __global__ __launch_bounds__(64 * HG_WPB, BSX_HSAME_WAVES) void k_hscan_same(Ali
 // the members of each group next to each other, in the order the groups were opened, and the group sizes into ghead.  Tasks
 // that span sub-ranges are groups of one; neutralised slots (n = 0) form one group.  The start slots of the groups go into glist, a wave's
 // groups next to each other, the waves' parts in the order their atomic additions arrive — nearly the scan order, which is all the
-// scan kernel needs (neighbouring waves on the same cache lines); glist[cap] counts them (zeroed by k_bin_scan).
+// scan kernel needs (neighbouring waves on the same cache lines); glist[cap], glist[cap + 1] count them (zeroed by k_bin_scan).
 __global__ __launch_bounds__(256) void k_task_groups(const HTask *tasks, const uint32_t *n_tasks_ptr, uint32_t cap, uint32_t *order, uint32_t *ghead, uint32_t *glist)
 {
     const int lane = threadIdx.x & 63;
@@ -3181,11 +3185,14 @@ __global__ __launch_bounds__(256) void k_task_groups(const HTask *tasks, const u
             off += K; todo &= ~mem;
         }
         if ((uint32_t)lane < nj) { order[s0 + dst] = tid; ghead[s0 + lane] = head; }
-        const u64 hm = bsx_ballot(head != 0);
+        // groups of HG_BIG tasks and more from the front of glist, the others from its back (they cannot meet: a slot starts at most one group)
+        const u64 hb = bsx_ballot(head >= HG_BIG), hs = bsx_ballot(head != 0 && head < HG_BIG);
         uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&glist[cap], (uint32_t)__builtin_popcountll(hm));
-        base = rfl(base);
-        if (head != 0) glist[base + (uint32_t)__builtin_popcountll(hm & lanemask_lt(lane))] = s0 + (uint32_t)lane;
+        if (lane == 0 && hb) base = atomicAdd(&glist[cap], (uint32_t)__builtin_popcountll(hb));
+        if (lane == 1 && hs) base = atomicAdd(&glist[cap + 1], (uint32_t)__builtin_popcountll(hs));
+        const uint32_t base_b = rl_u(base, 0), base_s = rl_u(base, 1);
+        if (head >= HG_BIG) glist[base_b + (uint32_t)__builtin_popcountll(hb & lanemask_lt(lane))] = s0 + (uint32_t)lane;
+        else if (head != 0) glist[cap - 1u - (base_s + (uint32_t)__builtin_popcountll(hs & lanemask_lt(lane)))] = s0 + (uint32_t)lane;
     }
 }
 
@@ -3694,7 +3701,7 @@ __global__ __launch_bounds__(256) void k_task_bins(const HTask *tasks, const uin
 __global__ __launch_bounds__(256) void k_bin_scan(const uint32_t *n_tasks_ptr, uint32_t *bins, uint32_t *bstart, uint32_t *chunk_tot, uint32_t n_bins, uint32_t *zero_word)
 {
     __shared__ uint32_t part[256];
-    if (zero_word && blockIdx.x == 0 && threadIdx.x == 0) *zero_word = 0;   // the group count of this pass (k_task_groups)
+    if (zero_word && blockIdx.x == 0 && threadIdx.x < 2) zero_word[threadIdx.x] = 0;   // the group counts of this pass (k_task_groups)
     if (*n_tasks_ptr == 0) return;  // (all counts are zero and stay zero; nothing reads the starts)
     const uint32_t base = blockIdx.x * BIN_CHUNK + threadIdx.x * 8u;
     uint32_t v[8], sum = 0;

@@ -376,7 +376,8 @@ static int ensure_scratch(bsx_batch *b)
         // scan order of a pass: bins of 2^shift index entries, at most 2^20 of them (bsx_launch_task_order)
         const uint64_t ne = std::max<uint64_t>(1, b->ref->n_entries);
         b->bin_shift = 0;
-        const uint32_t bin_log2 = getenv("BSX_BIN_LOG2") ? (uint32_t)std::max(8, std::min(21, atoi(getenv("BSX_BIN_LOG2")))) : 20u;  // tuning knob
+        // (WGBS: 2^21 — the tasks of one window are dealt over the bins it covers by read offset, for k_hscan_same: 16 bins of 512 entries per window)
+        const uint32_t bin_log2 = getenv("BSX_BIN_LOG2") ? (uint32_t)std::max(8, std::min(21, atoi(getenv("BSX_BIN_LOG2")))) : (b->ref->P.rrbs ? 20u : 21u);  // tuning knob
         while (((ne >> b->bin_shift) + 1) > (1u << bin_log2)) b->bin_shift++;
         b->n_bins = (uint32_t)(ne >> b->bin_shift) + 1;
         // The pools proper.  Their default sizes are for a device that holds two or three batches (31 GB each for WGBS, 74 GB for RRBS);
@@ -745,8 +746,8 @@ extern "C" int bsx_batch_run_range(bsx_batch *b, uint32_t first_unit, uint32_t n
         // 98 % of the candidates run that way and the texture path falls from 0.72 to 0.12 busy, but the kernel spends 53 instead of 42 vector
         // instructions per 64 candidates and its waves wait at two barriers per round: 356 against 491 G candidates/s (profiles/r04g_*)
         const bool multi_scan = !shared_scan && getenv("BSX_MULTI") && atoi(getenv("BSX_MULTI")) == 1;
-        // WGBS, BSX_SAME=1: the tasks of one window AND read offset share fetch and shift (k_hscan_same)
-        const bool same_scan = !shared_scan && !multi_scan && getenv("BSX_SAME") && atoi(getenv("BSX_SAME")) == 1;
+        // WGBS: the tasks of one window AND read offset share fetch and shift (k_hscan_same); BSX_SAME=0: one task per wave (k_hscan)
+        const bool same_scan = !shared_scan && !multi_scan && !(getenv("BSX_SAME") && atoi(getenv("BSX_SAME")) == 0);
         const uint32_t spread = getenv("BSX_SPREAD") ? (uint32_t)atoi(getenv("BSX_SPREAD")) : (same_scan ? 1u : 0u);
         const int n_groups = b->n_groups;
         struct Group { uint32_t n0 = 0, passes = 0, polls = 0, polled = 0; int cur = 0; bool done = true, tail = false; HeavyArgsRaw H; uint32_t *blk[2]; };

@@ -480,8 +480,8 @@ def test_heavy_units_redone_when_their_duplicate_set_overflows(pe, heavy_genome,
 
 
 @pytest.mark.parametrize("env", [dict(BSX_TAIL_TASKS="100000000", BSX_TAIL_GRID="64"), dict(BSX_TAIL_TASKS="0"), dict(BSX_HEAVY_GROUPS="2", BSX_TAIL_TASKS="100000000"), dict(BSX_MULTI="1"),
-                                 dict(BSX_SAME="1"), dict(BSX_SAME="0", BSX_SPREAD="1")],
-                         ids=["tail_from_the_start_tiny_grid", "no_tail_mode", "two_groups_tail", "shared_fetch_scan_kernel", "same_offset_scan_kernel", "one_task_kernel_spread_order"])
+                                 dict(BSX_SAME="0"), dict(BSX_SAME="0", BSX_SPREAD="1")],
+                         ids=["tail_from_the_start_tiny_grid", "no_tail_mode", "two_groups_tail", "shared_fetch_scan_kernel", "one_task_scan_kernel", "one_task_kernel_spread_order"])
 @pytest.mark.parametrize("pe", [False, True], ids=["se", "pe"])
 def test_heavy_pipeline_scan_grids_and_streams_do_not_matter(pe, env, heavy_genome, oracle, monkeypatch):
     """the scan kernels take their tasks in a grid-stride sweep, so any grid is correct: the tail mode (small grids on the group's

@@ -18,6 +18,7 @@ BUDGET = {
     "7k_alignILb1ELb0EE": (96, 128),    # paired-end WGBS main kernel (the headline config): five waves per SIMD, 112 B today
     "7k_alignILb0ELb0EE": (96, 128),    # single-end
     "7k_hscanE": (80, 0),               # scan kernel of the heavy pipeline: six waves per SIMD (read words and masks live in VGPRs)
+    "12k_hscan_same": (96, 32),         # WGBS scan kernel (groups of tasks over one window and read offset): five waves per SIMD
     "14k_hscan_shared": (96, 0),        # RRBS scan kernel
 }
 
