@@ -265,7 +265,7 @@ def main():
         hbm = {"raw_GBps": raw / step_s / 1e9, "x2_corrected_GBps": x2 / step_s / 1e9, "frac_of_peak_raw": raw / step_s / 1e9 / HBM_PEAK_GBS,
                "frac_of_peak_x2": x2 / step_s / 1e9 / HBM_PEAK_GBS, "bytes_per_step_raw": raw, "bytes_per_step_x2": x2,
                "note": "measured HBM bytes of one step (PMC passes, serial mode) over the wall time of a step in the timed region"}
-    bound = "L2-served gathers (texture addresser) and VALU issue of k_hscan, random 64-byte requests of k_align; NOT HBM bandwidth"
+    bound = "VALU issue and the gathers (texture addresser) of the scan kernel, random 64-byte requests of k_align; NOT HBM bandwidth"
     if hbm:
         bound += " (HBM carries %.2f-%.2f of its peak)" % (hbm["frac_of_peak_raw"], hbm["frac_of_peak_x2"])
     out = {
@@ -339,7 +339,7 @@ def roofline_block(dk, bound, achieved, traffic, traffic_note, hbm, k_ms, kernel
          "kernel": "one Do_Batch = k_align + heavy pipeline (k_hctrl/k_hscan passes)", "kernel_ms": k_ms,
          "event_ms_per_do_batch": float(np.mean(kernel_ms)), "heavy_units_last_step": heavy_last[0], "redo_units_last_step": heavy_last[1], "algorithmic_bytes_per_launch": alg_bytes_launch,
          "per_read": {"n_lookup": float(counters[0]) / n_reads_rank, "n_cand": float(counters[1]) / n_reads_rank, "ref_words64": float(counters[2]) / n_reads_rank},
-         "multi_share": float(counters[15]) / max(1.0, float(counters[7])),   # of the scan kernel's candidates: evaluated in runs of tasks over one window (k_hscan_multi, BSX_MULTI=1)
+         "group_share": float(counters[15]) / max(1.0, float(counters[7])),   # of the scan kernel's candidates: evaluated in groups of two tasks and more over one window and read offset (k_hscan_same), one fetch and shift for all its reads
          "per_kernel": per_kernel_split(counters, args.steps, n_reads_rank, pmc_j, serial),
          "dominant_kernel": dk}
     return r
@@ -401,7 +401,7 @@ def per_kernel_split(c, steps, n_reads, pmc_j, serial):
 
 
 def dominant_kernel(counters, scan_ms, steps, nfl, rrbs=False):
-    """k_hscan, the kernel most of the time goes to: launches and HIP-event durations measured live (events on the stream it
+    """The scan kernel of the heavy pipeline (k_hscan_same; RRBS k_hscan_shared), the kernel most of the time goes to: launches and HIP-event durations measured live (events on the stream it
     is launched on), algorithmic bytes of the candidates it evaluated (4 B index entry + 8 B per 64-bit reference word the
     reference's CountMismatch would touch).  `bound` is derived from the committed counter summaries of the
     same kernel (VALU issue rate against the ceiling measured by tools/microbench/valu_issue, texture-addresser busy
@@ -411,7 +411,8 @@ def dominant_kernel(counters, scan_ms, steps, nfl, rrbs=False):
     alg = 4.0 * cand + 8.0 * words
     if launches == 0 or tot_ms <= 0:
         return None
-    d = {"name": "k_hscan_shared" if rrbs else "k_hscan", "launches_per_step": launches / steps, "avg_launch_ms": tot_ms / launches, "ms_per_step": tot_ms / steps,
+    same_env = os.environ.get("BSX_SAME", "1")
+    d = {"name": ("k_hscan_same" if same_env == "2" else "k_hscan_shared") if rrbs else ("k_hscan" if same_env == "0" else "k_hscan_same"), "launches_per_step": launches / steps, "avg_launch_ms": tot_ms / launches, "ms_per_step": tot_ms / steps,
          "candidates_per_launch": cand / launches, "algorithmic_bytes_per_launch": alg / launches,
          "achieved_GBps": alg / (tot_ms * 1e-3) / 1e9, "frac_of_hbm_peak": alg / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
          "candidates_per_s": cand / (tot_ms * 1e-3),

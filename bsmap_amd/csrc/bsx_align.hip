@@ -1612,7 +1612,7 @@ struct HState {
     ListReq req[HS_NSLOT];
 };
 struct HTask { uint32_t h, c0, n, key;   // h: unit (bits 0-29) and list slot (bits 30-31); key: index entry the task starts at (tasks are scanned in key order, see bsx_api.hip)
-               uint32_t sub_h, flags, pad[2]; };  // of the sub-range the task starts in: its offset h; flags bit 0 strand copy, bit 1 the task lies inside that one sub-range, bits 8-11 the read's 32-nt words
+               uint32_t sub_h, flags, pad[2]; };  // of the sub-range the task starts in: its offset h; flags bit 0 strand copy, bit 1 the task lies inside that one sub-range, bit 2 RRBS list, bits 8-11 the read's 32-nt words; pad: RRBS tag filter
 struct HTaskOut { uint32_t count, overflow, acc[4], c0, n; SurvRec surv[HS_SCAP]; };  // c0, n: the task's candidates [c0, c0 + n) of its list, echoed by the scan kernel (the replay reads the geometry of a window from here: task descriptors are reused during a control pass, outputs are not)
 struct HeavyArgs {
     HState *state; uint8_t *slabs; uint32_t *active_in, *active_out, *n_active_out; HTask *tasks; HTaskOut *tout; uint32_t *n_tasks, *queue;
@@ -1741,10 +1741,11 @@ __device__ __forceinline__ bool publish_window(const DevParams &P, const HeavyAr
                 tk.c0 = a_; tk.n = b_ - a_;
             }
         }
-        tk.sub_h = 0; tk.flags = 0; tk.pad[0] = tk.pad[1] = 0;
+        tk.sub_h = 0; tk.flags = 0;
+        tk.pad[0] = P.rrbs && orient ? 0x1000000u : 0u; tk.pad[1] = !P.rrbs ? 0u : orient ? (uint32_t)(M.u->nfull - 1 - seg) : (uint32_t)seg;   // RRBS: the list's tag filter (ListReq::tag_xor, tag_want)
         for (int s_ = 0; s_ < cl.nsub; s_++) {  // the index entry the task starts at, and what a scan kernel needs to know about that sub-range
             const uint32_t ps_ = rl(cl.sub_pre, s_), ns_ = rl(cl.sub_n, s_), sb_ = rl(cl.sub_base, s_), sh_ = rl(cl.sub_h, s_);
-            if (tk.c0 >= ps_ && tk.c0 < ps_ + ns_) { tk.key = sb_ + (tk.c0 - ps_); tk.sub_h = sh_; tk.flags = ((uint32_t)s_ & 1u) | ((tk.c0 + tk.n <= ps_ + ns_ && !P.rrbs) ? 2u : 0u) | ((uint32_t)((M.u->len + 31) >> 5) << 8); }
+            if (tk.c0 >= ps_ && tk.c0 < ps_ + ns_) { tk.key = sb_ + (tk.c0 - ps_); tk.sub_h = sh_; tk.flags = ((uint32_t)s_ & 1u) | (tk.c0 + tk.n <= ps_ + ns_ ? 2u : 0u) | (P.rrbs ? 4u : 0u) | ((uint32_t)((M.u->len + 31) >> 5) << 8); }
         }
         if (t < nt) H.tasks[t0 + t] = tk;
     }
@@ -2874,7 +2875,7 @@ __global__ __launch_bounds__(64 * HM_WAVES, 4) void k_hscan_multi(AlignArgs A, H
             tid = H.order ? H.order[s0 + lane] : s0 + (uint32_t)lane;
             const HTask tk = H.tasks[tid];
             th = tk.h; tc0 = tk.c0; tn = tk.n;
-            key = tk.key; hh = tk.sub_h; strand = tk.flags & 1u; single = tn != 0 && (tk.flags & 2u) != 0;   // (publish_window: the sub-range the task starts in, and whether it ends there too)
+            key = tk.key; hh = tk.sub_h; strand = tk.flags & 1u; single = tn != 0 && (tk.flags & 6u) == 2u;   // (publish_window: the sub-range the task starts in, and whether it ends there too)
         }
         for (uint32_t i0 = 0; i0 < nj;) {
             const uint32_t n = rl_u(tn, i0);
@@ -2943,31 +2944,53 @@ __global__ __launch_bounds__(64 * HM_WAVES, 4) void k_hscan_multi(AlignArgs A, H
 #endif
 struct SameLds {
     // per read of a group (row of 20 dwords): X0 Y0 M0 X1 | Y1 M1 X2 Y2 | M2 threshold X3 Y3 | M3 X4 Y4 M4 | task, first list ordinal, -, -
-    __attribute__((aligned(16))) uint32_t UW[HG_WPB][HG_R][20];
-    uint32_t TAB[HG_WPB][4][32];      // one-task path (hp_task)
-    uint2 PT[HG_WPB][HP_PAIRS * 32];
-    uint2 Q[HG_WPB][HP_QCAP];
+    union {
+        __attribute__((aligned(16))) uint32_t UW[HG_R][20];
+        struct { uint32_t TAB[4][32]; uint2 PT[HP_PAIRS * 32]; uint2 Q[HP_QCAP]; } one;   // one-task path (hp_task); 4 KB per wave: k_hctrl's blocks (58 KB paired) have to fit beside 20 waves of this kernel
+    } W[HG_WPB];
 };
-struct SameChunk { U4 r0, r1, r2; uint32_t pm1; };   // pairs (pm1 >> 5) .. + 5 of the plane copy
+struct SameChunk { U4 r0, r1, r2; uint32_t pm1, strand; bool valid; };   // pairs (pm1 >> 5) .. + 5 of the plane copy; RRBS: the candidate's strand copy, and whether the entry passed the filters
+// what a group's window is made of.  WGBS: 4-byte entries, candidate position = entry + h.  RRBS: one bucket of {tag | chromosome, position}
+// pairs — the entries with ((tag ^ tag_xor) >> 16) == tag_want and position >= h are the candidates (align.cpp:187,229,263), position =
+// anchor[chromosome] + (position - h), each on its own strand copy
+struct SameWin { const uint32_t *ent; uint32_t n, h, tag_xor, tag_want, ref_off, rc_off; const uint32_t *anchor; const uint8_t *plane; int nwr; };
+struct SameEntry { uint32_t a, b; bool in; };
 
-__device__ __forceinline__ SameChunk same_load(uint32_t entry, uint32_t hm1, const uint8_t *plane, uint32_t ref_off, int nwr)
+template <bool RRBS>
+__device__ __forceinline__ SameEntry same_entry(const SameWin &W, uint32_t idx)
+{
+    SameEntry e; e.a = 1024u; e.b = 0; e.in = idx < W.n;   // (a lane without a candidate takes entry 1024: any position inside the copy)
+    if (RRBS) { e.a = 0; if (e.in) { const U2 v = reinterpret_cast<const U2 *>(W.ent)[idx]; e.a = v.a; e.b = v.b; } }
+    else if (e.in) e.a = W.ent[idx];
+    return e;
+}
+template <bool RRBS>
+__device__ __forceinline__ SameChunk same_load(const SameWin &W, const SameEntry &e)
 {
     SameChunk c;
-    c.pm1 = entry + hm1;
-    const uint8_t *src = plane + hp_boff(c.pm1, ref_off);
+    uint32_t off = W.ref_off;
+    if (RRBS) {
+        const uint32_t rchr = e.a & 0xffffu;
+        c.valid = e.in && ((e.a ^ W.tag_xor) >> 16) == W.tag_want && e.b >= W.h;  // mode or strand not match / underflow the start of refseq
+        c.pm1 = c.valid ? W.anchor[rchr >> 1] + (e.b - W.h) - 1u : 31u;
+        c.strand = rchr & 1u;
+        off = c.strand ? W.rc_off : 0u;
+    } else { c.valid = e.in; c.pm1 = e.a + W.h - 1u; c.strand = 0; }
+    const uint8_t *src = W.plane + hp_boff(c.pm1, off);
     c.r0 = *reinterpret_cast<const U4 *>(src);
     c.r1.a = c.r1.b = c.r1.c = c.r1.d = 0; c.r2.a = c.r2.b = c.r2.c = c.r2.d = 0;
-    if (nwr > 1) c.r1 = *reinterpret_cast<const U4 *>(src + 16);
-    if (nwr > 3) c.r2 = *reinterpret_cast<const U4 *>(src + 32);
+    if (W.nwr > 1) c.r1 = *reinterpret_cast<const U4 *>(src + 16);
+    if (W.nwr > 3) c.r2 = *reinterpret_cast<const U4 *>(src + 32);
     return c;
 }
 
 // the three counts of one candidate and read (align.h:189-197): first early-out word, second, whole read.
 // NWR: the read's 32-nt words if known at compile time (0: nwr_rt); PLAIN: the read has no N — only its last word is masked, the words
-// before it take two v_bitop3 instead of three
-template <int NWR, bool PLAIN>
+// before it take two v_bitop3 instead of three; SKIP: the words behind the first 64 nt only where a lane of `alive` is still within the
+// threshold there (RRBS, -v 2: 99 % of a repeat family's candidates fail early; both early-out classes and the survivors are settled by then)
+template <int NWR, bool PLAIN, bool SKIP>
 __device__ __forceinline__ void same_counts(const uint32_t (&flo)[5], const uint32_t (&fhi)[5], uint32_t him, int nwr_rt, const uint4 &a0, const uint4 &a1, const uint4 &a2,
-                                            const uint4 &a3, uint32_t &w0ref, uint32_t &w01ref, uint32_t &tot)
+                                            const uint4 &a3, uint32_t thr, u64 alive, uint32_t &w0ref, uint32_t &w01ref, uint32_t &tot)
 {
     static_assert(NWR != 0 || !PLAIN, "the plain form needs the word count");
     const int nwr = NWR ? NWR : nwr_rt;
@@ -2978,7 +3001,7 @@ __device__ __forceinline__ void same_counts(const uint32_t (&flo)[5], const uint
     if (nwr > 1) {
         const uint32_t m1 = SAME_MM(1, a0.w, a1.x, a1.y);
         tot = popc_acc(m1, c0); w01ref = popc_acc(m1 & him, c0);
-        if (nwr > 2) {
+        if (nwr > 2 && (!SKIP || (bsx_ballot(tot <= thr) & alive))) {
             tot = popc_acc(SAME_MM(2, a1.z, a1.w, a2.x), tot);
             if (nwr > 3) {
                 tot = popc_acc(SAME_MM(3, a2.z, a2.w, a3.x), tot);
@@ -2989,14 +3012,15 @@ __device__ __forceinline__ void same_counts(const uint32_t (&flo)[5], const uint
 #undef SAME_MM
 }
 
-// one group of K (2 .. HG_R) tasks: lane j < K holds task j's id, unit | slot and first list ordinal; they cover the n index entries
-// from `key` on with read offset `hh`.  NWR: 5 for reads of 129-160 nt (the code of the headline configuration), 0 for any length.
-template <int NWR>
+// one group of K (1 .. HG_R) tasks: lane j < K holds task j's id, unit | slot and first list ordinal; they cover the n index entries
+// from `key` on with read offset `hh` (RRBS: and tag filter tag_xor / tag_want).  NWR: the reads' 32-nt words where the length class has
+// its own code (5: 129-160 nt, the headline configuration; 4: 97-128 nt; 3: 65-96 nt, RRBS), 0 for any length.
+template <int NWR, bool RRBS>
 __device__ __forceinline__ void hs_group(const AlignArgs &A, const HeavyArgs &H, SameLds &L, int lane, int wv, uint32_t K, uint32_t tid, uint32_t th, uint32_t tc0,
-                                         uint32_t key, uint32_t n, uint32_t hh, uint32_t flags)
+                                         uint32_t key, uint32_t n, uint32_t hh, uint32_t flags, uint32_t tag_xor, uint32_t tag_want)
 {
     const DevParams &P = A.P;
-    uint32_t *uw = &L.UW[wv][0][0];
+    uint32_t *uw = &L.W[wv].UW[0][0];
     const int nwr = NWR ? NWR : (int)((flags >> 8) & 15u);
     if ((uint32_t)lane < K) {   // the read of this lane's task -> its row
         const ListReq &R = H.state[th & 0x3fffffffu].req[th >> 30];
@@ -3012,34 +3036,34 @@ __device__ __forceinline__ void hs_group(const AlignArgs &A, const HeavyArgs &H,
         row[9] = R.thres | (inner == 0xFFFFFFFFu ? 0x10000u : 0u); row[16] = tid; row[17] = tc0;
     }
     wave_fence();
-    const uint8_t *plane = reinterpret_cast<const uint8_t *>(P.refplane);
-    const uint32_t strand = flags & 1u, ref_off = strand ? P.plane_rc_off : 0u;
-    const uint32_t *ent = P.entries + key;
-    const uint32_t hm1 = hh - 1u;
+    const uint32_t strand = flags & 1u;
+    SameWin W;
+    W.ent = P.entries + (RRBS ? 2u * (size_t)key : (size_t)key); W.n = n; W.h = hh; W.tag_xor = tag_xor; W.tag_want = tag_want; W.rc_off = P.plane_rc_off;
+    W.ref_off = strand ? P.plane_rc_off : 0u; W.anchor = P.anchor; W.plane = reinterpret_cast<const uint8_t *>(P.refplane); W.nwr = nwr;
     uint32_t c15 = 0, nsv = 0;   // lane k: counters of read k — candidates beyond the first word | five-word candidates << 16; survivors
+    uint32_t n_cand = 0;         // RRBS: the entries that passed the filters
     // one step = HG_C chunks of 64 candidates.  nx: the gathers of the coming step (issued a step earlier); en: the entries of the step after it
-    // (a lane without a candidate takes entry 1024: any position inside the copy)
     constexpr uint32_t STEP = 64u * HG_C;
     SameChunk nx[HG_C];
-    uint32_t en[HG_C];
+    SameEntry en[HG_C];
 #if HG_PREFETCH
 #pragma unroll
-    for (int u = 0; u < HG_C; u++) { const uint32_t i0 = (uint32_t)(u * 64 + lane); nx[u] = same_load(i0 < n ? ent[i0] : 1024u, hm1, plane, ref_off, nwr); }
+    for (int u = 0; u < HG_C; u++) nx[u] = same_load<RRBS>(W, same_entry<RRBS>(W, (uint32_t)(u * 64 + lane)));
 #pragma unroll
-    for (int u = 0; u < HG_C; u++) { const uint32_t i1 = STEP + (uint32_t)(u * 64 + lane); en[u] = i1 < n ? ent[i1] : 1024u; }
+    for (int u = 0; u < HG_C; u++) en[u] = same_entry<RRBS>(W, STEP + (uint32_t)(u * 64 + lane));
 #else
 #pragma unroll
-    for (int u = 0; u < HG_C; u++) { const uint32_t i0 = (uint32_t)(u * 64 + lane); en[u] = i0 < n ? ent[i0] : 1024u; }
+    for (int u = 0; u < HG_C; u++) en[u] = same_entry<RRBS>(W, (uint32_t)(u * 64 + lane));
 #endif
     for (uint32_t cb = 0; cb < n; cb += STEP) {
 #if !HG_PREFETCH
 #pragma unroll
-        for (int u = 0; u < HG_C; u++) nx[u] = same_load(en[u], hm1, plane, ref_off, nwr);
+        for (int u = 0; u < HG_C; u++) nx[u] = same_load<RRBS>(W, en[u]);
 #pragma unroll
-        for (int u = 0; u < HG_C; u++) { const uint32_t i1 = cb + STEP + (uint32_t)(u * 64 + lane); en[u] = i1 < n ? ent[i1] : 1024u; }
+        for (int u = 0; u < HG_C; u++) en[u] = same_entry<RRBS>(W, cb + STEP + (uint32_t)(u * 64 + lane));
 #endif
         // the candidates' reference planes in the read frame — the same for every read of the group
-        uint32_t flo[HG_C][5], fhi[HG_C][5], him[HG_C], hloc[HG_C], ordsh[HG_C];
+        uint32_t flo[HG_C][5], fhi[HG_C][5], him[HG_C], hloc[HG_C], ordsh[HG_C], hchr[HG_C];
         u64 vm[HG_C];
 #pragma unroll
         for (int u = 0; u < HG_C; u++) {
@@ -3050,16 +3074,17 @@ __device__ __forceinline__ void hs_group(const AlignArgs &A, const HeavyArgs &H,
 #pragma unroll
             for (int t = 0; t < 5; t++) { flo[u][t] = __builtin_amdgcn_alignbit(wd[2 * t], wd[2 * t + 2], shf); fhi[u][t] = __builtin_amdgcn_alignbit(wd[2 * t + 1], wd[2 * t + 3], shf); }
             hloc[u] = c.pm1 + 1u;
-            const uint32_t ord = cb + (uint32_t)(u * 64 + lane);
-            ordsh[u] = ord << 8;
-            vm[u] = bsx_ballot(ord < n);
+            hchr[u] = RRBS ? c.strand : strand;
+            ordsh[u] = (cb + (uint32_t)(u * 64 + lane)) << 8;
+            vm[u] = bsx_ballot(c.valid);
+            if (RRBS) n_cand += (uint32_t)__builtin_popcountll(vm[u]);
         }
 #if HG_PREFETCH
         if (cb + STEP < n) {   // the next step's gathers fly while this step is evaluated, and the entries of the step after it
 #pragma unroll
-            for (int u = 0; u < HG_C; u++) nx[u] = same_load(en[u], hm1, plane, ref_off, nwr);
+            for (int u = 0; u < HG_C; u++) nx[u] = same_load<RRBS>(W, en[u]);
 #pragma unroll
-            for (int u = 0; u < HG_C; u++) { const uint32_t i2 = cb + 2u * STEP + (uint32_t)(u * 64 + lane); en[u] = i2 < n ? ent[i2] : 1024u; }
+            for (int u = 0; u < HG_C; u++) en[u] = same_entry<RRBS>(W, cb + 2u * STEP + (uint32_t)(u * 64 + lane));
         }
 #endif
         for (uint32_t k = 0; k < K; k++) {
@@ -3075,13 +3100,13 @@ __device__ __forceinline__ void hs_group(const AlignArgs &A, const HeavyArgs &H,
 #pragma unroll
             for (int u = 0; u < HG_C; u++) {
                 uint32_t w0ref, w01ref, tot;
-                if (plain) same_counts<NWR, NWR != 0>(flo[u], fhi[u], him[u], nwr, a0, a1, a2, a3, w0ref, w01ref, tot);
-                else same_counts<NWR, false>(flo[u], fhi[u], him[u], nwr, a0, a1, a2, a3, w0ref, w01ref, tot);
+                if (plain) same_counts<NWR, NWR != 0, RRBS>(flo[u], fhi[u], him[u], nwr, a0, a1, a2, a3, thr, vm[u], w0ref, w01ref, tot);
+                else same_counts<NWR, false, RRBS>(flo[u], fhi[u], him[u], nwr, a0, a1, a2, a3, thr, vm[u], w0ref, w01ref, tot);
                 const u64 b1 = bsx_ballot(w0ref > thr) & vm[u], b5 = bsx_ballot(w01ref <= thr) & vm[u], bp = bsx_ballot(tot <= thr) & vm[u];
                 add15 += (uint32_t)__builtin_popcountll(b1) + ((uint32_t)__builtin_popcountll(b5) << 16);
                 if (bp) {
                     const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(bp >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bp, nsk));
-                    if (__builtin_amdgcn_inverse_ballot_w64(bp) && pos < HS_SCAP) { SurvRec r; r.w_ord = tot | ordsh[u]; r.hchr = strand; r.hloc = hloc[u]; r.hkey = 0; sv[pos] = r; }
+                    if (__builtin_amdgcn_inverse_ballot_w64(bp) && pos < HS_SCAP) { SurvRec r; r.w_ord = tot | ordsh[u]; r.hchr = hchr[u]; r.hloc = hloc[u]; r.hkey = 0; sv[pos] = r; }
                     nsk += (uint32_t)__builtin_popcountll(bp);
                 }
             }
@@ -3090,21 +3115,22 @@ __device__ __forceinline__ void hs_group(const AlignArgs &A, const HeavyArgs &H,
     }
     wave_fence();
     // results: lane j < K holds read j's counters
+    if (!RRBS) n_cand = n;
     const bool mine = (uint32_t)lane < K;
     const uint32_t n1 = c15 & 0xffffu, n5 = c15 >> 16, ns = nsv;
     const bool ov = ns > HS_SCAP;
     if (mine) {
         HTaskOut *o = &H.tout[tid];
-        o->count = ov ? 0 : ns; o->overflow = ov ? 1 : 0; o->acc[0] = n; o->acc[1] = 2u * n - n1 + 3u * n5; o->acc[2] = 0; o->acc[3] = 0; o->c0 = tc0; o->n = n;
+        o->count = ov ? 0 : ns; o->overflow = ov ? 1 : 0; o->acc[0] = n_cand; o->acc[1] = 2u * n_cand - n1 + 3u * n5; o->acc[2] = 0; o->acc[3] = 0; o->c0 = tc0; o->n = n;
     }
     const bool cnt = mine && !ov;
     const uint32_t kk = (uint32_t)__builtin_popcountll(bsx_ballot(cnt));
     const uint32_t s1 = wave_sum(cnt ? n1 : 0), s5 = wave_sum(cnt ? n5 : 0);
     if (lane == 0 && kk) {   // (sharded statistics: see hscan_task)
         u64 *sh = (u64 *)A.scan_stats + (size_t)((blockIdx.x * (uint32_t)HG_WPB + (uint32_t)wv) & 63u) * 8;
-        atomicAdd((u64 *)&sh[0], (u64)kk * n); atomicAdd((u64 *)&sh[1], 2ull * kk * n - s1 + 3ull * s5); atomicAdd((u64 *)&sh[2], (u64)s1); atomicAdd((u64 *)&sh[3], (u64)s5);
-        atomicAdd((u64 *)&sh[4], (u64)kk * n);   // counter 15: candidates evaluated in groups
-        atomicAdd((u64 *)&sh[5], (u64)kk * n * K); if (K >= 4) atomicAdd((u64 *)&sh[6], (u64)kk * n); if (K >= 8) atomicAdd((u64 *)&sh[7], (u64)kk * n);  // diagnostics (BSX_SIGHIST)
+        atomicAdd((u64 *)&sh[0], (u64)kk * n_cand); atomicAdd((u64 *)&sh[1], 2ull * kk * n_cand - s1 + 3ull * s5); atomicAdd((u64 *)&sh[2], (u64)s1); atomicAdd((u64 *)&sh[3], (u64)s5);
+        if (K > 1) atomicAdd((u64 *)&sh[4], (u64)kk * n_cand);   // counter 15: candidates evaluated in groups of two reads and more
+        atomicAdd((u64 *)&sh[5], (u64)kk * n_cand * K); if (K >= 4) atomicAdd((u64 *)&sh[6], (u64)kk * n_cand); if (K >= 8) atomicAdd((u64 *)&sh[7], (u64)kk * n_cand);  // diagnostics (BSX_SIGHIST)
     }
     wave_fence();
 }
@@ -3121,7 +3147,8 @@ __global__ __launch_bounds__(64 * HG_WPB, BSX_HSAME_WAVES) void k_hscan_same(Ali
     const uint32_t nvb = (n_groups + HG_WPB - 1) / HG_WPB;
     for (uint32_t vb = blockIdx.x;; vb += gridDim.x) {
         uint32_t b_;
-        const int st_ = bsx_order_block(vb, nvb, H.xcd_map >= 2 ? max(2u, H.xcd_map * BSX_HSCAN_WPB / HG_WPB / 4u) : H.xcd_map, b_);   // (a group is 4-5 tasks on average)
+        // (pieces of 256 groups per XCD turn — about a thousand tasks, twice k_hscan's 512: 64 groups 97.7-98.5 ms per step, 256 96.0, 1024 97.1, 16 101.3, as dispatched 104.4)
+        const int st_ = bsx_order_block(vb, nvb, H.xcd_map >= 2 ? max(2u, H.xcd_map * BSX_HSCAN_WPB / HG_WPB) : H.xcd_map, b_);
         if (st_ == 2) break;
         if (st_ == 1) continue;
         const uint32_t g = b_ * HG_WPB + (uint32_t)wv;
@@ -3129,21 +3156,25 @@ __global__ __launch_bounds__(64 * HG_WPB, BSX_HSAME_WAVES) void k_hscan_same(Ali
         const uint32_t slot = rfl(H.glist[g < n_big ? g : H.task_cap - 1u - (g - n_big)]);   // the groups of HG_BIG tasks and more first: the short ones fill the tail of the launch
         const uint32_t K = rfl(H.ghead[slot]);
         // lane j < K: task j of the group
-        uint32_t tid = 0, th = 0, tc0 = 0, tn = 0, key = 0, hh = 0, flags = 0;
+        uint32_t tid = 0, th = 0, tc0 = 0, tn = 0, key = 0, hh = 0, flags = 0, tx = 0, tw = 0;
         if ((uint32_t)lane < K) {
             tid = H.order[slot + lane];
             const HTask tk = H.tasks[tid];
-            th = tk.h; tc0 = tk.c0; tn = tk.n; key = tk.key; hh = tk.sub_h; flags = tk.flags;
+            th = tk.h; tc0 = tk.c0; tn = tk.n; key = tk.key; hh = tk.sub_h; flags = tk.flags; tx = tk.pad[0]; tw = tk.pad[1];
         }
-        const uint32_t n0 = rfl(tn);
+        const uint32_t n0 = rfl(tn), f0 = rfl(flags);
         if (n0 == 0) {   // slots neutralised by a refused request: their units have not published a list
             if ((uint32_t)lane < K) { HTaskOut *o = &H.tout[tid]; o->count = 0; o->overflow = 0; o->acc[0] = o->acc[1] = o->acc[2] = o->acc[3] = 0; o->c0 = 0; o->n = 0; }
-        } else if (K > 1) {
-            const uint32_t f0 = rfl(flags);
-            if (((f0 >> 8) & 15u) == 5u) hs_group<5>(A, H, L, lane, wv, K, tid, th, tc0, rfl(key), n0, rfl(hh), f0);
-            else hs_group<0>(A, H, L, lane, wv, K, tid, th, tc0, rfl(key), n0, rfl(hh), f0);
+        } else if (f0 & 4u) {   // RRBS (hp_task takes WGBS lists only); reads of 65-96 nt have their own code
+            if (((f0 >> 8) & 15u) == 3u) hs_group<3, true>(A, H, L, lane, wv, K, tid, th, tc0, rfl(key), n0, rfl(hh), f0, rfl(tx), rfl(tw));
+            else hs_group<0, true>(A, H, L, lane, wv, K, tid, th, tc0, rfl(key), n0, rfl(hh), f0, rfl(tx), rfl(tw));
         }
-        else hp_task(A, H, rfl(tid), lane, L.TAB[wv], L.PT[wv], L.Q[wv]);
+        else if (K > 1) {
+            if (((f0 >> 8) & 15u) == 5u) hs_group<5, false>(A, H, L, lane, wv, K, tid, th, tc0, rfl(key), n0, rfl(hh), f0, 0u, 0u);
+            else if (((f0 >> 8) & 15u) == 4u) hs_group<4, false>(A, H, L, lane, wv, K, tid, th, tc0, rfl(key), n0, rfl(hh), f0, 0u, 0u);   // 97-128 nt (C2: 100 nt single-end)
+            else hs_group<0, false>(A, H, L, lane, wv, K, tid, th, tc0, rfl(key), n0, rfl(hh), f0, 0u, 0u);
+        }
+        else hp_task(A, H, rfl(tid), lane, L.W[wv].one.TAB, L.W[wv].one.PT, L.W[wv].one.Q);
         wave_fence();
     }
 }
@@ -3160,22 +3191,22 @@ __global__ __launch_bounds__(256) void k_task_groups(const HTask *tasks, const u
     const uint32_t n_tasks = min(*n_tasks_ptr, cap);
     for (uint32_t s0 = (blockIdx.x * 4u + (threadIdx.x >> 6)) * 64u; s0 < n_tasks; s0 += gridDim.x * 256u) {
         const uint32_t nj = min(64u, n_tasks - s0);
-        uint32_t tid = 0, tn = 0, key = 0, hh = 0, flags = 0;
+        uint32_t tid = 0, tn = 0, key = 0, hh = 0, flags = 0, tx = 0, tw = 0;
         if ((uint32_t)lane < nj) {
             tid = order[s0 + lane];
             const HTask tk = tasks[tid];
-            tn = tk.n; key = tk.key; hh = tk.sub_h; flags = tk.flags;
+            tn = tk.n; key = tk.key; hh = tk.sub_h; flags = tk.flags; tx = tk.pad[0]; tw = tk.pad[1];   // (pad: the tag filter of an RRBS list, 0 otherwise)
         }
         u64 todo = bsx_ballot((uint32_t)lane < nj);
         uint32_t off = 0, head = 0, dst = 0;
         while (todo) {
             const uint32_t i0 = (uint32_t)__builtin_ctzll(todo);
-            const uint32_t n0 = rl_u(tn, i0), f0 = rl_u(flags, i0), key0 = rl_u(key, i0), h0 = rl_u(hh, i0);
+            const uint32_t n0 = rl_u(tn, i0), f0 = rl_u(flags, i0), key0 = rl_u(key, i0), h0 = rl_u(hh, i0), tx0 = rl_u(tx, i0), tw0 = rl_u(tw, i0);
             const bool pending = (todo >> lane) & 1;
             u64 mem = 1ull << i0;
             if (n0 == 0) mem = bsx_ballot(pending && tn == 0);
             else if (f0 & 2u) {
-                const bool same = pending && tn == n0 && key == key0 && hh == h0 && flags == f0;
+                const bool same = pending && tn == n0 && key == key0 && hh == h0 && flags == f0 && tx == tx0 && tw == tw0;
                 mem = bsx_ballot(same);
                 if ((uint32_t)__builtin_popcountll(mem) > HG_R) mem = bsx_ballot(same && (uint32_t)__builtin_popcountll(mem & lanemask_lt(lane)) < HG_R);
             }
@@ -3620,7 +3651,11 @@ void bsx_launch_hscan_multi(const AlignArgs &A, const HeavyArgsRaw &R, hipStream
 void bsx_launch_hscan_same(const AlignArgs &A, const HeavyArgsRaw &R, hipStream_t stream, uint32_t max_tasks)
 {
     const HeavyArgs H = typed(R);
-    uint32_t blocks = ((max_tasks ? std::min(max_tasks, R.task_cap) : R.task_cap) + HG_WPB - 1) / HG_WPB;
+    // The host does not know the number of groups: the grid is sized for a quarter of the task pool (a group holds 4-5 tasks on average; where a pass
+    // has more groups the blocks sweep) — surplus blocks leave at once, but the dispatcher still has to start them: a grid for the whole pool 98.8 and
+    // 144.7 ms per step (WGBS, RRBS), a quarter 96.2 and 142.2, a sixteenth 100.3 and 142.0, 1/64 (RRBS) 150.2
+    static const uint32_t grid_div = getenv("BSX_SAME_GRID_DIV") ? (uint32_t)std::max(1, atoi(getenv("BSX_SAME_GRID_DIV"))) : 4u;
+    uint32_t blocks = ((max_tasks ? std::min(max_tasks, R.task_cap) : R.task_cap / grid_div) + HG_WPB - 1) / HG_WPB;
     blocks = (blocks + 7u) & ~7u;  // the same number of blocks for each of the 8 XCDs (the sweep relies on a multiple of 8)
     hipLaunchKernelGGL(k_hscan_same, dim3(blocks), dim3(64 * HG_WPB), 0, stream, A, H);
 }

@@ -747,7 +747,10 @@ extern "C" int bsx_batch_run_range(bsx_batch *b, uint32_t first_unit, uint32_t n
         // instructions per 64 candidates and its waves wait at two barriers per round: 356 against 491 G candidates/s (profiles/r04g_*)
         const bool multi_scan = !shared_scan && getenv("BSX_MULTI") && atoi(getenv("BSX_MULTI")) == 1;
         // WGBS: the tasks of one window AND read offset share fetch and shift (k_hscan_same); BSX_SAME=0: one task per wave (k_hscan)
-        const bool same_scan = !shared_scan && !multi_scan && !(getenv("BSX_SAME") && atoi(getenv("BSX_SAME")) == 0);
+        // RRBS lists go through the same kernel with BSX_SAME=2 (scan 75.9 against 90.5 ms per step; the step does not move — 142.2 against 141.0 ms —, it
+        // waits for the control passes there: k_hscan_shared stays the default for RRBS)
+        const int same_env = getenv("BSX_SAME") ? atoi(getenv("BSX_SAME")) : 1;
+        const bool same_scan = !multi_scan && (shared_scan ? same_env == 2 : same_env != 0);
         const uint32_t spread = getenv("BSX_SPREAD") ? (uint32_t)atoi(getenv("BSX_SPREAD")) : (same_scan ? 1u : 0u);
         const int n_groups = b->n_groups;
         struct Group { uint32_t n0 = 0, passes = 0, polls = 0, polled = 0; int cur = 0; bool done = true, tail = false; HeavyArgsRaw H; uint32_t *blk[2]; };
@@ -793,7 +796,8 @@ extern "C" int bsx_batch_run_range(bsx_batch *b, uint32_t first_unit, uint32_t n
                     b->scan_ev.push_back(e0); b->scan_ev.push_back(e1);
                 }
                 HIP_TRY(hipEventRecord(b->scan_ev[b->scan_ev_used], s_scan));
-                if (shared_scan) bsx_launch_hscan_shared(A, q.H, s_scan, q.tail ? b->tail_grid_tasks : 0);
+                if (same_scan) bsx_launch_hscan_same(A, q.H, s_scan, q.tail ? b->tail_grid_tasks : 0);
+                else if (shared_scan) bsx_launch_hscan_shared(A, q.H, s_scan, q.tail ? b->tail_grid_tasks : 0);
                 else if (same_scan) bsx_launch_hscan_same(A, q.H, s_scan, q.tail ? b->tail_grid_tasks : 0);
                 else if (multi_scan) bsx_launch_hscan_multi(A, q.H, s_scan, q.tail ? b->tail_grid_tasks : 0);
                 else bsx_launch_hscan(A, q.H, s_scan, q.tail ? b->tail_grid_tasks : 0);

@@ -480,8 +480,8 @@ def test_heavy_units_redone_when_their_duplicate_set_overflows(pe, heavy_genome,
 
 
 @pytest.mark.parametrize("env", [dict(BSX_TAIL_TASKS="100000000", BSX_TAIL_GRID="64"), dict(BSX_TAIL_TASKS="0"), dict(BSX_HEAVY_GROUPS="2", BSX_TAIL_TASKS="100000000"), dict(BSX_MULTI="1"),
-                                 dict(BSX_SAME="0"), dict(BSX_SAME="0", BSX_SPREAD="1")],
-                         ids=["tail_from_the_start_tiny_grid", "no_tail_mode", "two_groups_tail", "shared_fetch_scan_kernel", "one_task_scan_kernel", "one_task_kernel_spread_order"])
+                                 dict(BSX_SAME="0"), dict(BSX_SAME="0", BSX_SPREAD="1"), dict(BSX_SAME="2", BSX_SAME_GRID_DIV="64")],
+                         ids=["tail_from_the_start_tiny_grid", "no_tail_mode", "two_groups_tail", "shared_fetch_scan_kernel", "one_task_scan_kernel", "one_task_kernel_spread_order", "group_kernel_small_grid"])
 @pytest.mark.parametrize("pe", [False, True], ids=["se", "pe"])
 def test_heavy_pipeline_scan_grids_and_streams_do_not_matter(pe, env, heavy_genome, oracle, monkeypatch):
     """the scan kernels take their tasks in a grid-stride sweep, so any grid is correct: the tail mode (small grids on the group's
@@ -611,6 +611,20 @@ def test_heavy_pipeline_small_pools(heavy_genome, oracle):
         test_heavy_pipeline_large_buckets(False, heavy_genome, oracle)
     finally:
         B.lib().bsx_set_heavy_limits(32768, 524288)
+
+
+@pytest.mark.parametrize("seed", [1, 5, 12])
+def test_rrbs_through_the_group_scan_kernel(seed, oracle, tmp_path_factory, monkeypatch):
+    """BSX_SAME=2: RRBS lists through k_hscan_same (groups formed by the pre-pass, the tag filter part of a group's signature,
+    chromosome-local positions and per-entry strand copies in its loader) instead of k_hscan_shared — same records, same counters"""
+    monkeypatch.setenv("BSX_SAME", "2")
+    test_rrbs_through_the_heavy_pipeline(seed, oracle, tmp_path_factory)
+
+
+def test_rrbs_group_scan_runs_and_survivor_overflow(oracle, tmp_path, monkeypatch):
+    """the tandem families of the test below through k_hscan_same: survivor overflow per task, redone by the control kernel"""
+    monkeypatch.setenv("BSX_SAME", "2")
+    test_rrbs_shared_scan_runs_and_survivor_overflow(oracle, tmp_path)
 
 
 def test_rrbs_shared_scan_runs_and_survivor_overflow(oracle, tmp_path):

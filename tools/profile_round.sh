@@ -36,3 +36,13 @@ $R/tools/microbench/gather_cost > $O/${TAG}_gather_cost.json 2>/dev/null; echo "
 bash $R/tools/lanes_scaling.sh ${TAG}_lanes > $O/${TAG}_lanes.txt 2>&1; cp $R/gpurun_out/${TAG}_lanes/*.json $O/ 2>/dev/null; cat $O/${TAG}_lanes.txt
 rm -rf $S; ls -la $O | head -30
 timeout 900 python3 tools/validate_fullsize.py --mode pe > $O/${TAG}_validate_full_c3.json 2>/dev/null; echo "validate full rc=$?"
+# A/B on this box: the group scan kernel (k_hscan_same, the WGBS default) against the one-task kernel (BSX_SAME=0), paired and single-end; RRBS through
+# k_hscan_shared (its default) and through k_hscan_same (BSX_SAME=2); and the histogram of tasks per identical window / window and read offset
+for m in pe se rrbs; do for v in 1 0 2; do
+  if [ $m = rrbs ]; then [ $v = 0 ] && continue; else [ $v = 2 ] && continue; fi
+  BSX_SAME=$v timeout 600 python3 bench.py --mode $m --cpu-seconds 0 --e2e-pairs 0 --transfer-steps 0 --sensitivity 0 --other-configs 0 --steps 8 --warmup 2 > $O/${TAG}_ab_${m}_same$v.json 2>/dev/null
+  python3 -c "
+import json
+d=json.load(open('$O/${TAG}_ab_${m}_same$v.json')); k=d['roofline']['dominant_kernel']; print('$m BSX_SAME=$v: %.1f ms/step %.2f M reads/s | %s %.1f ms/step %.0f G candidates/s' % (d['ms_per_step'], d['value']/1e6, k['name'], k['ms_per_step'], k['candidates_per_s']/1e9))"
+done; done
+BSX_SIGHIST=1 timeout 600 python3 bench.py --in-flight 1 --cpu-seconds 0 --e2e-pairs 0 --transfer-steps 0 --sensitivity 0 --other-configs 0 --steps 2 --warmup 1 2>&1 >/dev/null | grep sighist > $O/${TAG}_sighist.txt; head -3 $O/${TAG}_sighist.txt
