@@ -376,7 +376,7 @@ static int ensure_scratch(bsx_batch *b)
         // scan order of a pass: bins of 2^shift index entries, at most 2^20 of them (bsx_launch_task_order)
         const uint64_t ne = std::max<uint64_t>(1, b->ref->n_entries);
         b->bin_shift = 0;
-        // (WGBS: 2^21 — the tasks of one window are dealt over the bins it covers by read offset, for k_hscan_same: 16 bins of 512 entries per window)
+        // (WGBS: 2^21 — the tasks of one window are dealt over the bins it covers by read offset, for k_hscan_same: 8 bins of 1 024 entries per window at hg38 size)
         const uint32_t bin_log2 = getenv("BSX_BIN_LOG2") ? (uint32_t)std::max(8, std::min(21, atoi(getenv("BSX_BIN_LOG2")))) : (b->ref->P.rrbs ? 20u : 21u);  // tuning knob
         while (((ne >> b->bin_shift) + 1) > (1u << bin_log2)) b->bin_shift++;
         b->n_bins = (uint32_t)(ne >> b->bin_shift) + 1;

@@ -147,8 +147,8 @@ typedef struct bsx_pair {
  * 7 candidates evaluated by the scan kernel of the heavy pipeline (k_hscan; a subset of 1 plus the little it evaluates
  * speculatively), 8 their reference words (as 2), 9 / 10 how many of them stopped after the first word / went through all
  * five, 11-14 the share of 0-3 that the main kernel (k_align) did itself — units it did not hand to the heavy pipeline —, so
- * that each kernel's algorithmic bytes can be recomputed from the counters, 15 the part of 7 that k_hscan_multi evaluated in runs of
- * tasks over one window (one fetch of the candidates' reference for up to 16 reads) */
+ * that each kernel's algorithmic bytes can be recomputed from the counters, 15 the part of 7 that was evaluated in groups of two and more
+ * tasks over one window and read offset (k_hscan_same: one fetch and shift of the candidates' reference for up to 16 reads; k_hscan_multi with BSX_MULTI=1) */
 #define BSX_N_COUNTERS 16
 
 int bsx_batch_create(bsx_ref *r, uint32_t max_units, int paired, bsx_batch **out);
