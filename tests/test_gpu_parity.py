@@ -464,6 +464,7 @@ def test_heavy_pipeline_large_buckets(pe, heavy_genome, oracle, extra=None):
         for f in ("a_chr", "a_loc", "b_chr", "b_loc", "insert", "na", "nb", "chain"):
             assert np.array_equal(ores["pick"][f][pr], out[f][pr]), f
         assert [int(x) for x in pa.counters()[:4]] == ocnt
+        test_heavy_pipeline_large_buckets.last_group_share = float(pa.counters()[15]) / max(1.0, float(pa.counters()[7]))
         pa.close()
     gref.close()
     oref.free()
@@ -490,6 +491,16 @@ def test_heavy_pipeline_scan_grids_and_streams_do_not_matter(pe, env, heavy_geno
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     test_heavy_pipeline_large_buckets(pe, heavy_genome, oracle)
+
+
+def test_heavy_pipeline_runs_its_scan_in_groups(heavy_genome, oracle, monkeypatch):
+    """the default WGBS scan kernel (k_hscan_same) finds tasks of equal window and read offset on the microsatellite genome and evaluates
+    them as groups (counter 15: the share of the scan's candidates that ran in groups of two and more); with BSX_SAME=0 none do"""
+    test_heavy_pipeline_large_buckets(True, heavy_genome, oracle)
+    assert test_heavy_pipeline_large_buckets.last_group_share > 0.2, test_heavy_pipeline_large_buckets.last_group_share
+    monkeypatch.setenv("BSX_SAME", "0")
+    test_heavy_pipeline_large_buckets(True, heavy_genome, oracle)
+    assert test_heavy_pipeline_large_buckets.last_group_share == 0.0
 
 
 @pytest.mark.parametrize("extra", [dict(w=20), dict(w=3, r=0), dict(w=150, n=1), dict(r=0, v=3)], ids=["w20", "w3_r0", "w150_n1", "r0_v3"])
