@@ -2108,68 +2108,7 @@ __global__ __launch_bounds__(256, PE ? BSX_HCTRL_WAVES : BSX_HCTRL_WAVES_SE) voi
 #define BSX_HSCAN_WPB 2  /* waves (= tasks) per block: 2 measured best (1: 104.5, 2: 101.3, 4: 102.9, 8: 106.2, 16: 116.6 ms per step) */
 #endif
 
-// k_hscan evaluates a candidate in two stages.  Stage 1 (every candidate): the first 48 nt from one 16-byte reference
-// gather, which settle the reference's first early-out and, for most candidates, the second.  Stage 2 (the 40 % that are
-// still within the threshold after 48 nt): the remaining words.  Run lane by lane, stage 2 would execute for nearly every
-// chunk of 64 with most lanes idle; instead stage 1 pushes its survivors into a per-wave FIFO in LDS and stage 2 pops
-// them 64 at a time, so both its loads and its arithmetic run with full lanes.  The FIFO keeps list order, so the
-// survivor records still come out in list order.
-// Everything a candidate needs is derived from pm1 = p - 1 (p = entry + h, its global nt position):
-//   reference word index        pm1 >> 4              (one word early when p is word-aligned, see eval_loaded)
-//   funnel-shift amount         (30 pm1 + 30) mod 32  = (32 - 2 (p & 15)) & 31   (v_alignbit uses the low 5 bits)
-//   mask of the first 16-k nt   0x80000000 >>arith ((30 pm1 + 29) mod 32)        (k = p & 15)
-// The work accounting of the reference's two early-outs (align.h:189-197; 1, 2 or 5 64-bit words per candidate) needs no
-// ballots: with w0ref <= p48 <= w01ref, a task of n candidates touches  2 n - #(w0ref > thres) + 3 #(w01ref <= thres)
-// words; both counts are accumulated per lane and reduced once per task.
-#ifndef BSX_HSCAN_TMV
-#define BSX_HSCAN_TMV 9  /* T-masks kept in vector registers (first three: stage 1) */
-#endif
-#define HS_QCAP 256u  /* FIFO slots per wave (16 bytes each): at most 63 left over + 2 chunks of 64 pushed between drains */
-#ifndef BSX_HSCAN_VVV
-#define BSX_HSCAN_VVV 1
-#endif
-#ifndef BSX_HSCAN_RV
-#define BSX_HSCAN_RV 3  /* read words kept in vector registers as well (stage 1) */
-#endif
 struct ScanAcc { uint32_t c1, f5, nv; };  // per wave (scalar registers, counted with s_bcnt1 on the compare masks): candidates with w0ref > thres / evaluated in full with w01ref <= thres / (RRBS) candidates at all
-struct ScanCtx {
-    const uint32_t *refall;  // forward copy; the rc copy follows it in the same allocation
-    uint4 *Q;                // this wave's FIFO
-    uint32_t qh, qn;         // head slot, items queued (wave-uniform)
-    uint32_t thres0, nsurv;
-    int nwords, lane;
-    bool overflow;
-    HTaskOut *o;
-    ScanAcc acc;
-    // T-masks of the read words (bsx_tmask) held in VECTOR registers: a VOP3 instruction reads one scalar operand only, so with both
-    // the read word and its mask in SGPRs every v_bitop3 of the mismatch rule came with a v_mov (3 of the first stage's 33 per chunk)
-    uint32_t tv[9];
-#if BSX_HSCAN_VVV
-    // ... and so do the read words themselves and the 0xAAAAAAAA of the rule: v_bitop3 with an SGPR operand issues at the rate of the shift /
-    // popcount class (2.6 SIMD cycles per wave64 instruction), with three VGPR operands at that of v_xor (1.5; profiles/r03c_valu_issue.json)
-    uint32_t rv[BSX_HSCAN_RV], kA;
-#endif
-};
-// bsx_mismatch_hi with all operands in vector registers and the shift as an add (both in the fast VALU class)
-__device__ __forceinline__ uint32_t mism_vvv(uint32_t kA, uint32_t read, uint32_t tmask, uint32_t ref)
-{
-    const uint32_t y = (read ^ ref) & tmask;
-    uint32_t y2;
-    asm("v_add_u32 %0, %1, %1" : "=v"(y2) : "v"(y));
-    return (y2 | y) & kA;
-}
-#if BSX_HSCAN_VVV
-__device__ __forceinline__ uint32_t hscan_mism(const ScanCtx &X, const uint32_t (&rw)[9], int t, uint32_t f)
-{
-    const uint32_t y = ((t < BSX_HSCAN_RV ? X.rv[t] : rw[t]) ^ f) & X.tv[t];  // (stage 2 keeps its read words in SGPRs: six registers that decide between 6 waves per SIMD with and without spills)
-    uint32_t y2;
-    asm("v_add_u32 %0, %1, %1" : "=v"(y2) : "v"(y));  // y << 1 as an add: v_lshlrev is in the slow class
-    return (y2 | y) & X.kA;
-}
-#else
-__device__ __forceinline__ uint32_t hscan_mism(const ScanCtx &X, const uint32_t (&rw)[9], int t, uint32_t f) { return bsx_mismatch_hi(rw[t], X.tv[t], f); }
-#endif
-
 // popcount(x) + acc in one instruction (the compiler prefers separate counts and a v_add3)
 __device__ __forceinline__ uint32_t popc_acc(uint32_t x, uint32_t acc)
 {
@@ -2178,203 +2117,8 @@ __device__ __forceinline__ uint32_t popc_acc(uint32_t x, uint32_t acc)
     return d;
 }
 
-// stage 2 for the first n (<= 64) queued candidates
-__device__ __forceinline__ void hscan_drain(ScanCtx &X, uint32_t n, const uint32_t (&rw)[9], const uint32_t (&rm)[9])
-{
-    const bool act = (uint32_t)X.lane < n;
-    const uint4 it = X.Q[(X.qh + (uint32_t)X.lane) & (HS_QCAP - 1)];  // x byte offset of the candidate's first word, y p48 | ordinal << 8 | strand << 31, z word 3, w pm1
-    X.qh = (X.qh + n) & (HS_QCAP - 1); X.qn -= n;
-    const uint32_t *rp = reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(X.refall) + it.x);
-    U4 r1; U2 r2;
-    r1.a = r1.b = r1.c = r1.d = 0; r2.a = r2.b = 0;
-    if (act && X.nwords > 3) r1 = *reinterpret_cast<const U4 *>(rp + 4);
-    if (act && X.nwords > 7) r2 = *reinterpret_cast<const U2 *>(rp + 8);
-    const uint32_t sh = mad30(it.w, 30);
-    const uint32_t him = (uint32_t)((int32_t)0x80000000 >> ((sh - 1u) & 31u));  // (30 pm1 + 29) mod 32
-    const uint32_t p48 = it.y & 0xffu;
-    const uint32_t wd[7] = {it.z, r1.a, r1.b, r1.c, r1.d, r2.a, r2.b};
-    uint32_t tot = p48, w01ref = p48;
-#pragma unroll
-    for (int t = 3; t < 9; t++) {
-        const uint32_t f = __builtin_amdgcn_alignbit(wd[t - 3], wd[t - 2], sh);
-        const uint32_t mm = hscan_mism(X, rw, t, f);
-        tot = popc_acc(mm, tot);
-        if (t == 3) w01ref = popc_acc(mm & him, w01ref);
-    }
-    X.acc.f5 += (uint32_t)__builtin_popcountll(bsx_ballot(act && w01ref <= X.thres0));
-    // (chromosome / end-of-sequence test and hit coordinates are left to the control kernel's replay: the record carries
-    //  the strand copy and the global position)
-    const bool pass = act && tot <= X.thres0;
-    const u64 m = bsx_ballot(pass);
-    if (m) {
-        const uint32_t pos = X.nsurv + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-        if (pass && pos < HS_SCAP) { SurvRec r; r.w_ord = tot | ((it.y & 0x7fffff00u)); r.hchr = it.y >> 31; r.hloc = it.w + 1; r.hkey = 0; X.o->surv[pos] = r; }
-        X.nsurv += (uint32_t)__builtin_popcountll(m);
-        if (X.nsurv > HS_SCAP) X.overflow = true;
-    }
-}
-
-// stage 1 for one chunk: 64 candidates, lane l holds one (pm1 = its position - 1, boff = byte offset of its first reference
-// word, r0 = those four words); candidates still within the threshold after 48 nt go into the FIFO.  MASKED: some lanes hold
-// no candidate (`valid`).
-template <bool MASKED>
-__device__ __forceinline__ void hscan_eval(ScanCtx &X, const U4 r0, uint32_t pm1, uint32_t boff, bool valid, uint32_t tag, int u, const uint32_t (&rw)[9],
-                                           const uint32_t (&rm)[9])
-{
-    const uint32_t sh = mad30(pm1, 30);
-    const uint32_t him = (uint32_t)((int32_t)0x80000000 >> ((sh - 1u) & 31u));  // (30 pm1 + 29) mod 32
-    const uint32_t f0 = __builtin_amdgcn_alignbit(r0.a, r0.b, sh), f1 = __builtin_amdgcn_alignbit(r0.b, r0.c, sh), f2 = __builtin_amdgcn_alignbit(r0.c, r0.d, sh);
-    const uint32_t m1 = hscan_mism(X, rw, 1, f1);
-    const uint32_t c0 = __popc(hscan_mism(X, rw, 0, f0));
-    const uint32_t w0ref = popc_acc(m1 & him, c0);
-    uint32_t p48 = popc_acc(hscan_mism(X, rw, 2, f2), popc_acc(m1, c0));
-    const bool need = (!MASKED || valid) && p48 <= X.thres0;
-    X.acc.c1 += (uint32_t)__builtin_popcountll(bsx_ballot((!MASKED || valid) && w0ref > X.thres0));
-    const u64 nm = bsx_ballot(need);
-    if (nm) {
-        if (need) {
-            const uint32_t pos = X.qh + X.qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(nm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nm, 0u));
-            X.Q[pos & (HS_QCAP - 1)] = make_uint4(boff, p48 | tag, r0.d, pm1);
-        }
-        X.qn += (uint32_t)__builtin_popcountll(nm);
-    }
-    if (u & 1) {  // (FIFO writes and reads of a wave are ordered: same wave, same LDS)
-        while (X.qn >= 64 && !X.overflow) hscan_drain(X, 64, rw, rm);
-    }
-}
-
-// stage 1 for 256 consecutive entries of an RRBS bucket ({tag, loc} pairs, align.cpp:175-252): only entries of the read's
-// segment / direction are candidates (tag filter), the strand copy comes with the entry, the position is chromosome-local
-__device__ __forceinline__ void hscan_step_rrbs(ScanCtx &X, const U2 *__restrict__ q, uint32_t n_here, uint32_t ord0, uint32_t h, uint32_t tag_xor, uint32_t tag_want,
-                                                uint32_t cref_off, const uint32_t *anchor, const uint32_t (&rw)[9], const uint32_t (&rm)[9])
-{
-    const int lane = X.lane;
-    U2 e[4];
-    uint32_t pm1[4], boff[4], tag[4];
-    bool valid[4];
-    U4 r0[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) { e[u].a = e[u].b = 0; if ((uint32_t)(u * 64 + lane) < n_here) e[u] = q[u * 64]; }
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-        const uint32_t rchr = e[u].a & 0xffffu;
-        valid[u] = (uint32_t)(u * 64 + lane) < n_here && ((e[u].a ^ tag_xor) >> 16) == tag_want && e[u].b >= h;  // mode or strand not match / underflow the start of refseq
-        pm1[u] = valid[u] ? anchor[rchr >> 1] + (e[u].b - h) - 1u : 15u;
-        boff[u] = ((pm1[u] >> 2) & 0x3ffffffcu) + ((rchr & 1u) ? cref_off : 0u);
-        tag[u] = (ord0 + (uint32_t)(u * 64 + lane)) << 8 | (rchr & 1u) << 31;
-        X.acc.nv += (uint32_t)__builtin_popcountll(bsx_ballot(valid[u]));
-    }
-#pragma unroll
-    for (int u = 0; u < 4; u++) r0[u] = *reinterpret_cast<const U4 *>(reinterpret_cast<const uint8_t *>(X.refall) + (valid[u] ? boff[u] : 0u));
-#pragma unroll
-    for (int u = 0; u < 4; u++) hscan_eval<true>(X, r0[u], pm1[u], boff[u], valid[u], tag[u], u, rw, rm);
-}
-
-// stage 1 for 256 consecutive candidates of one sub-range (four chunks of 64; lane l of chunk u holds candidate
-// cb + 64u + l).  FULL: all 256 exist (every step of a sub-range but its last).
-// e[]: the step's index entries, already in registers — loaded one step ahead, so that a step is ONE exposed memory round trip
-// (its reference gathers) instead of two dependent ones (entries, then gathers); a FULL step requests the entries of the step
-// behind it from `nextq` (one address + immediate offsets; may run up to 255 entries past the sub-range: loaded, never used —
-// BSX_ENTRY_PAD zeroed words lie behind the last entry).
-template <bool FULL>
-__device__ __forceinline__ void hscan_step(ScanCtx &X, uint32_t (&e)[4], const uint32_t *__restrict__ nextq, uint32_t ref_off, uint32_t hm1, uint32_t n_here, uint32_t ord0,
-                                           uint32_t strand, const uint32_t (&rw)[9], const uint32_t (&rm)[9])
-{
-    const int lane = X.lane;
-    uint32_t pm1[4], boff[4];
-    bool valid[4];
-    U4 r0[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-        valid[u] = FULL || (uint32_t)(u * 64 + lane) < n_here;
-        pm1[u] = (FULL || valid[u]) ? e[u] + hm1 : 15u;
-        boff[u] = ((pm1[u] >> 2) & 0x3ffffffcu) + ref_off;
-    }
-#pragma unroll
-    for (int u = 0; u < 4; u++) r0[u] = *reinterpret_cast<const U4 *>(reinterpret_cast<const uint8_t *>(X.refall) + boff[u]);
-    if (FULL) {
-#pragma unroll
-        for (int u = 0; u < 4; u++) e[u] = nextq[u * 64];
-    }
-    const uint32_t tag = (ord0 + (uint32_t)lane) << 8 | strand << 31;
-#pragma unroll
-    for (int u = 0; u < 4; u++) hscan_eval<!FULL>(X, r0[u], pm1[u], boff[u], valid[u], tag + ((uint32_t)u << 14), u, rw, rm);
-}
-
-// one scan task (a window of up to HS_TASK candidates of one published list) on one wave
-__device__ __forceinline__ void hscan_task(const AlignArgs &A, const HeavyArgs &H, uint32_t slot, int lane, int wv, uint32_t (&TAB)[BSX_HSCAN_WPB][4][32],
-                                           uint4 (&QBUF)[BSX_HSCAN_WPB][HS_QCAP], const uint32_t *ANCH)
-{
-    const DevParams &P = A.P;
-    const uint32_t t = H.order ? rfl(H.order[slot]) : slot;
-    const uint32_t hraw = rfl(H.tasks[t].h), hidx = hraw & 0x3fffffffu, tc0 = rfl(H.tasks[t].c0), tn = rfl(H.tasks[t].n);
-    HTaskOut *o = &H.tout[t];
-    if (tn == 0) {  // slot neutralised by a refused request: its unit has not published a list (ListReq may be stale)
-        if (lane == 0) { o->count = 0; o->overflow = 0; o->acc[0] = o->acc[1] = o->acc[2] = o->acc[3] = 0; o->c0 = 0; o->n = 0; }
-        return;
-    }
-    const ListReq &R = H.state[hidx].req[hraw >> 30];
-    if (lane < 32) { TAB[wv][0][lane] = R.sub_pre[lane]; TAB[wv][1][lane] = R.sub_n[lane]; TAB[wv][2][lane] = R.sub_base[lane]; TAB[wv][3][lane] = R.sub_h[lane]; }
-    uint32_t rw[9], rm[9];
-#pragma unroll
-    for (int k = 0; k < 9; k++) { rw[k] = rfl(R.rw[k]); rm[k] = rfl(R.rm[k]); }
-    const uint32_t nsub = min(rfl(R.nsub), 32u);
-    wave_fence();
-    ScanCtx X;
-    X.refall = P.refcat; X.Q = QBUF[wv]; X.qh = 0; X.qn = 0; X.thres0 = rfl(R.thres); X.nsurv = 0; X.nwords = (int)rfl(R.nwords); X.lane = lane;
-    X.overflow = false; X.o = o; X.acc.c1 = 0; X.acc.f5 = 0; X.acc.nv = 0;
-#pragma unroll
-    for (int k = 0; k < 9; k++) { X.tv[k] = bsx_tmask(rw[k], rm[k]); if (k < BSX_HSCAN_TMV) asm volatile("" : "+v"(X.tv[k])); }
-#if BSX_HSCAN_VVV
-#pragma unroll
-    for (int k = 0; k < BSX_HSCAN_RV; k++) { X.rv[k] = rw[k]; asm volatile("" : "+v"(X.rv[k])); }
-    X.kA = 0xAAAAAAAAu; asm volatile("" : "+v"(X.kA));
-#endif
-    const uint32_t cref_off = (uint32_t)((const uint8_t *)P.crefcat - (const uint8_t *)P.refcat);  // both copies live in one allocation (bsx_api.hip)
-    const uint32_t c_end = tc0 + tn;
-    const bool rrbs = rfl(R.rrbs) != 0;
-    if (rrbs) {  // one bucket of {tag, loc} pairs; four chunks of 64 entries per step, the tag filter decides which are candidates
-        const U2 *ent2 = reinterpret_cast<const U2 *>(P.entries) + rfl(TAB[wv][2][0]);
-        const uint32_t h = rfl(TAB[wv][3][0]), tx = rfl(R.tag_xor), tw = rfl(R.tag_want);
-        const uint32_t *anchor = P.n_chr <= BSX_LDS_CHR ? ANCH : P.anchor;
-        for (uint32_t cb = tc0; cb < c_end && !X.overflow; cb += 256)
-            hscan_step_rrbs(X, ent2 + cb + lane, min(256u, c_end - cb), cb - tc0, h, tx, tw, cref_off, anchor, rw, rm);
-    }
-    // the task's candidates sub-range by sub-range (list order): inside one sub-range entry address, h and strand are
-    // wave-uniform; four chunks are in flight per step — entries first, then all four 16-byte reference loads.
-    // Neighbouring lanes hold neighbouring entries, so in a repeat bucket one reference gather touches few lines.
-    for (uint32_t sidx = 0; sidx < nsub && !X.overflow && !rrbs; sidx++) {
-        const uint32_t ps = rfl(TAB[wv][0][sidx]), ns = rfl(TAB[wv][1][sidx]);
-        const uint32_t lo = max(tc0, ps), hi = min(c_end, ps + ns);
-        if (lo >= hi) continue;
-        const uint32_t *ent = P.entries + rfl(TAB[wv][2][sidx]);
-        const uint32_t hm1 = rfl(TAB[wv][3][sidx]) - 1u, strand = sidx & 1;
-        const uint32_t ref_off = strand ? cref_off : 0u;
-        uint32_t cb = lo;
-        uint32_t e[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) e[u] = (ent + (cb - ps) + lane)[u * 64];
-        for (; cb + 256 <= hi && !X.overflow; cb += 256) hscan_step<true>(X, e, ent + (cb + 256 - ps) + lane, ref_off, hm1, 256, cb - tc0, strand, rw, rm);
-        if (cb < hi && !X.overflow) hscan_step<false>(X, e, nullptr, ref_off, hm1, hi - cb, cb - tc0, strand, rw, rm);
-    }
-    while (X.qn && !X.overflow) hscan_drain(X, min(X.qn, 64u), rw, rm);
-    const uint32_t n1 = X.acc.c1, n5 = X.acc.f5;
-    const uint32_t n_cand = rrbs ? X.acc.nv : tn;  // RRBS: only the entries that passed the tag filter are candidates
-    const uint32_t words = 2u * n_cand - n1 + 3u * n5;  // 1, 2 or 5 words per candidate (see above)
-    if (lane == 0) {
-        o->count = X.overflow ? 0 : X.nsurv; o->overflow = X.overflow ? 1 : 0; o->acc[0] = n_cand; o->acc[1] = words; o->acc[2] = 0; o->acc[3] = 0; o->c0 = tc0; o->n = tn;
-        if (!X.overflow) {  // work of the scan kernel (incl. speculation); an overflowed task is redone by the control kernel.
-            // Millions of tasks per batch: one counter word takes ~88 atomics per microsecond, so these statistics are
-            // sharded over 64 cache lines (summed by bsx_batch_counters) instead of being added to four hot words
-            u64 *sh = (u64 *)A.scan_stats + (size_t)(blockIdx.x & 63u) * 8;
-            atomicAdd((u64 *)&sh[0], (u64)n_cand); atomicAdd((u64 *)&sh[1], (u64)words);
-            atomicAdd((u64 *)&sh[2], (u64)n1); atomicAdd((u64 *)&sh[3], (u64)n5);
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------------
-// k_hscan on bit planes (BSX_HSCAN_PLANES, the default).  The candidate's reference comes from the PLANE copy (DevParams::refplane:
+// k_hscan on bit planes (the packed-copy form of rounds 2-3 is in the history).  The candidate's reference comes from the PLANE copy (DevParams::refplane:
 // per 32 nt a {low bits, high bits} pair) and is compared where it lies; the READ is what gets shifted — once per task, into a
 // per-wave LDS table of its 32 possible shifts (the reference's own scheme, align.cpp:107-161, on 32-nt words).  Per 32 nt a
 // candidate then costs three v_bitop3 and one v_bcnt (bsx_plane_mismatch) — no funnel shifts, no per-candidate shift amounts
@@ -2391,9 +2135,6 @@ __device__ __forceinline__ void hscan_task(const AlignArgs &A, const HeavyArgs &
 //          (8-byte items: position, partial count | ordinal | strand).
 // Work accounting as before: w0ref <= p64 <= w01ref, so  words = 2 n - #(w0ref > thres) + 3 #(w01ref <= thres).
 // ---------------------------------------------------------------------------------------------------------------
-#ifndef BSX_HSCAN_PLANES
-#define BSX_HSCAN_PLANES 1
-#endif
 #define HP_QCAP 128u  /* FIFO slots per wave (8 bytes each): at most 63 left over + one chunk of 64 pushed between drains */
 #define HP_PAIRS 10u
 typedef unsigned long long q64;
@@ -2546,7 +2287,7 @@ __device__ __forceinline__ void hp_step(PlaneCtx &X, uint32_t (&e)[4], const uin
     }
 }
 
-// one scan task on one wave, plane form (same contract as hscan_task)
+// one scan task on one wave: candidates [c0, c0 + n) of the task's list, survivors in list order and the work counters into its output record
 // (TABw / PTw / Qw: this wave's sub-range table, read table and FIFO in LDS)
 __device__ __forceinline__ void hp_task(const AlignArgs &A, const HeavyArgs &H, uint32_t t, int lane, uint32_t (&TABw)[4][32], uint2 *PTw, uint2 *Qw)
 {
@@ -2589,7 +2330,9 @@ __device__ __forceinline__ void hp_task(const AlignArgs &A, const HeavyArgs &H, 
     const uint32_t words = 2u * n_cand - n1 + 3u * n5;  // 1, 2 or 5 words per candidate (see above)
     if (lane == 0) {
         o->count = X.overflow ? 0 : X.nsurv; o->overflow = X.overflow ? 1 : 0; o->acc[0] = n_cand; o->acc[1] = words; o->acc[2] = 0; o->acc[3] = 0; o->c0 = tc0; o->n = tn;
-        if (!X.overflow) {  // (sharded statistics: see hscan_task)
+        if (!X.overflow) {  // work of the scan kernel (incl. speculation); an overflowed task is redone by the control kernel.
+            // Millions of tasks per batch: one counter word takes ~88 atomics per microsecond, so these statistics are
+            // sharded over 64 cache lines (summed by bsx_batch_counters) instead of being added to four hot words
             u64 *sh = (u64 *)A.scan_stats + (size_t)(blockIdx.x & 63u) * 8;
             atomicAdd((u64 *)&sh[0], (u64)n_cand); atomicAdd((u64 *)&sh[1], (u64)words);
             atomicAdd((u64 *)&sh[2], (u64)n1); atomicAdd((u64 *)&sh[3], (u64)n5);
@@ -2600,21 +2343,9 @@ __device__ __forceinline__ void hp_task(const AlignArgs &A, const HeavyArgs &H, 
 __global__ __launch_bounds__(64 * BSX_HSCAN_WPB, BSX_HSCAN_WAVES) void k_hscan(AlignArgs A, HeavyArgs H)
 {
     __shared__ uint32_t TAB[BSX_HSCAN_WPB][4][32];
-#if BSX_HSCAN_PLANES
     __shared__ uint2 PT[BSX_HSCAN_WPB][HP_PAIRS * 32];   // the read of each wave's task at its 32 shifts
     __shared__ uint2 QBUF[BSX_HSCAN_WPB][HP_QCAP];
-#else
-    __shared__ uint4 QBUF[BSX_HSCAN_WPB][HS_QCAP];
-#endif
     const int lane = threadIdx.x & 63, wv = (int)rfl(threadIdx.x >> 6);  // (the wave number as a scalar: what depends on it stays wave-uniform for the compiler)
-#if !BSX_HSCAN_PLANES
-    __shared__ uint32_t ANCH[BSX_LDS_CHR + 1];  // RRBS: chromosome anchors (entries carry chromosome-local positions)
-    const DevParams &P = A.P;
-    if (P.rrbs) {
-        if (P.n_chr <= BSX_LDS_CHR) for (uint32_t i = threadIdx.x; i <= P.n_chr; i += 64 * BSX_HSCAN_WPB) ANCH[i] = P.anchor[i];
-        __syncthreads();
-    }
-#endif
     // one task per wave and sweep, no queue: the blocks of a pass retire one by one, so the control kernel of the other unit
     // group (high-priority stream) finds free slots while this kernel is still running
     const uint32_t n_tasks = min(*H.n_tasks, H.task_cap);
@@ -2629,11 +2360,7 @@ __global__ __launch_bounds__(64 * BSX_HSCAN_WPB, BSX_HSCAN_WAVES) void k_hscan(A
         if (st_ == 2) break;
         if (st_ == 1) continue;
         const uint32_t slot = b_ * BSX_HSCAN_WPB + (uint32_t)wv;
-#if BSX_HSCAN_PLANES
         if (slot < n_tasks) hp_task(A, H, H.order ? rfl(H.order[slot]) : slot, lane, TAB[wv], PT[wv], QBUF[wv]);
-#else
-        if (slot < n_tasks) hscan_task(A, H, slot, lane, wv, TAB, QBUF, ANCH);
-#endif
         wave_fence();
     }
 }
@@ -3126,7 +2853,7 @@ __device__ __forceinline__ void hs_group(const AlignArgs &A, const HeavyArgs &H,
     const bool cnt = mine && !ov;
     const uint32_t kk = (uint32_t)__builtin_popcountll(bsx_ballot(cnt));
     const uint32_t s1 = wave_sum(cnt ? n1 : 0), s5 = wave_sum(cnt ? n5 : 0);
-    if (lane == 0 && kk) {   // (sharded statistics: see hscan_task)
+    if (lane == 0 && kk) {   // (sharded statistics: see hp_task)
         u64 *sh = (u64 *)A.scan_stats + (size_t)((blockIdx.x * (uint32_t)HG_WPB + (uint32_t)wv) & 63u) * 8;
         atomicAdd((u64 *)&sh[0], (u64)kk * n_cand); atomicAdd((u64 *)&sh[1], 2ull * kk * n_cand - s1 + 3ull * s5); atomicAdd((u64 *)&sh[2], (u64)s1); atomicAdd((u64 *)&sh[3], (u64)s5);
         if (K > 1) atomicAdd((u64 *)&sh[4], (u64)kk * n_cand);   // counter 15: candidates evaluated in groups of two reads and more
@@ -3242,7 +2969,6 @@ __global__ __launch_bounds__(256) void k_task_groups(const HTask *tasks, const u
 #ifndef BSX_HSHARED_WAVES
 #define BSX_HSHARED_WAVES 5  /* waves per SIMD the register budget is set for */
 #endif
-#if BSX_HSCAN_PLANES
 // Plane form: the candidate's pairs of the plane copy are funnel-shifted into the READ's frame once per candidate (all reads of a run
 // have the same offset, hence the same shift) and every read of the run is compared 32 nt at a time: three v_bitop3 and one v_bcnt
 // per word (bsx_plane_mismatch) against four instructions per 16 nt on the packed copy.  Read frame word j holds read nt
@@ -3417,176 +3143,6 @@ __global__ __launch_bounds__(256, BSX_HSHARED_WAVES) void k_hscan_shared(AlignAr
     wave_fence();
     }
 }
-#else
-struct SharedChunk { uint32_t wd[10]; uint32_t pm1, strand; bool valid; };
-
-__device__ __forceinline__ SharedChunk shared_load(const U2 *__restrict__ ent2, uint32_t idx, bool in_range, uint32_t h, uint32_t tag_xor, uint32_t tag_want,
-                                                   const uint32_t *anchor, const uint32_t *refall, uint32_t cref_off, int nwords)
-{
-    SharedChunk c;
-    U2 e; e.a = e.b = 0;
-    if (in_range) e = ent2[idx];
-    const uint32_t rchr = e.a & 0xffffu;
-    c.valid = in_range && ((e.a ^ tag_xor) >> 16) == tag_want && e.b >= h;  // mode or strand not match / underflow the start of refseq
-    c.pm1 = c.valid ? anchor[rchr >> 1] + (e.b - h) - 1u : 15u;
-    c.strand = rchr & 1u;
-    const uint32_t boff = c.valid ? ((c.pm1 >> 2) & 0x3ffffffcu) + (c.strand ? cref_off : 0u) : 0u;
-    const uint32_t *rp = reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(refall) + boff);
-    const U4 r0 = *reinterpret_cast<const U4 *>(rp);
-    U4 r1; U2 r2;
-    r1.a = r1.b = r1.c = r1.d = 0; r2.a = r2.b = 0;
-    if (c.valid && nwords > 3) r1 = *reinterpret_cast<const U4 *>(rp + 4);
-    if (c.valid && nwords > 7) r2 = *reinterpret_cast<const U2 *>(rp + 8);
-    c.wd[0] = r0.a; c.wd[1] = r0.b; c.wd[2] = r0.c; c.wd[3] = r0.d; c.wd[4] = r1.a; c.wd[5] = r1.b; c.wd[6] = r1.c; c.wd[7] = r1.d; c.wd[8] = r2.a; c.wd[9] = r2.b;
-    return c;
-}
-
-__global__ __launch_bounds__(256, BSX_HSHARED_WAVES) void k_hscan_shared(AlignArgs A, HeavyArgs H)
-{
-    __shared__ __attribute__((aligned(16))) uint32_t UW[4][HS_SHARE][20];   // per read of the run: 9 read words, 9 T-masks, threshold, task id
-    __shared__ uint32_t ANCH[BSX_LDS_CHR + 1];
-    const DevParams &P = A.P;
-    const int lane = threadIdx.x & 63, wv = (int)rfl(threadIdx.x >> 6);  // (the wave number as a scalar: what depends on it stays wave-uniform for the compiler)
-    if (P.n_chr <= BSX_LDS_CHR) for (uint32_t i = threadIdx.x; i <= P.n_chr; i += 256) ANCH[i] = P.anchor[i];
-    __syncthreads();
-    const uint32_t *anchor = P.n_chr <= BSX_LDS_CHR ? ANCH : P.anchor;
-    const uint32_t n_tasks = min(*H.n_tasks, H.task_cap);
-    const uint32_t cref_off = (uint32_t)((const uint8_t *)P.crefcat - (const uint8_t *)P.refcat);
-    uint32_t kA = 0xAAAAAAAAu; asm volatile("" : "+v"(kA));   // in a VGPR: see hscan_mism
-    // (grid sized for the task pool, or — in the tail of a batch — smaller: then a wave sweeps over the order with the stride of the grid)
-    const uint32_t nvb = (n_tasks + 4u * HS_SHARE - 1u) / (4u * HS_SHARE);
-    for (uint32_t vb = blockIdx.x;; vb += gridDim.x) {
-    uint32_t b_;
-    const int st_ = bsx_order_block(vb, nvb, H.xcd_map >= 2 ? max(2u, H.xcd_map / 32u) : H.xcd_map, b_);   // (a block takes 64 tasks: 32 of k_hscan's blocks)
-    if (st_ == 2) break;
-    const uint32_t s0 = (b_ * 4u + (uint32_t)wv) * HS_SHARE;
-    if (st_ == 1 || s0 >= n_tasks) continue;
-    const uint32_t nj = min(HS_SHARE, n_tasks - s0);
-    // lane j < nj: task j of this wave, in scan order, and the signature of its window
-    uint32_t tid = 0, th = 0, tc0 = 0, tn = 0, tkey = 0, sh_ = 0, stx = 0, stw = 0, snw = 0;
-    if ((uint32_t)lane < nj) {
-        tid = H.order ? H.order[s0 + lane] : s0 + (uint32_t)lane;
-        const HTask tk = H.tasks[tid];
-        th = tk.h; tc0 = tk.c0; tn = tk.n; tkey = tk.key;
-        if (tn) {
-            const ListReq &R = H.state[th & 0x3fffffffu].req[th >> 30];
-            tkey = R.sub_base[0] + (tc0 - R.sub_pre[0]);  // first entry of the window
-            sh_ = R.sub_h[0]; stx = R.tag_xor; stw = R.tag_want; snw = R.nwords;
-        } else {  // slot neutralised by a refused request: its unit has not published a list
-            HTaskOut *o = &H.tout[tid];
-            o->count = 0; o->overflow = 0; o->acc[0] = o->acc[1] = o->acc[2] = o->acc[3] = 0; o->c0 = 0; o->n = 0;
-        }
-    }
-    u64 st_cand = 0, st_words = 0, st_n1 = 0, st_n5 = 0;  // statistics of the scan kernel (lane 0)
-    for (uint32_t i0 = 0; i0 < nj;) {
-        if (rl(tn, (int)i0) == 0) { i0++; continue; }
-        // the run of tasks from i0 that cover exactly the same window
-        const bool same = (uint32_t)lane >= i0 && (uint32_t)lane < nj && tn == rl(tn, (int)i0) && tkey == rl(tkey, (int)i0) && sh_ == rl(sh_, (int)i0) &&
-                          stx == rl(stx, (int)i0) && stw == rl(stw, (int)i0) && snw == rl(snw, (int)i0);
-        const u64 sm = bsx_ballot(same) >> i0;
-        const uint32_t K = (uint32_t)__builtin_ctzll(~sm);  // (bit 0 is set: the task equals itself)
-        const uint32_t key = rl(tkey, (int)i0), n = rl(tn, (int)i0), h = rl(sh_, (int)i0), tx = rl(stx, (int)i0), tw = rl(stw, (int)i0);
-        const int nwords = (int)rl(snw, (int)i0);
-        wave_fence();
-        for (uint32_t xb = 0; xb < K * 20u; xb += 64) {
-            const uint32_t x = xb + (uint32_t)lane, k = min(x / 20u, K - 1u), f = x - k * 20u;
-            const uint32_t hk = (uint32_t)__shfl((int)th, (int)(i0 + k)), tk = (uint32_t)__shfl((int)tid, (int)(i0 + k));  // (all lanes take part)
-            if (x < K * 20u) {
-                const ListReq &R = H.state[hk & 0x3fffffffu].req[hk >> 30];
-                uint32_t v;
-                if (f < 9) v = R.rw[f];
-                else if (f < 18) v = bsx_tmask(R.rw[f - 9], R.rm[f - 9]);
-                else if (f == 18) v = R.thres;
-                else v = tk;
-                UW[wv][k][f] = v;
-            }
-        }
-        uint32_t c15 = 0, nsv = 0;  // lane k: counters of read k (see the loop)
-        wave_fence();
-        const U2 *ent2 = reinterpret_cast<const U2 *>(P.entries) + key;
-        SharedChunk cur = shared_load(ent2, (uint32_t)lane, (uint32_t)lane < n, h, tx, tw, anchor, P.refcat, cref_off, nwords);
-        uint32_t nv = 0;
-        for (uint32_t cb = 0; cb < n; cb += 64) {
-            SharedChunk nxt;
-            const bool more = cb + 64 < n;
-            if (more) nxt = shared_load(ent2, cb + 64 + (uint32_t)lane, cb + 64 + (uint32_t)lane < n, h, tx, tw, anchor, P.refcat, cref_off, nwords);
-            // the candidate's reference words in the read frame — the same for every read of the run
-            const uint32_t shf = mad30(cur.pm1, 30);
-            const uint32_t him = (uint32_t)((int32_t)0x80000000 >> ((shf - 1u) & 31u));  // (30 pm1 + 29) mod 32
-            uint32_t f[9];
-#pragma unroll
-            for (int t = 0; t < 9; t++) f[t] = __builtin_amdgcn_alignbit(cur.wd[t], cur.wd[t + 1], shf);
-            nv += cur.valid ? 1u : 0u;
-            const uint32_t ord = (cb + (uint32_t)lane) << 8;
-            const u64 vm = bsx_ballot(cur.valid);
-            const uint4 *up = reinterpret_cast<const uint4 *>(UW[wv][0]);
-            for (uint32_t k = 0; k < K; k++, up += 5) {
-                const uint4 a0 = up[0], a1 = up[1], a2 = up[2], a3 = up[3], a4 = up[4];  // read words 0-3 | 4-7 | 8, masks 0-2 | masks 3-6 | masks 7-8, threshold, task id
-                const uint32_t thr = a4.z;
-                const uint32_t m1 = mism_vvv(kA, a0.y, a2.z, f[1]);
-                const uint32_t c0 = __popc(mism_vvv(kA, a0.x, a2.y, f[0]));
-                const uint32_t w0ref = popc_acc(m1 & him, c0);
-                uint32_t tot = popc_acc(mism_vvv(kA, a0.z, a2.w, f[2]), popc_acc(m1, c0));
-                uint32_t w01ref = tot;
-                // (the words behind the first 48 nt only matter for candidates still within the threshold there: where no lane of the chunk
-                //  is — half of the chunks of an RRBS repeat family — they are skipped; both early-out classes and the survivors are settled)
-                if (nwords > 3 && (bsx_ballot(tot <= thr) & vm)) {
-                    const uint32_t m3 = mism_vvv(kA, a0.w, a3.x, f[3]);
-                    tot = popc_acc(m3, tot); w01ref = popc_acc(m3 & him, w01ref);
-                    tot = popc_acc(mism_vvv(kA, a1.x, a3.y, f[4]), tot);
-                    if (nwords > 5) {
-                        tot = popc_acc(mism_vvv(kA, a1.y, a3.z, f[5]), tot);
-                        tot = popc_acc(mism_vvv(kA, a1.z, a3.w, f[6]), tot);
-                        if (nwords > 7) {
-                            tot = popc_acc(mism_vvv(kA, a1.w, a4.x, f[7]), tot);
-                            tot = popc_acc(mism_vvv(kA, a2.x, a4.y, f[8]), tot);
-                        }
-                    }
-                }
-                const u64 b1 = bsx_ballot(w0ref > thr) & vm, b5 = bsx_ballot(w01ref <= thr) & vm, bp = bsx_ballot(tot <= thr) & vm;
-                // lane k keeps read k's counters: candidates beyond the first word | five-word candidates << 16, survivors
-                const uint32_t add15 = (uint32_t)__builtin_popcountll(b1) | ((uint32_t)__builtin_popcountll(b5) << 16);
-                if ((uint32_t)lane == k) c15 += add15;
-                if (bp) {
-                    const uint32_t base = rl_u(nsv, k);
-                    const uint32_t pos = base + (uint32_t)__builtin_popcountll(bp & lanemask_lt(lane));
-                    if (((bp >> lane) & 1) && pos < HS_SCAP) {
-                        SurvRec r; r.w_ord = tot | ord; r.hchr = cur.strand; r.hloc = cur.pm1 + 1; r.hkey = 0;
-                        H.tout[a4.w].surv[pos] = r;
-                    }
-                    if ((uint32_t)lane == k) nsv += (uint32_t)__builtin_popcountll(bp);
-                }
-            }
-            if (more) cur = nxt;
-        }
-        wave_fence();
-        const uint32_t n_cand = wave_sum(nv);
-        {
-            const bool mine = (uint32_t)lane < K;
-            const uint32_t my_c0 = (uint32_t)__shfl((int)tc0, (int)min(i0 + (uint32_t)lane, 63u));  // (all lanes take part) the list ordinal read `lane`'s task starts at
-            const uint32_t ns = nsv, n1 = c15 & 0xffffu, n5 = c15 >> 16;
-            const bool ov = ns > HS_SCAP;
-            if (mine) {
-                HTaskOut *o = &H.tout[UW[wv][lane][19]];
-                o->count = ov ? 0 : ns; o->overflow = ov ? 1 : 0; o->acc[0] = n_cand; o->acc[1] = 2u * n_cand - n1 + 3u * n5; o->acc[2] = 0; o->acc[3] = 0; o->c0 = my_c0; o->n = n;
-            }
-            // work of the scan kernel (incl. speculation); an overflowed task is redone by the control kernel
-            const bool cnt = mine && !ov;
-            const uint32_t kk = (uint32_t)__builtin_popcountll(bsx_ballot(cnt));
-            const uint32_t s1 = wave_sum(cnt ? n1 : 0), s5 = wave_sum(cnt ? n5 : 0);
-            st_cand += (u64)kk * n_cand; st_n1 += s1; st_n5 += s5; st_words += 2ull * kk * n_cand - s1 + 3ull * s5;
-        }
-        wave_fence();
-        i0 += K;
-    }
-    if (lane == 0) {
-        u64 *sh = (u64 *)A.scan_stats + (size_t)(blockIdx.x & 63u) * 8;
-        atomicAdd((u64 *)&sh[0], st_cand); atomicAdd((u64 *)&sh[1], st_words); atomicAdd((u64 *)&sh[2], st_n1); atomicAdd((u64 *)&sh[3], st_n5);
-    }
-    wave_fence();
-    }
-}
-#endif
 }  // namespace
 
 // exact mode pre-pass (see k_leak_meta): with_meta = the stream's records are not up to date (new reads / history); `final_out` != null:
