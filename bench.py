@@ -98,8 +98,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of each cpu_baseline sample (0 = skip)")
     ap.add_argument("--e2e-pairs", type=int, default=16 << 20, help="pairs of the end-to-end CLI run (FASTQ -> SAM in /dev/shm) reported beside the metric; 0 = skip")
     ap.add_argument("--in-flight", type=int, default=0, help="batches in flight per GPU (host threads, one device batch each): the main kernel and the "
-                    "latency-bound tail of one batch overlap the scan passes of the other; 1 = strictly one Do_Batch at a time; default 2 (3 for "
-                    "--mode trim, whose control passes are long: 296-303 against 327 ms per step)")
+                    "latency-bound tail of one batch overlap the scan passes of the other; 1 = strictly one Do_Batch at a time; default 3")
     ap.add_argument("--transfer-steps", type=int, default=-1, help="steps of the PCIe-inclusive leg (upload -> Do_Batch -> results per step); -1 = as many as --steps (the same window length as the metric's), 0 = skip")
     ap.add_argument("--waves-per-cu", type=int, default=0)
     ap.add_argument("--heavy-limits", default="", help="tuning: units per round,scan-task pool of the heavy pipeline")
@@ -120,7 +119,7 @@ def main():
     if args.selftest_launch:
         return selftest_launch()
     if args.in_flight <= 0:
-        args.in_flight = 3 if args.mode in ("trim", "rrbs") else 2
+        args.in_flight = 3   # (three for every mode since the group scan kernel: C3 94.0-95.3 ms per step against 96.8-99.3 with two, five A/B pairs on three boxes)
         # C4: the control passes of its 630 K deferred reads hide better under three batches, whose pools then have to be two thirds
         # of the default size to fit (three with default pools do not fit; two with these pools: 169 ms per step against 150)
         if args.mode == "rrbs" and not args.heavy_limits and not args.profile_serial:
