@@ -3343,10 +3343,10 @@ void bsx_launch_task_order(const HeavyArgsRaw &R, uint32_t shift, uint32_t n_bin
 {
     const uint32_t grid = std::max(1u, std::min(512u, (R.task_cap + 255u) / 256u)), n_chunks = bsx_bin_chunks(n_bins);
     hipLaunchKernelGGL(k_task_bins, dim3(std::max(1u, std::min(256u, (R.task_cap + 1023u) / 1024u))), dim3(256), 0, stream, (const HTask *)R.tasks, R.n_tasks, R.task_cap, shift, n_bins, spread, bins, rank, zero_blk);
-    hipLaunchKernelGGL(k_bin_scan, dim3(n_chunks), dim3(256), 0, stream, R.n_tasks, bins, bstart, chunk_tot, n_bins, groups ? const_cast<uint32_t *>(R.glist) + R.task_cap : (uint32_t *)nullptr);
+    hipLaunchKernelGGL(k_bin_scan, dim3(n_chunks), dim3(256), 0, stream, R.n_tasks, bins, bstart, chunk_tot, n_bins, groups ? R.glist + R.task_cap : (uint32_t *)nullptr);
     hipLaunchKernelGGL(k_task_order, dim3(grid), dim3(256), 0, stream, (const HTask *)R.tasks, R.n_tasks, R.task_cap, shift, n_bins, spread, bstart, chunk_tot, n_chunks, rank, order);
     // (the ranks are spent: their array takes the group sizes)
-    if (groups) hipLaunchKernelGGL(k_task_groups, dim3(std::max(1u, std::min(1024u, (R.task_cap + 255u) / 256u))), dim3(256), 0, stream, (const HTask *)R.tasks, R.n_tasks, R.task_cap, order, rank, const_cast<uint32_t *>(R.glist));
+    if (groups) hipLaunchKernelGGL(k_task_groups, dim3(std::max(1u, std::min(1024u, (R.task_cap + 255u) / 256u))), dim3(256), 0, stream, (const HTask *)R.tasks, R.n_tasks, R.task_cap, order, rank, R.glist);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -57,7 +57,8 @@ struct HeavyArgsRaw {
     uint32_t n_active_in, task_cap, fresh, list_base, hidx_base;
     const uint32_t *order;     // task ids in scan order (sorted by the index entry they start at), or null
     uint32_t xcd_map;
-    const uint32_t *ghead, *glist;   // k_hscan_same: group sizes by scan slot, start slots of the groups [task_cap] + their count (bsx_launch_task_order with groups)
+    const uint32_t *ghead;           // k_hscan_same: group sizes by scan slot (bsx_launch_task_order with groups writes them into the rank array)
+    uint32_t *glist;                 // k_hscan_same: start slots of the groups [task_cap], then their two counts
 };
 
 void bsx_launch_align(const AlignArgs &A, int paired, int grid_blocks, hipStream_t stream);
