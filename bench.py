@@ -120,10 +120,10 @@ def main():
         return selftest_launch()
     if args.in_flight <= 0:
         args.in_flight = 3   # (three for every mode since the group scan kernel: C3 94.0-95.3 ms per step against 96.8-99.3 with two, five A/B pairs on three boxes)
-        # C4: the control passes of its 630 K deferred reads hide better under three batches, whose pools then have to be two thirds
-        # of the default size to fit (three with default pools do not fit; two with these pools: 169 ms per step against 150)
-        if args.mode == "rrbs" and not args.heavy_limits and not args.profile_serial:
-            args.heavy_limits = "110000,1400000"
+    # C4: the control passes of its 630 K deferred reads hide better under three batches, whose pools then have to be two thirds
+    # of the default size to fit (three with default pools do not fit; two with these pools: 169 ms per step against 150)
+    if args.mode == "rrbs" and args.in_flight >= 3 and not args.heavy_limits and not args.profile_serial:
+        args.heavy_limits = "110000,1400000"
     if args.profile_serial:
         args.in_flight, args.cpu_seconds, args.e2e_pairs, args.transfer_steps = 1, 0.0, 0, 0
         os.environ["BSX_HEAVY_GROUPS"] = "1"  # read by bsx_batch_create (also the default)
