@@ -44,6 +44,29 @@ MODES = {
 }
 
 
+RING_STEPS = 8          # distinct steps of resident reads (see main)
+RRBS_POOLS = "110000,1400000"   # starting pools of an RRBS batch when three are in flight (two thirds of the library's default: 26 GB of slabs, 1.4 M tasks)
+HBM_BYTES = 288e9       # MI355X
+
+
+def memory_plan(B, params, pe, B_, steps, warmup, nfl, n_entries, transfers, rrbs, genome_bp=3.1e9, n_cu=256, blocks_per_cu=5):
+    """device bytes of each phase of a run, from host arithmetic alone (bsx_batch_plan_bytes; tests/test_bench_memory_cpu.py holds every
+    mode's plan for the driver's `--steps 20 --warmup 5` under 0.9 of the device).  Pools count at their starting size: a batch halves them
+    when less is free, so the plan is an upper bound."""
+    ring = min(steps + warmup, RING_STEPS)
+    big = B.plan_bytes(params, B_ * ring, pe, n_entries, n_cu, blocks_per_cu)
+    small = B.plan_bytes(params, B_, pe, n_entries, n_cu, blocks_per_cu)
+    tot = lambda d: d["per_unit"] + d["scratch"] + d["pools"]
+    # reference: packed copy + plane copy (4 bits per nt in all), bucket offsets and forward counts, entries (RRBS: {tag, loc} pairs + group offsets)
+    K = int(params.total_kmers)
+    ref_b = genome_bp / 16 * 4 * 2 * 2 + 8.0 * K + n_entries * (8 if rrbs else 4) + (K * 32 * 4 if rrbs else 0)
+    build_b = 0 if rrbs else n_entries * 8 * 2 + n_entries * 4   # index build: key/value double buffers of the radix sort (transient)
+    nt = (1 if rrbs else min(nfl + 2, 4)) if transfers else 0
+    phases = {"index_build": ref_b + build_b, "timed": ref_b + nfl * tot(big), "side_legs": ref_b + tot(big) + nt * tot(small)}
+    return {"phases_GB": {k: round(v / 1e9, 1) for k, v in phases.items()}, "peak_GB": round(max(phases.values()) / 1e9, 1),
+            "peak_frac_of_device": round(max(phases.values()) / HBM_BYTES, 3), "per_batch_GB": {k: round(v / 1e9, 2) for k, v in big.items()}}
+
+
 def algorithmic_bytes(c, n_reads):
     """8*N_lookup + sum_cand(4 + 8*W_c) + 80*N_orient + 16 per read"""
     n_lookup, n_cand, sum_w, n_orient = (int(x) for x in c[:4])
@@ -123,7 +146,7 @@ def main():
     # C4: the control passes of its 630 K deferred reads hide better under three batches, whose pools then have to be two thirds
     # of the default size to fit (three with default pools do not fit; two with these pools: 169 ms per step against 150)
     if args.mode == "rrbs" and args.in_flight >= 3 and not args.heavy_limits and not args.profile_serial:
-        args.heavy_limits = "110000,1400000"
+        args.heavy_limits = RRBS_POOLS
     if args.profile_serial:
         args.in_flight, args.cpu_seconds, args.e2e_pairs, args.transfer_steps = 1, 0.0, 0, 0
         os.environ["BSX_HEAVY_GROUPS"] = "1"  # read by bsx_batch_create (also the default)
@@ -165,9 +188,14 @@ def main():
     ref.CreateIndex()
     t_index = time.time() - t0
     B_ = args.pairs_per_step
-    n_total = B_ * (args.steps + args.warmup)
+    # Resident reads: a ring of at most RING_STEPS distinct steps (2^20 pairs each: 300 MB of reads against 4 MB of L2 and 256 MB of
+    # Infinity Cache — a step that comes round again after 8 others finds nothing of itself anywhere).  Device memory then does not grow
+    # with --steps (round 4: 25 steps x 3 batches of resident reads left no room for the side legs under the driver's own command).
+    ring = min(args.steps + args.warmup, RING_STEPS)
+    n_total = B_ * ring
     nfl = max(1, args.in_flight)
     Align = B.PairAlign if pe else B.SingleAlign
+    plan = memory_plan(B, B.make_params(**kw), pe, B_, args.steps, args.warmup, nfl, int(ref.n_entries), args.transfer_steps != 0 and world == 1, bool(kw.get("D")), float(sum(lens)))
     t0 = time.time()
     batches = [Align(ref, n_total) for _ in range(nfl)]
     if args.exact:
@@ -191,7 +219,7 @@ def main():
     def run_steps(lo, hi):
         def worker(j):
             for i in range(lo + j, hi, nfl):
-                batches[j].run_range(i * B_, B_, sync=True)
+                batches[j].run_range((i % ring) * B_, B_, sync=True)
                 if i >= args.warmup:
                     kernel_ms.append(batches[j].kernel_ms())
                     scan_ms.append(batches[j].scan_ms())
@@ -203,6 +231,7 @@ def main():
             t.join()
 
     kernel_ms, scan_ms = [], []
+    serial_err = None
     run_steps(0, args.warmup)
     for bt in batches:
         bt.reset_counters()
@@ -215,21 +244,26 @@ def main():
     heavy_last = [int(batch.heavy_units()), int(batch.redo_units())]
     # per-kernel evidence comes from a serial replay (one batch, control and scan passes strictly alternating): with batches in
     # flight the launches of different batches overlap and their durations say nothing about one kernel
+    pools = [bt.pool_sizes() for bt in batches]
     serial = None
+    for bt in batches[1:]:   # the side legs below need the memory; batches[0] keeps the resident reads they sample
+        bt.close()
+    batches = batches[:1]
     if nfl > 1 and world == 1 and args.steps >= 2:
-        n_serial = B_ * (args.warmup + 2)   # (the replay only touches the steps it runs: the same reads, same unit ids)
-        sb = Align(ref, n_serial)   # (one unit group per batch, the default: control and scan passes alternate strictly)
-        sb.synth_reads(n_serial, read_len, seed=3, first_index=rank * n_total, kind=M["kind"])
-        sb.run_range(0, B_, sync=True)
-        sb.reset_counters()
-        s_ms, s_scan = [], []
-        t1 = time.perf_counter()
-        for i in range(args.warmup, args.warmup + 2):
-            sb.run_range(i * B_, B_, sync=True)
-            s_ms.append(sb.kernel_ms()); s_scan.append(sb.scan_ms())
-        serial = {"ms_per_step": (time.perf_counter() - t1) / 2 * 1e3, "event_ms_per_do_batch": float(np.mean(s_ms)), "scan_ms": s_scan,
-                  "counters": sb.counters().astype(np.float64)}
-        sb.close()
+        try:   # (a diagnostic leg must never cost the line)
+            sb = batch   # alone on the device now: one batch in flight, one unit group — control and scan passes alternate strictly
+            sb.run_range(0, B_, sync=True)
+            sb.reset_counters()
+            s_ms, s_scan = [], []
+            t1 = time.perf_counter()
+            for i in range(1, 3):
+                sb.run_range((i % ring) * B_, B_, sync=True)
+                s_ms.append(sb.kernel_ms()); s_scan.append(sb.scan_ms())
+            serial = {"ms_per_step": (time.perf_counter() - t1) / 2 * 1e3, "event_ms_per_do_batch": float(np.mean(s_ms)), "scan_ms": s_scan,
+                      "counters": sb.counters().astype(np.float64)}
+        except Exception as e:
+            serial = None
+            serial_err = str(e)[:300]
     reads_per_unit = 2 if pe else 1
     n_reads_rank = args.steps * B_ * reads_per_unit
     # stats reduction: the only collective of the path (RCCL all-gather of a few doubles per rank)
@@ -273,6 +307,7 @@ def main():
         "dtype": "u32", "data": "synthetic" if not real_fa else "synthetic reads sampled from " + os.path.basename(real_fa),
         "config": {"workload": M["workload"], "pairs_per_step" if pe else "reads_per_step": B_, "genome_bp": int(sum(lens)), "index_entries": int(ref.n_entries),
                    "parallelism": f"read-sharded x{world}", "batches_in_flight": nfl, "lib_sha16": sha, "exact_mode": bool(args.exact),
+                   "resident_ring_steps": ring, "heavy_pools": [{"units_per_round": u_, "scan_tasks": t_} for u_, t_ in pools], "device_memory_plan": plan,
                    "setup_s": {"genome": round(t_gen, 2), "index_build_gpu": round(t_index, 2), "device_batches": round(t_batches, 2)},
                    "aligned_fraction": float((2 * tot_counters[6] + tot_counters[5]) / max(1.0, n_reads_rank * world)) if pe
                    else float(tot_counters[5] / max(1.0, n_reads_rank * world))},
@@ -285,6 +320,8 @@ def main():
     }
     if world == 1 and not args.profile_serial:
         out["workload_shape"] = workload_shape(ref, counters, args.steps, B_, reads_per_unit, heavy_last[0])
+    if serial_err:
+        out["roofline"]["serial_replay"] = {"error": serial_err}
     if serial:
         out["roofline"]["serial_replay"] = {"ms_per_step": serial["ms_per_step"], "event_ms_per_do_batch": serial["event_ms_per_do_batch"],
                                             "note": "two steps with one batch in flight and one unit group after the timed region: the source of dominant_kernel"}
@@ -302,7 +339,7 @@ def main():
         args.transfer_steps = args.steps
     if world == 1 and args.transfer_steps > 0:
         try:
-            vt = incl_transfers(B, ref, batch, Align, pe, B_, min(args.transfer_steps, args.steps), 0 if kw.get("D") else nfl, reads_per_unit, args.warmup * B_, M["kind"] == 1)
+            vt = incl_transfers(B, ref, batch, Align, pe, B_, min(args.transfer_steps, args.steps), 0 if kw.get("D") else nfl, reads_per_unit, ring, M["kind"] == 1)
             # SURVEY 8(d)'s window is "first batch submitted -> last result returned"; `value` keeps reads and records in HBM (the contract's
             # definition): the same steps with the PCIe legs inside the window, and how far the two are apart
             vt["vs_resident"] = vt["value"] / value
@@ -310,7 +347,10 @@ def main():
         except Exception as e:
             out["value_incl_transfers"] = {"error": str(e)[:300]}
     if world == 1 and args.cpu_seconds > 0:
-        out["cpu_baseline"] = cpu_baseline(ref, batch, pe, kw, args.cpu_seconds, args.warmup * B_, M["kind"] == 1)
+        try:
+            out["cpu_baseline"] = cpu_baseline(ref, batch, pe, kw, args.cpu_seconds, min(args.warmup, ring - 1) * B_, M["kind"] == 1)
+        except Exception as e:
+            out["cpu_baseline"] = {"error": str(e)[:300]}
     for bt in batches:
         bt.close()
     ref.close()
@@ -506,23 +546,35 @@ def sensitivity(B, Align, kw, lens, read_len, B_, nfl, kind, headline):
 
 def other_configs(args):
     """BASELINE.json's other single-GPU configs, each in a child process of its own (this process has released its device memory): the same
-    timed region as the metric's (inputs in HBM, barrier + synchronize on both sides), fewer steps, none of the side legs."""
+    timed region as the metric's (inputs in HBM, barrier + synchronize on both sides), fewer steps, none of the side legs.  A child that fails
+    is reported with its return code and the end of its stderr, and tried once more with two batches in flight."""
     import subprocess
     res = {}
     for mode in ("se", "rrbs", "trim"):
-        cmd = [sys.executable, os.path.abspath(__file__), "--mode", mode, "--steps", "6", "--warmup", "3", "--genome", str(args.genome), "--pairs-per-step", str(args.pairs_per_step),
-               "--cpu-seconds", "0", "--transfer-steps", "0", "--e2e-pairs", "0", "--other-configs", "0"]
-        t0 = time.perf_counter()
-        try:
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
-            j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-            dk = j["roofline"].get("dominant_kernel") or {}
-            res[MODES[mode]["tag"]] = {"workload": j["config"]["workload"], "reads_per_s": j["value"], "ms_per_step": j["ms_per_step"], "steps": j["steps"],
-                                       "batches_in_flight": j["config"]["batches_in_flight"], "aligned_fraction": j["config"]["aligned_fraction"],
-                                       "candidates_per_read": j["roofline"]["per_read"]["n_cand"], "dominant_kernel": {k: dk.get(k) for k in ("name", "ms_per_step", "candidates_per_s")},
-                                       "wall_s": round(time.perf_counter() - t0, 1)}
-        except Exception as e:
-            res[MODES[mode]["tag"]] = {"error": str(e)[:300]}
+        base = [sys.executable, os.path.abspath(__file__), "--mode", mode, "--steps", "6", "--warmup", "3", "--genome", str(args.genome), "--pairs-per-step", str(args.pairs_per_step),
+                "--cpu-seconds", "0", "--transfer-steps", "0", "--e2e-pairs", "0", "--other-configs", "0"]
+        tag, failures = MODES[mode]["tag"], []
+        for extra in ([], ["--in-flight", "2"]):
+            t0 = time.perf_counter()
+            try:
+                r = subprocess.run(base + extra, capture_output=True, text=True, timeout=600)
+                lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+                if r.returncode != 0 or not lines:
+                    failures.append({"args": " ".join(extra), "rc": r.returncode, "stderr_tail": r.stderr[-300:]})
+                    continue
+                j = json.loads(lines[-1])
+                dk = j["roofline"].get("dominant_kernel") or {}
+                res[tag] = {"workload": j["config"]["workload"], "reads_per_s": j["value"], "ms_per_step": j["ms_per_step"], "steps": j["steps"],
+                            "batches_in_flight": j["config"]["batches_in_flight"], "aligned_fraction": j["config"]["aligned_fraction"], "heavy_pools": j["config"].get("heavy_pools"),
+                            "candidates_per_read": j["roofline"]["per_read"]["n_cand"], "dominant_kernel": {k: dk.get(k) for k in ("name", "ms_per_step", "candidates_per_s")},
+                            "roofline_frac": j["roofline"].get("frac"), "wall_s": round(time.perf_counter() - t0, 1)}
+                if failures:
+                    res[tag]["failed_attempts"] = failures
+                break
+            except Exception as e:
+                failures.append({"args": " ".join(extra), "error": str(e)[:300]})
+        if tag not in res:
+            res[tag] = {"error": "no result line", "attempts": failures}
     return res
 
 
@@ -534,101 +586,115 @@ def pinned_array(B, C, nbytes):
     return np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(p)), p
 
 
-def incl_transfers(B, ref, src, Align, pe, B_, steps, nfl, reads_per_unit, first_unit, quals):
+def incl_transfers(B, ref, src, Align, pe, B_, steps, nfl, reads_per_unit, ring, quals):
     """the second headline: the same Do_Batch with the PCIe legs inside the timed window — per step the reads of that step go up
     from page-locked host memory (bsx_batch_upload_*), the batch runs, and the records come back (bsx_batch_results_*);
-    `in_flight` host threads as in the command-line driver, so one batch's transfers overlap the other's kernels"""
+    `in_flight` host threads as in the command-line driver, so one batch's transfers overlap the other's kernels.  The host side holds
+    the `ring` distinct steps of the resident run (step i uploads slot i % ring); everything allocated here is released on any exit."""
     import ctypes as C
     import threading
     import numpy as np
-    B.lib().bsx_pinned_alloc.restype = C.c_void_p
-    B.lib().bsx_pinned_alloc.argtypes = [C.c_size_t]
-    B.lib().bsx_pinned_free.argtypes = [C.c_void_p]
-    nm = 2 if pe else 1
-    host, pins = [], []
-    for m in range(nm):
-        buf, off = src.download_reads(m)
-        lo, hi = int(off[first_unit]), int(off[first_unit + steps * B_])
-        a, p = pinned_array(B, C, hi - lo)
-        a[:] = buf[lo:hi]
-        pins.append(p)
-        q = None
-        if quals:
-            q, pq = pinned_array(B, C, hi - lo)
-            q[:] = src.download_quals(m)[lo:hi]
-            pins.append(pq)
-        host.append((a, (off[first_unit:first_unit + steps * B_ + 1] - off[first_unit]).astype(np.uint64), q))
-    nt = min(nfl + 2, 4) if nfl else 1  # (RRBS: one — a batch holds 74 GB there)  two more batches than the resident-input run keeps in flight (a batch that is moving data does not compute: 3 / 4 batches 0.93 / 0.96 of the resident rate); at most 4: each holds ~39 GB of pools
-    nt = int(os.environ.get("BSX_T_BATCHES", nt))            # (experiments: batches of this leg, and how many of them may be inside Do_Batch at once)
-    gate = threading.Semaphore(int(os.environ.get("BSX_T_GATE", nt)))
-    small = [Align(ref, B_) for _ in range(nt)]
     L = B.lib()
-    sinks = []    # page-locked result arrays per batch
-    for _ in range(nt):
-        arrs = []
-        for dt in ((B.PAIR_DTYPE, B.CC_DTYPE, B.CC_DTYPE) if pe else (B.HIT_DTYPE, B.CC_DTYPE)):
-            raw, p_ = pinned_array(B, C, B_ * dt.itemsize)
-            pins.append(p_)
-            arrs.append(raw.view(dt))
-        sinks.append(tuple(arrs))
+    L.bsx_pinned_alloc.restype = C.c_void_p
+    L.bsx_pinned_alloc.argtypes = [C.c_size_t]
+    L.bsx_pinned_free.argtypes = [C.c_void_p]
+    nm = 2 if pe else 1
+    slots = min(ring, steps)
+    host, pins, small = [], [], []
+    try:
+        for m in range(nm):
+            buf, off = src.download_reads(m)
+            hi = int(off[slots * B_])
+            a, p = pinned_array(B, C, hi)
+            pins.append(p)
+            a[:] = buf[:hi]
+            q = None
+            if quals:
+                q, pq = pinned_array(B, C, hi)
+                pins.append(pq)
+                q[:] = src.download_quals(m)[:hi]
+            host.append((a, off[:slots * B_ + 1].astype(np.uint64), q))
+            del buf
+        nt = min(nfl + 2, 4) if nfl else 1  # (RRBS: one — a batch holds 74 GB there)  two more batches than the resident-input run keeps in flight (a batch that is moving data does not compute: 3 / 4 batches 0.93 / 0.96 of the resident rate); at most 4: each holds ~39 GB of pools
+        nt = int(os.environ.get("BSX_T_BATCHES", nt))            # (experiments: batches of this leg, and how many of them may be inside Do_Batch at once)
+        gate = threading.Semaphore(int(os.environ.get("BSX_T_GATE", nt)))
+        for _ in range(nt):
+            small.append(Align(ref, B_))
+        sinks = []    # page-locked result arrays per batch
+        for _ in range(nt):
+            arrs = []
+            for dt in ((B.PAIR_DTYPE, B.CC_DTYPE, B.CC_DTYPE) if pe else (B.HIT_DTYPE, B.CC_DTYPE)):
+                raw, p_ = pinned_array(B, C, B_ * dt.itemsize)
+                pins.append(p_)
+                arrs.append(raw.view(dt))
+            sinks.append(tuple(arrs))
 
-    # per step the arrays a caller hands over: bytes of the step's reads and their offsets from 0 (prepared before the window opens — packing the
-    # reads of a batch is the caller's parser, which `end_to_end` measures; the window is upload -> Do_Batch -> results)
-    step_off = []
-    for a, off, q in host:
-        per = []
-        for i in range(steps):
-            raw, p_ = pinned_array(B, C, (B_ + 1) * 8)   # (page-locked like the read bytes: a pageable source is staged through a bounce buffer)
-            pins.append(p_)
-            o = raw.view(np.uint64)
-            o[:] = off[i * B_:(i + 1) * B_ + 1] - off[i * B_]
-            per.append(o)
-        step_off.append(per)
+        # per slot the arrays a caller hands over: bytes of the step's reads and their offsets from 0 (prepared before the window opens — packing the
+        # reads of a batch is the caller's parser, which `end_to_end` measures; the window is upload -> Do_Batch -> results)
+        step_off = []
+        for a, off, q in host:
+            per = []
+            for i in range(slots):
+                raw, p_ = pinned_array(B, C, (B_ + 1) * 8)   # (page-locked like the read bytes: a pageable source is staged through a bounce buffer)
+                pins.append(p_)
+                o = raw.view(np.uint64)
+                o[:] = off[i * B_:(i + 1) * B_ + 1] - off[i * B_]
+                per.append(o)
+            step_off.append(per)
 
-    def step(j, i):
-        b = small[j]
-        sl = []
-        for m_, (a, off, q) in enumerate(host):
-            o = step_off[m_][i]
-            s0, s1 = int(off[i * B_]), int(off[(i + 1) * B_])
-            sl.append((a[s0:s1], o, q[s0:s1] if q is not None else None))
-        if pe:
-            b.ImportBatchReads((sl[0][0], sl[0][1]), (sl[1][0], sl[1][1]), sl[0][2], sl[1][2], first_index=first_unit + i * B_)
-        else:
-            b.ImportBatchReads((sl[0][0], sl[0][1]), sl[0][2], first_index=first_unit + i * B_)
-        with gate:
-            b.Do_Batch()
-        b.results(into=sinks[j])
+        def step(j, i):
+            b = small[j]
+            k = i % slots
+            sl = []
+            for m_, (a, off, q) in enumerate(host):
+                o = step_off[m_][k]
+                s0, s1 = int(off[k * B_]), int(off[(k + 1) * B_])
+                sl.append((a[s0:s1], o, q[s0:s1] if q is not None else None))
+            if pe:
+                b.ImportBatchReads((sl[0][0], sl[0][1]), (sl[1][0], sl[1][1]), sl[0][2], sl[1][2], first_index=k * B_)
+            else:
+                b.ImportBatchReads((sl[0][0], sl[0][1]), sl[0][2], first_index=k * B_)
+            with gate:
+                b.Do_Batch()
+            b.results(into=sinks[j])
 
-    nxt, lock = [0], threading.Lock()
+        nxt, lock, errs = [0], threading.Lock(), []
 
-    def worker(j, lo, hi):  # a batch takes the next step that nobody has started (a fixed stride would leave batches idle when nt does not divide the steps)
-        while True:
-            with lock:
-                i = nxt[0]; nxt[0] += 1
-            if i >= hi:
-                return
-            step(j, i)
-    for j in range(nt):  # untimed warm-up of each small batch
-        step(j, 0)
-    t0 = time.perf_counter()
-    th = [threading.Thread(target=worker, args=(j, 0, steps)) for j in range(1, nt)]
-    for t in th:
-        t.start()
-    worker(0, 0, steps)
-    for t in th:
-        t.join()
-    dt = time.perf_counter() - t0
-    for b in small:
-        b.close()
-    for p in pins:
-        if p:
-            L.bsx_pinned_free(p)
-    up = sum(int(h[1][-1]) * (2 if h[2] is not None else 1) + 8 * (steps * B_ + 1) for h in host)
-    down = steps * B_ * ((64 + 128) if pe else (16 + 64))
-    return {"value": steps * B_ * reads_per_unit / dt, "unit": "reads/s", "steps": steps, "ms_per_step": dt / steps * 1e3,
-            "host_to_device_bytes_per_step": up / steps, "device_to_host_bytes_per_step": down / steps,
-            "window": "per step: bsx_batch_upload (page-locked read bytes, per-step offset arrays prepared beforehand) -> Do_Batch -> bsx_batch_results (page-locked), %d batches in flight" % nt}
+        def worker(j, lo, hi):  # a batch takes the next step that nobody has started (a fixed stride would leave batches idle when nt does not divide the steps)
+            try:
+                while not errs:
+                    with lock:
+                        i = nxt[0]; nxt[0] += 1
+                    if i >= hi:
+                        return
+                    step(j, i)
+            except Exception as e:
+                errs.append(e)
+        for j in range(nt):  # untimed warm-up of each small batch
+            step(j, 0)
+        t0 = time.perf_counter()
+        th = [threading.Thread(target=worker, args=(j, 0, steps)) for j in range(1, nt)]
+        for t in th:
+            t.start()
+        worker(0, 0, steps)
+        for t in th:
+            t.join()
+        dt = time.perf_counter() - t0
+        if errs:
+            raise errs[0]
+        pool = [b.pool_sizes() for b in small]
+        up = sum((int(h[1][-1]) * (2 if h[2] is not None else 1) + 8 * (slots * B_ + 1)) / slots for h in host)
+        down = B_ * ((64 + 128) if pe else (16 + 64))
+        return {"value": steps * B_ * reads_per_unit / dt, "unit": "reads/s", "steps": steps, "ms_per_step": dt / steps * 1e3,
+                "host_to_device_bytes_per_step": up, "device_to_host_bytes_per_step": down, "heavy_pools": [{"units_per_round": u_, "scan_tasks": t_} for u_, t_ in pool],
+                "window": "per step: bsx_batch_upload (page-locked read bytes, per-step offset arrays prepared beforehand) -> Do_Batch -> bsx_batch_results (page-locked), %d batches in flight" % nt}
+    finally:
+        for b in small:
+            b.close()
+        host.clear()
+        for p in pins:
+            if p:
+                L.bsx_pinned_free(p)
 
 
 def end_to_end(pairs, genome):

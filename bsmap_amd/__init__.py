@@ -66,7 +66,7 @@ EXPORTS = [
     "bsx_batch_create", "bsx_batch_destroy", "bsx_batch_upload_se", "bsx_batch_upload_pe", "bsx_batch_synth_reads", "bsx_batch_synth_reads_kind", "bsx_batch_download_quals",
     "bsx_batch_run", "bsx_batch_run_range", "bsx_batch_sync", "bsx_batch_set_leak_exact", "bsx_batch_set_history", "bsx_batch_set_leak_state", "bsx_batch_get_leak_state", "bsx_batch_kernel_ms", "bsx_batch_scan_ms", "bsx_batch_results_se", "bsx_batch_results_pe",
     "bsx_batch_counters", "bsx_batch_reset_counters", "bsx_batch_download_reads", "bsx_batch_set_debug", "bsx_batch_unit_cycles", "bsx_batch_ctrl_clocks",
-    "bsx_batch_debug_hits", "bsx_batch_debug_pairs", "bsx_batch_debug_plan", "bsx_set_waves_per_cu", "bsx_set_heavy_threshold", "bsx_set_heavy_limits", "bsx_batch_last_heavy_units", "bsx_batch_last_redo_units", "bsx_pinned_alloc", "bsx_pinned_free", "bsx_probe_memory", "bsx_thread_device",
+    "bsx_batch_debug_hits", "bsx_batch_debug_pairs", "bsx_batch_debug_plan", "bsx_set_waves_per_cu", "bsx_set_heavy_threshold", "bsx_set_heavy_limits", "bsx_set_pool_reserve", "bsx_batch_pool_sizes", "bsx_batch_plan_bytes", "bsx_batch_last_heavy_units", "bsx_batch_last_redo_units", "bsx_pinned_alloc", "bsx_pinned_free", "bsx_probe_memory", "bsx_thread_device",
     "bsx_meth_create", "bsx_meth_destroy", "bsx_meth_set_reference", "bsx_meth_add", "bsx_meth_combine_cpg", "bsx_meth_valid_mappings",
     "bsx_meth_report_chr", "bsx_meth_fetch_rows", "bsx_meth_add_file", "bsx_meth_write_table", "bsx_meth_create_from_fasta", "bsx_meth_n_chr", "bsx_meth_chr_name",
 ]
@@ -138,6 +138,9 @@ def lib():
         L.bsx_set_waves_per_cu.argtypes = [i32]
         L.bsx_set_heavy_threshold.argtypes = [i32]
         L.bsx_set_heavy_limits.argtypes = [u32, u32]
+        L.bsx_set_pool_reserve.argtypes = [u64]
+        L.bsx_batch_pool_sizes.argtypes = [vp, vp, vp]
+        L.bsx_batch_plan_bytes.argtypes = [C.POINTER(Params), u32, i32, u64, u32, u32, vp]
         L.bsx_batch_last_heavy_units.argtypes = [vp]
         L.bsx_batch_last_redo_units.argtypes = [vp]
         L.bsx_probe_memory.argtypes = [i32, u64, u64, vp, vp, vp, vp]
@@ -157,6 +160,13 @@ def probe_memory(device=0, nbytes=4 << 30, gather_window=1 << 30):
     v = [C.c_double() for _ in range(4)]
     _check(lib().bsx_probe_memory(device, nbytes, gather_window, *[C.addressof(x) for x in v]))
     return dict(zip(("stream_read", "stream_copy", "gather16", "gather16_Gloads_per_s"), (x.value for x in v)))
+
+
+def plan_bytes(params, max_units, paired, n_entries, n_cu=256, blocks_per_cu=5):
+    """{per_unit, scratch, pools}: device bytes a batch of max_units will allocate (host arithmetic, no device needed)"""
+    o = (C.c_uint64 * 3)()
+    _check(lib().bsx_batch_plan_bytes(C.byref(params), max_units, 1 if paired else 0, n_entries, n_cu, blocks_per_cu, o))
+    return {"per_unit": int(o[0]), "scratch": int(o[1]), "pools": int(o[2])}
 
 
 def make_params(**kw):
@@ -349,6 +359,12 @@ class _Batch:
     def reset_counters(self): _check(lib().bsx_batch_reset_counters(self.h))
 
     def heavy_units(self): return _check(lib().bsx_batch_last_heavy_units(self.h))
+
+    def pool_sizes(self):
+        """(deferred units per round, scan tasks) of the heavy pipeline's pools as allocated (starting sizes halved until they fit)"""
+        u, t = C.c_uint32(), C.c_uint32()
+        _check(lib().bsx_batch_pool_sizes(self.h, C.byref(u), C.byref(t)))
+        return u.value, t.value
     def redo_units(self): return _check(lib().bsx_batch_last_redo_units(self.h))
 
     def set_debug(self, mode): _check(lib().bsx_batch_set_debug(self.h, mode))

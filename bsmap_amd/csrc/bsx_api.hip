@@ -28,6 +28,7 @@ static bool g_user_limits = false;
 static uint32_t g_hcap = 24576, g_task_cap = 1048576;  // a 2^20-pair batch defers ~9.4 K units (C3) to ~17.3 K (C5, trimmed reads)
 extern "C" int bsx_set_heavy_limits(uint32_t units_per_round, uint32_t task_pool)
 {
+    if (units_per_round == 0 && task_pool == 0) { g_hcap = 24576; g_task_cap = 1048576; g_user_limits = false; return BSX_OK; }  // back to the defaults
     if (units_per_round < 1 || task_pool < 2 || task_pool > (1u << 22)) return BSX_ERR_ARG;  // (a task record is 8 KB: 2^22 tasks = 34 GB)
     g_hcap = units_per_round; g_task_cap = task_pool; g_user_limits = true;
     return BSX_OK;
@@ -328,6 +329,72 @@ static hipError_t stream_wait(bsx_batch *b)
     return wait_event(b->ev_wait);
 }
 
+// What a device batch will allocate, computed on the host from its parameters alone (bsx_batch_plan_bytes: bench.py and the CPU suite
+// check a run's whole plan against the device's memory before anything is allocated; ensure_scratch allocates exactly this).
+struct BatchPlan {
+    uint64_t per_unit_bytes = 0;   // reads, offsets, result records, deferred / redo lists: follows max_units
+    uint64_t scratch_bytes = 0;    // the main kernel's per-wave slabs: follows the grid, cannot shrink
+    uint64_t pool_bytes = 0;       // work pools of the heavy pipeline at their starting size (halved until they fit)
+    uint32_t hcap = 0, task_cap = 0, n_bins = 1, bin_shift = 0;
+    int grid_blocks = 0;
+};
+static uint64_t pool_bytes_for(const bsx_params &P, int paired, uint32_t hcap, uint32_t task_cap, uint32_t n_bins, int n_groups, uint64_t hslab_bytes)
+{
+    (void)P; (void)paired;
+    const uint64_t tcap = task_cap / (uint32_t)n_groups;
+    return (uint64_t)hcap * (bsx_hstate_bytes() + hslab_bytes + 8) + (uint64_t)task_cap * (bsx_htask_bytes() + bsx_htaskout_bytes()) +
+           (uint64_t)n_groups * ((uint64_t)n_bins * 8 + (uint64_t)bsx_bin_chunks(n_bins) * 4 + tcap * 12 + 16);
+}
+static BatchPlan plan_batch(const bsx_params &P, int paired, uint32_t max_units, uint64_t n_entries, int n_cu, int blocks_per_cu, int n_groups, bool debug)
+{
+    BatchPlan pl;
+    const uint32_t rowcap = BSX_ROWCAP;
+    const uint64_t slab = slab_size(P, paired, rowcap), hslab = slab_size(P, paired, rowcap, true);
+    int grid = n_cu * std::min(8, std::max(1, blocks_per_cu));
+    const int need = (int)((max_units + 3) / 4);
+    if (grid > need) grid = need > 0 ? need : 1;
+    pl.grid_blocks = grid;
+    pl.scratch_bytes = (debug ? (uint64_t)max_units : (uint64_t)grid * 4) * slab;
+    const int nm = paired ? 2 : 1;
+    pl.per_unit_bytes = (uint64_t)nm * (2 * ((uint64_t)max_units * 160 + 256) + ((uint64_t)max_units + 1) * 8 + (uint64_t)max_units * sizeof(bsx_class_counts)) +
+                        (paired ? (uint64_t)max_units * (sizeof(bsx_pair) + 64) : (uint64_t)max_units * sizeof(bsx_hit)) + 2 * ((uint64_t)max_units + 1) * 4;
+    // deferred units handled per round (more than this: several rounds): what 26 GB of slabs hold — 24 576 units of the 1.07 MB paired
+    // -v 6 slab, 111 K of the 234 KB single-end -v 2 one.  RRBS defers a third of its reads (Alu-like fragments) and its scan kernel
+    // shares work between the reads that walk one window in the same pass: the more units a round holds, the longer those runs — 40 GB
+    // of slabs (170 K units) and 2 M tasks: C4 195 -> 159 ms per step.  Task records (8 KB each): 1 M for WGBS (C5 358 -> 328 ms against
+    // 512 K: fewer requests refused), following the batch size for small batches.  bsx_set_heavy_limits replaces the STARTING sizes;
+    // either way the pools are halved until they fit (ensure_scratch).
+    const uint64_t slab_budget = P.rrbs ? (40ull << 30) : (26ull << 30);
+    pl.hcap = g_user_limits ? g_hcap : (uint32_t)std::min<uint64_t>(262144, std::max<uint64_t>(g_hcap, slab_budget / hslab));
+    pl.hcap = std::min<uint32_t>(max_units, pl.hcap);
+    const uint32_t task_default = P.rrbs ? 2u * g_task_cap : g_task_cap;
+    pl.task_cap = g_user_limits ? g_task_cap : std::min<uint32_t>(task_default, std::max<uint32_t>(4096u, 64u * pl.hcap));
+    // scan order of a pass: bins of 2^shift index entries, at most 2^20 of them (bsx_launch_task_order)
+    // (WGBS: 2^21 — the tasks of one window are dealt over the bins it covers by read offset, for k_hscan_same: 8 bins of 1 024 entries per window at hg38 size)
+    const uint64_t ne = std::max<uint64_t>(1, n_entries);
+    const uint32_t bin_log2 = getenv("BSX_BIN_LOG2") ? (uint32_t)std::max(8, std::min(21, atoi(getenv("BSX_BIN_LOG2")))) : (P.rrbs ? 20u : 21u);  // tuning knob
+    while (((ne >> pl.bin_shift) + 1) > (1u << bin_log2)) pl.bin_shift++;
+    pl.n_bins = (uint32_t)(ne >> pl.bin_shift) + 1;
+    pl.pool_bytes = pool_bytes_for(P, paired, pl.hcap, pl.task_cap, pl.n_bins, n_groups, hslab);
+    return pl;
+}
+
+// Device memory a batch keeps free behind its own allocations.  Pools that took everything but a flat 4 GB left no room for the NEXT batch's
+// fixed part (its per-wave slabs alone are 5.5 GB for paired -v 6, 17 GB for single-end RRBS): the driver's bench command died there in round 4.
+// A batch therefore leaves room for one more batch like itself (slabs + per-unit arrays) plus 4 GB; bsx_set_pool_reserve overrides.
+static uint64_t g_pool_reserve = 0;  // 0 = by batch
+extern "C" int bsx_set_pool_reserve(uint64_t bytes) { g_pool_reserve = bytes; return BSX_OK; }
+
+extern "C" int bsx_batch_plan_bytes(const bsx_params *p, uint32_t max_units, int paired, uint64_t n_entries, uint32_t n_cu, uint32_t blocks_per_cu, uint64_t *out3)
+{
+    if (!p || !out3 || max_units == 0 || n_cu == 0) return BSX_ERR_ARG;
+    int ng = 1;
+    if (const char *e = getenv("BSX_HEAVY_GROUPS")) ng = std::max(1, std::min(BSX_MAX_GROUPS, atoi(e)));
+    const BatchPlan pl = plan_batch(*p, paired ? 1 : 0, max_units, n_entries, (int)n_cu, (int)blocks_per_cu, ng, false);
+    out3[0] = pl.per_unit_bytes; out3[1] = pl.scratch_bytes; out3[2] = pl.pool_bytes;
+    return BSX_OK;
+}
+
 static int ensure_scratch(bsx_batch *b)
 {
     hipDeviceProp_t prop;
@@ -358,28 +425,14 @@ static int ensure_scratch(bsx_batch *b)
         b->scratch_bytes = bytes;
     }
     if (!b->d_heavy_list) {
-        // deferred units handled per round (more than this: several rounds): what 26 GB of slabs hold — 24 576 units of the 1.07 MB paired
-        // -v 6 slab, 111 K of the 234 KB single-end -v 2 one.  RRBS defers a third of its reads (Alu-like fragments) and its scan kernel
-        // shares work between the reads that walk one window in the same pass: the more units a round holds, the longer those runs — 40 GB
-        // of slabs (170 K units) and 2 M tasks: C4 195 -> 159 ms per step.  Task records (8 KB each): 1 M for WGBS (C5 358 -> 328 ms against
-        // 512 K: fewer requests refused), following the batch size for small batches.
-        const uint64_t slab_budget = b->ref->P.rrbs ? (40ull << 30) : (26ull << 30);
-        b->hcap = g_user_limits ? g_hcap : (uint32_t)std::min<uint64_t>(262144, std::max<uint64_t>(g_hcap, slab_budget / b->hslab_bytes));
-        b->hcap = std::min<uint32_t>(b->max_units, b->hcap);
-        const uint32_t task_default = b->ref->P.rrbs ? 2u * g_task_cap : g_task_cap;
-        b->task_cap = g_user_limits ? g_task_cap : std::min<uint32_t>(task_default, std::max<uint32_t>(4096u, 64u * b->hcap));
+        const BatchPlan pl = plan_batch(b->ref->P, b->paired, b->max_units, b->ref->n_entries, prop.multiProcessorCount, blocks_per_cu, b->n_groups, b->debug != 0);
+        b->hcap = pl.hcap; b->task_cap = pl.task_cap;
         HIP_TRY(hipMalloc((void **)&b->d_heavy_list, ((size_t)b->max_units + 1) * 4));
         HIP_TRY(hipMalloc((void **)&b->d_heavy_count, 256));
         HIP_TRY(hipHostMalloc((void **)&b->h_pinned, 1024, hipHostMallocDefault));
         HIP_TRY(hipMalloc((void **)&b->d_redo, ((size_t)b->max_units + 1) * 4));
         HIP_TRY(hipMalloc((void **)&b->d_hcnt, BSX_MAX_GROUPS * 64));
-        // scan order of a pass: bins of 2^shift index entries, at most 2^20 of them (bsx_launch_task_order)
-        const uint64_t ne = std::max<uint64_t>(1, b->ref->n_entries);
-        b->bin_shift = 0;
-        // (WGBS: 2^21 — the tasks of one window are dealt over the bins it covers by read offset, for k_hscan_same: 8 bins of 1 024 entries per window at hg38 size)
-        const uint32_t bin_log2 = getenv("BSX_BIN_LOG2") ? (uint32_t)std::max(8, std::min(21, atoi(getenv("BSX_BIN_LOG2")))) : (b->ref->P.rrbs ? 20u : 21u);  // tuning knob
-        while (((ne >> b->bin_shift) + 1) > (1u << bin_log2)) b->bin_shift++;
-        b->n_bins = (uint32_t)(ne >> b->bin_shift) + 1;
+        b->bin_shift = pl.bin_shift; b->n_bins = pl.n_bins;
         // The pools proper.  Their default sizes are for a device that holds two or three batches (31 GB each for WGBS, 74 GB for RRBS);
         // where that much is not free — more batches per device, a smaller or shared device — the pools are halved until they fit
         // (more rounds and refused requests then, same results) instead of failing the batch.
@@ -413,19 +466,25 @@ static int ensure_scratch(bsx_batch *b)
 #undef POOL_TRY
             return hipSuccess;
         };
+        // Starting sizes (the defaults above, or bsx_set_heavy_limits) are halved until the pools fit with `reserve` bytes to spare: first by
+        // arithmetic against hipMemGetInfo, then — another process or thread may be allocating at the same moment — on a failed hipMalloc.
+        const uint64_t reserve = g_pool_reserve ? g_pool_reserve : ((4ull << 30) + pl.scratch_bytes + pl.per_unit_bytes);
         for (int attempt = 0;; attempt++) {
-            hipError_t e = alloc_pools();
-            if (e == hipSuccess) {  // ... and leave room for what comes later (the reads of a batch, result arrays, other batches' buffers)
-                size_t fr = 0, tot = 0;
-                if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr >= ((size_t)4 << 30) || b->hcap <= 1024) break;
-                e = hipErrorOutOfMemory;
+            size_t fr = 0, tot = 0;
+            const bool smallest = b->hcap <= 1024 && b->task_cap <= 4096;
+            hipError_t e = hipErrorOutOfMemory;
+            if (smallest || hipMemGetInfo(&fr, &tot) != hipSuccess ||
+                pool_bytes_for(b->ref->P, b->paired, b->hcap, b->task_cap, b->n_bins, b->n_groups, b->hslab_bytes) + reserve <= fr) {
+                e = alloc_pools();
+                if (e == hipSuccess) break;
+                free_pools();
             }
-            free_pools();
-            if (e != hipErrorOutOfMemory || g_user_limits || attempt == 6 || b->hcap <= 1024) return bsx_hip_fail(e, "hipMalloc (work pools of the heavy pipeline)", __FILE__, __LINE__);
+            if (e != hipErrorOutOfMemory || attempt == 12 || smallest) return bsx_hip_fail(e, "hipMalloc (work pools of the heavy pipeline)", __FILE__, __LINE__);
             (void)hipGetLastError();
-            b->hcap = std::max<uint32_t>(1024u, b->hcap / 2);
+            b->hcap = std::max<uint32_t>(std::min<uint32_t>(1024u, b->max_units), b->hcap / 2);
             b->task_cap = std::max<uint32_t>(4096u, b->task_cap / 2);
         }
+        if (b->trace) fprintf(stderr, "[bsx] batch %p: pools for %u deferred units per round, %u scan tasks (planned %u / %u)\n", (void *)b, b->hcap, b->task_cap, pl.hcap, pl.task_cap);
         if (getenv("BSX_POISON")) HIP_TRY(hipMemsetAsync(b->d_hstate, 0xA5, (size_t)b->hcap * bsx_hstate_bytes(), b->stream));  // test hook: recycled memory is not zero
         HIP_TRY(hipMemsetAsync(b->d_hslabs, 0, (size_t)b->hcap * b->hslab_bytes, b->stream));
         if (getenv("BSX_POISON")) {
@@ -612,6 +671,14 @@ extern "C" int bsx_batch_set_history(bsx_batch *b, uint32_t n, const char *seqs_
         if (ql[m]) { HIP_TRY(hipMalloc((void **)&b->d_hist_qual[m], bytes + 256)); HIP_TRY(hipMemcpy(b->d_hist_qual[m], ql[m], bytes, hipMemcpyHostToDevice)); }
     }
     b->n_hist = n; b->leak_meta_valid = false;
+    return BSX_OK;
+}
+
+extern "C" int bsx_batch_pool_sizes(const bsx_batch *b, uint32_t *units_per_round, uint32_t *task_pool)
+{
+    if (!b) return BSX_ERR_ARG;
+    if (units_per_round) *units_per_round = b->hcap;
+    if (task_pool) *task_pool = b->task_cap;
     return BSX_OK;
 }
 

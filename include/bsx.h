@@ -226,8 +226,17 @@ int bsx_set_waves_per_cu(int waves);
  * a value no list reaches = never.  Results do not depend on it. */
 int bsx_set_heavy_threshold(int n_candidates);
 /* pool sizes of the heavy pipeline for batches created afterwards (defaults 24576 units per round and up to 524288 scan tasks, both scaled down for small batches; at most 2^22);
- * small values only make it take more rounds / passes — used by the tests to exercise those paths */
+ * small values only make it take more rounds / passes — used by the tests to exercise those paths; (0, 0) restores the defaults */
 int bsx_set_heavy_limits(uint32_t units_per_round, uint32_t task_pool);
+/* Either way those are STARTING sizes: a batch halves its pools until they fit the device's free memory with a reserve to spare —
+ * by default room for one more batch like itself (per-wave slabs + per-unit arrays) plus 4 GB; bsx_set_pool_reserve(bytes) sets the
+ * reserve for batches created afterwards (0 = that default).  bsx_batch_pool_sizes returns what a batch ended up with. */
+int bsx_set_pool_reserve(uint64_t bytes);
+int bsx_batch_pool_sizes(const bsx_batch *b, uint32_t *units_per_round, uint32_t *task_pool);
+/* Device bytes a batch of `max_units` will allocate, computed on the host (no device needed): out3 = {per-unit arrays (reads, offsets,
+ * records), the main kernel's per-wave slabs for a grid of n_cu x blocks_per_cu blocks, work pools at their starting size}.
+ * bench.py checks its whole plan against the device's memory with it before it allocates anything. */
+int bsx_batch_plan_bytes(const bsx_params *p, uint32_t max_units, int paired, uint64_t n_entries, uint32_t n_cu, uint32_t blocks_per_cu, uint64_t *out3);
 int bsx_batch_last_heavy_units(bsx_batch *b);   /* units the last run handed to the heavy pipeline */
 int bsx_batch_last_redo_units(bsx_batch *b);    /* of those, units the main kernel had to redo (their duplicate set outgrew the heavy slab; single-end RRBS) */
 
