@@ -44,13 +44,19 @@ def test_other_configs_runs_every_other_mode_in_a_child(monkeypatch):
         calls.append(cmd)
         mode = cmd[cmd.index("--mode") + 1]
         if mode == "rrbs":
-            return types.SimpleNamespace(stdout="no json here\n", stderr="", returncode=1)
+            return types.SimpleNamespace(stdout="no json here\n", stderr="x" * 500 + "hipMalloc -> out of memory", returncode=1)
+        if mode == "trim" and "--in-flight" not in cmd:
+            return types.SimpleNamespace(stdout="", stderr="first attempt died", returncode=-9)
         line = {"value": 1e6, "ms_per_step": 100.0, "steps": 6, "config": {"workload": "w", "batches_in_flight": 2, "aligned_fraction": 1.0},
                 "roofline": {"per_read": {"n_cand": 5.0}, "dominant_kernel": {"name": "k", "ms_per_step": 1.0, "candidates_per_s": 2.0}}}
         return types.SimpleNamespace(stdout="noise\n" + json.dumps(line) + "\n", stderr="", returncode=0)
     monkeypatch.setattr(subprocess, "run", fake_run)
     res = BN.other_configs(types.SimpleNamespace(genome="hg38", pairs_per_step=1 << 20))
-    assert [c[c.index("--mode") + 1] for c in calls] == ["se", "rrbs", "trim"]
+    # one child per mode; a failing child is tried once more with two batches in flight
+    assert [c[c.index("--mode") + 1] for c in calls] == ["se", "rrbs", "rrbs", "trim", "trim"]
     for c in calls:
         assert c[c.index("--other-configs") + 1] == "0" and c[c.index("--cpu-seconds") + 1] == "0" and int(c[c.index("--steps") + 1]) % 6 == 0
     assert res["C2"]["reads_per_s"] == 1e6 and res["C5"]["dominant_kernel"]["name"] == "k" and "error" in res["C4"]
+    # the record says WHY: return code and the end of the child's stderr (round 4's line said "list index out of range")
+    assert [a["rc"] for a in res["C4"]["attempts"]] == [1, 1] and res["C4"]["attempts"][0]["stderr_tail"].endswith("out of memory")
+    assert res["C5"]["failed_attempts"][0]["rc"] == -9
