@@ -44,16 +44,45 @@ MODES = {
 }
 
 
-RING_STEPS = 8          # distinct steps of resident reads (see main)
-RRBS_POOLS = "110000,1400000"   # starting pools of an RRBS batch when three are in flight (two thirds of the library's default: 26 GB of slabs, 1.4 M tasks)
+RING_UNITS = 1 << 23    # resident reads of a device batch: a ring of distinct steps, 2^23 units in all (8 steps of 2^20), at least 4 steps (see main)
+
+
+def ring_steps(steps, warmup, B_):
+    return max(1, min(steps + warmup, max(4, RING_UNITS // B_)))
+
+
 HBM_BYTES = 288e9       # MI355X
 
 
-def memory_plan(B, params, pe, B_, steps, warmup, nfl, n_entries, transfers, rrbs, genome_bp=3.1e9, n_cu=256, blocks_per_cu=5):
+RRBS_POOLS = "110000,1400000"   # starting pools of an RRBS batch when three are in flight (two thirds of the library's default: 26 GB of slabs, 1.4 M tasks)
+# units per step, batches in flight and starting pools by mode (measured: profiles/r05d_*).  A larger device batch gives the scan kernel larger
+# groups (more reads over one window and offset per pass): C3 24.3 M reads/s at 2^20 pairs per step with three in flight, 27.0 M at 2^22 with two.
+# (profiles/r05e: C2 16.8 M at 2^20 x 3, 18.9 M at 2^22 x 2; C5 9.2 M at 2^20 x 3, 10.5 M at 2^22 x 3; C4 8.6 M at 2^20 x 3, 9.4 M at 2^22 x 3)
+MODE_DEFAULTS = {"pe": (1 << 22, 2, None), "se": (1 << 22, 2, None), "trim": (1 << 22, 3, None), "rrbs": (1 << 22, 3, RRBS_POOLS)}
+
+
+def mode_defaults(mode):
+    """(units per step, batches in flight, starting pools (units per round, tasks) or None = the library's for that step size)"""
+    b, f, lim = MODE_DEFAULTS[mode]
+    return b, f, (tuple(int(x) for x in lim.split(",")) if lim else None)
+
+
+def transfer_batches(nfl, rrbs, ref_bytes, batch_bytes):
+    """device batches of the PCIe-inclusive leg: two more than the resident run keeps in flight (a batch that is moving data does not compute:
+    3 / 4 batches 0.93 / 0.96 of the resident rate at 2^20 pairs per step), at most 4, and no more than fit 0.85 of the device; RRBS one (74 GB each)"""
+    if rrbs:
+        return 1
+    return int(max(1, min(nfl + 2, 4, (0.85 * HBM_BYTES - ref_bytes) // batch_bytes)))
+
+
+def memory_plan(B, params, pe, B_, steps, warmup, nfl, n_entries, transfers, rrbs, genome_bp=3.1e9, n_cu=256, blocks_per_cu=5, limits=None):
     """device bytes of each phase of a run, from host arithmetic alone (bsx_batch_plan_bytes; tests/test_bench_memory_cpu.py holds every
     mode's plan for the driver's `--steps 20 --warmup 5` under 0.9 of the device).  Pools count at their starting size: a batch halves them
     when less is free, so the plan is an upper bound."""
-    ring = min(steps + warmup, RING_STEPS)
+    ring = ring_steps(steps, warmup, B_)
+    if limits is None:   # (what main() sets: pools for a step, not for the ring a batch holds; left set — bsx_set_heavy_limits(0, 0) restores the defaults)
+        limits = B.default_heavy_limits(params, B_, pe)
+    B.lib().bsx_set_heavy_limits(*limits)
     big = B.plan_bytes(params, B_ * ring, pe, n_entries, n_cu, blocks_per_cu)
     small = B.plan_bytes(params, B_, pe, n_entries, n_cu, blocks_per_cu)
     tot = lambda d: d["per_unit"] + d["scratch"] + d["pools"]
@@ -61,10 +90,12 @@ def memory_plan(B, params, pe, B_, steps, warmup, nfl, n_entries, transfers, rrb
     K = int(params.total_kmers)
     ref_b = genome_bp / 16 * 4 * 2 * 2 + 8.0 * K + n_entries * (8 if rrbs else 4) + (K * 32 * 4 if rrbs else 0)
     build_b = 0 if rrbs else n_entries * 8 * 2 + n_entries * 4   # index build: key/value double buffers of the radix sort (transient)
-    nt = (1 if rrbs else min(nfl + 2, 4)) if transfers else 0
-    phases = {"index_build": ref_b + build_b, "timed": ref_b + nfl * tot(big), "side_legs": ref_b + tot(big) + nt * tot(small)}
+    nt = transfer_batches(nfl, rrbs, ref_b, tot(small)) if transfers else 0
+    # (the serial / counted replays and the CPU baseline's downloads use the one timed batch that is kept; it is closed before the PCIe-inclusive leg creates its own)
+    phases = {"index_build": ref_b + build_b, "timed": ref_b + nfl * tot(big), "side_legs": ref_b + max(tot(big), nt * tot(small))}
     return {"phases_GB": {k: round(v / 1e9, 1) for k, v in phases.items()}, "peak_GB": round(max(phases.values()) / 1e9, 1),
-            "peak_frac_of_device": round(max(phases.values()) / HBM_BYTES, 3), "per_batch_GB": {k: round(v / 1e9, 2) for k, v in big.items()}}
+            "peak_frac_of_device": round(max(phases.values()) / HBM_BYTES, 3), "per_batch_GB": {k: round(v / 1e9, 2) for k, v in big.items()},
+            "transfer_leg_batches": nt, "transfer_leg_batch_GB": round(tot(small) / 1e9, 1), "reference_GB": round(ref_b / 1e9, 1)}
 
 
 def algorithmic_bytes(c, n_reads):
@@ -116,12 +147,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=12)   # a multiple of 2, 3 and 4: every batch in flight runs the same number of steps
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs-per-step", type=int, default=1 << 20, help="units (pairs, or single reads) per step")
+    ap.add_argument("--pairs-per-step", type=int, default=0, help="units (pairs, or single reads) per step; 0 = the mode's default (MODE_DEFAULTS: 2^22 for C3)")
     ap.add_argument("--genome", default="hg38", help="hg38 (3.09 Gbp synthetic, the bench config) or a fraction like 0.05 for quick checks")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of each cpu_baseline sample (0 = skip)")
     ap.add_argument("--e2e-pairs", type=int, default=16 << 20, help="pairs of the end-to-end CLI run (FASTQ -> SAM in /dev/shm) reported beside the metric; 0 = skip")
     ap.add_argument("--in-flight", type=int, default=0, help="batches in flight per GPU (host threads, one device batch each): the main kernel and the "
-                    "latency-bound tail of one batch overlap the scan passes of the other; 1 = strictly one Do_Batch at a time; default 3")
+                    "latency-bound tail of one batch overlap the scan passes of the other; 1 = strictly one Do_Batch at a time; 0 = the mode's default (MODE_DEFAULTS)")
     ap.add_argument("--transfer-steps", type=int, default=-1, help="steps of the PCIe-inclusive leg (upload -> Do_Batch -> results per step); -1 = as many as --steps (the same window length as the metric's), 0 = skip")
     ap.add_argument("--waves-per-cu", type=int, default=0)
     ap.add_argument("--heavy-limits", default="", help="tuning: units per round,scan-task pool of the heavy pipeline")
@@ -135,18 +166,23 @@ def main():
                     "elements) — the headline depends on the generator's repeat content; 0 = skip")
     ap.add_argument("--other-configs", type=int, default=1, help="1 (with the default mode, one GPU): after the metric's own config, run BASELINE's other single-GPU configs (C2, C4, C5) "
                     "for a few steps each in child processes and report them under other_configs — parity-test cases, not the metric")
+    ap.add_argument("--work-counters", type=int, default=0, help="0 (default): the timed region runs as the command line does, with the work counters off (bsx_batch_set_work_counters: the scan "
+                    "kernels skip the early-out classification that only the counters need; records identical) and the counters of the SURVEY 8(d) formula come from a counted "
+                    "pass over the same resident steps afterwards; 1: the timed region itself is counted")
     ap.add_argument("--selftest-launch", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     if args.selftest_launch:
         return selftest_launch()
+    d_units, d_nfl, d_lim = mode_defaults(args.mode)
+    args.units_given = args.pairs_per_step > 0
+    if args.pairs_per_step <= 0:
+        args.pairs_per_step = d_units
     if args.in_flight <= 0:
-        args.in_flight = 3   # (three for every mode since the group scan kernel: C3 94.0-95.3 ms per step against 96.8-99.3 with two, five A/B pairs on three boxes)
-    # C4: the control passes of its 630 K deferred reads hide better under three batches, whose pools then have to be two thirds
-    # of the default size to fit (three with default pools do not fit; two with these pools: 169 ms per step against 150)
-    if args.mode == "rrbs" and args.in_flight >= 3 and not args.heavy_limits and not args.profile_serial:
-        args.heavy_limits = RRBS_POOLS
+        args.in_flight = d_nfl
+    if d_lim and not args.heavy_limits and not args.profile_serial and args.in_flight >= 3:   # (C4: three batches in flight only fit with two-thirds pools)
+        args.heavy_limits = "%d,%d" % d_lim
     if args.profile_serial:
         args.in_flight, args.cpu_seconds, args.e2e_pairs, args.transfer_steps = 1, 0.0, 0, 0
         os.environ["BSX_HEAVY_GROUPS"] = "1"  # read by bsx_batch_create (also the default)
@@ -169,11 +205,11 @@ def main():
         B.lib().bsx_set_waves_per_cu(args.waves_per_cu)
     if args.heavy_threshold:
         B.lib().bsx_set_heavy_threshold(args.heavy_threshold)
-    if args.heavy_limits:
-        u_, t_ = (int(x) for x in args.heavy_limits.split(","))
-        B.lib().bsx_set_heavy_limits(u_, t_)
     M = MODES[args.mode]
     pe, kw, read_len = M["pe"], M["kw"], M["L"]
+    # a device batch here HOLDS a ring of steps and runs one step at a time: its pools are sized for a step, not for what it holds
+    u_, t_ = (int(x) for x in args.heavy_limits.split(",")) if args.heavy_limits else B.default_heavy_limits(B.make_params(**kw), args.pairs_per_step, pe)
+    B.lib().bsx_set_heavy_limits(u_, t_)
     lens = HG38 if args.genome == "hg38" else [max(200_000, int(x * float(args.genome))) for x in HG38]
     t0 = time.time()
     real_fa = os.environ.get("BSX_HG38")  # a real genome FASTA if one is at hand (never on the driver's box); reads are
@@ -188,18 +224,19 @@ def main():
     ref.CreateIndex()
     t_index = time.time() - t0
     B_ = args.pairs_per_step
-    # Resident reads: a ring of at most RING_STEPS distinct steps (2^20 pairs each: 300 MB of reads against 4 MB of L2 and 256 MB of
-    # Infinity Cache — a step that comes round again after 8 others finds nothing of itself anywhere).  Device memory then does not grow
+    # Resident reads: a ring of distinct steps, 2^23 units or four steps (8 steps of 2^20 pairs, 4 of 2^22: a step's reads are 300 MB - 1.2 GB against
+    # 4 MB of L2 and 256 MB of Infinity Cache — a step that comes round again finds nothing of itself anywhere).  Device memory then does not grow
     # with --steps (round 4: 25 steps x 3 batches of resident reads left no room for the side legs under the driver's own command).
-    ring = min(args.steps + args.warmup, RING_STEPS)
+    ring = ring_steps(args.steps, args.warmup, B_)
     n_total = B_ * ring
     nfl = max(1, args.in_flight)
     Align = B.PairAlign if pe else B.SingleAlign
-    plan = memory_plan(B, B.make_params(**kw), pe, B_, args.steps, args.warmup, nfl, int(ref.n_entries), args.transfer_steps != 0 and world == 1, bool(kw.get("D")), float(sum(lens)))
+    plan = memory_plan(B, B.make_params(**kw), pe, B_, args.steps, args.warmup, nfl, int(ref.n_entries), args.transfer_steps != 0 and world == 1, bool(kw.get("D")), float(sum(lens)), limits=(u_, t_))
     t0 = time.time()
     batches = [Align(ref, n_total) for _ in range(nfl)]
-    if args.exact:
-        for bt in batches:
+    for bt in batches:
+        bt.set_work_counters(bool(args.work_counters))
+        if args.exact:
             bt.set_leak_exact()
     t_batches = time.time() - t0
     batch = batches[0]
@@ -240,7 +277,7 @@ def main():
     run_steps(args.warmup, args.warmup + args.steps)
     sync_all()
     dt = time.perf_counter() - t0
-    counters = sum(bt.counters().astype(np.float64) for bt in batches)
+    counters = sum(bt.counters().astype(np.float64) for bt in batches)   # (with the work counters off: completed by the counted pass below)
     heavy_last = [int(batch.heavy_units()), int(batch.redo_units())]
     # per-kernel evidence comes from a serial replay (one batch, control and scan passes strictly alternating): with batches in
     # flight the launches of different batches overlap and their durations say nothing about one kernel
@@ -249,21 +286,47 @@ def main():
     for bt in batches[1:]:   # the side legs below need the memory; batches[0] keeps the resident reads they sample
         bt.close()
     batches = batches[:1]
+    def serial_steps(b_, slots):
+        ms, sc = [], []
+        t1 = time.perf_counter()
+        for k in slots:
+            b_.run_range(k * B_, B_, sync=True)
+            ms.append(b_.kernel_ms()); sc.append(b_.scan_ms())
+        return {"ms_per_step": (time.perf_counter() - t1) / len(slots) * 1e3, "event_ms_per_do_batch": float(np.mean(ms)), "scan_ms": sc}
+
+    counted = None
     if nfl > 1 and world == 1 and args.steps >= 2:
         try:   # (a diagnostic leg must never cost the line)
             sb = batch   # alone on the device now: one batch in flight, one unit group — control and scan passes alternate strictly
             sb.run_range(0, B_, sync=True)
             sb.reset_counters()
-            s_ms, s_scan = [], []
-            t1 = time.perf_counter()
-            for i in range(1, 3):
-                sb.run_range((i % ring) * B_, B_, sync=True)
-                s_ms.append(sb.kernel_ms()); s_scan.append(sb.scan_ms())
-            serial = {"ms_per_step": (time.perf_counter() - t1) / 2 * 1e3, "event_ms_per_do_batch": float(np.mean(s_ms)), "scan_ms": s_scan,
-                      "counters": sb.counters().astype(np.float64)}
+            serial = serial_steps(sb, [1 % ring, 2 % ring])
+            serial["counters"] = sb.counters().astype(np.float64)
+            serial["work_counters"] = bool(args.work_counters)
         except Exception as e:
             serial = None
             serial_err = str(e)[:300]
+    if not args.work_counters and not args.profile_serial:
+        # The counted pass: every resident step once more, alone on the device, with the work counters on.  A step's counters are a pure
+        # function of its reads, so the timed region's counters are the sum over its steps of their slots' — the numerator of the SURVEY 8(d)
+        # formula — and the same two steps as above give the scan kernel's time WITH the classification (A/B on this box, same minute).
+        try:
+            batch.set_work_counters(True)
+            per_slot = []
+            for k in range(ring):
+                batch.reset_counters()
+                batch.run_range(k * B_, B_, sync=True)
+                per_slot.append(batch.counters().astype(np.float64))
+            counters = sum(per_slot[i % ring] for i in range(args.warmup, args.warmup + args.steps))
+            if serial:
+                batch.reset_counters()
+                counted = serial_steps(batch, [1 % ring, 2 % ring])
+                counted["counters"] = batch.counters().astype(np.float64)
+                serial["counters"] = counted["counters"]   # (the same two steps: what the uncounted replay evaluated, with the words counted)
+        except Exception as e:
+            counted = {"error": str(e)[:300]}
+        finally:
+            batch.set_work_counters(False)
     reads_per_unit = 2 if pe else 1
     n_reads_rank = args.steps * B_ * reads_per_unit
     # stats reduction: the only collective of the path (RCCL all-gather of a few doubles per rank)
@@ -290,7 +353,8 @@ def main():
         except Exception:
             pass
     step_s = k_ms * 1e-3
-    dk = dominant_kernel(serial["counters"], serial["scan_ms"], 2, 1, args.mode == "rrbs") if serial else dominant_kernel(counters, scan_ms, args.steps, nfl, args.mode == "rrbs")
+    wc = bool(args.work_counters)
+    dk = dominant_kernel(serial["counters"], serial["scan_ms"], 2, 1, args.mode == "rrbs", args.mode, wc) if serial else dominant_kernel(counters, scan_ms, args.steps, nfl, args.mode == "rrbs", args.mode, wc)
     hbm = None
     if pmc_j:  # what the memory system really moved per step (FETCH_SIZE raw and with the guide's gfx950 x2 rule for wide reads, WRITE_SIZE)
         raw = pmc_j["fetch_bytes_per_step_raw"] + pmc_j["write_bytes_per_step"]
@@ -306,7 +370,7 @@ def main():
         "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u32", "data": "synthetic" if not real_fa else "synthetic reads sampled from " + os.path.basename(real_fa),
         "config": {"workload": M["workload"], "pairs_per_step" if pe else "reads_per_step": B_, "genome_bp": int(sum(lens)), "index_entries": int(ref.n_entries),
-                   "parallelism": f"read-sharded x{world}", "batches_in_flight": nfl, "lib_sha16": sha, "exact_mode": bool(args.exact),
+                   "parallelism": f"read-sharded x{world}", "batches_in_flight": nfl, "work_counters_in_timed_region": bool(args.work_counters), "lib_sha16": sha, "exact_mode": bool(args.exact),
                    "resident_ring_steps": ring, "heavy_pools": [{"units_per_round": u_, "scan_tasks": t_} for u_, t_ in pools], "device_memory_plan": plan,
                    "setup_s": {"genome": round(t_gen, 2), "index_build_gpu": round(t_index, 2), "device_batches": round(t_batches, 2)},
                    "aligned_fraction": float((2 * tot_counters[6] + tot_counters[5]) / max(1.0, n_reads_rank * world)) if pe
@@ -322,6 +386,14 @@ def main():
         out["workload_shape"] = workload_shape(ref, counters, args.steps, B_, reads_per_unit, heavy_last[0])
     if serial_err:
         out["roofline"]["serial_replay"] = {"error": serial_err}
+    if counted:
+        if "error" in counted:
+            out["roofline"]["with_work_counters"] = counted
+        else:
+            ck = dominant_kernel(counted["counters"], counted["scan_ms"], 2, 1, args.mode == "rrbs", args.mode, True) or {}
+            out["roofline"]["with_work_counters"] = {"serial_ms_per_step": counted["ms_per_step"], "scan_kernel_ms_per_step": ck.get("ms_per_step"), "scan_kernel_candidates_per_s": ck.get("candidates_per_s"),
+                                                     "note": "the same two serial steps with bsx_batch_set_work_counters(1): the scan kernels also classify every candidate by the reference's two early-outs "
+                                                             "(align.h:189-197) — what the parity suite runs, and where the counters of formula_rate come from; the timed region and dominant_kernel run without"}
     if serial:
         out["roofline"]["serial_replay"] = {"ms_per_step": serial["ms_per_step"], "event_ms_per_do_batch": serial["event_ms_per_do_batch"],
                                             "note": "two steps with one batch in flight and one unit group after the timed region: the source of dominant_kernel"}
@@ -333,24 +405,36 @@ def main():
                                                 "frac_of_stream_read": achieved / pm["stream_read"],
                                                 "note": "gather16 = 16-byte loads at random 4-byte-aligned addresses in a 1 GiB window (each moves a 64-byte sector): "
                                                         "the access pattern of the scan; its rate does not improve for windows down to 64 MiB (profiles/r02e_probe_sweep.json)"}
+            try:
+                fr = fabric_requests(args.mode, wc, B_, out["ms_per_step"], serial["ms_per_step"] if serial else None, pm["gather16_Gloads_per_s"])
+                if fr:
+                    out["roofline"]["fabric_requests"] = fr
+            except Exception as e:
+                out["roofline"]["fabric_requests"] = {"error": str(e)[:200]}
         except Exception as e:
             out["roofline"]["peak_measured"] = {"error": str(e)[:200]}
+    if world == 1 and args.cpu_seconds > 0:
+        try:
+            out["cpu_baseline"] = cpu_baseline(ref, batch, pe, kw, args.cpu_seconds, min(args.warmup, ring - 1) * B_, M["kind"] == 1)
+        except Exception as e:
+            out["cpu_baseline"] = {"error": str(e)[:300]}
     if args.transfer_steps < 0:
         args.transfer_steps = args.steps
     if world == 1 and args.transfer_steps > 0:
         try:
-            vt = incl_transfers(B, ref, batch, Align, pe, B_, min(args.transfer_steps, args.steps), 0 if kw.get("D") else nfl, reads_per_unit, ring, M["kind"] == 1)
+            t_slots = min(ring, args.transfer_steps, args.steps)
+            host_reads = [(batch.download_reads(m), batch.download_quals(m) if M["kind"] == 1 else None) for m in range(2 if pe else 1)]
+            for bt in batches:   # (the leg's own batches need the room)
+                bt.close()
+            nt = plan["transfer_leg_batches"]
+            vt = incl_transfers(B, ref, host_reads, Align, pe, B_, min(args.transfer_steps, args.steps), nt, reads_per_unit, t_slots, wc)
+            del host_reads
             # SURVEY 8(d)'s window is "first batch submitted -> last result returned"; `value` keeps reads and records in HBM (the contract's
             # definition): the same steps with the PCIe legs inside the window, and how far the two are apart
             vt["vs_resident"] = vt["value"] / value
             out["value_incl_transfers"] = vt
         except Exception as e:
             out["value_incl_transfers"] = {"error": str(e)[:300]}
-    if world == 1 and args.cpu_seconds > 0:
-        try:
-            out["cpu_baseline"] = cpu_baseline(ref, batch, pe, kw, args.cpu_seconds, min(args.warmup, ring - 1) * B_, M["kind"] == 1)
-        except Exception as e:
-            out["cpu_baseline"] = {"error": str(e)[:300]}
     for bt in batches:
         bt.close()
     ref.close()
@@ -439,12 +523,12 @@ def per_kernel_split(c, steps, n_reads, pmc_j, serial):
     return out
 
 
-def dominant_kernel(counters, scan_ms, steps, nfl, rrbs=False):
+def dominant_kernel(counters, scan_ms, steps, nfl, rrbs=False, mode="pe", work_counters=False):
     """The scan kernel of the heavy pipeline (k_hscan_same; RRBS k_hscan_shared), the kernel most of the time goes to: launches and HIP-event durations measured live (events on the stream it
     is launched on), algorithmic bytes of the candidates it evaluated (4 B index entry + 8 B per 64-bit reference word the
     reference's CountMismatch would touch).  `bound` is derived from the committed counter summaries of the
-    same kernel (VALU issue rate against the ceiling measured by tools/microbench/valu_issue, texture-addresser busy
-    fraction), not asserted: see profiles/README.md."""
+    same kernel, build, mode and counter setting (VALU issue rate against the ceiling of ITS instruction mix measured by
+    tools/microbench/valu_issue at its own residency, texture-addresser busy fraction), not asserted: see profiles/README.md."""
     tot_ms = float(sum(t for t, n in scan_ms)); launches = int(sum(n for t, n in scan_ms))
     cand, words = float(counters[7]), float(counters[8])
     alg = 4.0 * cand + 8.0 * words
@@ -457,52 +541,100 @@ def dominant_kernel(counters, scan_ms, steps, nfl, rrbs=False):
          "candidates_per_s": cand / (tot_ms * 1e-3),
          "class_shares": {"one_word": float(counters[9]) / max(cand, 1.0), "five_words": float(counters[10]) / max(cand, 1.0)},
          "timing_note": "launch durations overlap other kernels when batches_in_flight > 1" if nfl > 1 else "serial: no other kernel runs beside it"}
-    if rrbs:  # the RRBS scan kernel evaluates runs of reads over one window of candidates: the gather is shared, the rest is arithmetic
-        ev = {"note": "the one-read kernel on the same workload: TA_BUSY 0.94, L2 hit 0.99, 204 G candidates/s (DESIGN.md §3.2)"}
-        try:   # counter passes of this kernel kept under profiles/ (tools/profile_mode.sh <tag> --mode rrbs; the summary files it by its name's prefix)
-            import glob
-            f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sq_rrbs.json")))[-1]
-            k = json.load(open(f))["kernels"]["k_hscan"]["derived"]
-            ev.update({"source": os.path.basename(f), "fractions": {"valu_issue_4_cycles_per_instruction": k.get("valu_busy_frac_4cyc"), "texture_addresser_busy": k.get("ta_busy_frac"),
-                                                                     "l2_hit": k.get("l2_hit_frac"), "scalar_per_vector_instruction": k.get("salu_per_valu"),
-                                                                     "waiting_for_data": k.get("wait_any_frac")}})
-        except Exception:
-            pass
-        vu = (ev.get("fractions") or {}).get("valu_issue_4_cycles_per_instruction")
-        d.update({"bound": "VALU issue (reference planes are loaded and shifted once per candidate for up to 16 reads; the rest is arithmetic per candidate and read)",
-                  "binding_unit": "valu_issue", "binding_unit_utilisation": vu, "bound_evidence": ev})
-    else:
-        d.update(kernel_bound())
+    d.update(kernel_bound(mode, work_counters))
     return d
 
 
-def kernel_bound():
-    """utilisation of k_hscan's units from measurements kept under profiles/: SQ / TA / LDS counter passes of the kernel (tools/sq_passes.sh,
-    tools/summarize_sq.py) and the VALU issue ceiling of its instruction mix (tools/microbench/valu_issue.hip).  The binding unit is
-    the busiest one; `same_build` says whether the counters were taken with the library this process runs."""
+def profile_summary(kind, mode, work_counters):
+    """the newest (by name = round tag) profiles/r*_<kind>*.json taken with THIS libbsx.so in this mode and counter setting, or None.  Files of
+    rounds 1-4 carry no mode: *_rrbs.json is RRBS, the others C3, all counted."""
+    import glob
+    sha = lib_sha16()
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s*.json" % kind))):
+        try:
+            j = json.load(open(f))
+        except Exception:
+            continue
+        if j.get("lib_sha16") != sha or "kernels" not in j:
+            continue
+        if j.get("mode", "rrbs" if f.endswith("_rrbs.json") else "pe") != mode or bool(j.get("work_counters", 1)) != bool(work_counters):
+            continue
+        if j.get("scan_kernel", "1") != os.environ.get("BSX_SAME", "1"):
+            continue
+        best = (f, j)
+    return best
+
+
+def valu_ceiling(mix_prefix, waves):
+    """wave64 vector instructions per second the chip sustains for an instruction mix at `waves` resident waves per SIMD (tools/microbench/valu_issue
+    measured 1 / 2 / 4 / 6 / 8; linear in between), from the newest profiles/r*_valu_issue.json that holds the mix"""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_valu_issue.json")), reverse=True):
+        vi = json.load(open(f))
+        mx = [m for m in vi["mixes"] if m["mix"].startswith(mix_prefix)]
+        if not mx:
+            continue
+        pts = sorted((int(w), v["chip_G_wave_instr_per_s"] * 1e9) for w, v in mx[0]["by_waves_per_simd"].items())
+        w = min(max(waves, pts[0][0]), pts[-1][0])
+        for (w0, r0), (w1, r1) in zip(pts, pts[1:]):
+            if w0 <= w <= w1:
+                return r0 + (r1 - r0) * (w - w0) / (w1 - w0), pts[-1][1], os.path.basename(f), mx[0]["mix"]
+    return None
+
+
+def kernel_bound(mode="pe", work_counters=False):
+    """utilisation of the scan kernel's units from measurements kept under profiles/: SQ / TA / LDS counter passes of the kernel (tools/sq_passes.sh,
+    tools/summarize_sq.py) taken with this library, mode and counter setting — nothing borrowed from another build or config: without such a file the
+    fractions are null — and the VALU issue ceiling of the kernel's OWN inner word (tools/microbench/valu_issue.hip, mixes 16 / 17) at the kernel's own
+    residency.  The binding unit is the busiest one."""
+    none = {"bound": None, "binding_unit": None, "binding_unit_utilisation": None,
+            "bound_evidence": "no counter summary of this build (lib_sha16 %s), mode %s, work counters %s under profiles/" % (lib_sha16(), mode, "on" if work_counters else "off")}
     try:
-        import glob
-        sqs = [f for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sq.json")), key=os.path.getmtime) if "k_hscan" in json.load(open(f)).get("kernels", {})
-               and not json.load(open(f)).get("bsx_multi")]
-        sha = lib_sha16()
-        same = [f for f in sqs if json.load(open(f)).get("lib_sha16") == sha]
-        sq = (same or sqs)[-1]
-        k = json.load(open(sq))["kernels"]["k_hscan"]["derived"]
-        vif = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_valu_issue.json")))[-1]
-        vi = json.load(open(vif))
-        # (the ceiling of wave64 vector instructions per second: the slow class — shifts, popcounts — of the kernel's own mix)
-        mix = ([m for m in vi["mixes"] if m["mix"].startswith("k_hscan head word, VGPR")] or [m for m in vi["mixes"] if m["mix"].startswith("k_hscan head word")])[0]["by_waves_per_simd"]
-        ceil = max(v["chip_G_wave_instr_per_s"] for v in mix.values()) * 1e9
-        fr = {"valu_issue": k["valu_instr_per_s"] / ceil, "texture_addresser_busy": k.get("ta_busy_frac"), "lds_active": k.get("lds_active_frac"), "l2_hit": k.get("l2_hit_frac"),
-              "l1_miss_per_access": k.get("l1_miss_per_access"), "waiting_on_instruction_issue": k.get("wait_inst_frac"), "waiting_for_data": k.get("wait_any_frac")}
+        got = profile_summary("sq", mode, work_counters)
+        if not got:
+            return none
+        sq, j = got
+        k = [v for n, v in j["kernels"].items() if n.startswith("k_hscan")][0]["derived"]
+        waves = k.get("resident_waves_per_simd") or 4.0
+        vc = valu_ceiling("k_hscan_same inner word with work counters" if work_counters else "k_hscan_same inner word (", waves)
+        if not vc:
+            return none
+        ceil, ceil_full, vif, mixname = vc
+        fr = {"valu_issue": k["valu_instr_per_s"] / ceil, "valu_issue_at_full_occupancy": k["valu_instr_per_s"] / ceil_full, "texture_addresser_busy": k.get("ta_busy_frac"), "lds_active": k.get("lds_active_frac"),
+              "l2_hit": k.get("l2_hit_frac"), "l1_miss_per_access": k.get("l1_miss_per_access"), "waiting_on_instruction_issue": k.get("wait_inst_frac"), "waiting_for_data": k.get("wait_any_frac"),
+              "resident_waves_per_simd": waves}
         top = max((v, n) for n, v in fr.items() if v is not None and n in ("valu_issue", "texture_addresser_busy", "lds_active"))
-        names = {"valu_issue": "VALU issue", "texture_addresser_busy": "texture path (64-lane gathers: the addresser's busy time)", "lds_active": "LDS"}
-        return {"bound": f"{names[top[1]]} at {top[0]:.2f}; the others: " + ", ".join(f"{names[n]} {fr[n]:.2f}" for n in names if n != top[1] and fr[n] is not None) + f"; not HBM (L2 hit {fr['l2_hit']:.2f})",
+        names = {"valu_issue": "VALU issue (against the ceiling of the kernel's own inner word at its %.1f resident waves per SIMD)" % waves,
+                 "texture_addresser_busy": "texture path (64-lane gathers: the addresser's busy time)", "lds_active": "LDS"}
+        return {"bound": f"{names[top[1]]} at {top[0]:.2f}; the others: " + ", ".join(f"{names[n].split(' (')[0]} {fr[n]:.2f}" for n in names if n != top[1] and fr[n] is not None) + f"; not HBM (L2 hit {fr['l2_hit']:.2f})",
                 "binding_unit": top[1], "binding_unit_utilisation": top[0],
-                "bound_evidence": {"fractions": fr, "valu_ceiling_G_wave_instr_per_s": ceil / 1e9, "same_build": bool(same),
-                                   "sources": [os.path.basename(sq), os.path.basename(vif), "r04b_gather_cost.json"]}}
-    except Exception:
-        return {"bound": None, "binding_unit": None, "binding_unit_utilisation": None, "bound_evidence": "no counter summary under profiles/"}
+                "bound_evidence": {"fractions": fr, "valu_ceiling_G_wave_instr_per_s": ceil / 1e9, "valu_ceiling_at_8_waves_per_simd": ceil_full / 1e9, "valu_mix": mixname, "same_build": True,
+                                   "sources": [os.path.basename(sq), vif]}}
+    except Exception as e:
+        none["bound_evidence"] += " (%s)" % str(e)[:120]
+        return none
+
+
+def fabric_requests(mode, work_counters, B_, ms_per_step, serial_ms, gather_rate):
+    """The bound of the whole step: random 64-byte read requests to the fabric.  Per kernel TCC_EA0_RDREQ per step from the counter
+    passes of this build / mode / counter setting (serial mode), the live rate of random 16-byte gathers on this box, and how much of the step the
+    requests alone would take at that rate."""
+    got = profile_summary("sq", mode, work_counters)
+    if not got or not gather_rate:
+        return None
+    f, j = got
+    scale = B_ / float(j.get("units_per_step", B_))
+    per = {n: v["derived"]["fabric_read_requests_per_step"] * scale for n, v in j["kernels"].items() if "fabric_read_requests_per_step" in v["derived"]}
+    tot = sum(per.values())
+    t_ms = tot / (gather_rate * 1e9) * 1e3
+    out = {"requests_per_step": tot, "by_kernel": per, "gather16_Gloads_per_s": gather_rate, "ms_at_that_rate": t_ms, "frac": t_ms / ms_per_step,
+           "frac_of_serial_step": (t_ms / serial_ms) if serial_ms else None, "source": os.path.basename(f),
+           "note": "TCC_EA0_RDREQ (64-byte read requests that left an L2) per step, summed over the step's kernels, over the rate of random 16-byte gathers "
+                   "measured live on this box (peak_measured.gather16): the time the memory system needs for the step's requests alone, as a fraction of the step"}
+    if scale != 1.0:
+        out["note"] += "; counters taken at %d units per step, scaled to %d" % (j.get("units_per_step"), B_)
+    return out
 
 
 def sensitivity(B, Align, kw, lens, read_len, B_, nfl, kind, headline):
@@ -513,8 +645,8 @@ def sensitivity(B, Align, kw, lens, read_len, B_, nfl, kind, headline):
     out = {"headline_reads_per_s": headline, "variants": {}}
     for name, var in (("microsatellite_windows_halved", 1), ("no_repeat_elements", 2)):
         ref = B.RefSeq(B.make_params(**kw)).synthetic(lens, seed=38 | (var << 56)).CreateIndex()
-        steps, warm = 3, 1
-        bts = [Align(ref, B_ * (steps + warm)) for _ in range(nfl)]
+        steps, warm = (4, 2) if nfl == 2 else (3, 1)   # (every batch in flight runs the same number of steps)
+        bts = [Align(ref, B_ * (steps + warm)).set_work_counters(False) for _ in range(nfl)]   # (as the timed region; candidates_per_read then misses the few the count-only walks would add)
         for bt in bts:
             bt.synth_reads(B_ * (steps + warm), read_len, seed=3, kind=kind)
 
@@ -551,8 +683,10 @@ def other_configs(args):
     import subprocess
     res = {}
     for mode in ("se", "rrbs", "trim"):
-        base = [sys.executable, os.path.abspath(__file__), "--mode", mode, "--steps", "6", "--warmup", "3", "--genome", str(args.genome), "--pairs-per-step", str(args.pairs_per_step),
+        base = [sys.executable, os.path.abspath(__file__), "--mode", mode, "--steps", "6", "--warmup", "3", "--genome", str(args.genome),
                 "--cpu-seconds", "0", "--transfer-steps", "0", "--e2e-pairs", "0", "--other-configs", "0"]
+        if getattr(args, "units_given", False):   # (otherwise every mode runs its own default step size)
+            base += ["--pairs-per-step", str(args.pairs_per_step)]
         tag, failures = MODES[mode]["tag"], []
         for extra in ([], ["--in-flight", "2"]):
             t0 = time.perf_counter()
@@ -564,7 +698,9 @@ def other_configs(args):
                     continue
                 j = json.loads(lines[-1])
                 dk = j["roofline"].get("dominant_kernel") or {}
-                res[tag] = {"workload": j["config"]["workload"], "reads_per_s": j["value"], "ms_per_step": j["ms_per_step"], "steps": j["steps"],
+                upu = j["config"].get("pairs_per_step") or j["config"].get("reads_per_step")
+                res[tag] = {"workload": j["config"]["workload"], "reads_per_s": j["value"], "ms_per_step": j["ms_per_step"], "units_per_step": upu,
+                            "ms_per_2^20_units": j["ms_per_step"] * (1 << 20) / upu if upu else None, "steps": j["steps"],
                             "batches_in_flight": j["config"]["batches_in_flight"], "aligned_fraction": j["config"]["aligned_fraction"], "heavy_pools": j["config"].get("heavy_pools"),
                             "candidates_per_read": j["roofline"]["per_read"]["n_cand"], "dominant_kernel": {k: dk.get(k) for k in ("name", "ms_per_step", "candidates_per_s")},
                             "roofline_frac": j["roofline"].get("frac"), "wall_s": round(time.perf_counter() - t0, 1)}
@@ -586,11 +722,12 @@ def pinned_array(B, C, nbytes):
     return np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(p)), p
 
 
-def incl_transfers(B, ref, src, Align, pe, B_, steps, nfl, reads_per_unit, ring, quals):
+def incl_transfers(B, ref, host_reads, Align, pe, B_, steps, nt, reads_per_unit, slots, work_counters=False):
     """the second headline: the same Do_Batch with the PCIe legs inside the timed window — per step the reads of that step go up
     from page-locked host memory (bsx_batch_upload_*), the batch runs, and the records come back (bsx_batch_results_*);
-    `in_flight` host threads as in the command-line driver, so one batch's transfers overlap the other's kernels.  The host side holds
-    the `ring` distinct steps of the resident run (step i uploads slot i % ring); everything allocated here is released on any exit."""
+    `nt` device batches on as many host threads as in the command-line driver, so one batch's transfers overlap the other's kernels.  The host side
+    holds `slots` distinct steps of the resident run (host_reads: per mate ((bytes, offsets), quals or None); step i uploads slot i % slots);
+    everything allocated here is released on any exit."""
     import ctypes as C
     import threading
     import numpy as np
@@ -598,28 +735,23 @@ def incl_transfers(B, ref, src, Align, pe, B_, steps, nfl, reads_per_unit, ring,
     L.bsx_pinned_alloc.restype = C.c_void_p
     L.bsx_pinned_alloc.argtypes = [C.c_size_t]
     L.bsx_pinned_free.argtypes = [C.c_void_p]
-    nm = 2 if pe else 1
-    slots = min(ring, steps)
     host, pins, small = [], [], []
     try:
-        for m in range(nm):
-            buf, off = src.download_reads(m)
+        for (buf, off), qsrc in host_reads:
             hi = int(off[slots * B_])
             a, p = pinned_array(B, C, hi)
             pins.append(p)
             a[:] = buf[:hi]
             q = None
-            if quals:
+            if qsrc is not None:
                 q, pq = pinned_array(B, C, hi)
                 pins.append(pq)
-                q[:] = src.download_quals(m)[:hi]
+                q[:] = qsrc[:hi]
             host.append((a, off[:slots * B_ + 1].astype(np.uint64), q))
-            del buf
-        nt = min(nfl + 2, 4) if nfl else 1  # (RRBS: one — a batch holds 74 GB there)  two more batches than the resident-input run keeps in flight (a batch that is moving data does not compute: 3 / 4 batches 0.93 / 0.96 of the resident rate); at most 4: each holds ~39 GB of pools
         nt = int(os.environ.get("BSX_T_BATCHES", nt))            # (experiments: batches of this leg, and how many of them may be inside Do_Batch at once)
         gate = threading.Semaphore(int(os.environ.get("BSX_T_GATE", nt)))
         for _ in range(nt):
-            small.append(Align(ref, B_))
+            small.append(Align(ref, B_).set_work_counters(work_counters))
         sinks = []    # page-locked result arrays per batch
         for _ in range(nt):
             arrs = []

@@ -64,9 +64,9 @@ EXPORTS = [
     "bsx_ref_n_chr", "bsx_ref_n_words", "bsx_ref_n_blocks", "bsx_ref_info", "bsx_ref_chr_name", "bsx_ref_blocks",
     "bsx_ref_download_words", "bsx_index_build", "bsx_index_n_entries", "bsx_index_download", "bsx_ref_n_sites", "bsx_ref_sites",
     "bsx_batch_create", "bsx_batch_destroy", "bsx_batch_upload_se", "bsx_batch_upload_pe", "bsx_batch_synth_reads", "bsx_batch_synth_reads_kind", "bsx_batch_download_quals",
-    "bsx_batch_run", "bsx_batch_run_range", "bsx_batch_sync", "bsx_batch_set_leak_exact", "bsx_batch_set_history", "bsx_batch_set_leak_state", "bsx_batch_get_leak_state", "bsx_batch_kernel_ms", "bsx_batch_scan_ms", "bsx_batch_results_se", "bsx_batch_results_pe",
+    "bsx_batch_run", "bsx_batch_run_range", "bsx_batch_sync", "bsx_batch_set_work_counters", "bsx_batch_set_leak_exact", "bsx_batch_set_history", "bsx_batch_set_leak_state", "bsx_batch_get_leak_state", "bsx_batch_kernel_ms", "bsx_batch_scan_ms", "bsx_batch_results_se", "bsx_batch_results_pe",
     "bsx_batch_counters", "bsx_batch_reset_counters", "bsx_batch_download_reads", "bsx_batch_set_debug", "bsx_batch_unit_cycles", "bsx_batch_ctrl_clocks",
-    "bsx_batch_debug_hits", "bsx_batch_debug_pairs", "bsx_batch_debug_plan", "bsx_set_waves_per_cu", "bsx_set_heavy_threshold", "bsx_set_heavy_limits", "bsx_set_pool_reserve", "bsx_batch_pool_sizes", "bsx_batch_plan_bytes", "bsx_batch_last_heavy_units", "bsx_batch_last_redo_units", "bsx_pinned_alloc", "bsx_pinned_free", "bsx_probe_memory", "bsx_thread_device",
+    "bsx_batch_debug_hits", "bsx_batch_debug_pairs", "bsx_batch_debug_plan", "bsx_set_waves_per_cu", "bsx_set_heavy_threshold", "bsx_set_heavy_limits", "bsx_set_pool_reserve", "bsx_default_heavy_limits", "bsx_batch_pool_sizes", "bsx_batch_plan_bytes", "bsx_batch_last_heavy_units", "bsx_batch_last_redo_units", "bsx_pinned_alloc", "bsx_pinned_free", "bsx_probe_memory", "bsx_thread_device",
     "bsx_meth_create", "bsx_meth_destroy", "bsx_meth_set_reference", "bsx_meth_add", "bsx_meth_combine_cpg", "bsx_meth_valid_mappings",
     "bsx_meth_report_chr", "bsx_meth_fetch_rows", "bsx_meth_add_file", "bsx_meth_write_table", "bsx_meth_create_from_fasta", "bsx_meth_n_chr", "bsx_meth_chr_name",
 ]
@@ -119,6 +119,7 @@ def lib():
         L.bsx_batch_run_range.argtypes = [vp, u32, u32]
         L.bsx_batch_sync.argtypes = [vp]
         L.bsx_batch_set_leak_exact.argtypes = [vp, i32]
+        L.bsx_batch_set_work_counters.argtypes = [vp, i32]
         L.bsx_batch_set_history.argtypes = [vp, u32, vp, vp, vp, vp, vp, vp]
         L.bsx_batch_set_leak_state.argtypes = [vp, vp, C.c_size_t]
         L.bsx_batch_get_leak_state.argtypes = [vp, vp, C.c_size_t]
@@ -139,6 +140,7 @@ def lib():
         L.bsx_set_heavy_threshold.argtypes = [i32]
         L.bsx_set_heavy_limits.argtypes = [u32, u32]
         L.bsx_set_pool_reserve.argtypes = [u64]
+        L.bsx_default_heavy_limits.argtypes = [C.POINTER(Params), u32, i32, vp, vp]
         L.bsx_batch_pool_sizes.argtypes = [vp, vp, vp]
         L.bsx_batch_plan_bytes.argtypes = [C.POINTER(Params), u32, i32, u64, u32, u32, vp]
         L.bsx_batch_last_heavy_units.argtypes = [vp]
@@ -167,6 +169,13 @@ def plan_bytes(params, max_units, paired, n_entries, n_cu=256, blocks_per_cu=5):
     o = (C.c_uint64 * 3)()
     _check(lib().bsx_batch_plan_bytes(C.byref(params), max_units, 1 if paired else 0, n_entries, n_cu, blocks_per_cu, o))
     return {"per_unit": int(o[0]), "scratch": int(o[1]), "pools": int(o[2])}
+
+
+def default_heavy_limits(params, units, paired):
+    """(deferred units per round, scan tasks): the library's starting pool sizes for runs of `units` units"""
+    u, t = C.c_uint32(), C.c_uint32()
+    _check(lib().bsx_default_heavy_limits(C.byref(params), units, 1 if paired else 0, C.addressof(u), C.addressof(t)))
+    return u.value, t.value
 
 
 def make_params(**kw):
@@ -321,6 +330,11 @@ class _Batch:
     def set_leak_exact(self, on=True):
         """reproduce the single-threaded reference for reads whose planner state leaks from earlier reads (include/bsx.h)"""
         _check(lib().bsx_batch_set_leak_exact(self.h, 1 if on else 0))
+        return self
+
+    def set_work_counters(self, on=True):
+        """off: the scan kernels skip the classification that only the work counters need (records identical; include/bsx.h)"""
+        _check(lib().bsx_batch_set_work_counters(self.h, 1 if on else 0))
         return self
 
     def set_history(self, seqs_a, quals_a=None, seqs_b=None, quals_b=None):

@@ -915,6 +915,9 @@ int main(int argc, char **argv)
     for (int g = 0; g < NG; g++) {
         rc = bsx_batch_create(refs[g % ND], o.batch, pe ? 1 : 0, &batches[g]);
         if (rc) die(rc, "creating the batch");
+        // nothing the command line prints depends on the work counters (the reference has none): the scan kernels skip the classification
+        // that only they need (include/bsx.h; BSX_WORK_COUNTERS=1 keeps them, for diagnostics)
+        if (!getenv("BSX_WORK_COUNTERS")) bsx_batch_set_work_counters(batches[g], 0);
     }
     ReadOpts ro;
     ro.read_start = o.read_start; ro.read_end = o.read_end; ro.max_readlen = p.max_readlen; ro.zero_qual = p.zero_qual;

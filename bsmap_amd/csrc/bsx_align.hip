@@ -1851,7 +1851,7 @@ __device__ __forceinline__ int snp_align_heavy(const AlignArgs &A, const HeavyAr
                                 }
                                 // count exactly the candidates of the event's task up to and including the one that caused it
                                 const uint32_t tc0e = rl(gc0, (int)upto), Xe = tc0e + (rl(r.w_ord, ls) >> 8);
-                                { CAT_BEGIN(A); wave_scan_range<true, 4>(P, BL, L, M, SL, cl, orient, seg, mode, tc0e, Xe + 1, req_thres, lane, C); CAT_END(A, 5); }
+                                if (A.work_counters) { CAT_BEGIN(A); wave_scan_range<true, 4>(P, BL, L, M, SL, cl, orient, seg, mode, tc0e, Xe + 1, req_thres, lane, C); CAT_END(A, 5); }   // (a count-only walk: nothing but the work counters depends on it)
                                 K.c[ms] = Xe + 1;
                                 if (e == 2) { wave_fence(); return 1; }
                                 restart = true;
@@ -2195,7 +2195,8 @@ __device__ __forceinline__ void hp_build_table(const ListReq &R, uint2 *T, int l
     }
 }
 
-// stage 2 for the first n (<= 64) queued candidates
+// stage 2 for the first n (<= 64) queued candidates.  STATS: also the reference's second early-out class (work counters, AlignArgs::work_counters)
+template <bool STATS>
 __device__ __forceinline__ void hp_drain(PlaneCtx &X, uint32_t n)
 {
     const bool act = (uint32_t)X.lane < n;
@@ -2214,11 +2215,13 @@ __device__ __forceinline__ void hp_drain(PlaneCtx &X, uint32_t n)
     const uint32_t p64 = it.y & 0xffu;
     const uint32_t mm2 = bsx_plane_mismatch(g1.a, g1.b, qhi(q[0]), qlo(q[1]), qhi(q[1]));
     uint32_t tot = popc_acc(mm2, p64);
-    const uint32_t w01ref = popc_acc(mm2 & qlo(q[0]), p64);
     tot = popc_acc(bsx_plane_mismatch(g1.c, g1.d, qlo(q[2]), qhi(q[2]), qlo(q[3])), tot);
     tot = popc_acc(bsx_plane_mismatch(g2.a, g2.b, qhi(q[3]), qlo(q[4]), qhi(q[4])), tot);
     tot = popc_acc(bsx_plane_mismatch(g2.c, g2.d, qlo(q[5]), qhi(q[5]), qlo(q[6])), tot);
-    X.acc.f5 += (uint32_t)__builtin_popcountll(bsx_ballot(act && w01ref <= X.thres0));
+    if (STATS) {
+        const uint32_t w01ref = popc_acc(mm2 & qlo(q[0]), p64);
+        X.acc.f5 += (uint32_t)__builtin_popcountll(bsx_ballot(act && w01ref <= X.thres0));
+    }
     // (chromosome / end-of-sequence test and hit coordinates are left to the control kernel's replay: the record carries
     //  the strand copy and the global position)
     const bool pass = act && tot <= X.thres0;
@@ -2233,15 +2236,18 @@ __device__ __forceinline__ void hp_drain(PlaneCtx &X, uint32_t n)
 
 // stage 1 for one chunk: lane l holds one candidate (p its position, r0 its first two reference pairs, q0..q3 the first four
 // table pairs of its shift); candidates still within the threshold go into the FIFO.  MASKED: some lanes hold no candidate.
-template <bool MASKED>
+template <bool MASKED, bool STATS>
 __device__ __forceinline__ void hp_eval(PlaneCtx &X, const U4 r0, q64 q0, q64 q1, q64 q2, q64 q3, uint32_t p, bool valid, uint32_t tag)
 {
     const uint32_t mm0 = bsx_plane_mismatch(r0.a, r0.b, qlo(q0), qhi(q0), qlo(q1));
     const uint32_t mm1 = bsx_plane_mismatch(r0.c, r0.d, qlo(q2), qhi(q2), qhi(q1));
     const uint32_t c0 = __popc(mm0);
-    const uint32_t w0ref = popc_acc(mm1 & qlo(q3), c0), p64 = popc_acc(mm1, c0);
+    const uint32_t p64 = popc_acc(mm1, c0);
     const bool need = (!MASKED || valid) && p64 <= X.thres0;
-    X.acc.c1 += (uint32_t)__builtin_popcountll(bsx_ballot((!MASKED || valid) && w0ref > X.thres0));
+    if (STATS) {
+        const uint32_t w0ref = popc_acc(mm1 & qlo(q3), c0);
+        X.acc.c1 += (uint32_t)__builtin_popcountll(bsx_ballot((!MASKED || valid) && w0ref > X.thres0));
+    }
     const u64 nm = bsx_ballot(need);
     if (nm) {
         if (need) {
@@ -2250,11 +2256,11 @@ __device__ __forceinline__ void hp_eval(PlaneCtx &X, const U4 r0, q64 q0, q64 q1
         }
         X.qn += (uint32_t)__builtin_popcountll(nm);
     }
-    while (X.qn >= 64 && !X.overflow) hp_drain(X, 64);  // (FIFO writes and reads of a wave are ordered: same wave, same LDS)
+    while (X.qn >= 64 && !X.overflow) hp_drain<STATS>(X, 64);  // (FIFO writes and reads of a wave are ordered: same wave, same LDS)
 }
 
 // stage 1 for 256 consecutive candidates of one WGBS sub-range (see hscan_step: entries one step ahead)
-template <bool FULL>
+template <bool FULL, bool STATS>
 __device__ __forceinline__ void hp_step(PlaneCtx &X, uint32_t (&e)[4], const uint32_t *__restrict__ nextq, uint32_t ref_off, uint32_t h, uint32_t n_here, uint32_t ord0,
                                         uint32_t strand)
 {
@@ -2283,12 +2289,13 @@ __device__ __forceinline__ void hp_step(PlaneCtx &X, uint32_t (&e)[4], const uin
     for (int u = 0; u < 4; u++) {
         if (u < 3) { hp_lds4(hp_taddr(X.tbase, p[u + 1]), q[(u + 1) & 1][0], q[(u + 1) & 1][1], q[(u + 1) & 1][2], q[(u + 1) & 1][3]); HP_WAIT4N(4, q[u & 1][0], q[u & 1][1], q[u & 1][2], q[u & 1][3]); }
         else HP_WAIT4N(0, q[u & 1][0], q[u & 1][1], q[u & 1][2], q[u & 1][3]);
-        hp_eval<!FULL>(X, r0[u], q[u & 1][0], q[u & 1][1], q[u & 1][2], q[u & 1][3], p[u], valid[u], tag[u]);
+        hp_eval<!FULL, STATS>(X, r0[u], q[u & 1][0], q[u & 1][1], q[u & 1][2], q[u & 1][3], p[u], valid[u], tag[u]);
     }
 }
 
 // one scan task on one wave: candidates [c0, c0 + n) of the task's list, survivors in list order and the work counters into its output record
 // (TABw / PTw / Qw: this wave's sub-range table, read table and FIFO in LDS)
+template <bool STATS>
 __device__ __forceinline__ void hp_task(const AlignArgs &A, const HeavyArgs &H, uint32_t t, int lane, uint32_t (&TABw)[4][32], uint2 *PTw, uint2 *Qw)
 {
     const DevParams &P = A.P;
@@ -2321,25 +2328,26 @@ __device__ __forceinline__ void hp_task(const AlignArgs &A, const HeavyArgs &H, 
         uint32_t e[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) e[u] = (ent + (cb - ps) + lane)[u * 64];
-        for (; cb + 256 <= hi && !X.overflow; cb += 256) hp_step<true>(X, e, ent + (cb + 256 - ps) + lane, ref_off, h, 256, cb - tc0, strand);
-        if (cb < hi && !X.overflow) hp_step<false>(X, e, nullptr, ref_off, h, hi - cb, cb - tc0, strand);
+        for (; cb + 256 <= hi && !X.overflow; cb += 256) hp_step<true, STATS>(X, e, ent + (cb + 256 - ps) + lane, ref_off, h, 256, cb - tc0, strand);
+        if (cb < hi && !X.overflow) hp_step<false, STATS>(X, e, nullptr, ref_off, h, hi - cb, cb - tc0, strand);
     }
-    while (X.qn && !X.overflow) hp_drain(X, min(X.qn, 64u));
+    while (X.qn && !X.overflow) hp_drain<STATS>(X, min(X.qn, 64u));
     const uint32_t n1 = X.acc.c1, n5 = X.acc.f5;
     const uint32_t n_cand = tn;
-    const uint32_t words = 2u * n_cand - n1 + 3u * n5;  // 1, 2 or 5 words per candidate (see above)
+    const uint32_t words = STATS ? 2u * n_cand - n1 + 3u * n5 : 0u;  // 1, 2 or 5 words per candidate (see above); without the work counters: not known
     if (lane == 0) {
         o->count = X.overflow ? 0 : X.nsurv; o->overflow = X.overflow ? 1 : 0; o->acc[0] = n_cand; o->acc[1] = words; o->acc[2] = 0; o->acc[3] = 0; o->c0 = tc0; o->n = tn;
         if (!X.overflow) {  // work of the scan kernel (incl. speculation); an overflowed task is redone by the control kernel.
             // Millions of tasks per batch: one counter word takes ~88 atomics per microsecond, so these statistics are
             // sharded over 64 cache lines (summed by bsx_batch_counters) instead of being added to four hot words
             u64 *sh = (u64 *)A.scan_stats + (size_t)(blockIdx.x & 63u) * 8;
-            atomicAdd((u64 *)&sh[0], (u64)n_cand); atomicAdd((u64 *)&sh[1], (u64)words);
-            atomicAdd((u64 *)&sh[2], (u64)n1); atomicAdd((u64 *)&sh[3], (u64)n5);
+            atomicAdd((u64 *)&sh[0], (u64)n_cand);
+            if (STATS) { atomicAdd((u64 *)&sh[1], (u64)words); atomicAdd((u64 *)&sh[2], (u64)n1); atomicAdd((u64 *)&sh[3], (u64)n5); }
         }
     }
 }
 
+template <bool STATS>
 __global__ __launch_bounds__(64 * BSX_HSCAN_WPB, BSX_HSCAN_WAVES) void k_hscan(AlignArgs A, HeavyArgs H)
 {
     __shared__ uint32_t TAB[BSX_HSCAN_WPB][4][32];
@@ -2360,275 +2368,8 @@ __global__ __launch_bounds__(64 * BSX_HSCAN_WPB, BSX_HSCAN_WAVES) void k_hscan(A
         if (st_ == 2) break;
         if (st_ == 1) continue;
         const uint32_t slot = b_ * BSX_HSCAN_WPB + (uint32_t)wv;
-        if (slot < n_tasks) hp_task(A, H, H.order ? rfl(H.order[slot]) : slot, lane, TAB[wv], PT[wv], QBUF[wv]);
+        if (slot < n_tasks) hp_task<STATS>(A, H, H.order ? rfl(H.order[slot]) : slot, lane, TAB[wv], PT[wv], QBUF[wv]);
         wave_fence();
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// k_hscan_multi — WGBS: sixteen reads against ONE fetch of the candidates' reference windows.
-// Thousands of reads walk the same giant bucket in the same pass, and since publish_window cuts large sub-ranges on the grid of
-// absolute index entries, their tasks cover identical entry ranges: in scan order, runs of tasks with the same first entry, length
-// and strand copy.  A 64-lane gather costs the texture path the same for 4, 8 or 16 bytes per lane (39 CU cycles from L1, 144-158
-// from L2: tools/microbench/gather_cost.hip, profiles/r04b_gather_cost.json) and k_hscan spends 1.8 of them per 64 candidates and
-// read.  Here a block of four waves takes a run of up to 16 such tasks — each read with its own offset h into the candidate, hence
-// its own shift — and per round of 256 candidates
-//   * every wave fetches one chunk's entries and, per candidate, the 12 pairs of the plane copy that cover all the reads of the
-//     run (positions entry + hmin .. entry + hmax + read), six 16-byte gathers, into LDS: STG[chunk][pair][lane];
-//   * after a barrier every wave evaluates all four chunks for ITS four reads from LDS: candidate pairs by ds_read_b64 at
-//     [pair0 + d][lane] (32 lanes of a row are 32 different 8-byte units: no bank conflict whatever d is per lane), the read's
-//     pre-shifted tables as in k_hscan (hp_build_table, one table per read), the same two stages through one FIFO per wave whose
-//     items carry the read's slot; stage 2 reads the staged pairs too, so the FIFO is emptied before the round's buffer is released.
-// 0.375 gathers per 64 candidates and read instead of 1.8.  Results per task are exactly k_hscan's: survivors in list order,
-// candidate count, word count.  Runs shorter than HM_MINRUN, and tasks of small segments, go one task per wave through hp_task.
-// ---------------------------------------------------------------------------------------------------------------
-#define HM_TASKS 16u   /* tasks a block takes per group */
-#define HM_WAVES 8     /* waves per block */
-#define HM_SLOTS 2     /* reads per wave: HM_WAVES * HM_SLOTS = HM_TASKS */
-#define HM_MINRUN 4u
-#define HM_PAIRS 12u   /* staged pairs per candidate: ((31 + hmax - hmin) >> 5) + 6 of them are needed */
-#define HM_QCAP 128u
-struct MultiLds {
-    uint2 PT[HM_TASKS][HP_PAIRS * 32];  // read tables: wave w owns PT[HM_SLOTS w ..] (the one-task path uses the first)
-    uint2 STG[4][HM_PAIRS][64];         // the round's four chunks: pairs of the plane copy from each candidate's first pair on
-    uint32_t ENT[4][64];                // their index entries
-    uint2 Q[HM_WAVES][HM_QCAP];         // FIFO of each wave
-    uint32_t TAB[HM_WAVES][4][32];      // sub-range tables of the one-task path
-};
-__device__ __forceinline__ void hm_lds2(uint32_t addr, q64 &a, q64 &b)   // rows d, d + 1 of a staged chunk (a row is 512 bytes)
-{
-    asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:512" : "=&v"(a), "=&v"(b) : "v"(addr));
-}
-__device__ __forceinline__ void hm_lds4(uint32_t addr, q64 &a, q64 &b, q64 &c, q64 &d)
-{
-    asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:512\n\tds_read_b64 %2, %4 offset:1024\n\tds_read_b64 %3, %4 offset:1536"
-                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(addr));
-}
-struct MultiCtx {
-    uint32_t tbase, sbase;      // LDS byte addresses: this wave's first table, the staging buffer
-    uint2 *Q; uint32_t qh, qn;
-    uint32_t thr[HM_SLOTS], tid[HM_SLOTS];    // per read slot: threshold, task id (outputs)
-    uint32_t thr_pack;          // the thresholds, one byte each (a threshold is at most 15)
-    uint32_t c1[HM_SLOTS], f5[HM_SLOTS], ns[HM_SLOTS];
-    uint32_t valid_slots;       // bit q: slot q holds a read
-    HTaskOut *tout;
-    int lane;
-    uint32_t strand;
-};
-
-// stage 2 for the first n (<= 64) queued candidates of this wave's reads
-__device__ __forceinline__ void hm_drain(MultiCtx &X, uint32_t n)
-{
-    const bool act = (uint32_t)X.lane < n;
-    const uint2 it = X.Q[(X.qh + (uint32_t)X.lane) & (HM_QCAP - 1)];  // x position, y p64 | ordinal << 8 | slot << 21 | pair offset << 23
-    X.qh = (X.qh + n) & (HM_QCAP - 1); X.qn -= n;
-    const uint32_t p = it.x, y = it.y;
-    const uint32_t q = (y >> 21) & 3u, d = (y >> 23) & 7u, ord = (y >> 8) & 0x1fffu;
-    const uint32_t taddr = hp_taddr(X.tbase + q * (HP_PAIRS * 32u * 8u), p);
-    const uint32_t saddr = X.sbase + ((((ord >> 6) & 3u) * HM_PAIRS + d + 2u) * 64u + (ord & 63u)) * 8u;
-    q64 t7[7], r4[4];
-    hm_lds4(saddr, r4[0], r4[1], r4[2], r4[3]);
-    hp_lds7(taddr, t7);
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t7[0]), "+v"(t7[1]), "+v"(t7[2]), "+v"(t7[3]), "+v"(t7[4]), "+v"(t7[5]), "+v"(t7[6]), "+v"(r4[0]), "+v"(r4[1]), "+v"(r4[2]), "+v"(r4[3]));
-    const uint32_t thr = (X.thr_pack >> (q << 3)) & 0xffu;   // (a chain of selects becomes a chain of branches)
-    const uint32_t p64 = y & 0xffu;
-    const uint32_t mm2 = bsx_plane_mismatch(qlo(r4[0]), qhi(r4[0]), qhi(t7[0]), qlo(t7[1]), qhi(t7[1]));
-    uint32_t tot = popc_acc(mm2, p64);
-    const uint32_t w01ref = popc_acc(mm2 & qlo(t7[0]), p64);
-    tot = popc_acc(bsx_plane_mismatch(qlo(r4[1]), qhi(r4[1]), qlo(t7[2]), qhi(t7[2]), qlo(t7[3])), tot);
-    tot = popc_acc(bsx_plane_mismatch(qlo(r4[2]), qhi(r4[2]), qhi(t7[3]), qlo(t7[4]), qhi(t7[4])), tot);
-    tot = popc_acc(bsx_plane_mismatch(qlo(r4[3]), qhi(r4[3]), qlo(t7[5]), qhi(t7[5]), qlo(t7[6])), tot);
-    const u64 am = bsx_ballot(act), b0 = bsx_ballot((q & 1u) != 0);
-    const u64 m5 = bsx_ballot(w01ref <= thr) & am, mp = bsx_ballot(tot <= thr) & am;
-#pragma unroll
-    for (int k = 0; k < HM_SLOTS; k++) {
-        const u64 mk = (k & 1) ? b0 : ~b0;
-        X.f5[k] += (uint32_t)__builtin_popcountll(m5 & mk);
-        const u64 ms = mp & mk;
-        if (ms) {
-            const uint32_t pos = X.ns[k] + __builtin_amdgcn_mbcnt_hi((uint32_t)(ms >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ms, 0u));
-            if (((ms >> X.lane) & 1) && pos < HS_SCAP) { SurvRec r; r.w_ord = tot | (ord << 8); r.hchr = X.strand; r.hloc = p; r.hkey = 0; X.tout[X.tid[k]].surv[pos] = r; }
-            X.ns[k] += (uint32_t)__builtin_popcountll(ms);
-        }
-    }
-}
-
-// a run of K (HM_MINRUN..16) tasks over the same n index entries from `key` on, strand copy `strand`: lane j of every wave holds task
-// i0 + j's (tid, th, hh) — task id, unit | slot, offset h of its sub-range.  All waves of the block call this together (barriers inside).
-__device__ __forceinline__ void hm_run(const AlignArgs &A, const HeavyArgs &H, MultiLds &L, int lane, int wv, uint32_t i0, uint32_t K, uint32_t tid, uint32_t th, uint32_t hh,
-                                       uint32_t tc0, uint32_t key, uint32_t n, uint32_t strand, int hmin)
-{
-    static_assert(HM_SLOTS == 2, "slot masks of hm_drain");
-    const DevParams &P = A.P;
-    MultiCtx X;
-    X.tbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint2 *)L.PT[HM_SLOTS * wv];
-    X.sbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint2 *)&L.STG[0][0][0];
-    X.Q = L.Q[wv]; X.qh = 0; X.qn = 0; X.tout = H.tout; X.lane = lane; X.strand = strand; X.valid_slots = 0; X.thr_pack = 0;
-    uint32_t hq[HM_SLOTS], c0q[HM_SLOTS];
-#pragma unroll
-    for (int q = 0; q < HM_SLOTS; q++) {   // slot q of wave w: task i0 + w + HM_WAVES q of the run (an empty slot repeats the run's first task and is ignored)
-        const uint32_t j = (uint32_t)wv + (uint32_t)HM_WAVES * (uint32_t)q;
-        const bool ok = j < K;
-        const uint32_t src = i0 + (ok ? j : 0u);
-        X.tid[q] = rl_u(tid, src); hq[q] = rl_u(hh, src); c0q[q] = rl_u(tc0, src);
-        const uint32_t thq = rl_u(th, src);
-        const ListReq &R = H.state[thq & 0x3fffffffu].req[thq >> 30];
-        X.thr[q] = rfl(R.thres);
-        X.thr_pack |= (X.thr[q] & 0xffu) << (8 * q);
-        if (ok) X.valid_slots |= 1u << q;
-        hp_build_table(R, L.PT[HM_SLOTS * wv + q], lane);
-        X.c1[q] = 0; X.f5[q] = 0; X.ns[q] = 0;
-    }
-    const uint8_t *plane = reinterpret_cast<const uint8_t *>(P.refplane);
-    const uint32_t ref_off = strand ? P.plane_rc_off : 0u;
-    const uint32_t *ent = P.entries + key;
-    const uint32_t uhmin = (uint32_t)hmin;
-    wave_fence();
-    // Software pipeline over the rounds: the gathers of round r + 1 are in flight while round r is evaluated, and the entries they
-    // start from were loaded a round earlier still.  Waves 0-3 stage one chunk each.
-    //   e_cur: this wave's entries of the round whose pairs sit in g[] ; e_nxt: of the round after it
-    const bool stager = wv < 4;
-    const uint32_t my = 64u * (uint32_t)(wv & 3) + (uint32_t)lane;
-    uint32_t e_cur = (stager && my < n) ? ent[my] : 1024u;   // (a lane without a candidate: any position that keeps e + h from wrapping — its pair offsets stay inside the staged rows)
-    uint32_t e_nxt = (stager && 256u + my < n) ? ent[256u + my] : 1024u;
-    U4 g[6];
-#pragma unroll
-    for (int i = 0; i < 6; i++) g[i].a = g[i].b = g[i].c = g[i].d = 0;
-    if (stager) {
-        const uint8_t *src = plane + hp_boff(e_cur + uhmin, ref_off);
-#pragma unroll
-        for (int i = 0; i < 6; i++) g[i] = *reinterpret_cast<const U4 *>(src + 16 * i);
-    }
-    for (uint32_t cb = 0; cb < n; cb += 256) {
-        if (stager) {
-            // stage chunk `wv` of this round (the barrier at the end of the last round freed the buffer)
-            L.ENT[wv][lane] = e_cur;
-#pragma unroll
-            for (int i = 0; i < 6; i++) { L.STG[wv][2 * i][lane] = make_uint2(g[i].a, g[i].b); L.STG[wv][2 * i + 1][lane] = make_uint2(g[i].c, g[i].d); }
-            // the next round's gathers, and the entries of the one after it
-            e_cur = e_nxt;
-            if (cb + 256 < n) {
-                const uint8_t *src = plane + hp_boff(e_cur + uhmin, ref_off);
-#pragma unroll
-                for (int i = 0; i < 6; i++) g[i] = *reinterpret_cast<const U4 *>(src + 16 * i);
-                e_nxt = cb + 512u + my < n ? ent[cb + 512u + my] : 1024u;
-            }
-        }
-        __syncthreads();
-        // The round's (chunk, slot) evaluations as one flat sequence with the LDS reads of an evaluation issued TWO evaluations ahead
-        // (three rotating register sets; s_waitcnt lgkmcnt counts to 15: twelve reads may stay in flight).  Chunks beyond the run's
-        // end evaluate the dummy entries of their empty lanes and count nothing.
-        uint32_t ev[4], pair0[4];
-#pragma unroll
-        for (int c = 0; c < 4; c++) { ev[c] = L.ENT[c][lane]; pair0[c] = (ev[c] + uhmin) >> 5; }
-        q64 tq[3][4], rq[3][2];
-        uint32_t pq[3], dq[3];
-        auto issue = [&](int set, int it) {
-            const int c = it / HM_SLOTS, q = it % HM_SLOTS;
-            pq[set] = ev[c] + hq[q]; dq[set] = (pq[set] >> 5) - pair0[c];
-            hm_lds2(X.sbase + ((uint32_t)c * HM_PAIRS * 64u + (uint32_t)lane) * 8u + dq[set] * 512u, rq[set][0], rq[set][1]);
-            hp_lds4(hp_taddr(X.tbase + (uint32_t)q * (HP_PAIRS * 32u * 8u), pq[set]), tq[set][0], tq[set][1], tq[set][2], tq[set][3]);
-        };
-        constexpr int NIT = 4 * HM_SLOTS;
-        issue(0, 0); issue(1, 1);
-#pragma unroll
-        for (int it = 0; it < NIT; it++) {
-            const int c = it / HM_SLOTS, q = it % HM_SLOTS, cur = it % 3;
-            if (it + 2 < NIT) {
-                issue((it + 2) % 3, it + 2);
-                asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(rq[cur][0]), "+v"(rq[cur][1]), "+v"(tq[cur][0]), "+v"(tq[cur][1]), "+v"(tq[cur][2]), "+v"(tq[cur][3]));
-            } else if (it + 1 < NIT) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(rq[cur][0]), "+v"(rq[cur][1]), "+v"(tq[cur][0]), "+v"(tq[cur][1]), "+v"(tq[cur][2]), "+v"(tq[cur][3]));
-            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rq[cur][0]), "+v"(rq[cur][1]), "+v"(tq[cur][0]), "+v"(tq[cur][1]), "+v"(tq[cur][2]), "+v"(tq[cur][3]));
-            const uint32_t ord = cb + 64u * (uint32_t)c + (uint32_t)lane;
-            const bool validc = ord < n;
-            // (validity as a scalar mask: a ballot of a compare ANDed with another lane condition goes through a 0/1 register and a second compare)
-            const u64 okm = ((X.valid_slots >> q) & 1u) ? bsx_ballot(validc) : 0ull;
-            const uint32_t mm0 = bsx_plane_mismatch(qlo(rq[cur][0]), qhi(rq[cur][0]), qlo(tq[cur][0]), qhi(tq[cur][0]), qlo(tq[cur][1]));
-            const uint32_t mm1 = bsx_plane_mismatch(qlo(rq[cur][1]), qhi(rq[cur][1]), qlo(tq[cur][2]), qhi(tq[cur][2]), qhi(tq[cur][1]));
-            const uint32_t cnt0 = __popc(mm0);
-            const uint32_t w0ref = popc_acc(mm1 & qlo(tq[cur][3]), cnt0), p64 = popc_acc(mm1, cnt0);
-            const bool within = p64 <= X.thr[q];
-            X.c1[q] += (uint32_t)__builtin_popcountll(bsx_ballot(w0ref > X.thr[q]) & okm);
-            const u64 nm = bsx_ballot(within) & okm;
-            if (nm) {
-                if (within && validc && ((X.valid_slots >> q) & 1u)) {
-                    const uint32_t pos = X.qh + X.qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(nm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nm, 0u));
-                    X.Q[pos & (HM_QCAP - 1)] = make_uint2(pq[cur], p64 | (ord << 8) | ((uint32_t)q << 21) | (dq[cur] << 23));
-                }
-                X.qn += (uint32_t)__builtin_popcountll(nm);
-            }
-            while (X.qn >= 64) hm_drain(X, 64);
-        }
-        while (X.qn) hm_drain(X, min(X.qn, 64u));   // stage 2 reads the staged pairs: nothing may be left when the buffer is released
-        __syncthreads();
-    }
-    // results of this wave's reads
-    u64 st_cand = 0, st_words = 0, st_n1 = 0, st_n5 = 0;
-#pragma unroll
-    for (int q = 0; q < HM_SLOTS; q++) {
-        if (!((X.valid_slots >> q) & 1u)) continue;
-        const bool ov = X.ns[q] > HS_SCAP;
-        const uint32_t words = 2u * n - X.c1[q] + 3u * X.f5[q];
-        if (lane == 0) {
-            HTaskOut *o = &H.tout[X.tid[q]];
-            o->count = ov ? 0 : X.ns[q]; o->overflow = ov ? 1 : 0; o->acc[0] = n; o->acc[1] = words; o->acc[2] = 0; o->acc[3] = 0; o->c0 = c0q[q]; o->n = n;
-        }
-        if (!ov) { st_cand += n; st_words += words; st_n1 += X.c1[q]; st_n5 += X.f5[q]; }
-    }
-    if (lane == 0 && st_cand) {
-        u64 *sh = (u64 *)A.scan_stats + (size_t)((blockIdx.x * (uint32_t)HM_WAVES + (uint32_t)wv) & 63u) * 8;
-        atomicAdd((u64 *)&sh[0], st_cand); atomicAdd((u64 *)&sh[1], st_words); atomicAdd((u64 *)&sh[2], st_n1); atomicAdd((u64 *)&sh[3], st_n5);
-        atomicAdd((u64 *)&sh[4], st_cand);   // counter 15: the share of counter 7 that went through shared fetches
-    }
-}
-
-__global__ __launch_bounds__(64 * HM_WAVES, 4) void k_hscan_multi(AlignArgs A, HeavyArgs H)
-{
-    __shared__ MultiLds L;
-    const int lane = threadIdx.x & 63, wv = (int)rfl(threadIdx.x >> 6);
-    const uint32_t n_tasks = min(*H.n_tasks, H.task_cap);
-    const uint32_t ngrp = (n_tasks + HM_TASKS - 1) / HM_TASKS;
-    for (uint32_t vb = blockIdx.x;; vb += gridDim.x) {
-        uint32_t b_;
-        const int st_ = bsx_order_block(vb, ngrp, H.xcd_map >= 2 ? max(2u, H.xcd_map / 8u) : H.xcd_map, b_);   // (a group is 16 tasks: 8 of k_hscan's blocks)
-        if (st_ == 2) break;
-        if (st_ == 1) continue;
-        const uint32_t s0 = b_ * HM_TASKS;
-        const uint32_t nj = min(HM_TASKS, n_tasks - s0);
-        // lane j < nj: task j of the group, in scan order, and the signature of its window
-        uint32_t tid = 0, th = 0, tc0 = 0, tn = 0, key = 0, hh = 0, strand = 0;
-        bool single = false;
-        if ((uint32_t)lane < nj) {
-            tid = H.order ? H.order[s0 + lane] : s0 + (uint32_t)lane;
-            const HTask tk = H.tasks[tid];
-            th = tk.h; tc0 = tk.c0; tn = tk.n;
-            key = tk.key; hh = tk.sub_h; strand = tk.flags & 1u; single = tn != 0 && (tk.flags & 6u) == 2u;   // (publish_window: the sub-range the task starts in, and whether it ends there too)
-        }
-        for (uint32_t i0 = 0; i0 < nj;) {
-            const uint32_t n = rl_u(tn, i0);
-            uint32_t K = 1;
-            int hmin = 0, hmax = 0;
-            if (n && rl_u(single ? 1u : 0u, i0)) {
-                const uint32_t key0 = rl_u(key, i0), st0 = rl_u(strand, i0);
-                const bool same = (uint32_t)lane >= i0 && (uint32_t)lane < nj && single && tn == n && key == key0 && strand == st0;
-                K = (uint32_t)__builtin_ctzll(~(bsx_ballot(same) >> i0));   // (bit 0 is set: the task equals itself)
-                const bool in_run = (uint32_t)lane >= i0 && (uint32_t)lane < i0 + K;
-                int lo_ = in_run ? (int)hh : 0x7fffffff, hi_ = in_run ? (int)hh : (int)0x80000000;
-#pragma unroll
-                for (int o_ = 32; o_; o_ >>= 1) { lo_ = min(lo_, __shfl_xor(lo_, o_)); hi_ = max(hi_, __shfl_xor(hi_, o_)); }
-                hmin = lo_; hmax = hi_;
-            }
-            if (K >= HM_MINRUN && ((31 + hmax - hmin) >> 5) + 6 <= (int)HM_PAIRS) {
-                hm_run(A, H, L, lane, wv, i0, K, tid, th, hh, tc0, rl_u(key, i0), n, rl_u(strand, i0), hmin);
-            } else {
-                for (uint32_t j = i0 + (uint32_t)wv; j < i0 + K; j += HM_WAVES) {   // one task per wave
-                    hp_task(A, H, rl_u(tid, j), lane, L.TAB[wv], L.PT[HM_SLOTS * wv], L.Q[wv]);
-                    wave_fence();
-                }
-            }
-            i0 += K;
-        }
-        __syncthreads();
     }
 }
 
@@ -2715,7 +2456,7 @@ __device__ __forceinline__ SameChunk same_load(const SameWin &W, const SameEntry
 // NWR: the read's 32-nt words if known at compile time (0: nwr_rt); PLAIN: the read has no N — only its last word is masked, the words
 // before it take two v_bitop3 instead of three; SKIP: the words behind the first 64 nt only where a lane of `alive` is still within the
 // threshold there (RRBS, -v 2: 99 % of a repeat family's candidates fail early; both early-out classes and the survivors are settled by then)
-template <int NWR, bool PLAIN, bool SKIP>
+template <int NWR, bool PLAIN, bool SKIP, bool STATS>
 __device__ __forceinline__ void same_counts(const uint32_t (&flo)[5], const uint32_t (&fhi)[5], uint32_t him, int nwr_rt, const uint4 &a0, const uint4 &a1, const uint4 &a2,
                                             const uint4 &a3, uint32_t thr, u64 alive, uint32_t &w0ref, uint32_t &w01ref, uint32_t &tot)
 {
@@ -2724,10 +2465,10 @@ __device__ __forceinline__ void same_counts(const uint32_t (&flo)[5], const uint
 #define SAME_MM(j, X, Y, M) ((PLAIN && (j) < NWR - 1) ? bsx_plane_mismatch_full(flo[j], fhi[j], X, Y) : bsx_plane_mismatch(flo[j], fhi[j], X, Y, M))
     const uint32_t m0 = SAME_MM(0, a0.x, a0.y, a0.z);
     const uint32_t c0 = __popc(m0);
-    w0ref = __popc(m0 & him); tot = c0; w01ref = c0;
+    w0ref = STATS ? __popc(m0 & him) : 0u; tot = c0; w01ref = c0;
     if (nwr > 1) {
         const uint32_t m1 = SAME_MM(1, a0.w, a1.x, a1.y);
-        tot = popc_acc(m1, c0); w01ref = popc_acc(m1 & him, c0);
+        tot = popc_acc(m1, c0); if (STATS) w01ref = popc_acc(m1 & him, c0);
         if (nwr > 2 && (!SKIP || (bsx_ballot(tot <= thr) & alive))) {
             tot = popc_acc(SAME_MM(2, a1.z, a1.w, a2.x), tot);
             if (nwr > 3) {
@@ -2742,7 +2483,7 @@ __device__ __forceinline__ void same_counts(const uint32_t (&flo)[5], const uint
 // one read of a group against the step's chunks: counts and survivors.  PLAIN as in same_counts; FULL: every lane of every chunk holds a candidate
 // (all steps of a window but its last) — the masks need no AND with the valid lanes.  Both are decided once per read and step, outside the chunk loop
 // (scan 56.2-56.6 against 57.7-57.8 ms per step with the two tests inside it)
-template <int NWR, bool RRBS, bool PLAIN, bool FULL>
+template <int NWR, bool RRBS, bool PLAIN, bool FULL, bool STATS>
 __device__ __forceinline__ void hs_eval_read(const uint32_t (&flo)[HG_C][5], const uint32_t (&fhi)[HG_C][5], const uint32_t (&him)[HG_C], const u64 (&vm)[HG_C],
                                              const uint32_t (&ordsh)[HG_C], const uint32_t (&hchr)[HG_C], const uint32_t (&hloc)[HG_C], int nwr, const uint4 &a0, const uint4 &a1,
                                              const uint4 &a2, const uint4 &a3, uint32_t thr, SurvRec *sv, uint32_t &nsk, uint32_t &add15)
@@ -2750,10 +2491,14 @@ __device__ __forceinline__ void hs_eval_read(const uint32_t (&flo)[HG_C][5], con
 #pragma unroll
     for (int u = 0; u < HG_C; u++) {
         uint32_t w0ref, w01ref, tot;
-        same_counts<NWR, PLAIN, RRBS>(flo[u], fhi[u], him[u], nwr, a0, a1, a2, a3, thr, vm[u], w0ref, w01ref, tot);
-        u64 b1 = bsx_ballot(w0ref > thr), b5 = bsx_ballot(w01ref <= thr), bp = bsx_ballot(tot <= thr);
-        if (!FULL) { b1 &= vm[u]; b5 &= vm[u]; bp &= vm[u]; }
-        add15 += (uint32_t)__builtin_popcountll(b1) + ((uint32_t)__builtin_popcountll(b5) << 16);
+        same_counts<NWR, PLAIN, RRBS, STATS>(flo[u], fhi[u], him[u], nwr, a0, a1, a2, a3, thr, vm[u], w0ref, w01ref, tot);
+        u64 bp = bsx_ballot(tot <= thr);
+        if (!FULL) bp &= vm[u];
+        if (STATS) {   // the two early-out classes of the reference (align.h:189-197): work counters only, no effect on any hit
+            u64 b1 = bsx_ballot(w0ref > thr), b5 = bsx_ballot(w01ref <= thr);
+            if (!FULL) { b1 &= vm[u]; b5 &= vm[u]; }
+            add15 += (uint32_t)__builtin_popcountll(b1) + ((uint32_t)__builtin_popcountll(b5) << 16);
+        }
         if (bp) {
             const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(bp >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bp, nsk));
             if (__builtin_amdgcn_inverse_ballot_w64(bp) && pos < HS_SCAP) { SurvRec r; r.w_ord = tot | ordsh[u]; r.hchr = hchr[u]; r.hloc = hloc[u]; r.hkey = 0; sv[pos] = r; }
@@ -2765,13 +2510,14 @@ __device__ __forceinline__ void hs_eval_read(const uint32_t (&flo)[HG_C][5], con
 // one group of K (1 .. HG_R) tasks: lane j < K holds task j's id, unit | slot and first list ordinal; they cover the n index entries
 // from `key` on with read offset `hh` (RRBS: and tag filter tag_xor / tag_want).  NWR: the reads' 32-nt words where the length class has
 // its own code (5: 129-160 nt, the headline configuration; 4: 97-128 nt; 3: 65-96 nt, RRBS), 0 for any length.
-template <int NWR, bool RRBS>
+template <int NWR, bool RRBS, bool STATS>
 __device__ __forceinline__ void hs_group(const AlignArgs &A, const HeavyArgs &H, SameLds &L, int lane, int wv, uint32_t K, uint32_t tid, uint32_t th, uint32_t tc0,
                                          uint32_t key, uint32_t n, uint32_t hh, uint32_t flags, uint32_t tag_xor, uint32_t tag_want)
 {
     const DevParams &P = A.P;
     uint32_t *uw = &L.W[wv].UW[0][0];
     const int nwr = NWR ? NWR : (int)((flags >> 8) & 15u);
+    u64 rowsig = 0;
     if ((uint32_t)lane < K) {   // the read of this lane's task -> its row
         const ListReq &R = H.state[th & 0x3fffffffu].req[th >> 30];
         uint32_t *row = uw + (uint32_t)lane * 20u;
@@ -2784,6 +2530,16 @@ __device__ __forceinline__ void hs_group(const AlignArgs &A, const HeavyArgs &H,
             if (j < nwr - 1) inner &= pm;
         }
         row[9] = R.thres | (inner == 0xFFFFFFFFu ? 0x10000u : 0u); row[16] = tid; row[17] = tc0;
+        u64 hsh = R.thres;
+#pragma unroll
+        for (int j = 0; j < 5; j++) { hsh = (hsh ^ R.px[j]) * 0x9E3779B97F4A7C15ull; hsh = (hsh ^ R.py[j]) * 0xBF58476D1CE4E5B9ull; hsh = (hsh ^ R.pm[j]) * 0x94D049BB133111EBull; hsh ^= hsh >> 29; }
+        rowsig = hsh;
+    }
+    // diagnostics: members of the group whose read words and threshold equal an earlier member's (they would yield the same survivors)
+    uint32_t n_dup = 0;
+    for (uint32_t j = 1; j < K; j++) {
+        const u64 sj = ((u64)rl_u((uint32_t)(rowsig >> 32), j) << 32) | rl_u((uint32_t)rowsig, j);
+        if (bsx_ballot((uint32_t)lane < j && rowsig == sj)) n_dup++;
     }
     wave_fence();
     const uint32_t strand = flags & 1u;
@@ -2849,13 +2605,13 @@ __device__ __forceinline__ void hs_group(const AlignArgs &A, const HeavyArgs &H,
             SurvRec *const sv = H.tout[rl_u(tid, k)].surv;   // (wave-uniform: the address arithmetic stays on the scalar unit)
             uint32_t nsk = rl_u(nsv, k), add15 = 0;
             if (full) {
-                if (plain) hs_eval_read<NWR, RRBS, NWR != 0, !RRBS>(flo, fhi, him, vm, ordsh, hchr, hloc, nwr, a0, a1, a2, a3, thr, sv, nsk, add15);
-                else hs_eval_read<NWR, RRBS, false, !RRBS>(flo, fhi, him, vm, ordsh, hchr, hloc, nwr, a0, a1, a2, a3, thr, sv, nsk, add15);
+                if (plain) hs_eval_read<NWR, RRBS, NWR != 0, !RRBS, STATS>(flo, fhi, him, vm, ordsh, hchr, hloc, nwr, a0, a1, a2, a3, thr, sv, nsk, add15);
+                else hs_eval_read<NWR, RRBS, false, !RRBS, STATS>(flo, fhi, him, vm, ordsh, hchr, hloc, nwr, a0, a1, a2, a3, thr, sv, nsk, add15);
             } else {
-                if (plain) hs_eval_read<NWR, RRBS, NWR != 0, false>(flo, fhi, him, vm, ordsh, hchr, hloc, nwr, a0, a1, a2, a3, thr, sv, nsk, add15);
-                else hs_eval_read<NWR, RRBS, false, false>(flo, fhi, him, vm, ordsh, hchr, hloc, nwr, a0, a1, a2, a3, thr, sv, nsk, add15);
+                if (plain) hs_eval_read<NWR, RRBS, NWR != 0, false, STATS>(flo, fhi, him, vm, ordsh, hchr, hloc, nwr, a0, a1, a2, a3, thr, sv, nsk, add15);
+                else hs_eval_read<NWR, RRBS, false, false, STATS>(flo, fhi, him, vm, ordsh, hchr, hloc, nwr, a0, a1, a2, a3, thr, sv, nsk, add15);
             }
-            if ((uint32_t)lane == k) { c15 += add15; nsv = nsk; }
+            if ((uint32_t)lane == k) { if (STATS) c15 += add15; nsv = nsk; }
         }
     }
     wave_fence();
@@ -2866,16 +2622,17 @@ __device__ __forceinline__ void hs_group(const AlignArgs &A, const HeavyArgs &H,
     const bool ov = ns > HS_SCAP;
     if (mine) {
         HTaskOut *o = &H.tout[tid];
-        o->count = ov ? 0 : ns; o->overflow = ov ? 1 : 0; o->acc[0] = n_cand; o->acc[1] = 2u * n_cand - n1 + 3u * n5; o->acc[2] = 0; o->acc[3] = 0; o->c0 = tc0; o->n = n;
+        o->count = ov ? 0 : ns; o->overflow = ov ? 1 : 0; o->acc[0] = n_cand; o->acc[1] = STATS ? 2u * n_cand - n1 + 3u * n5 : 0u; o->acc[2] = 0; o->acc[3] = 0; o->c0 = tc0; o->n = n;
     }
     const bool cnt = mine && !ov;
     const uint32_t kk = (uint32_t)__builtin_popcountll(bsx_ballot(cnt));
     const uint32_t s1 = wave_sum(cnt ? n1 : 0), s5 = wave_sum(cnt ? n5 : 0);
     if (lane == 0 && kk) {   // (sharded statistics: see hp_task)
         u64 *sh = (u64 *)A.scan_stats + (size_t)((blockIdx.x * (uint32_t)HG_WPB + (uint32_t)wv) & 63u) * 8;
-        atomicAdd((u64 *)&sh[0], (u64)kk * n_cand); atomicAdd((u64 *)&sh[1], 2ull * kk * n_cand - s1 + 3ull * s5); atomicAdd((u64 *)&sh[2], (u64)s1); atomicAdd((u64 *)&sh[3], (u64)s5);
+        atomicAdd((u64 *)&sh[0], (u64)kk * n_cand);
+        if (STATS) { atomicAdd((u64 *)&sh[1], 2ull * kk * n_cand - s1 + 3ull * s5); atomicAdd((u64 *)&sh[2], (u64)s1); atomicAdd((u64 *)&sh[3], (u64)s5); }
         if (K > 1) atomicAdd((u64 *)&sh[4], (u64)kk * n_cand);   // counter 15: candidates evaluated in groups of two reads and more
-        atomicAdd((u64 *)&sh[5], (u64)kk * n_cand * K); if (K >= 4) atomicAdd((u64 *)&sh[6], (u64)kk * n_cand); if (K >= 8) atomicAdd((u64 *)&sh[7], (u64)kk * n_cand);  // diagnostics (BSX_SIGHIST)
+        atomicAdd((u64 *)&sh[5], (u64)kk * n_cand * K); if (K >= 4) atomicAdd((u64 *)&sh[6], (u64)kk * n_cand); if (n_dup) atomicAdd((u64 *)&sh[7], (u64)n_dup * n_cand);  // diagnostics (BSX_SIGHIST)
     }
     wave_fence();
 }
@@ -2884,6 +2641,7 @@ __device__ __forceinline__ void hs_group(const AlignArgs &A, const HeavyArgs &H,
 // H.ghead[slot] the size of the group that starts at scan slot `slot` and H.glist the slots at which groups start (their number in
 // H.glist[task_cap]).  One group per wave, as k_hscan takes one task per wave: the waves of a pass retire one by one, every
 // launched wave has work, and consecutive waves walk the groups of one window at the same time.
+template <bool STATS>
 __global__ __launch_bounds__(64 * HG_WPB, BSX_HSAME_WAVES) void k_hscan_same(AlignArgs A, HeavyArgs H)
 {
     __shared__ SameLds L;
@@ -2911,15 +2669,15 @@ __global__ __launch_bounds__(64 * HG_WPB, BSX_HSAME_WAVES) void k_hscan_same(Ali
         if (n0 == 0) {   // slots neutralised by a refused request: their units have not published a list
             if ((uint32_t)lane < K) { HTaskOut *o = &H.tout[tid]; o->count = 0; o->overflow = 0; o->acc[0] = o->acc[1] = o->acc[2] = o->acc[3] = 0; o->c0 = 0; o->n = 0; }
         } else if (f0 & 4u) {   // RRBS (hp_task takes WGBS lists only); reads of 65-96 nt have their own code
-            if (((f0 >> 8) & 15u) == 3u) hs_group<3, true>(A, H, L, lane, wv, K, tid, th, tc0, rfl(key), n0, rfl(hh), f0, rfl(tx), rfl(tw));
-            else hs_group<0, true>(A, H, L, lane, wv, K, tid, th, tc0, rfl(key), n0, rfl(hh), f0, rfl(tx), rfl(tw));
+            if (((f0 >> 8) & 15u) == 3u) hs_group<3, true, STATS>(A, H, L, lane, wv, K, tid, th, tc0, rfl(key), n0, rfl(hh), f0, rfl(tx), rfl(tw));
+            else hs_group<0, true, STATS>(A, H, L, lane, wv, K, tid, th, tc0, rfl(key), n0, rfl(hh), f0, rfl(tx), rfl(tw));
         }
         else if (K > 1) {
-            if (((f0 >> 8) & 15u) == 5u) hs_group<5, false>(A, H, L, lane, wv, K, tid, th, tc0, rfl(key), n0, rfl(hh), f0, 0u, 0u);
-            else if (((f0 >> 8) & 15u) == 4u) hs_group<4, false>(A, H, L, lane, wv, K, tid, th, tc0, rfl(key), n0, rfl(hh), f0, 0u, 0u);   // 97-128 nt (C2: 100 nt single-end)
-            else hs_group<0, false>(A, H, L, lane, wv, K, tid, th, tc0, rfl(key), n0, rfl(hh), f0, 0u, 0u);
+            if (((f0 >> 8) & 15u) == 5u) hs_group<5, false, STATS>(A, H, L, lane, wv, K, tid, th, tc0, rfl(key), n0, rfl(hh), f0, 0u, 0u);
+            else if (((f0 >> 8) & 15u) == 4u) hs_group<4, false, STATS>(A, H, L, lane, wv, K, tid, th, tc0, rfl(key), n0, rfl(hh), f0, 0u, 0u);   // 97-128 nt (C2: 100 nt single-end)
+            else hs_group<0, false, STATS>(A, H, L, lane, wv, K, tid, th, tc0, rfl(key), n0, rfl(hh), f0, 0u, 0u);
         }
-        else hp_task(A, H, rfl(tid), lane, L.W[wv].one.TAB, L.W[wv].one.PT, L.W[wv].one.Q);
+        else hp_task<STATS>(A, H, rfl(tid), lane, L.W[wv].one.TAB, L.W[wv].one.PT, L.W[wv].one.Q);
         wave_fence();
     }
 }
@@ -3016,6 +2774,7 @@ __device__ __forceinline__ SharedChunk shared_load(const U2 *__restrict__ ent2, 
     return c;
 }
 
+template <bool STATS>
 __global__ __launch_bounds__(256, BSX_HSHARED_WAVES) void k_hscan_shared(AlignArgs A, HeavyArgs H)
 {
     __shared__ __attribute__((aligned(16))) uint32_t UW[4][HS_SHARE][20];   // per read of the run: X0 Y0 M0 X1 | Y1 M1 X2 Y2 | M2 threshold X3 Y3 | M3 X4 Y4 M4 | task id
@@ -3103,11 +2862,11 @@ __global__ __launch_bounds__(256, BSX_HSHARED_WAVES) void k_hscan_shared(AlignAr
                 const uint32_t thr = a2.y;
                 const uint32_t m0 = bsx_plane_mismatch(flo[0], fhi[0], a0.x, a0.y, a0.z);
                 const uint32_t c0 = __popc(m0);
-                const uint32_t w0ref = __popc(m0 & him);
+                const uint32_t w0ref = STATS ? __popc(m0 & him) : 0u;
                 uint32_t tot = c0, w01ref = c0;
                 if (nwr > 1) {
                     const uint32_t m1 = bsx_plane_mismatch(flo[1], fhi[1], a0.w, a1.x, a1.y);
-                    tot = popc_acc(m1, c0); w01ref = popc_acc(m1 & him, c0);
+                    tot = popc_acc(m1, c0); if (STATS) w01ref = popc_acc(m1 & him, c0);
                     // (the words behind the first 64 nt only matter for candidates still within the threshold there: where no lane of the
                     //  chunk is, they are skipped — both early-out classes and the survivors are settled)
                     if (nwr > 2 && (bsx_ballot(tot <= thr) & vm)) {
@@ -3118,10 +2877,12 @@ __global__ __launch_bounds__(256, BSX_HSHARED_WAVES) void k_hscan_shared(AlignAr
                         }
                     }
                 }
-                const u64 b1 = bsx_ballot(w0ref > thr) & vm, b5 = bsx_ballot(w01ref <= thr) & vm, bp = bsx_ballot(tot <= thr) & vm;
-                // lane k keeps read k's counters: candidates beyond the first word | five-word candidates << 16, survivors
-                const uint32_t add15 = (uint32_t)__builtin_popcountll(b1) | ((uint32_t)__builtin_popcountll(b5) << 16);
-                if ((uint32_t)lane == k) c15 += add15;
+                const u64 bp = bsx_ballot(tot <= thr) & vm;
+                if (STATS) {   // lane k keeps read k's counters: candidates beyond the first word | five-word candidates << 16 (work counters only)
+                    const u64 b1 = bsx_ballot(w0ref > thr) & vm, b5 = bsx_ballot(w01ref <= thr) & vm;
+                    const uint32_t add15 = (uint32_t)__builtin_popcountll(b1) | ((uint32_t)__builtin_popcountll(b5) << 16);
+                    if ((uint32_t)lane == k) c15 += add15;
+                }
                 if (bp) {
                     const uint32_t base = rl_u(nsv, k);
                     const uint32_t pos = base + (uint32_t)__builtin_popcountll(bp & lanemask_lt(lane));
@@ -3143,13 +2904,14 @@ __global__ __launch_bounds__(256, BSX_HSHARED_WAVES) void k_hscan_shared(AlignAr
             const bool ov = ns > HS_SCAP;
             if (mine) {
                 HTaskOut *o = &H.tout[UW[wv][lane][16]];
-                o->count = ov ? 0 : ns; o->overflow = ov ? 1 : 0; o->acc[0] = n_cand; o->acc[1] = 2u * n_cand - n1 + 3u * n5; o->acc[2] = 0; o->acc[3] = 0; o->c0 = my_c0; o->n = n;
+                o->count = ov ? 0 : ns; o->overflow = ov ? 1 : 0; o->acc[0] = n_cand; o->acc[1] = STATS ? 2u * n_cand - n1 + 3u * n5 : 0u; o->acc[2] = 0; o->acc[3] = 0; o->c0 = my_c0; o->n = n;
             }
             // work of the scan kernel (incl. speculation); an overflowed task is redone by the control kernel
             const bool cnt = mine && !ov;
             const uint32_t kk = (uint32_t)__builtin_popcountll(bsx_ballot(cnt));
             const uint32_t s1 = wave_sum(cnt ? n1 : 0), s5 = wave_sum(cnt ? n5 : 0);
-            st_cand += (u64)kk * n_cand; st_n1 += s1; st_n5 += s5; st_words += 2ull * kk * n_cand - s1 + 3ull * s5;
+            st_cand += (u64)kk * n_cand;
+            if (STATS) { st_n1 += s1; st_n5 += s5; st_words += 2ull * kk * n_cand - s1 + 3ull * s5; }
         }
         wave_fence();
         i0 += K;
@@ -3211,15 +2973,9 @@ void bsx_launch_hscan_shared(const AlignArgs &A, const HeavyArgsRaw &R, hipStrea
 {
     const HeavyArgs H = typed(R);
     const uint32_t jobs = ((max_tasks ? std::min(max_tasks, R.task_cap) : R.task_cap) + HS_SHARE - 1) / HS_SHARE;
-    hipLaunchKernelGGL(k_hscan_shared, dim3(((jobs + 3) / 4 + 7u) & ~7u), dim3(256), 0, stream, A, H);   // (a multiple of 8: order_block)
-}
-
-void bsx_launch_hscan_multi(const AlignArgs &A, const HeavyArgsRaw &R, hipStream_t stream, uint32_t max_tasks)
-{
-    const HeavyArgs H = typed(R);
-    uint32_t blocks = ((max_tasks ? std::min(max_tasks, R.task_cap) : R.task_cap) + HM_TASKS - 1) / HM_TASKS;
-    blocks = (blocks + 7u) & ~7u;  // the same number of blocks for each of the 8 XCDs (the sweep relies on a multiple of 8)
-    hipLaunchKernelGGL(k_hscan_multi, dim3(blocks), dim3(64 * HM_WAVES), 0, stream, A, H);
+    // (a multiple of 8: order_block)
+    if (A.work_counters) hipLaunchKernelGGL(k_hscan_shared<true>, dim3(((jobs + 3) / 4 + 7u) & ~7u), dim3(256), 0, stream, A, H);
+    else hipLaunchKernelGGL(k_hscan_shared<false>, dim3(((jobs + 3) / 4 + 7u) & ~7u), dim3(256), 0, stream, A, H);
 }
 
 void bsx_launch_hscan_same(const AlignArgs &A, const HeavyArgsRaw &R, hipStream_t stream, uint32_t max_tasks)
@@ -3231,7 +2987,8 @@ void bsx_launch_hscan_same(const AlignArgs &A, const HeavyArgsRaw &R, hipStream_
     static const uint32_t grid_div = getenv("BSX_SAME_GRID_DIV") ? (uint32_t)std::max(1, atoi(getenv("BSX_SAME_GRID_DIV"))) : 4u;
     uint32_t blocks = ((max_tasks ? std::min(max_tasks, R.task_cap) : R.task_cap / grid_div) + HG_WPB - 1) / HG_WPB;
     blocks = (blocks + 7u) & ~7u;  // the same number of blocks for each of the 8 XCDs (the sweep relies on a multiple of 8)
-    hipLaunchKernelGGL(k_hscan_same, dim3(blocks), dim3(64 * HG_WPB), 0, stream, A, H);
+    if (A.work_counters) hipLaunchKernelGGL(k_hscan_same<true>, dim3(blocks), dim3(64 * HG_WPB), 0, stream, A, H);
+    else hipLaunchKernelGGL(k_hscan_same<false>, dim3(blocks), dim3(64 * HG_WPB), 0, stream, A, H);
 }
 
 void bsx_launch_hscan(const AlignArgs &A, const HeavyArgsRaw &R, hipStream_t stream, uint32_t max_tasks)
@@ -3239,7 +2996,8 @@ void bsx_launch_hscan(const AlignArgs &A, const HeavyArgsRaw &R, hipStream_t str
     const HeavyArgs H = typed(R);
     uint32_t blocks = ((max_tasks ? std::min(max_tasks, R.task_cap) : R.task_cap) + BSX_HSCAN_WPB - 1) / BSX_HSCAN_WPB;
     blocks = (blocks + 7u) & ~7u;  // the same number of blocks for each of the 8 XCDs (k_hscan's sweep relies on a multiple of 8)
-    hipLaunchKernelGGL(k_hscan, dim3(blocks), dim3(64 * BSX_HSCAN_WPB), 0, stream, A, H);
+    if (A.work_counters) hipLaunchKernelGGL(k_hscan<true>, dim3(blocks), dim3(64 * BSX_HSCAN_WPB), 0, stream, A, H);
+    else hipLaunchKernelGGL(k_hscan<false>, dim3(blocks), dim3(64 * BSX_HSCAN_WPB), 0, stream, A, H);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

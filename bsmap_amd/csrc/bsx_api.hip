@@ -223,7 +223,7 @@ void bsx_fill_devparams(const bsx_ref *r, DevParams &d)
 #define BSX_POLL_SLOTS 4
 struct bsx_batch {
     bsx_ref *ref = nullptr;
-    int paired = 0, debug = 0, has_qual = 0, leak_exact = 0;
+    int paired = 0, debug = 0, has_qual = 0, leak_exact = 0, work_counters = 1;
     uint32_t n_hist = 0;
     uint8_t *d_hist_seq[2] = {nullptr, nullptr}, *d_hist_qual[2] = {nullptr, nullptr};
     uint64_t *d_hist_off[2] = {nullptr, nullptr};
@@ -345,6 +345,28 @@ static uint64_t pool_bytes_for(const bsx_params &P, int paired, uint32_t hcap, u
     return (uint64_t)hcap * (bsx_hstate_bytes() + hslab_bytes + 8) + (uint64_t)task_cap * (bsx_htask_bytes() + bsx_htaskout_bytes()) +
            (uint64_t)n_groups * ((uint64_t)n_bins * 8 + (uint64_t)bsx_bin_chunks(n_bins) * 4 + tcap * 12 + 16);
 }
+// starting sizes of the heavy pipeline's pools for runs of `units` units (bsx_set_heavy_limits replaces them)
+static void default_pools(const bsx_params &P, uint64_t hslab, uint32_t units, uint32_t &hcap, uint32_t &task_cap)
+{
+    // Round 5: the pools follow the batch beyond 2^21 units.  The tasks of one window AND read offset that a pass holds are what k_hscan_same
+    // evaluates as a group, and their number grows with the deferred units of the pass: C3 at 2^22 pairs per batch with one round of 40 K units
+    // and 2 M tasks 27.0 M reads/s, with the 2^20-pair pools (two rounds of 19 K) 25.4 M, at 2^20 pairs per batch 24.3 M (profiles/r05d).
+    // WGBS: one deferred unit per 100 units (C3 defers 0.9 %), up to 64 GB of slabs; tasks: half a task per unit, up to 2^22.
+    const uint64_t slab_budget = P.rrbs ? (40ull << 30) : (26ull << 30);
+    uint64_t hc = std::min<uint64_t>(262144, std::max<uint64_t>(24576, slab_budget / hslab));
+    if (!P.rrbs) hc = std::max<uint64_t>(hc, std::min<uint64_t>((uint64_t)units / 100, (64ull << 30) / hslab));
+    hcap = (uint32_t)std::min<uint64_t>(units, hc);
+    uint32_t task_default = P.rrbs ? 2u * 1048576u : 1048576u;
+    if (!P.rrbs) task_default = (uint32_t)std::min<uint64_t>(1ull << 22, std::max<uint64_t>(task_default, (uint64_t)units / 2));
+    task_cap = std::min<uint32_t>(task_default, std::max<uint32_t>(4096u, 64u * hcap));
+}
+extern "C" int bsx_default_heavy_limits(const bsx_params *p, uint32_t units, int paired, uint32_t *units_per_round, uint32_t *task_pool)
+{
+    if (!p || !units || !units_per_round || !task_pool) return BSX_ERR_ARG;
+    default_pools(*p, slab_size(*p, paired ? 1 : 0, BSX_ROWCAP, true), units, *units_per_round, *task_pool);
+    return BSX_OK;
+}
+
 static BatchPlan plan_batch(const bsx_params &P, int paired, uint32_t max_units, uint64_t n_entries, int n_cu, int blocks_per_cu, int n_groups, bool debug)
 {
     BatchPlan pl;
@@ -364,11 +386,8 @@ static BatchPlan plan_batch(const bsx_params &P, int paired, uint32_t max_units,
     // of slabs (170 K units) and 2 M tasks: C4 195 -> 159 ms per step.  Task records (8 KB each): 1 M for WGBS (C5 358 -> 328 ms against
     // 512 K: fewer requests refused), following the batch size for small batches.  bsx_set_heavy_limits replaces the STARTING sizes;
     // either way the pools are halved until they fit (ensure_scratch).
-    const uint64_t slab_budget = P.rrbs ? (40ull << 30) : (26ull << 30);
-    pl.hcap = g_user_limits ? g_hcap : (uint32_t)std::min<uint64_t>(262144, std::max<uint64_t>(g_hcap, slab_budget / hslab));
-    pl.hcap = std::min<uint32_t>(max_units, pl.hcap);
-    const uint32_t task_default = P.rrbs ? 2u * g_task_cap : g_task_cap;
-    pl.task_cap = g_user_limits ? g_task_cap : std::min<uint32_t>(task_default, std::max<uint32_t>(4096u, 64u * pl.hcap));
+    if (g_user_limits) { pl.hcap = std::min<uint32_t>(max_units, g_hcap); pl.task_cap = g_task_cap; }
+    else default_pools(P, hslab, max_units, pl.hcap, pl.task_cap);
     // scan order of a pass: bins of 2^shift index entries, at most 2^20 of them (bsx_launch_task_order)
     // (WGBS: 2^21 — the tasks of one window are dealt over the bins it covers by read offset, for k_hscan_same: 8 bins of 1 024 entries per window at hg38 size)
     const uint64_t ne = std::max<uint64_t>(1, n_entries);
@@ -517,6 +536,7 @@ extern "C" int bsx_batch_create(bsx_ref *r, uint32_t max_units, int paired, bsx_
     if (const char *e = getenv("BSX_XCD_MAP")) b->xcd_map = (uint32_t)std::max(0, atoi(e));   // how k_hscan's blocks map onto the scan order: 0 as dispatched, 1 one contiguous eighth per XCD, N >= 2 pieces of N blocks dealt to the XCDs in turn
     if (const char *e = getenv("BSX_HEAVY_CHUNK")) b->chunk_passes = std::max(1, std::min(64, atoi(e)));
     b->trace = getenv("BSX_TRACE_HEAVY") != nullptr;
+    if (const char *e = getenv("BSX_WORK_COUNTERS")) b->work_counters = atoi(e) != 0;   // the default of bsx_batch_set_work_counters (test hook)
     b->sig_hist = getenv("BSX_SIGHIST") != nullptr;
     if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) return fail(BSX_ERR_DEVICE);
     {
@@ -639,6 +659,13 @@ extern "C" int bsx_batch_upload_pe(bsx_batch *b, uint32_t n, const char *seqs_a,
     if (rc) return rc;
     b->n_units = n; b->first_index = first_index; b->has_qual = quals_a != nullptr; b->leak_meta_valid = false;
     HIP_TRY(stream_wait(b));
+    return BSX_OK;
+}
+
+extern "C" int bsx_batch_set_work_counters(bsx_batch *b, int on)
+{
+    if (!b) return BSX_ERR_ARG;
+    b->work_counters = on ? 1 : 0;
     return BSX_OK;
 }
 
@@ -772,7 +799,7 @@ extern "C" int bsx_batch_run_range(bsx_batch *b, uint32_t first_unit, uint32_t n
     A.first_unit = first_unit;
     for (int m = 0; m < 2; m++) { A.seq[m] = b->d_seq[m]; A.off[m] = b->d_off[m]; A.qual[m] = b->has_qual ? b->d_qual[m] : nullptr; A.cc[m] = b->d_cc[m]; }
     A.hits_out = b->d_hits; A.pairs_out = b->d_pairs; A.npairs_out = b->d_npairs;
-    A.scratch = b->d_scratch; A.slab_bytes = b->slab_bytes; A.queue = b->d_queue; A.counters = b->d_counters; A.scan_stats = b->d_scan_stats; A.dbg_plan = b->d_dbg; A.dbg_cycles = b->d_cycles; A.dbg_cat = b->d_cycles ? b->d_counters + 16 : nullptr;
+    A.scratch = b->d_scratch; A.slab_bytes = b->slab_bytes; A.queue = b->d_queue; A.counters = b->d_counters; A.scan_stats = b->d_scan_stats; A.work_counters = (uint32_t)b->work_counters; A.dbg_plan = b->d_dbg; A.dbg_cycles = b->d_cycles; A.dbg_cat = b->d_cycles ? b->d_counters + 16 : nullptr;
     A.heavy_list = b->d_heavy_list; A.heavy_count = b->d_heavy_count;
     A.leak_exact = b->leak_exact; A.n_hist = b->leak_exact ? b->n_hist : 0; A.n_units_all = b->n_units;
     for (int m = 0; m < 2; m++) { A.hist_seq[m] = b->d_hist_seq[m]; A.hist_off[m] = b->d_hist_off[m]; A.hist_qual[m] = b->d_hist_qual[m]; }
@@ -809,21 +836,20 @@ extern "C" int bsx_batch_run_range(bsx_batch *b, uint32_t first_unit, uint32_t n
         // beyond that point find nothing to do.  While k_hscan evaluates the tasks of one group, the control kernels of the others
         // run beside it — they are latency-bound chains of a few thousand waves.
         const bool shared_scan = b->ref->P.rrbs != 0;  // RRBS: runs of tasks over one window, scanned together
-        // WGBS, BSX_MULTI=1: runs of tasks over one window share the fetch of the candidates' reference (k_hscan_multi).  Measured and NOT the default:
-        // 98 % of the candidates run that way and the texture path falls from 0.72 to 0.12 busy, but the kernel spends 53 instead of 42 vector
-        // instructions per 64 candidates and its waves wait at two barriers per round: 356 against 491 G candidates/s (profiles/r04g_*)
-        const bool multi_scan = !shared_scan && getenv("BSX_MULTI") && atoi(getenv("BSX_MULTI")) == 1;
         // WGBS: the tasks of one window AND read offset share fetch and shift (k_hscan_same); BSX_SAME=0: one task per wave (k_hscan)
         // RRBS lists go through the same kernel with BSX_SAME=2 (scan 75.9 against 90.5 ms per step; the step does not move — 142.2 against 141.0 ms —, it
         // waits for the control passes there: k_hscan_shared stays the default for RRBS)
         const int same_env = getenv("BSX_SAME") ? atoi(getenv("BSX_SAME")) : 1;
-        const bool same_scan = !multi_scan && (shared_scan ? same_env == 2 : same_env != 0);
+        const bool same_scan = shared_scan ? same_env == 2 : same_env != 0;
         const uint32_t spread = getenv("BSX_SPREAD") ? (uint32_t)atoi(getenv("BSX_SPREAD")) : (same_scan ? 1u : 0u);
         const int n_groups = b->n_groups;
         struct Group { uint32_t n0 = 0, passes = 0, polls = 0, polled = 0; int cur = 0; bool done = true, tail = false; HeavyArgsRaw H; uint32_t *blk[2]; };
         volatile uint32_t *pinned = (volatile uint32_t *)b->h_pinned;
-        for (uint32_t base = 0; base < n_heavy; base += b->hcap) {
-            const uint32_t n_round = std::min(b->hcap, n_heavy - base);
+        // (rounds of equal size: the reads of one window and offset that a pass holds are what k_hscan_same groups — a full round followed by
+        //  a short one would scan the short one's candidates in small groups)
+        const uint32_t n_rounds = (n_heavy + b->hcap - 1) / b->hcap, per_round = n_rounds ? (n_heavy + n_rounds - 1) / n_rounds : 0;
+        for (uint32_t base = 0; base < n_heavy; base += per_round) {
+            const uint32_t n_round = std::min(per_round, n_heavy - base);
             Group G[BSX_MAX_GROUPS];
             HIP_TRY(hipEventRecord(b->ev_sync, b->stream));             // everything queued so far (k_align, earlier rounds)
             auto enqueue_pass = [&](int g) -> int {
@@ -865,8 +891,6 @@ extern "C" int bsx_batch_run_range(bsx_batch *b, uint32_t first_unit, uint32_t n
                 HIP_TRY(hipEventRecord(b->scan_ev[b->scan_ev_used], s_scan));
                 if (same_scan) bsx_launch_hscan_same(A, q.H, s_scan, q.tail ? b->tail_grid_tasks : 0);
                 else if (shared_scan) bsx_launch_hscan_shared(A, q.H, s_scan, q.tail ? b->tail_grid_tasks : 0);
-                else if (same_scan) bsx_launch_hscan_same(A, q.H, s_scan, q.tail ? b->tail_grid_tasks : 0);
-                else if (multi_scan) bsx_launch_hscan_multi(A, q.H, s_scan, q.tail ? b->tail_grid_tasks : 0);
                 else bsx_launch_hscan(A, q.H, s_scan, q.tail ? b->tail_grid_tasks : 0);
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipEventRecord(b->scan_ev[b->scan_ev_used + 1], s_scan));
@@ -1019,7 +1043,7 @@ extern "C" int bsx_batch_counters(bsx_batch *b, uint64_t c[BSX_N_COUNTERS])
     uint64_t dg[3] = {0, 0, 0};
     for (int i = 0; i < 64; i++) { for (int k = 0; k < 4; k++) c[7 + k] += sh[i * 8 + k]; c[15] += sh[i * 8 + 4]; for (int k = 0; k < 3; k++) dg[k] += sh[i * 8 + 5 + k]; }
     if (b->sig_hist && c[15])
-        fprintf(stderr, "[sighist] scan kernel: %.4f of the candidates in groups, mean group %.2f reads, in groups of >= 4 %.4f, >= 8 %.4f\n", (double)c[15] / (double)std::max<uint64_t>(1, c[7]),
+        fprintf(stderr, "[sighist] scan kernel: %.4f of the candidates in groups, mean group %.2f reads, in groups of >= 4 %.4f; evaluations of a read whose words and threshold equal an earlier member's of its group: %.4f of all\n", (double)c[15] / (double)std::max<uint64_t>(1, c[7]),
                 (double)dg[0] / (double)c[15], (double)dg[1] / (double)c[7], (double)dg[2] / (double)c[7]);
     return BSX_OK;
 }

@@ -22,6 +22,9 @@ struct AlignArgs {
     uint16_t *npairs_out;      // [n_units][32], may be null
     uint8_t *scratch;
     uint64_t slab_bytes;
+    uint32_t work_counters;    // 1: the scan kernels also classify every candidate by the reference's two early-outs (align.h:189-197) so that counters 1-2 and 7-10
+                               //    equal the work the reference would do (the parity suite compares them with the oracle's); 0: hits only — n_cand / sum_w are
+                               //    then incomplete (bsx_batch_set_work_counters)
     uint32_t heavy_threshold;  // candidate-list length from which a unit is deferred to the heavy pipeline (0 = never)
     uint32_t *heavy_list;      // [n_units] unit ids deferred by the main kernel
     uint32_t *heavy_count;
@@ -68,7 +71,6 @@ size_t bsx_leakstate_bytes(void);
 uint32_t bsx_leak_blk(void);
 void bsx_launch_hctrl(const AlignArgs &A, const HeavyArgsRaw &H, int paired, int grid_blocks, hipStream_t stream);
 void bsx_launch_hscan(const AlignArgs &A, const HeavyArgsRaw &H, hipStream_t stream, uint32_t max_tasks = 0);         // grid sized for H.task_cap (or max_tasks: the blocks sweep); the count stays on the device
-void bsx_launch_hscan_multi(const AlignArgs &A, const HeavyArgsRaw &H, hipStream_t stream, uint32_t max_tasks = 0);   // WGBS: runs of tasks over one window, four waves x four reads per block
 void bsx_launch_hscan_same(const AlignArgs &A, const HeavyArgsRaw &H, hipStream_t stream, uint32_t max_tasks = 0);    // WGBS: tasks of one window and read offset share fetch and shift
 void bsx_launch_hscan_shared(const AlignArgs &A, const HeavyArgsRaw &H, hipStream_t stream, uint32_t max_tasks = 0);  // RRBS: up to 16 tasks of one window per wave
 // scan order of a pass (task ids by the index entry they start at, 2^shift entries per bin), computed on the device

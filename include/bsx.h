@@ -207,6 +207,13 @@ int bsx_batch_scan_ms(bsx_batch *b, float *total_ms, uint32_t *launches);
 int bsx_batch_results_se(bsx_batch *b, bsx_hit *out, bsx_class_counts *counts /* may be NULL */);
 int bsx_batch_results_pe(bsx_batch *b, bsx_pair *out, bsx_class_counts *counts_a, bsx_class_counts *counts_b, uint16_t *n_pairs31);
 int bsx_batch_counters(bsx_batch *b, uint64_t c[BSX_N_COUNTERS]);   /* accumulated since creation / last reset */
+/* Work counters (on by default).  Counters 1-2 and 7-10 count the work the REFERENCE would do on the same reads — candidates, and the
+ * 64-bit reference words CountMismatch would touch given its two early-outs (align.h:189-197); SURVEY §8(d)'s algorithmic-byte formula is
+ * evaluated with them and the parity suite compares them with the oracle's.  Classifying every candidate of the heavy pipeline's scan by
+ * those early-outs is a quarter of the scan kernel's vector instructions and changes no hit: with the counters off the scan kernels skip
+ * it (and the control kernel its count-only walks) — every record is identical, counters 0-3 and 7-15 are then incomplete, 4-6 (aligned
+ * reads / pairs) stay exact.  The command line runs with them off; bench.py times both and says which is which. */
+int bsx_batch_set_work_counters(bsx_batch *b, int on);
 int bsx_batch_reset_counters(bsx_batch *b);
 /* download the device-resident input reads (for the CPU baseline on device-synthesised input) */
 int bsx_batch_download_reads(bsx_batch *b, int mate, char *seqs, uint64_t *off);
@@ -232,6 +239,10 @@ int bsx_set_heavy_limits(uint32_t units_per_round, uint32_t task_pool);
  * by default room for one more batch like itself (per-wave slabs + per-unit arrays) plus 4 GB; bsx_set_pool_reserve(bytes) sets the
  * reserve for batches created afterwards (0 = that default).  bsx_batch_pool_sizes returns what a batch ended up with. */
 int bsx_set_pool_reserve(uint64_t bytes);
+/* the library's own starting sizes for runs of `units` units (a caller whose batches HOLD more units than a run covers — bench.py keeps a ring of
+ * steps resident and runs one step at a time with bsx_batch_run_range — passes these to bsx_set_heavy_limits: a batch sizes its pools for the
+ * units it was created for) */
+int bsx_default_heavy_limits(const bsx_params *p, uint32_t units, int paired, uint32_t *units_per_round, uint32_t *task_pool);
 int bsx_batch_pool_sizes(const bsx_batch *b, uint32_t *units_per_round, uint32_t *task_pool);
 /* Device bytes a batch of `max_units` will allocate, computed on the host (no device needed): out3 = {per-unit arrays (reads, offsets,
  * records), the main kernel's per-wave slabs for a grid of n_cu x blocks_per_cu blocks, work pools at their starting size}.

@@ -47,11 +47,12 @@ def test_other_configs_runs_every_other_mode_in_a_child(monkeypatch):
             return types.SimpleNamespace(stdout="no json here\n", stderr="x" * 500 + "hipMalloc -> out of memory", returncode=1)
         if mode == "trim" and "--in-flight" not in cmd:
             return types.SimpleNamespace(stdout="", stderr="first attempt died", returncode=-9)
-        line = {"value": 1e6, "ms_per_step": 100.0, "steps": 6, "config": {"workload": "w", "batches_in_flight": 2, "aligned_fraction": 1.0},
+        line = {"value": 1e6, "ms_per_step": 100.0, "steps": 6, "config": {"workload": "w", "batches_in_flight": 2, "aligned_fraction": 1.0, "pairs_per_step": 1 << 21},
                 "roofline": {"per_read": {"n_cand": 5.0}, "dominant_kernel": {"name": "k", "ms_per_step": 1.0, "candidates_per_s": 2.0}}}
         return types.SimpleNamespace(stdout="noise\n" + json.dumps(line) + "\n", stderr="", returncode=0)
     monkeypatch.setattr(subprocess, "run", fake_run)
-    res = BN.other_configs(types.SimpleNamespace(genome="hg38", pairs_per_step=1 << 20))
+    res = BN.other_configs(types.SimpleNamespace(genome="hg38", pairs_per_step=1 << 20, units_given=False))
+    assert all("--pairs-per-step" not in c for c in calls) and res["C2"]["ms_per_2^20_units"] == 50.0
     # one child per mode; a failing child is tried once more with two batches in flight
     assert [c[c.index("--mode") + 1] for c in calls] == ["se", "rrbs", "rrbs", "trim", "trim"]
     for c in calls:

@@ -133,6 +133,23 @@ def test_idempotent_and_partition_invariant(big):
     assert out3.tobytes() == out.tobytes() and cb3.tobytes() == cb.tobytes()
 
 
+def test_records_do_not_depend_on_the_work_counters(big):
+    """with the work counters off (bsx_batch_set_work_counters: the scan kernels skip the early-out classification, the control kernel its
+    count-only walks — what the command line and bench.py's timed region run) every record is byte-identical and the aligned counts agree"""
+    ref, pa, out, ca, cb, npairs, cnt = big
+    pa.set_work_counters(False)
+    try:
+        pa.reset_counters()
+        pa.Do_Batch()
+        out2, ca2, cb2, np2 = pa.results()
+        c2 = pa.counters()
+    finally:
+        pa.set_work_counters(True)
+    assert out2.tobytes() == out.tobytes() and ca2.tobytes() == ca.tobytes() and cb2.tobytes() == cb.tobytes() and np2.tobytes() == npairs.tobytes()
+    assert np.array_equal(c2[4:7], cnt[4:7]) and int(c2[2]) < int(cnt[2])   # (sum_w is what is no longer counted)
+    assert pa.heavy_units() == HEAVY["c3"]
+
+
 def test_heavy_path_invariance(big):
     ref, pa, out, ca, cb, npairs, cnt = big
     # 4096 units through the one-wave path only (threshold so high that nothing is deferred)
@@ -247,6 +264,15 @@ def test_other_configs_closure_idempotence_partition(other):
     al.run_range(0, n // 2, sync=True)
     for a, b in zip(res, al.results()):
         assert a.tobytes() == b.tobytes()
+    al.set_work_counters(False)   # (what the command line runs: records must not depend on the counters)
+    try:
+        al.reset_counters()
+        al.Do_Batch()
+        for a, b in zip(res, al.results()):
+            assert a.tobytes() == b.tobytes()
+        assert np.array_equal(al.counters()[4:7], cnt[4:7])
+    finally:
+        al.set_work_counters(True)
     if cfg["pe"]:
         out = res[0]
         placed = (out["unpaired_out"] == 0).mean()

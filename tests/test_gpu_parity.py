@@ -3,6 +3,8 @@
 Bar: bit-exact — packed reference words, block list, every index bucket, the planner state, every hit list, every
 pair list, the chosen hit / pair, and the work counters that feed the roofline numerator.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -13,6 +15,11 @@ import golden_util as G
 pytestmark = pytest.mark.gpu
 
 ADAPTER = "AGATCGGAAGAGC"
+
+
+def _counters_off():
+    """BSX_WORK_COUNTERS=0: batches are created with the work counters off (include/bsx.h) — records are compared, the counters are not"""
+    return os.environ.get("BSX_WORK_COUNTERS") == "0"
 
 
 def _leaky(length, kw):
@@ -204,7 +211,7 @@ def test_edge_cases_vs_oracle(name, kw, spec, edge_genome, oracle):
         for f in ("chr", "loc", "best_class"):
             assert np.array_equal(ores[f][has], hits[f][has]), f
         assert np.array_equal(ores["chain"][has], (hits["flags"][has] >> 1) & 1)
-        assert [int(x) for x in sa.counters()[:4]] == ocnt
+        assert _counters_off() or [int(x) for x in sa.counters()[:4]] == ocnt
         assert has.sum() > spec.get("min_frac", 0.2) * len(reads)
         sa.close()
     else:
@@ -234,7 +241,7 @@ def test_edge_cases_vs_oracle(name, kw, spec, edge_genome, oracle):
             sel = up & ok & (ores[m]["n_best"] > 0)
             for f in ("chr", "loc", "best_class"):
                 assert np.array_equal(ores[m][f][sel], out[m][f][sel]), (m, f)
-        assert [int(x) for x in pa.counters()[:4]] == ocnt
+        assert _counters_off() or [int(x) for x in pa.counters()[:4]] == ocnt
         assert pr.sum() > spec.get("min_frac", 0.2) * len(pairs)
         pa.close()
     gref.close()
@@ -307,7 +314,7 @@ def test_rrbs_random_options_vs_oracle(seed, oracle, tmp_path_factory):
         has = ok & (ores["n_best"] > 0)
         for f in ("chr", "loc", "best_class"):
             assert np.array_equal(ores[f][has], hits[f][has]), f
-        assert [int(x) for x in sa.counters()[:4]] == ocnt
+        assert _counters_off() or [int(x) for x in sa.counters()[:4]] == ocnt
         if kw["D"] == "C-CGG" and kw["v"] >= 2 and kw["L"] >= 75:
             assert has.sum() > 300, has.sum()  # the reads really are site-anchored fragments
         test_rrbs_random_options_vs_oracle.last_heavy = sa.heavy_units()
@@ -332,7 +339,7 @@ def test_rrbs_random_options_vs_oracle(seed, oracle, tmp_path_factory):
             sel = up & ok & (ores[m_]["n_best"] > 0)
             for f in ("chr", "loc", "best_class"):
                 assert np.array_equal(ores[m_][f][sel], out[m_][f][sel]), (m_, f)
-        assert [int(x) for x in pa.counters()[:4]] == ocnt
+        assert _counters_off() or [int(x) for x in pa.counters()[:4]] == ocnt
         test_rrbs_random_options_vs_oracle.last_heavy = pa.heavy_units()
         pa.close()
     gref.close()
@@ -423,7 +430,7 @@ def heavy_genome(tmp_path_factory):
 
 
 @pytest.mark.parametrize("pe", [False, True], ids=["se", "pe"])
-def test_heavy_pipeline_large_buckets(pe, heavy_genome, oracle, extra=None):
+def test_heavy_pipeline_large_buckets(pe, heavy_genome, oracle, extra=None, work_counters=True):
     g, fa = heavy_genome
     kw = dict(s=16, v=6, I=4, S=1, r=1)
     if pe:
@@ -436,7 +443,7 @@ def test_heavy_pipeline_large_buckets(pe, heavy_genome, oracle, extra=None):
         reads = td.make_se_reads(g, 3000, 144, seed=8, sub_rate=0.03)
         sb, so = oracle.pack_reads([r["seq"] for r in reads])
         ores, ocnt = oracle.se_batch(oref, sb, so, threads=8)
-        sa = B.SingleAlign(gref, len(reads))
+        sa = B.SingleAlign(gref, len(reads)).set_work_counters(work_counters)
         sa.ImportBatchReads((sb, so)).Do_Batch()
         hits, cc = sa.results()
         assert sa.heavy_units() > 500
@@ -445,14 +452,14 @@ def test_heavy_pipeline_large_buckets(pe, heavy_genome, oracle, extra=None):
         has = ores["n_best"] > 0
         for f in ("chr", "loc", "best_class"):
             assert np.array_equal(ores[f][has], hits[f][has]), f
-        assert [int(x) for x in sa.counters()[:4]] == ocnt
+        assert not work_counters or _counters_off() or [int(x) for x in sa.counters()[:4]] == ocnt
         sa.close()
     else:
         pairs = td.make_pe_reads(g, 3000, 144, seed=8, sub_rate=0.01)
         s1, o1 = oracle.pack_reads([p["seq1"] for p in pairs])
         s2, o2 = oracle.pack_reads([p["seq2"] for p in pairs])
         ores, ocnt = oracle.pe_batch(oref, s1, o1, s2, o2, threads=8)
-        pa = B.PairAlign(gref, len(pairs))
+        pa = B.PairAlign(gref, len(pairs)).set_work_counters(work_counters)
         pa.ImportBatchReads((s1, o1), (s2, o2)).Do_Batch()
         out, ca, cb, npairs = pa.results()
         assert pa.heavy_units() > 500
@@ -463,7 +470,7 @@ def test_heavy_pipeline_large_buckets(pe, heavy_genome, oracle, extra=None):
         pr = (ores["tmp"] == 0) & (ores["paired"] > 0)
         for f in ("a_chr", "a_loc", "b_chr", "b_loc", "insert", "na", "nb", "chain"):
             assert np.array_equal(ores["pick"][f][pr], out[f][pr]), f
-        assert [int(x) for x in pa.counters()[:4]] == ocnt
+        assert not work_counters or _counters_off() or [int(x) for x in pa.counters()[:4]] == ocnt
         test_heavy_pipeline_large_buckets.last_group_share = float(pa.counters()[15]) / max(1.0, float(pa.counters()[7]))
         pa.close()
     gref.close()
@@ -480,9 +487,9 @@ def test_heavy_units_redone_when_their_duplicate_set_overflows(pe, heavy_genome,
     assert test_heavy_pipeline_large_buckets.last_redo > 20
 
 
-@pytest.mark.parametrize("env", [dict(BSX_TAIL_TASKS="100000000", BSX_TAIL_GRID="64"), dict(BSX_TAIL_TASKS="0"), dict(BSX_HEAVY_GROUPS="2", BSX_TAIL_TASKS="100000000"), dict(BSX_MULTI="1"),
+@pytest.mark.parametrize("env", [dict(BSX_TAIL_TASKS="100000000", BSX_TAIL_GRID="64"), dict(BSX_TAIL_TASKS="0"), dict(BSX_HEAVY_GROUPS="2", BSX_TAIL_TASKS="100000000"),
                                  dict(BSX_SAME="0"), dict(BSX_SAME="0", BSX_SPREAD="1"), dict(BSX_SAME="2", BSX_SAME_GRID_DIV="64")],
-                         ids=["tail_from_the_start_tiny_grid", "no_tail_mode", "two_groups_tail", "shared_fetch_scan_kernel", "one_task_scan_kernel", "one_task_kernel_spread_order", "group_kernel_small_grid"])
+                         ids=["tail_from_the_start_tiny_grid", "no_tail_mode", "two_groups_tail", "one_task_scan_kernel", "one_task_kernel_spread_order", "group_kernel_small_grid"])
 @pytest.mark.parametrize("pe", [False, True], ids=["se", "pe"])
 def test_heavy_pipeline_scan_grids_and_streams_do_not_matter(pe, env, heavy_genome, oracle, monkeypatch):
     """the scan kernels take their tasks in a grid-stride sweep, so any grid is correct: the tail mode (small grids on the group's
@@ -491,6 +498,16 @@ def test_heavy_pipeline_scan_grids_and_streams_do_not_matter(pe, env, heavy_geno
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     test_heavy_pipeline_large_buckets(pe, heavy_genome, oracle)
+
+
+@pytest.mark.parametrize("env", [dict(), dict(BSX_SAME="0")], ids=["group_scan_kernel", "one_task_scan_kernel"])
+@pytest.mark.parametrize("pe", [False, True], ids=["se", "pe"])
+def test_heavy_pipeline_without_work_counters(pe, env, heavy_genome, oracle, monkeypatch):
+    """bsx_batch_set_work_counters(0) — the scan kernels without the early-out classification, what the command line runs: every record
+    equals the oracle's (the work counters are not compared: they are what is switched off)"""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    test_heavy_pipeline_large_buckets(pe, heavy_genome, oracle, work_counters=False)
 
 
 def test_heavy_pipeline_runs_its_scan_in_groups(heavy_genome, oracle, monkeypatch):
@@ -558,7 +575,7 @@ def test_heavy_pipeline_degenerate_genome(oracle, tmp_path):
             for f in ("chr", "loc", "best_class"):
                 assert np.array_equal(ores[f][has], hits[f][has]), f
             assert np.array_equal(np.maximum(ores["n_best"], 0), hits["n_best"])
-            assert [int(x) for x in sa.counters()[:4]] == ocnt
+            assert _counters_off() or [int(x) for x in sa.counters()[:4]] == ocnt
             sa.close()
         else:
             pairs = td.make_pe_reads(g, 300, 144, seed=9, sub_rate=0.02)
@@ -575,7 +592,7 @@ def test_heavy_pipeline_degenerate_genome(oracle, tmp_path):
             pr = (ores["tmp"] == 0) & (ores["paired"] > 0)
             for f in ("a_chr", "a_loc", "b_chr", "b_loc", "insert", "na", "nb", "chain"):
                 assert np.array_equal(ores["pick"][f][pr], out[f][pr]), f
-            assert [int(x) for x in pa.counters()[:4]] == ocnt
+            assert _counters_off() or [int(x) for x in pa.counters()[:4]] == ocnt
             pa.close()
         gref.close()
         oref.free()
@@ -622,6 +639,21 @@ def test_heavy_pipeline_small_pools(heavy_genome, oracle):
         test_heavy_pipeline_large_buckets(False, heavy_genome, oracle)
     finally:
         B.lib().bsx_set_heavy_limits(32768, 524288)
+
+
+@pytest.mark.parametrize("seed", [1, 5, 12])
+def test_rrbs_heavy_pipeline_without_work_counters(seed, oracle, tmp_path_factory, monkeypatch):
+    """RRBS lists through the scan kernels with the work counters off (BSX_WORK_COUNTERS=0 = bsx_batch_set_work_counters(0) for every batch):
+    records as the oracle's"""
+    monkeypatch.setenv("BSX_WORK_COUNTERS", "0")
+    test_rrbs_through_the_heavy_pipeline(seed, oracle, tmp_path_factory)
+
+
+@pytest.mark.parametrize("same", ["1", "2"], ids=["shared_scan_kernel", "group_scan_kernel"])
+def test_rrbs_survivor_overflow_without_work_counters(same, oracle, tmp_path, monkeypatch):
+    monkeypatch.setenv("BSX_WORK_COUNTERS", "0")
+    monkeypatch.setenv("BSX_SAME", same)
+    test_rrbs_shared_scan_runs_and_survivor_overflow(oracle, tmp_path)
 
 
 @pytest.mark.parametrize("seed", [1, 5, 12])
@@ -678,7 +710,7 @@ def test_rrbs_shared_scan_runs_and_survivor_overflow(oracle, tmp_path):
         has = ok & (ores["n_best"] > 0)
         for f in ("chr", "loc", "best_class"):
             assert np.array_equal(ores[f][has], hits[f][has]), f
-        assert [int(x) for x in sa.counters()[:4]] == ocnt
+        assert _counters_off() or [int(x) for x in sa.counters()[:4]] == ocnt
         sa.close()
     finally:
         B.lib().bsx_set_heavy_threshold(0)

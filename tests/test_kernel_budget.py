@@ -17,9 +17,10 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 BUDGET = {
     "7k_alignILb1ELb0EE": (96, 128),    # paired-end WGBS main kernel (the headline config): five waves per SIMD, 112 B today
     "7k_alignILb0ELb0EE": (96, 128),    # single-end
-    "7k_hscanE": (80, 0),               # scan kernel of the heavy pipeline: six waves per SIMD (read words and masks live in VGPRs)
-    "12k_hscan_same": (96, 32),         # WGBS scan kernel (groups of tasks over one window and read offset): five waves per SIMD
-    "14k_hscan_shared": (96, 0),        # RRBS scan kernel
+    # the scan kernels of the heavy pipeline, without (ILb0E: what the command line and the bench's timed region run) and with the work counters
+    "7k_hscanILb0EE": (80, 0), "7k_hscanILb1EE": (80, 0),                    # one task per wave: six waves per SIMD (read words and masks live in VGPRs)
+    "12k_hscan_sameILb0EE": (96, 32), "12k_hscan_sameILb1EE": (96, 32),      # WGBS (groups of tasks over one window and read offset): five waves per SIMD
+    "14k_hscan_sharedILb0EE": (96, 0), "14k_hscan_sharedILb1EE": (96, 0),    # RRBS
 }
 
 

@@ -40,6 +40,17 @@
 #define MIX_HEADV(c) asm volatile("v_alignbit_b32 %0, %0, %1, %2\n v_bitop3_b32 %0, %3, %0, %1 bitop3:0x60\n v_add_u32 %1, %0, %0\n" \
                                   "v_bitop3_b32 %0, %1, %4, %0 bitop3:0xc8\n v_bcnt_u32_b32 %0, %0, %1" : "+v"(a[c]), "+v"(b[c]) : "v"(sh), "v"(sc), "v"(sd));
 #define MIX_ADD(c)   asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[c]) : "v"(b[c]));
+// The inner word of k_hscan_same as the shipped code object issues it (hs_eval_read<5, false, PLAIN, FULL>: one read of 129-160 nt without N
+// against 64 candidates): per 32-nt word two v_bitop3 (three for the last, masked one) and a v_bcnt that accumulates; one compare into an
+// SGPR pair for the survivors; plus the group's ten v_alignbit per candidate shared by 9.6 reads on average (one here).
+//   counted (bsx_batch_set_work_counters(1)): + the reference's two early-out classes — 2 v_and, 2 v_bcnt, 2 compares.
+#define HS_WORD2(c)  "v_bitop3_b32 %1, %0, %3, %2 bitop3:0x34\n v_bitop3_b32 %1, %1, %0, %2 bitop3:0xf6\n v_bcnt_u32_b32 %0, %1, %0\n"
+#define HS_WORD3(c)  "v_bitop3_b32 %1, %0, %3, %2 bitop3:0x28\n v_bitop3_b32 %0, %0, %2, %3 bitop3:0x34\n v_bitop3_b32 %1, %1, %0, %2 bitop3:0xf8\n v_bcnt_u32_b32 %0, %1, %0\n"
+#define MIX_HSAME(c) asm volatile("v_alignbit_b32 %0, %0, %1, %2\n" HS_WORD2(c) HS_WORD2(c) HS_WORD2(c) HS_WORD2(c) HS_WORD3(c) \
+                                  "v_cmp_ge_u32_e64 s[10:11], %3, %0" : "+v"(a[c]), "+v"(b[c]) : "v"(sh), "v"(sc) : "s10", "s11");
+#define MIX_HSAMEC(c) asm volatile("v_alignbit_b32 %0, %0, %1, %2\n" HS_WORD2(c) "v_and_b32 %1, %1, %3\n v_bcnt_u32_b32 %1, %1, 0\n v_cmp_lt_u32_e64 s[12:13], %3, %1\n" \
+                                   HS_WORD2(c) "v_and_b32 %1, %1, %3\n v_bcnt_u32_b32 %1, %1, %0\n v_cmp_ge_u32_e64 s[14:15], %3, %1\n" HS_WORD2(c) HS_WORD2(c) HS_WORD3(c) \
+                                   "v_cmp_ge_u32_e64 s[10:11], %3, %0" : "+v"(a[c]), "+v"(b[c]) : "v"(sh), "v"(sc) : "s10", "s11", "s12", "s13", "s14", "s15");
 
 template <int MIX> struct Info;
 #define DEF(ID, NAME, BODY, N) \
@@ -61,7 +72,9 @@ DEF(12, "v_cndmask_b32", MIX_CNDMASK, 1)
 DEF(13, "k_hscan head word (alignbit,bitop3,lshl,bitop3,bcnt)", MIX_HEAD, 5)
 DEF(14, "v_add_u32", MIX_ADD, 1)
 DEF(15, "k_hscan head word, VGPR operands (alignbit,bitop3 vvv,add,bitop3 vvv,bcnt)", MIX_HEADV, 5)
-constexpr int N_MIX = 16;
+DEF(16, "k_hscan_same inner word (alignbit, 11 bitop3 vvv, 5 bcnt, 1 cmp -> sgpr)", MIX_HSAME, 18)
+DEF(17, "k_hscan_same inner word with work counters (alignbit, 11 bitop3 vvv, 7 bcnt, 2 and, 3 cmp -> sgpr)", MIX_HSAMEC, 24)
+constexpr int N_MIX = 18;
 
 template <int MIX> __global__ __launch_bounds__(256) void k_issue(uint32_t *out, unsigned long long *clk, int iters, uint32_t seed)
 {

@@ -3,6 +3,9 @@
 TAG=$1; shift
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O
 export BSX_PROFILES_DIR=$O
+# what is profiled, for the summary (bench.py quotes a summary only for the mode / counter setting it runs): --mode X and --work-counters N among the bench arguments
+MODE=pe; WC=0; prev=""; for a in "$@"; do [ "$prev" = "--mode" ] && MODE=$a; [ "$prev" = "--work-counters" ] && WC=$a; prev=$a; done
+export BSX_PROFILE_MODE=$MODE BSX_PROFILE_WORK_COUNTERS=$WC BSX_PROFILE_STEPS=3
 S=/tmp/bsx_prof_$$; mkdir -p $S
 cd /tmp && export TMPDIR=/tmp
 for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM SQ_WAIT_ANY SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE" "TA_TA_BUSY_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum"; do

@@ -8,6 +8,7 @@
 TAG=${1:-r02}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O
 export BSX_PROFILES_DIR=$O
+export BSX_PROFILE_MODE=pe BSX_PROFILE_WORK_COUNTERS=0 BSX_PROFILE_STEPS=3   # (the counter passes below: C3, work counters off as the timed region runs, --steps 2 --warmup 1)
 S=/tmp/bsx_prof_$$; mkdir -p $S
 cd $R
 cd /tmp && export TMPDIR=/tmp

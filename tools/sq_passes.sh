@@ -3,6 +3,9 @@
 TAG=${1:-sq}; shift
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O
 export BSX_PROFILES_DIR=$O
+# what is profiled, for the summary (bench.py quotes a summary only for the mode / counter setting it runs): --mode X and --work-counters N among the bench arguments
+MODE=pe; WC=0; prev=""; for a in "$@"; do [ "$prev" = "--mode" ] && MODE=$a; [ "$prev" = "--work-counters" ] && WC=$a; prev=$a; done
+export BSX_PROFILE_MODE=$MODE BSX_PROFILE_WORK_COUNTERS=$WC BSX_PROFILE_STEPS=3
 S=/tmp/bsx_sq_$$; mkdir -p $S
 cd /tmp && export TMPDIR=/tmp
 DIRS=""

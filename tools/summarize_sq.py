@@ -29,6 +29,8 @@ N_CU, N_SIMD = 256, 1024
 def short(name):
     for k in KERNELS:
         if k in name:
+            if k == "k_hscan":   # (the scan kernels' one template argument is the work-counter switch: a serial-mode run holds one of the two, named by the file's work_counters)
+                return k
             t = "<true>" if "<true>" in name else "<false>" if "<false>" in name else ""
             return k + t
     return None
@@ -66,9 +68,14 @@ def main():
         sys.path.insert(0, ROOT)
         import bench
         out["lib_sha16"] = bench.lib_sha16()
-        out["bsx_multi"] = os.environ.get("BSX_MULTI", "")
     except Exception:
         pass
+    # what was profiled (set by the profiling scripts): bench.py only quotes a summary for the mode and counter setting it runs
+    out["mode"] = os.environ.get("BSX_PROFILE_MODE", "pe")
+    out["work_counters"] = int(os.environ.get("BSX_PROFILE_WORK_COUNTERS", "0"))
+    out["steps_in_pass"] = int(os.environ.get("BSX_PROFILE_STEPS", "3"))          # warm-up + timed steps of each counter pass: counters are sums over all of them
+    out["units_per_step"] = int(os.environ.get("BSX_PROFILE_UNITS", str(1 << 20)))
+    out["scan_kernel"] = os.environ.get("BSX_SAME", "1")
     merged = collections.defaultdict(dict)
     for d in dirs:
         acc, disp = read_pass(d)
@@ -101,6 +108,11 @@ def main():
                     d[name] = g(c) / g("SQ_WAVE_CYCLES")  # (different passes: same kernel, same work)
             if g("SQ_WAVES"):
                 d["quad_cycles_per_wave"] = g("SQ_WAVE_CYCLES") / g("SQ_WAVES")
+        if g("SQ_WAVE_CYCLES") and g("GRBM_GUI_ACTIVE"):   # quad-cycles of resident waves over the SIMDs' cycles (different passes: same kernel, same work)
+            d["resident_waves_per_simd"] = g("SQ_WAVE_CYCLES") * 4 / (N_SIMD * g("GRBM_GUI_ACTIVE") / 8)
+        if g("TCC_EA0_RDREQ_sum") is not None:
+            d["fabric_read_requests_per_step"] = g("TCC_EA0_RDREQ_sum") / out["steps_in_pass"]
+            d["fabric_read_requests_per_s"] = g("TCC_EA0_RDREQ_sum") / t("TCC_EA0_RDREQ_sum")
         if g("TA_TA_BUSY_sum"):
             d["ta_busy_frac"] = g("TA_TA_BUSY_sum") / (N_CU * clk * t("TA_TA_BUSY_sum"))
         if g("TCP_TOTAL_CACHE_ACCESSES_sum") and g("TCP_TCC_READ_REQ_sum") is not None:
