@@ -2398,17 +2398,23 @@ __global__ __launch_bounds__(64 * BSX_HSCAN_WPB, BSX_HSCAN_WAVES) void k_hscan(A
 #define HG_R 16u        /* tasks per group at most */
 #endif
 #ifndef HG_C
-#define HG_C 2          /* chunks per step */
+#define HG_C 4          /* chunks per step.  Round 5 (without the work counters, 2^22 pairs per batch; scan ms per step / C3 M reads/s, one box): 2 chunks with the gathers a step
+                           ahead at five waves per SIMD 154.4-157.9 / 27.1-27.4; 3 without that prefetch 144.9 / 28.1; 4 without, five waves (64 B of scratch) 146.9 / 29.1; 4 without,
+                           four waves 141.7-143.0 / 28.0-28.9; 5, 6 at four waves 141.6, 143.7; 8 at three 141.8 / 27.6: what a step costs per READ (its LDS row, two v_readlane,
+                           the scalar bookkeeping) is spread over twice the candidates */
 #endif
 #ifndef HG_BIG
 #define HG_BIG 1u       /* groups of this many tasks and more are started first, the others fill the tail of the launch.  1 = plain scan order, measured best:
                            from 4 tasks 103.5-104.2 against 99.4-100.3 ms per step, from 8 103.0 — the long groups of all windows at once lose the shared cache lines */
 #endif
 #ifndef HG_PREFETCH
-#define HG_PREFETCH 1   /* the gathers of a step are issued a step earlier (13 registers per chunk) */
+#define HG_PREFETCH 0   /* 1: the gathers of a step are issued a step earlier (13 registers per chunk: only fits with two chunks per step) */
 #endif
 #ifndef BSX_HSAME_WAVES
-#define BSX_HSAME_WAVES 5
+#define BSX_HSAME_WAVES 4
+#endif
+#ifndef HG_ROWPF
+#define HG_ROWPF 0      /* the next read's LDS row requested before this read is evaluated (16 registers) */
 #endif
 struct SameLds {
     // per read of a group (row of 20 dwords): X0 Y0 M0 X1 | Y1 M1 X2 Y2 | M2 threshold X3 Y3 | M3 X4 Y4 M4 | task, first list ordinal, -, -
@@ -2594,12 +2600,22 @@ __device__ __forceinline__ void hs_group(const AlignArgs &A, const HeavyArgs &H,
         }
 #endif
         const bool full = !RRBS && cb + STEP <= n;   // (RRBS: the filters decide per entry)
+#if HG_ROWPF
+        // (the next read's row is requested before this read is evaluated: its LDS round trip — four 16-byte reads of a wave — hides behind ~50 vector instructions)
+        uint4 p0, p1, p2, p3 = make_uint4(0u, 0u, 0u, 0u);
+        { const uint4 *row = reinterpret_cast<const uint4 *>(uw); p0 = row[0]; p1 = row[1]; p2 = row[2]; if (nwr > 3) p3 = row[3]; }
+#endif
         for (uint32_t k = 0; k < K; k++) {
             // (a 16-byte LDS read of a wave moves 1 KB, 8 cycles of the CU's LDS path: one read of the row per step, not per chunk)
+#if HG_ROWPF
+            const uint4 a0 = p0, a1 = p1, a2 = p2, a3 = p3;
+            if (k + 1 < K) { const uint4 *row = reinterpret_cast<const uint4 *>(uw + (k + 1u) * 20u); p0 = row[0]; p1 = row[1]; p2 = row[2]; if (nwr > 3) p3 = row[3]; }
+#else
             const uint4 *row = reinterpret_cast<const uint4 *>(uw + k * 20u);
             const uint4 a0 = row[0], a1 = row[1], a2 = row[2];  // X0 Y0 M0 X1 | Y1 M1 X2 Y2 | M2 threshold X3 Y3 | M3 X4 Y4 M4
             uint4 a3 = make_uint4(0u, 0u, 0u, 0u);
             if (nwr > 3) a3 = row[3];
+#endif
             const uint32_t tp = rfl(a2.y), thr = tp & 0xffffu;
             const bool plain = NWR != 0 && (tp >> 16) != 0;
             SurvRec *const sv = H.tout[rl_u(tid, k)].surv;   // (wave-uniform: the address arithmetic stays on the scalar unit)

@@ -19,7 +19,7 @@ BUDGET = {
     "7k_alignILb0ELb0EE": (96, 128),    # single-end
     # the scan kernels of the heavy pipeline, without (ILb0E: what the command line and the bench's timed region run) and with the work counters
     "7k_hscanILb0EE": (80, 0), "7k_hscanILb1EE": (80, 0),                    # one task per wave: six waves per SIMD (read words and masks live in VGPRs)
-    "12k_hscan_sameILb0EE": (96, 32), "12k_hscan_sameILb1EE": (96, 32),      # WGBS (groups of tasks over one window and read offset): five waves per SIMD
+    "12k_hscan_sameILb0EE": (128, 0), "12k_hscan_sameILb1EE": (128, 0),      # WGBS (groups of tasks over one window and read offset): four chunks per step, four waves per SIMD, no scratch
     "14k_hscan_sharedILb0EE": (96, 0), "14k_hscan_sharedILb1EE": (96, 0),    # RRBS
 }
 
