@@ -332,6 +332,8 @@ def main():
     # stats reduction: the only collective of the path (RCCL all-gather of a few doubles per rank)
     from bsmap_amd import sharding
     dt_max, tot_counters, allstats = sharding.gather_stats(dt, counters, dist, device="cuda")
+    if dist is not None and os.environ.get("BSX_TRACE_COLLECTIVE"):
+        print("collective: backend %s world %d all_gather ok (%d rows)" % (dist.get_backend(), world, allstats.shape[0]), file=sys.stderr, flush=True)
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -373,6 +375,7 @@ def main():
                    "parallelism": f"read-sharded x{world}", "batches_in_flight": nfl, "work_counters_in_timed_region": bool(args.work_counters), "lib_sha16": sha, "exact_mode": bool(args.exact),
                    "resident_ring_steps": ring, "heavy_pools": [{"units_per_round": u_, "scan_tasks": t_} for u_, t_ in pools], "device_memory_plan": plan,
                    "setup_s": {"genome": round(t_gen, 2), "index_build_gpu": round(t_index, 2), "device_batches": round(t_batches, 2)},
+                   "records_flagged_BSX_F_LIMIT": int(tot_counters[16]) if len(tot_counters) > 16 else None,   # (the one capacity deviation from the reference, include/bsx.h: counted, 0)
                    "aligned_fraction": float((2 * tot_counters[6] + tot_counters[5]) / max(1.0, n_reads_rank * world)) if pe
                    else float(tot_counters[5] / max(1.0, n_reads_rank * world))},
         # The roofline of the dominant kernel against the unit that binds it: `achieved` = candidates per second of k_hscan measured live (HIP events

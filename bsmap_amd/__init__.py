@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BSX_LIB") or os.path.join(HERE, "libbsx.so")  # BSX_LIB: alternative build of the same library (kernel tuning experiments)
 CSRC = os.path.join(HERE, "csrc")
 
-BSX_N_COUNTERS = 16
+BSX_N_COUNTERS = 17
 LEAK_STATE_BYTES = 2576
 F_FILTERED, F_CHAIN = 1, 2
 

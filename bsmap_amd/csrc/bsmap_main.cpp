@@ -122,8 +122,9 @@ void usage()
          << "       -2  <str>   output file of unpaired alignment hits\n"
          << "       -G  <str>   GPU ordinal(s): N, a list N,M,... or 'all'; batches are dealt to the GPUs in turn, default 0 (extension)\n"
          << "       --lanes[=N] cut the reads into N ranges (default: one per -G device), one process, GPU and output stream per range,\n"
-         << "                   like -B / -E shards on one node; the output is joined in input order (extension)\n"
-         << "       --lane-files  with --lanes: leave one output file per range, <out>.<lane> (extension)\n"
+         << "                   like -B / -E shards on one node; the output is joined in input order (extension).  Joining copies every byte but\n"
+         << "                   the first lane's at 3-3.5 GB/s: on one GPU it costs more than the lanes gain - use --lane-files at scale\n"
+         << "       --lane-files  with --lanes: leave one output file per range, <out>.<lane>, no join (extension)\n"
          << "       -h          help\n\n";
     exit(1);
 }
@@ -690,6 +691,7 @@ int fork_lanes(Opts &o, LaneInfo &lane, time_t t_begin)
     if (!o.lane_files) {
         vector<string> parts, parts2;
         for (int l = 0; l < L; l++) { parts.push_back(out0 + "." + to_string(l)); if (!unpair0.empty() && !o.out_sam && pe) parts2.push_back(unpair0 + "." + to_string(l)); }
+        bsx_textout::install_sigbus_handler();   // (the join writes through shared mappings of a sparsely extended file: a full tmpfs is a SIGBUS here, too)
         if (!join_files(out0, parts, (int)ncpu) || (!parts2.empty() && !join_files(unpair0, parts2, (int)ncpu))) { cerr << "write error on the output file (joining the lanes)\n"; exit(1); }
     }
     const double join_s = now_s() - t_join0;
@@ -875,17 +877,8 @@ int main(int argc, char **argv)
     const bool map_out = use_map(fout);
     const int map_threads = getenv("BSX_WRITE_THREADS") ? max(1, atoi(getenv("BSX_WRITE_THREADS"))) : (int)max(1u, min(12u, ncpu));  // (4 / 8 / 14 threads: 18 / 21 / 22 M reads/s with the GPU stage nearly free; pwrite 16)
     if (map_out) {
-        // the input files are memory-mapped too (bsx_reads.h): only a fault inside the range map_write has mapped is the output's
-        struct sigaction sa; memset(&sa, 0, sizeof(sa));
-        sa.sa_flags = SA_SIGINFO;
-        sa.sa_sigaction = [](int, siginfo_t *si, void *) {
-            const uintptr_t a = (uintptr_t)si->si_addr, lo = bsx_textout::g_map_lo.load(std::memory_order_relaxed), hi = bsx_textout::g_map_hi.load(std::memory_order_relaxed);
-            static const char m_out[] = "write error on the output file (no space left?)\n", m_other[] = "bus error on a mapped file (an input file truncated while it was read?)\n";
-            const bool out = a >= lo && a < hi;
-            ssize_t r = write(2, out ? m_out : m_other, (out ? sizeof(m_out) : sizeof(m_other)) - 1); (void)r;
-            _exit(1);
-        };
-        sigaction(SIGBUS, &sa, nullptr);
+        // the input files are memory-mapped too (bsx_reads.h): only a fault inside a range map_write has mapped is the output's
+        bsx_textout::install_sigbus_handler();
     }
     auto map_write = bsx_textout::map_write;
     auto write_all = [](int fd, const char *p_, size_t n_, off_t at) {

@@ -1405,6 +1405,7 @@ __device__ void unit_finish(const AlignArgs &A, const MateLds &LA, const MateLds
         bsx_hit out;
         select_hit(P, MA, U.SA, out, false);
         if (lane == 0) A.hits_out[unit] = out;
+        if (lane == 0 && (out.flags & BSX_F_LIMIT)) atomicAdd((u64 *)&A.counters[16], 1ull);   // the one capacity deviation from the reference (include/bsx.h): counted, so that "never seen" is a number
         if (A.cc[0] && lane < 32) { uint16_t *cc = (uint16_t *)&A.cc[0][unit]; cc[lane] = (uint16_t)MA.cnt_reg; }
         if (A.debug && lane < 32) { A.dbg_plan[(size_t)unit * 128 + lane] = LA.start[lane >> 4][lane & 15]; A.dbg_plan[(size_t)unit * 128 + 32 + lane] = LA.order[lane >> 4][lane & 15]; }
         if (out.n_best == 1 || (out.n_best > 1 && P.report_repeat_hits == 1)) n_aligned++;
@@ -2438,6 +2439,38 @@ __device__ __forceinline__ SameEntry same_entry(const SameWin &W, uint32_t idx)
     else if (e.in) e.a = W.ent[idx];
     return e;
 }
+#ifdef BSX_SECTOR_STATS
+// Diagnostic build (tools/build_variant.sh sectors -DBSX_SECTOR_STATS; BSX_SECTOR_STATS=1 at run time): which 64-byte sectors of the plane copy the group
+// scan touches in a pass.  Every gather marks its sectors in a bitmap (one bit per sector: 3 MB for the hg38-sized copy) and counts its lane-sector
+// touches; after every scan launch bsx_sector_pass counts and clears the bitmap: the sum over passes is the COMPULSORY traffic of the scan — what an
+// ideal cache in front of one pass would still fetch — to set beside TCC_EA0_RDREQ (what the fabric served) and the touches (what L2 was asked for).
+__device__ uint32_t *g_sector_bits = nullptr;
+__device__ unsigned long long g_sector_touch = 0, g_sector_distinct = 0, g_sector_passes = 0;
+__device__ __forceinline__ void sector_mark(uint32_t byte_off, int n16)
+{
+    uint32_t *bits = g_sector_bits;
+    if (!bits) return;
+    uint32_t prev = 0xffffffffu, touches = 0;
+    for (int i = 0; i < n16; i++)
+        for (uint32_t b = byte_off + 16u * (uint32_t)i; b <= byte_off + 16u * (uint32_t)i + 15u; b += 15u) {
+            const uint32_t sct = b >> 6;
+            if (sct == prev) continue;
+            prev = sct; touches++;
+            if (!((bits[sct >> 5] >> (sct & 31u)) & 1u)) atomicOr(&bits[sct >> 5], 1u << (sct & 31u));
+        }
+    const unsigned long long tw = (unsigned long long)wave_sum(touches);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&g_sector_touch, tw);
+}
+__global__ __launch_bounds__(256) void k_sector_pop(uint32_t n_words)
+{
+    unsigned long long c = 0;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n_words; i += gridDim.x * 256) { const uint32_t w = g_sector_bits[i]; if (w) { c += (unsigned long long)__popc(w); g_sector_bits[i] = 0; } }
+    for (int o = 32; o; o >>= 1) c += __shfl_xor(c, o);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&g_sector_distinct, c);
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_sector_passes, 1ull);
+}
+#endif
+
 template <bool RRBS>
 __device__ __forceinline__ SameChunk same_load(const SameWin &W, const SameEntry &e)
 {
@@ -2455,6 +2488,9 @@ __device__ __forceinline__ SameChunk same_load(const SameWin &W, const SameEntry
     c.r1.a = c.r1.b = c.r1.c = c.r1.d = 0; c.r2.a = c.r2.b = c.r2.c = c.r2.d = 0;
     if (W.nwr > 1) c.r1 = *reinterpret_cast<const U4 *>(src + 16);
     if (W.nwr > 3) c.r2 = *reinterpret_cast<const U4 *>(src + 32);
+#ifdef BSX_SECTOR_STATS
+    if (c.valid) sector_mark(hp_boff(c.pm1, off), W.nwr > 3 ? 3 : W.nwr > 1 ? 2 : 1); else sector_mark(0u, 0);
+#endif
     return c;
 }
 
@@ -3175,10 +3211,14 @@ __global__ __launch_bounds__(256) void k_sig_hist(const HTask *tasks, const uint
         uint32_t k = 31;
         if (tk.flags & 2u) {
             const unsigned long long sg = sig_of(tk, with_h != 0);
-            uint32_t slot = (uint32_t)(sg >> 20) & mask;
-            while (tab[2 * (size_t)slot] != sg) slot = (slot + 1) & mask;
-            const unsigned long long r = tab[2 * (size_t)slot + 1];
-            k = r <= 1 ? 0u : 32u - (uint32_t)__builtin_clz((uint32_t)r - 1u);
+            // (bounded probe: the table is process-global — with a second batch in flight its memset can clear the table under this kernel;
+            //  the histogram is then wrong, diagnostics are meant for one batch in flight, but nothing may spin)
+            uint32_t slot = (uint32_t)(sg >> 20) & mask, probes = 0;
+            while (tab[2 * (size_t)slot] != sg && probes <= mask) { slot = (slot + 1) & mask; probes++; }
+            if (probes <= mask) {
+                const unsigned long long r = tab[2 * (size_t)slot + 1];
+                k = r <= 1 ? 0u : 32u - (uint32_t)__builtin_clz((uint32_t)r - 1u);
+            }
         }
         atomicAdd(&hist[k], (unsigned long long)tk.n);
         atomicAdd(&hist[32 + k], 1ull);
@@ -3215,6 +3255,35 @@ void bsx_sig_hist_report(void)
                 fprintf(stderr, "[sighist]   %s %-6u cand %.4f tasks %.4f\n", k == 31 ? "spanning" : "R <=", k == 31 ? 0u : 1u << k, (double)h[64 * with_h + k] / (double)std::max(1ull, tot), (double)h[64 * with_h + 32 + k] / (double)std::max(1ull, tt));
     }
     (void)hipMemset(g_sig_hist, 0, 2 * 64 * 8);
+}
+
+// BSX_SECTOR_STATS (diagnostic build only; a no-op in the shipped library): count and clear the sectors the scan launch just marked
+void bsx_sector_pass(const bsx_ref *r, hipStream_t stream)
+{
+#ifdef BSX_SECTOR_STATS
+    const uint32_t n_words = (uint32_t)(((uint64_t)r->plane_rc_off * 2 / 64 + 31) / 32 + 64);
+    static uint32_t *bits = nullptr;
+    if (!bits) {
+        if (hipMalloc((void **)&bits, (size_t)n_words * 4) != hipSuccess) return;
+        (void)hipMemset(bits, 0, (size_t)n_words * 4);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sector_bits), &bits, sizeof(bits));
+        return;   // (the first call only sets the bitmap up: called once before the first scan)
+    }
+    hipLaunchKernelGGL(k_sector_pop, dim3(1024), dim3(256), 0, stream, n_words);
+#else
+    (void)r; (void)stream;
+#endif
+}
+void bsx_sector_report(void)
+{
+#ifdef BSX_SECTOR_STATS
+    unsigned long long t = 0, d = 0, p = 0;
+    if (hipDeviceSynchronize() != hipSuccess) return;
+    (void)hipMemcpyFromSymbol(&t, HIP_SYMBOL(g_sector_touch), 8); (void)hipMemcpyFromSymbol(&d, HIP_SYMBOL(g_sector_distinct), 8); (void)hipMemcpyFromSymbol(&p, HIP_SYMBOL(g_sector_passes), 8);
+    fprintf(stderr, "[sectors] group scan: %llu lane-sector touches, %llu distinct sectors summed over %llu scan launches (compulsory), ratio %.2f\n", t, d, p, d ? (double)t / (double)d : 0.0);
+    const unsigned long long z = 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sector_touch), &z, 8); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sector_distinct), &z, 8); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sector_passes), &z, 8);
+#endif
 }
 
 size_t bsx_hstate_bytes(void) { return sizeof(HState); }

@@ -265,6 +265,8 @@ struct bsx_batch {
     uint32_t *d_hactive[2] = {nullptr, nullptr}, *d_hcnt = nullptr;  // d_hcnt: per group two ping-pong blocks {n_active, n_tasks, queue[2]}
     uint32_t hcap = 0, task_cap = 0;
     bool sig_hist = false;    // diagnostics: histogram of tasks per identical window (bsx_sig_hist_pass)
+    bool same_kernel = false;    // the scan kernel is k_hscan_same (WGBS unless BSX_SAME=0, RRBS with BSX_SAME=2): read once, at creation
+    bool sector_stats = false;   // diagnostics (a build with -DBSX_SECTOR_STATS): distinct sectors per scan launch
     uint32_t xcd_map = 128;   // order_block (bsx_align.hip): pieces of 128 scan blocks dealt to the XCDs in turn
     uint32_t *h_pinned = nullptr;  // pinned host words for the per-pass count read-backs
     int n_cu = 0;
@@ -300,7 +302,8 @@ static hipError_t stream_wait(bsx_batch *b);
 // duplicate-suppression set of one mate slab (Slab in bsx_align.hip).  WGBS and paired RRBS: every remembered coordinate is a
 // hit, the -w caps bound them.  Single-end RRBS also remembers the coordinates its fragment-size filter rejects
 // (align.cpp:201-207), which nothing caps: a poly-T read of the hg38-sized genome collects thousands — 2^18 keys, 2^19 slots.
-static uint32_t key_cap(const bsx_params &p, uint32_t rowcap) { return (p.rrbs && !p.pairend) ? (1u << 18) : (uint32_t)(p.max_snp_num + 2) * rowcap; }
+// (BSX_KCAP: test hook that makes the large set of single-end RRBS small, to exercise the BSX_F_LIMIT path)
+static uint32_t key_cap(const bsx_params &p, uint32_t rowcap) { return (p.rrbs && !p.pairend) ? (getenv("BSX_KCAP") ? (uint32_t)std::max(64, atoi(getenv("BSX_KCAP"))) : (1u << 18)) : (uint32_t)(p.max_snp_num + 2) * rowcap; }
 static uint32_t hset_bits(const bsx_params &p) { return (p.rrbs && !p.pairend) ? 19u : (uint32_t)BSX_HSET_BITS; }
 
 // the small set of the heavy pipeline's slabs (BSX_HEAVY_KCAP: test hook that makes it overflow)
@@ -464,6 +467,9 @@ static int ensure_scratch(bsx_batch *b)
                 for (void **x : gp) { if (*x) (void)hipFree(*x); *x = nullptr; }
             }
         };
+        // (the group scan kernel: WGBS unless BSX_SAME=0, RRBS with BSX_SAME=2 — the same rule as bsx_batch_run_range)
+        const int same_env0 = getenv("BSX_SAME") ? atoi(getenv("BSX_SAME")) : 1;
+        const bool same_kernel = b->same_kernel = b->ref->P.rrbs ? same_env0 == 2 : same_env0 != 0;
         auto alloc_pools = [&]() -> hipError_t {
             hipError_t e;
 #define POOL_TRY(x) do { if ((e = (x)) != hipSuccess) return e; } while (0)
@@ -480,7 +486,7 @@ static int ensure_scratch(bsx_batch *b)
                 POOL_TRY(hipMalloc((void **)&q.d_chunk_tot, (size_t)bsx_bin_chunks(b->n_bins) * 4));
                 POOL_TRY(hipMalloc((void **)&q.d_rank, (size_t)tcap * 4));
                 POOL_TRY(hipMalloc((void **)&q.d_order, (size_t)tcap * 4));
-                POOL_TRY(hipMalloc((void **)&q.d_glist, ((size_t)tcap + 4) * 4));   // (k_hscan_same: start slots of the groups, then their count)
+                if (same_kernel) POOL_TRY(hipMalloc((void **)&q.d_glist, ((size_t)tcap + 4) * 4));   // (k_hscan_same: start slots of the groups, then their count)
             }
 #undef POOL_TRY
             return hipSuccess;
@@ -538,6 +544,8 @@ extern "C" int bsx_batch_create(bsx_ref *r, uint32_t max_units, int paired, bsx_
     b->trace = getenv("BSX_TRACE_HEAVY") != nullptr;
     if (const char *e = getenv("BSX_WORK_COUNTERS")) b->work_counters = atoi(e) != 0;   // the default of bsx_batch_set_work_counters (test hook)
     b->sig_hist = getenv("BSX_SIGHIST") != nullptr;
+    b->sector_stats = getenv("BSX_SECTOR_STATS") != nullptr;
+    if (b->sector_stats) bsx_sector_pass(r, nullptr);   // (sets the bitmap up)
     if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) return fail(BSX_ERR_DEVICE);
     {
         int lo_p = 0, hi_p = 0;
@@ -565,8 +573,9 @@ extern "C" int bsx_batch_create(bsx_ref *r, uint32_t max_units, int paired, bsx_
         if (hipMalloc((void **)&b->d_pairs, (size_t)max_units * sizeof(bsx_pair)) != hipSuccess || hipMalloc((void **)&b->d_npairs, (size_t)max_units * 64) != hipSuccess)
             return fail(BSX_ERR_NOMEM);
     } else if (hipMalloc((void **)&b->d_hits, (size_t)max_units * sizeof(bsx_hit)) != hipSuccess) return fail(BSX_ERR_NOMEM);
-    if (hipMalloc((void **)&b->d_queue, 256) != hipSuccess || hipMalloc((void **)&b->d_counters, BSX_N_COUNTERS * 8 + 256) != hipSuccess) return fail(BSX_ERR_NOMEM);
-    if (hipMemsetAsync(b->d_counters, 0, BSX_N_COUNTERS * 8 + 256, b->stream) != hipSuccess) return fail(BSX_ERR_DEVICE);
+    if (hipMalloc((void **)&b->d_queue, 256) != hipSuccess || hipMalloc((void **)&b->d_counters, 24 * 8 + 256) != hipSuccess) return fail(BSX_ERR_NOMEM);
+    static_assert(BSX_N_COUNTERS <= 24, "the diagnostic clocks start at word 24");
+    if (hipMemsetAsync(b->d_counters, 0, 24 * 8 + 256, b->stream) != hipSuccess) return fail(BSX_ERR_DEVICE);
     if (hipMalloc((void **)&b->d_scan_stats, 64 * 64) != hipSuccess) return fail(BSX_ERR_NOMEM);
     if (hipMemsetAsync(b->d_scan_stats, 0, 64 * 64, b->stream) != hipSuccess) return fail(BSX_ERR_DEVICE);
     if ((rc = ensure_scratch(b)) != BSX_OK) return fail(rc);
@@ -580,6 +589,7 @@ extern "C" void bsx_batch_destroy(bsx_batch *b)
     (void)hipSetDevice(b->ref->device);
     if (b->stream) (void)hipStreamSynchronize(b->stream);
     if (b->sig_hist) bsx_sig_hist_report();
+    if (b->sector_stats) bsx_sector_report();
     for (int m = 0; m < 2; m++)
         for (void *q : {(void *)b->d_seq[m], (void *)b->d_qual[m], (void *)b->d_off[m], (void *)b->d_cc[m]})
             if (q) (void)hipFree(q);
@@ -799,7 +809,7 @@ extern "C" int bsx_batch_run_range(bsx_batch *b, uint32_t first_unit, uint32_t n
     A.first_unit = first_unit;
     for (int m = 0; m < 2; m++) { A.seq[m] = b->d_seq[m]; A.off[m] = b->d_off[m]; A.qual[m] = b->has_qual ? b->d_qual[m] : nullptr; A.cc[m] = b->d_cc[m]; }
     A.hits_out = b->d_hits; A.pairs_out = b->d_pairs; A.npairs_out = b->d_npairs;
-    A.scratch = b->d_scratch; A.slab_bytes = b->slab_bytes; A.queue = b->d_queue; A.counters = b->d_counters; A.scan_stats = b->d_scan_stats; A.work_counters = (uint32_t)b->work_counters; A.dbg_plan = b->d_dbg; A.dbg_cycles = b->d_cycles; A.dbg_cat = b->d_cycles ? b->d_counters + 16 : nullptr;
+    A.scratch = b->d_scratch; A.slab_bytes = b->slab_bytes; A.queue = b->d_queue; A.counters = b->d_counters; A.scan_stats = b->d_scan_stats; A.work_counters = (uint32_t)b->work_counters; A.dbg_plan = b->d_dbg; A.dbg_cycles = b->d_cycles; A.dbg_cat = b->d_cycles ? b->d_counters + 24 : nullptr;
     A.heavy_list = b->d_heavy_list; A.heavy_count = b->d_heavy_count;
     A.leak_exact = b->leak_exact; A.n_hist = b->leak_exact ? b->n_hist : 0; A.n_units_all = b->n_units;
     for (int m = 0; m < 2; m++) { A.hist_seq[m] = b->d_hist_seq[m]; A.hist_off[m] = b->d_hist_off[m]; A.hist_qual[m] = b->d_hist_qual[m]; }
@@ -839,8 +849,7 @@ extern "C" int bsx_batch_run_range(bsx_batch *b, uint32_t first_unit, uint32_t n
         // WGBS: the tasks of one window AND read offset share fetch and shift (k_hscan_same); BSX_SAME=0: one task per wave (k_hscan)
         // RRBS lists go through the same kernel with BSX_SAME=2 (scan 75.9 against 90.5 ms per step; the step does not move — 142.2 against 141.0 ms —, it
         // waits for the control passes there: k_hscan_shared stays the default for RRBS)
-        const int same_env = getenv("BSX_SAME") ? atoi(getenv("BSX_SAME")) : 1;
-        const bool same_scan = shared_scan ? same_env == 2 : same_env != 0;
+        const bool same_scan = b->same_kernel;   // (decided when the batch was created: its group list exists or not)
         const uint32_t spread = getenv("BSX_SPREAD") ? (uint32_t)atoi(getenv("BSX_SPREAD")) : (same_scan ? 1u : 0u);
         const int n_groups = b->n_groups;
         struct Group { uint32_t n0 = 0, passes = 0, polls = 0, polled = 0; int cur = 0; bool done = true, tail = false; HeavyArgsRaw H; uint32_t *blk[2]; };
@@ -893,6 +902,7 @@ extern "C" int bsx_batch_run_range(bsx_batch *b, uint32_t first_unit, uint32_t n
                 else if (shared_scan) bsx_launch_hscan_shared(A, q.H, s_scan, q.tail ? b->tail_grid_tasks : 0);
                 else bsx_launch_hscan(A, q.H, s_scan, q.tail ? b->tail_grid_tasks : 0);
                 HIP_TRY(hipGetLastError());
+                if (b->sector_stats) bsx_sector_pass(b->ref, s_scan);
                 HIP_TRY(hipEventRecord(b->scan_ev[b->scan_ev_used + 1], s_scan));
                 b->scan_ev_used += 2;
                 HIP_TRY(hipEventRecord(hw.ev_scan, s_scan));
@@ -1125,7 +1135,7 @@ extern "C" int bsx_batch_ctrl_clocks(bsx_batch *b, uint64_t out[24])
     if (!b || !out) return BSX_ERR_ARG;
     HIP_TRY(hipSetDevice(b->ref->device));
     HIP_TRY(stream_wait(b));
-    HIP_TRY(hipMemcpy(out, b->d_counters + 16, 192, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, b->d_counters + 24, 192, hipMemcpyDeviceToHost));   // (behind the BSX_N_COUNTERS counters: A.dbg_cat)
     return BSX_OK;
 }
 

@@ -37,7 +37,9 @@ inline unsigned bsx_pin_to_node(int node, unsigned n_cpus, unsigned skip = 0)
 {
     cpu_set_t have, want;
     if (node < 0 || sched_getaffinity(0, sizeof have, &have) != 0) return 0;
-    if ((unsigned)CPU_COUNT(&have) <= n_cpus + skip) return 0;   // nothing to gain: the quota does not bite
+    // nothing to gain where the quota does not bite: the mask IS the share (skip == 0), or it is too small to hold this lane's share behind `skip` others'
+    // (a mask that the lanes' shares partition exactly still pins its last lane: an unpinned one would float over the other lanes' CPUs)
+    if (skip == 0 ? (unsigned)CPU_COUNT(&have) <= n_cpus : (unsigned)CPU_COUNT(&have) < n_cpus + skip) return 0;
     char path[96], buf[4096];
     snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
     FILE *f = fopen(path, "r");

@@ -79,6 +79,8 @@ void bsx_launch_task_order(const HeavyArgsRaw &H, uint32_t shift, uint32_t n_bin
                            uint32_t *zero_blk, hipStream_t stream, uint32_t spread = 0, bool groups = false);   // spread: tasks inside one sub-range are dealt over the bins they cover by their read offset (k_hscan_same)
 void bsx_sig_hist_pass(const HeavyArgsRaw &H, hipStream_t stream);   // diagnostics, BSX_SIGHIST=1
 void bsx_sig_hist_report(void);
+void bsx_sector_pass(const bsx_ref *r, hipStream_t stream);   // diagnostics (build with -DBSX_SECTOR_STATS, run with BSX_SECTOR_STATS=1): distinct 64-byte sectors the group scan touches per launch
+void bsx_sector_report(void);
 size_t bsx_hstate_bytes(void);
 size_t bsx_htask_bytes(void);
 size_t bsx_htaskout_bytes(void);

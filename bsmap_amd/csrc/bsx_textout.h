@@ -5,6 +5,7 @@
 // mapping run in parallel: the file is extended to the end of the new range, the range is mapped, and the pieces are copied in by several
 // threads that split the BYTES evenly (whatever the pieces are), at whatever page offset the range starts.
 #pragma once
+#include <signal.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -18,9 +19,31 @@
 
 namespace bsx_textout {
 
-// the range map_write is copying into right now (one writer at a time), for a SIGBUS handler that has to tell a full output file
-// system from a fault on some other mapping (the memory-mapped input files)
-inline std::atomic<uintptr_t> g_map_lo{0}, g_map_hi{0};
+// the ranges map_write calls are copying into right now (several may run at once: the lanes' join copies every part on threads of its
+// own), for a SIGBUS handler that has to tell a full output file system from a fault on some other mapping (the memory-mapped input files)
+constexpr int MAP_SLOTS = 64;
+inline std::atomic<uintptr_t> g_map_lo[MAP_SLOTS], g_map_hi[MAP_SLOTS];
+inline bool in_mapped_output(uintptr_t a)
+{
+    for (int i = 0; i < MAP_SLOTS; i++) {
+        const uintptr_t lo = g_map_lo[i].load(std::memory_order_relaxed), hi = g_map_hi[i].load(std::memory_order_relaxed);
+        if (lo && a >= lo && a < hi) return true;
+    }
+    return false;
+}
+// SIGBUS: a full file system under a shared mapping of the output, or an input file truncated while it was read — said, then exit(1)
+inline void install_sigbus_handler()
+{
+    struct sigaction sa; memset(&sa, 0, sizeof(sa));
+    sa.sa_flags = SA_SIGINFO;
+    sa.sa_sigaction = [](int, siginfo_t *si, void *) {
+        static const char m_out[] = "write error on the output file (no space left?)\n", m_other[] = "bus error on a mapped file (an input file truncated while it was read?)\n";
+        const bool out = in_mapped_output((uintptr_t)si->si_addr);
+        ssize_t r = write(2, out ? m_out : m_other, (out ? sizeof(m_out) : sizeof(m_other)) - 1); (void)r;
+        _exit(1);
+    };
+    sigaction(SIGBUS, &sa, nullptr);
+}
 
 // copy the pieces [p_i, p_i + n_i) to consecutive offsets of fd starting at `at`, with up to `nthreads` threads (at least 1 MB each);
 // false: nothing was written (the file cannot be extended or mapped) - the caller falls back to pwrite
@@ -39,7 +62,8 @@ inline bool map_write(int fd, const std::vector<std::pair<const char *, size_t>>
     const size_t lead = (size_t)(at - base), len = lead + total;
     char *m = (char *)mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_SHARED, fd, base);
     if (m == MAP_FAILED) return false;
-    g_map_lo.store((uintptr_t)m, std::memory_order_relaxed); g_map_hi.store((uintptr_t)m + len, std::memory_order_relaxed);
+    int slot = -1;   // (a free slot of the registry; none free: the copy goes on, a fault would be reported as "a mapped file")
+    for (int i = 0; i < MAP_SLOTS && slot < 0; i++) { uintptr_t z = 0; if (g_map_lo[i].compare_exchange_strong(z, (uintptr_t)m)) { g_map_hi[i].store((uintptr_t)m + len, std::memory_order_relaxed); slot = i; } }
     std::vector<size_t> start(pieces.size() + 1, 0);
     for (size_t i = 0; i < pieces.size(); i++) start[i + 1] = start[i] + pieces[i].second;
     auto copy_range = [&](size_t lo, size_t hi) {
@@ -53,7 +77,7 @@ inline bool map_write(int fd, const std::vector<std::pair<const char *, size_t>>
     for (int t = 1; t < T; t++) th.emplace_back(copy_range, total * t / T, total * (t + 1) / T);
     copy_range(0, total / T);
     for (std::thread &x : th) x.join();
-    g_map_hi.store(0, std::memory_order_relaxed); g_map_lo.store(0, std::memory_order_relaxed);
+    if (slot >= 0) { g_map_hi[slot].store(0, std::memory_order_relaxed); g_map_lo[slot].store(0, std::memory_order_relaxed); }
     munmap(m, len);
     return true;
 }

@@ -19,7 +19,7 @@ def gather_stats(elapsed_s, counters, dist=None, device="cpu"):
     """all-gather (elapsed, counters...) of every rank; returns (max elapsed over ranks, summed counters, per-rank table)"""
     import torch
     v = torch.tensor([float(elapsed_s)] + [float(x) for x in counters], dtype=torch.float64, device=device)
-    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist is not None and dist.is_initialized():   # (also at world size 1: the collective is the path — a launcher-started single rank runs it, too)
         parts = [torch.zeros_like(v) for _ in range(dist.get_world_size())]
         dist.all_gather(parts, v)
         table = torch.stack(parts).cpu().numpy()

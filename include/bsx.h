@@ -148,8 +148,9 @@ typedef struct bsx_pair {
  * speculatively), 8 their reference words (as 2), 9 / 10 how many of them stopped after the first word / went through all
  * five, 11-14 the share of 0-3 that the main kernel (k_align) did itself — units it did not hand to the heavy pipeline —, so
  * that each kernel's algorithmic bytes can be recomputed from the counters, 15 the part of 7 that was evaluated in groups of two and more
- * tasks over one window and read offset (k_hscan_same: one fetch and shift of the candidates' reference for up to 16 reads; k_hscan_multi with BSX_MULTI=1) */
-#define BSX_N_COUNTERS 16
+ * tasks over one window and read offset (k_hscan_same: one fetch and shift of the candidates' reference for up to 16 reads), 16 records flagged BSX_F_LIMIT
+ * (single-end RRBS reads that matched more than 2^18 distinct places: the one capacity the reference does not have — 0 on every workload seen) */
+#define BSX_N_COUNTERS 17
 
 int bsx_batch_create(bsx_ref *r, uint32_t max_units, int paired, bsx_batch **out);
 void bsx_batch_destroy(bsx_batch *b);

@@ -180,6 +180,53 @@ def test_whole_batch_equals_oracle_c3(big, oracle, oracle_wgbs):
     assert [int(x) for x in cnt[:4]] == ocnt
 
 
+def test_blocks_of_a_bench_sized_batch_equal_the_oracle(big, oracle, oracle_wgbs):
+    """bench.py's own step — 2^22 pairs, read seed 3, unit ids from 0, the pools the bench gives it, work counters off as in the timed region — run as
+    ONE batch (its deferred units are grouped as in the bench: 37 K of them), and 32 blocks of 4 096 consecutive units spread over the batch (2^17 units)
+    re-aligned by the oracle against its own reference + index: every record field.  (Round 4 validated the 2^20-pair bench batch with a tool outside
+    the suite, profiles/r04h_validate_full_c3.json.)"""
+    import wholebatch as W
+    ref = big[0]
+    if oracle_wgbs.base is None:
+        oracle_wgbs.check(ref, "c3")
+    oref = oracle_wgbs.ref_for(KW)
+    NB, BLK, NBLK = 1 << 22, 4096, 32
+    L = B.lib()
+    u, t = B.default_heavy_limits(B.make_params(**KW), NB, True)
+    L.bsx_set_heavy_limits(u, t)
+    try:
+        pa = B.PairAlign(ref, NB).set_work_counters(False)
+    finally:
+        L.bsx_set_heavy_limits(0, 0)
+    try:
+        pa.synth_reads(NB, 144, seed=3)
+        t0 = time.time()
+        pa.Do_Batch()
+        t_gpu = time.time() - t0
+        out, ca, cb, npairs = pa.results()
+        heavy = int(pa.heavy_units())
+        b1, o1 = pa.download_reads(0)
+        b2, o2 = pa.download_reads(1)
+    finally:
+        pa.close()
+    bad_all, t_cpu, placed = {}, 0.0, 0
+    for k in range(NBLK):
+        lo = k * (NB // NBLK) + 17 * k   # (not on any power-of-two grid)
+        hi = lo + BLK
+        t0 = time.time()
+        ores, _ = oracle.pe_batch(oref, b1[int(o1[lo]):int(o1[hi])], (o1[lo:hi + 1] - o1[lo]).copy(), b2[int(o2[lo]):int(o2[hi])], (o2[lo:hi + 1] - o2[lo]).copy(),
+                                  first_index=lo, threads=W.usable_cpus())
+        t_cpu += time.time() - t0
+        bad, info = W.compare_pe(ores, out[lo:hi], ca[lo:hi], cb[lo:hi], npairs[lo:hi], KW["v"] + 1)
+        placed += info["paired_out"]
+        for f, n in bad.items():
+            bad_all[f] = bad_all.get(f, 0) + n
+    W.record("bench_step_c3", dict(units_in_batch=NB, units_compared=BLK * NBLK, blocks=NBLK, heavy_units=heavy, paired_out=placed, oracle_s=round(t_cpu, 1), do_batch_s=round(t_gpu, 3),
+                                   mismatching_fields=bad_all, options=KW, work_counters=False, reference="oracle-built from the genome text"))
+    assert heavy > NB // 200 and placed > 0.95 * BLK * NBLK
+    assert not bad_all, bad_all
+
+
 def test_pair_geometry(big):
     """the sampler draws fragments of 50..480 nt from one chromosome: reported pairs must respect that geometry"""
     ref, pa, out, ca, cb, npairs, cnt = big

@@ -716,3 +716,62 @@ def test_rrbs_shared_scan_runs_and_survivor_overflow(oracle, tmp_path):
         B.lib().bsx_set_heavy_threshold(0)
     gref.close()
     oref.free()
+
+
+def test_rrbs_capacity_limit_is_flagged_and_counted(oracle, tmp_path, monkeypatch):
+    """BSX_F_LIMIT (include/bsx.h): a single-end RRBS read that remembers more than the set's capacity of distinct in-threshold coordinates (2^18; the
+    reference's std::set is unbounded, align.cpp:274) is flagged and counted (counter 16), nothing is written past the slab, and every OTHER read of the
+    batch still equals the oracle's.  Forced with a 64-key set (BSX_KCAP) on the tandem families of the test above, undeferred; with the real capacity
+    the same batch has no flagged read."""
+    rng = np.random.default_rng(78)
+    unit = td.random_seq(rng, 100, 0.5)
+    fam = []
+    for _ in range(600):
+        cp = unit.copy()
+        mut = rng.random(100) < 0.004
+        cp[mut] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, int(mut.sum()))]
+        fam.append(b"CCGG" + cp.tobytes())
+    flank = lambda n: td.random_seq(rng, n, 0.5).tobytes()
+    g = [("chr1", (flank(20_000) + b"".join(fam) + b"CCGG" + flank(20_000)).decode()), ("chr2", td.make_genome(seed=4, chr_lens=(60_000,), cpg_sites=150)[0][1])]
+    fa = str(tmp_path / "g.fa")
+    td.write_fasta(fa, g)
+    kw = dict(D="C-CGG", v=2, S=7, r=1, w=1000, m=40, x=220)
+    oref = oracle.OracleRef(oracle.make_params(**kw), fasta_path=fa)
+    reads = td.make_rrbs_reads(g, 600, 75, seed=6, sub_rate=0.004)
+    sb, so = oracle.pack_reads([r["seq"] for r in reads])
+    ores, ocnt = oracle.se_batch(oref, sb, so, threads=8)
+    B.lib().bsx_set_heavy_threshold(1 << 30)   # the main kernel's own set is the one with the capacity flag
+    try:
+        res = {}
+        for cap in ("64", None):
+            if cap:
+                monkeypatch.setenv("BSX_KCAP", cap)
+            else:
+                monkeypatch.delenv("BSX_KCAP")
+            gref = B.RefSeq(B.make_params(**kw)).Run_ConvertBinseq(fasta_path=fa).CreateIndex()
+            sa = B.SingleAlign(gref, len(reads))
+            sa.ImportBatchReads((sb, so)).Do_Batch()
+            hits, cc = sa.results()
+            res[cap] = (hits.copy(), cc.copy(), sa.counters().copy())
+            sa.close()
+            gref.close()
+    finally:
+        B.lib().bsx_set_heavy_threshold(0)
+    hits, cc, cnt = res["64"]
+    flagged = (hits["flags"] & 4) != 0
+    assert 50 < int(flagged.sum()) < len(reads) and int(cnt[16]) == int(flagged.sum())
+    ok = (ores["filtered"] == 0) & ~flagged
+    nclass = kw["v"] + 1
+    assert np.array_equal(ores["n_hit"][ok][:, :nclass], cc["n_hit"][ok][:, :nclass]) and np.array_equal(ores["n_chit"][ok][:, :nclass], cc["n_chit"][ok][:, :nclass])
+    has = ok & (ores["n_best"] > 0)
+    for f in ("chr", "loc", "best_class"):
+        assert np.array_equal(ores[f][has], hits[f][has]), f
+    hits, cc, cnt = res[None]   # the shipped capacity: nothing flagged, everything equal
+    assert int(cnt[16]) == 0 and not ((hits["flags"] & 4) != 0).any()
+    ok = ores["filtered"] == 0
+    assert np.array_equal(ores["n_hit"][ok][:, :nclass], cc["n_hit"][ok][:, :nclass])
+    has = ok & (ores["n_best"] > 0)
+    for f in ("chr", "loc", "best_class"):
+        assert np.array_equal(ores[f][has], hits[f][has]), f
+    assert _counters_off() or [int(x) for x in cnt[:4]] == ocnt
+    oref.free()

@@ -36,7 +36,10 @@ def compare_se(ores, hits, cc, nclass):
     for f in ("chr", "loc", "best_class"):
         _chk(bad, f, ores[f][has], hits[f][has])
     _chk(bad, "chain", ores["chain"][has] != 0, (hits["flags"][has] & 2) != 0)
-    return bad, {"placed": int(has.sum()), "filtered": int((~ok).sum())}
+    n_limit = int(((hits["flags"] & 4) != 0).sum())   # BSX_F_LIMIT: the one capacity the reference does not have (include/bsx.h) — never reached
+    if n_limit:
+        bad["BSX_F_LIMIT"] = n_limit
+    return bad, {"placed": int(has.sum()), "filtered": int((~ok).sum()), "flagged_BSX_F_LIMIT": n_limit}
 
 
 def compare_pe(ores, out, ca, cb, npairs, nclass):
@@ -87,7 +90,7 @@ def run_oracle(O, oref, al, pe, quals, K, leak_mode=0):
     return res, [int(x) for x in cnt], time.time() - t0
 
 
-ROUND = "r04"
+ROUND = "r05"
 
 
 def record(name, info):
