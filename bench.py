@@ -627,7 +627,7 @@ def fabric_requests(mode, work_counters, B_, ms_per_step, serial_ms, gather_rate
     if not got or not gather_rate:
         return None
     f, j = got
-    scale = B_ / float(j.get("units_per_step", B_))
+    scale = B_ / float(j.get("units_per_step") or B_)
     per = {n: v["derived"]["fabric_read_requests_per_step"] * scale for n, v in j["kernels"].items() if "fabric_read_requests_per_step" in v["derived"]}
     tot = sum(per.values())
     t_ms = tot / (gather_rate * 1e9) * 1e3

@@ -74,7 +74,10 @@ def main():
     out["mode"] = os.environ.get("BSX_PROFILE_MODE", "pe")
     out["work_counters"] = int(os.environ.get("BSX_PROFILE_WORK_COUNTERS", "0"))
     out["steps_in_pass"] = int(os.environ.get("BSX_PROFILE_STEPS", "3"))          # warm-up + timed steps of each counter pass: counters are sums over all of them
-    out["units_per_step"] = int(os.environ.get("BSX_PROFILE_UNITS", str(1 << 20)))
+    try:   # units per step of the profiled run: given, or the mode's default step size (what `bench.py --profile-serial` runs without --pairs-per-step)
+        out["units_per_step"] = int(os.environ["BSX_PROFILE_UNITS"]) if os.environ.get("BSX_PROFILE_UNITS") else bench.mode_defaults(out["mode"])[0]
+    except Exception:
+        out["units_per_step"] = None
     out["scan_kernel"] = os.environ.get("BSX_SAME", "1")
     merged = collections.defaultdict(dict)
     for d in dirs:
