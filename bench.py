@@ -58,7 +58,8 @@ RRBS_POOLS = "110000,1400000"   # starting pools of an RRBS batch when three are
 # units per step, batches in flight and starting pools by mode (measured: profiles/r05d_*).  A larger device batch gives the scan kernel larger
 # groups (more reads over one window and offset per pass): C3 24.3 M reads/s at 2^20 pairs per step with three in flight, 27.0 M at 2^22 with two.
 # (profiles/r05e: C2 16.8 M at 2^20 x 3, 18.9 M at 2^22 x 2; C5 9.2 M at 2^20 x 3, 10.5 M at 2^22 x 3; C4 8.6 M at 2^20 x 3, 9.4 M at 2^22 x 3)
-MODE_DEFAULTS = {"pe": (1 << 22, 2, None), "se": (1 << 22, 2, None), "trim": (1 << 22, 3, None), "rrbs": (1 << 22, 3, RRBS_POOLS)}
+# (gpurun_out/r05o, final scan kernel: C3 at 2^22 pairs 299-301 ms per step with two batches in flight, 285.9 with three; 2^22 x 3 plans 0.87 of the device)
+MODE_DEFAULTS = {"pe": (1 << 22, 3, None), "se": (1 << 22, 3, None), "trim": (1 << 22, 3, None), "rrbs": (1 << 22, 3, RRBS_POOLS)}
 
 
 def mode_defaults(mode):
