@@ -70,9 +70,7 @@ def mode_defaults(mode):
 
 def transfer_batches(nfl, rrbs, ref_bytes, batch_bytes):
     """device batches of the PCIe-inclusive leg: two more than the resident run keeps in flight (a batch that is moving data does not compute:
-    3 / 4 batches 0.93 / 0.96 of the resident rate at 2^20 pairs per step), at most 4, and no more than fit 0.85 of the device; RRBS one (74 GB each)"""
-    if rrbs:
-        return 1
+    3 / 4 batches 0.93 / 0.96 of the resident rate at 2^20 pairs per step), at most 4, and no more than fit 0.85 of the device (RRBS: three of 62 GB)"""
     return int(max(1, min(nfl + 2, 4, (0.85 * HBM_BYTES - ref_bytes) // batch_bytes)))
 
 
