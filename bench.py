@@ -59,7 +59,10 @@ RRBS_POOLS = "110000,1400000"   # starting pools of an RRBS batch when three are
 # groups (more reads over one window and offset per pass): C3 24.3 M reads/s at 2^20 pairs per step with three in flight, 27.0 M at 2^22 with two.
 # (profiles/r05e: C2 16.8 M at 2^20 x 3, 18.9 M at 2^22 x 2; C5 9.2 M at 2^20 x 3, 10.5 M at 2^22 x 3; C4 8.6 M at 2^20 x 3, 9.4 M at 2^22 x 3)
 # (gpurun_out/r05o, final scan kernel: C3 at 2^22 pairs 299-301 ms per step with two batches in flight, 285.9 with three; 2^22 x 3 plans 0.87 of the device)
-MODE_DEFAULTS = {"pe": (1 << 22, 3, None), "se": (1 << 22, 3, None), "trim": (1 << 22, 3, None), "rrbs": (1 << 22, 3, RRBS_POOLS)}
+# With the context prefilter (23.6 GB of context words beside the index) the main kernel is 1.7 x faster and a third batch in flight no longer pays for C3
+# (gpurun_out/r05s: 242.0-244.2 ms per step with two, 241.9 with three) — and 2^22 pairs x 3 would plan 0.95 of the device.
+# (gpurun_out/r05t: C5 10.7 M reads/s at 2^22 x 2, 10.9 M at 3 x 2^20 x 3, 10.1 M at 2^21 x 3; C2 20.8 M at 2^22 x 2, 22.1 M at 2^22 x 3)
+MODE_DEFAULTS = {"pe": (1 << 22, 2, None), "se": (1 << 22, 3, None), "trim": (3 << 20, 3, None), "rrbs": (1 << 22, 3, RRBS_POOLS)}
 
 
 def mode_defaults(mode):
@@ -88,6 +91,8 @@ def memory_plan(B, params, pe, B_, steps, warmup, nfl, n_entries, transfers, rrb
     # reference: packed copy + plane copy (4 bits per nt in all), bucket offsets and forward counts, entries (RRBS: {tag, loc} pairs + group offsets)
     K = int(params.total_kmers)
     ref_b = genome_bp / 16 * 4 * 2 * 2 + 8.0 * K + n_entries * (8 if rrbs else 4) + (K * 32 * 4 if rrbs else 0)
+    if not rrbs and int(params.index_interval) <= 4 and os.environ.get("BSX_CTX") != "0":
+        ref_b += 16.0 * n_entries   # the entries' context words (the main kernel's prefilter)
     build_b = 0 if rrbs else n_entries * 8 * 2 + n_entries * 4   # index build: key/value double buffers of the radix sort (transient)
     nt = transfer_batches(nfl, rrbs, ref_b, tot(small)) if transfers else 0
     # (the serial / counted replays and the CPU baseline's downloads use the one timed batch that is kept; it is closed before the PCIe-inclusive leg creates its own)

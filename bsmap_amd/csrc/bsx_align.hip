@@ -124,6 +124,7 @@ struct MateLds {
     uint32_t stale_key[2][16];    // seed_array / cseed_array entries [noff, noff+16) left behind by earlier, longer reads
     uint8_t stale_so[2];          // seed_start_offset / cseed_start_offset of the last read that set them
     MateU u, u2;                  // the read's wave-uniform state (Mate::u points here); u2: the absent second mate of a single-end unit
+    __attribute__((aligned(16))) uint32_t fl[4][8];   // context prefilter (wave_scan_range<.., CTX>): per index phase the read's 32 nt left and right of the seed and their T-masks
 };
 
 template <bool PE> struct WaveLds { MateLds mate[PE ? 2 : 1]; };
@@ -805,7 +806,12 @@ __device__ __forceinline__ CandList make_list(const DevParams &P, const BlockLds
 //   re-count the part of a pre-scanned task that precedes an event).
 // Returns 0 = range finished, 1 = range finished and the threshold was lowered on the way, 2 = SnpAlign returns.
 // PE: instantiated for a paired batch (only picks the form of the single-end RRBS fragment filter's site search, see ccgg_seglen)
-template <bool COUNT_ONLY, int BSX_SCAN_NB, bool PE = true>
+// CTX (round 5, the main kernel with the work counters off): the index keeps, beside every entry, the 32 reference nt left and right of its seed
+// (DevParams::ctx, 16 bytes per entry, bsx_index.hip).  A candidate is first compared with the read's own flanks of that seed — data that comes with the
+// coalesced entry load — and only candidates within the threshold THERE gather their reference words: a candidate that fails on a part of the read fails on
+// the whole (the prefilter only ever removes candidates the full count would reject; the threshold can only fall while a list is walked), so every hit list is
+// unchanged, and four candidates in five never touch the reference.  The work counters need every candidate's first-word count: they take the plain path.
+template <bool COUNT_ONLY, int BSX_SCAN_NB, bool PE = true, bool CTX = false>
 __device__ int wave_scan_range(const DevParams &P, const BlockLds &BL, const MateLds &L, Mate &M, const Slab &SL, const CandList &cl, int orient,
                                int seg, int mode, uint32_t c_begin, uint32_t c_end, uint32_t thres_fixed, int lane, Counters &C)
 {
@@ -826,13 +832,34 @@ __device__ int wave_scan_range(const DevParams &P, const BlockLds &BL, const Mat
     // kernel is a chain of such round trips (SQ_WAIT_ANY 0.76 of its wave cycles).  e_pf: the prefetched entry, hs_pf: its h << 1 | strand.
     constexpr bool PREFETCH = BSX_SCAN_NB == 1 && BSX_MAIN_PREFETCH;
     // (a macro, not a lambda: a closure over `cl` put the whole list descriptor into scratch — 1.1 KB per lane)
+    // (hs: h << 5 | sub-range: its lowest bit is the strand copy, the others the index phase)
 #define BSX_LOCATE(idx_, e_idx_, hs_) do { e_idx_ = 0; hs_ = 0; \
         for (int s_ = 0; s_ < cl.nsub; s_++) { \
             const uint32_t ps_ = rl(cl.sub_pre, s_), ns_ = rl(cl.sub_n, s_); \
-            if ((idx_) >= ps_ && (idx_) < ps_ + ns_) { e_idx_ = rl(cl.sub_base, s_) + ((idx_) - ps_); hs_ = (rl(cl.sub_h, s_) << 1) | (uint32_t)(s_ & 1); } \
+            if ((idx_) >= ps_ && (idx_) < ps_ + ns_) { e_idx_ = rl(cl.sub_base, s_) + ((idx_) - ps_); hs_ = (rl(cl.sub_h, s_) << 5) | (uint32_t)(s_ & 31); } \
         } } while (0)
+    constexpr bool USE_CTX = CTX && PREFETCH && !COUNT_ONLY;
+    uint32_t *flt = const_cast<uint32_t *>(&L.fl[0][0]);
+    if (USE_CTX) {   // the read's flanks of this list's seed, per index phase (at most four: the context is only built for -I <= 4): lane 4 ph + j -> word j of phase ph
+        if (lane < 16) {
+            const int ph = lane >> 2, j = lane & 3;
+            const int o = -__shfl((int)cl.sub_h, min(2 * ph, cl.nsub - 1));      // the seed's offset in the read (lane s of the list descriptor holds sub-range s)
+            const int x = o + (j < 2 ? 16 * j - 32 : 16 * j - 16);               // first nt of flank word j: [o - 32, o) and [o + 16, o + 48)
+            const int i = x >> 4, sh = x & 15;
+            const uint32_t *rw_ = L.w[orient], *rm_ = L.m[orient];
+            const uint32_t w0 = (i >= 0 && i < 10) ? rw_[i] : 0u, w1 = (i + 1 >= 0 && i + 1 < 10) ? rw_[i + 1] : 0u;
+            const uint32_t m0 = (i >= 0 && i < 10) ? rm_[i] : 0u, m1 = (i + 1 >= 0 && i + 1 < 10) ? rm_[i + 1] : 0u;
+            const uint32_t f = sh ? __builtin_amdgcn_alignbit(w0, w1, 32u - 2u * (uint32_t)sh) : w0, mk = sh ? __builtin_amdgcn_alignbit(m0, m1, 32u - 2u * (uint32_t)sh) : m0;
+            flt[ph * 8 + j] = f; flt[ph * 8 + 4 + j] = bsx_tmask(f, mk);
+        }
+        wave_fence();
+    }
     uint32_t e_pf = 0, hs_pf = 0;
-    if (PREFETCH && !P.rrbs && c_begin < c_end) { uint32_t ei; const uint32_t i0_ = c_begin + (uint32_t)lane; BSX_LOCATE(i0_, ei, hs_pf); e_pf = ldm1(P.entries + ei); }
+    U4 c_pf; c_pf.a = c_pf.b = c_pf.c = c_pf.d = 0;
+    if (PREFETCH && !P.rrbs && c_begin < c_end) {
+        uint32_t ei; const uint32_t i0_ = c_begin + (uint32_t)lane; BSX_LOCATE(i0_, ei, hs_pf); e_pf = ldm1(P.entries + ei);
+        if (USE_CTX) c_pf = ldm4(P.ctx + 4 * (size_t)ei);
+    }
     for (uint32_t cs = c_begin; cs < c_end; cs += 64 * BSX_SCAN_NB) {
       uint32_t p_[BSX_SCAN_NB], aux_[BSX_SCAN_NB];  // aux: WGBS strand / RRBS chromosome id
       bool valid_[BSX_SCAN_NB];
@@ -854,9 +881,19 @@ __device__ int wave_scan_range(const DevParams &P, const BlockLds &BL, const Mat
             }
         } else if (PREFETCH) {
             const uint32_t e = e_pf, hs = hs_pf;
+            const U4 cx = c_pf;
             strand = hs & 1u;
-            if (valid) p = e + (uint32_t)((int32_t)hs >> 1);
-            if (cs + 64 < c_end) { uint32_t ei; const uint32_t in_ = idx + 64u; BSX_LOCATE(in_, ei, hs_pf); e_pf = ldm1(P.entries + ei); }   // (a lane behind the list's end reads entry 0: never used)
+            if (cs + 64 < c_end) {   // (a lane behind the list's end reads entry 0: never used)
+                uint32_t ei; const uint32_t in_ = idx + 64u; BSX_LOCATE(in_, ei, hs_pf); e_pf = ldm1(P.entries + ei);
+                if (USE_CTX) c_pf = ldm4(P.ctx + 4 * (size_t)ei);
+            }
+            if (USE_CTX && valid) {   // the read's flanks of the seed against the entry's context: within the threshold there, or no candidate at all
+                const uint4 *fr = reinterpret_cast<const uint4 *>(flt + ((hs >> 1) & 3u) * 8u);
+                const uint4 f = fr[0], t = fr[1];
+                const uint32_t cn = __popc(bsx_mismatch_hi(f.x, t.x, cx.a)) + __popc(bsx_mismatch_hi(f.y, t.y, cx.b)) + __popc(bsx_mismatch_hi(f.z, t.z, cx.c)) + __popc(bsx_mismatch_hi(f.w, t.w, cx.d));
+                valid = cn <= M.u->snp_thres;
+            }
+            if (valid) p = e + (uint32_t)((int32_t)hs >> 5);
         } else {
             uint32_t e_idx = 0, h = 0;
             for (int s = 0; s < cl.nsub; s++) {
@@ -868,6 +905,7 @@ __device__ int wave_scan_range(const DevParams &P, const BlockLds &BL, const Mat
         }
         p_[u] = p; aux_[u] = P.rrbs ? rchr : strand; valid_[u] = valid;
       }
+      if (USE_CTX && BSX_SCAN_NB == 1 && !bsx_ballot(valid_[0])) continue;   // no candidate of the chunk got past its context: nothing to gather, nothing to replay
 #pragma unroll
       for (int u = 0; u < BSX_SCAN_NB; u++)
         r0_[u] = ldm4(((P.rrbs ? (aux_[u] & 1) : aux_[u]) ? P.crefcat : P.refcat) + ((p_[u] - 1) >> 4));
@@ -934,7 +972,7 @@ __device__ int wave_scan_range(const DevParams &P, const BlockLds &BL, const Mat
 #endif
 // SnpAlign (align.cpp:168-347) in the main kernel.  A WGBS list of heavy_threshold candidates or more sets M.u->defer and
 // returns: the unit is redone from scratch by the heavy pipeline, which scans such lists with the whole chip.
-template <bool EXACT, bool PE>
+template <bool EXACT, bool PE, bool CTX = false>
 __device__ __forceinline__ void snp_align(const DevParams &P, const BlockLds &BL, const MateLds &L, Mate &M, const Slab &SL, int mode, int lane,
                           Counters &C, uint32_t heavy_threshold)
 {
@@ -944,19 +982,19 @@ __device__ __forceinline__ void snp_align(const DevParams &P, const BlockLds &BL
         const CandList cl = make_list<EXACT>(P, BL, L, M, orient, seg, lane);
         if (heavy_threshold && cl.total >= heavy_threshold) { M.u->defer = 1; return; }
         int r_;   // (inlined here whatever the inliner thinks of its size: as a call it costs the main kernel 1.1 KB of stack per lane)
-        [[clang::always_inline]] r_ = wave_scan_range<false, BSX_MAIN_NB, PE>(P, BL, L, M, SL, cl, orient, seg, mode, 0, cl.total, 0, lane, C);
+        [[clang::always_inline]] r_ = wave_scan_range<false, BSX_MAIN_NB, PE, CTX>(P, BL, L, M, SL, cl, orient, seg, mode, 0, cl.total, 0, lane, C);
         if (r_ == 2) { wave_fence(); return; }
     }
     wave_fence();
 }
 
 // SingleAlign::RunAlign (align.cpp:435-452) after packing/planning
-template <bool EXACT, bool PE>
+template <bool EXACT, bool PE, bool CTX = false>
 __device__ __forceinline__ void run_align_single(const DevParams &P, const BlockLds &BL, const MateLds &L, Mate &M, const Slab &SL, int lane, Counters &C,
                                  uint32_t heavy_threshold)
 {
     for (int i = 0; i < M.u->seedseg; i++) {
-        snp_align<EXACT, PE>(P, BL, L, M, SL, i, lane, C, heavy_threshold);
+        snp_align<EXACT, PE, CTX>(P, BL, L, M, SL, i, lane, C, heavy_threshold);
         if (M.u->defer) return;
         if (!P.rrbs) {
             const u64 nz = bsx_ballot(M.cnt_reg != 0 && (lane & 15) <= i && lane < 32);
@@ -1181,7 +1219,7 @@ __device__ __forceinline__ UnitSlabs carve_slab(uint8_t *slab, uint32_t nclass, 
 //                    the tail entries from the reads that wrote them -> LeakRec for the align kernels
 //   k_leak_final   : the state behind the stream's last read (bsx_batch_get_leak_state: the next batch starts from it)
 #define LEAK_BLK 4096
-__device__ void init_block_lds(const DevParams &P, BlockLds &BL, int tid, int nthreads);
+__device__ __forceinline__ void init_block_lds(const DevParams &P, BlockLds &BL, int tid, int nthreads);   // (inlined by force: the main kernel has to stay a leaf)
 #define LEAK_KEYS 160
 struct LeakState { uint32_t key[2][2][LEAK_KEYS]; uint32_t so[2][2]; };  // [mate][orientation]
 
@@ -1456,7 +1494,7 @@ __device__ void unit_finish(const AlignArgs &A, const MateLds &LA, const MateLds
 // UnitLds: the wave-uniform per-unit state that is not in MateU — slab pointers and the work counters with their value at the
 // unit's start (restored when the unit is deferred); in LDS for the same reason (the main kernel is short of scalar registers)
 struct UnitLds { UnitSlabs U; Counters C, C0; };
-template <bool PE, bool EXACT>
+template <bool PE, bool EXACT, bool CTX = false>
 __device__ __forceinline__ bool process_unit(const AlignArgs &A, const BlockLds &BL, MateLds &LA, MateLds &LB, uint32_t unit, uint8_t *slab, int lane, UnitLds &UL,
                              u64 &n_aligned, u64 &n_aligned_pairs)
 {
@@ -1476,23 +1514,23 @@ __device__ __forceinline__ bool process_unit(const AlignArgs &A, const BlockLds 
     if (PE && !MA.u->filtered && !MB.u->filtered) {
         const int maxi = max(MA.u->max_snp, MB.u->max_snp);  // PairAlign::RunAlign (pairs.cpp:163-172)
         for (int i = 0; i <= maxi && !paired && !defer; i++) {
-            if (i < MA.u->seedseg) snp_align<EXACT, PE>(P, BL, LA, MA, U.SA, i, lane, C, hthr);
-            if (!MA.u->defer && i < MB.u->seedseg) snp_align<EXACT, PE>(P, BL, LB, MB, U.SB, i, lane, C, hthr);
+            if (i < MA.u->seedseg) snp_align<EXACT, PE, CTX>(P, BL, LA, MA, U.SA, i, lane, C, hthr);
+            if (!MA.u->defer && i < MB.u->seedseg) snp_align<EXACT, PE, CTX>(P, BL, LB, MB, U.SB, i, lane, C, hthr);
             if (MA.u->defer || MB.u->defer) { defer = true; break; }
             int np_;
             [[clang::always_inline]] np_ = pair_level_post(P, MA, MB, U, pcnt_reg, i, lane);
             if (np_ > 0) paired = i + 1;
         }
     } else {
-        if (!MA.u->filtered) { run_align_single<EXACT, PE>(P, BL, LA, MA, U.SA, lane, C, hthr); defer = MA.u->defer; }
-        if (PE && !defer && !MB.u->filtered) { run_align_single<EXACT, PE>(P, BL, LB, MB, U.SB, lane, C, hthr); defer = MB.u->defer; }
+        if (!MA.u->filtered) { run_align_single<EXACT, PE, CTX>(P, BL, LA, MA, U.SA, lane, C, hthr); defer = MA.u->defer; }
+        if (PE && !defer && !MB.u->filtered) { run_align_single<EXACT, PE, CTX>(P, BL, LB, MB, U.SB, lane, C, hthr); defer = MB.u->defer; }
     }
     if (defer) { forget_keys(MA, U.SA, lane); if (PE) forget_keys(MB, U.SB, lane); C = C0; return true; }
     [[clang::always_inline]] unit_finish<PE>(A, LA, LB, MA, MB, U, pcnt_reg, paired, unit, lane, n_aligned, n_aligned_pairs);   // (the main kernel stays a leaf: a call costs it a kilobyte of stack per lane)
     return false;
 }
 
-__device__ void init_block_lds(const DevParams &P, BlockLds &BL, int tid, int nthreads)
+__device__ __forceinline__ void init_block_lds(const DevParams &P, BlockLds &BL, int tid, int nthreads)
 {
     for (int i = tid; i < 256; i += nthreads) ((uint8_t *)BL.prof)[i] = ((const uint8_t *)P.profile_a)[i];
     if (P.n_chr <= BSX_LDS_CHR) {
@@ -1501,7 +1539,7 @@ __device__ void init_block_lds(const DevParams &P, BlockLds &BL, int tid, int nt
     }
 }
 
-__device__ void flush_counters(const AlignArgs &A, const Counters &C, u64 n_units_done, u64 n_aligned, u64 n_aligned_pairs, bool main_kernel = false)
+__device__ __forceinline__ void flush_counters(const AlignArgs &A, const Counters &C, u64 n_units_done, u64 n_aligned, u64 n_aligned_pairs, bool main_kernel = false)
 {
     atomicAdd((u64 *)&A.counters[0], C.n_lookup); atomicAdd((u64 *)&A.counters[1], C.n_cand);
     atomicAdd((u64 *)&A.counters[2], C.sum_w); atomicAdd((u64 *)&A.counters[3], C.n_orient);
@@ -1520,7 +1558,7 @@ __device__ void flush_counters(const AlignArgs &A, const Counters &C, u64 n_unit
 #define BSX_WAVES_PER_EU_PE 5  /* round 4: 96 VGPRs, 112 B of scratch per lane; five waves per SIMD of a kernel that waits on memory 76 % of its cycles: 112.4-113.4 against 114.6-114.7 ms per step (4 waves: 128 VGPRs, 56 B) */
 #endif
 // main kernel: persistent waves, one unit per wave at a time
-template <bool PE, bool EXACT>
+template <bool PE, bool EXACT, bool CTX = false>
 __global__ __launch_bounds__(256, PE ? BSX_WAVES_PER_EU_PE : BSX_WAVES_PER_EU_SE) void k_align(AlignArgs A)
 {
     __shared__ BlockLds BL;
@@ -1544,7 +1582,7 @@ __global__ __launch_bounds__(256, PE ? BSX_WAVES_PER_EU_PE : BSX_WAVES_PER_EU_SE
         if (A.unit_list) unit = rfl(A.unit_list[unit]);  // redo run: the units named by the list
         const u64 t_begin = A.dbg_cycles ? __builtin_readcyclecounter() : 0;
         uint8_t *slab = A.scratch + (size_t)(A.debug ? unit : slot) * A.slab_bytes;
-        const bool deferred = process_unit<PE, EXACT>(A, BL, LA, LB, unit, slab, lane, UL, n_aligned, n_aligned_pairs);
+        const bool deferred = process_unit<PE, EXACT, CTX>(A, BL, LA, LB, unit, slab, lane, UL, n_aligned, n_aligned_pairs);
         if (deferred) { if (lane == 0) A.heavy_list[atomicAdd(A.heavy_count, 1u)] = unit; }
         else n_units_done++;
         if (A.dbg_cycles && lane == 0) A.dbg_cycles[unit] = (uint32_t)min((u64)0xffffffffull, (u64)__builtin_readcyclecounter() - t_begin);
@@ -3006,6 +3044,9 @@ void bsx_launch_align(const AlignArgs &A, int paired, int grid_blocks, hipStream
     if (A.leak_exact) {
         if (paired) hipLaunchKernelGGL((k_align<true, true>), dim3(grid_blocks), dim3(256), 0, stream, A);
         else hipLaunchKernelGGL((k_align<false, true>), dim3(grid_blocks), dim3(256), 0, stream, A);
+    } else if (A.P.ctx && !A.work_counters) {   // the context prefilter: with the index's flank words, and only where nobody reads the work counters
+        if (paired) hipLaunchKernelGGL((k_align<true, false, true>), dim3(grid_blocks), dim3(256), 0, stream, A);
+        else hipLaunchKernelGGL((k_align<false, false, true>), dim3(grid_blocks), dim3(256), 0, stream, A);
     } else if (paired) hipLaunchKernelGGL((k_align<true, false>), dim3(grid_blocks), dim3(256), 0, stream, A);
     else hipLaunchKernelGGL((k_align<false, false>), dim3(grid_blocks), dim3(256), 0, stream, A);
 }

@@ -130,7 +130,7 @@ extern "C" void bsx_ref_destroy(bsx_ref *r)
     if (!r) return;
     (void)hipSetDevice(r->device);
     for (void *q : {(void *)r->d_refcat, (void *)r->d_refplane, (void *)r->d_anchor, (void *)r->d_chr_size, (void *)r->d_rc_offset,
-                    (void *)r->d_bucket_off, (void *)r->d_bucket_nfwd, (void *)r->d_entries, (void *)r->d_sites, (void *)r->d_site_off, (void *)r->d_rrbs_goff, (void *)r->d_site_bin, (void *)r->d_site_bin_off})
+                    (void *)r->d_bucket_off, (void *)r->d_bucket_nfwd, (void *)r->d_entries, (void *)r->d_ctx, (void *)r->d_sites, (void *)r->d_site_off, (void *)r->d_rrbs_goff, (void *)r->d_site_bin, (void *)r->d_site_bin_off})
         if (q) (void)hipFree(q);
     delete r;
 }
@@ -212,7 +212,7 @@ void bsx_fill_devparams(const bsx_ref *r, DevParams &d)
     d.n_chr = r->n_chr;
     d.refplane = r->d_refplane; d.plane_rc_off = r->plane_rc_off;
     d.refcat = r->d_refcat; d.crefcat = r->d_crefcat; d.anchor = r->d_anchor; d.chr_size = r->d_chr_size; d.rc_offset = r->d_rc_offset;
-    d.bucket_off = r->d_bucket_off; d.bucket_nfwd = r->d_bucket_nfwd; d.entries = r->d_entries;
+    d.bucket_off = r->d_bucket_off; d.bucket_nfwd = r->d_bucket_nfwd; d.entries = r->d_entries; d.ctx = r->d_ctx;
     d.sites = r->d_sites; d.site_off = r->d_site_off; d.rrbs_goff = r->d_rrbs_goff; d.site_bin = r->d_site_bin; d.site_bin_off = r->d_site_bin_off;
 }
 

@@ -70,6 +70,26 @@ __global__ void k_boundaries(const uint32_t *__restrict__ skeys, uint64_t total,
     }
 }
 
+// The context of every index entry: the 32 reference nt left and right of its seed, as four packed words (16 nt each, first nt in the top bits, like the
+// reference copies themselves): {[e - 32, e - 16), [e - 16, e), [e + 16, e + 32), [e + 32, e + 48)} of the strand copy the entry lies on (the low bit of its
+// sort key).  The main kernel compares a read's own flanks of the seed with them before it gathers anything (wave_scan_range<.., CTX>): data that arrives
+// with the coalesced entry load.  16 bytes per entry: 23.6 GB at hg38 size — what 288 GB of HBM are for.
+__global__ void k_context(const uint32_t *__restrict__ skeys, const uint32_t *__restrict__ entries, uint64_t total, const uint32_t *__restrict__ refcat,
+                          const uint32_t *__restrict__ crefcat, uint32_t *__restrict__ ctx)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t e = entries[i];
+        const uint32_t *m = (skeys[i] & 1u) ? crefcat : refcat;
+        uint32_t out[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t x = e + (j < 2 ? 16u * j - 32u : 16u * j - 16u), w = x >> 4, sh = x & 15u;   // (every entry lies behind the 400-word margin: e >= 6400)
+            out[j] = sh ? __builtin_amdgcn_alignbit(m[w], m[w + 1], 32u - 2u * sh) : m[w];
+        }
+        reinterpret_cast<uint4 *>(ctx)[i] = make_uint4(out[0], out[1], out[2], out[3]);
+    }
+}
+
 template <class T> struct DevBuf {
     T *p = nullptr;
     ~DevBuf() { if (p) (void)hipFree(p); }
@@ -151,11 +171,25 @@ int bsx_index_build_wgbs(bsx_ref *r)
         hipLaunchKernelGGL(k_boundaries, dim3(grid), dim3(256), 0, 0, d_skeys.p, total, K, d_off.p, d_nfwd.p);
         HIP_TRY(hipGetLastError());
     }
+    // the entries' context for the main kernel's prefilter (-I <= 4: its flank table holds four phases; BSX_CTX=0: none — 16 bytes per entry).  Not fatal:
+    // without it the main kernel takes its plain path
+    DevBuf<uint32_t> d_ctx;
+    const bool want_ctx = total && P.index_interval <= 4 && !(getenv("BSX_CTX") && atoi(getenv("BSX_CTX")) == 0);
+    if (want_ctx) {
+        d_keys.~DevBuf(); d_keys.p = nullptr; d_vals.~DevBuf(); d_vals.p = nullptr; d_temp.~DevBuf(); d_temp.p = nullptr;   // (the sort's inputs and workspace are spent)
+        if (d_ctx.alloc((total + BSX_ENTRY_PAD) * 4) == 0) {
+            HIP_TRY(hipMemset(d_ctx.p, 0, (total + BSX_ENTRY_PAD) * 16));
+            const int grid = (int)std::min<uint64_t>((total + 255) / 256, 256 * 32);
+            hipLaunchKernelGGL(k_context, dim3(grid), dim3(256), 0, 0, d_skeys.p, d_entries.p, total, r->d_refcat, r->d_crefcat, d_ctx.p);
+            HIP_TRY(hipGetLastError());
+        } else (void)hipGetLastError();
+    }
     HIP_TRY(hipDeviceSynchronize());
     if (r->d_bucket_off) (void)hipFree(r->d_bucket_off);
     if (r->d_bucket_nfwd) (void)hipFree(r->d_bucket_nfwd);
     if (r->d_entries) (void)hipFree(r->d_entries);
-    r->d_bucket_off = d_off.release(); r->d_bucket_nfwd = d_nfwd.release(); r->d_entries = d_entries.release();
+    if (r->d_ctx) (void)hipFree(r->d_ctx);
+    r->d_bucket_off = d_off.release(); r->d_bucket_nfwd = d_nfwd.release(); r->d_entries = d_entries.release(); r->d_ctx = d_ctx.release();
     r->n_entries = total;
     r->has_index = true;
     return BSX_OK;

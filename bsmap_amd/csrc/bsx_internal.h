@@ -36,6 +36,8 @@ struct DevParams {
     uint32_t plane_rc_off;
     // index (CSR)
     const uint32_t *bucket_off, *bucket_nfwd, *entries;
+    // per index entry the 32 reference nt left and right of its seed, four packed words (null: not built) — the main kernel's context prefilter
+    const uint32_t *ctx;
     // RRBS site table
     const uint32_t *sites, *site_off;
     // RRBS: entries of a bucket grouped by (segment + 16 * direction); rrbs_goff[key * 32 + group] = first entry (null: ungrouped)
@@ -63,7 +65,7 @@ struct bsx_ref {
     uint32_t *d_refcat = nullptr, *d_crefcat = nullptr, *d_anchor = nullptr, *d_chr_size = nullptr, *d_rc_offset = nullptr;
     uint32_t *d_refplane = nullptr;   // plane copy (bsx_planes_build)
     uint32_t plane_rc_off = 0;
-    uint32_t *d_bucket_off = nullptr, *d_bucket_nfwd = nullptr, *d_entries = nullptr;
+    uint32_t *d_bucket_off = nullptr, *d_bucket_nfwd = nullptr, *d_entries = nullptr, *d_ctx = nullptr;
     uint32_t *d_sites = nullptr, *d_site_off = nullptr, *d_rrbs_goff = nullptr, *d_site_bin = nullptr, *d_site_bin_off = nullptr;
     std::vector<uint32_t> rrbs_entries_host;  // RRBS entries in the reference's order (the device copy is grouped, see bsx_index_build_rrbs)
     uint64_t n_entries = 0;

@@ -1,5 +1,7 @@
 """The device-side synthetic workload (bench input) is held to the same parity bar: the oracle packs and indexes the
 text of the synthetic genome and aligns the device-sampled reads; everything must match the GPU path bit for bit."""
+import os
+
 import numpy as np
 import pytest
 
@@ -58,7 +60,7 @@ def test_synth_se_reads_align_like_oracle(synth, oracle):
     has = ores["n_best"] > 0
     for f in ("chr", "loc", "best_class"):
         assert np.array_equal(ores[f][has], hits[f][has]), f
-    assert [int(x) for x in sa.counters()[:4]] == ocnt
+    assert os.environ.get("BSX_WORK_COUNTERS") == "0" or [int(x) for x in sa.counters()[:4]] == ocnt
     assert has.mean() > 0.9  # the sampler produces alignable bisulfite reads
     sa.close()
 
@@ -76,7 +78,7 @@ def test_synth_pe_reads_align_like_oracle(synth, oracle):
     pr = (ores["tmp"] == 0) & (ores["paired"] > 0)
     for f in ("a_chr", "a_loc", "b_chr", "b_loc", "insert", "na", "nb", "chain"):
         assert np.array_equal(ores["pick"][f][pr], out[f][pr]), f
-    assert [int(x) for x in pa.counters()[:4]] == ocnt
+    assert os.environ.get("BSX_WORK_COUNTERS") == "0" or [int(x) for x in pa.counters()[:4]] == ocnt
     assert pr.mean() > 0.85
     # mates are proper pairs: a maps to ++/-+ and b to the opposite read orientation on the same reference copy
     assert np.array_equal(out["a_chr"][pr], out["b_chr"][pr])
