@@ -96,6 +96,8 @@ int bsx_ref_blocks(const bsx_ref *r, uint32_t *id, uint32_t *begin, uint32_t *en
 int bsx_ref_download_words(const bsx_ref *r, uint32_t *refcat, uint32_t *crefcat);  /* device -> host, n_words each */
 
 /* ---- seed index: RefSeq::CreateIndex (dbseq.cpp:516-539) ---------------------------------------- */
+/* (WGBS, -I <= 4: the build also stores, per entry, the 32 reference nt left and right of the entry's seed — 16 bytes per entry, 23.6 GB at hg38 size —
+ *  for the main kernel's context prefilter, which runs where the work counters are off; BSX_CTX=0 in the environment builds none) */
 int bsx_index_build(bsx_ref *r);                        /* built on the GPU; entry order identical to the reference */
 uint64_t bsx_index_n_entries(const bsx_ref *r);
 /* CSR copy-out: bucket_off[total_kmers+1], bucket_nfwd[total_kmers], entries[n_entries]
