@@ -94,6 +94,7 @@ template <class T> struct DevBuf {
     T *p = nullptr;
     ~DevBuf() { if (p) (void)hipFree(p); }
     int alloc(size_t n) { return hipMalloc(&p, (n ? n : 1) * sizeof(T)) == hipSuccess ? 0 : -1; }
+    void reset() { if (p) (void)hipFree(p); p = nullptr; }
     T *release() { T *q = p; p = nullptr; return q; }
 };
 
@@ -176,7 +177,7 @@ int bsx_index_build_wgbs(bsx_ref *r)
     DevBuf<uint32_t> d_ctx;
     const bool want_ctx = total && P.index_interval <= 4 && !(getenv("BSX_CTX") && atoi(getenv("BSX_CTX")) == 0);
     if (want_ctx) {
-        d_keys.~DevBuf(); d_keys.p = nullptr; d_vals.~DevBuf(); d_vals.p = nullptr; d_temp.~DevBuf(); d_temp.p = nullptr;   // (the sort's inputs and workspace are spent)
+        d_keys.reset(); d_vals.reset(); d_temp.reset();   // (the sort's inputs and workspace are spent)
         if (d_ctx.alloc((total + BSX_ENTRY_PAD) * 4) == 0) {
             HIP_TRY(hipMemset(d_ctx.p, 0, (total + BSX_ENTRY_PAD) * 16));
             const int grid = (int)std::min<uint64_t>((total + 255) / 256, 256 * 32);
