@@ -83,15 +83,19 @@ __device__ __forceinline__ u64 rl64(u64 x, int l) { return ((u64)rl((uint32_t)(x
 __device__ __forceinline__ u64 lanemask_lt(int lane) { return lane ? (~0ull >> (64 - lane)) : 0ull; }
 __device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
 
-// wave-wide minimum of a 64-bit key (all lanes get the result)
-__device__ __forceinline__ u64 wave_min64(u64 v)
+// the first lane that holds the minimum of v (0xffffffff: the lane does not compete), -1 if none competes: the minimum of (v << 8 | lane) over the wave.
+// (Round 5 also tried the 32-bit minimum by DPP — six v_min_u32 with a DPP operand and a ballot, tools/experiments/r05/dpp_min_test.hip — which is a third
+// of the instructions; in the paired main kernel it moved the register allocation from 30 to 67 spilled VGPRs and cost more than it saved, see
+// tools/experiments/README.md.)
+__device__ __forceinline__ int wave_argmin_u32(uint32_t v)
 {
+    u64 k = v == 0xffffffffu ? ~0ull : (((u64)v << 8) | (uint32_t)(threadIdx.x & 63));
 #pragma unroll
     for (int o = 32; o; o >>= 1) {
-        u64 t = ((u64)__shfl_xor((uint32_t)(v >> 32), o) << 32) | __shfl_xor((uint32_t)v, o);
-        v = t < v ? t : v;
+        u64 t = ((u64)__shfl_xor((uint32_t)(k >> 32), o) << 32) | __shfl_xor((uint32_t)k, o);
+        k = t < k ? t : k;
     }
-    return v;
+    return k != ~0ull ? (int)(k & 0xff) : -1;
 }
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 {
@@ -332,20 +336,25 @@ __device__ void plan_counts(const DevParams &P, MateLds &L, const Mate &M, int o
     wave_fence();
 }
 
+// GetTotalSeedLoc of start offset (lane & 15) in every lane (align.cpp:458-468): the segments are dealt to the four groups of 16 lanes
+// (there are fewer than 16 start offsets) and the partial sums added across the groups
+__device__ __forceinline__ uint32_t start_totals(const DevParams &P, const BlockLds &BL, const uint32_t *cnt, int nseg, int nstart, int lane)
+{
+    const int I = P.index_interval, g = lane >> 4, sl = lane & 15;
+    int tot = 0;
+    if (sl < nstart)
+        for (int seg = g; seg < nseg; seg += 4)
+            for (int ph = 0; ph < I; ph++) tot += (int)cnt[BL.prof[seg][ph] + sl - ph];
+    tot += __shfl_xor(tot, 16);
+    tot += __shfl_xor(tot, 32);
+    return lane < nstart ? (uint32_t)tot : 0xffffffffu;   // (only the lanes that ARE a start offset compete)
+}
+
 // GetTotalSeedLoc for every start offset, first minimum wins (align.cpp:458-468); counts must be in L.cnt
 __device__ int plan_best_offset(const DevParams &P, const BlockLds &BL, const MateLds &L, const Mate &M, int orient, int lane)
 {
     const int I = P.index_interval, nseg = M.u->seedseg, nstart = (M.u->len - I + 1) % P.seed_size;
-    const uint32_t *cnt = L.cnt[orient];
-    u64 key = ~0ull;
-    if (lane < nstart) {
-        int tot = 0;
-        for (int seg = 0; seg < nseg; seg++)
-            for (int ph = 0; ph < I; ph++) tot += (int)cnt[BL.prof[seg][ph] + lane - ph];
-        if ((uint32_t)tot != 0xffffffffu) key = ((u64)(uint32_t)tot << 8) | (uint32_t)lane;
-    }
-    key = wave_min64(key);
-    return key != ~0ull ? (int)(key & 0xff) : -1;
+    return wave_argmin_u32(start_totals(P, BL, L.cnt[orient], nseg, nstart, lane));
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -362,15 +371,8 @@ __device__ void plan_orient(const DevParams &P, const BlockLds &BL, MateLds &L, 
     const int nstart = P.rrbs ? 0 : (M.u->len - I + 1) % S;
     u64 lookups = 0;
     if (nstart > 0) {  // GetTotalSeedLoc for every start, first minimum wins (align.cpp:458-468)
-        u64 key = ~0ull;
-        if (lane < nstart) {
-            int tot = 0;
-            for (int seg = 0; seg < nseg; seg++)
-                for (int ph = 0; ph < I; ph++) tot += (int)cnt[BL.prof[seg][ph] + lane - ph];
-            if ((uint32_t)tot != 0xffffffffu) key = ((u64)(uint32_t)tot << 8) | (uint32_t)lane;
-        }
-        key = wave_min64(key);
-        if (key != ~0ull) offset = (int)(key & 0xff);
+        const int best = wave_argmin_u32(start_totals(P, BL, cnt, nseg, nstart, lane));
+        if (best >= 0) offset = best;
         lookups += (u64)nstart * nseg * I;
     }
     // AdjustSeedStartArray (align.cpp:506-528)
@@ -381,15 +383,15 @@ __device__ void plan_orient(const DevParams &P, const BlockLds &BL, MateLds &L, 
             const int ptr = (i % 2 == 0) ? i / 2 : nseg - 1 - i / 2;
             const int start = ptr == 0 ? 0 : L.start[orient][ptr - 1];
             const int end = ptr == nseg - 1 ? nstart : L.start[orient][ptr + 1];
-            u64 key = ~0ull;
+            uint32_t tv = 0xffffffffu;
             const int ii = start + lane;
             if (ii <= end) {
                 int tt = 0;
                 for (int ph = 0; ph < I; ph++) tt += (int)cnt[BL.prof[ptr][ph] + ii - ph];
-                if ((uint32_t)tt != 0xffffffffu) key = ((u64)(uint32_t)tt << 8) | (uint32_t)lane;
+                tv = (uint32_t)tt;
             }
-            key = wave_min64(key);
-            const int pick = key != ~0ull ? start + (int)(key & 0xff) : start;
+            const int best = wave_argmin_u32(tv);
+            const int pick = best >= 0 ? start + best : start;
             if (lane == 0) L.start[orient][ptr] = (uint8_t)pick;
             wave_fence();
             if (end >= start) lookups += (u64)(end - start + 1) * I;
@@ -833,11 +835,18 @@ __device__ int wave_scan_range(const DevParams &P, const BlockLds &BL, const Mat
     constexpr bool PREFETCH = BSX_SCAN_NB == 1 && BSX_MAIN_PREFETCH;
     // (a macro, not a lambda: a closure over `cl` put the whole list descriptor into scratch — 1.1 KB per lane)
     // (hs: h << 5 | sub-range: its lowest bit is the strand copy, the others the index phase)
-#define BSX_LOCATE(idx_, e_idx_, hs_) do { e_idx_ = 0; hs_ = 0; \
-        for (int s_ = 0; s_ < cl.nsub; s_++) { \
-            const uint32_t ps_ = rl(cl.sub_pre, s_), ns_ = rl(cl.sub_n, s_); \
-            if ((idx_) >= ps_ && (idx_) < ps_ + ns_) { e_idx_ = rl(cl.sub_base, s_) + ((idx_) - ps_); hs_ = (rl(cl.sub_h, s_) << 5) | (uint32_t)(s_ & 31); } \
-        } } while (0)
+    // (round 5: the sub-range of a candidate = the number of later sub-ranges that begin at or before it — their prefix sums never fall, an empty one
+    // shares its begin with its successor — counted against seven scalars; its entry offset and h come from the lane that holds the sub-range.
+    // 18 vector instructions per chunk where a loop over the sub-ranges with its four v_readlane each took ~80.)
+    uint32_t loc_pk[7];
+#pragma unroll
+    for (int k_ = 0; k_ < 7; k_++) loc_pk[k_] = (PREFETCH && k_ + 1 < cl.nsub) ? rl(cl.sub_pre, k_ + 1) : 0xffffffffu;
+    const uint32_t loc_delta = cl.sub_base - cl.sub_pre, loc_hs = (cl.sub_h << 5) | (uint32_t)(lane & 31);
+#define BSX_LOCATE(idx_, e_idx_, hs_) do { uint32_t s_ = 0; \
+        _Pragma("unroll") for (int k_ = 0; k_ < 7; k_++) s_ += (idx_) >= loc_pk[k_]; \
+        for (int k_ = 8; k_ < cl.nsub; k_++) s_ += (idx_) >= rl(cl.sub_pre, k_);   /* (-I above 4: up to 32 sub-ranges) */ \
+        const uint32_t d_ = (uint32_t)__shfl((int)loc_delta, (int)s_);   /* (by every lane, before the select: a lane that is switched off hands out zero) */ \
+        hs_ = (uint32_t)__shfl((int)loc_hs, (int)s_); e_idx_ = (idx_) < cl.total ? (idx_) + d_ : 0u; } while (0)
     constexpr bool USE_CTX = CTX && PREFETCH && !COUNT_ONLY;
     uint32_t *flt = const_cast<uint32_t *>(&L.fl[0][0]);
     if (USE_CTX) {   // the read's flanks of this list's seed, per index phase (at most four: the context is only built for -I <= 4): lane 4 ph + j -> word j of phase ph
