@@ -135,6 +135,7 @@ template <bool PE> struct WaveLds { MateLds mate[PE ? 2 : 1]; };
 
 struct BlockLds {
     uint8_t prof[16][16];
+    uint8_t nt_tab[256];   // per read byte: bits 0-1 the nt's code (alphabet), 2-3 the code of its complement (rev_alphabet), 4-5 reg_alphabet (3 for a nucleotide, 0 for N); N: codes of A / T
     uint32_t anchor[BSX_LDS_CHR + 1], chr_size[BSX_LDS_CHR], rc_offset[BSX_LDS_CHR];
 };
 
@@ -276,26 +277,31 @@ __device__ void load_and_filter(const AlignArgs &A, MateLds &L, Mate &M, int mat
 // ConvertBinaySeq (align.cpp:90-162): 2-bit words + N masks for the enabled orientations (no shifted copies:
 // the scan shifts the reference instead)
 // ---------------------------------------------------------------------------------------------------------------
-__device__ void pack_read(const DevParams &P, MateLds &L, Mate &M, int readset, int lane, Counters &C)
+#ifndef BSX_PACK_UNROLL
+#define BSX_PACK_UNROLL 2   /* (unrolled eight times the sixteen table reads in flight tip the paired kernel's register allocation into its bad state: 51 spilled VGPRs against 35) */
+#endif
+__device__ void pack_read(const DevParams &P, const BlockLds &BL, MateLds &L, Mate &M, int readset, int lane, Counters &C)
 {
     M.u->flags = ((P.chains || readset < 2) ? 1u : 0u) | ((P.chains || readset == 2) ? 2u : 0u);  // align.cpp:93-94
-    const int orient = lane >> 4, t = lane & 15;
-    if (orient < 2 && t < 10) {
-        uint32_t w = 0, m = 0;
-        for (int j = 0; j < 16; j++) {
-            const int pos = t * 16 + j;
-            uint32_t code = 0, reg = 0;
-            if (pos < M.u->len) {
-                const int k = nt_idx(L.seq[orient ? M.u->len - 1 - pos : pos]);
-                const int sel = orient ? (k < 0 ? 3 : 3 - k) : (k < 0 ? 0 : k);  // rev_alphabet / alphabet
-                code = (P.bit_nt_packed >> (8 * sel)) & 3u;
-                reg = k < 0 ? 0u : 3u;                                              // reg_alphabet
-            }
-            w = (w << 2) | code;
-            m = (m << 2) | reg;
+    // lane = orientation (1 bit), word (4 bits), half of the word (1 bit): eight nt per lane through the byte table, the halves joined across neighbouring lanes
+    // (round 5: twenty lanes of sixteen nt each with the alphabet worked out per nt were 440 vector instructions per read of a kernel whose VALU is 0.7 busy)
+    const int orient = lane >> 5, t = (lane >> 1) & 15, hf = lane & 1, len = M.u->len;
+    uint32_t w = 0, m = 0;
+    if (t < 10) {
+        const int pos0 = t * 16 + hf * 8;
+#pragma unroll BSX_PACK_UNROLL
+        for (int j = 0; j < 8; j++) {
+            const int pos = pos0 + j;
+            uint32_t e = 0;
+            if (pos < len) e = BL.nt_tab[L.seq[orient ? len - 1 - pos : pos]];
+            w = (w << 2) | ((e >> (2 * orient)) & 3u);
+            m = (m << 2) | (e >> 4);
         }
-        L.w[orient][t] = w;
-        L.m[orient][t] = m;
+    }
+    const uint32_t w_lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0xB1, 0xf, 0xf, true), m_lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0xB1, 0xf, 0xf, true);   // quad_perm [1, 0, 3, 2]: the neighbour's half
+    if (t < 10 && hf == 0) {
+        L.w[orient][t] = (w << 16) | w_lo;
+        L.m[orient][t] = (m << 16) | m_lo;
     }
     wave_fence();
     C.n_orient += (M.u->flags & 1) + ((M.u->flags >> 1) & 1);
@@ -1303,7 +1309,7 @@ __device__ void leak_offsets(const AlignArgs &A, const BlockLds &BL, MateLds &LS
         MJ.u = lds_mate(&LS.u);
         MJ.u->index = 0;
         load_and_filter(A, LS, MJ, mate, j - (long)A.n_hist, lane);
-        pack_read(P, LS, MJ, PE ? mate + 1 : 0, lane, dummy);
+        pack_read(P, BL, LS, MJ, PE ? mate + 1 : 0, lane, dummy);
         for (int orient = 0; orient < 2; orient++) {
             if (!((need >> orient) & 1)) continue;
             plan_counts<false>(P, LS, MJ, orient, lane, false);
@@ -1316,7 +1322,7 @@ __device__ void leak_offsets(const AlignArgs &A, const BlockLds &BL, MateLds &LS
 
 // seed_array / cseed_array entries [e0, e0 + n) (n <= 64 per call, lane i = entry e0 + i) of the stream's state before position p
 template <bool PE>
-__device__ void leak_entries(const AlignArgs &A, MateLds &LS, int mate, long p, uint32_t flags, int e0, int n, int lane, uint32_t (&key)[2])
+__device__ void leak_entries(const AlignArgs &A, const BlockLds &BL, MateLds &LS, int mate, long p, uint32_t flags, int e0, int n, int lane, uint32_t (&key)[2])
 {
     const DevParams &P = A.P;
     const LeakState *init = (const LeakState *)A.leak_init;
@@ -1333,7 +1339,7 @@ __device__ void leak_entries(const AlignArgs &A, MateLds &LS, int mate, long p, 
         MJ.u = lds_mate(&LS.u);
         MJ.u->index = 0;
         load_and_filter(A, LS, MJ, mate, j - (long)A.n_hist, lane);
-        pack_read(P, LS, MJ, PE ? mate + 1 : 0, lane, dummy);
+        pack_read(P, BL, LS, MJ, PE ? mate + 1 : 0, lane, dummy);
         const int noff_j = MJ.u->len - P.seed_size + 1;
         for (int orient = 0; orient < 2; orient++) {
             if (!((flags >> orient) & 1)) continue;
@@ -1362,7 +1368,7 @@ __global__ __launch_bounds__(256) void k_leak_resolve(AlignArgs A)
             const uint32_t flags = ((P.chains || readset < 2) ? 1u : 0u) | ((P.chains || readset == 2) ? 2u : 0u);  // align.cpp:93-94
             uint32_t so[2], key[2];
             leak_offsets<PE>(A, BL, LSC[wv], mate, pos, flags, lane, so);
-            leak_entries<PE>(A, LSC[wv], mate, pos, flags, (int)v - P.seed_size + 1, 16, lane, key);
+            leak_entries<PE>(A, BL, LSC[wv], mate, pos, flags, (int)v - P.seed_size + 1, 16, lane, key);
             LeakRec *r = (LeakRec *)A.leak_rec + ((size_t)unit * 2 + mate);
             if (lane < 16) { r->key[0][lane] = key[0]; r->key[1][lane] = key[1]; }
             if (lane < 2) r->so[lane] = (uint8_t)so[lane];
@@ -1396,7 +1402,7 @@ __global__ __launch_bounds__(64) void k_leak_final(AlignArgs A, LeakState *out)
     for (int e0 = 0; e0 < LEAK_KEYS; e0 += 64) {
         uint32_t key[2];
         const int n = min(64, LEAK_KEYS - e0);
-        leak_entries<PE>(A, LSC, mate, pos, flags, e0, n, lane, key);
+        leak_entries<PE>(A, BL, LSC, mate, pos, flags, e0, n, lane, key);
         if (lane < n) { out->key[mate][0][e0 + lane] = key[0]; out->key[mate][1][e0 + lane] = key[1]; }
     }
 }
@@ -1419,13 +1425,13 @@ __device__ void unit_prepare(const AlignArgs &A, const BlockLds &BL, MateLds &LA
     if (PE) load_and_filter(A, LB, MB, 1, (long)unit, lane);
     else MB = MA;
     if (!MA.u->filtered) {
-        pack_read(P, LA, MA, PE ? 1 : 0, lane, C);
+        pack_read(P, BL, LA, MA, PE ? 1 : 0, lane, C);
         const bool lk = EXACT && A.leak_exact && !P.rrbs && (MA.u->len - P.index_interval + 1) % P.seed_size == 0;
         if (lk) load_leak_rec(A, LA, unit, 0, lane);
         for (int o = 0; o < 2; o++) if ((MA.u->flags >> o) & 1) plan_orient<EXACT>(P, BL, LA, MA, o, lane, C, lk);  // pairs.cpp:160 / align.cpp:444
     }
     if (PE && !MB.u->filtered) {
-        pack_read(P, LB, MB, 2, lane, C);
+        pack_read(P, BL, LB, MB, 2, lane, C);
         const bool lk = EXACT && A.leak_exact && !P.rrbs && (MB.u->len - P.index_interval + 1) % P.seed_size == 0;
         if (lk) load_leak_rec(A, LB, unit, 1, lane);
         for (int o = 0; o < 2; o++) if ((MB.u->flags >> o) & 1) plan_orient<EXACT>(P, BL, LB, MB, o, lane, C, lk);
@@ -1541,7 +1547,11 @@ __device__ __forceinline__ bool process_unit(const AlignArgs &A, const BlockLds 
 
 __device__ __forceinline__ void init_block_lds(const DevParams &P, BlockLds &BL, int tid, int nthreads)
 {
-    for (int i = tid; i < 256; i += nthreads) ((uint8_t *)BL.prof)[i] = ((const uint8_t *)P.profile_a)[i];
+    for (int i = tid; i < 256; i += nthreads) {
+        ((uint8_t *)BL.prof)[i] = ((const uint8_t *)P.profile_a)[i];
+        const int k = nt_idx((uint32_t)i);
+        BL.nt_tab[i] = (uint8_t)(((P.bit_nt_packed >> (8 * (k < 0 ? 0 : k))) & 3u) | (((P.bit_nt_packed >> (8 * (k < 0 ? 3 : 3 - k))) & 3u) << 2) | (k < 0 ? 0u : 0x30u));
+    }
     if (P.n_chr <= BSX_LDS_CHR) {
         for (uint32_t i = tid; i <= P.n_chr; i += nthreads) BL.anchor[i] = P.anchor[i];
         for (uint32_t i = tid; i < P.n_chr; i += nthreads) { BL.chr_size[i] = P.chr_size[i]; BL.rc_offset[i] = P.rc_offset[i]; }
