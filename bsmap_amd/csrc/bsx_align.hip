@@ -969,6 +969,7 @@ __device__ int wave_scan_range(const DevParams &P, const BlockLds &BL, const Mat
             }
         }
         // work accounting exactly as the reference's CountMismatch early-outs (align.h:189-197)
+        if (!USE_CTX)   // (the prefiltered scan runs with the work counters off: what it would add is not a count of anything)
         {
             const bool one = alive && ev.w0ref > thr_eff;
             const bool two = alive && !one && (ev.p48 > thr_eff || ev.w01ref > thr_eff);
