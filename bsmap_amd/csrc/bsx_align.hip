@@ -83,19 +83,17 @@ __device__ __forceinline__ u64 rl64(u64 x, int l) { return ((u64)rl((uint32_t)(x
 __device__ __forceinline__ u64 lanemask_lt(int lane) { return lane ? (~0ull >> (64 - lane)) : 0ull; }
 __device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
 
-// the first lane that holds the minimum of v (0xffffffff: the lane does not compete), -1 if none competes: the minimum of (v << 8 | lane) over the wave.
-// (Round 5 also tried the 32-bit minimum by DPP — six v_min_u32 with a DPP operand and a ballot, tools/experiments/r05/dpp_min_test.hip — which is a third
-// of the instructions; in the paired main kernel it moved the register allocation from 30 to 67 spilled VGPRs and cost more than it saved, see
-// tools/experiments/README.md.)
+// the first lane that holds the minimum of v (0xffffffff: the lane does not compete), -1 if none competes: the minimum of (v << 8 | lane) over the wave
 __device__ __forceinline__ int wave_argmin_u32(uint32_t v)
 {
-    u64 k = v == 0xffffffffu ? ~0ull : (((u64)v << 8) | (uint32_t)(threadIdx.x & 63));
-#pragma unroll
-    for (int o = 32; o; o >>= 1) {
-        u64 t = ((u64)__shfl_xor((uint32_t)(k >> 32), o) << 32) | __shfl_xor((uint32_t)k, o);
-        k = t < k ? t : k;
-    }
-    return k != ~0ull ? (int)(k & 0xff) : -1;
+    // minimum of every row of 16 lanes by four shifted v_min_u32 (lane 15 of the row holds it), the four rows joined on the scalar unit, the lane by a ballot
+    // (correct on the box: tools/experiments/r05/dpp_min_test.hip; the 64-bit shuffle reduction it replaces was 18 vector and 12 LDS instructions per call, ~40 calls per pair)
+    uint32_t r = v;
+#define BSX_DPP_MIN(ctrl) r = min(r, (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)r, ctrl, 0xf, 0xf, false))
+    BSX_DPP_MIN(0x111); BSX_DPP_MIN(0x112); BSX_DPP_MIN(0x114); BSX_DPP_MIN(0x118);   // row_shr 1, 2, 4, 8
+#undef BSX_DPP_MIN
+    const uint32_t m = min(min(rl(r, 15), rl(r, 31)), min(rl(r, 47), rl(r, 63)));
+    return m == 0xffffffffu ? -1 : (int)__builtin_ctzll(bsx_ballot(v == m));
 }
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 {
