@@ -62,7 +62,7 @@ EXPORTS = [
     "bsx_strerror", "bsx_last_error_detail", "bsx_params_default", "bsx_params_set_digest", "bsx_params_finish",
     "bsx_device_count", "bsx_device_numa_node", "bsx_ref_create_from_fasta", "bsx_ref_create_from_file", "bsx_ref_create_synthetic", "bsx_synth_chr_text", "bsx_ref_destroy",
     "bsx_ref_n_chr", "bsx_ref_n_words", "bsx_ref_n_blocks", "bsx_ref_info", "bsx_ref_chr_name", "bsx_ref_blocks",
-    "bsx_ref_download_words", "bsx_index_build", "bsx_index_n_entries", "bsx_index_download", "bsx_ref_n_sites", "bsx_ref_sites",
+    "bsx_ref_download_words", "bsx_ref_set_context", "bsx_ref_context_bytes", "bsx_ref_drop_context", "bsx_index_build", "bsx_index_n_entries", "bsx_index_download", "bsx_ref_n_sites", "bsx_ref_sites",
     "bsx_batch_create", "bsx_batch_destroy", "bsx_batch_upload_se", "bsx_batch_upload_pe", "bsx_batch_synth_reads", "bsx_batch_synth_reads_kind", "bsx_batch_download_quals",
     "bsx_batch_run", "bsx_batch_run_range", "bsx_batch_sync", "bsx_batch_set_work_counters", "bsx_batch_set_leak_exact", "bsx_batch_set_history", "bsx_batch_set_leak_state", "bsx_batch_get_leak_state", "bsx_batch_kernel_ms", "bsx_batch_scan_ms", "bsx_batch_results_se", "bsx_batch_results_pe",
     "bsx_batch_counters", "bsx_batch_reset_counters", "bsx_batch_download_reads", "bsx_batch_set_debug", "bsx_batch_unit_cycles", "bsx_batch_ctrl_clocks",
@@ -104,6 +104,10 @@ def lib():
         L.bsx_index_build.argtypes = [vp]
         L.bsx_index_n_entries.argtypes = [vp]
         L.bsx_index_n_entries.restype = u64
+        L.bsx_ref_set_context.argtypes = [vp, i32, u64]
+        L.bsx_ref_context_bytes.argtypes = [vp]
+        L.bsx_ref_context_bytes.restype = u64
+        L.bsx_ref_drop_context.argtypes = [vp]
         L.bsx_index_download.argtypes = [vp, vp, vp, vp]
         L.bsx_ref_n_sites.argtypes = [vp, u32]
         L.bsx_ref_n_sites.restype = u32
@@ -242,8 +246,19 @@ class RefSeq:
         _check(lib().bsx_synth_chr_text(self.h, c, start, n, buf.ctypes.data))
         return buf
 
-    def CreateIndex(self):
+    def CreateIndex(self, context=None, headroom=0):
+        """RefSeq::CreateIndex.  context: None = the library's default (the context table of the main kernel's prefilter is built where `headroom` bytes
+        stay free behind it), 0 never, 1 with that headroom rule, 2 always (bsx.h: bsx_ref_set_context)"""
+        if context is not None:
+            _check(lib().bsx_ref_set_context(self.h, int(context), int(headroom)))
         _check(lib().bsx_index_build(self.h))
+        return self
+
+    @property
+    def context_bytes(self): return lib().bsx_ref_context_bytes(self.h)
+
+    def drop_context(self):
+        _check(lib().bsx_ref_drop_context(self.h))
         return self
 
     # ---- inspection ----

@@ -1636,6 +1636,9 @@ __global__ __launch_bounds__(256, PE ? BSX_WAVES_PER_EU_PE : BSX_WAVES_PER_EU_SE
 #ifndef HS_GROW
 #define HS_GROW 4u
 #endif
+#ifndef BSX_EVENT_CONTINUE
+#define BSX_EVENT_CONTINUE 1  /* work counters off: a lowered threshold does not end a window's replay (snp_align_heavy) */
+#endif
 #ifndef HS_WINMAX
 #define HS_WINMAX (1u << 22)
 #endif
@@ -1847,6 +1850,7 @@ __device__ __forceinline__ int snp_align_heavy(const AlignArgs &A, const HeavyAr
                 // (task descriptors in the pool may already have been reused by other units of this pass: the window is
                 //  reconstructed from the unit's own state, only the task OUTPUTS are read from the pool)
                 const uint32_t t0 = rfl(S->t0[ms]), nt = rfl(S->n_tasks[ms]), req_thres = rfl(S->req[ms].thres);
+                const bool cont_events = BSX_EVENT_CONTINUE && !A.work_counters;
                 bool restart = false;
                 for (uint32_t tg = 0; tg < nt && !restart; tg += 64) {
                     // 64 task headers at a time: tasks without survivors only contribute their work counters
@@ -1886,14 +1890,25 @@ __device__ __forceinline__ int snp_align_heavy(const AlignArgs &A, const HeavyAr
                                     if ((uint32_t)lane < total) r = H.tout[t0 + tg + my_t].surv[my_i];
                                     u64 m = total >= 64 ? ~0ull : ((1ull << total) - 1);
                                     m &= surv_coords(P, BL, r, M.u->len, lane, m);
-                                    if (total > BSX_GROUP_MIN) e = accept_group(P, M, SL, orient, mode, m, r.w_ord & 0xff, r.hchr, r.hloc, r.hkey, lane, ls);
-                                    else
-                                        while (m) {
-                                            const int l1 = (int)__builtin_ctzll(m);
-                                            m &= m - 1;
-                                            e = accept_survivor<true>(P, M, SL, orient, mode, rl(r.w_ord, l1) & 0xff, rl(r.hchr, l1), rl(r.hloc, l1), rl(r.hkey, l1), lane);
-                                            if (e) { ls = l1; break; }
+                                    for (;;) {
+                                        if (__builtin_popcountll(m) > BSX_GROUP_MIN) e = accept_group(P, M, SL, orient, mode, m, r.w_ord & 0xff, r.hchr, r.hloc, r.hkey, lane, ls);
+                                        else {
+                                            e = 0;
+                                            while (m) {
+                                                const int l1 = (int)__builtin_ctzll(m);
+                                                m &= m - 1;
+                                                e = accept_survivor<true>(P, M, SL, orient, mode, rl(r.w_ord, l1) & 0xff, rl(r.hchr, l1), rl(r.hloc, l1), rl(r.hkey, l1), lane);
+                                                if (e) { ls = l1; break; }
+                                            }
                                         }
+                                        // A lowered threshold (align.cpp:278) ends the window only where the work counters are kept (the early-out classes of the
+                                        // candidates behind it depend on it).  The HITS do not: a survivor's record carries its exact count, and accept_* tests it
+                                        // against the CURRENT threshold — the survivors behind the event are simply replayed under the new one.
+                                        if (e != 1 || !cont_events) break;
+                                        m &= ls >= 63 ? 0ull : ~((2ull << ls) - 1ull);
+                                        e = 0;
+                                        if (!m) break;
+                                    }
                                     CAT_END(A, 2);
                                 }
                                 const uint32_t upto = e ? rl(my_t, ls) : bend;  // tasks [done_upto, upto) are complete
@@ -1932,7 +1947,7 @@ __device__ __forceinline__ int snp_align_heavy(const AlignArgs &A, const HeavyAr
                             CAT_END(A, 1);
                             if (r == 2) { wave_fence(); return 1; }
                             K.c[ms] = tc0 + tn;
-                            if (r == 1) restart = true;  // later tasks were evaluated under the old threshold
+                            if (r == 1 && !cont_events) restart = true;  // later tasks were evaluated under the old threshold (their work counters, not their hits, depend on it)
                             continue;
                         }
                         int event = 0; uint32_t X = 0;
@@ -1944,9 +1959,10 @@ __device__ __forceinline__ int snp_align_heavy(const AlignArgs &A, const HeavyAr
                             if (i < nv) r = o->surv[i];
                             u64 m = bsx_ballot(i < nv);
                             m &= surv_coords(P, BL, r, M.u->len, lane, m);
-                            if (__builtin_popcountll(m) > BSX_GROUP_MIN) {
+                            while (__builtin_popcountll(m) > BSX_GROUP_MIN) {
                                 int ls;
                                 const int e = accept_group(P, M, SL, orient, mode, m, r.w_ord & 0xff, r.hchr, r.hloc, r.hkey, lane, ls);
+                                if (e == 1 && cont_events) { m &= ls >= 63 ? 0ull : ~((2ull << ls) - 1ull); continue; }  // (see above: the rest under the new threshold)
                                 if (e) { event = e; X = tc0 + (rl(r.w_ord, ls) >> 8); }
                                 m = 0;
                             }
@@ -1955,6 +1971,7 @@ __device__ __forceinline__ int snp_align_heavy(const AlignArgs &A, const HeavyAr
                                 m &= m - 1;
                                 const uint32_t wo = rl(r.w_ord, ls);
                                 const int e = accept_survivor<true>(P, M, SL, orient, mode, wo & 0xff, rl(r.hchr, ls), rl(r.hloc, ls), rl(r.hkey, ls), lane);
+                                if (e == 1 && cont_events) continue;
                                 if (e) { event = e; X = tc0 + (wo >> 8); break; }
                             }
                         }
@@ -2615,7 +2632,9 @@ __device__ __forceinline__ void hs_group(const AlignArgs &A, const HeavyArgs &H,
     const DevParams &P = A.P;
     uint32_t *uw = &L.W[wv].UW[0][0];
     const int nwr = NWR ? NWR : (int)((flags >> 8) & 15u);
+#ifdef BSX_SIGHIST_DUPS
     u64 rowsig = 0;
+#endif
     if ((uint32_t)lane < K) {   // the read of this lane's task -> its row
         const ListReq &R = H.state[th & 0x3fffffffu].req[th >> 30];
         uint32_t *row = uw + (uint32_t)lane * 20u;
@@ -2628,17 +2647,22 @@ __device__ __forceinline__ void hs_group(const AlignArgs &A, const HeavyArgs &H,
             if (j < nwr - 1) inner &= pm;
         }
         row[9] = R.thres | (inner == 0xFFFFFFFFu ? 0x10000u : 0u); row[16] = tid; row[17] = tc0;
+#ifdef BSX_SIGHIST_DUPS
         u64 hsh = R.thres;
 #pragma unroll
         for (int j = 0; j < 5; j++) { hsh = (hsh ^ R.px[j]) * 0x9E3779B97F4A7C15ull; hsh = (hsh ^ R.py[j]) * 0xBF58476D1CE4E5B9ull; hsh = (hsh ^ R.pm[j]) * 0x94D049BB133111EBull; hsh ^= hsh >> 29; }
         rowsig = hsh;
+#endif
     }
-    // diagnostics: members of the group whose read words and threshold equal an earlier member's (they would yield the same survivors)
+    // diagnostic build (-DBSX_SIGHIST_DUPS, with BSX_SIGHIST=1; round 5 measured 0.00 % for C3, 1.4 % for C2): members of the group whose read words
+    // and threshold equal an earlier member's (they would yield the same survivors).  Not in the shipped kernel: it is bound by its vector issue.
     uint32_t n_dup = 0;
+#ifdef BSX_SIGHIST_DUPS
     for (uint32_t j = 1; j < K; j++) {
         const u64 sj = ((u64)rl_u((uint32_t)(rowsig >> 32), j) << 32) | rl_u((uint32_t)rowsig, j);
         if (bsx_ballot((uint32_t)lane < j && rowsig == sj)) n_dup++;
     }
+#endif
     wave_fence();
     const uint32_t strand = flags & 1u;
     SameWin W;
@@ -3062,7 +3086,7 @@ void bsx_launch_align(const AlignArgs &A, int paired, int grid_blocks, hipStream
     if (A.leak_exact) {
         if (paired) hipLaunchKernelGGL((k_align<true, true>), dim3(grid_blocks), dim3(256), 0, stream, A);
         else hipLaunchKernelGGL((k_align<false, true>), dim3(grid_blocks), dim3(256), 0, stream, A);
-    } else if (A.P.ctx && !A.work_counters) {   // the context prefilter: with the index's flank words, and only where nobody reads the work counters
+    } else if (A.P.ctx && !A.work_counters && A.P.index_interval <= 4 && !A.P.rrbs) {   // the context prefilter: with the index's flank words (the kernel's flank table holds four phases: -I <= 4, WGBS), and only where nobody reads the work counters
         if (paired) hipLaunchKernelGGL((k_align<true, false, true>), dim3(grid_blocks), dim3(256), 0, stream, A);
         else hipLaunchKernelGGL((k_align<false, false, true>), dim3(grid_blocks), dim3(256), 0, stream, A);
     } else if (paired) hipLaunchKernelGGL((k_align<true, false>), dim3(grid_blocks), dim3(256), 0, stream, A);

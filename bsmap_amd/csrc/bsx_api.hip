@@ -169,6 +169,22 @@ extern "C" int bsx_index_build(bsx_ref *r)
     return bsx_index_build_wgbs(r);
 }
 extern "C" uint64_t bsx_index_n_entries(const bsx_ref *r) { return r ? r->n_entries : 0; }
+
+extern "C" int bsx_ref_set_context(bsx_ref *r, int mode, uint64_t headroom_bytes)
+{
+    if (!r || mode < 0 || mode > 2) return BSX_ERR_ARG;
+    r->ctx_mode = mode;
+    r->ctx_headroom = headroom_bytes ? headroom_bytes : BSX_CTX_HEADROOM_DEFAULT;
+    return BSX_OK;
+}
+extern "C" uint64_t bsx_ref_context_bytes(const bsx_ref *r) { return r ? r->ctx_bytes : 0; }
+extern "C" int bsx_ref_drop_context(bsx_ref *r)
+{
+    if (!r) return BSX_ERR_ARG;
+    if (r->n_batches > 0) { g_bsx_err = "the context table can only be dropped while no batch of the reference exists"; return BSX_ERR_STATE; }
+    if (r->d_ctx) { HIP_TRY(hipSetDevice(r->device)); (void)hipFree(r->d_ctx); r->d_ctx = nullptr; r->ctx_bytes = 0; }
+    return BSX_OK;
+}
 extern "C" int bsx_index_download(const bsx_ref *r, uint32_t *bucket_off, uint32_t *bucket_nfwd, uint32_t *entries)
 {
     if (!r) return BSX_ERR_ARG;
@@ -279,6 +295,7 @@ struct bsx_batch {
     uint32_t rowcap = 0, hkcap = 0;  // hkcap: key capacity of a deferred unit's duplicate set (BSX_HEAVY_KCAP test hook, read at creation)
     int grid_blocks = 0;
     bool ran = false;
+    bool counted = false;        // the batch is in its reference's n_batches
 };
 
 // Waiting without burning a CPU.  hipStreamSynchronize busy-waits, and so — measured on this ROCm (tools/driver_cpu.py: thread CPU time =
@@ -496,7 +513,7 @@ static int ensure_scratch(bsx_batch *b)
         const uint64_t reserve = g_pool_reserve ? g_pool_reserve : ((4ull << 30) + pl.scratch_bytes + pl.per_unit_bytes);
         for (int attempt = 0;; attempt++) {
             size_t fr = 0, tot = 0;
-            const bool smallest = b->hcap <= 1024 && b->task_cap <= 4096;
+            const bool smallest = b->hcap <= std::min<uint32_t>(1024u, b->max_units) && b->task_cap <= 4096;
             hipError_t e = hipErrorOutOfMemory;
             if (smallest || hipMemGetInfo(&fr, &tot) != hipSuccess ||
                 pool_bytes_for(b->ref->P, b->paired, b->hcap, b->task_cap, b->n_bins, b->n_groups, b->hslab_bytes) + reserve <= fr) {
@@ -506,8 +523,9 @@ static int ensure_scratch(bsx_batch *b)
             }
             if (e != hipErrorOutOfMemory || attempt == 12 || smallest) return bsx_hip_fail(e, "hipMalloc (work pools of the heavy pipeline)", __FILE__, __LINE__);
             (void)hipGetLastError();
-            b->hcap = std::max<uint32_t>(std::min<uint32_t>(1024u, b->max_units), b->hcap / 2);
-            b->task_cap = std::max<uint32_t>(4096u, b->task_cap / 2);
+            // (the floors never RAISE a pool: a caller's small limits — the tests' way into the many-round paths — stay as they are)
+            b->hcap = std::min<uint32_t>(b->hcap, std::max<uint32_t>(std::min<uint32_t>(1024u, b->max_units), b->hcap / 2));
+            b->task_cap = std::min<uint32_t>(b->task_cap, std::max<uint32_t>(4096u, b->task_cap / 2));
         }
         if (b->trace) fprintf(stderr, "[bsx] batch %p: pools for %u deferred units per round, %u scan tasks (planned %u / %u)\n", (void *)b, b->hcap, b->task_cap, pl.hcap, pl.task_cap);
         if (getenv("BSX_POISON")) HIP_TRY(hipMemsetAsync(b->d_hstate, 0xA5, (size_t)b->hcap * bsx_hstate_bytes(), b->stream));  // test hook: recycled memory is not zero
@@ -521,7 +539,24 @@ static int ensure_scratch(bsx_batch *b)
     return BSX_OK;
 }
 
+static int batch_create_once(bsx_ref *r, uint32_t max_units, int paired, bsx_batch **out);
 extern "C" int bsx_batch_create(bsx_ref *r, uint32_t max_units, int paired, bsx_batch **out)
+{
+    int rc = batch_create_once(r, max_units, paired, out);
+    // The context table is an accelerator, not a requirement: where the FIXED part of the first batch (per-wave slabs, per-unit arrays, smallest pools) does
+    // not fit beside it, it goes and the batch is tried once more (no batch exists, so no kernel can hold its address; later batches find the memory as it is).
+    if (rc == BSX_ERR_NOMEM && r && r->d_ctx && r->n_batches == 0 && r->ctx_mode != 2) {
+        const std::string first = g_bsx_err;
+        (void)hipGetLastError();
+        if (bsx_ref_drop_context(r) == BSX_OK) {
+            rc = batch_create_once(r, max_units, paired, out);
+            if (rc == BSX_OK && getenv("BSX_TRACE_HEAVY")) fprintf(stderr, "[bsx] the index's context table was dropped to make room for the batch (%s)\n", first.c_str());
+        }
+    }
+    if (rc == BSX_OK) r->n_batches++;
+    return rc;
+}
+static int batch_create_once(bsx_ref *r, uint32_t max_units, int paired, bsx_batch **out)
 {
     if (!r || !out || max_units == 0) return BSX_ERR_ARG;
     if (!r->has_index) { g_bsx_err = "bsx_index_build must run before bsx_batch_create"; return BSX_ERR_STATE; }
@@ -579,6 +614,7 @@ extern "C" int bsx_batch_create(bsx_ref *r, uint32_t max_units, int paired, bsx_
     if (hipMalloc((void **)&b->d_scan_stats, 64 * 64) != hipSuccess) return fail(BSX_ERR_NOMEM);
     if (hipMemsetAsync(b->d_scan_stats, 0, 64 * 64, b->stream) != hipSuccess) return fail(BSX_ERR_DEVICE);
     if ((rc = ensure_scratch(b)) != BSX_OK) return fail(rc);
+    b->counted = true;
     *out = b;
     return BSX_OK;
 }
@@ -611,6 +647,7 @@ extern "C" void bsx_batch_destroy(bsx_batch *b)
     if (b->ev_wait) (void)hipEventDestroy(b->ev_wait);
     for (hipEvent_t e : b->scan_ev) (void)hipEventDestroy(e);
     if (b->stream) (void)hipStreamDestroy(b->stream);
+    if (b->counted && b->ref->n_batches > 0) b->ref->n_batches--;
     delete b;
 }
 

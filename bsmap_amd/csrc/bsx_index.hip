@@ -175,9 +175,18 @@ int bsx_index_build_wgbs(bsx_ref *r)
     // the entries' context for the main kernel's prefilter (-I <= 4: its flank table holds four phases; BSX_CTX=0: none — 16 bytes per entry).  Not fatal:
     // without it the main kernel takes its plain path
     DevBuf<uint32_t> d_ctx;
-    const bool want_ctx = total && P.index_interval <= 4 && !(getenv("BSX_CTX") && atoi(getenv("BSX_CTX")) == 0);
+    bool want_ctx = total && P.index_interval <= 4 && r->ctx_mode != 0 && !(getenv("BSX_CTX") && atoi(getenv("BSX_CTX")) == 0);   // (BSX_CTX=0: test hook)
+    const uint64_t ctx_bytes = (total + BSX_ENTRY_PAD) * 16;
     if (want_ctx) {
         d_keys.reset(); d_vals.reset(); d_temp.reset();   // (the sort's inputs and workspace are spent)
+        // The table buys speed, never results: it must not take the memory the batches need (a smaller or shared device, several lanes on one GPU).
+        // Mode 1 (default) builds it only if `ctx_headroom` bytes stay free behind it — room for the fixed part of a 2^22-pair batch (20.6 GB of
+        // per-wave slabs and per-unit arrays) plus the pools' reserve; a batch whose fixed part still does not fit drops the table and tries again
+        // (bsx_batch_create).
+        size_t fr = 0, tot = 0;
+        if (r->ctx_mode == 1 && hipMemGetInfo(&fr, &tot) == hipSuccess && (uint64_t)fr < ctx_bytes + r->ctx_headroom) want_ctx = false;
+    }
+    if (want_ctx) {
         if (d_ctx.alloc((total + BSX_ENTRY_PAD) * 4) == 0) {
             HIP_TRY(hipMemset(d_ctx.p, 0, (total + BSX_ENTRY_PAD) * 16));
             const int grid = (int)std::min<uint64_t>((total + 255) / 256, 256 * 32);
@@ -191,6 +200,7 @@ int bsx_index_build_wgbs(bsx_ref *r)
     if (r->d_entries) (void)hipFree(r->d_entries);
     if (r->d_ctx) (void)hipFree(r->d_ctx);
     r->d_bucket_off = d_off.release(); r->d_bucket_nfwd = d_nfwd.release(); r->d_entries = d_entries.release(); r->d_ctx = d_ctx.release();
+    r->ctx_bytes = r->d_ctx ? ctx_bytes : 0;
     r->n_entries = total;
     r->has_index = true;
     return BSX_OK;
@@ -207,6 +217,7 @@ int bsx_index_build_rrbs(bsx_ref *r, const std::vector<uint32_t> &refcat, const 
     // the kernels take a read's candidates from the (segment, direction) group of its bucket: 16 segments per direction (RRBS forces
     // seed 12, i.e. 12 segments of a 144-nt read; a shorter seed would need more groups than the table has)
     if (P.max_seedseg_num > 16) { g_bsx_err = "RRBS index: more than 16 seed segments per read"; return BSX_ERR_LIMIT; }
+    if (r->d_ctx) { (void)hipFree(r->d_ctx); r->d_ctx = nullptr; r->ctx_bytes = 0; }   // (an RRBS index has no context table: the prefiltered kernel must never see a stale one)
     auto seed_at = [&](uint32_t chr, uint32_t loc) {
         const uint32_t *m = ((chr & 1) ? crefcat.data() : refcat.data()) + r->anchor[chr >> 1] / BSX_SEGLEN + (loc >> 4);
         const uint64_t v = ((uint64_t)m[0] << 32) | m[1];

@@ -14,6 +14,7 @@
 #define BSX_HSET_BITS 15
 #define BSX_HSET_SLOTS (1u << BSX_HSET_BITS)  // duplicate-suppression hash set, >= 2x the most hits a read can collect
 #define BSX_ENTRY_PAD 512  /* zeroed words behind the index entries: k_hscan loads whole 256-entry chunks */
+#define BSX_CTX_HEADROOM_DEFAULT (32ull << 30)  /* free device bytes the optional context table must leave (bsx.h: bsx_ref_set_context) */
 #define BSX_SORT_TMP 1280            // scratch entries for sorting one class list      // chromosomes whose anchors are staged in LDS by the align kernel
 
 // everything the align kernel needs, passed by value as the kernel argument
@@ -70,6 +71,10 @@ struct bsx_ref {
     std::vector<uint32_t> rrbs_entries_host;  // RRBS entries in the reference's order (the device copy is grouped, see bsx_index_build_rrbs)
     uint64_t n_entries = 0;
     bool has_index = false;
+    // the entries' context table (d_ctx, 16 bytes per entry; bsx_ref_set_context): 0 never, 1 only if ctx_headroom bytes stay free behind it, 2 whenever it can be allocated
+    int ctx_mode = 1;
+    uint64_t ctx_headroom = BSX_CTX_HEADROOM_DEFAULT, ctx_bytes = 0;
+    int n_batches = 0;   // device batches alive on this reference (the context may only be dropped while none can be running)
     uint64_t synth_seed = 0;
 };
 

@@ -96,8 +96,19 @@ int bsx_ref_blocks(const bsx_ref *r, uint32_t *id, uint32_t *begin, uint32_t *en
 int bsx_ref_download_words(const bsx_ref *r, uint32_t *refcat, uint32_t *crefcat);  /* device -> host, n_words each */
 
 /* ---- seed index: RefSeq::CreateIndex (dbseq.cpp:516-539) ---------------------------------------- */
-/* (WGBS, -I <= 4: the build also stores, per entry, the 32 reference nt left and right of the entry's seed — 16 bytes per entry, 23.6 GB at hg38 size —
- *  for the main kernel's context prefilter, which runs where the work counters are off; BSX_CTX=0 in the environment builds none) */
+/* (WGBS, -I <= 4: the build can also store, per entry, the 32 reference nt left and right of the entry's seed — the CONTEXT TABLE, 16 bytes per entry,
+ *  23.6 GB at hg38 size — for the main kernel's context prefilter, which runs where the work counters are off.  It buys speed, never results, and it must
+ *  not take the memory the batches need:
+ *    bsx_ref_set_context(r, mode, headroom)  before bsx_index_build.  mode 0: never; 1 (default): only if `headroom` bytes of device memory stay free
+ *        behind it (0 = the default, 32 GiB: the fixed part of a 2^22-pair batch — 20.6 GB of per-wave slabs and per-unit arrays — plus the pools'
+ *        reserve); 2: whenever it can be allocated, and never dropped.
+ *    bsx_ref_context_bytes(r)                what the built index holds (0: none).
+ *    bsx_ref_drop_context(r)                 frees it (BSX_ERR_STATE while a batch of the reference exists: a running kernel may hold its address).
+ *  In modes 0 / 1 bsx_batch_create itself drops the table and tries once more when the FIRST batch of a reference does not fit beside it.
+ *  Test hook: BSX_CTX=0 in the environment builds none.) */
+int bsx_ref_set_context(bsx_ref *r, int mode, uint64_t headroom_bytes);
+uint64_t bsx_ref_context_bytes(const bsx_ref *r);
+int bsx_ref_drop_context(bsx_ref *r);
 int bsx_index_build(bsx_ref *r);                        /* built on the GPU; entry order identical to the reference */
 uint64_t bsx_index_n_entries(const bsx_ref *r);
 /* CSR copy-out: bucket_off[total_kmers+1], bucket_nfwd[total_kmers], entries[n_entries]
@@ -235,8 +246,9 @@ int bsx_set_waves_per_cu(int waves);
  * heavy pipeline (chip-wide scan tasks + resumable control passes); 0 = the library's choice by mode (32768 WGBS, 4096 RRBS),
  * a value no list reaches = never.  Results do not depend on it. */
 int bsx_set_heavy_threshold(int n_candidates);
-/* pool sizes of the heavy pipeline for batches created afterwards (defaults 24576 units per round and up to 524288 scan tasks, both scaled down for small batches; at most 2^22);
- * small values only make it take more rounds / passes — used by the tests to exercise those paths; (0, 0) restores the defaults */
+/* pool sizes of the heavy pipeline for batches created afterwards (the defaults follow the batch: bsx_default_heavy_limits returns them — up to 262144 units per round
+ * (64 GB of slabs) and 2^22 scan tasks for a 2^22-pair batch —, and bsx_batch_pool_sizes what a batch ended up with); small values only make it take more rounds / passes —
+ * used by the tests to exercise those paths; (0, 0) restores the defaults.  The halving below never raises a value set here. */
 int bsx_set_heavy_limits(uint32_t units_per_round, uint32_t task_pool);
 /* Either way those are STARTING sizes: a batch halves its pools until they fit the device's free memory with a reserve to spare —
  * by default room for one more batch like itself (per-wave slabs + per-unit arrays) plus 4 GB; bsx_set_pool_reserve(bytes) sets the

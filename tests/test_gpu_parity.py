@@ -800,3 +800,58 @@ def test_random_option_combinations_without_work_counters(seed, edge_genome, ora
 def test_empty_and_degenerate_inputs_without_work_counters(edge_genome, oracle, monkeypatch):
     monkeypatch.setenv("BSX_WORK_COUNTERS", "0")
     test_empty_and_degenerate_inputs(edge_genome, oracle)
+
+
+# ---- the heavy pipeline's replay with the work counters off (round 6): a lowered threshold (align.cpp:278) no longer ends a window — the survivors behind the
+# event are replayed under the new threshold in the same control pass (snp_align_heavy, BSX_EVENT_CONTINUE).  The cap / early-return cases, the option draws and
+# the degenerate genome are where thresholds fall all the time.
+@pytest.mark.parametrize("extra", [dict(w=20), dict(w=3, r=0), dict(w=150, n=1), dict(r=0, v=3), dict(w=1), dict(w=2, v=8)], ids=["w20", "w3_r0", "w150_n1", "r0_v3", "w1", "w2_v8"])
+def test_heavy_pipeline_caps_and_early_returns_without_work_counters(extra, heavy_genome, oracle, monkeypatch):
+    monkeypatch.setenv("BSX_WORK_COUNTERS", "0")
+    test_heavy_pipeline_large_buckets(False, heavy_genome, oracle, extra, work_counters=False)
+    if "n" not in extra:
+        test_heavy_pipeline_large_buckets(True, heavy_genome, oracle, extra, work_counters=False)
+
+
+@pytest.mark.parametrize("seed", list(range(1, 9)))
+def test_heavy_pipeline_random_options_without_work_counters(seed, heavy_genome, oracle, monkeypatch):
+    monkeypatch.setenv("BSX_WORK_COUNTERS", "0")
+    test_heavy_pipeline_random_options(seed, heavy_genome, oracle)
+
+
+def test_heavy_pipeline_degenerate_genome_without_work_counters(oracle, tmp_path, monkeypatch):
+    monkeypatch.setenv("BSX_WORK_COUNTERS", "0")
+    test_heavy_pipeline_degenerate_genome(oracle, tmp_path)
+
+
+def test_context_table_is_optional_and_droppable(heavy_genome, oracle):
+    """bsx_ref_set_context / bsx_ref_context_bytes / bsx_ref_drop_context: the table of the main kernel's prefilter is built by the headroom rule,
+    never when switched off, is refused a drop while a batch lives, and records are the same with and without it"""
+    g, fa = heavy_genome
+    kw = dict(s=16, v=6, I=4, S=1, r=1, m=28, x=500, pairend=1)
+    pairs = td.make_pe_reads(g, 1500, 144, seed=18, sub_rate=0.01)
+    s1, o1 = oracle.pack_reads([p["seq1"] for p in pairs])
+    s2, o2 = oracle.pack_reads([p["seq2"] for p in pairs])
+    outs = []
+    for context, headroom, expect in ((0, 0, False), (1, 1 << 50, False), (1, 0, True), (2, 0, True)):
+        gref = B.RefSeq(B.make_params(**kw)).Run_ConvertBinseq(fasta_path=fa).CreateIndex(context=context, headroom=headroom)
+        assert (gref.context_bytes > 0) == expect, (context, headroom, gref.context_bytes)
+        if expect:
+            assert gref.context_bytes >= 16 * gref.n_entries
+        pa = B.PairAlign(gref, len(pairs)).set_work_counters(False)
+        pa.ImportBatchReads((s1, o1), (s2, o2)).Do_Batch()
+        out, ca, cb, npairs = pa.results()
+        outs.append((out.tobytes(), ca.tobytes(), cb.tobytes(), npairs.tobytes()))
+        if expect:
+            with pytest.raises(Exception):
+                gref.drop_context()   # a batch of the reference exists
+        pa.close()
+        gref.drop_context()
+        assert gref.context_bytes == 0
+        pa = B.PairAlign(gref, len(pairs)).set_work_counters(False)   # the same reference without its table: the plain main kernel
+        pa.ImportBatchReads((s1, o1), (s2, o2)).Do_Batch()
+        out, ca, cb, npairs = pa.results()
+        assert (out.tobytes(), ca.tobytes(), cb.tobytes(), npairs.tobytes()) == outs[-1]
+        pa.close()
+        gref.close()
+    assert all(o == outs[0] for o in outs)
