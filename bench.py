@@ -205,6 +205,7 @@ def main():
     import numpy as np
     import bsmap_amd as B
 
+    rank_cpus = pin_rank_to_gpu_node(B, local_rank, world) if world > 1 else None
     if args.waves_per_cu:
         B.lib().bsx_set_waves_per_cu(args.waves_per_cu)
     if args.heavy_threshold:
@@ -376,7 +377,10 @@ def main():
         "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u32", "data": "synthetic" if not real_fa else "synthetic reads sampled from " + os.path.basename(real_fa),
         "config": {"workload": M["workload"], "pairs_per_step" if pe else "reads_per_step": B_, "genome_bp": int(sum(lens)), "index_entries": int(ref.n_entries),
-                   "parallelism": f"read-sharded x{world}", "batches_in_flight": nfl, "work_counters_in_timed_region": bool(args.work_counters), "lib_sha16": sha, "exact_mode": bool(args.exact),
+                   "parallelism": f"read-sharded x{world}",
+                   # what the one collective of the path saw: a row per rank of the all-gather (RCCL under the launcher), each rank's own time per step — `value` uses the slowest
+                   "ranks": {"seen_by_all_gather": int(allstats.shape[0]), "backend": (dist.get_backend() if dist is not None else None),
+                             "ms_per_step_by_rank": [round(float(t) / args.steps * 1e3, 3) for t in allstats[:, 0]], "rank0_pinned_cpus": rank_cpus}, "batches_in_flight": nfl, "work_counters_in_timed_region": bool(args.work_counters), "lib_sha16": sha, "exact_mode": bool(args.exact),
                    "resident_ring_steps": ring, "heavy_pools": [{"units_per_round": u_, "scan_tasks": t_} for u_, t_ in pools], "device_memory_plan": plan,
                    "setup_s": {"genome": round(t_gen, 2), "index_build_gpu": round(t_index, 2), "device_batches": round(t_batches, 2)},
                    "records_flagged_BSX_F_LIMIT": int(tot_counters[16]) if len(tot_counters) > 16 else None,   # (the one capacity deviation from the reference, include/bsx.h: counted, 0)
@@ -852,6 +856,40 @@ def end_to_end(pairs, genome):
                 "command": "bsmap -a r_1.fq -b r_2.fq -d genome.fa -o out.sam -s 16 -v 6 -m 28 -x 500 -S 1"}
     except Exception as e:  # the metric above does not depend on this leg
         return {"error": str(e)[:300]}
+
+
+def rank_cpu_share(cpus_of_node, ranks_on_node, k, per_rank):
+    """the CPUs rank k (of `ranks_on_node` ranks that share a NUMA node) pins to: `per_rank` consecutive CPUs of the node's list, the ranks side by side;
+    None when the node has fewer than that to give (no pinning then)"""
+    cpus = sorted(cpus_of_node)
+    if per_rank < 1 or len(cpus) < ranks_on_node * per_rank:
+        return None
+    return set(cpus[k * per_rank:(k + 1) * per_rank])
+
+
+def pin_rank_to_gpu_node(B, local_rank, world):
+    """A rank's host side is its driver threads (one per batch in flight; they sleep on events) and the Python that queues them: pin the process to its
+    share of the CPU quota on the NUMA node of ITS GPU, so that page-locked buffers, launch queues and the threads that touch them sit beside the device
+    (the command line does the same per lane: csrc/bsx_cpus.h).  Returns the CPU set, or None where nothing was pinned (no quota headroom, no sysfs)."""
+    try:
+        n_dev = max(1, B.lib().bsx_device_count())
+        nodes = [B.lib().bsx_device_numa_node(d) for d in range(min(world, n_dev))]
+        node = nodes[local_rank] if local_rank < len(nodes) else -1
+        if node < 0:
+            return None
+        have = os.sched_getaffinity(0)
+        cpus = []
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus += [c for c in range(int(a), int(b or a) + 1) if c in have]
+        same = [r for r in range(len(nodes)) if nodes[r] == node]
+        per_rank = max(2, usable_cpus() // max(1, world))
+        share = rank_cpu_share(cpus, len(same), same.index(local_rank), per_rank)
+        if share:
+            os.sched_setaffinity(0, share)
+        return sorted(share) if share else None
+    except (OSError, ValueError, AttributeError):
+        return None
 
 
 def usable_cpus():

@@ -1126,8 +1126,13 @@ __device__ __forceinline__ uint32_t first_chr_ge(const u64 *lst, uint32_t from, 
 }
 
 // PairAlign::GetPairs (pairs.cpp:34-135)
+// lds (the heavy control kernel's per-wave sort buffer, or null): the b hits of the current chromosome are staged there when more than 64 and at most BSX_LDS_SORT —
+// a read pair in a repeat family brings up to -w hits per class and side on ONE chromosome, and the literal loop (every a hit against every 64 b hits, from HBM) was the
+// longest single span of a C5 control pass: 31 M cycles, 13 ms, for one unit (profiles/r06d_ctrl_clocks_trim.json).  Where the staged hits are sorted by position (they are,
+// bar the -w overshoot entries) the b hits within the insert range of an a hit are a contiguous run: one 64-lane probe bounds it, and only the chunks that overlap it are
+// evaluated — by the same per-hit test, in the same order, so the pair rows are the reference's entry for entry.
 __device__ int get_pairs(const DevParams &P, const Mate &MA, const Mate &MB, const Slab &SA, const Slab &SB, const PairSlab &PS,
-                         uint32_t &pcnt_reg, int na, int nb, int lane)
+                         uint32_t &pcnt_reg, int na, int nb, int lane, u64 *lds = nullptr)
 {
     if (na > MA.u->max_snp || nb > MB.u->max_snp) return 0;
     const int cls = na + nb;
@@ -1139,7 +1144,8 @@ __device__ int get_pairs(const DevParams &P, const Mate &MA, const Mate &MB, con
         const uint32_t n_a = n_of(MA, pass, na), n_b = n_of(MB, 1 - pass, nb);
         uint32_t chra = 0xffffffffu, bstart = 0, bend = 0;
         u64 hb_cache = 0;     // the b hits of the current chromosome, when there are at most 64 of them
-        bool cached = false;
+        bool cached = false, staged = false, narrow = false;
+        uint32_t stride = 1;
         for (uint32_t a_base = 0; a_base < n_a && result < 0; a_base += 64) {
           // 64 a hits per load; the loops below then run out of registers (the lists live in HBM: a load per a hit and
           // per 64 b hits made this join the longest span of the heavy control passes)
@@ -1154,11 +1160,39 @@ __device__ int get_pairs(const DevParams &P, const Mate &MA, const Mate &MB, con
                 bend = first_chr_ge(bl, bstart, n_b, chra, true, lane);
                 cached = bend - bstart <= 64;
                 if (cached) hb_cache = bstart + lane < bend ? bl[bstart + lane] : 0;
+                const uint32_t nr = bend - bstart;
+                staged = lds != nullptr && !cached && nr <= (uint32_t)BSX_LDS_SORT;
+                narrow = false;
+                if (staged) {
+                    bool okl = true;   // positions ascending and small enough for the interval arithmetic below to be exact
+                    for (uint32_t i = (uint32_t)lane; i < nr; i += 64) {
+                        const u64 v = bl[bstart + i];
+                        lds[i] = v;
+                        okl = okl && (uint32_t)v < 0x40000000u && (i + 1 >= nr || (uint32_t)v <= (uint32_t)bl[bstart + i + 1]);
+                    }
+                    wave_fence();
+                    narrow = !bsx_ballot(!okl);
+                    stride = (nr + 63u) / 64u;
+                }
             }
-            for (uint32_t jb = bstart; jb < bend && result < 0; jb += 64) {
+            uint32_t j_lo = bstart, j_hi = bend;
+            if (narrow && aloc < 0x40000000u) {
+                // the b positions whose insert size can lie in [min_insert, max_insert] (pairs.cpp:72-75,99-102), and a run of staged hits that holds them all
+                const bool odd_ = (chra & 1) != 0, b_first = pass == 0 ? odd_ : !odd_;
+                const long long lo_ = b_first ? (long long)aloc + MA.u->len - P.max_insert : (long long)aloc + P.min_insert - MB.u->len;
+                const long long hi_ = b_first ? (long long)aloc + MA.u->len - P.min_insert : (long long)aloc + P.max_insert - MB.u->len;
+                const uint32_t nr = bend - bstart, pi = (uint32_t)lane * stride;
+                const long long pv = pi < nr ? (long long)(uint32_t)lds[pi] : (1ll << 40);
+                const u64 ge_lo = bsx_ballot(pv >= lo_), gt_hi = bsx_ballot(pv > hi_);
+                const uint32_t f_lo = ge_lo ? (uint32_t)__builtin_ctzll(ge_lo) : 64u, f_hi = gt_hi ? (uint32_t)__builtin_ctzll(gt_hi) : 64u;
+                j_lo = bstart + (f_lo ? (f_lo - 1u) * stride : 0u);
+                j_hi = min(bend, bstart + f_hi * stride);
+                if (j_hi < j_lo) j_hi = j_lo;
+            }
+            for (uint32_t jb = j_lo; jb < j_hi && result < 0; jb += 64) {
                 const uint32_t j = jb + lane;
-                const bool valid = j < bend;
-                const u64 hb = cached ? hb_cache : (valid ? bl[j] : 0);
+                const bool valid = j < j_hi;
+                const u64 hb = cached ? hb_cache : (valid ? (staged ? lds[j - bstart] : bl[j]) : 0);
                 const uint32_t bloc = (uint32_t)hb;
                 uint32_t seg_start, seg_end;
                 const bool odd = (chra & 1) != 0;
@@ -1442,8 +1476,8 @@ __device__ int pair_level_post(const DevParams &P, const Mate &MA, const Mate &M
 {
     if (i <= MA.u->max_snp) { sort_list(U.SA.list(0, i), n_of(MA, 0, i), U.SA.tmp, lane, lds_sort); sort_list(U.SA.list(1, i), n_of(MA, 1, i), U.SA.tmp, lane, lds_sort); }
     if (i <= MB.u->max_snp) { sort_list(U.SB.list(0, i), n_of(MB, 0, i), U.SB.tmp, lane, lds_sort); sort_list(U.SB.list(1, i), n_of(MB, 1, i), U.SB.tmp, lane, lds_sort); }
-    int n = get_pairs(P, MA, MB, U.SA, U.SB, U.PS, pcnt_reg, i, i, lane);
-    for (int j = 0; j < i; j++) n += get_pairs(P, MA, MB, U.SA, U.SB, U.PS, pcnt_reg, i, j, lane) + get_pairs(P, MA, MB, U.SA, U.SB, U.PS, pcnt_reg, j, i, lane);
+    int n = get_pairs(P, MA, MB, U.SA, U.SB, U.PS, pcnt_reg, i, i, lane, lds_sort);
+    for (int j = 0; j < i; j++) n += get_pairs(P, MA, MB, U.SA, U.SB, U.PS, pcnt_reg, i, j, lane, lds_sort) + get_pairs(P, MA, MB, U.SA, U.SB, U.PS, pcnt_reg, j, i, lane, lds_sort);
     return n;
 }
 
@@ -1656,14 +1690,17 @@ struct HMate {
     uint8_t start[2][16], order[2][16];
     uint32_t stale_key[2][16];  // "-p 1 exact" mode: make_list needs the tail entries again on later visits
 };
-#define HS_NSLOT 2  /* list slots of a unit: the list each mate is working on */
+#define HS_NSLOT 4  /* list slots of a unit: slot = 2 * mate + read orientation — the list each mate is working on, and (round 6, work counters off) the other orientation's list of the same SnpAlign call, published ahead */
+#ifndef BSX_SPECULATE
+#define BSX_SPECULATE 1  /* snp_align_heavy: publish the complementary-chain list together with the last window of the direct-chain list */
+#endif
 struct HState {
     uint32_t want;  // tasks of a request the pool refused (0: none): the unit is only restored once that many are free
     int32_t level, sub;
     int32_t paired;
     // per list cursor (slot = mate): both mates of a pair publish their lists of a level in the same visit (their SnpAlign calls
     // are independent, pairs.cpp:165-166), so each keeps its own orientation / position / window
-    int32_t orient[2], have[2];
+    int32_t orient[2], have[HS_NSLOT];
     uint32_t c[2], W[2];
     uint32_t t0[HS_NSLOT], n_tasks[HS_NSLOT], win_c0[HS_NSLOT], win_n[HS_NSLOT];  // the published window: tasks t0.. cover candidates [win_c0, win_c0+win_n)
     Counters C;
@@ -1715,10 +1752,10 @@ __device__ void load_mate(const HMate &d, Mate &M, MateLds &L, int lane)
     wave_fence();
 }
 
-struct HCursor { int level, sub, paired; int orient[2], have[2]; uint32_t c[2], W[2], n_active, want; u64 vc[6]; uint32_t vn[6]; };  // vc/vn: per-visit category clocks and counts (diagnostics)
+struct HCursor { int level, sub, paired; int orient[2], have[HS_NSLOT]; uint32_t c[2], W[2], n_active, want; u64 vc[8]; uint32_t vn[8]; };  // vc/vn: per-visit category clocks and counts (diagnostics)
 
 // diagnostic category clocks of k_hctrl (only when the caller asked for unit cycles): 0 prepare/restore, 1 inline scans,
-// 2 survivor replay, 3 sort+pairs, 4 save/finish, 5 recount after events
+// 2 survivor replay, 3 sort+pairs, 4 save/finish, 5 recount after events, (6 the whole advance,) 7 the rest of an overflowed task behind its recorded survivors
 #define CAT_BEGIN(A) const u64 cat_t0_ = (A).dbg_cat ? __builtin_readcyclecounter() : 0
 #define CAT_END(A, k) do { if ((A).dbg_cat) { const u64 d_ = (u64)__builtin_readcyclecounter() - cat_t0_; K.vc[k] += d_; K.vn[k]++; if (lane == 0) { atomicAdd((u64 *)&(A).dbg_cat[k], d_); atomicMax((u64 *)&(A).dbg_cat[8 + (k)], d_); } } } while (0)
 
@@ -1834,6 +1871,7 @@ __device__ __forceinline__ int snp_align_heavy(const AlignArgs &A, const HeavyAr
     const DevParams &P = A.P;
     for (; K.orient[ms] < 2; K.orient[ms]++, K.c[ms] = 0, K.W[ms] = HS_WIN0) {
         const int orient = K.orient[ms];
+        const int slot = 2 * ms + orient;
         if (!((M.u->flags >> orient) & 1)) continue;
         const int seg = L.order[orient][mode];
         const CandList cl = make_list<true>(P, BL, L, M, orient, seg, lane);
@@ -1845,11 +1883,11 @@ __device__ __forceinline__ int snp_align_heavy(const AlignArgs &A, const HeavyAr
             continue;
         }
         while (K.c[ms] < cl.total) {
-            if (K.have[ms]) {
-                K.have[ms] = 0;
+            if (K.have[slot]) {
+                K.have[slot] = 0;
                 // (task descriptors in the pool may already have been reused by other units of this pass: the window is
                 //  reconstructed from the unit's own state, only the task OUTPUTS are read from the pool)
-                const uint32_t t0 = rfl(S->t0[ms]), nt = rfl(S->n_tasks[ms]), req_thres = rfl(S->req[ms].thres);
+                const uint32_t t0 = rfl(S->t0[slot]), nt = rfl(S->n_tasks[slot]), req_thres = rfl(S->req[slot].thres);
                 const bool cont_events = BSX_EVENT_CONTINUE && !A.work_counters;
                 bool restart = false;
                 for (uint32_t tg = 0; tg < nt && !restart; tg += 64) {
@@ -1941,7 +1979,12 @@ __device__ __forceinline__ int snp_align_heavy(const AlignArgs &A, const HeavyAr
                         const uint32_t t = tg + nxt;
                         const uint32_t tc0 = rl(gc0, (int)nxt), tn = rl(gn_, (int)nxt);
                         const HTaskOut *o = &H.tout[t0 + t];
-                        if (rl(hov, (int)nxt)) {  // too many survivors for the record: redo this task with the one-wave path
+                        // A task with more survivors than its record holds (HS_SCAP) carries the FIRST HS_SCAP of them, in list order.  With the work counters on the
+                        // owning wave redoes the whole task itself (exact counters).  Without them the recorded prefix is replayed like any other record, and only
+                        // what lies behind its last survivor is still open (below) — a one-wave scan of 8 192 candidates is 128 dependent round trips, and
+                        // short reads in repeats overflow in most tasks of their first windows (C5).
+                        const bool ovt = rl(hov, (int)nxt) != 0;
+                        if (ovt && !cont_events) {  // too many survivors for the record: redo this task with the one-wave path
                             CAT_BEGIN(A);
                             const int r = wave_scan_range<false, 4>(P, BL, L, M, SL, cl, orient, seg, mode, tc0, tc0 + tn, 0, lane, C);
                             CAT_END(A, 1);
@@ -1951,7 +1994,7 @@ __device__ __forceinline__ int snp_align_heavy(const AlignArgs &A, const HeavyAr
                             continue;
                         }
                         int event = 0; uint32_t X = 0;
-                        const uint32_t nv = rl(hc, (int)nxt);
+                        const uint32_t nv = ovt ? (uint32_t)HS_SCAP : rl(hc, (int)nxt);
                         CAT_BEGIN(A);
                         for (uint32_t base = 0; base < nv && !event; base += 64) {
                             const uint32_t i = base + lane;
@@ -1976,12 +2019,25 @@ __device__ __forceinline__ int snp_align_heavy(const AlignArgs &A, const HeavyAr
                             }
                         }
                         CAT_END(A, 2);
-                        if (!event) {
+                        if (!event && ovt) {
+                            // (work counters off) behind the last recorded survivor: if the threshold has fallen since the window was published, the scan kernel
+                            // will find fewer survivors there — the window ends here and the rest is published again (at most max_snp such cuts per list);
+                            // otherwise the rest of this one task is walked by the wave itself, as the whole task used to be
+                            const uint32_t c_next = tc0 + (rfl(o->surv[HS_SCAP - 1u].w_ord) >> 8) + 1u;
+                            if (M.u->snp_thres < req_thres) { K.c[ms] = c_next; restart = true; }
+                            else {
+                                CAT_BEGIN(A);
+                                const int r = c_next < tc0 + tn ? wave_scan_range<false, 4>(P, BL, L, M, SL, cl, orient, seg, mode, c_next, tc0 + tn, 0, lane, C) : 0;
+                                CAT_END(A, 7);   // (its own clock: what is left of the one-wave scans of overflowed tasks)
+                                if (r == 2) { wave_fence(); return 1; }
+                                K.c[ms] = tc0 + tn;
+                            }
+                        } else if (!event) {
                             C.n_cand += rl(h0, (int)nxt);
                             C.sum_w += rl(hw, (int)nxt);
                             K.c[ms] = tc0 + tn;
                         } else {  // count exactly the candidates up to and including the one that caused the event
-                            { CAT_BEGIN(A); wave_scan_range<true, 4>(P, BL, L, M, SL, cl, orient, seg, mode, tc0, X + 1, req_thres, lane, C); CAT_END(A, 5); }
+                            if (A.work_counters) { CAT_BEGIN(A); wave_scan_range<true, 4>(P, BL, L, M, SL, cl, orient, seg, mode, tc0, X + 1, req_thres, lane, C); CAT_END(A, 5); }
                             K.c[ms] = X + 1;
                             if (event == 2) { wave_fence(); return 1; }
                             restart = true;
@@ -1995,8 +2051,25 @@ __device__ __forceinline__ int snp_align_heavy(const AlignArgs &A, const HeavyAr
                 const uint32_t wpool = (u64)tfit * HS_TASK < (u64)weff ? tfit * HS_TASK : weff;  // a window must fit the task pool
                 const uint32_t wn = min(wpool, cl.total - K.c[ms]);
                 uint32_t nt = 0;
-                if (publish_window(P, H, S, hidx, ms, cl, orient, seg, L, M, K.c[ms], wn, lane, nt)) K.have[ms] = 1;
-                else K.want = nt;  // the request is repeated in a later iteration, once the pool can take it
+                if (orient == 0) K.have[slot + 1] = 0;   // (a list published ahead is only good for the very next pass: its records live one pass)
+                if (publish_window(P, H, S, hidx, slot, cl, orient, seg, L, M, K.c[ms], wn, lane, nt)) {
+                    K.have[slot] = 1;
+                    // Publish ahead (work counters off).  This window takes the direct-chain list to its end: the next thing the call does is the complementary-chain
+                    // list (align.cpp:300), under a threshold that can only have fallen by then — its first window goes out now, under today's threshold, and the
+                    // replay takes from its records what the threshold of the moment admits (as behind any lowered threshold).  One control pass per SnpAlign call and
+                    // mate instead of two.  If the call returns inside the direct chain (align.cpp:277) the records are never read.  Only while the task pool is
+                    // less than half full: a refused request of ANOTHER unit costs that unit a pass.
+                    if (BSX_SPECULATE && !A.work_counters && orient == 0 && K.c[ms] + wn == cl.total && ((M.u->flags >> 1) & 1)) {
+                        const int seg1 = L.order[1][mode];
+                        const CandList cl1 = make_list<true>(P, BL, L, M, 1, seg1, lane);
+                        const uint32_t w1 = min(K.n_active < 2048u ? (uint32_t)HS_WINMAX : (uint32_t)HS_WIN0, min(wpool, cl1.total));
+                        if (cl1.total >= min(A.heavy_threshold, (uint32_t)HS_TASK_MIN) &&
+                            rfl(__hip_atomic_load(H.n_tasks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) + w1 / HS_TASK + 66u <= H.task_cap / 2u) {
+                            uint32_t nt1 = 0;
+                            if (publish_window(P, H, S, hidx, slot + 1, cl1, 1, seg1, L, M, 0u, w1, lane, nt1)) K.have[slot + 1] = 1;
+                        }
+                    }
+                } else K.want = nt;  // the request is repeated in a later iteration, once the pool can take it
                 wave_fence();
                 return 2;
             }
@@ -2024,10 +2097,10 @@ __device__ __forceinline__ bool heavy_advance(const AlignArgs &A, const HeavyArg
                 if ((K.sub >> m) & 1) continue;
                 Mate &M = m ? MB : MA;
                 if (K.level < M.u->seedseg && snp_align_heavy(A, H, S, hidx, BL, m ? LB : LA, M, m ? U.SB : U.SA, K.level, K, m, lane, C) == 2) { waiting = true; continue; }
-                K.sub |= 1 << m;
+                K.sub |= 1 << m; K.have[2 * m] = 0; K.have[2 * m + 1] = 0;
             }
             if (waiting) {
-                if (K.have[0] | K.have[1]) K.want = 0;  // a published window must be replayed in the next pass (its records live one pass): never parked
+                if (K.have[0] | K.have[1] | K.have[2] | K.have[3]) K.want = 0;  // a published window must be replayed in the next pass (its records live one pass): never parked
                 return false;
             }
             CAT_BEGIN(A);
@@ -2035,7 +2108,7 @@ __device__ __forceinline__ bool heavy_advance(const AlignArgs &A, const HeavyArg
             CAT_END(A, 3);
             if (np_ > 0) { K.paired = K.level + 1; return true; }
             K.level++; K.sub = 0;
-            for (int m = 0; m < 2; m++) { K.orient[m] = 0; K.c[m] = 0; K.W[m] = HS_WIN0; K.have[m] = 0; }
+            for (int m = 0; m < 2; m++) { K.orient[m] = 0; K.c[m] = 0; K.W[m] = HS_WIN0; K.have[2 * m] = 0; K.have[2 * m + 1] = 0; }
         }
     }
     // SingleAlign::RunAlign (align.cpp:445-449) for each surviving mate in turn; K.sub selects the mate (and its cursor slot)
@@ -2049,7 +2122,7 @@ __device__ __forceinline__ bool heavy_advance(const AlignArgs &A, const HeavyArg
         const u64 nz = P.rrbs ? 0ull : bsx_ballot(M.cnt_reg != 0 && (lane & 15) <= K.level && lane < 32);  // RRBS runs all rounds (align.cpp:448)
         if (nz) { K.sub++; K.level = 0; }
         else K.level++;
-        K.orient[ms] = 0; K.c[ms] = 0; K.W[ms] = HS_WIN0; K.have[ms] = 0;
+        K.orient[ms] = 0; K.c[ms] = 0; K.W[ms] = HS_WIN0; K.have[2 * ms] = 0; K.have[2 * ms + 1] = 0;
     }
 }
 
@@ -2074,6 +2147,7 @@ __global__ __launch_bounds__(256, PE ? BSX_HCTRL_WAVES : BSX_HCTRL_WAVES_SE) voi
     __shared__ HCursor KS[4];
     __shared__ Counters CS[4];
     __shared__ UnitSlabs US[4];
+    __shared__ uint32_t PEND[4][32];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (uint32_t i = threadIdx.x; i < sizeof(AlignArgs) / 4; i += 256) ((uint32_t *)&As)[i] = ((const uint32_t *)&A_)[i];
     for (uint32_t i = threadIdx.x; i < sizeof(HeavyArgs) / 4; i += 256) ((uint32_t *)&Hs)[i] = ((const uint32_t *)&H_)[i];
@@ -2087,11 +2161,21 @@ __global__ __launch_bounds__(256, PE ? BSX_HCTRL_WAVES : BSX_HCTRL_WAVES_SE) voi
     Counters Cflush = {0, 0, 0, 0};
     u64 n_units_done = 0, n_aligned = 0, n_aligned_pairs = 0;
     const uint32_t n_active_in = H.fresh ? H.n_active_in : rfl(*H.n_active_in_ptr);  // later passes: count left by the previous pass
+    // One word takes ~88 atomics per microsecond and an RRBS pass visits 10^5 units: a wave takes queue entries in chunks (one while units are few: the pass
+    // then ends with its longest visit, not with a wave's leftover chunk) and hands in the units it leaves active 32 at a time (PEND).
+    const uint32_t q_chunk = BSX_HCTRL_BATCH ? max(1u, min(16u, n_active_in / (gridDim.x * 128u))) : 1u;   // (RRBS: 175 short visits per wave and pass, chunks of 5; C5: 25 long ones, one at a time)
+    uint32_t q_next = 0, q_end = 0, n_pend = 0;
+    uint32_t *const pend = PEND[wv];
+#define HCTRL_PEND_FLUSH() do { if (n_pend) { uint32_t b_ = 0; if (lane == 0) b_ = atomicAdd(H.n_active_out, n_pend); b_ = rfl(b_); if ((uint32_t)lane < n_pend) H.active_out[b_ + (uint32_t)lane] = pend[lane]; n_pend = 0; wave_fence(); } } while (0)
+#define HCTRL_PEND_PUSH(x) do { if (lane == 0) pend[n_pend] = (x); n_pend++; wave_fence(); if (n_pend == (BSX_HCTRL_BATCH ? 32u : 1u)) HCTRL_PEND_FLUSH(); } while (0)
     for (;;) {
-        uint32_t i = 0;
-        if (lane == 0) i = atomicAdd(H.queue, 1u);
-        i = rfl(i);
-        if (i >= n_active_in) break;
+        if (q_next == q_end) {
+            uint32_t i0 = 0;
+            if (lane == 0) i0 = atomicAdd(H.queue, q_chunk);
+            q_next = rfl(i0); q_end = min(q_next + q_chunk, n_active_in);
+            if (q_next >= n_active_in) break;
+        }
+        const uint32_t i = q_next++;
         // (later passes take the list back to front: a unit whose visit ended last in the previous pass — a long visit — was appended
         //  last; starting those first keeps the pass from waiting for one long visit that began when all the others were done)
         const uint32_t hidx = H.fresh ? H.hidx_base + i : rfl(H.active_in[n_active_in - 1u - i]);
@@ -2102,7 +2186,7 @@ __global__ __launch_bounds__(256, PE ? BSX_HCTRL_WAVES : BSX_HCTRL_WAVES_SE) voi
             // n_tasks only grows during a pass, so the reservation below would be refused again
             const uint32_t want = rfl(S->want);
             if (want && rfl(__hip_atomic_load(H.n_tasks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) + want > H.task_cap) {
-                if (lane == 0) H.active_out[atomicAdd(H.n_active_out, 1u)] = hidx;
+                HCTRL_PEND_PUSH(hidx);
                 continue;
             }
         }
@@ -2118,13 +2202,13 @@ __global__ __launch_bounds__(256, PE ? BSX_HCTRL_WAVES : BSX_HCTRL_WAVES_SE) voi
         C.n_lookup = 0; C.n_cand = 0; C.sum_w = 0; C.n_orient = 0;
         HCursor &K = KS[wv];
         K.n_active = n_active_in; K.want = 0;
-        for (int k_ = 0; k_ < 6; k_++) { K.vc[k_] = 0; K.vn[k_] = 0; }
+        for (int k_ = 0; k_ < 8; k_++) { K.vc[k_] = 0; K.vn[k_] = 0; }
         uint32_t pcnt_reg = 0;
         const u64 cat_prep0 = A.dbg_cat ? __builtin_readcyclecounter() : 0;
         if (H.fresh) {
             unit_prepare<PE, true>(A, BL, LA, LB, MA, MB, unit, lane, C);
             K.level = 0; K.sub = 0; K.paired = 0;
-            for (int m_ = 0; m_ < 2; m_++) { K.orient[m_] = 0; K.have[m_] = 0; K.c[m_] = 0; K.W[m_] = HS_WIN0; }
+            for (int m_ = 0; m_ < 2; m_++) { K.orient[m_] = 0; K.have[2 * m_] = 0; K.have[2 * m_ + 1] = 0; K.c[m_] = 0; K.W[m_] = HS_WIN0; }
         } else {
             load_mate(S->mate[0], MA, LA, lane);
             if (PE) load_mate(S->mate[1], MB, LB, lane); else MB = MA;
@@ -2134,7 +2218,7 @@ __global__ __launch_bounds__(256, PE ? BSX_HCTRL_WAVES : BSX_HCTRL_WAVES_SE) voi
             pcnt_reg = S->pcnt_reg[lane];
             K.level = (int)rfl((uint32_t)S->level); K.sub = (int)rfl((uint32_t)S->sub); K.paired = (int)rfl((uint32_t)S->paired);
             for (int m_ = 0; m_ < 2; m_++) {
-                K.orient[m_] = (int)rfl((uint32_t)S->orient[m_]); K.have[m_] = (int)rfl((uint32_t)S->have[m_]); K.c[m_] = rfl(S->c[m_]); K.W[m_] = rfl(S->W[m_]);
+                K.orient[m_] = (int)rfl((uint32_t)S->orient[m_]); K.have[2 * m_] = (int)rfl((uint32_t)S->have[2 * m_]); K.have[2 * m_ + 1] = (int)rfl((uint32_t)S->have[2 * m_ + 1]); K.c[m_] = rfl(S->c[m_]); K.W[m_] = rfl(S->W[m_]);
             }
         }
         if (A.dbg_cat && lane == 0) { const u64 d_ = (u64)__builtin_readcyclecounter() - cat_prep0; atomicAdd((u64 *)&A.dbg_cat[0], d_); atomicMax((u64 *)&A.dbg_cat[8], d_); }
@@ -2163,14 +2247,17 @@ __global__ __launch_bounds__(256, PE ? BSX_HCTRL_WAVES : BSX_HCTRL_WAVES_SE) voi
             if (lane == 0) {
                 S->want = K.want; S->C = C; S->level = K.level; S->sub = K.sub; S->paired = K.paired;
                 for (int m_ = 0; m_ < 2; m_++) {
-                    S->orient[m_] = K.orient[m_]; S->have[m_] = K.have[m_]; S->c[m_] = K.c[m_]; S->W[m_] = K.W[m_];
+                    S->orient[m_] = K.orient[m_]; S->have[2 * m_] = K.have[2 * m_]; S->have[2 * m_ + 1] = K.have[2 * m_ + 1]; S->c[m_] = K.c[m_]; S->W[m_] = K.W[m_];
                 }
-                H.active_out[atomicAdd(H.n_active_out, 1u)] = hidx;
             }
+            HCTRL_PEND_PUSH(hidx);
         }
         if (A.dbg_cat && lane == 0) { const u64 d_ = (u64)__builtin_readcyclecounter() - cat_fin0; atomicAdd((u64 *)&A.dbg_cat[4], d_); atomicMax((u64 *)&A.dbg_cat[12], d_); }
         wave_fence();
     }
+    HCTRL_PEND_FLUSH();
+#undef HCTRL_PEND_PUSH
+#undef HCTRL_PEND_FLUSH
     if (lane == 0) flush_counters(A, Cflush, n_units_done, n_aligned, n_aligned_pairs);
 }
 
@@ -2410,7 +2497,7 @@ __device__ __forceinline__ void hp_task(const AlignArgs &A, const HeavyArgs &H, 
     const uint32_t n_cand = tn;
     const uint32_t words = STATS ? 2u * n_cand - n1 + 3u * n5 : 0u;  // 1, 2 or 5 words per candidate (see above); without the work counters: not known
     if (lane == 0) {
-        o->count = X.overflow ? 0 : X.nsurv; o->overflow = X.overflow ? 1 : 0; o->acc[0] = n_cand; o->acc[1] = words; o->acc[2] = 0; o->acc[3] = 0; o->c0 = tc0; o->n = tn;
+        o->count = min(X.nsurv, (uint32_t)HS_SCAP); o->overflow = X.overflow ? 1 : 0; o->acc[0] = n_cand; o->acc[1] = words; /* (overflowed: the first HS_SCAP survivors, in list order) */ o->acc[2] = 0; o->acc[3] = 0; o->c0 = tc0; o->n = tn;
         if (!X.overflow) {  // work of the scan kernel (incl. speculation); an overflowed task is redone by the control kernel.
             // Millions of tasks per batch: one counter word takes ~88 atomics per microsecond, so these statistics are
             // sharded over 64 cache lines (summed by bsx_batch_counters) instead of being added to four hot words
@@ -2754,7 +2841,7 @@ __device__ __forceinline__ void hs_group(const AlignArgs &A, const HeavyArgs &H,
     const bool ov = ns > HS_SCAP;
     if (mine) {
         HTaskOut *o = &H.tout[tid];
-        o->count = ov ? 0 : ns; o->overflow = ov ? 1 : 0; o->acc[0] = n_cand; o->acc[1] = STATS ? 2u * n_cand - n1 + 3u * n5 : 0u; o->acc[2] = 0; o->acc[3] = 0; o->c0 = tc0; o->n = n;
+        o->count = min(ns, (uint32_t)HS_SCAP); o->overflow = ov ? 1 : 0; o->acc[0] = n_cand; o->acc[1] = STATS ? 2u * n_cand - n1 + 3u * n5 : 0u; o->acc[2] = 0; o->acc[3] = 0; o->c0 = tc0; o->n = n;
     }
     const bool cnt = mine && !ov;
     const uint32_t kk = (uint32_t)__builtin_popcountll(bsx_ballot(cnt));
@@ -3036,7 +3123,7 @@ __global__ __launch_bounds__(256, BSX_HSHARED_WAVES) void k_hscan_shared(AlignAr
             const bool ov = ns > HS_SCAP;
             if (mine) {
                 HTaskOut *o = &H.tout[UW[wv][lane][16]];
-                o->count = ov ? 0 : ns; o->overflow = ov ? 1 : 0; o->acc[0] = n_cand; o->acc[1] = STATS ? 2u * n_cand - n1 + 3u * n5 : 0u; o->acc[2] = 0; o->acc[3] = 0; o->c0 = my_c0; o->n = n;
+                o->count = min(ns, (uint32_t)HS_SCAP); o->overflow = ov ? 1 : 0; o->acc[0] = n_cand; o->acc[1] = STATS ? 2u * n_cand - n1 + 3u * n5 : 0u; o->acc[2] = 0; o->acc[3] = 0; o->c0 = my_c0; o->n = n;
             }
             // work of the scan kernel (incl. speculation); an overflowed task is redone by the control kernel
             const bool cnt = mine && !ov;
@@ -3167,7 +3254,7 @@ __global__ __launch_bounds__(256) void k_task_bins(const HTask *tasks, const uin
                                                     uint32_t *rank, uint32_t *zero_blk)
 {
     __shared__ uint32_t hkey[BIN_LDS], hcnt[BIN_LDS];
-    if (zero_blk && blockIdx.x == 0 && threadIdx.x < 4) zero_blk[threadIdx.x] = 0;
+    if (zero_blk && blockIdx.x == 0 && threadIdx.x < 3) zero_blk[threadIdx.x == 0 ? 0u : threadIdx.x == 1 ? BSX_HCNT_TASKS : BSX_HCNT_QUEUE] = 0;   // (a counter block: bsx_kernel_args.h)
     const uint32_t n = min(*n_tasks_ptr, cap);
     for (uint32_t chunk = blockIdx.x * 1024u; chunk < n; chunk += gridDim.x * 1024u) {
         for (uint32_t i = threadIdx.x; i < BIN_LDS; i += 256) { hkey[i] = 0xffffffffu; hcnt[i] = 0; }
@@ -3248,7 +3335,7 @@ __global__ __launch_bounds__(256) void k_task_order(const HTask *tasks, const ui
 uint32_t bsx_bin_chunks(uint32_t n_bins) { return (n_bins + BIN_CHUNK - 1) / BIN_CHUNK; }
 
 // bins: [n_bins] zero on entry and on exit; bstart: [n_bins]; chunk_tot: [bsx_bin_chunks(n_bins)] (<= 1024 chunks); rank, order: [task_cap];
-// zero_blk: four words to clear (or null)
+// zero_blk: the counter block to clear for the coming pass (or null)
 void bsx_launch_task_order(const HeavyArgsRaw &R, uint32_t shift, uint32_t n_bins, uint32_t *bins, uint32_t *bstart, uint32_t *chunk_tot, uint32_t *rank, uint32_t *order,
                            uint32_t *zero_blk, hipStream_t stream, uint32_t spread, bool groups)
 {

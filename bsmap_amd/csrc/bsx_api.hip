@@ -278,7 +278,7 @@ struct bsx_batch {
     uint32_t *d_heavy_list = nullptr, *d_heavy_count = nullptr;
     // heavy pipeline pools
     uint8_t *d_hstate = nullptr, *d_hslabs = nullptr, *d_htasks = nullptr, *d_htout = nullptr;
-    uint32_t *d_hactive[2] = {nullptr, nullptr}, *d_hcnt = nullptr;  // d_hcnt: per group two ping-pong blocks {n_active, n_tasks, queue[2]}
+    uint32_t *d_hactive[2] = {nullptr, nullptr}, *d_hcnt = nullptr;  // d_hcnt: per group two ping-pong counter blocks (BSX_HCNT_*: active units, tasks, queue head)
     uint32_t hcap = 0, task_cap = 0;
     bool sig_hist = false;    // diagnostics: histogram of tasks per identical window (bsx_sig_hist_pass)
     bool same_kernel = false;    // the scan kernel is k_hscan_same (WGBS unless BSX_SAME=0, RRBS with BSX_SAME=2): read once, at creation
@@ -470,7 +470,7 @@ static int ensure_scratch(bsx_batch *b)
         HIP_TRY(hipMalloc((void **)&b->d_heavy_count, 256));
         HIP_TRY(hipHostMalloc((void **)&b->h_pinned, 1024, hipHostMallocDefault));
         HIP_TRY(hipMalloc((void **)&b->d_redo, ((size_t)b->max_units + 1) * 4));
-        HIP_TRY(hipMalloc((void **)&b->d_hcnt, BSX_MAX_GROUPS * 64));
+        HIP_TRY(hipMalloc((void **)&b->d_hcnt, (size_t)BSX_MAX_GROUPS * 2 * BSX_HCNT_BLOCK * 4));
         b->bin_shift = pl.bin_shift; b->n_bins = pl.n_bins;
         // The pools proper.  Their default sizes are for a device that holds two or three batches (31 GB each for WGBS, 74 GB for RRBS);
         // where that much is not free — more batches per device, a smaller or shared device — the pools are halved until they fit
@@ -905,10 +905,10 @@ extern "C" int bsx_batch_run_range(bsx_batch *b, uint32_t first_unit, uint32_t n
                 const bool fresh = q.passes == 0;
                 if (fresh) {
                     HIP_TRY(hipStreamWaitEvent(hw.s_ctrl, b->ev_sync, 0));
-                    HIP_TRY(hipMemsetAsync(out, 0, 16, hw.s_ctrl));
+                    HIP_TRY(hipMemsetAsync(out, 0, (size_t)BSX_HCNT_BLOCK * 4, hw.s_ctrl));
                 } else HIP_TRY(hipStreamWaitEvent(hw.s_ctrl, hw.ev_scan, 0));  // the scan of the previous pass (its first kernel also cleared `out`)
                 q.H.active_in = b->d_hactive[q.cur] + q.H.hidx_base; q.H.active_out = b->d_hactive[q.cur ^ 1] + q.H.hidx_base;
-                q.H.n_active_in_ptr = in; q.H.n_active_in = q.n0; q.H.n_active_out = out; q.H.n_tasks = out + 1; q.H.queue = out + 2;
+                q.H.n_active_in_ptr = in; q.H.n_active_in = q.n0; q.H.n_active_out = out; q.H.n_tasks = out + BSX_HCNT_TASKS; q.H.queue = out + BSX_HCNT_QUEUE;   // (apart: see BSX_HCNT_*)
                 q.H.fresh = fresh ? 1 : 0;
                 // (no more blocks than are resident at once — two per CU by their LDS —: blocks of a high-priority kernel that wait for a slot
                 //  keep the dispatcher from placing the kernels of the normal-priority stream, 300 us per pass when the grid was twice that)
@@ -958,7 +958,8 @@ extern "C" int bsx_batch_run_range(bsx_batch *b, uint32_t first_unit, uint32_t n
                     Group &q = G[g];
                     if (q.done) continue;
                     const uint32_t slot = q.polls % BSX_POLL_SLOTS;
-                    HIP_TRY(hipMemcpyAsync(b->h_pinned + 32 + 16 * g + 2 * slot, q.blk[q.cur], 8, hipMemcpyDeviceToHost, b->grp[g].s_ctrl));
+                    HIP_TRY(hipMemcpyAsync(b->h_pinned + 32 + 16 * g + 2 * slot, q.blk[q.cur], 4, hipMemcpyDeviceToHost, b->grp[g].s_ctrl));
+                    HIP_TRY(hipMemcpyAsync(b->h_pinned + 32 + 16 * g + 2 * slot + 1, q.blk[q.cur] + BSX_HCNT_TASKS, 4, hipMemcpyDeviceToHost, b->grp[g].s_ctrl));
                     HIP_TRY(hipEventRecord(b->grp[g].ev_poll[slot], b->grp[g].s_ctrl));
                     q.polls++;
                 }
@@ -974,7 +975,7 @@ extern "C" int bsx_batch_run_range(bsx_batch *b, uint32_t first_unit, uint32_t n
                 q.H.state = b->d_hstate; q.H.slabs = b->d_hslabs;
                 q.H.tasks = b->d_htasks + (size_t)toff * bsx_htask_bytes(); q.H.tout = b->d_htout + (size_t)toff * bsx_htaskout_bytes();
                 q.H.task_cap = tcap; q.H.list_base = base; q.H.hidx_base = lo;
-                q.blk[0] = b->d_hcnt + 16 * g; q.blk[1] = b->d_hcnt + 16 * g + 8;
+                q.blk[0] = b->d_hcnt + (size_t)(2 * g) * BSX_HCNT_BLOCK; q.blk[1] = b->d_hcnt + (size_t)(2 * g + 1) * BSX_HCNT_BLOCK;
                 if (!q.done) n_open++;
             }
             for (int depth = 0; depth < 2; depth++) { int rc = enqueue_chunk(); if (rc) return rc; }

@@ -48,6 +48,19 @@ struct AlignArgs {
     const uint8_t *hist_qual[2];
 };
 
+// The three counters of a control pass — active units it leaves, scan tasks it publishes, its work queue — take an atomic per visit each.  One memory word (one
+// L2 channel) serves about 88 atomics per microsecond: side by side in one cache line, as they were through round 5, the 3 x 179 K atomics of an RRBS pass were
+// 6 ms of its 6.4 (C4 spent as long in k_hctrl as in its scans).  A counter block keeps them 4 KB + 256 B apart (different channels), and k_hctrl takes queue
+// entries in chunks and hands in its active units in batches (bsx_align.hip).
+#ifndef BSX_HCNT_TASKS   /* (tools/build_variant.sh: -DBSX_HCNT_TASKS=1 -DBSX_HCNT_QUEUE=2 -DBSX_HCTRL_BATCH=0 is the round-5 arrangement) */
+#define BSX_HCNT_TASKS 1088u   /* word offset of the task counter inside a counter block */
+#define BSX_HCNT_QUEUE 2176u   /* ... of the queue head */
+#endif
+#define BSX_HCNT_BLOCK 3072u   /* words per counter block */
+#ifndef BSX_HCTRL_BATCH
+#define BSX_HCTRL_BATCH 1      /* k_hctrl: queue entries in chunks, active units handed in 32 at a time */
+#endif
+
 // heavy pipeline (see bsx_align.hip): untyped view used by the host side
 struct HeavyArgsRaw {
     uint8_t *state;            // [cap] HState

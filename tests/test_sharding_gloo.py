@@ -86,3 +86,44 @@ def test_bench_launcher_spawns_ranks_itself():
     assert len(lines) == 1
     got = json.loads(lines[0])
     assert got == {"selftest": "launch", "n_gpus": 2, "max_elapsed": 1.0, "sum": [3.0, 20.0], "rows": 2}
+
+
+def test_eight_rank_gloo_reduction(tmp_path):
+    """the stats reduction at the node's full width (8 ranks, gloo): every rank's row arrives, the maximum time and the counter sums are exact, and the
+    shards partition the batch — what bench.py --gpus 8 does over RCCL, without a device"""
+    import json
+    script = tmp_path / "worker8.py"
+    script.write_text(textwrap.dedent("""
+        import os, sys, json
+        sys.path.insert(0, {root!r})
+        import torch.distributed as dist
+        from bsmap_amd import sharding
+        dist.init_process_group("gloo")
+        rank, world = dist.get_rank(), dist.get_world_size()
+        lo, hi = sharding.shard_range(1000003, rank, world)
+        mx, tot, table = sharding.gather_stats(0.125 * (rank + 1), [hi - lo, lo, 1, rank], dist)
+        if rank == 0:
+            print("RESULT " + json.dumps(dict(max=mx, tot=[float(x) for x in tot], rows=int(table.shape[0]), times=[float(x) for x in table[:, 0]])))
+        dist.barrier()
+        dist.destroy_process_group()
+    """).format(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                          "--master-port", "29541", str(script)], capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    got = json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT ")][0][7:])
+    ranges = [sharding.shard_range(1000003, r, 8) for r in range(8)]
+    assert got["rows"] == 8 and got["max"] == 1.0 and got["times"] == [0.125 * (r + 1) for r in range(8)]
+    assert got["tot"] == [1000003.0, float(sum(lo for lo, _ in ranges)), 8.0, 28.0]
+
+
+def test_rank_cpu_shares_are_disjoint_and_on_the_node():
+    """bench.py pins each rank to its share of the quota on its GPU's NUMA node: ranks that share a node get consecutive, disjoint CPU ranges; a node with too
+    few CPUs pins nothing"""
+    sys.path.insert(0, ROOT)
+    import bench
+    node = set(range(64, 128))
+    shares = [bench.rank_cpu_share(node, 4, k, 8) for k in range(4)]
+    assert all(len(s) == 8 and s <= node for s in shares)
+    assert len(set().union(*shares)) == 32 and min(shares[0]) == 64 and min(shares[3]) == 88
+    assert bench.rank_cpu_share(set(range(6)), 4, 0, 2) is None and bench.rank_cpu_share(node, 4, 1, 0) is None

@@ -1,0 +1,6 @@
+# round 6, call 4: counter lines apart + chunked queue + batched active list: parity, category clocks without the work counters, per-pass tables, A/B against the round-5 arrangement
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r06d; mkdir -p $O; cd $R
+timeout 1500 python3 -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "without_work_counters or heavy or context" > $O/parity.txt 2>&1; tail -n 3 $O/parity.txt
+for m in trim rrbs pe; do timeout 600 python3 tools/ctrl_clocks.py --mode $m > $O/ctrl_clocks_${m}.json 2> $O/ctrl_clocks_${m}.err; cut -c1-1200 $O/ctrl_clocks_${m}.json; echo; done
+for m in trim rrbs; do bash tools/pass_profile.sh r06d_new $m --cpu-seconds 0 --e2e-pairs 0 --transfer-steps 0 --sensitivity 0 --other-configs 0; done
+bash tools/ab_libs.sh r06d_ab r05 "trim rrbs pe se" 1
