@@ -66,7 +66,7 @@ EXPORTS = [
     "bsx_batch_create", "bsx_batch_destroy", "bsx_batch_upload_se", "bsx_batch_upload_pe", "bsx_batch_synth_reads", "bsx_batch_synth_reads_kind", "bsx_batch_download_quals",
     "bsx_batch_run", "bsx_batch_run_range", "bsx_batch_sync", "bsx_batch_set_work_counters", "bsx_batch_set_leak_exact", "bsx_batch_set_history", "bsx_batch_set_leak_state", "bsx_batch_get_leak_state", "bsx_batch_kernel_ms", "bsx_batch_scan_ms", "bsx_batch_results_se", "bsx_batch_results_pe",
     "bsx_batch_counters", "bsx_batch_reset_counters", "bsx_batch_download_reads", "bsx_batch_set_debug", "bsx_batch_unit_cycles", "bsx_batch_ctrl_clocks",
-    "bsx_batch_debug_hits", "bsx_batch_debug_pairs", "bsx_batch_debug_plan", "bsx_set_waves_per_cu", "bsx_set_heavy_threshold", "bsx_set_heavy_limits", "bsx_set_pool_reserve", "bsx_default_heavy_limits", "bsx_batch_pool_sizes", "bsx_batch_plan_bytes", "bsx_batch_last_heavy_units", "bsx_batch_last_redo_units", "bsx_pinned_alloc", "bsx_pinned_free", "bsx_probe_memory", "bsx_thread_device",
+    "bsx_batch_debug_hits", "bsx_batch_debug_pairs", "bsx_batch_debug_plan", "bsx_set_waves_per_cu", "bsx_set_heavy_threshold", "bsx_set_heavy_limits", "bsx_set_pool_reserve", "bsx_default_heavy_limits", "bsx_batch_pool_sizes", "bsx_batch_plan_bytes", "bsx_batch_last_heavy_units", "bsx_batch_last_heavy_list", "bsx_batch_last_redo_units", "bsx_pinned_alloc", "bsx_pinned_free", "bsx_probe_memory", "bsx_thread_device",
     "bsx_meth_create", "bsx_meth_destroy", "bsx_meth_set_reference", "bsx_meth_add", "bsx_meth_combine_cpg", "bsx_meth_valid_mappings",
     "bsx_meth_report_chr", "bsx_meth_fetch_rows", "bsx_meth_add_file", "bsx_meth_write_table", "bsx_meth_create_from_fasta", "bsx_meth_n_chr", "bsx_meth_chr_name",
 ]
@@ -149,6 +149,7 @@ def lib():
         L.bsx_batch_plan_bytes.argtypes = [C.POINTER(Params), u32, i32, u64, u32, u32, vp]
         L.bsx_batch_last_heavy_units.argtypes = [vp]
         L.bsx_batch_last_redo_units.argtypes = [vp]
+        L.bsx_batch_last_heavy_list.argtypes = [vp, vp, u32]
         L.bsx_probe_memory.argtypes = [i32, u64, u64, vp, vp, vp, vp]
         _lib = L
     return _lib
@@ -388,6 +389,13 @@ class _Batch:
     def reset_counters(self): _check(lib().bsx_batch_reset_counters(self.h))
 
     def heavy_units(self): return _check(lib().bsx_batch_last_heavy_units(self.h))
+
+    def heavy_list(self):
+        """unit numbers (inside the batch) of the units the last run handed to the heavy pipeline"""
+        n = self.heavy_units()
+        out = np.zeros(max(n, 1), np.uint32)
+        got = _check(lib().bsx_batch_last_heavy_list(self.h, out.ctypes.data, n))
+        return out[:got]
 
     def pool_sizes(self):
         """(deferred units per round, scan tasks) of the heavy pipeline's pools as allocated (starting sizes halved until they fit)"""

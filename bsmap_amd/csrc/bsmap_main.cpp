@@ -498,10 +498,18 @@ void apply_trim(Rd &r, const bsx_hit &h, const Opts &o)
 // CPU time of the calling thread (what a stage really costs under a CPU quota, beside its wall time)
 inline double thread_cpu_s() { struct timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 
+// A fatal error after the GPU runtime has been touched leaves through _exit: exit() would run the runtime's own exit handlers while helper threads (buffer
+// touch, replica loaders, device batches) may still be inside it — without a device that ended in a segmentation fault inside libamdhip64's finalizer instead
+// of exit status 1 (found by the sanitizer build, tests/test_cli_asan_cpu.py).  Everything worth keeping is flushed first.
+[[noreturn]] void fatal_exit()
+{
+    cout.flush(); cerr.flush(); fflush(nullptr);
+    _exit(1);
+}
 void die(int rc, const char *what)
 {
     cerr << "bsx: " << what << ": " << bsx_strerror(rc) << " (" << bsx_last_error_detail() << ")\n";
-    exit(1);
+    fatal_exit();
 }
 
 // ---- the mapping pipeline ---------------------------------------------------------------------------------------------
@@ -884,7 +892,7 @@ int main(int argc, char **argv)
     auto write_all = [](int fd, const char *p_, size_t n_, off_t at) {
         while (n_) {
             const ssize_t w = pwrite(fd, p_, n_, at);
-            if (w <= 0) { cerr << "write error on the output file\n"; exit(1); }
+            if (w <= 0) { cerr << "write error on the output file\n"; fatal_exit(); }
             p_ += w; n_ -= (size_t)w; at += w;
         }
     };

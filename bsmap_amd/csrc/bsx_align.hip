@@ -2163,7 +2163,10 @@ __global__ __launch_bounds__(256, PE ? BSX_HCTRL_WAVES : BSX_HCTRL_WAVES_SE) voi
     const uint32_t n_active_in = H.fresh ? H.n_active_in : rfl(*H.n_active_in_ptr);  // later passes: count left by the previous pass
     // One word takes ~88 atomics per microsecond and an RRBS pass visits 10^5 units: a wave takes queue entries in chunks (one while units are few: the pass
     // then ends with its longest visit, not with a wave's leftover chunk) and hands in the units it leaves active 32 at a time (PEND).
-    const uint32_t q_chunk = BSX_HCTRL_BATCH ? max(1u, min(16u, n_active_in / (gridDim.x * 128u))) : 1u;   // (RRBS: 175 short visits per wave and pass, chunks of 5; C5: 25 long ones, one at a time)
+#ifndef BSX_QCHUNK_DIV
+#define BSX_QCHUNK_DIV 128u
+#endif
+    const uint32_t q_chunk = BSX_HCTRL_BATCH ? max(1u, min(16u, n_active_in / (gridDim.x * BSX_QCHUNK_DIV))) : 1u;   // (RRBS: 175 short visits per wave and pass, chunks of 5; C5: 25 long ones, one at a time)
     uint32_t q_next = 0, q_end = 0, n_pend = 0;
     uint32_t *const pend = PEND[wv];
 #define HCTRL_PEND_FLUSH() do { if (n_pend) { uint32_t b_ = 0; if (lane == 0) b_ = atomicAdd(H.n_active_out, n_pend); b_ = rfl(b_); if ((uint32_t)lane < n_pend) H.active_out[b_ + (uint32_t)lane] = pend[lane]; n_pend = 0; wave_fence(); } } while (0)

@@ -1160,6 +1160,17 @@ extern "C" int bsx_batch_last_heavy_units(bsx_batch *b)
     return (int)b->last_heavy;
 }
 
+extern "C" int bsx_batch_last_heavy_list(bsx_batch *b, uint32_t *units, uint32_t cap)
+{
+    if (!b || (!units && cap)) return BSX_ERR_ARG;
+    if (!b->ran) return BSX_ERR_STATE;
+    HIP_TRY(hipSetDevice(b->ref->device));
+    HIP_TRY(stream_wait(b));
+    const uint32_t n = std::min<uint32_t>(cap, (uint32_t)b->last_heavy);
+    if (n) HIP_TRY(hipMemcpy(units, b->d_heavy_list, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return (int)n;
+}
+
 extern "C" int bsx_batch_last_redo_units(bsx_batch *b)
 {
     if (!b || !b->ran) return BSX_ERR_STATE;

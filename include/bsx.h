@@ -264,6 +264,7 @@ int bsx_batch_pool_sizes(const bsx_batch *b, uint32_t *units_per_round, uint32_t
  * bench.py checks its whole plan against the device's memory with it before it allocates anything. */
 int bsx_batch_plan_bytes(const bsx_params *p, uint32_t max_units, int paired, uint64_t n_entries, uint32_t n_cu, uint32_t blocks_per_cu, uint64_t *out3);
 int bsx_batch_last_heavy_units(bsx_batch *b);   /* units the last run handed to the heavy pipeline */
+int bsx_batch_last_heavy_list(bsx_batch *b, uint32_t *units, uint32_t cap);   /* their unit numbers inside the batch, in the order the main kernel deferred them (at most cap; returns how many): the tests use it to aim the oracle at them */
 int bsx_batch_last_redo_units(bsx_batch *b);    /* of those, units the main kernel had to redo (their duplicate set outgrew the heavy slab; single-end RRBS) */
 
 /* ---- measurement aid ("report both peak and a measured ceiling") -----------------------------------

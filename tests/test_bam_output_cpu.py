@@ -10,6 +10,8 @@ import subprocess
 
 import pytest
 
+from conftest import HOST_SAN_FLAGS
+
 import bam_util
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -20,7 +22,7 @@ CLI = json.load(gzip.open(os.path.join(ROOT, "tests", "golden", "cli_outputs.jso
 @pytest.fixture(scope="module")
 def harness(tmp_path_factory):
     exe = str(tmp_path_factory.mktemp("bo") / "bamout_check")
-    subprocess.run(["g++", "-O1", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "harness", "bamout_check.cpp"), "-lz"], check=True)
+    subprocess.run(["g++"] + HOST_SAN_FLAGS + ["-o", exe, os.path.join(ROOT, "tests", "harness", "bamout_check.cpp"), "-lz"], check=True)   # (ASan + UBSan: conftest.py)
     return exe
 
 

@@ -205,14 +205,19 @@ def test_blocks_of_a_bench_sized_batch_equal_the_oracle(big, oracle, oracle_wgbs
         t_gpu = time.time() - t0
         out, ca, cb, npairs = pa.results()
         heavy = int(pa.heavy_units())
+        hlist = np.sort(pa.heavy_list().astype(np.int64))
         b1, o1 = pa.download_reads(0)
         b2, o2 = pa.download_reads(1)
     finally:
         pa.close()
     bad_all, t_cpu, placed = {}, 0.0, 0
-    for k in range(NBLK):
-        lo = k * (NB // NBLK) + 17 * k   # (not on any power-of-two grid)
-        hi = lo + BLK
+    # the deferred units carry 97 % of the step's candidates: the comparison has to hold a good number of them — those that fall into the blocks, and 256 more
+    # taken evenly from the deferred list, each re-aligned alone (the pick RNG is a function of the unit's own index)
+    spans = [(k * (NB // NBLK) + 17 * k, k * (NB // NBLK) + 17 * k + BLK) for k in range(NBLK)]   # (not on any power-of-two grid)
+    in_blocks = int(sum(np.searchsorted(hlist, hi) - np.searchsorted(hlist, lo) for lo, hi in spans))
+    extra = [int(u) for u in hlist[:: max(1, len(hlist) // 256)][:256] if not any(lo <= u < hi for lo, hi in spans)]
+    assert len(hlist) == heavy and in_blocks >= 1000 and len(extra) >= 200, (len(hlist), heavy, in_blocks, len(extra))
+    for lo, hi in spans + [(u, u + 1) for u in extra]:
         t0 = time.time()
         ores, _ = oracle.pe_batch(oref, b1[int(o1[lo]):int(o1[hi])], (o1[lo:hi + 1] - o1[lo]).copy(), b2[int(o2[lo]):int(o2[hi])], (o2[lo:hi + 1] - o2[lo]).copy(),
                                   first_index=lo, threads=W.usable_cpus())
@@ -221,7 +226,7 @@ def test_blocks_of_a_bench_sized_batch_equal_the_oracle(big, oracle, oracle_wgbs
         placed += info["paired_out"]
         for f, n in bad.items():
             bad_all[f] = bad_all.get(f, 0) + n
-    W.record("bench_step_c3", dict(units_in_batch=NB, units_compared=BLK * NBLK, blocks=NBLK, heavy_units=heavy, paired_out=placed, oracle_s=round(t_cpu, 1), do_batch_s=round(t_gpu, 3),
+    W.record("bench_step_c3", dict(units_in_batch=NB, units_compared=BLK * NBLK + len(extra), blocks=NBLK, heavy_units=heavy, deferred_units_compared=in_blocks + len(extra), paired_out=placed, oracle_s=round(t_cpu, 1), do_batch_s=round(t_gpu, 3),
                                    mismatching_fields=bad_all, options=KW, work_counters=False, reference="oracle-built from the genome text"))
     assert heavy > NB // 200 and placed > 0.95 * BLK * NBLK
     assert not bad_all, bad_all

@@ -8,13 +8,15 @@ import subprocess
 
 import pytest
 
+from conftest import HOST_SAN_FLAGS
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
 def harness(tmp_path_factory):
     exe = str(tmp_path_factory.mktemp("lh") / "lanes_check")
-    subprocess.run(["g++", "-O1", "-std=c++17", "-pthread", "-o", exe, os.path.join(ROOT, "tests", "harness", "lanes_check.cpp")], check=True)
+    subprocess.run(["g++"] + HOST_SAN_FLAGS + ["-o", exe, os.path.join(ROOT, "tests", "harness", "lanes_check.cpp")], check=True)   # (ASan + UBSan: conftest.py)
     return exe
 
 

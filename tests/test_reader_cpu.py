@@ -6,13 +6,15 @@ import subprocess
 
 import pytest
 
+from conftest import HOST_SAN_FLAGS
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
 def harness(tmp_path_factory):
     exe = str(tmp_path_factory.mktemp("rh") / "reader_check")
-    subprocess.run(["g++", "-O1", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "harness", "reader_check.cpp"), "-lz"], check=True)
+    subprocess.run(["g++"] + HOST_SAN_FLAGS + ["-o", exe, os.path.join(ROOT, "tests", "harness", "reader_check.cpp"), "-lz"], check=True)   # (ASan + UBSan: conftest.py)
     return exe
 
 
