@@ -64,7 +64,7 @@ EXPORTS = [
     "bsx_ref_n_chr", "bsx_ref_n_words", "bsx_ref_n_blocks", "bsx_ref_info", "bsx_ref_chr_name", "bsx_ref_blocks",
     "bsx_ref_download_words", "bsx_ref_set_context", "bsx_ref_context_bytes", "bsx_ref_drop_context", "bsx_index_build", "bsx_index_n_entries", "bsx_index_download", "bsx_ref_n_sites", "bsx_ref_sites",
     "bsx_batch_create", "bsx_batch_destroy", "bsx_batch_upload_se", "bsx_batch_upload_pe", "bsx_batch_synth_reads", "bsx_batch_synth_reads_kind", "bsx_batch_download_quals",
-    "bsx_batch_run", "bsx_batch_run_range", "bsx_batch_sync", "bsx_batch_set_work_counters", "bsx_batch_set_leak_exact", "bsx_batch_set_history", "bsx_batch_set_leak_state", "bsx_batch_get_leak_state", "bsx_batch_kernel_ms", "bsx_batch_scan_ms", "bsx_batch_results_se", "bsx_batch_results_pe",
+    "bsx_batch_run", "bsx_batch_run_range", "bsx_batch_sync", "bsx_batch_set_work_counters", "bsx_batch_set_leak_exact", "bsx_batch_set_history", "bsx_batch_set_leak_state", "bsx_batch_get_leak_state", "bsx_batch_kernel_ms", "bsx_batch_scan_ms", "bsx_batch_set_stage_timing", "bsx_batch_stage_ms", "bsx_batch_results_se", "bsx_batch_results_pe",
     "bsx_batch_counters", "bsx_batch_reset_counters", "bsx_batch_download_reads", "bsx_batch_set_debug", "bsx_batch_unit_cycles", "bsx_batch_ctrl_clocks",
     "bsx_batch_debug_hits", "bsx_batch_debug_pairs", "bsx_batch_debug_plan", "bsx_set_waves_per_cu", "bsx_set_heavy_threshold", "bsx_set_heavy_limits", "bsx_set_pool_reserve", "bsx_default_heavy_limits", "bsx_batch_pool_sizes", "bsx_batch_plan_bytes", "bsx_batch_last_heavy_units", "bsx_batch_last_heavy_list", "bsx_batch_last_redo_units", "bsx_pinned_alloc", "bsx_pinned_free", "bsx_probe_memory", "bsx_thread_device",
     "bsx_meth_create", "bsx_meth_destroy", "bsx_meth_set_reference", "bsx_meth_add", "bsx_meth_combine_cpg", "bsx_meth_valid_mappings",
@@ -149,6 +149,8 @@ def lib():
         L.bsx_batch_plan_bytes.argtypes = [C.POINTER(Params), u32, i32, u64, u32, u32, vp]
         L.bsx_batch_last_heavy_units.argtypes = [vp]
         L.bsx_batch_last_redo_units.argtypes = [vp]
+        L.bsx_batch_stage_ms.argtypes = [vp, vp, vp]
+        L.bsx_batch_set_stage_timing.argtypes = [vp, i32]
         L.bsx_batch_last_heavy_list.argtypes = [vp, vp, u32]
         L.bsx_probe_memory.argtypes = [i32, u64, u64, vp, vp, vp, vp]
         _lib = L
@@ -389,6 +391,16 @@ class _Batch:
     def reset_counters(self): _check(lib().bsx_batch_reset_counters(self.h))
 
     def heavy_units(self): return _check(lib().bsx_batch_last_heavy_units(self.h))
+
+    def set_stage_timing(self, on=True):
+        _check(lib().bsx_batch_set_stage_timing(self.h, 1 if on else 0))
+        return self
+
+    def stage_ms(self):
+        """HIP-event times of the last run by stage (bsx.h: bsx_batch_stage_ms): {'k_align', 'k_hctrl', 'order', 'scan', 'control_passes'}"""
+        t = (C.c_float * 4)(); n = C.c_uint32(0)
+        _check(lib().bsx_batch_stage_ms(self.h, C.cast(t, C.c_void_p), C.cast(C.byref(n), C.c_void_p)))
+        return {"k_align": float(t[0]), "k_hctrl": float(t[1]), "order": float(t[2]), "scan": float(t[3]), "control_passes": int(n.value)}
 
     def heavy_list(self):
         """unit numbers (inside the batch) of the units the last run handed to the heavy pipeline"""

@@ -294,6 +294,10 @@ struct bsx_batch {
     uint32_t *d_redo = nullptr;  // [max_units + 1]: count, then unit ids
     uint32_t rowcap = 0, hkcap = 0;  // hkcap: key capacity of a deferred unit's duplicate set (BSX_HEAVY_KCAP test hook, read at creation)
     int grid_blocks = 0;
+    std::vector<hipEvent_t> ctrl_ev;   // per control pass: before k_hctrl, behind it, behind the order kernels (bsx_batch_stage_ms)
+    size_t ctrl_ev_used = 0;
+    hipEvent_t ev_align = nullptr;     // behind the main kernel (and the exact mode's pre-pass)
+    bool stage_timing = false;         // bsx_batch_set_stage_timing: the events above are only recorded on request (three more per control pass on its stream)
     bool ran = false;
     bool counted = false;        // the batch is in its reference's n_batches
 };
@@ -646,6 +650,8 @@ extern "C" void bsx_batch_destroy(bsx_batch *b)
     if (b->ev_sync) (void)hipEventDestroy(b->ev_sync);
     if (b->ev_wait) (void)hipEventDestroy(b->ev_wait);
     for (hipEvent_t e : b->scan_ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : b->ctrl_ev) (void)hipEventDestroy(e);
+    if (b->ev_align) (void)hipEventDestroy(b->ev_align);
     if (b->stream) (void)hipStreamDestroy(b->stream);
     if (b->counted && b->ref->n_batches > 0) b->ref->n_batches--;
     delete b;
@@ -865,7 +871,11 @@ extern "C" int bsx_batch_run_range(bsx_batch *b, uint32_t first_unit, uint32_t n
     }
     bsx_launch_align(A, b->paired, b->grid_blocks, b->stream);
     HIP_TRY(hipGetLastError());
-    b->last_heavy = 0; b->last_heavy_iters = 0; b->last_redo = 0; b->scan_ev_used = 0;
+    if (b->stage_timing) {
+        if (!b->ev_align) HIP_TRY(hipEventCreate(&b->ev_align));
+        HIP_TRY(hipEventRecord(b->ev_align, b->stream));
+    }
+    b->last_heavy = 0; b->last_heavy_iters = 0; b->last_redo = 0; b->scan_ev_used = 0; b->ctrl_ev_used = 0;
     if (A.heavy_threshold) {
         // heavy pipeline: passes of k_hctrl / k_hscan until every deferred unit is finished (this call returns once the last pass
         // is queued and known to be the last; units that were not deferred are already complete)
@@ -910,10 +920,13 @@ extern "C" int bsx_batch_run_range(bsx_batch *b, uint32_t first_unit, uint32_t n
                 q.H.active_in = b->d_hactive[q.cur] + q.H.hidx_base; q.H.active_out = b->d_hactive[q.cur ^ 1] + q.H.hidx_base;
                 q.H.n_active_in_ptr = in; q.H.n_active_in = q.n0; q.H.n_active_out = out; q.H.n_tasks = out + BSX_HCNT_TASKS; q.H.queue = out + BSX_HCNT_QUEUE;   // (apart: see BSX_HCNT_*)
                 q.H.fresh = fresh ? 1 : 0;
+                while (b->stage_timing && b->ctrl_ev_used + 3 > b->ctrl_ev.size()) { hipEvent_t ev_new = nullptr; HIP_TRY(hipEventCreate(&ev_new)); b->ctrl_ev.push_back(ev_new); }
+                if (b->stage_timing) HIP_TRY(hipEventRecord(b->ctrl_ev[b->ctrl_ev_used], hw.s_ctrl));
                 // (no more blocks than are resident at once — two per CU by their LDS —: blocks of a high-priority kernel that wait for a slot
                 //  keep the dispatcher from placing the kernels of the normal-priority stream, 300 us per pass when the grid was twice that)
                 bsx_launch_hctrl(A, q.H, b->paired, (int)std::min<uint32_t>((q.n0 + 3) / 4, (uint32_t)b->n_cu * b->hctrl_blocks_per_cu), hw.s_ctrl);
                 HIP_TRY(hipGetLastError());
+                if (b->stage_timing) HIP_TRY(hipEventRecord(b->ctrl_ev[b->ctrl_ev_used + 1], hw.s_ctrl));
                 // scan order of the tasks this pass published, still on the group's stream: done by the time the main stream gets to the scan
                 q.H.order = hw.d_order; q.H.xcd_map = b->xcd_map; q.H.ghead = hw.d_rank; q.H.glist = hw.d_glist;
                 bsx_launch_task_order(q.H, b->bin_shift, b->n_bins, hw.d_bins, hw.d_bstart, hw.d_chunk_tot, hw.d_rank, hw.d_order, in, hw.s_ctrl, spread, same_scan);
@@ -922,6 +935,7 @@ extern "C" int bsx_batch_run_range(bsx_batch *b, uint32_t first_unit, uint32_t n
                 // blocks sweep: beside ANOTHER batch's bulk scans a pool-sized grid of mostly empty blocks only trickles through the
                 // dispatcher, which stretched the tail of the older batch until the younger one's bulk was done — two batches in flight
                 // always finished together, and their transfers never overlapped the other's kernels.
+                if (b->stage_timing) { HIP_TRY(hipEventRecord(b->ctrl_ev[b->ctrl_ev_used + 2], hw.s_ctrl)); b->ctrl_ev_used += 3; }
                 if (b->sig_hist) bsx_sig_hist_pass(q.H, hw.s_ctrl);
                 hipStream_t s_scan = b->stream;
                 if (q.tail) s_scan = hw.s_ctrl;
@@ -1049,6 +1063,31 @@ extern "C" int bsx_batch_scan_ms(bsx_batch *b, float *total_ms, uint32_t *launch
     float sum = 0.f;
     for (size_t i = 0; i + 1 < b->scan_ev_used; i += 2) { float ms = 0.f; HIP_TRY(hipEventElapsedTime(&ms, b->scan_ev[i], b->scan_ev[i + 1])); sum += ms; }
     *total_ms = sum; *launches = (uint32_t)(b->scan_ev_used / 2);
+    return BSX_OK;
+}
+
+extern "C" int bsx_batch_set_stage_timing(bsx_batch *b, int on)
+{
+    if (!b) return BSX_ERR_ARG;
+    b->stage_timing = on != 0;
+    return BSX_OK;
+}
+extern "C" int bsx_batch_stage_ms(bsx_batch *b, float out4[4], uint32_t *control_passes)
+{
+    if (!b || !out4) return BSX_ERR_ARG;
+    if (!b->ran || !b->stage_timing || !b->ev_align) return BSX_ERR_STATE;
+    HIP_TRY(hipSetDevice(b->ref->device));
+    HIP_TRY(stream_wait(b));
+    out4[0] = out4[1] = out4[2] = out4[3] = 0.f;
+    if (b->ev_align) HIP_TRY(hipEventElapsedTime(&out4[0], b->ev0, b->ev_align));
+    for (size_t i = 0; i + 2 < b->ctrl_ev_used; i += 3) {   // (the batch's stream waits for every group's last control pass before ev1: all recorded)
+        float a = 0.f, o = 0.f;
+        HIP_TRY(hipEventElapsedTime(&a, b->ctrl_ev[i], b->ctrl_ev[i + 1]));
+        HIP_TRY(hipEventElapsedTime(&o, b->ctrl_ev[i + 1], b->ctrl_ev[i + 2]));
+        out4[1] += a; out4[2] += o;
+    }
+    for (size_t i = 0; i + 1 < b->scan_ev_used; i += 2) { float ms = 0.f; HIP_TRY(hipEventElapsedTime(&ms, b->scan_ev[i], b->scan_ev[i + 1])); out4[3] += ms; }
+    if (control_passes) *control_passes = (uint32_t)(b->ctrl_ev_used / 3);
     return BSX_OK;
 }
 

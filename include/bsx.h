@@ -218,6 +218,12 @@ float bsx_batch_kernel_ms(bsx_batch *b);          /* HIP-event time of the last 
  * chunks ahead of what the host knows (bsx_batch_run), so the count includes the launches queued behind a group's last pass:
  * they find no task, their grids exit at once (tens of microseconds each) and they are part of the sum. */
 int bsx_batch_scan_ms(bsx_batch *b, float *total_ms, uint32_t *launches);
+/* HIP-event times of the last run by stage, in ms (after sync): out4 = {main kernel k_align (with the exact mode's pre-pass), control kernel k_hctrl summed over
+ * its passes, the order kernels between a control pass and its scan, the scan kernel summed over its launches}; each on the stream the kernel is launched on.
+ * With ONE batch in flight and one unit group (bench.py's serial replay) no two of them overlap and they add up to the run; with several batches in flight the
+ * durations include what ran beside them. */
+int bsx_batch_set_stage_timing(bsx_batch *b, int on);   /* off by default: the per-pass events are only recorded for runs queued while it is on */
+int bsx_batch_stage_ms(bsx_batch *b, float out4[4], uint32_t *control_passes /* may be NULL */);
 int bsx_batch_results_se(bsx_batch *b, bsx_hit *out, bsx_class_counts *counts /* may be NULL */);
 int bsx_batch_results_pe(bsx_batch *b, bsx_pair *out, bsx_class_counts *counts_a, bsx_class_counts *counts_b, uint16_t *n_pairs31);
 int bsx_batch_counters(bsx_batch *b, uint64_t c[BSX_N_COUNTERS]);   /* accumulated since creation / last reset */

@@ -98,8 +98,10 @@ def _run_cli(a, fq, fa, lens, n, t_fa, t_fq, extra):
         cmd += ["-p", str(a.threads)]
     if os.environ.get("BSX_TASKSET"):   # experiment: pin the whole command line to a CPU list (one NUMA node)
         cmd = ["taskset", "-c", os.environ["BSX_TASKSET"]] + cmd
+    envx = {t.split("=", 1)[0]: t.split("=", 1)[1] for t in extra if t.startswith("BSX_") and "=" in t}   # (tokens BSX_X=v of a variant are environment settings, not arguments)
+    cmd = [t for t in cmd if not (t.startswith("BSX_") and "=" in t)]
     t0 = time.time()
-    res = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, BSX_TIMING=os.environ.get("BSX_TIMING", "1")))
+    res = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, BSX_TIMING=os.environ.get("BSX_TIMING", "1"), **envx))
     wall = time.time() - t0
     if res.returncode != 0:
         raise RuntimeError("bsmap failed: " + res.stdout[-2000:] + res.stderr[-2000:])
