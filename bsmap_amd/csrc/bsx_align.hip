@@ -1871,6 +1871,10 @@ __device__ __forceinline__ bool publish_window(const DevParams &P, const HeavyAr
 
 // resumable SnpAlign for a deferred unit: 0 = call complete, 1 = the reference's SnpAlign returned early, 2 = a window
 // of the current list was published and the unit must wait for k_hscan
+// SPEC: the instantiation carries the publish-ahead code (paired batches only: in the single-end control kernel the extra code lifted the register count from 224
+// to 256 — a control wave then leaves room for two scan waves beside it on its SIMD instead of three, and C4 with three batches in flight went from 415 to
+// 464 ms per step although the code never ran there, gpurun_out/r06f, r06h)
+template <bool SPEC>
 __device__ __forceinline__ int snp_align_heavy(const AlignArgs &A, const HeavyArgs &H, HState *S, uint32_t hidx, const BlockLds &BL, const MateLds &L, Mate &M,
                                const Slab &SL, int mode, HCursor &K, int ms, int lane, Counters &C)
 {
@@ -2069,7 +2073,7 @@ __device__ __forceinline__ int snp_align_heavy(const AlignArgs &A, const HeavyAr
                     // less than half full: a refused request of ANOTHER unit costs that unit a pass.
                     // Not for RRBS: its rounds fill the task pool (1.26 M tasks per 125 K units against 1.4 M), and lists published ahead push other units'
                     // requests out of the pass — C4 464 against 415 ms per step with three batches in flight (gpurun_out/r06f).
-                    if (BSX_SPECULATE && !A.work_counters && !P.rrbs && orient == 0 && K.c[ms] + wn == cl.total && ((M.u->flags >> 1) & 1)) {
+                    if (BSX_SPECULATE && SPEC && !A.work_counters && !P.rrbs && orient == 0 && K.c[ms] + wn == cl.total && ((M.u->flags >> 1) & 1)) {
                         const int seg1 = L.order[1][mode];
                         const CandList cl1 = make_list<true>(P, BL, L, M, 1, seg1, lane);
                         const uint32_t w1 = min(K.n_active < 256u ? (uint32_t)HS_WINTAIL : K.n_active < 2048u ? (uint32_t)HS_WINTAIL2K : (uint32_t)HS_WIN0, min(wpool, cl1.total));
@@ -2106,7 +2110,7 @@ __device__ __forceinline__ bool heavy_advance(const AlignArgs &A, const HeavyArg
             for (int m = 0; m < 2; m++) {
                 if ((K.sub >> m) & 1) continue;
                 Mate &M = m ? MB : MA;
-                if (K.level < M.u->seedseg && snp_align_heavy(A, H, S, hidx, BL, m ? LB : LA, M, m ? U.SB : U.SA, K.level, K, m, lane, C) == 2) { waiting = true; continue; }
+                if (K.level < M.u->seedseg && snp_align_heavy<PE>(A, H, S, hidx, BL, m ? LB : LA, M, m ? U.SB : U.SA, K.level, K, m, lane, C) == 2) { waiting = true; continue; }
                 K.sub |= 1 << m; K.have[2 * m] = 0; K.have[2 * m + 1] = 0;
             }
             if (waiting) {
@@ -2128,7 +2132,7 @@ __device__ __forceinline__ bool heavy_advance(const AlignArgs &A, const HeavyArg
         const int ms = second ? 1 : 0;
         Mate &M = second ? MB : MA;
         if (M.u->filtered || K.level >= M.u->seedseg) { K.sub++; K.level = 0; continue; }
-        if (snp_align_heavy(A, H, S, hidx, BL, second ? LB : LA, M, second ? U.SB : U.SA, K.level, K, ms, lane, C) == 2) return false;
+        if (snp_align_heavy<PE>(A, H, S, hidx, BL, second ? LB : LA, M, second ? U.SB : U.SA, K.level, K, ms, lane, C) == 2) return false;
         const u64 nz = P.rrbs ? 0ull : bsx_ballot(M.cnt_reg != 0 && (lane & 15) <= K.level && lane < 32);  // RRBS runs all rounds (align.cpp:448)
         if (nz) { K.sub++; K.level = 0; }
         else K.level++;

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <memory>
 #include <sstream>
 #include <thread>
 
@@ -148,41 +149,113 @@ struct Packed {
     std::vector<std::vector<uint32_t>> ccgg_f, ccgg_r;  // [segment]
 };
 
+// chunk sizes of the parallel packer (tests/harness/pack_check.cpp builds with tiny ones so that a 100 kb FASTA crosses hundreds of chunk borders)
+#ifndef BSX_PACK_CHUNK
+#define BSX_PACK_CHUNK (4u << 20)       /* text bytes per task of the count / copy phases */
+#define BSX_PACK_WORDS (1u << 18)       /* packed words per task */
+#define BSX_PACK_NXCHUNK (8u << 20)     /* characters per task of the N/X run listing */
+#define BSX_PACK_BIG (32u << 20)        /* records from this size on are packed chunk-parallel, one after another */
+#define BSX_PACK_MINTEXT (8u << 20)     /* texts below this: one thread */
+#endif
+// run fn(k) for k in [0, n) on up to nt threads (the calling thread included); n small: chunks of a record
+template <class F> void pfor(size_t n, unsigned nt, F fn)
+{
+    if (nt <= 1 || n <= 1) { for (size_t k = 0; k < n; k++) fn(k); return; }
+    std::atomic<size_t> next(0);
+    auto work = [&] { for (size_t k; (k = next.fetch_add(1)) < n;) fn(k); };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < std::min<size_t>(nt, n); t++) th.emplace_back(work);
+    work();
+    for (std::thread &t : th) t.join();
+}
+
+// One record -> packed words of both strand copies, unmasked blocks, RRBS site tables.  nt threads work on CHUNKS of the record (round 6): a human chromosome is
+// 250 MB of text and one thread per record left the whole load waiting for chromosome 1 (2.25 s of a 6.9 s run at hg38 size; 24 records on 16 CPUs).  Every
+// phase streams the record once: count the non-blank characters per chunk, copy them to their place, pack word ranges, list the N/X runs per chunk.
 void pack_record(const bsx_params &P, const char *text, const Rec &R, uint32_t chr, const uint8_t *code_f, const uint8_t *code_r,
-                 const uint8_t *cls, Packed &o)
+                 const uint8_t *cls, Packed &o, unsigned nt = 1)
 {
     // concatenate the whitespace-separated tokens (dbseq.cpp:40-50)
-    std::vector<char> buf((size_t)(R.se - R.sb) + 4 * BSX_SEGLEN + 8);
-    uint64_t len = 0;
-    for (uint64_t i = R.sb; i < R.se; i++) { const char ch = text[i]; buf[len] = ch; len += !(cls[(uint8_t)ch] & 4); }
+    const uint64_t span = R.se - R.sb, CH = BSX_PACK_CHUNK;
+    const size_t nck = (size_t)std::max<uint64_t>(1, (span + CH - 1) / CH);
+    std::vector<uint64_t> cnt(nck + 1, 0);
+    pfor(nck, nt, [&](size_t k) {
+        const uint64_t a = R.sb + k * CH, b = std::min(R.se, a + CH);
+        uint64_t c = 0;
+        for (uint64_t i = a; i < b; i++) c += !(cls[(uint8_t)text[i]] & 4);
+        cnt[k + 1] = c;
+    });
+    for (size_t k = 0; k < nck; k++) cnt[k + 1] += cnt[k];
+    const uint64_t len = cnt[nck];
     if (len >= 0xFFFFFFFFull - 64) { o.rc = BSX_ERR_LIMIT; return; }
     const uint32_t L = (uint32_t)len;
     const uint32_t nw = (L + BSX_SEGLEN - 1) / BSX_SEGLEN + 2;  // BinSeq: two spare words (dbseq.cpp:60)
     const uint64_t padded = (uint64_t)nw * BSX_SEGLEN;
-    std::fill(buf.begin() + L, buf.begin() + padded, 'N');
+    std::unique_ptr<char[]> bufp(new char[padded + 64]);   // (not value-initialised: every byte below `padded` is written by the two loops that follow)
+    char *const buf = bufp.get();
+    const uint64_t buf_size = padded + 64;
+    pfor(nck, nt, [&](size_t k) {
+        const uint64_t a = R.sb + k * CH, b = std::min(R.se, a + CH);
+        uint64_t q = cnt[k];
+        const uint64_t lim = cnt[k + 1];   // (chunks write side by side: never past the chunk's own last character)
+        for (uint64_t i = a; i < b && q < lim; i++) { const char ch = text[i]; buf[q] = ch; q += !(cls[(uint8_t)ch] & 4); }
+    });
+    std::fill(buf + L, buf + buf_size, 'N');
     o.L = L; o.padded = (uint32_t)padded;
     o.f.resize(nw); o.c.resize(nw);
-    for (uint32_t w = 0; w < nw; w++) {
-        uint32_t x = 0, y = 0;
-        const uint64_t base = (uint64_t)w * BSX_SEGLEN, rbase = padded - 1 - base;
-        for (uint32_t j = 0; j < BSX_SEGLEN; j++) {
-            x = (x << 2) | code_f[(uint8_t)buf[base + j]];
-            y = (y << 2) | code_r[(uint8_t)buf[rbase - j]];
+    const uint32_t WCH = BSX_PACK_WORDS;   // words per task (4 M nt)
+    pfor((nw + WCH - 1) / WCH, nt, [&](size_t k) {
+        const uint32_t w0 = (uint32_t)k * WCH, w1 = std::min(nw, w0 + WCH);
+        for (uint32_t w = w0; w < w1; w++) {
+            uint32_t x = 0, y = 0;
+            const uint64_t base = (uint64_t)w * BSX_SEGLEN, rbase = padded - 1 - base;
+            for (uint32_t j = 0; j < BSX_SEGLEN; j++) {
+                x = (x << 2) | code_f[(uint8_t)buf[base + j]];
+                y = (y << 2) | code_r[(uint8_t)buf[rbase - j]];
+            }
+            o.f[w] = x; o.c[w] = y;
         }
-        o.f[w] = x; o.c[w] = y;
-    }
+    });
     // UnmaskRegion (dbseq.cpp:114-142): maximal runs between N/X characters that start at an ACGT letter and are
     // >= 30 nt; each run is recorded on the forward copy (id 2c) and mirrored on the rc copy (id 2c+1).  The
     // reference scans a work string that still holds older records behind this one; the 'N' padding written above
     // stops both scans before that tail, so the record alone decides.
+    // The reference's two alternating scans — to the next ACGT letter, then to the next N/X — only ever stop at the ends of N/X runs or inside the stretches
+    // between them: the N/X runs of [0, padded) are listed per chunk in parallel (a handful per chromosome), joined where they touch, and the scans then jump
+    // over them.
     {
+        const uint64_t NCH = BSX_PACK_NXCHUNK;
+        const size_t nnk = (size_t)((padded + NCH - 1) / NCH);
+        std::vector<std::vector<std::pair<uint64_t, uint64_t>>> runs_k(nnk);
+        pfor(nnk, nt, [&](size_t k) {
+            const uint64_t a = k * NCH, b = std::min<uint64_t>(padded, a + NCH);
+            uint64_t i = a;
+            while (i < b) {
+                if (!(cls[(uint8_t)buf[i]] & 2)) { i++; continue; }
+                uint64_t j = i + 1;
+                while (j < b && (cls[(uint8_t)buf[j]] & 2)) j++;
+                runs_k[k].emplace_back(i, j);
+                i = j;
+            }
+        });
+        std::vector<std::pair<uint64_t, uint64_t>> runs;   // maximal N/X runs [start, end) of the padded record, ascending
+        for (auto &v : runs_k) for (auto &r_ : v) { if (!runs.empty() && runs.back().second == r_.first) runs.back().second = r_.second; else runs.push_back(r_); }
+        size_t ri = 0;   // first run that ends behind the scan position
         uint32_t begin, end = 0;
         while (end < L) {
             uint64_t q = end;
-            while (q < padded && !(cls[(uint8_t)buf[q]] & 1)) q++;
+            // while (q < padded && !(cls & 1)) q++   — N/X runs are skipped whole
+            for (;;) {
+                while (ri < runs.size() && runs[ri].second <= q) ri++;
+                if (ri < runs.size() && runs[ri].first <= q) { q = runs[ri].second; continue; }
+                if (q >= padded || (cls[(uint8_t)buf[q]] & 1)) break;
+                q++;
+            }
             if (q >= padded || q > L) break;
             begin = (uint32_t)q;
-            while (q < padded && !(cls[(uint8_t)buf[q]] & 2)) q++;
+            // while (q < padded && !(cls & 2)) q++   — the next N/X character is the start of the next run
+            while (ri < runs.size() && runs[ri].second <= q) ri++;
+            q = ri < runs.size() ? std::max<uint64_t>(q, runs[ri].first) : padded;
             end = q <= L ? (uint32_t)q : L;
             if (end - begin < 30) continue;
             // (the reference's "merge with previous block if gap < 5" test compares against the rc twin pushed
@@ -194,7 +267,7 @@ void pack_record(const bsx_params &P, const char *text, const Rec &R, uint32_t c
     if (P.rrbs) {
         // find_CCGG (dbseq.cpp:144-211)
         const size_t dl = strlen(P.digest_site);
-        const uint64_t bs = buf.size();
+        const uint64_t bs = buf_size;
         for (uint64_t q = 0; q < L && q + dl <= bs; q++) {
             bool ok = true;
             for (size_t k = 0; k < dl && ok; k++) ok = toupper((uint8_t)buf[q + k]) == P.digest_site[k];
@@ -271,14 +344,14 @@ int bsx_pack_fasta(const bsx_params &P, const char *text, uint64_t n, bsx_ref &r
     r.ccgg_index.assign(P.rrbs ? P.max_seedseg_num : 0, {});
     std::vector<Packed> pk(recs.size());
     {
-        std::atomic<size_t> next(0);
-        auto work = [&] { for (size_t i; (i = next.fetch_add(1)) < recs.size();) pack_record(P, text, recs[i], (uint32_t)i, code_f, code_r, cls, pk[i]); };
-        // large records first would balance better, but FASTA files list the long chromosomes first anyway
-        const size_t nt = std::min<size_t>(recs.size(), n < (8u << 20) ? 1 : std::max(1u, std::min(32u, bsx_usable_cpus())));
-        std::vector<std::thread> th;
-        for (size_t t = 1; t < nt; t++) th.emplace_back(work);
-        work();
-        for (std::thread &t : th) t.join();
+        // records of 32 MB and more one after another, every thread on chunks of the record; the small ones (contigs, plasmids) by a pool, one thread each
+        const unsigned ncpu = n < (uint64_t)BSX_PACK_MINTEXT ? 1u : std::max(1u, std::min(32u, bsx_usable_cpus()));
+        std::vector<size_t> small;
+        for (size_t i = 0; i < recs.size(); i++) {
+            if (recs[i].se - recs[i].sb >= (uint64_t)BSX_PACK_BIG && ncpu > 1) pack_record(P, text, recs[i], (uint32_t)i, code_f, code_r, cls, pk[i], ncpu);
+            else small.push_back(i);
+        }
+        pfor(small.size(), ncpu, [&](size_t k) { pack_record(P, text, recs[small[k]], (uint32_t)small[k], code_f, code_r, cls, pk[small[k]], 1); });
     }
     std::vector<std::vector<uint32_t>> fw, rc;
     for (size_t i = 0; i < recs.size(); i++) {

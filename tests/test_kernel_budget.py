@@ -23,6 +23,10 @@ BUDGET = {
     "7k_hscanILb0EE": (80, 0), "7k_hscanILb1EE": (80, 0),                    # one task per wave: six waves per SIMD (read words and masks live in VGPRs)
     "12k_hscan_sameILb0EE": (128, 0), "12k_hscan_sameILb1EE": (128, 0),      # WGBS (groups of tasks over one window and read offset): four chunks per step, four waves per SIMD, no scratch
     "14k_hscan_sharedILb0EE": (96, 0), "14k_hscan_sharedILb1EE": (96, 0),    # RRBS
+    # the control kernel of the heavy pipeline runs one block per CU BESIDE the scan kernels of the other batches in flight: what its waves hold of their SIMD's 512
+    # registers decides how many scan waves fit next to them.  Single-end (C4, C2): 224 leaves room for three 96-register scan waves; round 6 saw an edit lift it
+    # to 256 — two scan waves — and C4 go from 415 to 464 ms per step through code that never ran there.
+    "7k_hctrlILb0EE": (224, 128), "7k_hctrlILb1EE": (256, 128),
 }
 
 
