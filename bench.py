@@ -292,12 +292,19 @@ def main():
         bt.close()
     batches = batches[:1]
     def serial_steps(b_, slots):
-        ms, sc = [], []
-        t1 = time.perf_counter()
-        for k in slots:
-            b_.run_range(k * B_, B_, sync=True)
-            ms.append(b_.kernel_ms()); sc.append(b_.scan_ms())
-        return {"ms_per_step": (time.perf_counter() - t1) / len(slots) * 1e3, "event_ms_per_do_batch": float(np.mean(ms)), "scan_ms": sc}
+        ms, sc, st = [], [], []
+        b_.set_stage_timing(True)   # (three more events per control pass: only here)
+        try:
+            t1 = time.perf_counter()
+            for k in slots:
+                b_.run_range(k * B_, B_, sync=True)
+                ms.append(b_.kernel_ms()); sc.append(b_.scan_ms()); st.append(b_.stage_ms())
+            wall = (time.perf_counter() - t1) / len(slots) * 1e3
+        finally:
+            b_.set_stage_timing(False)
+        stage = {k: float(np.mean([x[k] for x in st])) for k in ("k_align", "k_hctrl", "order", "scan")}
+        stage["control_passes"] = float(np.mean([x["control_passes"] for x in st]))
+        return {"ms_per_step": wall, "event_ms_per_do_batch": float(np.mean(ms)), "scan_ms": sc, "stage_ms": stage}
 
     counted = None
     if nfl > 1 and world == 1 and args.steps >= 2:
@@ -361,7 +368,7 @@ def main():
             pass
     step_s = k_ms * 1e-3
     wc = bool(args.work_counters)
-    dk = dominant_kernel(serial["counters"], serial["scan_ms"], 2, 1, args.mode == "rrbs", args.mode, wc) if serial else dominant_kernel(counters, scan_ms, args.steps, nfl, args.mode == "rrbs", args.mode, wc)
+    dk = dominant_kernel(serial["counters"], serial["scan_ms"], 2, 1, args.mode == "rrbs", args.mode, wc, B_) if serial else dominant_kernel(counters, scan_ms, args.steps, nfl, args.mode == "rrbs", args.mode, wc, B_)
     hbm = None
     if pmc_j:  # what the memory system really moved per step (FETCH_SIZE raw and with the guide's gfx950 x2 rule for wide reads, WRITE_SIZE)
         raw = pmc_j["fetch_bytes_per_step_raw"] + pmc_j["write_bytes_per_step"]
@@ -401,7 +408,7 @@ def main():
         if "error" in counted:
             out["roofline"]["with_work_counters"] = counted
         else:
-            ck = dominant_kernel(counted["counters"], counted["scan_ms"], 2, 1, args.mode == "rrbs", args.mode, True) or {}
+            ck = dominant_kernel(counted["counters"], counted["scan_ms"], 2, 1, args.mode == "rrbs", args.mode, True, B_) or {}
             out["roofline"]["with_work_counters"] = {"serial_ms_per_step": counted["ms_per_step"], "scan_kernel_ms_per_step": ck.get("ms_per_step"), "scan_kernel_candidates_per_s": ck.get("candidates_per_s"),
                                                      "note": "the same two serial steps with bsx_batch_set_work_counters(1): the scan kernels also classify every candidate by the reference's two early-outs "
                                                              "(align.h:189-197) — what the parity suite runs, and where the counters of formula_rate come from; the timed region and dominant_kernel run without"}
@@ -461,12 +468,27 @@ def main():
 
 
 def roofline_block(dk, bound, achieved, traffic, traffic_note, hbm, k_ms, kernel_ms, heavy_last, alg_bytes_launch, counters, n_reads_rank, args, pmc_j, serial, np):
+    """`achieved` = (candidate, read) evaluations per second of the scan kernel, live (HIP events on its stream, device counters).  `peak` = the rate at which the
+    kernel would run if it issued NOTHING but its inner word (3 nw + 3 vector instructions per 64 evaluations of nw 32-nt words) at the issue ceiling
+    tools/microbench/valu_issue measured for that very word at the kernel's residency — from the microbenchmark, not from the kernel.  `frac` = achieved / peak: the USEFUL
+    fraction.  `issue_utilisation` is what round 5 printed as frac: all vector instructions the kernel issues (overhead included: SQ_INSTS_VALU of the same build) over
+    the same ceiling; `instructions_per_evaluation` says how many of those it spends per 64 evaluations.  Flat scalars and a short `bound`: the driver's record keeps
+    only those (strings up to 120 characters)."""
     dk = dk or {}
-    util = dk.get("binding_unit_utilisation")
     cand_s = dk.get("candidates_per_s")
-    r = {"bound": dk.get("bound") or bound,
-         "achieved": cand_s / 1e9 if cand_s else None, "peak": (cand_s / util / 1e9) if (cand_s and util) else None, "unit": "G candidates/s (" + str(dk.get("name")) + ")",
-         "frac": util,
+    ev = dk.get("bound_evidence") if isinstance(dk.get("bound_evidence"), dict) else {}
+    peak = ev.get("peak_candidates_per_s")
+    stage = (serial or {}).get("stage_ms") or {}
+    kern = {"k_align": stage.get("k_align"), "k_hctrl": stage.get("k_hctrl"), dk.get("name") or "scan": stage.get("scan")}
+    binding = max((v, k) for k, v in kern.items() if v is not None)[1] if any(v is not None for v in kern.values()) else None
+    r = {"bound": short_bound(dk, binding, stage),
+         "achieved": cand_s / 1e9 if cand_s else None, "peak": peak / 1e9 if peak else None, "unit": "G candidate-read evaluations/s (" + str(dk.get("name")) + ")",
+         "frac": (cand_s / peak) if (cand_s and peak) else None,
+         "issue_utilisation": dk.get("binding_unit_utilisation") if dk.get("binding_unit") == "valu_issue" else (ev.get("fractions") or {}).get("valu_issue"),
+         "instructions_per_evaluation": ev.get("instructions_per_evaluation"), "inner_word_instructions": ev.get("inner_word_instructions"),
+         "binding_kernel": binding, "serial_ms_k_align": stage.get("k_align"), "serial_ms_k_hctrl": stage.get("k_hctrl"), "serial_ms_order": stage.get("order"),
+         "serial_ms_scan": stage.get("scan"), "serial_control_passes": stage.get("control_passes"), "serial_ms_per_step": (serial or {}).get("ms_per_step"),
+         "bound_long": dk.get("bound") or bound,
          "formula_rate": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                           "note": "SURVEY 8(d): algorithmic bytes of a step / its wall time, against the HBM peak; " + bound},
          "traffic": traffic, "traffic_source": traffic_note, "hbm_traffic": hbm,
@@ -477,6 +499,19 @@ def roofline_block(dk, bound, achieved, traffic, traffic_note, hbm, k_ms, kernel
          "per_kernel": per_kernel_split(counters, args.steps, n_reads_rank, pmc_j, serial),
          "dominant_kernel": dk}
     return r
+
+
+def short_bound(dk, binding, stage):
+    """<= 120 characters (the driver's record cuts strings there): the step's binding kernel, and what the scan kernel is bound by"""
+    ev = dk.get("bound_evidence") if isinstance(dk.get("bound_evidence"), dict) else {}
+    fr = ev.get("fractions") or {}
+    unit = {"valu_issue": "VALU issue", "texture_addresser_busy": "texture path", "lds_active": "LDS"}.get(dk.get("binding_unit"), "no counter file")
+    txt = "%s: %s %.2f of own ceiling" % (dk.get("name"), unit, dk.get("binding_unit_utilisation") or 0.0) if dk.get("binding_unit") else "%s: no counter file of this build" % dk.get("name")
+    if fr.get("l2_hit") is not None:
+        txt += ", L2 hit %.2f, not HBM" % fr["l2_hit"]
+    if binding and stage.get("scan"):
+        txt += "; serial step: %s longest" % binding
+    return txt[:120]
 
 
 def workload_shape(ref, c, steps, units_per_step, reads_per_unit, heavy_units):
@@ -534,7 +569,7 @@ def per_kernel_split(c, steps, n_reads, pmc_j, serial):
     return out
 
 
-def dominant_kernel(counters, scan_ms, steps, nfl, rrbs=False, mode="pe", work_counters=False):
+def dominant_kernel(counters, scan_ms, steps, nfl, rrbs=False, mode="pe", work_counters=False, units_per_step=None):
     """The scan kernel of the heavy pipeline (k_hscan_same; RRBS k_hscan_shared), the kernel most of the time goes to: launches and HIP-event durations measured live (events on the stream it
     is launched on), algorithmic bytes of the candidates it evaluated (4 B index entry + 8 B per 64-bit reference word the
     reference's CountMismatch would touch).  `bound` is derived from the committed counter summaries of the
@@ -552,7 +587,7 @@ def dominant_kernel(counters, scan_ms, steps, nfl, rrbs=False, mode="pe", work_c
          "candidates_per_s": cand / (tot_ms * 1e-3),
          "class_shares": {"one_word": float(counters[9]) / max(cand, 1.0), "five_words": float(counters[10]) / max(cand, 1.0)},
          "timing_note": "launch durations overlap other kernels when batches_in_flight > 1" if nfl > 1 else "serial: no other kernel runs beside it"}
-    d.update(kernel_bound(mode, work_counters))
+    d.update(kernel_bound(mode, work_counters, cand / steps, cand / (tot_ms * 1e-3), units_per_step))
     return d
 
 
@@ -594,7 +629,17 @@ def valu_ceiling(mix_prefix, waves):
     return None
 
 
-def kernel_bound(mode="pe", work_counters=False):
+INNER_WORDS = {"pe": 5, "trim": 5, "se": 4, "rrbs": 3}   # 32-nt words of a read in the scan kernels (144 / 100 / 75 nt)
+
+
+def inner_word_instructions(mode, work_counters):
+    """vector instructions of the scan kernels' inner word per 64 (candidate, read) evaluations: per 32-nt word two v_bitop3 (three for the last) and one v_bcnt,
+    the candidate's share of the funnel shifts and the compare — 3 nw + 3 (nw = 5: tools/microbench/valu_issue mix 16, 18 instructions); with the work counters
+    two more v_bcnt, two v_and and two compares (mix 17, 24)"""
+    return 3 * INNER_WORDS[mode] + 3 + (6 if work_counters else 0)
+
+
+def kernel_bound(mode="pe", work_counters=False, cand_per_step=None, cand_per_s=None, units_per_step=None):
     """utilisation of the scan kernel's units from measurements kept under profiles/: SQ / TA / LDS counter passes of the kernel (tools/sq_passes.sh,
     tools/summarize_sq.py) taken with this library, mode and counter setting — nothing borrowed from another build or config: without such a file the
     fractions are null — and the VALU issue ceiling of the kernel's OWN inner word (tools/microbench/valu_issue.hip, mixes 16 / 17) at the kernel's own
@@ -612,6 +657,12 @@ def kernel_bound(mode="pe", work_counters=False):
         if not vc:
             return none
         ceil, ceil_full, vif, mixname = vc
+        inner = inner_word_instructions(mode, work_counters)
+        kk = [v for n, v in j["kernels"].items() if n.startswith("k_hscan")][0]
+        ipe = None
+        if cand_per_step and kk["counters"].get("SQ_INSTS_VALU"):   # vector instructions per 64 evaluations: the profile's count per step over the live candidates of a step
+            scale = (units_per_step / float(j["units_per_step"])) if (units_per_step and j.get("units_per_step")) else 1.0
+            ipe = kk["counters"]["SQ_INSTS_VALU"] / float(j.get("steps_in_pass") or 3) * scale / (cand_per_step / 64.0)
         fr = {"valu_issue": k["valu_instr_per_s"] / ceil, "valu_issue_at_full_occupancy": k["valu_instr_per_s"] / ceil_full, "texture_addresser_busy": k.get("ta_busy_frac"), "lds_active": k.get("lds_active_frac"),
               "l2_hit": k.get("l2_hit_frac"), "l1_miss_per_access": k.get("l1_miss_per_access"), "waiting_on_instruction_issue": k.get("wait_inst_frac"), "waiting_for_data": k.get("wait_any_frac"),
               "resident_waves_per_simd": waves}
@@ -621,6 +672,8 @@ def kernel_bound(mode="pe", work_counters=False):
         return {"bound": f"{names[top[1]]} at {top[0]:.2f}; the others: " + ", ".join(f"{names[n].split(' (')[0]} {fr[n]:.2f}" for n in names if n != top[1] and fr[n] is not None) + f"; not HBM (L2 hit {fr['l2_hit']:.2f})",
                 "binding_unit": top[1], "binding_unit_utilisation": top[0],
                 "bound_evidence": {"fractions": fr, "valu_ceiling_G_wave_instr_per_s": ceil / 1e9, "valu_ceiling_at_8_waves_per_simd": ceil_full / 1e9, "valu_mix": mixname, "same_build": True,
+                                   "inner_word_instructions": inner, "instructions_per_evaluation": ipe, "peak_candidates_per_s": ceil / inner * 64.0,
+                                   "useful_frac": (cand_per_s / 64.0 * inner / ceil) if cand_per_s else None,
                                    "sources": [os.path.basename(sq), vif]}}
     except Exception as e:
         none["bound_evidence"] += " (%s)" % str(e)[:120]
@@ -714,7 +767,11 @@ def other_configs(args):
                             "ms_per_2^20_units": j["ms_per_step"] * (1 << 20) / upu if upu else None, "steps": j["steps"],
                             "batches_in_flight": j["config"]["batches_in_flight"], "aligned_fraction": j["config"]["aligned_fraction"], "heavy_pools": j["config"].get("heavy_pools"),
                             "candidates_per_read": j["roofline"]["per_read"]["n_cand"], "dominant_kernel": {k: dk.get(k) for k in ("name", "ms_per_step", "candidates_per_s")},
-                            "roofline_frac": j["roofline"].get("frac"), "wall_s": round(time.perf_counter() - t0, 1)}
+                            # one serial step by kernel (HIP events, one batch in flight: they add up), which of them is the longest, and the scan kernel's fractions
+                            "serial_ms": {k: j["roofline"].get("serial_ms_" + k) for k in ("k_align", "k_hctrl", "order", "scan", "per_step")}, "binding_kernel": j["roofline"].get("binding_kernel"),
+                            "control_passes": j["roofline"].get("serial_control_passes"),
+                            "scan_kernel_frac": j["roofline"].get("frac"), "scan_kernel_issue_utilisation": j["roofline"].get("issue_utilisation"),
+                            "scan_kernel_instructions_per_evaluation": j["roofline"].get("instructions_per_evaluation"), "wall_s": round(time.perf_counter() - t0, 1)}
                 if failures:
                     res[tag]["failed_attempts"] = failures
                 break
@@ -989,7 +1046,14 @@ def cpu_baseline(ref, batch, pe, kw, target_s, first_unit, quals):
     finally:
         os.sched_setaffinity(0, old_aff)
     rp = 2 if pe else 1
+    por, por_src = None, None
+    try:   # what the real `bsmap -p 8` does against the port in this regime (build container, tools/cpu_port_vs_reference.py --pe): the port is the slower one
+        pj = json.load(open(os.path.join(ROOT, "profiles", "r05_cpu_port_vs_reference_pe.json")))
+        por, por_src = float(pj["port_over_reference"]), "profiles/r05_cpu_port_vs_reference_pe.json"
+    except Exception:
+        pass
     return {"value": n * rp / t, "unit": "reads/s", "cores": cores, "kind": "port", "hardware_threads": hw,
+            "port_over_reference": por, "value_reference_equivalent": (n * rp / t / por) if por else None, "port_over_reference_source": por_src,
             "sample": f"{n} {'pairs' if pe else 'reads'} of the timed workload ({L} nt), oracle/bsx_oracle.c with {cores} pthreads"
                       f" (the CPUs this process may use: affinity mask and cgroup quota; the box shows {hw} hardware threads"
                       f"{'; pinned to that many CPUs of one NUMA node' if pin else ''}), {t:.1f} s",

@@ -61,3 +61,28 @@ def test_other_configs_runs_every_other_mode_in_a_child(monkeypatch):
     # the record says WHY: return code and the end of the child's stderr (round 4's line said "list index out of range")
     assert [a["rc"] for a in res["C4"]["attempts"]] == [1, 1] and res["C4"]["attempts"][0]["stderr_tail"].endswith("out of memory")
     assert res["C5"]["failed_attempts"][0]["rc"] == -9
+
+
+def test_roofline_block_is_flat_short_and_priced_against_the_microbenchmark():
+    """the driver's record keeps scalars and the first 120 characters of a string: `bound` fits, `frac` = achieved / peak with the peak taken from the
+    microbenchmark's ceiling of the kernel's inner word (not from achieved / utilisation), instructions per evaluation and the per-kernel serial times are top-level"""
+    import numpy as np
+    assert [BN.inner_word_instructions(m, False) for m in ("pe", "se", "rrbs")] == [18, 15, 12] and BN.inner_word_instructions("pe", True) == 24
+    ceil = 660e9
+    dk = {"name": "k_hscan_same", "candidates_per_s": 1.2e12, "binding_unit": "valu_issue", "binding_unit_utilisation": 0.64,
+          "bound": "VALU issue (against the ceiling of the kernel's own inner word at its 3.4 resident waves per SIMD) at 0.64; the others: texture path 0.60, LDS 0.16; not HBM (L2 hit 0.61)",
+          "bound_evidence": {"fractions": {"valu_issue": 0.64, "l2_hit": 0.61}, "inner_word_instructions": 18, "instructions_per_evaluation": 23.2,
+                             "peak_candidates_per_s": ceil / 18 * 64, "useful_frac": 1.2e12 / 64 * 18 / ceil}}
+    serial = {"ms_per_step": 240.0, "stage_ms": {"k_align": 70.0, "k_hctrl": 23.0, "order": 6.0, "scan": 137.0, "control_passes": 20.0}}
+    args = type("A", (), {"steps": 2})()
+    r = BN.roofline_block(dk, "x", 1.0, None, "none", None, 224.0, [448.0], (37000, 0), 4e12, [1.0] * 17, 1 << 23, args, None, serial, np)
+    assert len(r["bound"]) <= 120 and "k_hscan_same" in r["bound"] and r["bound_long"].startswith("VALU issue")
+    assert abs(r["peak"] - ceil / 18 * 64 / 1e9) < 1e-6 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and abs(r["frac"] - 0.511) < 0.01
+    assert r["issue_utilisation"] == 0.64 and r["instructions_per_evaluation"] == 23.2 and r["inner_word_instructions"] == 18
+    assert r["binding_kernel"] == "k_hscan_same" and r["serial_ms_k_hctrl"] == 23.0 and r["serial_ms_k_align"] == 70.0 and r["serial_control_passes"] == 20.0
+    for k, v in r.items():   # what the record keeps: everything named above is a scalar
+        if k in ("bound", "achieved", "peak", "frac", "issue_utilisation", "instructions_per_evaluation", "binding_kernel", "serial_ms_scan"):
+            assert isinstance(v, (int, float, str))
+    # a control-bound config names the control kernel
+    serial["stage_ms"].update(k_hctrl=400.0)
+    assert BN.roofline_block(dk, "x", 1.0, None, "none", None, 224.0, [448.0], (37000, 0), 4e12, [1.0] * 17, 1 << 23, args, None, serial, np)["binding_kernel"] == "k_hctrl"
