@@ -904,13 +904,24 @@ def end_to_end(pairs, genome):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
     try:
         import e2e_bench
-        r = e2e_bench.run(types.SimpleNamespace(pairs=pairs, genome=1.0 if genome == "hg38" else float(genome), dir="/dev/shm/bsx_e2e_%d" % os.getpid(),
-                                                threads=0, keep=False))
-        t = r["timing"]
-        return {"reads_per_s": r["reads_per_s_mapping_phase"], "unit": "reads/s, first batch parsed -> last SAM line written", "pairs": pairs,
-                "mapping_s": t["mapping_s"], "load_reference_s": t["load_reference_s"], "index_build_s": t["index_build_s"], "whole_process_s": r["cli_wall_s"],
-                "fastq_bytes": r["fastq_bytes"], "sam_bytes": r["sam_bytes"], "stage_busy_s": t["stage_busy_s"], "host_threads": t["workers"],
-                "command": "bsmap -a r_1.fq -b r_2.fq -d genome.fa -o out.sam -s 16 -v 6 -m 28 -x 500 -S 1"}
+        # the same input files twice: ONE pipeline (one reader per file, one ring, one output file: its host side tops out near 20 M reads/s on the box's 16 CPUs,
+        # DESIGN.md §8), and two lanes that share the GPU (`--lanes=2 --lane-files`: two processes, each with its own reader, ring, replica and output file — the
+        # reference's -B / -E shards on one node), the mode to use where one pipeline's host side is the limit
+        rr = e2e_bench.run(types.SimpleNamespace(pairs=pairs, genome=1.0 if genome == "hg38" else float(genome), dir="/dev/shm/bsx_e2e_%d" % os.getpid(),
+                                                 threads=0, keep=False, variants=";--lanes=2 --lane-files"))
+        rs = rr.get("variants") or [rr]
+
+        def leg(r, cmd):
+            t = r["timing"]
+            return {"reads_per_s": r["reads_per_s_mapping_phase"], "mapping_s": t["mapping_s"], "load_reference_s": t.get("load_reference_s"), "index_build_s": t.get("index_build_s"),
+                    "whole_process_s": r["cli_wall_s"], "mapping_cpu_s": t.get("mapping_cpu_s"), "stage_busy_s": t.get("stage_busy_s"), "host_threads": t.get("workers"), "command": cmd}
+        base = "bsmap -a r_1.fq -b r_2.fq -d genome.fa -o out.sam -s 16 -v 6 -m 28 -x 500 -S 1"
+        out = leg(rs[0], base)
+        out.update({"unit": "reads/s, first batch parsed -> last SAM line written", "pairs": pairs, "fastq_bytes": rs[0]["fastq_bytes"], "sam_bytes": rs[0]["sam_bytes"]})
+        if len(rs) > 1:
+            out["two_lanes_one_gpu"] = leg(rs[1], base + " --lanes=2 --lane-files")
+            out["best_reads_per_s"] = max(out["reads_per_s"], out["two_lanes_one_gpu"]["reads_per_s"])
+        return out
     except Exception as e:  # the metric above does not depend on this leg
         return {"error": str(e)[:300]}
 

@@ -2146,8 +2146,13 @@ __device__ __forceinline__ bool heavy_advance(const AlignArgs &A, const HeavyArg
 #ifndef BSX_HCTRL_WAVES
 #define BSX_HCTRL_WAVES 1  /* waves per SIMD the control kernel's register budget allows (1 = 512 registers) */
 #endif
+#ifdef BSX_HCTRL_VGPR   /* experiment: cap the control kernel's registers (more scan waves of the other batches beside it) */
+#define HCTRL_VGPR_ATTR __attribute__((amdgpu_num_vgpr(BSX_HCTRL_VGPR)))
+#else
+#define HCTRL_VGPR_ATTR
+#endif
 template <bool PE>
-__global__ __launch_bounds__(256, PE ? BSX_HCTRL_WAVES : BSX_HCTRL_WAVES_SE) void k_hctrl(AlignArgs A_, HeavyArgs H_)
+__global__ __launch_bounds__(256, PE ? BSX_HCTRL_WAVES : BSX_HCTRL_WAVES_SE) HCTRL_VGPR_ATTR void k_hctrl(AlignArgs A_, HeavyArgs H_)
 {
     __shared__ BlockLds BL;
     __shared__ WaveLds<PE> WL[4];
@@ -3187,7 +3192,11 @@ uint32_t bsx_leak_blk(void) { return LEAK_BLK; }
 
 void bsx_launch_align(const AlignArgs &A, int paired, int grid_blocks, hipStream_t stream)
 {
-    if (A.leak_exact) {
+    const bool ctx = A.P.ctx && !A.work_counters && A.P.index_interval <= 4 && !A.P.rrbs;
+    if (A.leak_exact && ctx) {   // (round 6: the exact mode keeps the context prefilter — it used to fall back to the plain scan, most of its 11 % on C5)
+        if (paired) hipLaunchKernelGGL((k_align<true, true, true>), dim3(grid_blocks), dim3(256), 0, stream, A);
+        else hipLaunchKernelGGL((k_align<false, true, true>), dim3(grid_blocks), dim3(256), 0, stream, A);
+    } else if (A.leak_exact) {
         if (paired) hipLaunchKernelGGL((k_align<true, true>), dim3(grid_blocks), dim3(256), 0, stream, A);
         else hipLaunchKernelGGL((k_align<false, true>), dim3(grid_blocks), dim3(256), 0, stream, A);
     } else if (A.P.ctx && !A.work_counters && A.P.index_interval <= 4 && !A.P.rrbs) {   // the context prefilter: with the index's flank words (the kernel's flank table holds four phases: -I <= 4, WGBS), and only where nobody reads the work counters

@@ -19,6 +19,7 @@ BUDGET = {
     "7k_alignILb0ELb0ELb0EE": (96, 128),    # single-end
     "7k_alignILb1ELb0ELb1EE": (96, 160),    # the same with the context prefilter (counters off: what the command line and the bench's timed region run), 160 B today: 35 spilled VGPRs — edits that took it to 50-67 cost 6-10 ms per 2^22 pairs
     "7k_alignILb0ELb0ELb1EE": (96, 128),
+    "7k_alignILb1ELb1ELb1EE": (96, 160),    # exact mode on top of the context prefilter (round 6: BSX_P1_EXACT no longer falls back to the plain scan), 144 B today
     # the scan kernels of the heavy pipeline, without (ILb0E: what the command line and the bench's timed region run) and with the work counters
     "7k_hscanILb0EE": (80, 0), "7k_hscanILb1EE": (80, 0),                    # one task per wave: six waves per SIMD (read words and masks live in VGPRs)
     "12k_hscan_sameILb0EE": (128, 0), "12k_hscan_sameILb1EE": (128, 0),      # WGBS (groups of tasks over one window and read offset): four chunks per step, four waves per SIMD, no scratch
