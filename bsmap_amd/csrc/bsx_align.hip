@@ -2146,13 +2146,8 @@ __device__ __forceinline__ bool heavy_advance(const AlignArgs &A, const HeavyArg
 #ifndef BSX_HCTRL_WAVES
 #define BSX_HCTRL_WAVES 1  /* waves per SIMD the control kernel's register budget allows (1 = 512 registers) */
 #endif
-#ifdef BSX_HCTRL_VGPR   /* experiment: cap the control kernel's registers (more scan waves of the other batches beside it) */
-#define HCTRL_VGPR_ATTR __attribute__((amdgpu_num_vgpr(BSX_HCTRL_VGPR)))
-#else
-#define HCTRL_VGPR_ATTR
-#endif
 template <bool PE>
-__global__ __launch_bounds__(256, PE ? BSX_HCTRL_WAVES : BSX_HCTRL_WAVES_SE) HCTRL_VGPR_ATTR void k_hctrl(AlignArgs A_, HeavyArgs H_)
+__global__ __launch_bounds__(256, PE ? BSX_HCTRL_WAVES : BSX_HCTRL_WAVES_SE) void k_hctrl(AlignArgs A_, HeavyArgs H_)
 {
     __shared__ BlockLds BL;
     __shared__ WaveLds<PE> WL[4];

@@ -1,0 +1,13 @@
+# round 6, call 12-13: overflow chunks and k_hfilter: parity, clocks, A/B (default = both, filt_noovf = filter without chunks, nofilt = neither)
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r06m; mkdir -p $O; cd $R
+timeout 1500 python3 -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "without_work_counters or heavy" > $O/parity.txt 2>&1; tail -n 3 $O/parity.txt
+line() { python3 -c "
+import json
+d=json.load(open('$1')); r=d['roofline']; print('$2: %.1f ms/step  %.2f M reads/s   serial %.1f  align %.1f ctrl %.1f order %.1f scan %.1f passes %.0f' % (d['ms_per_step'], d['value']/1e6, r['serial_ms_per_step'] or 0, r['serial_ms_k_align'] or 0, r['serial_ms_k_hctrl'] or 0, r['serial_ms_order'] or 0, r['serial_ms_scan'] or 0, r['serial_control_passes'] or 0))"; }
+for rep in 1 2; do for v in default filt_noovf nofilt; do for m in trim pe se; do
+  if [ $v = default ]; then unset BSX_LIB; else export BSX_LIB=$R/bsmap_amd/libbsx_$v.so; fi
+  timeout 600 python3 bench.py --mode $m --cpu-seconds 0 --e2e-pairs 0 --transfer-steps 0 --sensitivity 0 --other-configs 0 --steps 9 --warmup 3 > $O/${m}_${v}_$rep.json 2> $O/${m}_${v}_$rep.err
+  line $O/${m}_${v}_$rep.json "$m $v #$rep"
+done; done; done
+unset BSX_LIB
+timeout 600 python3 tools/ctrl_clocks.py --mode trim > $O/ctrl_clocks_trim.json 2> $O/ctrl_clocks_trim.err; cut -c1-900 $O/ctrl_clocks_trim.json
