@@ -63,6 +63,7 @@ struct Opts {
 struct LaneInfo {
     int index = -1, n = 1, stats_fd = -1;
     int ready_fd = -1, go_fd = -1;     // the lanes start mapping together: a lane says when its reference is loaded and indexed, the parent releases all of them
+    int state_fd = -1;                 // BSX_P1_EXACT: the planner state at this lane's first read, from the parent (which composes it from the lanes' range effects)
     size_t off_a = ~(size_t)0, off_b = ~(size_t)0;
     unsigned cpus = 0;                 // this lane's share of the CPUs the run may use
     vector<int> lane_devices;          // GPU of every lane of the run (a lane takes the CPU range of its NUMA node that follows the earlier lanes on that node)
@@ -617,7 +618,7 @@ int fork_lanes(Opts &o, LaneInfo &lane, time_t t_begin)
     const bool pe = !o.a_file.empty() && !o.b_file.empty();
     const char *why = nullptr;
     if (o.out_sam == 2) why = "BAM output is sorted over the whole run";
-    else if (getenv("BSX_P1_EXACT") && atoi(getenv("BSX_P1_EXACT")) != 0) why = "BSX_P1_EXACT chains the planner state through the whole input";
+    const bool p1_exact = getenv("BSX_P1_EXACT") && atoi(getenv("BSX_P1_EXACT")) != 0;   // (round 6: composes with lanes, see the parent's loop below)
     if (o.devices_all) { o.devices.clear(); const int n = count_devices_in_a_child(); for (int d = 0; d < n; d++) o.devices.push_back(d); o.devices_all = false; }
     if (o.devices.empty()) o.devices.push_back(0);
     const int want = o.lanes > 0 ? o.lanes : (int)o.devices.size();
@@ -639,7 +640,7 @@ int fork_lanes(Opts &o, LaneInfo &lane, time_t t_begin)
     const int L = (int)plan.lanes.size();
     const unsigned ncpu = bsx_usable_cpus(), share = max(2u, ncpu / (unsigned)L);
     vector<pid_t> pids(L, -1);
-    vector<int> fds(L, -1);
+    vector<int> fds(L, -1), sfds(L, -1);
     int ready[2], go[2];
     if (pipe(ready) != 0 || pipe(go) != 0) { cerr << "bsx: pipe failed\n"; exit(1); }
     const string out0 = o.out_file, unpair0 = o.out_unpair;
@@ -647,14 +648,15 @@ int fork_lanes(Opts &o, LaneInfo &lane, time_t t_begin)
     const unsigned end0 = o.read_end;
     cout.flush(); cerr.flush();
     for (int l = 0; l < L; l++) {
-        int fd[2];
-        if (pipe(fd) != 0) { cerr << "bsx: pipe failed\n"; exit(1); }
+        int fd[2], sfd[2] = {-1, -1};
+        if (pipe(fd) != 0 || (p1_exact && pipe(sfd) != 0)) { cerr << "bsx: pipe failed\n"; exit(1); }
         const pid_t pid = fork();
         if (pid < 0) { cerr << "bsx: fork failed\n"; exit(1); }
         if (pid == 0) {
-            for (int k = 0; k < l; k++) ::close(fds[k]);
+            for (int k = 0; k < l; k++) { ::close(fds[k]); if (sfds[k] >= 0) ::close(sfds[k]); }
             ::close(fd[0]); ::close(ready[0]); ::close(go[1]);
-            lane.ready_fd = ready[1]; lane.go_fd = go[0];
+            if (p1_exact) ::close(sfd[1]);
+            lane.ready_fd = ready[1]; lane.go_fd = go[0]; lane.state_fd = sfd[0];
             const bsx_lanes::Lane &R = plan.lanes[l];
             lane.index = l; lane.n = L; lane.stats_fd = fd[1]; lane.off_a = R.off_a; lane.off_b = R.off_b;
             lane.cpus = share; lane.final_out = out0; lane.final_unpair = unpair0;
@@ -669,11 +671,37 @@ int fork_lanes(Opts &o, LaneInfo &lane, time_t t_begin)
             return l;
         }
         ::close(fd[1]);
-        pids[l] = pid; fds[l] = fd[0];
+        if (p1_exact) ::close(sfd[0]);
+        pids[l] = pid; fds[l] = fd[0]; sfds[l] = sfd[1];
     }
     // parent: once every lane has its reference and index (or has died: its end of the pipe closes), all start mapping
     ::close(ready[1]); ::close(go[0]);
-    for (int got = 0; got < L;) { char c[64]; const ssize_t r = read(ready[0], c, sizeof c); if (r <= 0) break; got += (int)r; }
+    if (!p1_exact) { for (int got = 0; got < L;) { char c[64]; const ssize_t r = read(ready[0], c, sizeof c); if (r <= 0) break; got += (int)r; } }
+    else {
+        // BSX_P1_EXACT across lanes.  What the reads of a range do to the reference's never-reset planner state (align.h:82-91) does not depend on the state they
+        // find: a read either writes a slot — start offset, seed_array entry — with a value of its own, or leaves it.  Every lane first sweeps its range with the
+        // pre-pass alone (upload, k_leak_meta, k_leak_final; no alignment) from a state of MARKER words and sends what comes out: its range's effect, marker = "left
+        // alone".  The state at lane j's first read is then, slot by slot, the effect of the nearest earlier lane that wrote the slot, zero (a fresh aligner
+        // object) if none did — composed here, where no GPU is touched, and handed back before the lanes start mapping.  One message per lane (lane index + state:
+        // under PIPE_BUF, so the writes of different lanes never interleave).
+        signal(SIGPIPE, SIG_IGN);   // (a lane that died before it could listen: its stats pipe reports it below)
+        const size_t W = BSX_LEAK_STATE_BYTES / 4, MSG = 1 + BSX_LEAK_STATE_BYTES;
+        vector<vector<uint32_t>> eff((size_t)L, vector<uint32_t>(W, 0xFFFFFFFFu));
+        vector<char> have((size_t)L, 0);
+        vector<unsigned char> msg(MSG);
+        for (int got = 0; got < L; got++) {
+            size_t n = 0;
+            while (n < MSG) { const ssize_t r = read(ready[0], msg.data() + n, MSG - n); if (r <= 0) break; n += (size_t)r; }
+            if (n < MSG || msg[0] >= (unsigned)L) break;   // (a lane died: its stats pipe will say so)
+            memcpy(eff[msg[0]].data(), msg.data() + 1, BSX_LEAK_STATE_BYTES); have[msg[0]] = 1;
+        }
+        vector<uint32_t> st(W, 0u);   // the state at lane 0's first read: a fresh object
+        for (int l = 0; l < L; l++) {
+            const ssize_t w = write(sfds[l], st.data(), BSX_LEAK_STATE_BYTES); (void)w;
+            ::close(sfds[l]);
+            if (have[(size_t)l]) for (size_t k = 0; k < W; k++) if (eff[(size_t)l][k] != 0xFFFFFFFFu) st[k] = eff[(size_t)l][k];
+        }
+    }
     { const string all((size_t)L, 'g'); const ssize_t w = write(go[1], all.data(), all.size()); (void)w; }
     ::close(ready[0]); ::close(go[1]);
     LaneStats tot; memset(&tot, 0, sizeof tot);
@@ -944,10 +972,53 @@ int main(int argc, char **argv)
     for (auto &c : cpu_ns) c = 0;
     auto add_cpu = [&](int st, double t0) { cpu_ns[st] += (long long)((thread_cpu_s() - t0) * 1e9); };
     t_pin.join();
+    vector<unsigned char> lane_state;   // BSX_P1_EXACT in a lane: the planner state at the lane's first read (the parent's composition)
     if (lane.index >= 0) {   // every lane is ready: the mapping phases start together (the index build / upload is not part of them)
-        char c = 'r';
-        ssize_t r = write(lane.ready_fd, &c, 1); ::close(lane.ready_fd);
-        r = read(lane.go_fd, &c, 1); (void)r; ::close(lane.go_fd);
+        const bool x1 = getenv("BSX_P1_EXACT") && atoi(getenv("BSX_P1_EXACT")) != 0;
+        if (!x1) {
+            char c = 'r';
+            ssize_t r = write(lane.ready_fd, &c, 1); ::close(lane.ready_fd);
+            r = read(lane.go_fd, &c, 1); (void)r; ::close(lane.go_fd);
+        } else {
+            // the effect of this lane's range on the planner state (see fork_lanes): the pre-pass alone over every batch of the range, from a state of marker words
+            vector<unsigned char> st(BSX_LEAK_STATE_BYTES, 0xFF);
+            {
+                Reader qa, qb;
+                ReadOpts roa = ro, rob = ro; roa.start_offset = lane.off_a; rob.start_offset = lane.off_b;
+                qa.open(o.a_file, roa);
+                if (pe) qb.open(o.b_file, rob);
+                ReadSet A, B;
+                bsx_batch *bt = batches[0];
+                bsx_batch_set_leak_exact(bt, 1);
+                for (;;) {
+                    size_t n2 = 0;
+                    thread tb;
+                    if (pe) tb = thread([&] { n2 = load_reads(qb, B, o.batch, ro, 2); });
+                    const size_t n1 = load_reads(qa, A, o.batch, ro, pe ? 1 : 0);
+                    if (pe) tb.join();
+                    const size_t n = pe ? min(n1, n2) : n1;
+                    if (n == 0) break;
+                    int r;
+                    if (!pe) r = bsx_batch_upload_se(bt, (uint32_t)n, A.seq.data(), A.soff.data(), qa.format != 1 ? A.upload_qual() : nullptr, A.first_index);
+                    else { const bool q = qa.format != 1 && qb.format != 1;
+                           r = bsx_batch_upload_pe(bt, (uint32_t)n, A.seq.data(), A.soff.data(), q ? A.upload_qual() : nullptr, B.seq.data(), B.soff.data(), q ? B.upload_qual() : nullptr, A.first_index); }
+                    if (!r) r = bsx_batch_set_leak_state(bt, st.data(), st.size());
+                    if (!r) r = bsx_batch_get_leak_state(bt, st.data(), st.size());
+                    if (r) die(r, "sweeping the lane's range for its planner-state effect");
+                    if (n < o.batch) break;
+                }
+                (void)bsx_batch_set_leak_state(bt, nullptr, 0);
+            }
+            vector<unsigned char> msg(1 + BSX_LEAK_STATE_BYTES);
+            msg[0] = (unsigned char)lane.index; memcpy(msg.data() + 1, st.data(), BSX_LEAK_STATE_BYTES);
+            ssize_t r = write(lane.ready_fd, msg.data(), msg.size()); ::close(lane.ready_fd);
+            lane_state.assign(BSX_LEAK_STATE_BYTES, 0);
+            size_t got = 0;
+            while (got < lane_state.size()) { r = read(lane.state_fd, lane_state.data() + got, lane_state.size() - got); if (r <= 0) break; got += (size_t)r; }
+            ::close(lane.state_fd);
+            if (got != lane_state.size()) { cerr << "bsx: lane " << lane.index << ": no planner state from the parent\n"; fatal_exit(); }
+            char c; r = read(lane.go_fd, &c, 1); (void)r; ::close(lane.go_fd);
+        }
     }
     const double t_map0 = now_s();
     struct rusage ru0; getrusage(RUSAGE_SELF, &ru0);
@@ -960,6 +1031,7 @@ int main(int argc, char **argv)
     if (p1_exact) for (int g = 0; g < NG; g++) bsx_batch_set_leak_exact(batches[g], 1);
     struct LeakChain { mutex mu; condition_variable cv; long have = -1; vector<unsigned char> state; } chain;  // state behind batch `have`
     chain.state.assign(BSX_LEAK_STATE_BYTES, 0);
+    if (!lane_state.empty()) chain.state = lane_state;   // (a lane: not a fresh object, the state the reads before its range leave)
     thread t_parse([&] {
         long k = 0;
         for (;; k++) {

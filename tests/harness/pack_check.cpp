@@ -7,6 +7,7 @@
 #define BSX_PACK_NXCHUNK 1013u
 #define BSX_PACK_BIG 4096u
 #define BSX_PACK_MINTEXT 1u
+#define BSX_PACK_FEW(ncpu) 1000000u
 #include "../../bsmap_amd/csrc/bsx_host.cpp"
 #include <cstdio>
 int main(int argc, char **argv)

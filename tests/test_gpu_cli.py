@@ -367,6 +367,27 @@ def test_cli_exact_mode_state_crosses_many_batches(key, env, tmp_path):
         assert _body(open(plain).read()) != _body(case["out"])
 
 
+@pytest.mark.parametrize("key", sorted(LEAKRUN))
+@pytest.mark.parametrize("lanes", [["--lanes=3"], ["--lanes=4", "--lane-files"], ["-G", "0,0", "--lanes"]], ids=["lanes3", "lanes4_files", "lanes_G00"])
+def test_cli_exact_mode_composes_with_lanes(key, lanes, tmp_path):
+    """BSX_P1_EXACT with --lanes (round 6): the runs of reads that never set the planner's offset are cut into lanes right through the stretch that depends on
+    one early read; every lane sweeps its range for the range's effect on the state, the parent composes the state at each lane's first read, and the joined
+    output (or the lane files, concatenated) equals the REAL `bsmap -p 1` byte for byte — as the single pipeline's does"""
+    case = LEAKRUN[key]
+    meta = dict(kind=case["kind"], reads=case["reads"], kw={})
+    files = _write_fastq(meta, tmp_path, "lr")
+    out = str(tmp_path / "o.sam")
+    _run_cli(meta, os.path.join(G.GOLDEN, "genome_wgbs.fa"), files, out, case["options"] + ["-p", "2"] + lanes, {"BSX_BATCH": "23", "BSX_P1_EXACT": "1"})
+    if "--lane-files" in lanes:
+        body = []
+        for k in range(4):
+            assert os.path.exists(out + f".{k}")
+            body += [ln for ln in _body(open(out + f".{k}").read()) if k == 0 or not ln.startswith("@")]   # (every lane file carries the header)
+        assert body == _body(case["out"])
+    else:
+        assert _body(open(out).read()) == _body(case["out"])
+
+
 def _names_by_kind():
     se = [n for n in sorted(CLI) if G.load(n)[0]["kind"] == "se" and CLI[n]["sam_Ru"]["out"]]
     pe = [n for n in sorted(CLI) if G.load(n)[0]["kind"] == "pe" and CLI[n]["sam_Ru"]["out"]]
