@@ -60,7 +60,7 @@ def build(force=False):
 
 EXPORTS = [
     "bsx_strerror", "bsx_last_error_detail", "bsx_params_default", "bsx_params_set_digest", "bsx_params_finish",
-    "bsx_device_count", "bsx_device_numa_node", "bsx_ref_create_from_fasta", "bsx_ref_create_from_file", "bsx_ref_create_synthetic", "bsx_synth_chr_text", "bsx_ref_destroy",
+    "bsx_device_count", "bsx_device_numa_node", "bsx_ref_create_from_fasta", "bsx_ref_create_from_file", "bsx_ref_create_synthetic", "bsx_synth_chr_text", "bsx_ref_packed_on_device", "bsx_ref_destroy",
     "bsx_ref_n_chr", "bsx_ref_n_words", "bsx_ref_n_blocks", "bsx_ref_info", "bsx_ref_chr_name", "bsx_ref_blocks",
     "bsx_ref_download_words", "bsx_ref_set_context", "bsx_ref_context_bytes", "bsx_ref_drop_context", "bsx_index_build", "bsx_index_n_entries", "bsx_index_download", "bsx_ref_n_sites", "bsx_ref_sites",
     "bsx_batch_create", "bsx_batch_destroy", "bsx_batch_upload_se", "bsx_batch_upload_pe", "bsx_batch_synth_reads", "bsx_batch_synth_reads_kind", "bsx_batch_download_quals",
@@ -89,6 +89,7 @@ def lib():
         L.bsx_ref_create_from_file.argtypes = [C.POINTER(Params), C.c_char_p, i32, C.POINTER(vp)]
         L.bsx_ref_create_synthetic.argtypes = [C.POINTER(Params), u32, vp, u64, i32, C.POINTER(vp)]
         L.bsx_ref_destroy.argtypes = [vp]
+        L.bsx_ref_packed_on_device.argtypes = [vp]
         L.bsx_synth_chr_text.argtypes = [vp, u32, u32, u32, vp]
         L.bsx_ref_n_chr.argtypes = [vp]
         L.bsx_ref_n_chr.restype = u32
@@ -256,6 +257,9 @@ class RefSeq:
             _check(lib().bsx_ref_set_context(self.h, int(context), int(headroom)))
         _check(lib().bsx_index_build(self.h))
         return self
+
+    @property
+    def packed_on_device(self): return bool(lib().bsx_ref_packed_on_device(self.h))
 
     @property
     def context_bytes(self): return lib().bsx_ref_context_bytes(self.h)

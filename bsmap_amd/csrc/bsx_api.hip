@@ -75,9 +75,18 @@ template <class T> static int upload(T **dst, const T *src, size_t n)
     return BSX_OK;
 }
 
-static int finish_ref_upload(bsx_ref *r, const std::vector<uint32_t> &refcat, const std::vector<uint32_t> &crefcat)
+// the per-chromosome tables and the plane copy, behind the packed words (host-packed and uploaded, or packed on the device)
+static int finish_ref_tables(bsx_ref *r)
 {
     int rc;
+    if ((rc = upload(&r->d_anchor, r->anchor.data(), r->anchor.size()))) return rc;
+    if ((rc = upload(&r->d_chr_size, r->chr_size.data(), r->chr_size.size()))) return rc;
+    if ((rc = upload(&r->d_rc_offset, r->rc_offset.data(), r->rc_offset.size()))) return rc;
+    return bsx_planes_build(r);
+}
+
+static int finish_ref_upload(bsx_ref *r, const std::vector<uint32_t> &refcat, const std::vector<uint32_t> &crefcat)
+{
     // 64 spare words behind each copy so that 16-byte candidate loads never leave the allocation
     // (both strand copies in one allocation, the rc copy right behind the forward one: a candidate's reference words are
     //  then addressed by one 32-bit byte offset whatever its strand — the scan kernel's tail queue relies on that)
@@ -86,10 +95,7 @@ static int finish_ref_upload(bsx_ref *r, const std::vector<uint32_t> &refcat, co
     HIP_TRY(hipMemset(r->d_refcat, 0, 2 * (r->n_words + 64) * 4));
     HIP_TRY(hipMemcpy(r->d_refcat, refcat.data(), r->n_words * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(r->d_crefcat, crefcat.data(), r->n_words * 4, hipMemcpyHostToDevice));
-    if ((rc = upload(&r->d_anchor, r->anchor.data(), r->anchor.size()))) return rc;
-    if ((rc = upload(&r->d_chr_size, r->chr_size.data(), r->chr_size.size()))) return rc;
-    if ((rc = upload(&r->d_rc_offset, r->rc_offset.data(), r->rc_offset.size()))) return rc;
-    return bsx_planes_build(r);
+    return finish_ref_tables(r);
 }
 
 extern "C" int bsx_ref_create_from_fasta(const bsx_params *p, const char *text, uint64_t n_bytes, int device, bsx_ref **out)
@@ -100,9 +106,15 @@ extern "C" int bsx_ref_create_from_fasta(const bsx_params *p, const char *text, 
     bsx_ref *r = new bsx_ref();
     r->P = *p; r->device = device;
     std::vector<uint32_t> refcat, crefcat;
-    rc = bsx_pack_fasta(*p, text, n_bytes, *r, refcat, crefcat);
-    if (rc == BSX_OK && r->n_chr == 0) rc = BSX_ERR_IO;
-    if (rc == BSX_OK) rc = finish_ref_upload(r, refcat, crefcat);
+    // Run_ConvertBinseq on the device where the text allows it (bsx_pack.hip: line-regular FASTA, WGBS): the text goes up as it is and is packed there; any
+    // other text — and every RRBS reference, whose site tables come from the text — through the host packer, which applies the reference's token rules
+    rc = bsx_pack_fasta_device(*p, text, n_bytes, *r);
+    if (rc == BSX_OK) { r->packed_on_device = true; rc = r->n_chr == 0 ? BSX_ERR_IO : finish_ref_tables(r); }
+    else if (rc == 1) {
+        rc = bsx_pack_fasta(*p, text, n_bytes, *r, refcat, crefcat);
+        if (rc == BSX_OK && r->n_chr == 0) rc = BSX_ERR_IO;
+        if (rc == BSX_OK) rc = finish_ref_upload(r, refcat, crefcat);
+    }
     if (rc == BSX_OK && p->rrbs) rc = bsx_index_build_rrbs(r, refcat, crefcat);
     if (rc == BSX_OK && hipDeviceSynchronize() != hipSuccess) rc = BSX_ERR_DEVICE;  // null-stream memsets must land before any batch stream runs
     if (rc != BSX_OK) { bsx_ref_destroy(r); return rc; }
@@ -136,6 +148,7 @@ extern "C" void bsx_ref_destroy(bsx_ref *r)
 }
 
 extern "C" uint32_t bsx_ref_n_chr(const bsx_ref *r) { return r ? r->n_chr : 0; }
+extern "C" int bsx_ref_packed_on_device(const bsx_ref *r) { return r && r->packed_on_device ? 1 : 0; }
 extern "C" uint64_t bsx_ref_n_words(const bsx_ref *r) { return r ? r->n_words : 0; }
 extern "C" uint32_t bsx_ref_n_blocks(const bsx_ref *r) { return r ? (uint32_t)r->blocks.size() : 0; }
 extern "C" int bsx_ref_info(const bsx_ref *r, uint32_t *anchor, uint32_t *chr_size, uint32_t *rc_offset)

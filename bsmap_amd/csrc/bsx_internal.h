@@ -74,6 +74,7 @@ struct bsx_ref {
     // the entries' context table (d_ctx, 16 bytes per entry; bsx_ref_set_context): 0 never, 1 only if ctx_headroom bytes stay free behind it, 2 whenever it can be allocated
     int ctx_mode = 1;
     uint64_t ctx_headroom = BSX_CTX_HEADROOM_DEFAULT, ctx_bytes = 0;
+    bool packed_on_device = false;   // Run_ConvertBinseq ran on the device (bsx_pack.hip)
     int n_batches = 0;   // device batches alive on this reference (the context may only be dropped while none can be running)
     uint64_t synth_seed = 0;
 };
@@ -89,6 +90,8 @@ int bsx_hip_fail(hipError_t e, const char *what, const char *file, int line);
 // bsx_refpack.cpp
 int bsx_pack_fasta(const bsx_params &P, const char *text, uint64_t n, bsx_ref &r, std::vector<uint32_t> &refcat,
                    std::vector<uint32_t> &crefcat);
+// bsx_pack.hip: the same on the device for line-regular FASTA text (WGBS); 1 = not applicable, the caller takes bsx_pack_fasta
+int bsx_pack_fasta_device(const bsx_params &P, const char *text, uint64_t n, bsx_ref &r);
 // bsx_index.hip
 int bsx_planes_build(bsx_ref *r);   // the plane copy of the packed reference (d_refcat / d_crefcat must be filled)
 int bsx_index_build_wgbs(bsx_ref *r);

@@ -16,6 +16,8 @@
 // tests/test_gpu_pack.py: the texts of tests/test_pack_cpu.py in regular and irregular form).
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -108,6 +110,9 @@ inline bool is_space_h(char c) { return c == ' ' || (c >= '\t' && c <= '\r'); }
 int bsx_pack_fasta_device(const bsx_params &P, const char *text, uint64_t n, bsx_ref &r)
 {
     if (P.rrbs || n < (1u << 16) || getenv("BSX_HOST_PACK")) return 1;   // (small texts: the host packer is instant; BSX_HOST_PACK=1: test hook)
+    const bool timing = getenv("BSX_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_0 = now();
     // ---- records: the reference reads with operator>> (dbseq.cpp:18-54) — the first non-blank character is consumed unchecked, the next token is the name,
     // the rest of that line is dropped, then tokens are concatenated until one begins with '>'.  The '>' bytes are collected by a pool of threads.
     std::vector<u64> gt;
@@ -156,6 +161,7 @@ int bsx_pack_fasta_device(const bsx_params &P, const char *text, uint64_t n, bsx
         }
     }
     if (recs.empty()) return 1;   // (the host packer reports the empty reference)
+    const double t_recs = now();
     // ---- line structure of every record, from its first line; the device checks the rest
     std::vector<FaRec> fr(recs.size());
     uint64_t words = 0;
@@ -195,7 +201,11 @@ int bsx_pack_fasta_device(const bsx_params &P, const char *text, uint64_t n, bsx
     PK_TRY(hipMalloc((void **)&d_bad, (size_t)n_rec * 4));
     PK_TRY(hipMalloc((void **)&d_nev, 4));
     PK_TRY(hipMalloc((void **)&d_ev, (size_t)EV_CAP * 8));
+    const double t_alloc = now();
+    // (one hipMemcpy from the mapping: 9.5 GB/s, 0.33 s at hg38 size.  Page-locked staging buffers filled by six threads with a stream each were tried and are
+    //  SLOWER inside the command line — 0.89 s: their hipHostMalloc calls queue behind the gigabytes the command line is page-locking for its ring at that moment)
     PK_TRY(hipMemcpy(d_text, text, n, hipMemcpyHostToDevice));
+    const double t_up = now();
     PK_TRY(hipMemcpy(d_codes, code_f, 256, hipMemcpyHostToDevice));
     PK_TRY(hipMemcpy(d_codes + 256, code_r, 256, hipMemcpyHostToDevice));
     PK_TRY(hipMemcpy(d_recs, fr.data(), (size_t)n_rec * sizeof(FaRec), hipMemcpyHostToDevice));
@@ -224,6 +234,7 @@ int bsx_pack_fasta_device(const bsx_params &P, const char *text, uint64_t n, bsx
     PK_TRY(hipDeviceSynchronize());
     cleanup();
 #undef PK_TRY
+    const double t_kern = now();
     std::sort(ev.begin(), ev.end());
     // ---- host tables (bsx_pack_fasta's, from the same quantities)
     r.n_chr = 0; r.sum_length = 0;
@@ -267,5 +278,7 @@ int bsx_pack_fasta_device(const bsx_params &P, const char *text, uint64_t n, bsx
         }
     }
     std::sort(r.blocks.begin(), r.blocks.end(), [](const Block &a, const Block &b) { return a.id < b.id || (a.id == b.id && a.begin < b.begin); });
+    if (timing) fprintf(stderr, "{\"device_pack_s\": {\"records\": %.3f, \"alloc\": %.3f, \"upload\": %.3f, \"kernels_and_free\": %.3f, \"blocks\": %.3f}, \"text_bytes\": %llu, \"n_events\": %u}\n",
+                        t_recs - t_0, t_alloc - t_recs, t_up - t_alloc, t_kern - t_up, now() - t_kern, (unsigned long long)n, nev);
     return BSX_OK;
 }

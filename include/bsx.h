@@ -85,6 +85,7 @@ int bsx_ref_create_from_file(const bsx_params *p, const char *path, int device, 
 int bsx_ref_create_synthetic(const bsx_params *p, uint32_t n_chr, const uint32_t *chr_len, uint64_t seed, int device, bsx_ref **out);
 /* text of a synthetic chromosome, positions [from, from+n) (lets tests run the oracle's packer on the same sequence) */
 int bsx_synth_chr_text(const bsx_ref *r, uint32_t c, uint32_t from, uint32_t n, char *out);
+int bsx_ref_packed_on_device(const bsx_ref *r);   /* 1: the FASTA text was uploaded and packed by kernels (line-regular text of a WGBS reference, csrc/bsx_pack.hip); 0: by the host packer.  Same words either way */
 void bsx_ref_destroy(bsx_ref *r);
 uint32_t bsx_ref_n_chr(const bsx_ref *r);
 uint64_t bsx_ref_n_words(const bsx_ref *r);            /* words per strand copy incl. 2*400 margin (dbseq.h:15) */

@@ -108,6 +108,9 @@ def _run_cli(a, fq, fa, lens, n, t_fa, t_fq, extra):
     js = [json.loads(l) for l in res.stderr.split("\n") if l.startswith("{")]
     tim = [j for j in js if "mapping_s" in j][-1]
     ev = [j for j in js if "events" in j]
+    dp = [j for j in js if "device_pack_s" in j]
+    if dp:   # (the reference was packed on the device: where its start-up time went)
+        tim["device_pack"] = dp[-1]
     pt = [l for l in res.stderr.split("\n") if l.startswith("pace:")]
     if pt:
         tim["pace_trace"] = pt
