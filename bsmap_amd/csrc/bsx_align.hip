@@ -1679,6 +1679,10 @@ __global__ __launch_bounds__(256, PE ? BSX_WAVES_PER_EU_PE : BSX_WAVES_PER_EU_SE
 #ifndef HS_WINTAIL
 #define HS_WINTAIL (1u << 27)  /* window of a list once fewer than 256 units of the round are active (through round 5: HS_WINMAX) */
 #endif
+#ifndef HS_TAILU_A
+#define HS_TAILU_A 256u    /* active units of the round below which a list goes out whole (HS_WINTAIL) */
+#define HS_TAILU_B 2048u   /* ... below which windows are HS_WINTAIL2K */
+#endif
 #ifndef HS_WINTAIL2K
 #define HS_WINTAIL2K (1u << 24)  /* ... fewer than 2048 (2048 tasks per list: 2048 such units can fill a 2 M-task pool twice) */
 #endif
@@ -2058,7 +2062,7 @@ __device__ __forceinline__ int snp_align_heavy(const AlignArgs &A, const HeavyAr
             } else {
                 // few units left: the scan kernel's capacity is idle and every further window of a list is one more pass of the batch's tail (a control visit, three
                 // order kernels, a scan launch) — the whole list goes out at once (a microsatellite bucket is 3.9 M entries per strand part, a list 8-30 M candidates)
-                const uint32_t weff = K.n_active < 256u ? (uint32_t)HS_WINTAIL : K.n_active < 2048u ? (uint32_t)HS_WINTAIL2K : K.W[ms];
+                const uint32_t weff = K.n_active < HS_TAILU_A ? (uint32_t)HS_WINTAIL : K.n_active < HS_TAILU_B ? (uint32_t)HS_WINTAIL2K : K.W[ms];
                 const uint32_t tfit = H.task_cap > 128u ? H.task_cap - 64u : H.task_cap / 2u;   // (a window of w candidates makes at most w / HS_TASK + 2 tasks per segment, 32 segments)
                 const uint32_t wpool = (u64)tfit * HS_TASK < (u64)weff ? tfit * HS_TASK : weff;  // a window must fit the task pool
                 const uint32_t wn = min(wpool, cl.total - K.c[ms]);
@@ -2076,7 +2080,7 @@ __device__ __forceinline__ int snp_align_heavy(const AlignArgs &A, const HeavyAr
                     if (BSX_SPECULATE && SPEC && !A.work_counters && !P.rrbs && orient == 0 && K.c[ms] + wn == cl.total && ((M.u->flags >> 1) & 1)) {
                         const int seg1 = L.order[1][mode];
                         const CandList cl1 = make_list<true>(P, BL, L, M, 1, seg1, lane);
-                        const uint32_t w1 = min(K.n_active < 256u ? (uint32_t)HS_WINTAIL : K.n_active < 2048u ? (uint32_t)HS_WINTAIL2K : (uint32_t)HS_WIN0, min(wpool, cl1.total));
+                        const uint32_t w1 = min(K.n_active < HS_TAILU_A ? (uint32_t)HS_WINTAIL : K.n_active < HS_TAILU_B ? (uint32_t)HS_WINTAIL2K : (uint32_t)HS_WIN0, min(wpool, cl1.total));
                         if (cl1.total >= min(A.heavy_threshold, (uint32_t)HS_TASK_MIN) &&
                             rfl(__hip_atomic_load(H.n_tasks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) + w1 / HS_TASK + 66u <= H.task_cap / 2u) {
                             uint32_t nt1 = 0;
