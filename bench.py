@@ -54,7 +54,7 @@ def ring_steps(steps, warmup, B_):
 HBM_BYTES = 288e9       # MI355X
 
 
-RRBS_POOLS = "110000,1400000"   # starting pools of an RRBS batch when three are in flight (two thirds of the library's default: 26 GB of slabs, 1.4 M tasks)
+RRBS_POOLS = "160000,1900000"   # (round 6: 110000,1400000 until the control passes got cheaper — fewer, larger rounds: C4 415-420 -> 398 ms per step at 150000,1800000, gpurun_out/r06s; three batches of these pools plan 0.88 of the device)
 # units per step, batches in flight and starting pools by mode (measured: profiles/r05d_*).  A larger device batch gives the scan kernel larger
 # groups (more reads over one window and offset per pass): C3 24.3 M reads/s at 2^20 pairs per step with three in flight, 27.0 M at 2^22 with two.
 # (profiles/r05e: C2 16.8 M at 2^20 x 3, 18.9 M at 2^22 x 2; C5 9.2 M at 2^20 x 3, 10.5 M at 2^22 x 3; C4 8.6 M at 2^20 x 3, 9.4 M at 2^22 x 3)
@@ -62,7 +62,8 @@ RRBS_POOLS = "110000,1400000"   # starting pools of an RRBS batch when three are
 # With the context prefilter (23.6 GB of context words beside the index) the main kernel is 1.7 x faster and a third batch in flight no longer pays for C3
 # (gpurun_out/r05s: 242.0-244.2 ms per step with two, 241.9 with three) — and 2^22 pairs x 3 would plan 0.95 of the device.
 # (gpurun_out/r05t: C5 10.7 M reads/s at 2^22 x 2, 10.9 M at 3 x 2^20 x 3, 10.1 M at 2^21 x 3; C2 20.8 M at 2^22 x 2, 22.1 M at 2^22 x 3)
-MODE_DEFAULTS = {"pe": (1 << 22, 2, None), "se": (1 << 22, 3, None), "trim": (3 << 20, 3, None), "rrbs": (1 << 22, 3, RRBS_POOLS)}
+TRIM_POOLS = "31457,2500000"   # (round 6: C5's first passes ask for 2.4 M scan tasks — short trimmed reads publish whole windows that survive — where the library's starting size for 3 x 2^20 pairs is 1.57 M: refused requests cost their units a pass; 490 -> 468-470 ms per step, gpurun_out/r06u)
+MODE_DEFAULTS = {"pe": (1 << 22, 2, None), "se": (1 << 22, 3, None), "trim": (3 << 20, 3, TRIM_POOLS), "rrbs": (1 << 22, 3, RRBS_POOLS)}
 
 
 def mode_defaults(mode):

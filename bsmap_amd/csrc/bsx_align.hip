@@ -2912,7 +2912,7 @@ __global__ __launch_bounds__(64 * HG_WPB, BSX_HSAME_WAVES) void k_hscan_same(Ali
             if (((f0 >> 8) & 15u) == 3u) hs_group<3, true, STATS>(A, H, L, lane, wv, K, tid, th, tc0, rfl(key), n0, rfl(hh), f0, rfl(tx), rfl(tw));
             else hs_group<0, true, STATS>(A, H, L, lane, wv, K, tid, th, tc0, rfl(key), n0, rfl(hh), f0, rfl(tx), rfl(tw));
         }
-        else if (K > 1) {
+        else if (K > 1) {   // (a lone task as a group of one instead of through hp_task: measured slower, C3 222.4-222.8 against 218.2-218.9 ms per step, gpurun_out/r06t)
             if (((f0 >> 8) & 15u) == 5u) hs_group<5, false, STATS>(A, H, L, lane, wv, K, tid, th, tc0, rfl(key), n0, rfl(hh), f0, 0u, 0u);
             else if (((f0 >> 8) & 15u) == 4u) hs_group<4, false, STATS>(A, H, L, lane, wv, K, tid, th, tc0, rfl(key), n0, rfl(hh), f0, 0u, 0u);   // 97-128 nt (C2: 100 nt single-end)
             else hs_group<0, false, STATS>(A, H, L, lane, wv, K, tid, th, tc0, rfl(key), n0, rfl(hh), f0, 0u, 0u);

@@ -194,7 +194,8 @@ int bsx_pack_fasta_device(const bsx_params &P, const char *text, uint64_t n, bsx
     const uint32_t EV_CAP = 1u << 22;
     auto cleanup = [&] { for (void *q : {(void *)d_text, (void *)d_codes, (void *)d_recs, (void *)d_bad, (void *)d_nev, (void *)d_ev}) if (q) (void)hipFree(q); };
     auto fail = [&](int code) { cleanup(); if (r.d_refcat) { (void)hipFree(r.d_refcat); r.d_refcat = r.d_crefcat = nullptr; } return code; };
-#define PK_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(bsx_hip_fail(e_, #x, __FILE__, __LINE__)); } while (0)
+    // (no room for the text beside what the device already holds — several lanes on one GPU, a shared device: not an error, the host packer needs none of it)
+#define PK_TRY(x) do { hipError_t e_ = (x); if (e_ == hipErrorOutOfMemory) { (void)hipGetLastError(); return fail(1); } if (e_ != hipSuccess) return fail(bsx_hip_fail(e_, #x, __FILE__, __LINE__)); } while (0)
     PK_TRY(hipMalloc((void **)&d_text, n + 64));
     PK_TRY(hipMalloc((void **)&d_codes, 512));
     PK_TRY(hipMalloc((void **)&d_recs, (size_t)n_rec * sizeof(FaRec)));
