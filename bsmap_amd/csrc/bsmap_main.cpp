@@ -695,11 +695,10 @@ int fork_lanes(Opts &o, LaneInfo &lane, time_t t_begin)
             if (n < MSG || msg[0] >= (unsigned)L) break;   // (a lane died: its stats pipe will say so)
             memcpy(eff[msg[0]].data(), msg.data() + 1, BSX_LEAK_STATE_BYTES); have[msg[0]] = 1;
         }
-        vector<uint32_t> st(W, 0u);   // the state at lane 0's first read: a fresh object
+        const vector<vector<uint32_t>> start = bsx_lanes::compose_lane_states(eff, have, W);   // (lane 0: a fresh object; tests/test_lanes_cpu.py)
         for (int l = 0; l < L; l++) {
-            const ssize_t w = write(sfds[l], st.data(), BSX_LEAK_STATE_BYTES); (void)w;
+            const ssize_t w = write(sfds[l], start[(size_t)l].data(), BSX_LEAK_STATE_BYTES); (void)w;
             ::close(sfds[l]);
-            if (have[(size_t)l]) for (size_t k = 0; k < W; k++) if (eff[(size_t)l][k] != 0xFFFFFFFFu) st[k] = eff[(size_t)l][k];
         }
     }
     { const string all((size_t)L, 'g'); const ssize_t w = write(go[1], all.data(), all.size()); (void)w; }

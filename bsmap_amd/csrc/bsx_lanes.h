@@ -128,4 +128,18 @@ inline Plan plan_lanes(const LineIndex &a, const LineIndex *b, int n_lanes, uint
     return P;
 }
 
+// BSX_P1_EXACT across lanes (bsmap_main.cpp: fork_lanes).  effect[l] = what the reads of lane l do to the reference's never-reset planner state, as 32-bit words with
+// 0xFFFFFFFF = "this range leaves the word alone" (the lane's pre-pass run from a state of marker words); have[l] = lane l delivered one.  Returns the state at the
+// FIRST read of every lane: word by word the effect of the nearest earlier lane that wrote the word, zero — a fresh aligner object — if none did.
+inline std::vector<std::vector<uint32_t>> compose_lane_states(const std::vector<std::vector<uint32_t>> &effect, const std::vector<char> &have, size_t words)
+{
+    std::vector<std::vector<uint32_t>> start(effect.size(), std::vector<uint32_t>(words, 0u));
+    std::vector<uint32_t> st(words, 0u);
+    for (size_t l = 0; l < effect.size(); l++) {
+        start[l] = st;
+        if (have[l]) for (size_t k = 0; k < words; k++) if (effect[l][k] != 0xFFFFFFFFu) st[k] = effect[l][k];
+    }
+    return start;
+}
+
 }  // namespace bsx_lanes

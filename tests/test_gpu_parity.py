@@ -529,7 +529,10 @@ def test_heavy_pipeline_caps_and_early_returns(extra, heavy_genome, oracle):
         test_heavy_pipeline_large_buckets(True, heavy_genome, oracle, extra)
 
 
-@pytest.mark.parametrize("seed", list(range(1, 9)))
+HEAVY_SEEDS = list(range(1, 9 + int(os.environ.get("BSX_EXTRA_FUZZ", "0"))))   # (BSX_EXTRA_FUZZ=N: N more option draws, for a one-off soak)
+
+
+@pytest.mark.parametrize("seed", HEAVY_SEEDS)
 def test_heavy_pipeline_random_options(seed, heavy_genome, oracle):
     """seeded option draws on the microsatellite genome: windows, restarts, grouped acceptance and caps under other
     thresholds, hit caps, strand modes, read-length caps and insert ranges"""
@@ -813,7 +816,7 @@ def test_heavy_pipeline_caps_and_early_returns_without_work_counters(extra, heav
         test_heavy_pipeline_large_buckets(True, heavy_genome, oracle, extra, work_counters=False)
 
 
-@pytest.mark.parametrize("seed", list(range(1, 9)))
+@pytest.mark.parametrize("seed", HEAVY_SEEDS)
 def test_heavy_pipeline_random_options_without_work_counters(seed, heavy_genome, oracle, monkeypatch):
     monkeypatch.setenv("BSX_WORK_COUNTERS", "0")
     test_heavy_pipeline_random_options(seed, heavy_genome, oracle)

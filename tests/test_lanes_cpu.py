@@ -104,3 +104,23 @@ def test_files_that_cannot_be_cut(harness, tmp_path):
     empty = str(tmp_path / "e.fq")
     open(empty, "w").close()
     assert _plan(harness, empty, None, 2)["lanes"] == []
+
+
+def test_exact_mode_lane_states_compose_word_by_word(harness):
+    """BSX_P1_EXACT with lanes: lane l starts from the effect of the nearest earlier lane that wrote each word of the reference's never-reset planner state,
+    zero (a fresh object) if none did; a lane that delivered no effect changes nothing.  Checked against a sequential replay in Python."""
+    import random
+    rng = random.Random(7)
+    for W, L in ((1, 1), (3, 4), (5, 8)):
+        for _ in range(20):
+            lanes = []
+            for l in range(L):
+                lanes.append(["-"] * W if rng.random() < 0.15 else [("x" if rng.random() < 0.5 else str(rng.randrange(0, 2**32 - 1))) for _ in range(W)])
+            out = subprocess.run([harness, "compose", str(W), str(L)] + [t for row in lanes for t in row], capture_output=True, text=True, check=True)
+            got = json.loads(out.stdout)
+            st, want = [0] * W, []
+            for row in lanes:
+                want.append(list(st))
+                if row[0] != "-":
+                    st = [s if t == "x" else int(t) for s, t in zip(st, row)]
+            assert got == want
