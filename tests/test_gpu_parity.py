@@ -12,6 +12,8 @@ import bsmap_amd as B
 import bsx_testdata as td
 import golden_util as G
 
+EXTRA_FUZZ = int(os.environ.get("BSX_EXTRA_FUZZ", "0"))   # N more seeded option draws in every fuzz test below, for a one-off soak outside the suite
+
 pytestmark = pytest.mark.gpu
 
 ADAPTER = "AGATCGGAAGAGC"
@@ -269,7 +271,7 @@ def _random_config(seed):
     return kw, spec
 
 
-@pytest.mark.parametrize("seed", list(range(101, 221)))
+@pytest.mark.parametrize("seed", list(range(101, 221 + EXTRA_FUZZ)))
 def test_random_option_combinations_vs_oracle(seed, edge_genome, oracle):
     """120 seeded draws from the option space (seed size, mismatches, interval, -w, -r, -n, -M, -f, -L, trimming, insert
     range, single / paired) through the same comparison as the edge cases: index, every count, every pick, work counters"""
@@ -277,7 +279,7 @@ def test_random_option_combinations_vs_oracle(seed, edge_genome, oracle):
     test_edge_cases_vs_oracle(f"fuzz{seed}", kw, spec, edge_genome, oracle)
 
 
-@pytest.mark.parametrize("seed", list(range(1, 25)))
+@pytest.mark.parametrize("seed", list(range(1, 25 + EXTRA_FUZZ)))
 def test_rrbs_random_options_vs_oracle(seed, oracle, tmp_path_factory):
     """RRBS mode (-D, site-anchored index, segment tags, fragment-size filter, short-fragment fix) under seeded option draws,
     single reads (with and without -n 1) and pairs; reads start at digestion sites of a CpG-rich genome"""
@@ -529,7 +531,7 @@ def test_heavy_pipeline_caps_and_early_returns(extra, heavy_genome, oracle):
         test_heavy_pipeline_large_buckets(True, heavy_genome, oracle, extra)
 
 
-HEAVY_SEEDS = list(range(1, 9 + int(os.environ.get("BSX_EXTRA_FUZZ", "0"))))   # (BSX_EXTRA_FUZZ=N: N more option draws, for a one-off soak)
+HEAVY_SEEDS = list(range(1, 9 + EXTRA_FUZZ))   # (BSX_EXTRA_FUZZ=N: N more option draws, for a one-off soak)
 
 
 @pytest.mark.parametrize("seed", HEAVY_SEEDS)
@@ -794,7 +796,7 @@ def test_edge_cases_without_work_counters(name, kw, spec, edge_genome, oracle, m
     test_edge_cases_vs_oracle(name, kw, spec, edge_genome, oracle)
 
 
-@pytest.mark.parametrize("seed", list(range(101, 161)))
+@pytest.mark.parametrize("seed", list(range(101, 161 + EXTRA_FUZZ)))
 def test_random_option_combinations_without_work_counters(seed, edge_genome, oracle, monkeypatch):
     monkeypatch.setenv("BSX_WORK_COUNTERS", "0")
     test_random_option_combinations_vs_oracle(seed, edge_genome, oracle)
