@@ -2982,6 +2982,9 @@ __global__ __launch_bounds__(256) void k_task_groups(const HTask *tasks, const u
 // Results per task are exactly those of k_hscan: survivors in list order, candidate count and word count (align.h:189-197).
 // ---------------------------------------------------------------------------------------------------------------
 #define HS_SHARE 16u  /* tasks per wave */
+#ifndef BSX_HSHARED_W3
+#define BSX_HSHARED_W3 1  /* reads of 65-96 nt through shared_window<3> */
+#endif
 #ifndef BSX_HSHARED_WAVES
 #define BSX_HSHARED_WAVES 5  /* waves per SIMD the register budget is set for */
 #endif
@@ -2992,6 +2995,7 @@ __global__ __launch_bounds__(256) void k_task_groups(const HTask *tasks, const u
 // word 1 for its second early-out (align.h:189-197).
 struct SharedChunk { uint32_t wd[12]; uint32_t pm1, strand; bool valid; };  // wd: pairs (pm1 >> 5) .. + 5 of the plane copy, {low, high} each
 
+template <int NWR>
 __device__ __forceinline__ SharedChunk shared_load(const U2 *__restrict__ ent2, uint32_t idx, bool in_range, uint32_t h, uint32_t tag_xor, uint32_t tag_want,
                                                    const uint32_t *anchor, const uint8_t *plane, uint32_t rc_off, int nwr)
 {
@@ -3008,10 +3012,75 @@ __device__ __forceinline__ SharedChunk shared_load(const U2 *__restrict__ ent2, 
     U4 r1, r2;
     r1.a = r1.b = r1.c = r1.d = 0; r2.a = r2.b = r2.c = r2.d = 0;
     if (c.valid && nwr > 1) r1 = *reinterpret_cast<const U4 *>(plane + boff + 16);
-    if (c.valid && nwr > 3) r2 = *reinterpret_cast<const U4 *>(plane + boff + 32);
+    if ((NWR == 0 || NWR > 3) && c.valid && nwr > 3) r2 = *reinterpret_cast<const U4 *>(plane + boff + 32);
     c.wd[0] = r0.a; c.wd[1] = r0.b; c.wd[2] = r0.c; c.wd[3] = r0.d; c.wd[4] = r1.a; c.wd[5] = r1.b; c.wd[6] = r1.c; c.wd[7] = r1.d;
     c.wd[8] = r2.a; c.wd[9] = r2.b; c.wd[10] = r2.c; c.wd[11] = r2.d;
     return c;
+}
+
+// one window of candidates against the K reads of a run (rows of 20 dwords at uw).  NWR = 3: reads of 65-96 nt, the RRBS headline's 75 — no fourth and fifth word, no
+// third 16-byte gather, and the row in the order [X0 Y0 X1 Y1 | X2 Y2 M2 threshold | M0 M1 - -]: a read without N in its first 64 nt (bit 16 of the threshold word) takes
+// two 16-byte LDS reads and two v_bitop3 per inner word (round 6: the generic form spent 7 of its 19-21 vector instructions per evaluation on the absent words —
+// four zeroed registers, the materialised word-count test — and moved three row units).  NWR = 0: any length, the row in k_hscan_same's order.
+template <int NWR, bool STATS>
+__device__ __forceinline__ void shared_window(const HeavyArgs &H, const uint32_t *uw, const U2 *ent2, uint32_t n, uint32_t h, uint32_t tx, uint32_t tw, const uint32_t *anchor,
+                                              const uint8_t *plane, uint32_t rc_off, int nwr, uint32_t K, int lane, uint32_t &c15, uint32_t &nsv, uint32_t &nv)
+{
+    SharedChunk cur = shared_load<NWR>(ent2, (uint32_t)lane, (uint32_t)lane < n, h, tx, tw, anchor, plane, rc_off, nwr);
+    for (uint32_t cb = 0; cb < n; cb += 64) {
+        SharedChunk nxt;
+        const bool more = cb + 64 < n;
+        if (more) nxt = shared_load<NWR>(ent2, cb + 64 + (uint32_t)lane, cb + 64 + (uint32_t)lane < n, h, tx, tw, anchor, plane, rc_off, nwr);
+        // the candidate's reference planes in the read frame — the same for every read of the run
+        const uint32_t shf = 31u - (cur.pm1 & 31u);                       // 32 - ((pm1 & 31) + 1)
+        const uint32_t him = 0xFFFFFFFFu << ((cur.pm1 + 1u) & 15u);      // read nt [0, 32 - k), k = position mod 16
+        uint32_t flo[5], fhi[5];
+#pragma unroll
+        for (int t = 0; t < 5; t++) { flo[t] = __builtin_amdgcn_alignbit(cur.wd[2 * t], cur.wd[2 * t + 2], shf); fhi[t] = __builtin_amdgcn_alignbit(cur.wd[2 * t + 1], cur.wd[2 * t + 3], shf); }
+        nv += cur.valid ? 1u : 0u;
+        const uint32_t ord = (cb + (uint32_t)lane) << 8;
+        const u64 vm = bsx_ballot(cur.valid);
+        const uint4 *up = reinterpret_cast<const uint4 *>(uw);
+        for (uint32_t k = 0; k < K; k++, up += 5) {
+            // (a 16-byte LDS read of a wave moves 1 KB — 8 cycles of the CU's LDS path, which the vector instructions of an evaluation do not hide four times over)
+            uint32_t w0ref, w01ref, tot, thr;
+            if (NWR == 3) {
+                const uint4 u0 = up[0], u1 = up[1];   // X0 Y0 X1 Y1 | X2 Y2 M2 threshold
+                const uint32_t tp = rfl(u1.w);
+                thr = tp & 0xffffu;
+                if (tp >> 16) {
+                    const uint4 a0 = make_uint4(u0.x, u0.y, 0xFFFFFFFFu, u0.z), a1 = make_uint4(u0.w, 0xFFFFFFFFu, u1.x, u1.y), a2 = make_uint4(u1.z, 0u, 0u, 0u), a3 = make_uint4(0u, 0u, 0u, 0u);
+                    same_counts<3, true, true, STATS>(flo, fhi, him, nwr, a0, a1, a2, a3, thr, vm, w0ref, w01ref, tot);
+                } else {
+                    const uint4 u2 = up[2];           // M0 M1 - -
+                    const uint4 a0 = make_uint4(u0.x, u0.y, u2.x, u0.z), a1 = make_uint4(u0.w, u2.y, u1.x, u1.y), a2 = make_uint4(u1.z, 0u, 0u, 0u), a3 = make_uint4(0u, 0u, 0u, 0u);
+                    same_counts<3, false, true, STATS>(flo, fhi, him, nwr, a0, a1, a2, a3, thr, vm, w0ref, w01ref, tot);
+                }
+            } else {
+                const uint4 a0 = up[0], a1 = up[1], a2 = up[2];  // X0 Y0 M0 X1 | Y1 M1 X2 Y2 | M2 threshold X3 Y3 | M3 X4 Y4 M4
+                uint4 a3 = make_uint4(0u, 0u, 0u, 0u);
+                if (nwr > 3) a3 = up[3];
+                thr = rfl(a2.y) & 0xffffu;
+                same_counts<0, false, true, STATS>(flo, fhi, him, nwr, a0, a1, a2, a3, thr, vm, w0ref, w01ref, tot);
+            }
+            const u64 bp = bsx_ballot(tot <= thr) & vm;
+            if (STATS) {   // lane k keeps read k's counters: candidates beyond the first word | five-word candidates << 16 (work counters only)
+                const u64 b1 = bsx_ballot(w0ref > thr) & vm, b5 = bsx_ballot(w01ref <= thr) & vm;
+                const uint32_t add15 = (uint32_t)__builtin_popcountll(b1) | ((uint32_t)__builtin_popcountll(b5) << 16);
+                if ((uint32_t)lane == k) c15 += add15;
+            }
+            if (bp) {
+                const uint32_t base = rl_u(nsv, k);
+                const uint32_t pos = base + (uint32_t)__builtin_popcountll(bp & lanemask_lt(lane));
+                if (((bp >> lane) & 1) && pos < HS_SCAP) {
+                    SurvRec r; r.w_ord = tot | ord; r.hchr = cur.strand; r.hloc = cur.pm1 + 1; r.hkey = 0;
+                    H.tout[uw[k * 20u + 16u]].surv[pos] = r;
+                }
+                if ((uint32_t)lane == k) nsv += (uint32_t)__builtin_popcountll(bp);
+            }
+        }
+        if (more) cur = nxt;
+    }
 }
 
 template <bool STATS>
@@ -3068,73 +3137,22 @@ __global__ __launch_bounds__(256, BSX_HSHARED_WAVES) void k_hscan_shared(AlignAr
             if (x < K * 20u) {
                 const ListReq &R = H.state[hk & 0x3fffffffu].req[hk >> 30];
                 uint32_t v = 0;
-                if (f < 15) { const uint32_t j = f / 3u, c = f - 3u * j; v = c == 0 ? R.px[j] : c == 1 ? R.py[j] : R.pm[j]; }
-                else if (f == 15) v = R.thres;
+                const uint32_t j = f / 3u, c = f - 3u * j;
+                if (f < 15) v = c == 0 ? R.px[j] : c == 1 ? R.py[j] : R.pm[j];
+                else if (f == 15) v = R.thres | ((BSX_HSHARED_W3 && nwr == 3 && (R.pm[0] & R.pm[1]) == 0xFFFFFFFFu) ? 0x10000u : 0u);   // bit 16: no N in the first 64 nt (shared_window<3>)
                 else if (f == 16) v = tk;
-                UW[wv][k][f < 9 ? f : f < 15 ? f + 1u : f == 15 ? 9u : f] = v;   // the threshold behind word 2: reads of up to 96 nt need three of the row's 16-byte units
+                uint32_t at = f < 9 ? f : f < 15 ? f + 1u : f == 15 ? 9u : f;   // the threshold behind word 2: reads of up to 96 nt need three of the row's 16-byte units
+                if (BSX_HSHARED_W3 && nwr == 3)   // X0 Y0 X1 Y1 | X2 Y2 M2 threshold | M0 M1 - - | (words 3, 4: absent) | task
+                    at = f >= 15 ? (f == 15 ? 7u : f) : j > 2 ? 1u + f : c == 2 ? (j == 2 ? 6u : 8u + j) : (j == 2 ? 4u + c : 2u * j + c);
+                UW[wv][k][at] = v;
             }
         }
         uint32_t c15 = 0, nsv = 0;  // lane k: counters of read k (see the loop)
         wave_fence();
         const U2 *ent2 = reinterpret_cast<const U2 *>(P.entries) + key;
-        SharedChunk cur = shared_load(ent2, (uint32_t)lane, (uint32_t)lane < n, h, tx, tw, anchor, plane, rc_off, nwr);
         uint32_t nv = 0;
-        for (uint32_t cb = 0; cb < n; cb += 64) {
-            SharedChunk nxt;
-            const bool more = cb + 64 < n;
-            if (more) nxt = shared_load(ent2, cb + 64 + (uint32_t)lane, cb + 64 + (uint32_t)lane < n, h, tx, tw, anchor, plane, rc_off, nwr);
-            // the candidate's reference planes in the read frame — the same for every read of the run
-            const uint32_t shf = 31u - (cur.pm1 & 31u);                       // 32 - ((pm1 & 31) + 1)
-            const uint32_t him = 0xFFFFFFFFu << ((cur.pm1 + 1u) & 15u);      // read nt [0, 32 - k), k = position mod 16
-            uint32_t flo[5], fhi[5];
-#pragma unroll
-            for (int t = 0; t < 5; t++) { flo[t] = __builtin_amdgcn_alignbit(cur.wd[2 * t], cur.wd[2 * t + 2], shf); fhi[t] = __builtin_amdgcn_alignbit(cur.wd[2 * t + 1], cur.wd[2 * t + 3], shf); }
-            nv += cur.valid ? 1u : 0u;
-            const uint32_t ord = (cb + (uint32_t)lane) << 8;
-            const u64 vm = bsx_ballot(cur.valid);
-            const uint4 *up = reinterpret_cast<const uint4 *>(UW[wv][0]);
-            for (uint32_t k = 0; k < K; k++, up += 5) {
-                // (a 16-byte LDS read of a wave moves 1 KB — 8 cycles of the CU's LDS path, which the 25-30 vector instructions of an evaluation do
-                //  not hide four times over: the fourth unit only for reads of more than 96 nt)
-                const uint4 a0 = up[0], a1 = up[1], a2 = up[2];  // X0 Y0 M0 X1 | Y1 M1 X2 Y2 | M2 threshold X3 Y3 | M3 X4 Y4 M4
-                uint4 a3 = make_uint4(0u, 0u, 0u, 0u);
-                if (nwr > 3) a3 = up[3];
-                const uint32_t thr = a2.y;
-                const uint32_t m0 = bsx_plane_mismatch(flo[0], fhi[0], a0.x, a0.y, a0.z);
-                const uint32_t c0 = __popc(m0);
-                const uint32_t w0ref = STATS ? __popc(m0 & him) : 0u;
-                uint32_t tot = c0, w01ref = c0;
-                if (nwr > 1) {
-                    const uint32_t m1 = bsx_plane_mismatch(flo[1], fhi[1], a0.w, a1.x, a1.y);
-                    tot = popc_acc(m1, c0); if (STATS) w01ref = popc_acc(m1 & him, c0);
-                    // (the words behind the first 64 nt only matter for candidates still within the threshold there: where no lane of the
-                    //  chunk is, they are skipped — both early-out classes and the survivors are settled)
-                    if (nwr > 2 && (bsx_ballot(tot <= thr) & vm)) {
-                        tot = popc_acc(bsx_plane_mismatch(flo[2], fhi[2], a1.z, a1.w, a2.x), tot);
-                        if (nwr > 3) {
-                            tot = popc_acc(bsx_plane_mismatch(flo[3], fhi[3], a2.z, a2.w, a3.x), tot);
-                            if (nwr > 4) tot = popc_acc(bsx_plane_mismatch(flo[4], fhi[4], a3.y, a3.z, a3.w), tot);
-                        }
-                    }
-                }
-                const u64 bp = bsx_ballot(tot <= thr) & vm;
-                if (STATS) {   // lane k keeps read k's counters: candidates beyond the first word | five-word candidates << 16 (work counters only)
-                    const u64 b1 = bsx_ballot(w0ref > thr) & vm, b5 = bsx_ballot(w01ref <= thr) & vm;
-                    const uint32_t add15 = (uint32_t)__builtin_popcountll(b1) | ((uint32_t)__builtin_popcountll(b5) << 16);
-                    if ((uint32_t)lane == k) c15 += add15;
-                }
-                if (bp) {
-                    const uint32_t base = rl_u(nsv, k);
-                    const uint32_t pos = base + (uint32_t)__builtin_popcountll(bp & lanemask_lt(lane));
-                    if (((bp >> lane) & 1) && pos < HS_SCAP) {
-                        SurvRec r; r.w_ord = tot | ord; r.hchr = cur.strand; r.hloc = cur.pm1 + 1; r.hkey = 0;
-                        H.tout[UW[wv][k][16]].surv[pos] = r;
-                    }
-                    if ((uint32_t)lane == k) nsv += (uint32_t)__builtin_popcountll(bp);
-                }
-            }
-            if (more) cur = nxt;
-        }
+        if (BSX_HSHARED_W3 && nwr == 3) shared_window<3, STATS>(H, &UW[wv][0][0], ent2, n, h, tx, tw, anchor, plane, rc_off, nwr, K, lane, c15, nsv, nv);
+        else shared_window<0, STATS>(H, &UW[wv][0][0], ent2, n, h, tx, tw, anchor, plane, rc_off, nwr, K, lane, c15, nsv, nv);
         wave_fence();
         const uint32_t n_cand = wave_sum(nv);
         {
