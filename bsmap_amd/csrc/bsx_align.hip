@@ -2787,6 +2787,10 @@ __device__ __forceinline__ void hs_group(const AlignArgs &A, const HeavyArgs &H,
     for (int u = 0; u < HG_C; u++) nx[u] = same_load<RRBS>(W, same_entry<RRBS>(W, (uint32_t)(u * 64 + lane)));
 #pragma unroll
     for (int u = 0; u < HG_C; u++) en[u] = same_entry<RRBS>(W, STEP + (uint32_t)(u * 64 + lane));
+    // (the first step's gathers are waited for here: pending into the loop they make the compiler wait for every load in flight — the coming step's too — before each step's
+    //  evaluation, and the prefetch is none: round 5's measurements of this switch were of that form)
+#pragma unroll
+    for (int u = 0; u < HG_C; u++) asm volatile("" :: "v"(nx[u].r0.a), "v"(nx[u].r1.a), "v"(nx[u].r2.a));
 #else
 #pragma unroll
     for (int u = 0; u < HG_C; u++) en[u] = same_entry<RRBS>(W, (uint32_t)(u * 64 + lane));
@@ -2985,6 +2989,9 @@ __global__ __launch_bounds__(256) void k_task_groups(const HTask *tasks, const u
 #ifndef BSX_HSHARED_W3
 #define BSX_HSHARED_W3 1  /* reads of 65-96 nt through shared_window<3> */
 #endif
+#ifndef BSX_HSHARED_C2
+#define BSX_HSHARED_C2 1  /* ... two chunks of 64 candidates per step there */
+#endif
 #ifndef BSX_HSHARED_WAVES
 #define BSX_HSHARED_WAVES 5  /* waves per SIMD the register budget is set for */
 #endif
@@ -2995,16 +3002,26 @@ __global__ __launch_bounds__(256) void k_task_groups(const HTask *tasks, const u
 // word 1 for its second early-out (align.h:189-197).
 struct SharedChunk { uint32_t wd[12]; uint32_t pm1, strand; bool valid; };  // wd: pairs (pm1 >> 5) .. + 5 of the plane copy, {low, high} each
 
-template <int NWR>
-__device__ __forceinline__ SharedChunk shared_load(const U2 *__restrict__ ent2, uint32_t idx, bool in_range, uint32_t h, uint32_t tag_xor, uint32_t tag_want,
-                                                   const uint32_t *anchor, const uint8_t *plane, uint32_t rc_off, int nwr)
+// the two halves of a chunk's fetch: the index entry, and — one step later, when the entry has arrived — the candidate's pairs of the plane copy.  (Round 6: as one function the
+// entry's round trip stood in front of the gathers in every step, and the chromosome anchors behind a pointer that may be LDS or global made the gathers FLAT loads, behind
+// which the compiler waits for everything: nothing of the "next chunk" was in flight while the reads were evaluated.)
+__device__ __forceinline__ U2 shared_entry(const U2 *__restrict__ ent2, uint32_t idx, bool in_range)
+{
+    U2 e; e.a = 0xFFFFFFFFu; e.b = 0;   // (a lane behind the window's end loads nothing; shared_gather is told so again and never looks at these words)
+    if (in_range) e = ent2[idx];
+    return e;
+}
+template <int NWR, bool LDS_CHR>
+__device__ __forceinline__ SharedChunk shared_gather(const U2 e, bool in_range, uint32_t h, uint32_t tag_xor, uint32_t tag_want, const uint32_t *anch_lds,
+                                                     const uint32_t *__restrict__ anch_glb, const uint8_t *plane, uint32_t rc_off, int nwr)
 {
     SharedChunk c;
-    U2 e; e.a = e.b = 0;
-    if (in_range) e = ent2[idx];
     const uint32_t rchr = e.a & 0xffffu;
     c.valid = in_range && ((e.a ^ tag_xor) >> 16) == tag_want && e.b >= h;  // mode or strand not match / underflow the start of refseq
-    c.pm1 = c.valid ? anchor[rchr >> 1] + (e.b - h) - 1u : 31u;
+    uint32_t an = 0;   // (two loads of known address spaces, not one through a pointer that may be either: that is a FLAT load, and the compiler waits for every load in flight behind it)
+    typedef __attribute__((address_space(3))) const uint32_t LdsU32;
+    if (c.valid) an = LDS_CHR ? ((LdsU32 *)anch_lds)[rchr >> 1] : ldm1(anch_glb + (rchr >> 1));
+    c.pm1 = c.valid ? an + (e.b - h) - 1u : 31u;
     c.strand = rchr & 1u;
     // one pair early when the position is pair-aligned, so that the shift into the read's frame is one v_alignbit with a 5-bit amount
     const uint32_t boff = c.valid ? hp_boff(c.pm1, c.strand ? rc_off : 0u) : 0u;
@@ -3018,68 +3035,108 @@ __device__ __forceinline__ SharedChunk shared_load(const U2 *__restrict__ ent2, 
     return c;
 }
 
+// one read of a run against one chunk of 64 candidates: the counts, the work counters' two classes, the survivors in list order behind the read's earlier ones
+template <int NWR, bool PLAIN, bool STATS>
+__device__ __forceinline__ void shared_eval(const HeavyArgs &H, const uint32_t *uw, uint32_t k, const uint32_t (&flo)[5], const uint32_t (&fhi)[5], uint32_t him, u64 vm, uint32_t ord,
+                                            uint32_t strand, uint32_t hloc, int nwr, const uint4 &a0, const uint4 &a1, const uint4 &a2, const uint4 &a3, uint32_t thr, int lane,
+                                            uint32_t &c15, uint32_t &nsv)
+{
+    uint32_t w0ref, w01ref, tot;
+    same_counts<NWR, PLAIN, true, STATS>(flo, fhi, him, nwr, a0, a1, a2, a3, thr, vm, w0ref, w01ref, tot);
+    const u64 bp = bsx_ballot(tot <= thr) & vm;
+    if (STATS) {   // lane k keeps read k's counters: candidates beyond the first word | five-word candidates << 16 (work counters only)
+        const u64 b1 = bsx_ballot(w0ref > thr) & vm, b5 = bsx_ballot(w01ref <= thr) & vm;
+        const uint32_t add15 = (uint32_t)__builtin_popcountll(b1) | ((uint32_t)__builtin_popcountll(b5) << 16);
+        if ((uint32_t)lane == k) c15 += add15;
+    }
+    if (bp) {
+        const uint32_t base = rl_u(nsv, k);
+        const uint32_t pos = base + (uint32_t)__builtin_popcountll(bp & lanemask_lt(lane));
+        if (((bp >> lane) & 1) && pos < HS_SCAP) {
+            SurvRec r; r.w_ord = tot | ord; r.hchr = strand; r.hloc = hloc; r.hkey = 0;
+            H.tout[uw[k * 20u + 16u]].surv[pos] = r;
+        }
+        if ((uint32_t)lane == k) nsv += (uint32_t)__builtin_popcountll(bp);
+    }
+}
+
 // one window of candidates against the K reads of a run (rows of 20 dwords at uw).  NWR = 3: reads of 65-96 nt, the RRBS headline's 75 — no fourth and fifth word, no
 // third 16-byte gather, and the row in the order [X0 Y0 X1 Y1 | X2 Y2 M2 threshold | M0 M1 - -]: a read without N in its first 64 nt (bit 16 of the threshold word) takes
 // two 16-byte LDS reads and two v_bitop3 per inner word (round 6: the generic form spent 7 of its 19-21 vector instructions per evaluation on the absent words —
 // four zeroed registers, the materialised word-count test — and moved three row units).  NWR = 0: any length, the row in k_hscan_same's order.
-template <int NWR, bool STATS>
-__device__ __forceinline__ void shared_window(const HeavyArgs &H, const uint32_t *uw, const U2 *ent2, uint32_t n, uint32_t h, uint32_t tx, uint32_t tw, const uint32_t *anchor,
-                                              const uint8_t *plane, uint32_t rc_off, int nwr, uint32_t K, int lane, uint32_t &c15, uint32_t &nsv, uint32_t &nv)
+template <int NWR, bool STATS, bool LDS_CHR>
+__device__ __forceinline__ void shared_window(const HeavyArgs &H, const uint32_t *uw, const U2 *ent2, uint32_t n, uint32_t h, uint32_t tx, uint32_t tw,
+                                              const uint32_t *anch_lds, const uint32_t *anch_glb, const uint8_t *plane, uint32_t rc_off, int nwr, uint32_t K, int lane,
+                                              uint32_t &c15, uint32_t &nsv, uint32_t &nv)
 {
-    SharedChunk cur = shared_load<NWR>(ent2, (uint32_t)lane, (uint32_t)lane < n, h, tx, tw, anchor, plane, rc_off, nwr);
-    for (uint32_t cb = 0; cb < n; cb += 64) {
-        SharedChunk nxt;
-        const bool more = cb + 64 < n;
-        if (more) nxt = shared_load<NWR>(ent2, cb + 64 + (uint32_t)lane, cb + 64 + (uint32_t)lane < n, h, tx, tw, anchor, plane, rc_off, nwr);
-        // the candidate's reference planes in the read frame — the same for every read of the run
-        const uint32_t shf = 31u - (cur.pm1 & 31u);                       // 32 - ((pm1 & 31) + 1)
-        const uint32_t him = 0xFFFFFFFFu << ((cur.pm1 + 1u) & 15u);      // read nt [0, 32 - k), k = position mod 16
-        uint32_t flo[5], fhi[5];
+    // C chunks of 64 candidates per step: a read's row is fetched from LDS once per step, not per chunk (the three-word form without the work counters: registers for two)
+    constexpr int C = (NWR == 3 && !STATS && BSX_HSHARED_C2) ? 2 : 1;
+    constexpr uint32_t STEP = 64u * C;
+    SharedChunk cur[C], nxt[C];
+    U2 en[C];   // the entries of the step after this one
 #pragma unroll
-        for (int t = 0; t < 5; t++) { flo[t] = __builtin_amdgcn_alignbit(cur.wd[2 * t], cur.wd[2 * t + 2], shf); fhi[t] = __builtin_amdgcn_alignbit(cur.wd[2 * t + 1], cur.wd[2 * t + 3], shf); }
-        nv += cur.valid ? 1u : 0u;
-        const uint32_t ord = (cb + (uint32_t)lane) << 8;
-        const u64 vm = bsx_ballot(cur.valid);
+    for (int u = 0; u < C; u++) { const uint32_t i_ = (uint32_t)(u * 64 + lane); cur[u] = shared_gather<NWR, LDS_CHR>(shared_entry(ent2, i_, i_ < n), i_ < n, h, tx, tw, anch_lds, anch_glb, plane, rc_off, nwr); }
+#pragma unroll
+    for (int u = 0; u < C; u++) { const uint32_t i_ = STEP + (uint32_t)(u * 64 + lane); en[u] = shared_entry(ent2, i_, i_ < n); }
+    // (the first step's gathers are waited for HERE: left pending into the loop they make the compiler wait for every load in flight — the coming step's too — before each step's evaluation)
+    asm volatile("" :: "v"(cur[C - 1].wd[NWR == 3 ? 7 : 11]), "v"(cur[0].wd[NWR == 3 ? 7 : 11]));
+    for (uint32_t cb = 0; cb < n; cb += STEP) {
+        const bool more = cb + STEP < n;
+        if (more) {   // the coming step's gathers (its entries arrived during the last step) and the entries of the step behind it fly while this step's reads are evaluated
+#pragma unroll
+            for (int u = 0; u < C; u++) { const uint32_t i_ = cb + STEP + (uint32_t)(u * 64 + lane); nxt[u] = shared_gather<NWR, LDS_CHR>(en[u], i_ < n, h, tx, tw, anch_lds, anch_glb, plane, rc_off, nwr); }
+#pragma unroll
+            for (int u = 0; u < C; u++) { const uint32_t i_ = cb + 2u * STEP + (uint32_t)(u * 64 + lane); en[u] = shared_entry(ent2, i_, i_ < n); }
+        }
+        // the candidates' reference planes in the read frame — the same for every read of the run
+        uint32_t flo[C][5], fhi[C][5], him[C], ord[C];
+        u64 vm[C];
+#pragma unroll
+        for (int u = 0; u < C; u++) {
+            const uint32_t shf = 31u - (cur[u].pm1 & 31u);                   // 32 - ((pm1 & 31) + 1)
+            him[u] = 0xFFFFFFFFu << ((cur[u].pm1 + 1u) & 15u);               // read nt [0, 32 - k), k = position mod 16
+#pragma unroll
+            for (int t = 0; t < 5; t++) { flo[u][t] = __builtin_amdgcn_alignbit(cur[u].wd[2 * t], cur[u].wd[2 * t + 2], shf); fhi[u][t] = __builtin_amdgcn_alignbit(cur[u].wd[2 * t + 1], cur[u].wd[2 * t + 3], shf); }
+            nv += cur[u].valid ? 1u : 0u;
+            ord[u] = (cb + (uint32_t)(u * 64 + lane)) << 8;
+            vm[u] = bsx_ballot(cur[u].valid);
+        }
         const uint4 *up = reinterpret_cast<const uint4 *>(uw);
         for (uint32_t k = 0; k < K; k++, up += 5) {
-            // (a 16-byte LDS read of a wave moves 1 KB — 8 cycles of the CU's LDS path, which the vector instructions of an evaluation do not hide four times over)
-            uint32_t w0ref, w01ref, tot, thr;
+            // (a 16-byte LDS read of a wave moves 1 KB — 8 cycles of the CU's LDS path, which the vector instructions of an evaluation do not hide four times over;
+            //  the loop is kept lean on purpose: the same evaluations with seven more vector and a few more scalar instructions per read ran 25 % slower, r06/run27.sh)
             if (NWR == 3) {
                 const uint4 u0 = up[0], u1 = up[1];   // X0 Y0 X1 Y1 | X2 Y2 M2 threshold
-                const uint32_t tp = rfl(u1.w);
-                thr = tp & 0xffffu;
+                const uint32_t tp = rfl(u1.w), thr = tp & 0xffffu;
+                const uint4 a2 = make_uint4(u1.z, 0u, 0u, 0u), a3 = make_uint4(0u, 0u, 0u, 0u);
                 if (tp >> 16) {
-                    const uint4 a0 = make_uint4(u0.x, u0.y, 0xFFFFFFFFu, u0.z), a1 = make_uint4(u0.w, 0xFFFFFFFFu, u1.x, u1.y), a2 = make_uint4(u1.z, 0u, 0u, 0u), a3 = make_uint4(0u, 0u, 0u, 0u);
-                    same_counts<3, true, true, STATS>(flo, fhi, him, nwr, a0, a1, a2, a3, thr, vm, w0ref, w01ref, tot);
+                    const uint4 a0 = make_uint4(u0.x, u0.y, 0xFFFFFFFFu, u0.z), a1 = make_uint4(u0.w, 0xFFFFFFFFu, u1.x, u1.y);
+#pragma unroll
+                    for (int u = 0; u < C; u++) {
+                        if (u && !vm[u]) continue;   // (the window ends inside the step's first chunk)
+                        shared_eval<NWR == 3 ? 3 : 0, NWR == 3, STATS>(H, uw, k, flo[u], fhi[u], him[u], vm[u], ord[u], cur[u].strand, cur[u].pm1 + 1u, nwr, a0, a1, a2, a3, thr, lane, c15, nsv);
+                    }
                 } else {
                     const uint4 u2 = up[2];           // M0 M1 - -
-                    const uint4 a0 = make_uint4(u0.x, u0.y, u2.x, u0.z), a1 = make_uint4(u0.w, u2.y, u1.x, u1.y), a2 = make_uint4(u1.z, 0u, 0u, 0u), a3 = make_uint4(0u, 0u, 0u, 0u);
-                    same_counts<3, false, true, STATS>(flo, fhi, him, nwr, a0, a1, a2, a3, thr, vm, w0ref, w01ref, tot);
+                    const uint4 a0 = make_uint4(u0.x, u0.y, u2.x, u0.z), a1 = make_uint4(u0.w, u2.y, u1.x, u1.y);
+#pragma unroll
+                    for (int u = 0; u < C; u++) {
+                        if (u && !vm[u]) continue;
+                        shared_eval<NWR == 3 ? 3 : 0, false, STATS>(H, uw, k, flo[u], fhi[u], him[u], vm[u], ord[u], cur[u].strand, cur[u].pm1 + 1u, nwr, a0, a1, a2, a3, thr, lane, c15, nsv);
+                    }
                 }
             } else {
                 const uint4 a0 = up[0], a1 = up[1], a2 = up[2];  // X0 Y0 M0 X1 | Y1 M1 X2 Y2 | M2 threshold X3 Y3 | M3 X4 Y4 M4
                 uint4 a3 = make_uint4(0u, 0u, 0u, 0u);
                 if (nwr > 3) a3 = up[3];
-                thr = rfl(a2.y) & 0xffffu;
-                same_counts<0, false, true, STATS>(flo, fhi, him, nwr, a0, a1, a2, a3, thr, vm, w0ref, w01ref, tot);
-            }
-            const u64 bp = bsx_ballot(tot <= thr) & vm;
-            if (STATS) {   // lane k keeps read k's counters: candidates beyond the first word | five-word candidates << 16 (work counters only)
-                const u64 b1 = bsx_ballot(w0ref > thr) & vm, b5 = bsx_ballot(w01ref <= thr) & vm;
-                const uint32_t add15 = (uint32_t)__builtin_popcountll(b1) | ((uint32_t)__builtin_popcountll(b5) << 16);
-                if ((uint32_t)lane == k) c15 += add15;
-            }
-            if (bp) {
-                const uint32_t base = rl_u(nsv, k);
-                const uint32_t pos = base + (uint32_t)__builtin_popcountll(bp & lanemask_lt(lane));
-                if (((bp >> lane) & 1) && pos < HS_SCAP) {
-                    SurvRec r; r.w_ord = tot | ord; r.hchr = cur.strand; r.hloc = cur.pm1 + 1; r.hkey = 0;
-                    H.tout[uw[k * 20u + 16u]].surv[pos] = r;
-                }
-                if ((uint32_t)lane == k) nsv += (uint32_t)__builtin_popcountll(bp);
+                const uint32_t thr = rfl(a2.y) & 0xffffu;
+                shared_eval<0, false, STATS>(H, uw, k, flo[0], fhi[0], him[0], vm[0], ord[0], cur[0].strand, cur[0].pm1 + 1u, nwr, a0, a1, a2, a3, thr, lane, c15, nsv);
             }
         }
-        if (more) cur = nxt;
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < C; u++) cur[u] = nxt[u];
+        }
     }
 }
 
@@ -3092,7 +3149,7 @@ __global__ __launch_bounds__(256, BSX_HSHARED_WAVES) void k_hscan_shared(AlignAr
     const int lane = threadIdx.x & 63, wv = (int)rfl(threadIdx.x >> 6);  // (the wave number as a scalar: what depends on it stays wave-uniform for the compiler)
     if (P.n_chr <= BSX_LDS_CHR) for (uint32_t i = threadIdx.x; i <= P.n_chr; i += 256) ANCH[i] = P.anchor[i];
     __syncthreads();
-    const uint32_t *anchor = P.n_chr <= BSX_LDS_CHR ? ANCH : P.anchor;
+    const bool lds_chr = P.n_chr <= BSX_LDS_CHR;
     const uint32_t n_tasks = min(*H.n_tasks, H.task_cap);
     const uint8_t *plane = reinterpret_cast<const uint8_t *>(P.refplane);
     const uint32_t rc_off = P.plane_rc_off;
@@ -3151,8 +3208,13 @@ __global__ __launch_bounds__(256, BSX_HSHARED_WAVES) void k_hscan_shared(AlignAr
         wave_fence();
         const U2 *ent2 = reinterpret_cast<const U2 *>(P.entries) + key;
         uint32_t nv = 0;
-        if (BSX_HSHARED_W3 && nwr == 3) shared_window<3, STATS>(H, &UW[wv][0][0], ent2, n, h, tx, tw, anchor, plane, rc_off, nwr, K, lane, c15, nsv, nv);
-        else shared_window<0, STATS>(H, &UW[wv][0][0], ent2, n, h, tx, tw, anchor, plane, rc_off, nwr, K, lane, c15, nsv, nv);
+        if (lds_chr) {
+            if (BSX_HSHARED_W3 && nwr == 3) shared_window<3, STATS, true>(H, &UW[wv][0][0], ent2, n, h, tx, tw, ANCH, P.anchor, plane, rc_off, nwr, K, lane, c15, nsv, nv);
+            else shared_window<0, STATS, true>(H, &UW[wv][0][0], ent2, n, h, tx, tw, ANCH, P.anchor, plane, rc_off, nwr, K, lane, c15, nsv, nv);
+        } else {   // (more chromosomes than the LDS table holds: the anchors from global memory)
+            if (BSX_HSHARED_W3 && nwr == 3) shared_window<3, STATS, false>(H, &UW[wv][0][0], ent2, n, h, tx, tw, ANCH, P.anchor, plane, rc_off, nwr, K, lane, c15, nsv, nv);
+            else shared_window<0, STATS, false>(H, &UW[wv][0][0], ent2, n, h, tx, tw, ANCH, P.anchor, plane, rc_off, nwr, K, lane, c15, nsv, nv);
+        }
         wave_fence();
         const uint32_t n_cand = wave_sum(nv);
         {
